@@ -1,0 +1,377 @@
+"""CPU oracle for the point-cloud-audio hot path.  TEST INFRASTRUCTURE ONLY.
+
+This file is the *checker*, never the product: only ``tests/``,
+``__graft_entry__.smoke()`` and the ``cpu_baseline`` leg of ``bench.py`` may
+import it.  The product path (``point-cloud-audio_amd/``) never imports
+anything from ``oracle/`` and fails loudly when the HIP library is missing.
+
+It restates, in plain functional PyTorch-CPU / numpy, the arithmetic of the
+reference functions on the path:
+
+  mab_forward      set_transformer-master/modules.py:19-33   (MAB.forward)
+  mab_backward     hand-derived adjoint of the above (what autograd does for
+                   the reference)
+  isab_forward     set_transformer-master/modules.py:51-53   (ISAB.forward)
+  pma_forward      set_transformer-master/modules.py:62-63   (PMA.forward)
+  st_forward       Code/models.py:43-44                      (ST.forward)
+  pack_points_2d   Code/dataset.py:50-54                     (ESC_pc.__getitem__)
+  pack_points_3d   Code/dataset.py:160-166                   (ESC_pc_temp.__getitem__)
+  stft_logmag      Code/settransformer.py:49-50 (librosa.stft(...)/Nfft,
+                   log(1e-8+|.|)); librosa 0.8.0 itself is a third-party
+                   dependency that is NOT vendored in the reference and not
+                   installed here, so this one function is "parity unpinned"
+                   against librosa and pinned against torch.stft instead.
+  train_step       Code/settransformer.py:100-108 (CE loss, Adam lr 1e-3 with
+                   coupled weight_decay 1e-3)
+
+Pinning: ``tests/test_oracle_golden.py`` checks every function here (except
+stft_logmag, see above) against ``tests/golden/*.npz`` which were produced by
+importing the real reference in the build container
+(``tests/golden/make_golden.py``).
+
+Parameter naming follows the reference state_dict:
+a MAB is a dict with keys fc_q.weight, fc_q.bias, fc_k.*, fc_v.*, fc_o.*.
+"""
+from __future__ import annotations
+
+import math
+from typing import Dict, List, Optional, Tuple
+
+import numpy as np
+import torch
+
+Tensor = torch.Tensor
+Params = Dict[str, Tensor]
+
+
+# --------------------------------------------------------------------------- #
+# MAB                                                                          #
+# --------------------------------------------------------------------------- #
+def _lin(x: Tensor, p: Params, name: str) -> Tensor:
+    return x @ p[name + ".weight"].t() + p[name + ".bias"]
+
+
+def mab_forward(Q: Tensor, K: Tensor, p: Params, num_heads: int,
+                return_saved: bool = False):
+    """modules.py:19-33 in ``view(B, n, h, dh)`` form.
+
+    Head j owns the contiguous feature slice [j*dh, (j+1)*dh) (modules.py:23-26),
+    the score scale is 1/sqrt(dim_V) -- NOT 1/sqrt(dh) -- (modules.py:28) and the
+    residual added to A.V is the *projected* query (modules.py:29).
+    """
+    B, nq, _ = Q.shape
+    nk = K.shape[1]
+    d = p["fc_q.weight"].shape[0]
+    h = num_heads
+    dh = d // h
+    Qp = _lin(Q, p, "fc_q")                       # :20
+    Kp = _lin(K, p, "fc_k")                       # :21
+    Vp = _lin(K, p, "fc_v")                       # :21
+    Qh = Qp.view(B, nq, h, dh).permute(0, 2, 1, 3)  # [B,h,nq,dh]
+    Kh = Kp.view(B, nk, h, dh).permute(0, 2, 1, 3)
+    Vh = Vp.view(B, nk, h, dh).permute(0, 2, 1, 3)
+    S = Qh @ Kh.transpose(-1, -2) / math.sqrt(d)    # :28
+    A = torch.softmax(S, dim=-1)                    # :28
+    Oh = Qh + A @ Vh                                # :29
+    O = Oh.permute(0, 2, 1, 3).reshape(B, nq, d)    # :29 (merge heads)
+    Z = _lin(O, p, "fc_o")                          # :31
+    Y = O + torch.relu(Z)                           # :31
+    if return_saved:
+        return Y, dict(Qp=Qp, Kp=Kp, Vp=Vp, A=A, O=O, Z=Z)
+    return Y
+
+
+def mab_backward(dY: Tensor, Q: Tensor, K: Tensor, p: Params, num_heads: int
+                 ) -> Dict[str, Tensor]:
+    """Adjoint of mab_forward, written out.
+
+    Returns dQ, dK (input grads) and d<param> for the 8 parameter tensors.
+    This is what the HIP backward kernels implement; it is itself checked
+    against reference autograd through the golden fixtures.
+    """
+    B, nq, _ = Q.shape
+    nk = K.shape[1]
+    d = p["fc_q.weight"].shape[0]
+    h = num_heads
+    dh = d // h
+    scale = 1.0 / math.sqrt(d)
+    _, s = mab_forward(Q, K, p, h, return_saved=True)
+    Qp, Kp, Vp, A, O, Z = s["Qp"], s["Kp"], s["Vp"], s["A"], s["O"], s["Z"]
+    Wq, Wk, Wv, Wo = (p["fc_q.weight"], p["fc_k.weight"], p["fc_v.weight"],
+                      p["fc_o.weight"])
+
+    dZ = dY * (Z > 0).to(dY.dtype)
+    dO = dY + dZ @ Wo
+    g: Dict[str, Tensor] = {}
+    g["fc_o.weight"] = dZ.reshape(-1, d).t() @ O.reshape(-1, d)
+    g["fc_o.bias"] = dZ.reshape(-1, d).sum(0)
+
+    dOh = dO.view(B, nq, h, dh).permute(0, 2, 1, 3)
+    Qh = Qp.view(B, nq, h, dh).permute(0, 2, 1, 3)
+    Kh = Kp.view(B, nk, h, dh).permute(0, 2, 1, 3)
+    Vh = Vp.view(B, nk, h, dh).permute(0, 2, 1, 3)
+    dVh = A.transpose(-1, -2) @ dOh
+    dA = dOh @ Vh.transpose(-1, -2)
+    dS = A * (dA - (dA * A).sum(-1, keepdim=True))
+    dQh = dOh + (dS @ Kh) * scale
+    dKh = (dS.transpose(-1, -2) @ Qh) * scale
+    dQp = dQh.permute(0, 2, 1, 3).reshape(B, nq, d)
+    dKp = dKh.permute(0, 2, 1, 3).reshape(B, nk, d)
+    dVp = dVh.permute(0, 2, 1, 3).reshape(B, nk, d)
+
+    g["fc_q.weight"] = dQp.reshape(-1, d).t() @ Q.reshape(-1, Q.shape[-1])
+    g["fc_q.bias"] = dQp.reshape(-1, d).sum(0)
+    g["fc_k.weight"] = dKp.reshape(-1, d).t() @ K.reshape(-1, K.shape[-1])
+    g["fc_k.bias"] = dKp.reshape(-1, d).sum(0)
+    g["fc_v.weight"] = dVp.reshape(-1, d).t() @ K.reshape(-1, K.shape[-1])
+    g["fc_v.bias"] = dVp.reshape(-1, d).sum(0)
+    g["dQ"] = dQp @ Wq
+    g["dK"] = dKp @ Wk + dVp @ Wv
+    return g
+
+
+# --------------------------------------------------------------------------- #
+# ISAB / PMA / ST                                                              #
+# --------------------------------------------------------------------------- #
+def _sub(p: Params, prefix: str) -> Params:
+    n = len(prefix)
+    return {k[n:]: v for k, v in p.items() if k.startswith(prefix)}
+
+
+def isab_forward(X: Tensor, p: Params, num_heads: int) -> Tensor:
+    """modules.py:51-53.  p has keys I, mab0.*, mab1.*"""
+    B = X.shape[0]
+    I = p["I"].expand(B, -1, -1)                  # I.repeat(B,1,1), :52
+    H = mab_forward(I, X, _sub(p, "mab0."), num_heads)
+    return mab_forward(X, H, _sub(p, "mab1."), num_heads)   # :53
+
+
+def pma_forward(X: Tensor, p: Params, num_heads: int) -> Tensor:
+    """modules.py:62-63.  p has keys S, mab.*"""
+    B = X.shape[0]
+    S = p["S"].expand(B, -1, -1)
+    return mab_forward(S, X, _sub(p, "mab."), num_heads)
+
+
+def st_forward(X: Tensor, p: Params, num_heads: int) -> Tensor:
+    """Code/models.py:34-44: enc = ISAB, ISAB ; dec = PMA, Linear ; .squeeze()"""
+    p = {k[7:] if k.startswith("module.") else k: v for k, v in p.items()}
+    Y = isab_forward(X, _sub(p, "enc.0."), num_heads)
+    Y = isab_forward(Y, _sub(p, "enc.1."), num_heads)
+    Y = pma_forward(Y, _sub(p, "dec.0."), num_heads)
+    Y = Y @ p["dec.1.weight"].t() + p["dec.1.bias"]
+    return Y.squeeze()
+
+
+def st_param_shapes(dim_input: int, num_outputs: int, dim_output: int,
+                    num_inds: int, dim_hidden: int) -> List[Tuple[str, Tuple[int, ...]]]:
+    """The 45 tensors of Code/models.py:13-44 in state_dict order."""
+    d, m, k = dim_hidden, num_inds, num_outputs
+    out: List[Tuple[str, Tuple[int, ...]]] = []
+
+    def mab(prefix, dq, dk):
+        for nm, din in (("fc_q", dq), ("fc_k", dk), ("fc_v", dk), ("fc_o", d)):
+            out.append((f"{prefix}.{nm}.weight", (d, din)))
+            out.append((f"{prefix}.{nm}.bias", (d,)))
+
+    for li, din in ((0, dim_input), (1, d)):
+        out.append((f"enc.{li}.I", (1, m, d)))
+        mab(f"enc.{li}.mab0", d, din)
+        mab(f"enc.{li}.mab1", din, d)
+    out.append(("dec.0.S", (1, k, d)))
+    mab("dec.0.mab", d, d)
+    out.append(("dec.1.weight", (dim_output, d)))
+    out.append(("dec.1.bias", (dim_output,)))
+    return out
+
+
+def st_init_params(dim_input: int, num_outputs: int, dim_output: int, num_inds: int,
+                   dim_hidden: int, seed: int, dtype=torch.float32) -> Params:
+    """Deterministic init with the reference's distributions (nn.Linear default
+    Kaiming-uniform(a=sqrt5) => U(-1/sqrt(fan_in), 1/sqrt(fan_in)) for weight and
+    bias; xavier_uniform for I / S, modules.py:46,58).  Not bit-identical to a
+    torch-seeded reference model -- used where the *same* numbers are fed to
+    both sides."""
+    g = torch.Generator().manual_seed(seed)
+    p: Params = {}
+    for name, shape in st_param_shapes(dim_input, num_outputs, dim_output,
+                                       num_inds, dim_hidden):
+        if name.endswith(".I") or name.endswith(".S"):
+            fan_in, fan_out = shape[1] * shape[2], shape[2]   # torch's rule for 3-D
+            bound = math.sqrt(6.0 / (fan_in + fan_out))
+        elif name.endswith(".weight"):
+            bound = 1.0 / math.sqrt(shape[1])
+        else:  # bias: fan_in of the matching weight
+            wshape = dict(st_param_shapes(dim_input, num_outputs, dim_output,
+                                          num_inds, dim_hidden))[name[:-4] + "weight"]
+            bound = 1.0 / math.sqrt(wshape[1])
+        p[name] = ((torch.rand(shape, generator=g, dtype=torch.float64) * 2 - 1)
+                   * bound).to(dtype)
+    return p
+
+
+# --------------------------------------------------------------------------- #
+# Training step                                                                #
+# --------------------------------------------------------------------------- #
+def cross_entropy(logits: Tensor, labels: Tensor) -> Tensor:
+    """nn.CrossEntropyLoss() (mean) -- Code/settransformer.py:88,104"""
+    lse = torch.logsumexp(logits, dim=-1)
+    picked = logits.gather(-1, labels.view(-1, 1)).squeeze(-1)
+    return (lse - picked).mean()
+
+
+class AdamState:
+    """torch.optim.Adam(lr, betas=(0.9,0.999), eps=1e-8, weight_decay=wd) with
+    COUPLED L2 (grad += wd*param), Code/settransformer.py:89-91."""
+
+    def __init__(self, params: Params, lr=1e-3, wd=1e-3, b1=0.9, b2=0.999, eps=1e-8):
+        self.lr, self.wd, self.b1, self.b2, self.eps = lr, wd, b1, b2, eps
+        self.t = 0
+        self.m = {k: torch.zeros_like(v) for k, v in params.items()}
+        self.v = {k: torch.zeros_like(v) for k, v in params.items()}
+
+    def step(self, params: Params, grads: Params) -> None:
+        self.t += 1
+        bc1 = 1 - self.b1 ** self.t
+        bc2 = 1 - self.b2 ** self.t
+        for k, w in params.items():
+            g = grads[k] + self.wd * w
+            self.m[k].mul_(self.b1).add_(g, alpha=1 - self.b1)
+            self.v[k].mul_(self.b2).addcmul_(g, g, value=1 - self.b2)
+            denom = (self.v[k].sqrt() / math.sqrt(bc2)).add_(self.eps)
+            w.addcdiv_(self.m[k], denom, value=-self.lr / bc1)
+
+
+def train_step(X: Tensor, labels: Tensor, params: Params, opt: AdamState,
+               num_heads: int) -> Tuple[float, Tensor]:
+    """One step of Code/settransformer.py:100-108 on leaf tensors in ``params``
+    (updated in place).  Returns (loss, logits)."""
+    leaves = {k: v.detach().clone().requires_grad_(True) for k, v in params.items()}
+    logits = st_forward(X, leaves, num_heads)
+    if logits.dim() == 1:
+        logits = logits.unsqueeze(0)
+    loss = cross_entropy(logits, labels)
+    loss.backward()
+    grads = {k: v.grad for k, v in leaves.items()}
+    with torch.no_grad():
+        opt.step(params, grads)
+    return float(loss.detach()), logits.detach()
+
+
+def st_grads(X: Tensor, labels: Tensor, params: Params, num_heads: int
+             ) -> Tuple[float, Tensor, Params]:
+    """loss, logits and d(loss)/d(param) for every tensor (autograd of the
+    restatement; used to check the HIP backward)."""
+    leaves = {k: v.detach().clone().requires_grad_(True) for k, v in params.items()}
+    logits = st_forward(X, leaves, num_heads)
+    if logits.dim() == 1:
+        logits = logits.unsqueeze(0)
+    loss = cross_entropy(logits, labels)
+    loss.backward()
+    return float(loss.detach()), logits.detach(), {k: v.grad for k, v in leaves.items()}
+
+
+# --------------------------------------------------------------------------- #
+# Point-set packing                                                            #
+# --------------------------------------------------------------------------- #
+def pack_points_2d(x: np.ndarray, farr: np.ndarray, idx: int) -> np.ndarray:
+    """Code/dataset.py:50-54 -> float32 [F, 2], col0 = f, col1 = logmag."""
+    pc = np.stack((farr.astype(np.float64), x[:, idx].astype(np.float64)), axis=1)
+    return pc.astype(np.float32)
+
+
+def pack_points_3d(x: np.ndarray, farr: np.ndarray, tarr: np.ndarray, idx: int
+                   ) -> np.ndarray:
+    """Code/dataset.py:160-166 -> float32 [F*Nt, 3]; point p = t*F + f
+    (time-major), columns (f, t, logmag)."""
+    F, Nt = farr.shape[0], tarr.shape[0]
+    xt = x[:, :, idx]
+    out = np.empty((Nt * F, 3), dtype=np.float64)
+    for t in range(Nt):
+        out[t * F:(t + 1) * F, 0] = farr
+        out[t * F:(t + 1) * F, 1] = tarr[t]
+        out[t * F:(t + 1) * F, 2] = xt[:, t]
+    return out.astype(np.float32)
+
+
+def pc_maxk_3d(x: np.ndarray, farr: np.ndarray, tarr: np.ndarray, idx: int, K: int
+               ) -> np.ndarray:
+    """Code/dataset.py:194-202 (ESC_pc_temp_maxKSS): the K largest-magnitude
+    points, descending, float64 [K,3]."""
+    F, Nt = farr.shape[0], tarr.shape[0]
+    xt = x[:, :, idx]
+    pc = np.empty((Nt * F, 3), dtype=np.float64)
+    for t in range(Nt):
+        pc[t * F:(t + 1) * F, 0] = farr
+        pc[t * F:(t + 1) * F, 1] = tarr[t]
+        pc[t * F:(t + 1) * F, 2] = xt[:, t]
+    order = np.argsort(-pc[:, 2])[:K]
+    return pc[order]
+
+
+# --------------------------------------------------------------------------- #
+# STFT + log magnitude                                                         #
+# --------------------------------------------------------------------------- #
+def hann_periodic(n: int) -> np.ndarray:
+    """scipy.signal.get_window('hann', n, fftbins=True) -- librosa 0.8 default."""
+    return 0.5 - 0.5 * np.cos(2.0 * np.pi * np.arange(n) / n)
+
+
+def stft_logmag(wave: np.ndarray, n_fft: int, win_length: Optional[int] = None,
+                hop: Optional[int] = None, drop_nyquist: bool = False) -> np.ndarray:
+    """log(1e-8 + |librosa.stft(x, n_fft, win_length, hop, 'hann')| / n_fft).
+
+    Code/settransformer.py:49-50 (2-D path keeps all 1+n_fft/2 bins),
+    Code/settransformertemp.py:51-53 (3-D path drops the Nyquist bin, x[:-1]).
+    librosa 0.8 semantics: center=True with pad_mode='reflect' (n_fft//2 each
+    side), periodic Hann of win_length zero-padded (centred) to n_fft, frame t
+    starts at t*hop, T = 1 + L//hop.  Returns float32 [F, T].
+    Computed in float64, then magnitude/log, cast to float32.
+    """
+    win_length = n_fft if win_length is None else win_length
+    hop = n_fft // 2 if hop is None else hop
+    w = hann_periodic(win_length)
+    lpad = (n_fft - win_length) // 2
+    win = np.zeros(n_fft)
+    win[lpad:lpad + win_length] = w
+    x = np.pad(wave.astype(np.float64), n_fft // 2, mode="reflect")
+    T = 1 + (len(wave)) // hop
+    F = 1 + n_fft // 2
+    out = np.empty((F, T), dtype=np.float64)
+    for t in range(T):
+        seg = x[t * hop:t * hop + n_fft] * win
+        out[:, t] = np.abs(np.fft.rfft(seg)) / n_fft
+    out = np.log(1.0e-8 + out)
+    if drop_nyquist:
+        out = out[:-1]
+    return out.astype(np.float32)
+
+
+def chunk_frames(a: np.ndarray, ntemp: int) -> np.ndarray:
+    """Code/settransformertemp.py:54-61: hsplit into ntemp-frame chunks, drop
+    the short tail, dstack -> [F, ntemp, S]."""
+    F, T = a.shape
+    S = T // ntemp
+    return np.ascontiguousarray(
+        a[:, :S * ntemp].reshape(F, S, ntemp).transpose(0, 2, 1))
+
+
+# --------------------------------------------------------------------------- #
+# Synthetic ESC-50-shaped audio                         #
+# --------------------------------------------------------------------------- #
+def synth_clip(clip_id: int, cls: int, seconds: float = 5.0, fs: int = 44100
+               ) -> np.ndarray:
+    """Class-conditional clip: 3 harmonics of f0(c)=110*2^(c/12) Hz with seeded
+    phases + low-passed noise, PCG64(seed=1000+clip_id).  float32 in [-1,1]."""
+    rng = np.random.Generator(np.random.PCG64(1000 + clip_id))
+    L = int(round(seconds * fs))
+    t = np.arange(L) / fs
+    f0 = 110.0 * 2.0 ** (cls / 12.0)
+    x = np.zeros(L)
+    for k in range(1, 4):
+        x += (0.5 / k) * np.sin(2 * np.pi * f0 * k * t + rng.uniform(0, 2 * np.pi))
+    noise = rng.standard_normal(L)
+    noise = np.convolve(noise, np.ones(8) / 8.0, mode="same")
+    x = x + 0.1 * noise
+    x = x / (np.max(np.abs(x)) + 1e-9) * 0.9
+    return x.astype(np.float32)

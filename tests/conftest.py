@@ -1,0 +1,72 @@
+import os
+import sys
+
+import numpy as np
+import pytest
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+PKG = os.path.join(ROOT, "point-cloud-audio_amd")
+GOLDEN = os.path.join(ROOT, "tests", "golden")
+for p in (ROOT, PKG, GOLDEN):
+    if p not in sys.path:
+        sys.path.insert(0, p)
+
+
+def pytest_configure(config):
+    config.addinivalue_line("markers", "gpu: needs a real MI355X (run with -m gpu)")
+
+
+def _has_gpu():
+    try:
+        import torch
+        return torch.cuda.is_available()
+    except Exception:
+        return False
+
+
+def pytest_collection_modifyitems(config, items):
+    if _has_gpu():
+        return
+    skip = pytest.mark.skip(reason="no GPU in this container")
+    for it in items:
+        if "gpu" in it.keywords:
+            it.add_marker(skip)
+
+
+class Golden:
+    """Lazy view over one golden .npz with '/'-separated keys."""
+
+    def __init__(self, name):
+        self.z = np.load(os.path.join(GOLDEN, name), allow_pickle=False)
+
+    def __getitem__(self, k):
+        return self.z[k]
+
+    def sub(self, prefix):
+        n = len(prefix)
+        return {k[n:]: self.z[k] for k in self.z.files if k.startswith(prefix)}
+
+
+@pytest.fixture(scope="session")
+def golden_mab():
+    return Golden("golden_mab.npz")
+
+
+@pytest.fixture(scope="session")
+def golden_st():
+    return Golden("golden_st.npz")
+
+
+@pytest.fixture(scope="session")
+def golden_ckpt():
+    return Golden("golden_ckpt.npz")
+
+
+@pytest.fixture(scope="session")
+def golden_dataset():
+    return Golden("golden_dataset.npz")
+
+
+@pytest.fixture(scope="session")
+def golden_train():
+    return Golden("golden_train.npz")
