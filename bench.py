@@ -1,0 +1,242 @@
+#!/usr/bin/env python3
+"""Headline benchmark: train clips/sec of the ESC-50-shaped Set Transformer on MI355X.
+
+    python bench.py --gpus N --steps K --warmup W            (N = 1)
+    python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 \
+        --master-port P bench.py --gpus N --steps K --warmup W
+
+A "step" is one pass of the hot path over one batch of synthetic input per GPU:
+  gather B point sets from the HBM-resident log-magnitude spectrogram (pack kernel) ->
+  ST forward -> mean cross-entropy -> backward -> [all-reduce of the two gradient buckets
+  over RCCL, overlapped] -> fused Adam (coupled weight decay).
+The spectrogram itself is produced once, before the timed region, by the STFT kernel from
+synthetic class-conditional clips (5 s @ 44.1 kHz) -- the reference also runs its STFT as
+a one-off pre-pass (Code/settransformer.py:43-53).  value = sets/s of all ranks divided by
+the sets one clip yields at this framing (cfg2: 431).
+
+Prints ONE JSON line on rank 0.
+"""
+import argparse
+import ctypes as C
+import json
+import os
+import sys
+import time
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+for _p in (ROOT, os.path.join(ROOT, "point-cloud-audio_amd")):
+    if _p not in sys.path:
+        sys.path.insert(0, _p)
+
+import numpy as np  # noqa: E402
+import torch  # noqa: E402
+import torch.distributed as dist  # noqa: E402
+
+# name: (din, n_fft, ntemp, d, h, m, C, B per GPU, sets per 5-s clip, description)
+CONFIGS = {
+    "cfg2": dict(din=2, n_fft=1024, ntemp=1, d=128, h=4, m=16, C=50, B=128, sets_per_clip=431,
+                 desc="BASELINE configs[1]: ESC-50-shaped 2-D point sets N=512, ST d=128 h=4 "
+                      "m=16 C=50"),
+    "cfg3": dict(din=3, n_fft=1024, ntemp=4, d=128, h=4, m=16, C=50, B=32, sets_per_clip=107,
+                 desc="BASELINE configs[2]: 3-D temporal point sets N=2048, ST d=128 h=4 m=16"),
+    "cfg4": dict(din=3, n_fft=1024, ntemp=8, d=256, h=8, m=32, C=50, B=128, sets_per_clip=53,
+                 desc="BASELINE configs[3] shape: N=4096, ST d=256 h=8 m=32"),
+    "fst": dict(din=2, n_fft=2048, ntemp=1, d=64, h=8, m=64, C=10, B=128, sets_per_clip=216,
+                desc="shipped FST shape: N=1025, ST d=64 h=8 m=64"),
+    "3st": dict(din=3, n_fft=1024, ntemp=10, d=64, h=8, m=64, C=10, B=16, sets_per_clip=43,
+                desc="shipped 3ST shape: N=5120, ST d=64 h=8 m=64"),
+}
+FS = 44100
+MFMA_BF16_PEAK_TFLOPS = 2500.0     # MI355X_MICROARCH.md: ~2.5 PF dense bf16
+FP32_VALU_PEAK_TFLOPS = 157.3
+HBM_PEAK_GBS = 8000.0
+
+
+def st_fwd_macs(N, din, d, m, k, C):
+    """SURVEY.md 8d closed form, reference formulation (MACs per set, forward)."""
+    return N * (3 * din * d + 7 * d * d + 8 * m * d + 2 * k * d) + 6 * m * d * d + k * d * d + k * d * C
+
+
+def build_dataset(cfg, n_clips, dev, seed):
+    """Synthetic class-conditional clips -> STFT kernel -> device-resident dataset."""
+    import dataset
+    import pca_hip
+    from oracle import st_oracle as orc          # only for the synthetic waveform generator
+    n_fft, ntemp, C_ = cfg["n_fft"], cfg["ntemp"], cfg["C"]
+    hop = n_fft // 2
+    drop = not (cfg["din"] == 2 and n_fft == 2048)      # FST keeps the Nyquist bin (N=1025)
+    F = n_fft // 2 if drop else n_fft // 2 + 1
+    specs, labels = [], []
+    t_stft = 0.0
+    for i in range(n_clips):
+        cls = (seed * 7919 + i) % C_
+        wave = torch.from_numpy(orc.synth_clip(seed * 100000 + i, cls)).to(dev)
+        torch.cuda.synchronize(dev)
+        t0 = time.perf_counter()
+        s = pca_hip.stft_logmag(wave, n_fft, n_fft, hop, drop_nyquist=drop, frame_major=True)
+        torch.cuda.synchronize(dev)
+        t_stft += time.perf_counter() - t0
+        if ntemp > 1:
+            S = s.shape[0] // ntemp
+            s = s[:S * ntemp].reshape(S, ntemp, F)       # chunks of ntemp frames, tail dropped
+        specs.append(s)
+        labels.append(torch.full((s.shape[0],), cls, dtype=torch.int64, device=dev))
+    spec = torch.cat(specs).contiguous()
+    lab = torch.cat(labels)
+    farr = np.linspace(0, FS / 2, F) / FS if drop else np.linspace(0, FS / 2, n_fft // 2 + 1) / FS
+    if ntemp == 1:
+        ds = dataset.ESC_pc.from_device(spec, lab, farr)
+    else:
+        tarr = np.linspace(0, (hop / FS) * ntemp, ntemp)
+        ds = dataset.ESC_pc_temp.from_device(spec, lab, farr, tarr)
+    return ds, t_stft / max(n_clips, 1)
+
+
+def cpu_baseline(cfg, N, budget_s=20.0):
+    """Oracle ('port') train step on the host cores: same B, N, architecture, fp32, Adam."""
+    from oracle import st_oracle as orc
+    ncore = min(16, os.cpu_count() or 1)
+    torch.set_num_threads(ncore)
+    B = cfg["B"]
+    p = orc.st_init_params(cfg["din"], 1, cfg["C"], cfg["m"], cfg["d"], seed=0)
+    opt = orc.AdamState(p)
+    g = torch.Generator().manual_seed(0)
+    X = torch.randn(B, N, cfg["din"], generator=g)
+    y = torch.randint(0, cfg["C"], (B,), generator=g)
+    orc.train_step(X, y, p, opt, cfg["h"])           # warm-up
+    times = []
+    t_end = time.perf_counter() + budget_s
+    while len(times) < 3 or (time.perf_counter() < t_end and len(times) < 50):
+        t0 = time.perf_counter()
+        orc.train_step(X, y, p, opt, cfg["h"])
+        times.append(time.perf_counter() - t0)
+    med = float(np.median(times))
+    return dict(value=round(B / med / cfg["sets_per_clip"], 4), unit="clips/s", cores=ncore,
+                kind="port",
+                sample=f"{len(times)} train steps of B={B} sets (median {med * 1e3:.1f} ms/step, "
+                       f"{B / med:.1f} sets/s), oracle/st_oracle.py on torch CPU fp32")
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=200)
+    ap.add_argument("--warmup", type=int, default=20)
+    ap.add_argument("--config", default="cfg2", choices=sorted(CONFIGS))
+    ap.add_argument("--batch", type=int, default=0, help="sets per GPU per step (0 = config)")
+    ap.add_argument("--mode", default="f32", choices=["f32", "bf16"])
+    ap.add_argument("--clips", type=int, default=48, help="synthetic clips in the corpus")
+    ap.add_argument("--no-graph", action="store_true")
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-roofline", action="store_true")
+    args = ap.parse_args()
+
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    assert world == args.gpus, f"WORLD_SIZE={world} but --gpus {args.gpus}"
+    torch.cuda.set_device(local_rank)
+    dev = torch.device("cuda", local_rank)
+    if world > 1:
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        dist.init_process_group("nccl", device_id=dev)
+
+    import models
+    import pca_hip
+    from pca_hip import _lib, trainer
+    L = pca_hip.lib()
+
+    cfg = dict(CONFIGS[args.config])
+    if args.batch:
+        cfg["B"] = args.batch
+    mode = _lib.MODE_F32 if args.mode == "f32" else _lib.MODE_BF16
+    ds, stft_s_per_clip = build_dataset(cfg, args.clips, dev, seed=rank)
+    N = ds.num_points
+    torch.manual_seed(1)
+    net = models.ST(dim_input=cfg["din"], num_outputs=1, dim_output=cfg["C"],
+                    num_inds=cfg["m"], dim_hidden=cfg["d"], num_heads=cfg["h"]).to(dev)
+    tr = trainer.Trainer(net, ds, cfg["B"], lr=1e-3, weight_decay=1e-3, mode=mode,
+                         use_graph=not args.no_graph, seed=1)
+
+    def barrier():
+        if world > 1:
+            dist.barrier()
+        torch.cuda.synchronize(dev)
+
+    for _ in range(args.warmup):
+        tr.step()
+    barrier()
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        tr.step()
+    barrier()
+    elapsed = time.perf_counter() - t0
+    if world > 1:
+        t = torch.tensor([elapsed], dtype=torch.float64, device=dev)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        elapsed = float(t)
+    loss_sum, correct = tr.read_stats()
+    n_seen = (args.warmup + args.steps) * cfg["B"] * world
+
+    sets_per_s = args.steps * cfg["B"] * world / elapsed
+    out = {
+        "metric": "train clips/sec, ESC-50 SetTransformer",
+        "value": round(sets_per_s / cfg["sets_per_clip"], 3),
+        "unit": "clips/s",
+        "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
+        "ms_per_step": round(elapsed / args.steps * 1e3, 4),
+        "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
+        "dtype": args.mode, "data": "synthetic",
+        "config": {"workload": f"{args.config}: {cfg['desc']}; N={N} points/set, "
+                               f"B={cfg['B']} sets/GPU/step, CE + Adam(lr 1e-3, wd 1e-3)",
+                   "global_batch": cfg["B"] * world, "points_per_set": N,
+                   "sets_per_clip": cfg["sets_per_clip"], "parallelism": f"dp{world}",
+                   "hipgraph": not args.no_graph},
+        "sets_per_s": round(sets_per_s, 1),
+        "train_loss_mean": round(loss_sum / max(n_seen, 1), 4),
+        "stft_ms_per_clip": round(stft_s_per_clip * 1e3, 3),
+    }
+
+    # ---- roofline of the dominant kernel: HIP events on its launch stream, live ------
+    if not args.no_roofline:
+        kid = _lib.K_GEMM_F32 if args.mode == "f32" else _lib.K_MAB1_BWD
+        ksteps = min(args.steps, 20)
+        # eager (un-captured) steps of the same workload so the events bracket real launches
+        tr_use_graph = tr.use_graph
+        tr.use_graph = False
+        _lib.check(L.pca_prof_start(kid, 4096 * ksteps), "prof_start")
+        for _ in range(ksteps):
+            tr.step()
+        torch.cuda.synchronize(dev)
+        ms, n, fl, by = C.c_double(), C.c_int64(), C.c_double(), C.c_double()
+        _lib.check(L.pca_prof_stop(C.byref(ms), C.byref(n), C.byref(fl), C.byref(by)),
+                   "prof_stop")
+        tr.use_graph = tr_use_graph
+        if n.value > 0 and ms.value > 0:
+            tflops = fl.value / (ms.value * 1e-3) / 1e12
+            peak = FP32_VALU_PEAK_TFLOPS if args.mode == "f32" else MFMA_BF16_PEAK_TFLOPS
+            out["roofline"] = {
+                "kernel": "k_gemm_f32" if args.mode == "f32" else "k_mab1_bwd_bf16",
+                "bound": "mfma", "achieved": round(tflops, 3), "peak": peak,
+                "unit": "TFLOP/s", "frac": round(tflops / peak, 5), "traffic": None,
+                "launches": int(n.value), "avg_us": round(ms.value * 1e3 / n.value, 3),
+                "note": ("exact-fp32 parity path: strided VALU GEMMs, priced against the fp32 "
+                         "vector/matrix peak (157.3 TFLOP/s)" if args.mode == "f32" else
+                         "fused bf16 MFMA kernel, reference-formulation FLOPs"),
+            }
+        fwd = st_fwd_macs(N, cfg["din"], cfg["d"], cfg["m"], 1, cfg["C"]) * 2
+        out["model_tflops_ref_formulation"] = round(
+            3 * fwd * cfg["B"] * world * args.steps / elapsed / 1e12, 3)
+
+    if world > 1:
+        dist.barrier()
+    if rank == 0:
+        if world == 1 and not args.no_cpu_baseline:
+            out["cpu_baseline"] = cpu_baseline(cfg, N)
+        print(json.dumps(out), flush=True)
+    if world > 1:
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

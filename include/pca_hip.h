@@ -1,0 +1,256 @@
+/*
+ * pca_hip.h -- C ABI of libpca_hip.so, the MI355X (gfx950) implementation of the
+ * point-cloud-audio hot path:  STFT log-magnitude -> (f[,t],logmag) point sets ->
+ * Set Transformer (MAB / ISAB / PMA) forward + backward -> loss -> Adam.
+ *
+ * Conventions
+ *   - every pointer is a DEVICE pointer unless the name ends in _host;
+ *   - tensors are dense row-major unless a stride argument says otherwise;
+ *   - `stream` is a hipStream_t passed as void* (NULL = the null stream); every
+ *     entry point only ENQUEUES work on it: no allocation, no synchronisation, no
+ *     host<->device copies, so a caller may capture any of them into a hipGraph;
+ *   - scratch and saved-for-backward memory is owned by the caller and sized with
+ *     the *_bytes() queries;
+ *   - return value: 0 on success, a negative PCA_E* code on failure (never
+ *     aborts); pca_last_error() returns a thread-local message for the last
+ *     failure on the calling thread;
+ *   - re-entrant: no global mutable state apart from that thread-local string.
+ *
+ * Each entry point names the reference interface it replaces (paths relative to
+ * the reference repository root).
+ */
+#ifndef PCA_HIP_H
+#define PCA_HIP_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define PCA_ABI_VERSION 1
+
+enum {
+  PCA_OK = 0,
+  PCA_EINVAL = -1,      /* bad shape / null pointer / unsupported combination */
+  PCA_EUNSUPPORTED = -2,/* valid request this build has no kernel for          */
+  PCA_ELAUNCH = -3      /* hipGetLastError() != hipSuccess after a launch      */
+};
+
+/* element types of activation tensors crossing the ABI */
+enum { PCA_F32 = 0, PCA_BF16 = 1 };
+
+/* arithmetic mode of a MAB: PCA_MODE_F32 = exact fp32 everywhere (parity mode);
+ * PCA_MODE_BF16 = bf16 MFMA operands, fp32 accumulate / softmax / residuals.    */
+enum { PCA_MODE_F32 = 0, PCA_MODE_BF16 = 1 };
+
+int pca_abi_version(void);
+const char* pca_last_error(void);
+
+/* ------------------------------------------------------------------------- *
+ * Feature extraction                                                         *
+ * ------------------------------------------------------------------------- */
+
+/* Number of STFT frames librosa.stft(center=True) yields: 1 + L / hop. */
+int64_t pca_stft_num_frames(int64_t L, int hop);
+
+/* log(1e-8 + |STFT(wave)| / n_fft)
+ * replaces: Code/settransformer.py:49-50, Code/settransformertemp.py:51-53
+ *           (librosa.stft(x, n_fft, win_length, hop, 'hann')/Nfft ; np.log(1e-8+np.abs(.)))
+ * wave[L] float32; centred frames with reflect padding, periodic Hann of win_length
+ * zero-padded to n_fft (power of two, 64..4096).  Output element (f, t) is written
+ * to out[f*stride_f + t*stride_t] for f < n_bins (n_bins = 1+n_fft/2, or n_fft/2 to
+ * drop the Nyquist bin as the 3-D path does), t < pca_stft_num_frames(L, hop). */
+int pca_stft_logmag(const float* wave, int64_t L, int n_fft, int win_length, int hop,
+                    int n_bins, float* out, int64_t stride_f, int64_t stride_t,
+                    void* stream);
+
+/* 2-D point sets for a batch of frames
+ * replaces: Code/dataset.py:50-54  ESC_pc.__getitem__ (+ default_collate)
+ * spec element (f, t) at spec[f*stride_f + t*stride_t]; farr[F] float32 (the
+ * reference's float64 farr rounded once, as its .float() does); idx[B] frame ids.
+ * out[B, F, 2] = (farr[f], spec[f, idx[b]]).  labels_out[b] = labels[idx[b]] when
+ * both label pointers are non-NULL. */
+int pca_pack_points_2d(const float* spec, int64_t stride_f, int64_t stride_t,
+                       const float* farr, const int64_t* idx, int B, int F,
+                       float* out, const int64_t* labels, int64_t* labels_out,
+                       void* stream);
+
+/* 3-D point sets for a batch of frame chunks
+ * replaces: Code/dataset.py:160-166  ESC_pc_temp.__getitem__ (+ default_collate)
+ * spec element (f, t, s) at spec[f*stride_f + t*stride_t + s*stride_s];
+ * out[B, Nt*F, 3]: point p = t*F + f -> (farr[f], tarr[t], spec[f, t, idx[b]]). */
+int pca_pack_points_3d(const float* spec, int64_t stride_f, int64_t stride_t,
+                       int64_t stride_s, const float* farr, const float* tarr,
+                       const int64_t* idx, int B, int F, int Nt, float* out,
+                       const int64_t* labels, int64_t* labels_out, void* stream);
+
+/* ------------------------------------------------------------------------- *
+ * Multihead attention block                                                  *
+ * replaces: set_transformer-master/modules.py:19-33 MAB.forward and the       *
+ * autograd graph torch builds for it; ISAB (modules.py:51-53) and PMA          *
+ * (modules.py:62-63) are MABs whose query is a learned [nq, dq] tensor shared  *
+ * by all sets (q_shared = 1), i.e. I.repeat(B,1,1) is never materialised.      *
+ * ------------------------------------------------------------------------- */
+typedef struct pca_mab_shape {
+  int32_t B;         /* sets in the batch                                        */
+  int32_t nq, nk;    /* queries / keys per set                                   */
+  int32_t dq, dk;    /* input feature widths of Q and K                          */
+  int32_t d;         /* dim_V (hidden width)                                     */
+  int32_t h;         /* heads; d % h == 0; score scale is 1/sqrt(d)              */
+  int32_t q_shared;  /* 1: Q is [nq, dq] shared by all sets; 0: Q is [B, nq, dq] */
+  int32_t mode;      /* PCA_MODE_F32 | PCA_MODE_BF16                             */
+  int32_t q_dtype, k_dtype, y_dtype;   /* PCA_F32 | PCA_BF16 of Q, K and Y       */
+} pca_mab_shape;
+
+/* nn.Linear layout: weight [d_out, d_in] row-major, y = x W^T + b.  fp32. */
+typedef struct pca_mab_params {
+  const float *wq, *bq, *wk, *bk, *wv, *bv, *wo, *bo;
+} pca_mab_params;
+
+typedef struct pca_mab_grads {      /* ACCUMULATED into (+=); caller zeroes     */
+  float *wq, *bq, *wk, *bk, *wv, *bv, *wo, *bo;
+} pca_mab_grads;
+
+/* bytes of the saved-for-backward block / of the scratch block (both 256-aligned) */
+size_t pca_mab_saved_bytes(const pca_mab_shape* s);
+size_t pca_mab_fwd_ws_bytes(const pca_mab_shape* s);
+size_t pca_mab_bwd_ws_bytes(const pca_mab_shape* s);
+
+/* Y[B, nq, d] = MAB(Q, K).  `saved` may be NULL for inference (nothing kept). */
+int pca_mab_fwd(const pca_mab_shape* s, const void* Q, const void* K,
+                const pca_mab_params* p, void* Y, void* saved, void* ws, void* stream);
+
+/* Given dY[B, nq, d] (dtype y_dtype) and the forward's `saved` block:
+ * dQ (q_shared ? [nq, dq] fp32, ACCUMULATED : [B, nq, dq] q_dtype, written) and
+ * dK ([B, nk, dk] k_dtype, written, or ACCUMULATED when dk_accumulate != 0 --
+ * ISAB feeds X to mab0 as K and to mab1 as Q, modules.py:52-53) may be NULL. */
+int pca_mab_bwd(const pca_mab_shape* s, const void* Q, const void* K,
+                const pca_mab_params* p, const void* saved, const void* dY,
+                void* dQ, void* dK, int dk_accumulate, const pca_mab_grads* g,
+                void* ws, void* stream);
+
+/* ------------------------------------------------------------------------- *
+ * Classifier head, loss and optimiser                                        *
+ * ------------------------------------------------------------------------- */
+
+/* Y[M, dout] = X[M, din] W^T + b  (nn.Linear; Code/models.py:40) -- fp32 */
+int pca_linear_fwd(const float* X, const float* W, const float* b, float* Y,
+                   int64_t M, int din, int dout, void* stream);
+/* dX = dY W (may be NULL); dW += dY^T X ; db += colsum(dY) */
+int pca_linear_bwd(const float* X, const float* W, const float* dY, float* dX,
+                   float* dW, float* db, int64_t M, int din, int dout, void* ws,
+                   void* stream);
+size_t pca_linear_bwd_ws_bytes(int64_t M, int din, int dout);
+
+/* nn.CrossEntropyLoss() (mean) forward + gradient in one launch
+ * replaces: Code/settransformer.py:88,104,107.  logits[B, C] fp32, labels[B] int64.
+ * loss_out[0] = mean loss; dlogits[B, C] = (softmax - onehot) * grad_scale / B;
+ * stats_out (nullable) [2]: += {sum of per-sample loss, #(argmax == label)}. */
+int pca_cross_entropy(const float* logits, const int64_t* labels, int B, int C,
+                      float grad_scale, float* loss_out, float* dlogits,
+                      float* stats_out, void* stream);
+
+/* torch.optim.Adam(lr, betas, eps, weight_decay) with COUPLED L2, one fused pass
+ * over a flat parameter vector.  replaces: Code/settransformer.py:89-91,108.
+ * step_count_dev: device int32 incremented by the kernel (bias correction uses the
+ * incremented value) so that a captured graph replays correctly.
+ * grad_scale multiplies the gradient first (1/world_size after an all-reduce SUM). */
+int pca_adam_step(float* param, const float* grad, float* exp_avg, float* exp_avg_sq,
+                  int64_t n, float lr, float beta1, float beta2, float eps,
+                  float weight_decay, float grad_scale, int32_t* step_count_dev,
+                  void* stream);
+
+/* ------------------------------------------------------------------------- *
+ * Whole-model engine: the train / eval step of Code/settransformer.py:100-108  *
+ * for the ST classifier of Code/models.py:13-44, enqueued by ONE call (so a    *
+ * caller can capture it in a hipGraph and replay it with zero host work).      *
+ * Parameters and gradients are flat fp32 vectors in state_dict order:          *
+ *   enc.0.{I, mab0.fc_{q,k,v,o}.{weight,bias}, mab1....}, enc.1...., dec.0.S,  *
+ *   dec.0.mab...., dec.1.{weight,bias}          (45 tensors, Code/models.py)   *
+ * so views of the flat vector ARE the nn.Module parameters.                    *
+ * ------------------------------------------------------------------------- */
+typedef struct pca_st_config {
+  int32_t B;        /* sets per step on this GPU                               */
+  int32_t N;        /* points per set                                          */
+  int32_t din;      /* 2: (f, logmag)   3: (f, t, logmag)                      */
+  int32_t d, h, m;  /* hidden width, heads, inducing points                    */
+  int32_t k;        /* PMA seeds (num_outputs); the train step needs k == 1    */
+  int32_t C;        /* classes                                                 */
+  int32_t mode;     /* PCA_MODE_F32 | PCA_MODE_BF16                            */
+} pca_st_config;
+
+/* number of fp32 parameters (= sum over the 45 tensors) */
+int64_t pca_st_param_count(const pca_st_config* c);
+/* element offset of the first parameter of enc.1 in the flat vector: gradients of
+ * [offset, end) (enc.1 + dec) are complete after phase 0 of the backward, those of
+ * [0, offset) (enc.0) after phase 1 -- the two all-reduce buckets of SURVEY.md 8e. */
+int64_t pca_st_bucket_split(const pca_st_config* c);
+size_t pca_st_ws_bytes(const pca_st_config* c, int training);
+
+/* logits[B*k, C] = ST(X[B, N, din]) -- inference, nothing saved */
+int pca_st_forward(const pca_st_config* c, const float* params, const float* X,
+                   float* logits, void* ws, void* stream);
+
+/* phase 0: forward, mean cross-entropy (loss_out[0]; stats += {sum loss, #correct}),
+ *          backward through dec and enc.1 ; phase 1: backward through enc.0.
+ * phase -1 runs both.  grads is ACCUMULATED into (caller zeroes it once per step).
+ * grad_scale multiplies dlogits (1.0 normally).  labels int64[B]. */
+int pca_st_train_fwd_bwd(const pca_st_config* c, const float* params, const float* X,
+                         const int64_t* labels, float* grads, float* loss_out,
+                         float* stats, float* logits, float grad_scale, int phase,
+                         void* ws, void* stream);
+
+/* ------------------------------------------------------------------------- *
+ * Building blocks (exported for unit tests and for composing other blocks)   *
+ * ------------------------------------------------------------------------- */
+
+/* Batched strided fp32 GEMM:  C[z] (+)= A[z] . B[z] (+ bias[j])
+ * z = z1*nb2 + z2 ; X[z] = X + z1*sX_b1 + z2*sX_b2 ; op(A)[i,k] = A[i*sa_m + k*sa_k],
+ * op(B)[k,j] = B[k*sb_k + j*sb_n], C[i,j] = C[i*sc_m + j].  accumulate != 0 adds to C.
+ * split_k > 1 splits K over workgroups and accumulates atomically (C must hold the
+ * initial value: zeros or the tensor being accumulated into). */
+typedef struct pca_gemm_desc {
+  int64_t M, N, K;
+  int64_t sa_m, sa_k, sb_k, sb_n, sc_m;
+  int32_t nb1, nb2;
+  int64_t sa_b1, sa_b2, sb_b1, sb_b2, sc_b1, sc_b2;
+  int32_t accumulate;
+  int32_t split_k;
+  float alpha;
+} pca_gemm_desc;
+int pca_gemm_f32(const pca_gemm_desc* g, const float* A, const float* B,
+                 const float* bias, float* C, void* stream);
+
+/* rows of length n: X <- softmax(X * scale) in place */
+int pca_softmax_rows(float* X, int64_t rows, int n, float scale, void* stream);
+/* dA <- A * (dA - rowsum(dA*A)) * scale  in place on dA */
+int pca_softmax_bwd_rows(const float* A, float* dA, int64_t rows, int n, float scale,
+                         void* stream);
+/* out[j] (+)= sum_i X[i, j] */
+int pca_colsum(const float* X, int64_t rows, int cols, float* out, int accumulate,
+               void* stream);
+
+/* ------------------------------------------------------------------------- *
+ * Measurement hook (bench.py's roofline leg; the only process-global state)   *
+ * While armed, every launch of the designated kernel is bracketed by a pair of *
+ * HIP events recorded on the stream the kernel is launched on (skipped while   *
+ * that stream is being captured), and its algorithmic FLOPs and bytes are      *
+ * accumulated.  pca_prof_stop() synchronises the events and returns the sums.  *
+ * ------------------------------------------------------------------------- */
+enum {
+  PCA_K_GEMM_F32 = 1,      /* k_gemm_f32 (exact path)                          */
+  PCA_K_MAB1_FWD = 2,      /* fused bf16 mab1 forward                          */
+  PCA_K_MAB1_BWD = 3,      /* fused bf16 mab1 backward                         */
+  PCA_K_MAB0_FWD = 4,      /* fused bf16 mab0 / PMA forward                    */
+  PCA_K_MAB0_BWD = 5,
+  PCA_K_WGRAD = 6          /* bf16 weight-gradient GEMM                        */
+};
+int pca_prof_start(int kernel_id, int max_launches);
+int pca_prof_stop(double* total_ms, int64_t* launches, double* flops, double* bytes);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* PCA_HIP_H */

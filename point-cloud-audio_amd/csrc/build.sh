@@ -1,0 +1,24 @@
+#!/bin/bash
+# Build libpca_hip.so for gfx950 (MI355X).  hipcc cross-compiles without a GPU.
+set -euo pipefail
+HERE="$(cd "$(dirname "${BASH_SOURCE[0]}")" && pwd)"
+ROOT="$(cd "$HERE/../.." && pwd)"
+OUT="$HERE/../pca_hip/libpca_hip.so"
+HIPCC="${HIPCC:-/opt/rocm/bin/hipcc}"
+FLAGS="-O3 -std=c++17 -fPIC --offload-arch=gfx950 -I$ROOT/include -I$HERE -Wall -Wno-unused-function"
+mkdir -p "$HERE/build"
+objs=()
+pids=()
+for src in "$HERE"/*.hip; do
+  obj="$HERE/build/$(basename "${src%.hip}").o"
+  objs+=("$obj")
+  if [ ! -f "$obj" ] || [ "$src" -nt "$obj" ] || [ "$HERE/pca_common.h" -nt "$obj" ] || \
+     [ "$ROOT/include/pca_hip.h" -nt "$obj" ] || \
+     { ls "$HERE"/*.hpp >/dev/null 2>&1 && [ -n "$(find "$HERE" -name '*.hpp' -newer "$obj")" ]; }; then
+    $HIPCC $FLAGS -c "$src" -o "$obj" &
+    pids+=($!)
+  fi
+done
+for p in "${pids[@]:-}"; do [ -n "$p" ] && wait "$p"; done
+$HIPCC -shared -fPIC --offload-arch=gfx950 "${objs[@]}" -o "$OUT"
+echo "built $OUT"

@@ -1,0 +1,309 @@
+// Row softmax (forward / backward), column sums and the small elementwise kernels of
+// the exact fp32 MAB path, plus the library's error-string plumbing.
+#include "pca_common.h"
+
+#include <string.h>
+
+#include <mutex>
+#include <vector>
+
+namespace pca {
+
+static thread_local char g_err[512] = "";
+
+void set_error(const char* fmt, ...) {
+  va_list ap;
+  va_start(ap, fmt);
+  vsnprintf(g_err, sizeof(g_err), fmt, ap);
+  va_end(ap);
+}
+
+// ---- measurement hook ------------------------------------------------------------
+namespace {
+struct ProfState {
+  std::mutex mu;
+  int kernel_id = 0;
+  int max_launches = 0;
+  int used = 0;
+  double flops = 0, bytes = 0;
+  std::vector<hipEvent_t> ev;     // 2 per launch
+} g_prof;
+}  // namespace
+
+ProfScope::ProfScope(int kernel_id, hipStream_t stream, double flops, double bytes)
+    : st(stream) {
+  if (g_prof.kernel_id != kernel_id) return;
+  std::lock_guard<std::mutex> lk(g_prof.mu);
+  if (g_prof.kernel_id != kernel_id || g_prof.used >= g_prof.max_launches) return;
+  hipStreamCaptureStatus cs = hipStreamCaptureStatusNone;
+  if (hipStreamIsCapturing(stream, &cs) != hipSuccess || cs != hipStreamCaptureStatusNone)
+    return;
+  slot = g_prof.used++;
+  g_prof.flops += flops;
+  g_prof.bytes += bytes;
+  (void)hipEventRecord(g_prof.ev[2 * slot], stream);
+}
+
+void ProfScope::end() {
+  if (slot < 0) return;
+  (void)hipEventRecord(g_prof.ev[2 * slot + 1], st);
+  slot = -1;
+}
+
+namespace {
+
+// ---- sub-wave reductions over G consecutive lanes (G power of two <= 64) ------
+template <int G>
+__device__ __forceinline__ float group_max(float v) {
+#pragma unroll
+  for (int o = G / 2; o > 0; o >>= 1) v = fmaxf(v, __shfl_xor(v, o, 64));
+  return v;
+}
+template <int G>
+__device__ __forceinline__ float group_sum(float v) {
+#pragma unroll
+  for (int o = G / 2; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);
+  return v;
+}
+
+// softmax(X*scale) in place; G lanes cooperate on one row
+// (set_transformer-master/modules.py:28)
+template <int G>
+__global__ __launch_bounds__(256) void k_softmax_rows(float* __restrict__ X, int64_t rows,
+                                                       int n, float scale) {
+  const int lane = threadIdx.x % G;
+  const int64_t row = ((int64_t)blockIdx.x * 256 + threadIdx.x) / G;
+  const bool live = row < rows;
+  float* x = X + (live ? row : 0) * (int64_t)n;
+  float m = -INFINITY;
+  if (live)
+    for (int j = lane; j < n; j += G) m = fmaxf(m, x[j] * scale);
+  m = group_max<G>(m);
+  float s = 0.f;
+  if (live)
+    for (int j = lane; j < n; j += G) s += expf(x[j] * scale - m);
+  s = group_sum<G>(s);
+  const float inv = 1.f / s;
+  if (live)
+    for (int j = lane; j < n; j += G) x[j] = expf(x[j] * scale - m) * inv;
+}
+
+// dS = A * (dA - sum_j dA_j A_j) * scale, in place on dA
+template <int G>
+__global__ __launch_bounds__(256) void k_softmax_bwd_rows(const float* __restrict__ A,
+                                                           float* __restrict__ dA,
+                                                           int64_t rows, int n, float scale) {
+  const int lane = threadIdx.x % G;
+  const int64_t row = ((int64_t)blockIdx.x * 256 + threadIdx.x) / G;
+  const bool live = row < rows;
+  const float* a = A + (live ? row : 0) * (int64_t)n;
+  float* da = dA + (live ? row : 0) * (int64_t)n;
+  float dot = 0.f;
+  if (live)
+    for (int j = lane; j < n; j += G) dot += a[j] * da[j];
+  dot = group_sum<G>(dot);
+  if (live)
+    for (int j = lane; j < n; j += G) da[j] = a[j] * (da[j] - dot) * scale;
+}
+
+// out[j] += sum_i X[i,j]; block = 64 column lanes x 4 row lanes; grid.x tiles the rows
+// (256 per block), grid.y tiles the columns (64 per block)
+__global__ __launch_bounds__(256) void k_colsum(const float* __restrict__ X, int64_t rows,
+                                                 int cols, float* __restrict__ out) {
+  __shared__ float red[4][64];
+  const int tx = threadIdx.x & 63, ty = threadIdx.x >> 6;
+  const int64_t r0 = (int64_t)blockIdx.x * 256;
+  const int64_t r1 = (r0 + 256 < rows) ? r0 + 256 : rows;
+  const int j = blockIdx.y * 64 + tx;
+  float s = 0.f;
+  if (j < cols)
+    for (int64_t i = r0 + ty; i < r1; i += 4) s += X[i * cols + j];
+  red[ty][tx] = s;
+  __syncthreads();
+  if (ty == 0 && j < cols) {
+    s = red[0][tx] + red[1][tx] + red[2][tx] + red[3][tx];
+    atomicAdd(&out[j], s);
+  }
+}
+
+__global__ void k_add_relu(const float* __restrict__ O, const float* __restrict__ Z,
+                           float* __restrict__ Y, int64_t n) {
+  int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  const int64_t stride = (int64_t)gridDim.x * blockDim.x;
+  for (; i < n; i += stride) Y[i] = O[i] + fmaxf(Z[i], 0.f);
+}
+
+__global__ void k_relu_bwd(const float* __restrict__ dY, const float* __restrict__ Z,
+                           float* __restrict__ dZ, int64_t n) {
+  int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  const int64_t stride = (int64_t)gridDim.x * blockDim.x;
+  for (; i < n; i += stride) dZ[i] = Z[i] > 0.f ? dY[i] : 0.f;
+}
+
+__global__ void k_copy_rows(const float* __restrict__ src, int64_t src_elems,
+                            float* __restrict__ dst, int64_t n) {
+  int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  const int64_t stride = (int64_t)gridDim.x * blockDim.x;
+  for (; i < n; i += stride) dst[i] = src[i % src_elems];
+}
+
+// zero fill (a kernel rather than hipMemsetAsync: identical behaviour eager and captured)
+__global__ void k_fill_zero(float* __restrict__ dst, int64_t n) {
+  int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  const int64_t stride = (int64_t)gridDim.x * blockDim.x;
+  const int64_t n4 = n >> 2;
+  if ((reinterpret_cast<uintptr_t>(dst) & 15) == 0) {
+    float4* d4 = reinterpret_cast<float4*>(dst);
+    for (int64_t j = i; j < n4; j += stride) d4[j] = make_float4(0.f, 0.f, 0.f, 0.f);
+    for (int64_t j = (n4 << 2) + i; j < n; j += stride) dst[j] = 0.f;
+  } else {
+    for (; i < n; i += stride) dst[i] = 0.f;
+  }
+}
+
+__global__ void k_add_inplace(float* __restrict__ dst, const float* __restrict__ src,
+                              int64_t n) {
+  int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  const int64_t stride = (int64_t)gridDim.x * blockDim.x;
+  for (; i < n; i += stride) dst[i] += src[i];
+}
+
+inline unsigned ew_blocks(int64_t n) {
+  int64_t b = cdiv(n, 256);
+  if (b > 4096) b = 4096;
+  if (b < 1) b = 1;
+  return (unsigned)b;
+}
+
+}  // namespace
+
+#define PCA_DISPATCH_G(n, CALL)     \
+  do {                              \
+    if ((n) > 32) { CALL(64); }     \
+    else if ((n) > 16) { CALL(32); }\
+    else if ((n) > 8) { CALL(16); } \
+    else { CALL(8); }               \
+  } while (0)
+
+int softmax_rows(float* X, int64_t rows, int n, float scale, hipStream_t st) {
+  PCA_REQUIRE(X && n > 0 && rows >= 0, "softmax_rows: bad arguments");
+  if (rows == 0) return PCA_OK;
+#define CALL(G)                                                                       \
+  hipLaunchKernelGGL(k_softmax_rows<G>, dim3((unsigned)cdiv(rows * G, 256)), dim3(256), \
+                     0, st, X, rows, n, scale)
+  PCA_DISPATCH_G(n, CALL);
+#undef CALL
+  return check_launch("k_softmax_rows");
+}
+
+int softmax_bwd_rows(const float* A, float* dA, int64_t rows, int n, float scale,
+                     hipStream_t st) {
+  PCA_REQUIRE(A && dA && n > 0 && rows >= 0, "softmax_bwd_rows: bad arguments");
+  if (rows == 0) return PCA_OK;
+#define CALL(G)                                                                           \
+  hipLaunchKernelGGL(k_softmax_bwd_rows<G>, dim3((unsigned)cdiv(rows * G, 256)), dim3(256), \
+                     0, st, A, dA, rows, n, scale)
+  PCA_DISPATCH_G(n, CALL);
+#undef CALL
+  return check_launch("k_softmax_bwd_rows");
+}
+
+int fill_zero(float* dst, int64_t n, hipStream_t st) {
+  if (n <= 0) return PCA_OK;
+  hipLaunchKernelGGL(k_fill_zero, dim3(ew_blocks((n + 3) / 4)), dim3(256), 0, st, dst, n);
+  return check_launch("k_fill_zero");
+}
+
+int colsum(const float* X, int64_t rows, int cols, float* out, int accumulate,
+           hipStream_t st) {
+  PCA_REQUIRE(X && out && cols > 0 && rows >= 0, "colsum: bad arguments");
+  if (!accumulate) PCA_TRY(fill_zero(out, cols, st));
+  if (rows == 0) return PCA_OK;
+  hipLaunchKernelGGL(k_colsum, dim3((unsigned)cdiv(rows, 256), (unsigned)cdiv(cols, 64)),
+                     dim3(256), 0, st, X, rows, cols, out);
+  return check_launch("k_colsum");
+}
+
+int add_relu(const float* O, const float* Z, float* Y, int64_t n, hipStream_t st) {
+  if (n <= 0) return PCA_OK;
+  hipLaunchKernelGGL(k_add_relu, dim3(ew_blocks(n)), dim3(256), 0, st, O, Z, Y, n);
+  return check_launch("k_add_relu");
+}
+
+int relu_bwd(const float* dY, const float* Z, float* dZ, int64_t n, hipStream_t st) {
+  if (n <= 0) return PCA_OK;
+  hipLaunchKernelGGL(k_relu_bwd, dim3(ew_blocks(n)), dim3(256), 0, st, dY, Z, dZ, n);
+  return check_launch("k_relu_bwd");
+}
+
+int copy_rows(const float* src, int64_t src_rows, float* dst, int64_t rows, int64_t cols,
+              hipStream_t st) {
+  const int64_t n = rows * cols;
+  if (n <= 0) return PCA_OK;
+  hipLaunchKernelGGL(k_copy_rows, dim3(ew_blocks(n)), dim3(256), 0, st, src,
+                     src_rows * cols, dst, n);
+  return check_launch("k_copy_rows");
+}
+
+int add_inplace(float* dst, const float* src, int64_t n, hipStream_t st) {
+  if (n <= 0) return PCA_OK;
+  hipLaunchKernelGGL(k_add_inplace, dim3(ew_blocks(n)), dim3(256), 0, st, dst, src, n);
+  return check_launch("k_add_inplace");
+}
+
+}  // namespace pca
+
+extern "C" {
+
+int pca_abi_version(void) { return PCA_ABI_VERSION; }
+const char* pca_last_error(void) { return pca::g_err; }
+
+int pca_prof_start(int kernel_id, int max_launches) {
+  PCA_REQUIRE(kernel_id > 0 && max_launches > 0, "prof_start: bad arguments");
+  std::lock_guard<std::mutex> lk(pca::g_prof.mu);
+  PCA_REQUIRE(pca::g_prof.kernel_id == 0, "prof_start: already armed");
+  pca::g_prof.ev.resize(2 * (size_t)max_launches);
+  for (auto& e : pca::g_prof.ev)
+    if (hipEventCreate(&e) != hipSuccess) {
+      pca::set_error("prof_start: hipEventCreate failed");
+      return PCA_ELAUNCH;
+    }
+  pca::g_prof.max_launches = max_launches;
+  pca::g_prof.used = 0;
+  pca::g_prof.flops = pca::g_prof.bytes = 0;
+  pca::g_prof.kernel_id = kernel_id;
+  return PCA_OK;
+}
+
+int pca_prof_stop(double* total_ms, int64_t* launches, double* flops, double* bytes) {
+  std::lock_guard<std::mutex> lk(pca::g_prof.mu);
+  PCA_REQUIRE(pca::g_prof.kernel_id != 0, "prof_stop: not armed");
+  double ms = 0;
+  for (int i = 0; i < pca::g_prof.used; ++i) {
+    float t = 0;
+    (void)hipEventSynchronize(pca::g_prof.ev[2 * i + 1]);
+    if (hipEventElapsedTime(&t, pca::g_prof.ev[2 * i], pca::g_prof.ev[2 * i + 1]) == hipSuccess)
+      ms += t;
+  }
+  for (auto& e : pca::g_prof.ev) (void)hipEventDestroy(e);
+  pca::g_prof.ev.clear();
+  if (total_ms) *total_ms = ms;
+  if (launches) *launches = pca::g_prof.used;
+  if (flops) *flops = pca::g_prof.flops;
+  if (bytes) *bytes = pca::g_prof.bytes;
+  pca::g_prof.kernel_id = 0;
+  return PCA_OK;
+}
+
+int pca_softmax_rows(float* X, int64_t rows, int n, float scale, void* stream) {
+  return pca::softmax_rows(X, rows, n, scale, pca::as_stream(stream));
+}
+int pca_softmax_bwd_rows(const float* A, float* dA, int64_t rows, int n, float scale,
+                         void* stream) {
+  return pca::softmax_bwd_rows(A, dA, rows, n, scale, pca::as_stream(stream));
+}
+int pca_colsum(const float* X, int64_t rows, int cols, float* out, int accumulate,
+               void* stream) {
+  return pca::colsum(X, rows, cols, out, accumulate, pca::as_stream(stream));
+}
+}

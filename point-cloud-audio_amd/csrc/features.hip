@@ -1,0 +1,181 @@
+// STFT log-magnitude and point-set packing: the data side of the hot path.
+//
+//   k_stft_logmag  : Code/settransformer.py:49-50  librosa.stft(...)/Nfft ; log(1e-8+|.|)
+//   k_pack_2d      : Code/dataset.py:50-54         ESC_pc.__getitem__ for a whole batch
+//   k_pack_3d      : Code/dataset.py:160-166       ESC_pc_temp.__getitem__ for a whole batch
+//
+// The reference does this per item in Python/numpy on the host (45.6 us / 331 us per set);
+// here the spectrogram stays resident in HBM and a batch is assembled by one launch.
+#include "pca_common.h"
+
+#include <mutex>
+
+namespace pca {
+namespace {
+
+// One workgroup per frame.  In-place radix-2 decimation-in-time FFT in LDS, in float64:
+// librosa computes the transform in double (numpy.fft) and only then rounds to complex64,
+// so matching it to ~1e-7 in log-magnitude -- including the near-silent bins that the
+// log(1e-8 + .) floor amplifies -- needs double butterflies; the op is a one-off pre-pass
+// and stays HBM/LDS-bound.  LDS: n_fft complex doubles (data) + n_fft/2 (twiddles)
+// = 24 B * n_fft (96 KiB at n_fft = 4096).  Frame t covers samples
+// [t*hop - n_fft/2, t*hop + n_fft/2) of the reflect-padded signal (center=True).
+__global__ __launch_bounds__(256) void k_stft_logmag(const float* __restrict__ wave,
+                                                      int64_t L, int n_fft, int log2n,
+                                                      int win_length, int hop, int n_bins,
+                                                      float* __restrict__ out,
+                                                      int64_t stride_f, int64_t stride_t) {
+  extern __shared__ __attribute__((aligned(16))) double2 lds_c[];
+  double2* x = lds_c;                 // [n_fft]
+  double2* tw = lds_c + n_fft;        // [n_fft/2]  exp(-2 pi i k / n_fft)
+  const int tid = threadIdx.x;
+  const int64_t t = blockIdx.x;
+  const int lpad = (n_fft - win_length) / 2;
+  const int64_t start = t * hop - n_fft / 2;
+  const int half = n_fft >> 1;
+
+  for (int k = tid; k < half; k += 256) {
+    double sn, cs;
+    sincospi(-2.0 * (double)k / (double)n_fft, &sn, &cs);
+    tw[k] = make_double2(cs, sn);
+  }
+  for (int n = tid; n < n_fft; n += 256) {
+    int64_t src = start + n;
+    if (src < 0) src = -src;
+    if (src >= L) src = 2 * (L - 1) - src;
+    if (src < 0) src = 0;  // only reachable when L <= n_fft/2 (rejected on the host)
+    const int nw = n - lpad;
+    double w = 0.0;
+    if (nw >= 0 && nw < win_length)
+      w = 0.5 - 0.5 * cospi(2.0 * (double)nw / (double)win_length);   // periodic Hann
+    const int r = (int)(__brev((unsigned)n) >> (32 - log2n));          // bit-reversed slot
+    x[r] = make_double2((double)wave[src] * w, 0.0);
+  }
+  __syncthreads();
+
+  for (int s = 1; s <= log2n; ++s) {
+    const int hm = 1 << (s - 1);               // half butterfly span
+    const int tstride = n_fft >> s;            // twiddle index stride
+    for (int j = tid; j < half; j += 256) {
+      const int k = j & (hm - 1);
+      const int i0 = ((j - k) << 1) + k;
+      const int i1 = i0 + hm;
+      const double2 w = tw[k * tstride];
+      const double2 a = x[i0];
+      const double2 b = x[i1];
+      const double2 bw = make_double2(b.x * w.x - b.y * w.y, b.x * w.y + b.y * w.x);
+      x[i0] = make_double2(a.x + bw.x, a.y + bw.y);
+      x[i1] = make_double2(a.x - bw.x, a.y - bw.y);
+    }
+    __syncthreads();
+  }
+
+  const double inv = 1.0 / (double)n_fft;
+  for (int f = tid; f < n_bins; f += 256) {
+    const double2 v = x[f];
+    // the reference rounds the spectrum to complex64 before |.| (librosa dtype=complex64)
+    const float re = (float)(v.x * inv), im = (float)(v.y * inv);
+    const float mag = sqrtf(re * re + im * im);
+    out[f * stride_f + t * stride_t] = logf(1.0e-8f + mag);
+  }
+}
+
+__global__ __launch_bounds__(256) void k_pack_2d(const float* __restrict__ spec,
+                                                  int64_t stride_f, int64_t stride_t,
+                                                  const float* __restrict__ farr,
+                                                  const int64_t* __restrict__ idx, int F,
+                                                  float* __restrict__ out,
+                                                  const int64_t* __restrict__ labels,
+                                                  int64_t* __restrict__ labels_out) {
+  const int b = blockIdx.y;
+  const int64_t frame = idx[b];
+  if (labels != nullptr && labels_out != nullptr && blockIdx.x == 0 && threadIdx.x == 0)
+    labels_out[b] = labels[frame];
+  const int f = blockIdx.x * 256 + threadIdx.x;
+  if (f >= F) return;
+  float2 p;
+  p.x = farr[f];
+  p.y = spec[f * stride_f + frame * stride_t];
+  reinterpret_cast<float2*>(out)[(int64_t)b * F + f] = p;
+}
+
+__global__ __launch_bounds__(256) void k_pack_3d(const float* __restrict__ spec,
+                                                  int64_t stride_f, int64_t stride_t,
+                                                  int64_t stride_s,
+                                                  const float* __restrict__ farr,
+                                                  const float* __restrict__ tarr,
+                                                  const int64_t* __restrict__ idx, int F,
+                                                  int Nt, float* __restrict__ out,
+                                                  const int64_t* __restrict__ labels,
+                                                  int64_t* __restrict__ labels_out) {
+  const int b = blockIdx.y;
+  const int64_t chunk = idx[b];
+  if (labels != nullptr && labels_out != nullptr && blockIdx.x == 0 && threadIdx.x == 0)
+    labels_out[b] = labels[chunk];
+  const int p = blockIdx.x * 256 + threadIdx.x;      // point index = t*F + f (time-major)
+  if (p >= F * Nt) return;
+  const int t = p / F, f = p - t * F;
+  float* o = out + ((int64_t)b * F * Nt + p) * 3;
+  o[0] = farr[f];
+  o[1] = tarr[t];
+  o[2] = spec[f * stride_f + t * stride_t + chunk * stride_s];
+}
+
+}  // namespace
+}  // namespace pca
+
+extern "C" {
+
+int64_t pca_stft_num_frames(int64_t L, int hop) { return hop > 0 ? 1 + L / hop : 0; }
+
+int pca_stft_logmag(const float* wave, int64_t L, int n_fft, int win_length, int hop,
+                    int n_bins, float* out, int64_t stride_f, int64_t stride_t,
+                    void* stream) {
+  PCA_REQUIRE(wave && out, "stft_logmag: null pointer");
+  PCA_REQUIRE(n_fft >= 64 && n_fft <= 4096 && (n_fft & (n_fft - 1)) == 0,
+              "stft_logmag: n_fft=%d must be a power of two in [64, 4096]", n_fft);
+  PCA_REQUIRE(win_length > 0 && win_length <= n_fft, "stft_logmag: win_length=%d", win_length);
+  PCA_REQUIRE(hop > 0, "stft_logmag: hop=%d", hop);
+  PCA_REQUIRE(n_bins > 0 && n_bins <= n_fft / 2 + 1, "stft_logmag: n_bins=%d", n_bins);
+  PCA_REQUIRE(L > n_fft / 2, "stft_logmag: reflect padding needs L=%lld > n_fft/2",
+              (long long)L);
+  int log2n = 0;
+  while ((1 << log2n) < n_fft) ++log2n;
+  const int64_t T = pca_stft_num_frames(L, hop);
+  const size_t lds = ((size_t)n_fft + n_fft / 2) * sizeof(double2);
+  static std::once_flag lds_once;   // allow > 64 KiB of dynamic LDS (96 KiB at n_fft 4096)
+  std::call_once(lds_once, [] {
+    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(pca::k_stft_logmag),
+                              hipFuncAttributeMaxDynamicSharedMemorySize, 96 * 1024);
+  });
+  hipLaunchKernelGGL(pca::k_stft_logmag, dim3((unsigned)T), dim3(256), lds,
+                     pca::as_stream(stream), wave, L, n_fft, log2n, win_length, hop, n_bins,
+                     out, stride_f, stride_t);
+  return pca::check_launch("k_stft_logmag");
+}
+
+int pca_pack_points_2d(const float* spec, int64_t stride_f, int64_t stride_t,
+                       const float* farr, const int64_t* idx, int B, int F, float* out,
+                       const int64_t* labels, int64_t* labels_out, void* stream) {
+  PCA_REQUIRE(spec && farr && idx && out, "pack_points_2d: null pointer");
+  PCA_REQUIRE(B > 0 && F > 0 && B <= 65535, "pack_points_2d: B=%d F=%d", B, F);
+  hipLaunchKernelGGL(pca::k_pack_2d, dim3((unsigned)pca::cdiv(F, 256), (unsigned)B),
+                     dim3(256), 0, pca::as_stream(stream), spec, stride_f, stride_t, farr,
+                     idx, F, out, labels, labels_out);
+  return pca::check_launch("k_pack_2d");
+}
+
+int pca_pack_points_3d(const float* spec, int64_t stride_f, int64_t stride_t,
+                       int64_t stride_s, const float* farr, const float* tarr,
+                       const int64_t* idx, int B, int F, int Nt, float* out,
+                       const int64_t* labels, int64_t* labels_out, void* stream) {
+  PCA_REQUIRE(spec && farr && tarr && idx && out, "pack_points_3d: null pointer");
+  PCA_REQUIRE(B > 0 && F > 0 && Nt > 0 && B <= 65535, "pack_points_3d: B=%d F=%d Nt=%d", B,
+              F, Nt);
+  hipLaunchKernelGGL(pca::k_pack_3d,
+                     dim3((unsigned)pca::cdiv((int64_t)F * Nt, 256), (unsigned)B), dim3(256),
+                     0, pca::as_stream(stream), spec, stride_f, stride_t, stride_s, farr,
+                     tarr, idx, F, Nt, out, labels, labels_out);
+  return pca::check_launch("k_pack_3d");
+}
+}

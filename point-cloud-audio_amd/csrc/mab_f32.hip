@@ -1,0 +1,231 @@
+// Exact-fp32 MAB forward / backward (PCA_MODE_F32): the parity path.
+//
+// Restates set_transformer-master/modules.py:19-33 as a chain of strided GEMM launches
+// (gemm_f32.hip) with the row softmax in between.  The reference's head split
+// (`torch.cat(X.split(dh, 2), 0)`, modules.py:24-26) is pure index arithmetic here: head j
+// of set b is the batch element (b, j) of a two-level strided batch over the [B, n, d]
+// projection, so no head-major copy is ever made.  The learned query of ISAB / PMA
+// (modules.py:52,63 `I.repeat(B,1,1)`) is projected once (q_shared) and broadcast through
+// a zero batch stride.
+#include "pca_common.h"
+
+#include <math.h>
+
+namespace pca {
+
+namespace {
+
+struct SavedF32 {
+  float *Qp, *Kp, *Vp, *A, *O, *Z;
+};
+
+inline size_t saved_elems(const pca_mab_shape& s, SavedF32* out, void* base) {
+  const int64_t Bq = s.q_shared ? 1 : s.B;
+  Carver c(base);
+  SavedF32 v;
+  v.Qp = c.take<float>((size_t)Bq * s.nq * s.d);
+  v.Kp = c.take<float>((size_t)s.B * s.nk * s.d);
+  v.Vp = c.take<float>((size_t)s.B * s.nk * s.d);
+  v.A = c.take<float>((size_t)s.B * s.h * s.nq * s.nk);
+  v.O = c.take<float>((size_t)s.B * s.nq * s.d);
+  v.Z = c.take<float>((size_t)s.B * s.nq * s.d);
+  if (out) *out = v;
+  return c.off;
+}
+
+struct BwdWsF32 {
+  float *dZ, *dO, *dQp, *dA, *dKp, *dVp, *dQps;
+};
+
+inline size_t bwd_ws_elems(const pca_mab_shape& s, BwdWsF32* out, void* base) {
+  Carver c(base);
+  BwdWsF32 v;
+  v.dZ = c.take<float>((size_t)s.B * s.nq * s.d);
+  v.dO = c.take<float>((size_t)s.B * s.nq * s.d);
+  v.dQp = c.take<float>((size_t)s.B * s.nq * s.d);
+  v.dA = c.take<float>((size_t)s.B * s.h * s.nq * s.nk);
+  v.dKp = c.take<float>((size_t)s.B * s.nk * s.d);
+  v.dVp = c.take<float>((size_t)s.B * s.nk * s.d);
+  v.dQps = c.take<float>((size_t)s.nq * s.d);
+  if (out) *out = v;
+  return c.off;
+}
+
+inline pca_gemm_desc gd(int64_t M, int64_t N, int64_t K, int64_t sa_m, int64_t sa_k,
+                        int64_t sb_k, int64_t sb_n, int64_t sc_m, int accumulate) {
+  pca_gemm_desc g{};
+  g.M = M; g.N = N; g.K = K;
+  g.sa_m = sa_m; g.sa_k = sa_k; g.sb_k = sb_k; g.sb_n = sb_n; g.sc_m = sc_m;
+  g.nb1 = 1; g.nb2 = 1;
+  g.accumulate = accumulate;
+  g.split_k = 0;
+  g.alpha = 1.f;
+  return g;
+}
+
+// Y[M, dout] (+)= X[M, din] W^T (+ b)
+inline int linear(const float* X, const float* W, const float* b, float* Y, int64_t M,
+                  int din, int dout, int accumulate, hipStream_t st) {
+  pca_gemm_desc g = gd(M, dout, din, din, 1, 1, din, dout, accumulate);
+  g.split_k = 1;
+  return gemm_f32(g, X, W, b, Y, st);
+}
+// dX[M, din] (+)= dY[M, dout] W
+inline int linear_dx(const float* dY, const float* W, float* dX, int64_t M, int din,
+                     int dout, int accumulate, hipStream_t st) {
+  pca_gemm_desc g = gd(M, din, dout, dout, 1, din, 1, din, accumulate);
+  g.split_k = 1;
+  return gemm_f32(g, dY, W, nullptr, dX, st);
+}
+// dW[dout, din] += dY[M, dout]^T X[M, din]   (split-K over the M rows)
+inline int linear_dw(const float* dY, const float* X, float* dW, int64_t M, int din,
+                     int dout, hipStream_t st) {
+  pca_gemm_desc g = gd(dout, din, M, 1, dout, din, 1, din, 1);
+  return gemm_f32(g, dY, X, nullptr, dW, st);
+}
+
+inline void set_heads(pca_gemm_desc& g, const pca_mab_shape& s, int64_t a_b, int64_t a_h,
+                      int64_t b_b, int64_t b_h, int64_t c_b, int64_t c_h) {
+  g.nb1 = s.B; g.nb2 = s.h;
+  g.sa_b1 = a_b; g.sa_b2 = a_h;
+  g.sb_b1 = b_b; g.sb_b2 = b_h;
+  g.sc_b1 = c_b; g.sc_b2 = c_h;
+}
+
+}  // namespace
+
+int validate_shape(const pca_mab_shape* s) {
+  PCA_REQUIRE(s != nullptr, "mab: null shape");
+  PCA_REQUIRE(s->B > 0 && s->nq > 0 && s->nk > 0 && s->dq > 0 && s->dk > 0 && s->d > 0 &&
+                  s->h > 0,
+              "mab: non-positive extent (B=%d nq=%d nk=%d dq=%d dk=%d d=%d h=%d)", s->B,
+              s->nq, s->nk, s->dq, s->dk, s->d, s->h);
+  PCA_REQUIRE(s->d % s->h == 0, "mab: d=%d not divisible by h=%d", s->d, s->h);
+  return PCA_OK;
+}
+
+size_t mab_f32_saved_bytes(const pca_mab_shape& s) { return saved_elems(s, nullptr, nullptr); }
+size_t mab_f32_bwd_ws_bytes(const pca_mab_shape& s) { return bwd_ws_elems(s, nullptr, nullptr); }
+
+int mab_f32_fwd(const pca_mab_shape& s, const float* Q, const float* K,
+                const pca_mab_params& p, float* Y, void* saved, hipStream_t st) {
+  SavedF32 v;
+  saved_elems(s, &v, saved);
+  const int64_t Bq = s.q_shared ? 1 : s.B;
+  const int d = s.d, h = s.h, dh = d / h, nq = s.nq, nk = s.nk;
+  const int64_t qb = s.q_shared ? 0 : (int64_t)nq * d;   // batch stride of Qp
+  const float scale = 1.0f / sqrtf((float)d);            // modules.py:28: sqrt(dim_V)
+
+  PCA_TRY(linear(Q, p.wq, p.bq, v.Qp, Bq * nq, s.dq, d, 0, st));           // :20
+  PCA_TRY(linear(K, p.wk, p.bk, v.Kp, (int64_t)s.B * nk, s.dk, d, 0, st)); // :21
+  PCA_TRY(linear(K, p.wv, p.bv, v.Vp, (int64_t)s.B * nk, s.dk, d, 0, st)); // :21
+
+  {  // S[b,j] = Qp_j Kp_j^T  -> A buffer                                       :28
+    pca_gemm_desc g = gd(nq, nk, dh, d, 1, 1, d, nk, 0);
+    g.split_k = 1;
+    set_heads(g, s, qb, dh, (int64_t)nk * d, dh, (int64_t)h * nq * nk, (int64_t)nq * nk);
+    PCA_TRY(gemm_f32(g, v.Qp, v.Kp, nullptr, v.A, st));
+  }
+  PCA_TRY(softmax_rows(v.A, (int64_t)s.B * h * nq, nk, scale, st));         // :28
+  PCA_TRY(copy_rows(v.Qp, Bq * nq, v.O, (int64_t)s.B * nq, d, st));         // O = Q_
+  {  // O_j += A_j Vp_j                                                          :29
+    pca_gemm_desc g = gd(nq, dh, nk, nk, 1, d, 1, d, 1);
+    g.split_k = 1;
+    set_heads(g, s, (int64_t)h * nq * nk, (int64_t)nq * nk, (int64_t)nk * d, dh,
+              (int64_t)nq * d, dh);
+    PCA_TRY(gemm_f32(g, v.A, v.Vp, nullptr, v.O, st));
+  }
+  PCA_TRY(linear(v.O, p.wo, p.bo, v.Z, (int64_t)s.B * nq, d, d, 0, st));    // :31
+  PCA_TRY(add_relu(v.O, v.Z, Y, (int64_t)s.B * nq * d, st));                // :31
+  return PCA_OK;
+}
+
+int mab_f32_bwd(const pca_mab_shape& s, const float* Q, const float* K,
+                const pca_mab_params& p, const void* saved, const float* dY, float* dQ,
+                float* dK, int dk_accumulate, const pca_mab_grads& g, void* ws,
+                hipStream_t st) {
+  SavedF32 v;
+  saved_elems(s, &v, const_cast<void*>(saved));
+  BwdWsF32 w;
+  bwd_ws_elems(s, &w, ws);
+  const int d = s.d, h = s.h, dh = d / h, nq = s.nq, nk = s.nk;
+  const int64_t Mq = (int64_t)s.B * nq, Mk = (int64_t)s.B * nk;
+  const int64_t qb = s.q_shared ? 0 : (int64_t)nq * d;
+  const float scale = 1.0f / sqrtf((float)d);
+
+  // O + relu(fc_o(O))
+  PCA_TRY(relu_bwd(dY, v.Z, w.dZ, Mq * d, st));
+  PCA_TRY(linear_dw(w.dZ, v.O, g.wo, Mq, d, d, st));
+  PCA_TRY(colsum(w.dZ, Mq, d, g.bo, 1, st));
+  PCA_TRY(copy_rows(dY, Mq, w.dO, Mq, d, st));
+  PCA_TRY(linear_dx(w.dZ, p.wo, w.dO, Mq, d, d, 1, st));
+
+  // attention: dV_j = A_j^T dO_j
+  PCA_TRY(fill_zero(w.dVp, Mk * d, st));
+  PCA_TRY(fill_zero(w.dKp, Mk * d, st));
+  {
+    pca_gemm_desc gg = gd(nk, dh, nq, 1, nk, d, 1, d, 1);
+    set_heads(gg, s, (int64_t)h * nq * nk, (int64_t)nq * nk, (int64_t)nq * d, dh,
+              (int64_t)nk * d, dh);
+    PCA_TRY(gemm_f32(gg, v.A, w.dO, nullptr, w.dVp, st));
+  }
+  {  // dA = dO_j Vp_j^T
+    pca_gemm_desc gg = gd(nq, nk, dh, d, 1, 1, d, nk, 0);
+    gg.split_k = 1;
+    set_heads(gg, s, (int64_t)nq * d, dh, (int64_t)nk * d, dh, (int64_t)h * nq * nk,
+              (int64_t)nq * nk);
+    PCA_TRY(gemm_f32(gg, w.dO, v.Vp, nullptr, w.dA, st));
+  }
+  PCA_TRY(softmax_bwd_rows(v.A, w.dA, (int64_t)s.B * h * nq, nk, scale, st));  // dS*scale
+  PCA_TRY(copy_rows(w.dO, Mq, w.dQp, Mq, d, st));                              // residual Q_
+  {  // dQp_j += dS Kp_j
+    pca_gemm_desc gg = gd(nq, dh, nk, nk, 1, d, 1, d, 1);
+    gg.split_k = 1;
+    set_heads(gg, s, (int64_t)h * nq * nk, (int64_t)nq * nk, (int64_t)nk * d, dh,
+              (int64_t)nq * d, dh);
+    PCA_TRY(gemm_f32(gg, w.dA, v.Kp, nullptr, w.dQp, st));
+  }
+  {  // dKp_j = dS^T Qp_j
+    pca_gemm_desc gg = gd(nk, dh, nq, 1, nk, d, 1, d, 1);
+    set_heads(gg, s, (int64_t)h * nq * nk, (int64_t)nq * nk, qb, dh, (int64_t)nk * d, dh);
+    PCA_TRY(gemm_f32(gg, w.dA, v.Qp, nullptr, w.dKp, st));
+  }
+
+  // fc_k / fc_v
+  PCA_TRY(linear_dw(w.dKp, K, g.wk, Mk, s.dk, d, st));
+  PCA_TRY(colsum(w.dKp, Mk, d, g.bk, 1, st));
+  PCA_TRY(linear_dw(w.dVp, K, g.wv, Mk, s.dk, d, st));
+  PCA_TRY(colsum(w.dVp, Mk, d, g.bv, 1, st));
+  if (dK != nullptr) {
+    PCA_TRY(linear_dx(w.dKp, p.wk, dK, Mk, s.dk, d, dk_accumulate ? 1 : 0, st));
+    PCA_TRY(linear_dx(w.dVp, p.wv, dK, Mk, s.dk, d, 1, st));
+  }
+
+  // fc_q
+  if (s.q_shared) {
+    PCA_TRY(colsum(w.dQp, s.B, nq * d, w.dQps, 0, st));   // sum over sets
+    PCA_TRY(linear_dw(w.dQps, Q, g.wq, nq, s.dq, d, st));
+    PCA_TRY(colsum(w.dQps, nq, d, g.bq, 1, st));
+    if (dQ != nullptr) PCA_TRY(linear_dx(w.dQps, p.wq, dQ, nq, s.dq, d, 1, st));
+  } else {
+    PCA_TRY(linear_dw(w.dQp, Q, g.wq, Mq, s.dq, d, st));
+    PCA_TRY(colsum(w.dQp, Mq, d, g.bq, 1, st));
+    if (dQ != nullptr) PCA_TRY(linear_dx(w.dQp, p.wq, dQ, Mq, s.dq, d, 0, st));
+  }
+  return PCA_OK;
+}
+
+// ---- classifier head ----------------------------------------------------------
+int linear_fwd_f32(const float* X, const float* W, const float* b, float* Y, int64_t M,
+                   int din, int dout, hipStream_t st) {
+  return linear(X, W, b, Y, M, din, dout, 0, st);
+}
+int linear_bwd_f32(const float* X, const float* W, const float* dY, float* dX, float* dW,
+                   float* db, int64_t M, int din, int dout, hipStream_t st) {
+  if (dW) PCA_TRY(linear_dw(dY, X, dW, M, din, dout, st));
+  if (db) PCA_TRY(colsum(dY, M, dout, db, 1, st));
+  if (dX) PCA_TRY(linear_dx(dY, W, dX, M, din, dout, 0, st));
+  return PCA_OK;
+}
+
+}  // namespace pca

@@ -1,0 +1,85 @@
+// Internal helpers shared by the HIP translation units of libpca_hip.so.
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+#include <stdio.h>
+#include <stdarg.h>
+
+#include "pca_hip.h"
+
+namespace pca {
+
+// thread-local error string (the only mutable global state of the library)
+void set_error(const char* fmt, ...);
+
+inline hipStream_t as_stream(void* s) { return reinterpret_cast<hipStream_t>(s); }
+
+inline int check_launch(const char* what) {
+  hipError_t e = hipGetLastError();
+  if (e != hipSuccess) {
+    set_error("%s: %s", what, hipGetErrorString(e));
+    return PCA_ELAUNCH;
+  }
+  return PCA_OK;
+}
+
+#define PCA_REQUIRE(cond, ...)        \
+  do {                                \
+    if (!(cond)) {                    \
+      ::pca::set_error(__VA_ARGS__);  \
+      return PCA_EINVAL;              \
+    }                                 \
+  } while (0)
+
+#define PCA_TRY(expr)                 \
+  do {                                \
+    int _rc = (expr);                 \
+    if (_rc != PCA_OK) return _rc;    \
+  } while (0)
+
+inline size_t align256(size_t n) { return (n + 255) & ~size_t(255); }
+
+inline int64_t cdiv(int64_t a, int64_t b) { return (a + b - 1) / b; }
+
+// bump allocator over a caller-provided block
+struct Carver {
+  char* base;
+  size_t off = 0;
+  explicit Carver(void* p) : base(reinterpret_cast<char*>(p)) {}
+  template <typename T>
+  T* take(size_t count) {
+    T* r = reinterpret_cast<T*>(base + off);
+    off += align256(count * sizeof(T));
+    return r;
+  }
+};
+
+// ---- measurement hook (see pca_prof_start in pca_hip.h) -------------------------
+// Usage in a launcher:  ProfScope ps(PCA_K_X, stream, flops, bytes);  <launch>;  ps.end();
+struct ProfScope {
+  int slot = -1;
+  hipStream_t st;
+  ProfScope(int kernel_id, hipStream_t stream, double flops, double bytes);
+  void end();
+};
+
+// ---- internal launchers used across translation units -------------------
+int gemm_f32(const pca_gemm_desc& g, const float* A, const float* B, const float* bias,
+             float* C, hipStream_t st);
+int softmax_rows(float* X, int64_t rows, int n, float scale, hipStream_t st);
+int softmax_bwd_rows(const float* A, float* dA, int64_t rows, int n, float scale,
+                     hipStream_t st);
+int colsum(const float* X, int64_t rows, int cols, float* out, int accumulate,
+           hipStream_t st);
+// Y = O + relu(Z)
+int add_relu(const float* O, const float* Z, float* Y, int64_t n, hipStream_t st);
+// dZ = dY * [Z > 0]
+int relu_bwd(const float* dY, const float* Z, float* dZ, int64_t n, hipStream_t st);
+// dst[r, :] = src[(r % src_rows), :]   (broadcast copy when src_rows < rows)
+int copy_rows(const float* src, int64_t src_rows, float* dst, int64_t rows, int64_t cols,
+              hipStream_t st);
+// dst += src (n elements)
+int add_inplace(float* dst, const float* src, int64_t n, hipStream_t st);
+int fill_zero(float* dst, int64_t n, hipStream_t st);
+
+}  // namespace pca

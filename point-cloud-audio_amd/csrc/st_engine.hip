@@ -1,0 +1,259 @@
+// Whole-model engine for the ST classifier (Code/models.py:13-44) and its train step
+// (Code/settransformer.py:100-108): one host call enqueues every kernel of
+// forward -> cross-entropy -> backward against flat parameter / gradient vectors laid out
+// in state_dict order.  No Python, autograd or allocator sits between the kernels, so the
+// caller can capture the call in a hipGraph.
+#include "pca_common.h"
+
+namespace pca {
+
+int validate_shape(const pca_mab_shape* s);
+size_t mab_f32_saved_bytes(const pca_mab_shape& s);
+size_t mab_f32_bwd_ws_bytes(const pca_mab_shape& s);
+int mab_f32_fwd(const pca_mab_shape& s, const float* Q, const float* K,
+                const pca_mab_params& p, float* Y, void* saved, hipStream_t st);
+int mab_f32_bwd(const pca_mab_shape& s, const float* Q, const float* K,
+                const pca_mab_params& p, const void* saved, const float* dY, float* dQ,
+                float* dK, int dk_accumulate, const pca_mab_grads& g, void* ws,
+                hipStream_t st);
+int linear_fwd_f32(const float* X, const float* W, const float* b, float* Y, int64_t M,
+                   int din, int dout, hipStream_t st);
+int linear_bwd_f32(const float* X, const float* W, const float* dY, float* dX, float* dW,
+                   float* db, int64_t M, int din, int dout, hipStream_t st);
+
+namespace {
+
+struct MabOff {   // element offsets of one MAB's 8 tensors in the flat vector
+  int64_t wq, bq, wk, bk, wv, bv, wo, bo;
+};
+
+struct Layout {
+  int64_t I[2];
+  MabOff mab0[2], mab1[2];
+  int64_t S;
+  MabOff pma;
+  int64_t wc, bc;
+  int64_t total;
+  int64_t enc1_begin;
+};
+
+inline MabOff lay_mab(int64_t& o, int dq, int dk, int d) {
+  MabOff m;
+  m.wq = o; o += (int64_t)d * dq;
+  m.bq = o; o += d;
+  m.wk = o; o += (int64_t)d * dk;
+  m.bk = o; o += d;
+  m.wv = o; o += (int64_t)d * dk;
+  m.bv = o; o += d;
+  m.wo = o; o += (int64_t)d * d;
+  m.bo = o; o += d;
+  return m;
+}
+
+// state_dict order of Code/models.py:34-41 (ISAB: I, mab0, mab1 -- modules.py:45-49)
+inline Layout layout(const pca_st_config& c) {
+  Layout L;
+  int64_t o = 0;
+  for (int li = 0; li < 2; ++li) {
+    const int din = li == 0 ? c.din : c.d;
+    if (li == 1) L.enc1_begin = o;
+    L.I[li] = o; o += (int64_t)c.m * c.d;
+    L.mab0[li] = lay_mab(o, c.d, din, c.d);   // MAB(dim_out, dim_in, dim_out)
+    L.mab1[li] = lay_mab(o, din, c.d, c.d);   // MAB(dim_in, dim_out, dim_out)
+  }
+  L.S = o; o += (int64_t)c.k * c.d;
+  L.pma = lay_mab(o, c.d, c.d, c.d);
+  L.wc = o; o += (int64_t)c.C * c.d;
+  L.bc = o; o += c.C;
+  L.total = o;
+  return L;
+}
+
+inline pca_mab_params params_at(const float* base, const MabOff& m) {
+  return pca_mab_params{base + m.wq, base + m.bq, base + m.wk, base + m.bk,
+                        base + m.wv, base + m.bv, base + m.wo, base + m.bo};
+}
+inline pca_mab_grads grads_at(float* base, const MabOff& m) {
+  return pca_mab_grads{base + m.wq, base + m.bq, base + m.wk, base + m.bk,
+                       base + m.wv, base + m.bv, base + m.wo, base + m.bo};
+}
+
+inline pca_mab_shape shape(const pca_st_config& c, int nq, int nk, int dq, int dk,
+                           int q_shared) {
+  pca_mab_shape s{};
+  s.B = c.B; s.nq = nq; s.nk = nk; s.dq = dq; s.dk = dk; s.d = c.d; s.h = c.h;
+  s.q_shared = q_shared; s.mode = c.mode;
+  s.q_dtype = s.k_dtype = s.y_dtype = PCA_F32;
+  return s;
+}
+
+struct Shapes {
+  pca_mab_shape m0[2], m1[2], pma;
+};
+inline Shapes shapes(const pca_st_config& c) {
+  Shapes s;
+  for (int li = 0; li < 2; ++li) {
+    const int din = li == 0 ? c.din : c.d;
+    s.m0[li] = shape(c, c.m, c.N, c.d, din, 1);
+    s.m1[li] = shape(c, c.N, c.m, din, c.d, 0);
+  }
+  s.pma = shape(c, c.k, c.N, c.d, c.d, 1);
+  return s;
+}
+
+struct Ws {
+  void* saved[5];            // mab0[0], mab1[0], mab0[1], mab1[1], pma
+  float *H[2], *Y[2], *P, *logits, *dlogits;
+  float *dP, *dY2, *dY1, *dH;
+  void* scratch;
+};
+
+inline size_t carve(const pca_st_config& c, int training, Ws* out, void* base) {
+  const Shapes s = shapes(c);
+  Carver cv(base);
+  Ws w{};
+  const pca_mab_shape* order[5] = {&s.m0[0], &s.m1[0], &s.m0[1], &s.m1[1], &s.pma};
+  size_t max_saved = 0, max_bwd = 0;
+  for (int i = 0; i < 5; ++i) {
+    const size_t sb = mab_f32_saved_bytes(*order[i]);
+    max_saved = sb > max_saved ? sb : max_saved;
+    const size_t bb = mab_f32_bwd_ws_bytes(*order[i]);
+    max_bwd = bb > max_bwd ? bb : max_bwd;
+    if (training) w.saved[i] = cv.take<char>(sb);
+  }
+  const size_t BN = (size_t)c.B * c.N, Bm = (size_t)c.B * c.m;
+  w.H[0] = cv.take<float>(Bm * c.d);
+  w.H[1] = cv.take<float>(Bm * c.d);
+  w.Y[0] = cv.take<float>(BN * c.d);
+  w.Y[1] = cv.take<float>(BN * c.d);
+  w.P = cv.take<float>((size_t)c.B * c.k * c.d);
+  w.logits = cv.take<float>((size_t)c.B * c.k * c.C);
+  if (training) {
+    w.dlogits = cv.take<float>((size_t)c.B * c.k * c.C);
+    w.dP = cv.take<float>((size_t)c.B * c.k * c.d);
+    w.dY2 = cv.take<float>(BN * c.d);
+    w.dY1 = cv.take<float>(BN * c.d);
+    w.dH = cv.take<float>(Bm * c.d);
+    w.scratch = cv.take<char>(max_bwd);
+  } else {
+    w.scratch = cv.take<char>(max_saved);   // inference: intermediates live in scratch
+  }
+  if (out) *out = w;
+  return cv.off;
+}
+
+int validate(const pca_st_config* c) {
+  PCA_REQUIRE(c != nullptr, "st: null config");
+  PCA_REQUIRE(c->B > 0 && c->N > 0 && c->din > 0 && c->d > 0 && c->h > 0 && c->m > 0 &&
+                  c->k > 0 && c->C > 0,
+              "st: non-positive extent");
+  PCA_REQUIRE(c->d % c->h == 0, "st: d=%d not divisible by h=%d", c->d, c->h);
+  if (c->mode != PCA_MODE_F32) {
+    set_error("st: mode %d not built", c->mode);
+    return PCA_EUNSUPPORTED;
+  }
+  return PCA_OK;
+}
+
+int forward(const pca_st_config& c, const Layout& L, const Shapes& s, const float* p,
+            const float* X, Ws& w, bool training, hipStream_t st) {
+  const float* in = X;
+  for (int li = 0; li < 2; ++li) {
+    void* sv0 = training ? w.saved[2 * li] : w.scratch;
+    void* sv1 = training ? w.saved[2 * li + 1] : w.scratch;
+    PCA_TRY(mab_f32_fwd(s.m0[li], p + L.I[li], in, params_at(p, L.mab0[li]), w.H[li], sv0,
+                        st));                                       // modules.py:52
+    PCA_TRY(mab_f32_fwd(s.m1[li], in, w.H[li], params_at(p, L.mab1[li]), w.Y[li], sv1,
+                        st));                                       // modules.py:53
+    in = w.Y[li];
+  }
+  PCA_TRY(mab_f32_fwd(s.pma, p + L.S, w.Y[1], params_at(p, L.pma), w.P,
+                      training ? w.saved[4] : w.scratch, st));      // modules.py:63
+  PCA_TRY(linear_fwd_f32(w.P, p + L.wc, p + L.bc, w.logits, (int64_t)c.B * c.k, c.d, c.C,
+                         st));                                      // models.py:40
+  return PCA_OK;
+}
+
+}  // namespace
+}  // namespace pca
+
+extern "C" {
+
+int64_t pca_st_param_count(const pca_st_config* c) {
+  if (pca::validate(c) != PCA_OK) return -1;
+  return pca::layout(*c).total;
+}
+
+int64_t pca_st_bucket_split(const pca_st_config* c) {
+  if (pca::validate(c) != PCA_OK) return -1;
+  return pca::layout(*c).enc1_begin;
+}
+
+size_t pca_st_ws_bytes(const pca_st_config* c, int training) {
+  if (pca::validate(c) != PCA_OK) return 0;
+  return pca::carve(*c, training, nullptr, nullptr);
+}
+
+int pca_st_forward(const pca_st_config* c, const float* params, const float* X,
+                   float* logits, void* ws, void* stream) {
+  PCA_TRY(pca::validate(c));
+  PCA_REQUIRE(params && X && logits && ws, "st_forward: null pointer");
+  hipStream_t st = pca::as_stream(stream);
+  pca::Ws w;
+  pca::carve(*c, 0, &w, ws);
+  const pca::Layout L = pca::layout(*c);
+  const pca::Shapes s = pca::shapes(*c);
+  float* own = w.logits;
+  w.logits = logits;
+  (void)own;
+  return pca::forward(*c, L, s, params, X, w, false, st);
+}
+
+int pca_st_train_fwd_bwd(const pca_st_config* c, const float* params, const float* X,
+                         const int64_t* labels, float* grads, float* loss_out, float* stats,
+                         float* logits, float grad_scale, int phase, void* ws,
+                         void* stream) {
+  PCA_TRY(pca::validate(c));
+  PCA_REQUIRE(params && X && labels && grads && loss_out && ws,
+              "st_train_fwd_bwd: null pointer");
+  PCA_REQUIRE(c->k == 1, "st_train_fwd_bwd: the train step needs k == 1 (got %d)", c->k);
+  PCA_REQUIRE(phase >= -1 && phase <= 1, "st_train_fwd_bwd: phase=%d", phase);
+  hipStream_t st = pca::as_stream(stream);
+  pca::Ws w;
+  pca::carve(*c, 1, &w, ws);
+  const pca::Layout L = pca::layout(*c);
+  const pca::Shapes s = pca::shapes(*c);
+  const float* p = params;
+  float* g = grads;
+  if (logits != nullptr) w.logits = logits;
+
+  if (phase != 1) {
+    PCA_TRY(pca::forward(*c, L, s, p, X, w, true, st));
+    PCA_TRY(pca_cross_entropy(w.logits, labels, c->B, c->C, grad_scale, loss_out, w.dlogits,
+                              stats, stream));
+    // dec.1 (Linear), dec.0 (PMA)
+    PCA_TRY(pca::linear_bwd_f32(w.P, p + L.wc, w.dlogits, w.dP, g + L.wc, g + L.bc,
+                                (int64_t)c->B, c->d, c->C, st));
+    PCA_TRY(pca::mab_f32_bwd(s.pma, p + L.S, w.Y[1], pca::params_at(p, L.pma), w.saved[4],
+                             w.dP, g + L.S, w.dY2, 0, pca::grads_at(g, L.pma), w.scratch,
+                             st));
+    // enc.1: mab1(Y1, H2) then mab0(I2, Y1); Y1 feeds both, so dY1 accumulates
+    PCA_TRY(pca::mab_f32_bwd(s.m1[1], w.Y[0], w.H[1], pca::params_at(p, L.mab1[1]),
+                             w.saved[3], w.dY2, w.dY1, w.dH, 0, pca::grads_at(g, L.mab1[1]),
+                             w.scratch, st));
+    PCA_TRY(pca::mab_f32_bwd(s.m0[1], p + L.I[1], w.Y[0], pca::params_at(p, L.mab0[1]),
+                             w.saved[2], w.dH, g + L.I[1], w.dY1, 1,
+                             pca::grads_at(g, L.mab0[1]), w.scratch, st));
+  }
+  if (phase != 0) {
+    // enc.0: the set itself needs no gradient
+    PCA_TRY(pca::mab_f32_bwd(s.m1[0], X, w.H[0], pca::params_at(p, L.mab1[0]), w.saved[1],
+                             w.dY1, nullptr, w.dH, 0, pca::grads_at(g, L.mab1[0]),
+                             w.scratch, st));
+    PCA_TRY(pca::mab_f32_bwd(s.m0[0], p + L.I[0], X, pca::params_at(p, L.mab0[0]),
+                             w.saved[0], w.dH, g + L.I[0], nullptr, 0,
+                             pca::grads_at(g, L.mab0[0]), w.scratch, st));
+  }
+  return PCA_OK;
+}
+}

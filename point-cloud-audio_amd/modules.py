@@ -1,0 +1,91 @@
+"""Set-attention blocks on MI355X: drop-in for ``set_transformer-master/modules.py``.
+
+Same class names, constructor signatures, sub-module / parameter names and state_dict
+layout as the reference (modules.py:6-63), so ``from modules import ISAB, PMA, SAB``
+(Code/models.py:10) and the shipped checkpoints keep working.  The arithmetic of
+``MAB.forward`` (modules.py:19-33) runs in libpca_hip.so; nothing here falls back to
+PyTorch ops or to the CPU.
+
+Differences a caller can observe:
+  * tensors must live on a HIP device ('cuda'); a CPU tensor raises PcaHipError;
+  * ``ln=True`` (never enabled by any reference caller, Code/models.py:31) raises
+    NotImplementedError at construction;
+  * ISAB / PMA do not materialise ``I.repeat(B,1,1)`` / ``S.repeat(B,1,1)``
+    (modules.py:52,63): the learned query is projected once and shared by all sets.
+"""
+import torch
+import torch.nn as nn
+
+import pca_hip
+
+__all__ = ["MAB", "SAB", "ISAB", "PMA"]
+
+
+class MAB(nn.Module):
+    """Multihead attention block, reference modules.py:6-33."""
+
+    def __init__(self, dim_Q, dim_K, dim_V, num_heads, ln=False):
+        super().__init__()
+        if ln:
+            raise NotImplementedError(
+                "MAB(ln=True): LayerNorm variants are not built in the HIP path "
+                "(no caller in the reference enables them)")
+        if dim_V % num_heads != 0:
+            raise ValueError(f"dim_V={dim_V} must be divisible by num_heads={num_heads}")
+        self.dim_V = dim_V
+        self.num_heads = num_heads
+        self.fc_q = nn.Linear(dim_Q, dim_V)
+        self.fc_k = nn.Linear(dim_K, dim_V)
+        self.fc_v = nn.Linear(dim_K, dim_V)
+        self.fc_o = nn.Linear(dim_V, dim_V)
+
+    def _params(self):
+        return (self.fc_q.weight, self.fc_q.bias, self.fc_k.weight, self.fc_k.bias,
+                self.fc_v.weight, self.fc_v.bias, self.fc_o.weight, self.fc_o.bias)
+
+    def forward(self, Q, K, q_shared=False):
+        """Q [B,nq,dim_Q] (or the shared learned query [1,nq,dim_Q] with q_shared),
+        K [B,nk,dim_K] -> [B,nq,dim_V]."""
+        if torch.is_grad_enabled() and (
+                Q.requires_grad or K.requires_grad or self.fc_q.weight.requires_grad):
+            return pca_hip.mab(Q, K, *self._params(), self.num_heads, q_shared)
+        return pca_hip.mab_infer(Q, K, self._params(), self.num_heads, q_shared)
+
+
+class SAB(nn.Module):
+    """Self-attention block MAB(X, X), reference modules.py:35-41."""
+
+    def __init__(self, dim_in, dim_out, num_heads, ln=False):
+        super().__init__()
+        self.mab = MAB(dim_in, dim_in, dim_out, num_heads, ln=ln)
+
+    def forward(self, X):
+        return self.mab(X, X)
+
+
+class ISAB(nn.Module):
+    """Induced set-attention block, reference modules.py:43-53."""
+
+    def __init__(self, dim_in, dim_out, num_heads, num_inds, ln=False):
+        super().__init__()
+        self.I = nn.Parameter(torch.empty(1, num_inds, dim_out))
+        nn.init.xavier_uniform_(self.I)
+        self.mab0 = MAB(dim_out, dim_in, dim_out, num_heads, ln=ln)
+        self.mab1 = MAB(dim_in, dim_out, dim_out, num_heads, ln=ln)
+
+    def forward(self, X):
+        H = self.mab0(self.I, X, q_shared=True)     # [B, m, d]
+        return self.mab1(X, H)
+
+
+class PMA(nn.Module):
+    """Pooling by multihead attention, reference modules.py:55-63."""
+
+    def __init__(self, dim, num_heads, num_seeds, ln=False):
+        super().__init__()
+        self.S = nn.Parameter(torch.empty(1, num_seeds, dim))
+        nn.init.xavier_uniform_(self.S)
+        self.mab = MAB(dim, dim, dim, num_heads, ln=ln)
+
+    def forward(self, X):
+        return self.mab(self.S, X, q_shared=True)

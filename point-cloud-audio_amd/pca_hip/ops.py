@@ -1,0 +1,282 @@
+"""torch.autograd glue over the C ABI: device pointers and the current HIP stream are the
+only things that cross the boundary (no torch types in the library).
+
+PyTorch is plumbing here -- it owns device memory and streams; all arithmetic of the hot
+path runs in libpca_hip.so.
+"""
+from __future__ import annotations
+
+import ctypes as C
+from typing import Optional, Tuple
+
+import torch
+
+from . import _lib
+from ._lib import MabGrads, MabParams, MabShape, check, lib
+
+_MODE = "f32"           # "f32" | "bf16" | "auto"
+
+
+def set_mode(mode: str) -> None:
+    """Arithmetic mode of MAB blocks: 'f32' = exact fp32 kernels (parity mode),
+    'bf16' = bf16 MFMA operands with fp32 accumulate/softmax (fails for shapes the fused
+    kernels do not cover), 'auto' = bf16 where covered, else f32."""
+    global _MODE
+    if mode not in ("f32", "bf16", "auto"):
+        raise ValueError(mode)
+    _MODE = mode
+
+
+def get_mode() -> str:
+    return _MODE
+
+
+def _stream(t: torch.Tensor) -> C.c_void_p:
+    return C.c_void_p(torch.cuda.current_stream(t.device).cuda_stream)
+
+
+def _ptr(t: Optional[torch.Tensor]) -> C.c_void_p:
+    return C.c_void_p(0 if t is None else t.data_ptr())
+
+
+def _need_cuda(*ts: torch.Tensor) -> None:
+    for t in ts:
+        if t is not None and not t.is_cuda:
+            raise _lib.PcaHipError(
+                "point-cloud-audio_amd runs on MI355X only: got a CPU tensor "
+                "(move the module and its inputs to 'cuda'; there is no CPU fallback)")
+
+
+def _f32c(t: torch.Tensor) -> torch.Tensor:
+    if t.dtype != torch.float32:
+        t = t.float()
+    return t.contiguous()
+
+
+def _bytes(n: int, like: torch.Tensor) -> torch.Tensor:
+    return torch.empty(max(int(n), 256), dtype=torch.uint8, device=like.device)
+
+
+def _shape(B, nq, nk, dq, dk, d, h, q_shared, mode=_lib.MODE_F32) -> MabShape:
+    return MabShape(B, nq, nk, dq, dk, d, h, int(q_shared), mode, _lib.PCA_F32,
+                    _lib.PCA_F32, _lib.PCA_F32)
+
+
+class _MabFn(torch.autograd.Function):
+    """set_transformer-master/modules.py:19-33 MAB.forward + its adjoint."""
+
+    @staticmethod
+    def forward(ctx, Q, K, wq, bq, wk, bk, wv, bv, wo, bo, num_heads: int, q_shared: bool):
+        _need_cuda(Q, K, wq)
+        Q, K = _f32c(Q), _f32c(K)
+        params = [_f32c(p) for p in (wq, bq, wk, bk, wv, bv, wo, bo)]
+        B, nk, dk = K.shape
+        if q_shared:
+            nq, dq = Q.shape[-2], Q.shape[-1]
+        else:
+            if Q.shape[0] != B:
+                raise RuntimeError(f"MAB: batch mismatch Q {tuple(Q.shape)} K {tuple(K.shape)}")
+            nq, dq = Q.shape[1], Q.shape[2]
+        d = params[0].shape[0]
+        if params[0].shape[1] != dq or params[2].shape[1] != dk:
+            raise RuntimeError("MAB: input width does not match fc_q / fc_k")
+        s = _shape(B, nq, nk, dq, dk, d, num_heads, q_shared)
+        L = lib()
+        with torch.cuda.device(K.device):
+            Y = torch.empty((B, nq, d), dtype=torch.float32, device=K.device)
+            saved = _bytes(L.pca_mab_saved_bytes(C.byref(s)), K)
+            pp = MabParams(*[_ptr(p) for p in params])
+            check(L.pca_mab_fwd(C.byref(s), _ptr(Q), _ptr(K), C.byref(pp), _ptr(Y),
+                                _ptr(saved), None, _stream(K)), "pca_mab_fwd")
+        ctx.s = s
+        ctx.save_for_backward(Q, K, saved, *params)
+        return Y
+
+    @staticmethod
+    def backward(ctx, dY):
+        Q, K, saved, *params = ctx.saved_tensors
+        s = ctx.s
+        L = lib()
+        dY = _f32c(dY)
+        need_dq, need_dk = ctx.needs_input_grad[0], ctx.needs_input_grad[1]
+        with torch.cuda.device(K.device):
+            sizes = [p.numel() for p in params]
+            flat = torch.zeros(sum(sizes), dtype=torch.float32, device=K.device)
+            gviews = list(torch.split(flat, sizes))
+            gg = MabGrads(*[_ptr(g) for g in gviews])
+            pp = MabParams(*[_ptr(p) for p in params])
+            dQ = dK = None
+            if need_dq:
+                dQ = (torch.zeros_like(Q) if s.q_shared else torch.empty_like(Q))
+            if need_dk:
+                dK = torch.empty_like(K)
+            ws = _bytes(L.pca_mab_bwd_ws_bytes(C.byref(s)), K)
+            check(L.pca_mab_bwd(C.byref(s), _ptr(Q), _ptr(K), C.byref(pp), _ptr(saved),
+                                _ptr(dY), _ptr(dQ), _ptr(dK), 0, C.byref(gg), _ptr(ws),
+                                _stream(K)), "pca_mab_bwd")
+        grads = [g.view_as(p) for g, p in zip(gviews, params)]
+        return (dQ, dK, *grads, None, None)
+
+
+def mab(Q, K, wq, bq, wk, bk, wv, bv, wo, bo, num_heads: int, q_shared: bool = False):
+    return _MabFn.apply(Q, K, wq, bq, wk, bk, wv, bv, wo, bo, num_heads, q_shared)
+
+
+def mab_infer(Q, K, params, num_heads: int, q_shared: bool = False) -> torch.Tensor:
+    """Forward only, nothing saved (used under torch.no_grad())."""
+    _need_cuda(Q, K)
+    Q, K = _f32c(Q), _f32c(K)
+    params = [_f32c(p) for p in params]
+    B, nk, dk = K.shape
+    nq, dq = Q.shape[-2], Q.shape[-1]
+    d = params[0].shape[0]
+    s = _shape(B, nq, nk, dq, dk, d, num_heads, q_shared)
+    L = lib()
+    with torch.cuda.device(K.device):
+        Y = torch.empty((B, nq, d), dtype=torch.float32, device=K.device)
+        ws = _bytes(L.pca_mab_fwd_ws_bytes(C.byref(s)), K)
+        pp = MabParams(*[_ptr(p) for p in params])
+        check(L.pca_mab_fwd(C.byref(s), _ptr(Q), _ptr(K), C.byref(pp), _ptr(Y), None,
+                            _ptr(ws), _stream(K)), "pca_mab_fwd")
+    return Y
+
+
+class _LinearFn(torch.autograd.Function):
+    """nn.Linear (Code/models.py:40) on the library's GEMM."""
+
+    @staticmethod
+    def forward(ctx, X, W, b):
+        _need_cuda(X, W, b)
+        X, W, b = _f32c(X), _f32c(W), _f32c(b)
+        lead = X.shape[:-1]
+        M = X.numel() // X.shape[-1]
+        with torch.cuda.device(X.device):
+            Y = torch.empty((*lead, W.shape[0]), dtype=torch.float32, device=X.device)
+            check(lib().pca_linear_fwd(_ptr(X), _ptr(W), _ptr(b), _ptr(Y), M, W.shape[1],
+                                       W.shape[0], _stream(X)), "pca_linear_fwd")
+        ctx.save_for_backward(X, W)
+        return Y
+
+    @staticmethod
+    def backward(ctx, dY):
+        X, W = ctx.saved_tensors
+        dY = _f32c(dY)
+        M = X.numel() // X.shape[-1]
+        with torch.cuda.device(X.device):
+            dX = torch.empty_like(X) if ctx.needs_input_grad[0] else None
+            dW = torch.zeros_like(W)
+            db = torch.zeros(W.shape[0], dtype=torch.float32, device=X.device)
+            check(lib().pca_linear_bwd(_ptr(X), _ptr(W), _ptr(dY), _ptr(dX), _ptr(dW),
+                                       _ptr(db), M, W.shape[1], W.shape[0], None,
+                                       _stream(X)), "pca_linear_bwd")
+        return dX, dW, db
+
+
+def linear(X, W, b):
+    return _LinearFn.apply(X, W, b)
+
+
+class _CrossEntropyFn(torch.autograd.Function):
+    """nn.CrossEntropyLoss() (mean), Code/settransformer.py:88,104."""
+
+    @staticmethod
+    def forward(ctx, logits, labels):
+        _need_cuda(logits, labels)
+        logits = _f32c(logits)
+        labels = labels.to(torch.int64).contiguous()
+        B, Cc = logits.shape
+        with torch.cuda.device(logits.device):
+            loss = torch.empty(1, dtype=torch.float32, device=logits.device)
+            dlog = torch.empty_like(logits)
+            check(lib().pca_cross_entropy(_ptr(logits), _ptr(labels), B, Cc, 1.0, _ptr(loss),
+                                          _ptr(dlog), None, _stream(logits)),
+                  "pca_cross_entropy")
+        ctx.save_for_backward(dlog)
+        return loss.squeeze(0)
+
+    @staticmethod
+    def backward(ctx, g):
+        (dlog,) = ctx.saved_tensors
+        return dlog * g, None
+
+
+def cross_entropy(logits, labels):
+    return _CrossEntropyFn.apply(logits, labels)
+
+
+# --------------------------------------------------------------------------- #
+# feature extraction                                                           #
+# --------------------------------------------------------------------------- #
+def stft_logmag(wave: torch.Tensor, n_fft: int, win_length: Optional[int] = None,
+                hop: Optional[int] = None, drop_nyquist: bool = False,
+                frame_major: bool = False) -> torch.Tensor:
+    """log(1e-8 + |stft|/n_fft) of a 1-D float32 device waveform.
+    Returns [F, T] (reference layout) or, with frame_major, [T, F] (each frame -- one
+    2-D point set -- contiguous, the layout the packers read coalesced)."""
+    _need_cuda(wave)
+    wave = _f32c(wave)
+    win_length = n_fft if win_length is None else win_length
+    hop = n_fft // 2 if hop is None else hop
+    L = lib()
+    T = L.pca_stft_num_frames(wave.numel(), hop)
+    F = n_fft // 2 if drop_nyquist else n_fft // 2 + 1
+    with torch.cuda.device(wave.device):
+        if frame_major:
+            out = torch.empty((T, F), dtype=torch.float32, device=wave.device)
+            sf, st = 1, F
+        else:
+            out = torch.empty((F, T), dtype=torch.float32, device=wave.device)
+            sf, st = T, 1
+        check(L.pca_stft_logmag(_ptr(wave), wave.numel(), n_fft, win_length, hop, F,
+                                _ptr(out), sf, st, _stream(wave)), "pca_stft_logmag")
+    return out
+
+
+def pack_points_2d(spec: torch.Tensor, farr: torch.Tensor, idx: torch.Tensor,
+                   labels: Optional[torch.Tensor] = None, frame_major: bool = False,
+                   out: Optional[torch.Tensor] = None, labels_out: Optional[torch.Tensor] = None
+                   ) -> Tuple[torch.Tensor, Optional[torch.Tensor]]:
+    """Batch of ESC_pc items: spec [F,T] (or [T,F] frame_major), idx int64[B] ->
+    ([B,F,2] float32, labels[idx])."""
+    _need_cuda(spec, farr, idx)
+    assert spec.dtype == torch.float32 and farr.dtype == torch.float32
+    assert idx.dtype == torch.int64
+    if frame_major:
+        T, F = spec.shape
+        sf, st = spec.stride(1), spec.stride(0)
+    else:
+        F, T = spec.shape
+        sf, st = spec.stride(0), spec.stride(1)
+    B = idx.numel()
+    with torch.cuda.device(spec.device):
+        if out is None:
+            out = torch.empty((B, F, 2), dtype=torch.float32, device=spec.device)
+        if labels is not None and labels_out is None:
+            labels_out = torch.empty(B, dtype=torch.int64, device=spec.device)
+        check(lib().pca_pack_points_2d(_ptr(spec), sf, st, _ptr(farr), _ptr(idx), B, F,
+                                       _ptr(out), _ptr(labels), _ptr(labels_out),
+                                       _stream(spec)), "pca_pack_points_2d")
+    return out, labels_out
+
+
+def pack_points_3d(spec: torch.Tensor, farr: torch.Tensor, tarr: torch.Tensor,
+                   idx: torch.Tensor, labels: Optional[torch.Tensor] = None,
+                   out: Optional[torch.Tensor] = None,
+                   labels_out: Optional[torch.Tensor] = None
+                   ) -> Tuple[torch.Tensor, Optional[torch.Tensor]]:
+    """Batch of ESC_pc_temp items: spec indexed [f, t, s] through its strides (any
+    layout), idx int64[B] -> ([B, Nt*F, 3] float32, labels[idx])."""
+    _need_cuda(spec, farr, tarr, idx)
+    assert spec.dtype == torch.float32 and idx.dtype == torch.int64
+    F, Nt, S = spec.shape
+    B = idx.numel()
+    with torch.cuda.device(spec.device):
+        if out is None:
+            out = torch.empty((B, F * Nt, 3), dtype=torch.float32, device=spec.device)
+        if labels is not None and labels_out is None:
+            labels_out = torch.empty(B, dtype=torch.int64, device=spec.device)
+        check(lib().pca_pack_points_3d(_ptr(spec), spec.stride(0), spec.stride(1),
+                                       spec.stride(2), _ptr(farr), _ptr(tarr), _ptr(idx), B,
+                                       F, Nt, _ptr(out), _ptr(labels), _ptr(labels_out),
+                                       _stream(spec)), "pca_pack_points_3d")
+    return out, labels_out

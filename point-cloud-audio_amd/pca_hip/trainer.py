@@ -1,0 +1,271 @@
+"""Train / eval engine for the ST classifier on MI355X.
+
+Replaces the training loop of Code/settransformer.py:96-112 (and settransformertemp.py):
+``DataLoader -> .to(device) -> nn.DataParallel(model)(imgs) -> CrossEntropyLoss -> backward ->
+Adam.step -> .item()`` becomes, per step and per GPU,
+
+    [pack batch] -> pca_st_train_fwd_bwd(phase 0) -> all-reduce(bucket enc.1+dec)
+                 -> pca_st_train_fwd_bwd(phase 1) -> all-reduce(bucket enc.0) -> pca_adam_step
+
+* one process per GPU; parameters, gradients and Adam moments are flat fp32 vectors in
+  state_dict order, so the all-reduce is over two contiguous buckets and the optimiser is
+  one fused kernel; the nn.Module's parameters are views of the flat vector;
+* the device work of a step is captured once into hipGraphs (torch.cuda.CUDAGraph) and
+  replayed, so no Python / autograd / allocator work sits between kernels;
+* nn.DataParallel (Code/settransformer.py:94: single process, per-step parameter broadcast,
+  scatter and gather) is replaced by an RCCL all-reduce of gradients (torch.distributed
+  backend 'nccl' over xGMI) on a side stream, overlapped with the enc.0 backward;
+* loss / accuracy are accumulated on the device and read once per epoch instead of the
+  two ``.item()`` host syncs per step of Code/settransformer.py:110-112.
+"""
+from __future__ import annotations
+
+import ctypes as C
+from typing import Optional, Tuple
+
+import torch
+import torch.distributed as dist
+
+from . import _lib
+from ._lib import StConfig, check, lib
+from .ops import _need_cuda
+
+
+def st_config(model, B: int, N: int, mode: int = _lib.MODE_F32) -> StConfig:
+    """Read the architecture off an ``models.ST`` instance."""
+    isab0 = model.enc[0]
+    d = isab0.mab0.dim_V
+    return StConfig(B, N, isab0.mab1.fc_q.in_features, d, isab0.mab0.num_heads,
+                    isab0.I.shape[1], model.dec[0].S.shape[1],
+                    model.dec[1].out_features, mode)
+
+
+def flatten_parameters(model) -> torch.Tensor:
+    """Re-home every parameter of ``model`` as a view of ONE flat fp32 vector (state_dict
+    order, the layout pca_st_* expects) and return that vector.  Idempotent: a model that
+    is already flat keeps its vector (so several engines can share one model)."""
+    params = list(model.parameters())
+    names = [n for n, _ in model.named_parameters()]
+    assert names == list(model.state_dict().keys()), "unexpected parameter order"
+    flat = getattr(model, "_pca_flat", None)
+    if flat is not None:
+        off, ok = 0, True
+        for p in params:
+            ok = ok and p.data_ptr() == flat.data_ptr() + 4 * off and p.is_contiguous()
+            off += p.numel()
+        if ok and off == flat.numel():
+            return flat
+    flat = torch.cat([p.detach().reshape(-1).float() for p in params]).contiguous()
+    off = 0
+    for p in params:
+        n = p.numel()
+        p.data = flat[off:off + n].view_as(p)
+        off += n
+    object.__setattr__(model, "_pca_flat", flat)
+    return flat
+
+
+class STEngine:
+    """Forward / train-step of an ``models.ST`` through the pca_st_* entry points."""
+
+    def __init__(self, model, B: int, N: int, mode: int = _lib.MODE_F32, training: bool = True):
+        self.model = model
+        self.flat = flatten_parameters(model)
+        _need_cuda(self.flat)
+        self.dev = self.flat.device
+        self.cfg = st_config(model, B, N, mode)
+        L = lib()
+        n = L.pca_st_param_count(C.byref(self.cfg))
+        if n != self.flat.numel():
+            raise _lib.PcaHipError(f"parameter count mismatch: engine {n}, model "
+                                   f"{self.flat.numel()}: {L.pca_last_error()}")
+        self.split = int(L.pca_st_bucket_split(C.byref(self.cfg)))
+        self.training = training
+        with torch.cuda.device(self.dev):
+            self.ws = torch.empty(L.pca_st_ws_bytes(C.byref(self.cfg), int(training)),
+                                  dtype=torch.uint8, device=self.dev)
+            self.logits = torch.empty((B * self.cfg.k, self.cfg.C), dtype=torch.float32,
+                                      device=self.dev)
+            if training:
+                self.grads = torch.zeros_like(self.flat)
+                self.loss = torch.zeros(1, dtype=torch.float32, device=self.dev)
+                self.stats = torch.zeros(2, dtype=torch.float32, device=self.dev)
+
+    def _stream(self):
+        return C.c_void_p(torch.cuda.current_stream(self.dev).cuda_stream)
+
+    def forward(self, X: torch.Tensor) -> torch.Tensor:
+        assert X.is_cuda and X.dtype == torch.float32 and X.is_contiguous()
+        assert tuple(X.shape) == (self.cfg.B, self.cfg.N, self.cfg.din), X.shape
+        check(lib().pca_st_forward(C.byref(self.cfg), self.flat.data_ptr(), X.data_ptr(),
+                                   self.logits.data_ptr(), self.ws.data_ptr(), self._stream()),
+              "pca_st_forward")
+        return self.logits
+
+    def fwd_bwd(self, X: torch.Tensor, labels: torch.Tensor, phase: int = -1,
+                grad_scale: float = 1.0) -> None:
+        check(lib().pca_st_train_fwd_bwd(C.byref(self.cfg), self.flat.data_ptr(), X.data_ptr(),
+                                         labels.data_ptr(), self.grads.data_ptr(),
+                                         self.loss.data_ptr(), self.stats.data_ptr(),
+                                         self.logits.data_ptr(), grad_scale, phase,
+                                         self.ws.data_ptr(), self._stream()),
+              "pca_st_train_fwd_bwd")
+
+
+class Trainer:
+    """Data-parallel trainer: one instance per process / GPU.
+
+    dataset   object with ``batch(idx, out=, labels_out=)`` (dataset.ESC_pc / ESC_pc_temp)
+    The step consumes ``batch_size`` sets per GPU; indices come from a per-epoch device
+    permutation (rank r takes r::world, DistributedSampler semantics).
+    """
+
+    def __init__(self, model, dataset, batch_size: int, lr: float = 1e-3,
+                 weight_decay: float = 1e-3, betas=(0.9, 0.999), eps: float = 1e-8,
+                 mode: int = _lib.MODE_F32, use_graph: bool = True, seed: int = 0,
+                 shuffle: bool = True, process_group=None):
+        self.ds = dataset
+        self.B = int(batch_size)
+        self.N = int(dataset.num_points)
+        self.eng = STEngine(model, self.B, self.N, mode, training=True)
+        self.dev = self.eng.dev
+        self.lr, self.wd, self.betas, self.eps = lr, weight_decay, betas, eps
+        self.pg = process_group
+        self.world = dist.get_world_size(process_group) if dist.is_initialized() else 1
+        self.rank = dist.get_rank(process_group) if dist.is_initialized() else 0
+        self.seed = seed
+        self.shuffle = shuffle
+        self.use_graph = use_graph
+        n = self.eng.flat.numel()
+        with torch.cuda.device(self.dev):
+            self.m = torch.zeros(n, dtype=torch.float32, device=self.dev)
+            self.v = torch.zeros(n, dtype=torch.float32, device=self.dev)
+            self.step_count = torch.zeros(1, dtype=torch.int32, device=self.dev)
+            self.idx = torch.zeros(self.B, dtype=torch.int64, device=self.dev)
+            self.X = torch.empty((self.B, self.N, self.eng.cfg.din), dtype=torch.float32,
+                                 device=self.dev)
+            self.labels = torch.zeros(self.B, dtype=torch.int64, device=self.dev)
+            self.comm_stream = torch.cuda.Stream(self.dev) if self.world > 1 else None
+        self.g0 = self.g1 = self.g2 = None
+        self.epoch = 0
+        self._perm = None
+        self._cursor = 0
+        if self.world > 1:      # identical initial weights on every rank (rank 0's)
+            dist.broadcast(self.eng.flat, src=0, group=self.pg)
+
+    # ---- index stream ------------------------------------------------------------
+    def _next_indices(self) -> torch.Tensor:
+        per = len(self.ds) // self.world
+        if self._perm is None or self._cursor + self.B > per:
+            if self.shuffle:
+                g = torch.Generator(device="cpu").manual_seed(self.seed + self.epoch)
+                perm = torch.randperm(len(self.ds), generator=g).to(self.dev)
+            else:
+                perm = torch.arange(len(self.ds), device=self.dev)
+            self._perm = perm[self.rank:per * self.world:self.world].contiguous()
+            self._cursor = 0
+            self.epoch += 1
+        out = self._perm[self._cursor:self._cursor + self.B]
+        self._cursor += self.B
+        return out
+
+    # ---- the three device segments of a step ---------------------------------------
+    def _seg0(self):     # pack + zero grads + forward + loss + backward(dec, enc.1)
+        self.ds.batch(self.idx, out=self.X, labels_out=self.labels)
+        self.eng.grads.zero_()
+        self.eng.fwd_bwd(self.X, self.labels, phase=0)
+
+    def _seg1(self):     # backward(enc.0)
+        self.eng.fwd_bwd(self.X, self.labels, phase=1)
+
+    def _seg2(self):     # Adam over the flat vector
+        e = self.eng
+        check(lib().pca_adam_step(e.flat.data_ptr(), e.grads.data_ptr(), self.m.data_ptr(),
+                                  self.v.data_ptr(), e.flat.numel(), self.lr, self.betas[0],
+                                  self.betas[1], self.eps, self.wd, 1.0 / self.world,
+                                  self.step_count.data_ptr(), e._stream()), "pca_adam_step")
+
+    def _capture(self):
+        """Warm up eagerly on a side stream, then capture the segments."""
+        s = torch.cuda.Stream(self.dev)
+        s.wait_stream(torch.cuda.current_stream(self.dev))
+        snap = (self.eng.flat.clone(), self.m.clone(), self.v.clone(),
+                self.step_count.clone(), self.eng.stats.clone())
+        with torch.cuda.stream(s):
+            self._seg0(); self._seg1(); self._seg2()
+        torch.cuda.current_stream(self.dev).wait_stream(s)
+        torch.cuda.synchronize(self.dev)
+        for dst, src in zip((self.eng.flat, self.m, self.v, self.step_count, self.eng.stats),
+                            snap):
+            dst.copy_(src)
+        if self.world == 1:
+            self.g0 = torch.cuda.CUDAGraph()
+            with torch.cuda.graph(self.g0):
+                self._seg0(); self._seg1(); self._seg2()
+        else:
+            self.g0, self.g1, self.g2 = (torch.cuda.CUDAGraph() for _ in range(3))
+            with torch.cuda.graph(self.g0):
+                self._seg0()
+            with torch.cuda.graph(self.g1, pool=self.g0.pool()):
+                self._seg1()
+            with torch.cuda.graph(self.g2, pool=self.g0.pool()):
+                self._seg2()
+        for dst, src in zip((self.eng.flat, self.m, self.v, self.step_count, self.eng.stats),
+                            snap):
+            dst.copy_(src)
+
+    def step(self) -> None:
+        """One optimiser step; enqueues only (no host sync)."""
+        self.idx.copy_(self._next_indices(), non_blocking=True)
+        if self.use_graph and self.g0 is None:
+            self._capture()
+        main = torch.cuda.current_stream(self.dev)
+        if self.world == 1:
+            if self.use_graph:
+                self.g0.replay()
+            else:
+                self._seg0(); self._seg1(); self._seg2()
+            return
+        e = self.eng
+        self.g0.replay() if self.use_graph else self._seg0()
+        # bucket A (enc.1 + dec) is final: reduce it while enc.0's backward runs
+        self.comm_stream.wait_stream(main)
+        with torch.cuda.stream(self.comm_stream):
+            dist.all_reduce(e.grads[e.split:], group=self.pg)
+        self.g1.replay() if self.use_graph else self._seg1()
+        dist.all_reduce(e.grads[:e.split], group=self.pg)
+        main.wait_stream(self.comm_stream)
+        self.g2.replay() if self.use_graph else self._seg2()
+
+    # ---- epoch statistics ------------------------------------------------------------
+    def read_stats(self, reset: bool = True) -> Tuple[float, float]:
+        """(sum of per-sample losses, number of correct predictions) since the last reset,
+        summed over ranks.  One host sync."""
+        st = self.eng.stats.clone()
+        if self.world > 1:
+            dist.all_reduce(st, group=self.pg)
+        out = st.cpu().tolist()
+        if reset:
+            self.eng.stats.zero_()
+        return float(out[0]), float(out[1])
+
+
+@torch.no_grad()
+def evaluate(model, dataset, batch_size: int, mode: int = _lib.MODE_F32
+             ) -> Tuple[float, int]:
+    """Accuracy over ``dataset`` in order (full batches through the engine, the tail through
+    a second engine sized for it).  Returns (accuracy, n)."""
+    n = len(dataset)
+    dev = next(model.parameters()).device
+    correct = torch.zeros((), dtype=torch.int64, device=dev)
+    done = 0
+    while done < n:
+        b = min(batch_size, n - done)
+        eng = STEngine(model, b, dataset.num_points, mode, training=False)
+        while done + b <= n:
+            idx = torch.arange(done, done + b, device=dev)
+            X, lab = dataset.batch(idx)
+            logits = eng.forward(X)
+            correct += (logits.argmax(1) == lab).sum()
+            done += b
+    return float(correct) / max(n, 1), n

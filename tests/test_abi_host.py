@@ -1,0 +1,85 @@
+"""CPU-side checks: the C-ABI library loads and exports every symbol include/pca_hip.h
+declares; host logic (module surface, state_dict layout, loaders) without any compute."""
+import ctypes
+import os
+import re
+
+import numpy as np
+import pytest
+import torch
+
+from conftest import ROOT
+
+import pca_hip
+from pca_hip import _lib
+
+
+def header_symbols():
+    txt = open(os.path.join(ROOT, "include", "pca_hip.h")).read()
+    txt = re.sub(r"/\*.*?\*/", "", txt, flags=re.S)
+    return sorted(set(re.findall(r"\b(pca_[a-z0-9_]+)\s*\(", txt)))
+
+
+def test_library_exports_every_declared_symbol():
+    syms = header_symbols()
+    assert len(syms) >= 20
+    handle = ctypes.CDLL(_lib.LIB_PATH)
+    for s in syms:
+        assert hasattr(handle, s), f"{s} declared in pca_hip.h but not exported"
+    assert sorted(_lib.SIGNATURES) == syms, "python binding and header disagree"
+    L = pca_hip.lib()
+    assert L.pca_abi_version() == 1
+    assert L.pca_stft_num_frames(220500, 512) == 431
+    assert L.pca_stft_num_frames(220500, 1024) == 216
+
+
+def test_shape_queries_and_errors_without_gpu():
+    L = pca_hip.lib()
+    s = _lib.MabShape(4, 16, 512, 128, 128, 128, 4, 1, 0, 0, 0, 0)
+    n = L.pca_mab_saved_bytes(ctypes.byref(s))
+    # Qp[16,128] + Kp,Vp[4,512,128]*2 + A[4,4,16,512] + O,Z[4,16,128]*2 floats
+    assert n >= 4 * (16 * 128 + 2 * 4 * 512 * 128 + 4 * 4 * 16 * 512 + 2 * 4 * 16 * 128)
+    bad = _lib.MabShape(4, 16, 512, 128, 128, 130, 4, 1, 0, 0, 0, 0)   # d % h != 0
+    assert L.pca_mab_saved_bytes(ctypes.byref(bad)) == 0
+    rc = L.pca_mab_fwd(ctypes.byref(bad), None, None, None, None, None, None, None)
+    assert rc == -1 and b"divisible" in L.pca_last_error()
+    rc = L.pca_stft_logmag(None, 1000, 1000, 1000, 500, 501, None, 1, 1, None)
+    assert rc == -1
+
+
+def test_module_surface_matches_reference():
+    import models
+    import modules
+    net = models.ST(dim_input=3, dim_hidden=64, num_heads=8, num_inds=64, dim_output=10)
+    keys = list(net.state_dict().keys())
+    assert len(keys) == 45
+    from oracle import st_oracle as orc
+    assert keys == [k for k, _ in orc.st_param_shapes(3, 1, 10, 64, 64)]
+    for (k, shp), v in zip(orc.st_param_shapes(3, 1, 10, 64, 64), net.state_dict().values()):
+        assert tuple(v.shape) == shp, k
+    assert sum(p.numel() for p in net.parameters()) == 80394
+    assert sum(p.numel() for p in models.ST(dim_hidden=64, num_heads=8, num_inds=64)
+               .parameters()) == 80202
+    for name in ("MAB", "SAB", "ISAB", "PMA"):
+        assert hasattr(modules, name)
+    with pytest.raises(NotImplementedError):
+        modules.MAB(4, 4, 4, 2, ln=True)
+    # xavier bound of I: sqrt(6/(m*d+d))
+    I = modules.ISAB(2, 64, 8, 64).I
+    assert float(I.abs().max()) <= (6.0 / (64 * 64 + 64)) ** 0.5 + 1e-6
+
+
+def test_shipped_checkpoint_loads_with_and_without_prefix(golden_ckpt):
+    import models
+    sd = {k: torch.from_numpy(v) for k, v in golden_ckpt.sub("fst/p/").items()}
+    net = torch.nn.DataParallel(models.ST(dim_hidden=64, num_heads=8, num_inds=64))
+    net.load_state_dict(sd)                                   # 'module.' prefix
+    bare = models.ST(dim_hidden=64, num_heads=8, num_inds=64)
+    bare.load_state_dict({k[7:]: v for k, v in sd.items()})
+
+
+def test_cpu_tensor_fails_loudly():
+    import models
+    net = models.ST(dim_hidden=8, num_heads=2, num_inds=4)
+    with pytest.raises(pca_hip.PcaHipError):
+        net(torch.zeros(2, 5, 2))
