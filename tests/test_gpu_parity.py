@@ -425,7 +425,7 @@ def test_trainer_full_size_graph_vs_eager_vs_oracle(dev):
         tr_e.step()
     torch.cuda.synchronize()
     assert float(tr_g.eng.grads.abs().max()) < 1e3
-    close(tr_g.eng.flat, tr_e.eng.flat, 1e-5, "graph vs eager parameters")
+    close(tr_g.eng.flat, tr_e.eng.flat, 1e-4, "graph vs eager parameters")  # split-K atomics: order noise
     sg, se = tr_g.read_stats(), tr_e.read_stats()
     assert abs(sg[0] - se[0]) < 1e-3 * se[0] and sg[1] == se[1]
 
