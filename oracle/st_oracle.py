@@ -375,3 +375,51 @@ def synth_clip(clip_id: int, cls: int, seconds: float = 5.0, fs: int = 44100
     x = x + 0.1 * noise
     x = x / (np.max(np.abs(x)) + 1e-9) * 0.9
     return x.astype(np.float32)
+
+
+# --------------------------------------------------------------------------- #
+# bf16-operand emulation of the fused MFMA kernels (PCA_MODE_BF16)              #
+# --------------------------------------------------------------------------- #
+class _RoundBF16(torch.autograd.Function):
+    """x -> float(bfloat16(x)) (round-to-nearest-even, as v_cvt_pk_bf16_f32) with a
+    straight-through gradient: the kernels' backward chain also treats the operand rounding
+    of the forward as identity."""
+
+    @staticmethod
+    def forward(ctx, x):
+        return x.to(torch.bfloat16).to(x.dtype)
+
+    @staticmethod
+    def backward(ctx, g):
+        return g
+
+
+def rb(x: Tensor) -> Tensor:
+    return _RoundBF16.apply(x)
+
+
+def mab1_forward_bf16emu(X: Tensor, H: Tensor, p: Params, num_heads: int) -> Tensor:
+    """mab_forward(X, H) with MFMA operands rounded to bf16 exactly where
+    csrc/mab1_bf16.hip rounds them and everything else (accumulation, bias, softmax,
+    residuals, ReLU) in fp32.  Being bit-faithful in the operands it reproduces the
+    kernel's ReLU mask, which a plain fp32 evaluation does not for |Z| below the bf16
+    rounding error; autograd of this function is the gradient the fused backward computes."""
+    B, nq, dq = X.shape
+    nk = H.shape[1]
+    d = p["fc_q.weight"].shape[0]
+    h = num_heads
+    dh = d // h
+    if dq <= 4:       # layer 1: exact fp32 projection on the vector ALU
+        Qp = X @ p["fc_q.weight"].t() + p["fc_q.bias"]
+    else:
+        Qp = rb(X) @ rb(p["fc_q.weight"]).t() + p["fc_q.bias"]
+    Kp = rb(_lin(H, p, "fc_k"))
+    Vp = rb(_lin(H, p, "fc_v"))
+    Qh = rb(Qp).view(B, nq, h, dh).permute(0, 2, 1, 3)
+    Kh = Kp.view(B, nk, h, dh).permute(0, 2, 1, 3)
+    Vh = Vp.view(B, nk, h, dh).permute(0, 2, 1, 3)
+    A = torch.softmax(Qh @ Kh.transpose(-1, -2) / math.sqrt(d), dim=-1)
+    Oh = Qp.view(B, nq, h, dh).permute(0, 2, 1, 3) + rb(A) @ Vh
+    O = Oh.permute(0, 2, 1, 3).reshape(B, nq, d)
+    Z = rb(O) @ rb(p["fc_o.weight"]).t() + p["fc_o.bias"]
+    return O + torch.relu(Z)

@@ -17,28 +17,83 @@ int linear_fwd_f32(const float* X, const float* W, const float* b, float* Y, int
 int linear_bwd_f32(const float* X, const float* W, const float* dY, float* dX, float* dW,
                    float* db, int64_t M, int din, int dout, hipStream_t st);
 
+bool mab1_bf16_supported(const pca_mab_shape& s);
+size_t mab1_bf16_saved_bytes(const pca_mab_shape& s);
+size_t mab1_bf16_fwd_ws_bytes(const pca_mab_shape& s);
+int mab1_bf16_fwd(const pca_mab_shape& s, const float* X, const float* H,
+                  const pca_mab_params& p, float* Y, void* saved, void* ws, hipStream_t st);
+
+size_t mab1_bf16_bwd_ws_bytes(const pca_mab_shape& s);
+int mab1_bf16_bwd(const pca_mab_shape& s, const float* X, const float* H,
+                  const pca_mab_params& p, const void* saved, const float* dY, float* dX,
+                  float* dH, int dk_accumulate, const pca_mab_grads& gr, void* ws,
+                  hipStream_t st);
+
 static int check_f32(const pca_mab_shape* s) {
   PCA_REQUIRE(s->q_dtype == PCA_F32 && s->k_dtype == PCA_F32 && s->y_dtype == PCA_F32,
-              "mab: PCA_MODE_F32 needs fp32 Q, K and Y");
+              "mab: this build exchanges fp32 Q, K and Y");
   return PCA_OK;
+}
+
+// ---- mode resolution + dispatch, shared by the C entry points and the ST engine ----
+// kind: 0 = exact fp32 chain of GEMMs, 1 = fused bf16 mab1 (many queries, few keys)
+int mab_kind(const pca_mab_shape& s) {
+  if (s.mode == PCA_MODE_BF16 && mab1_bf16_supported(s)) return 1;
+  return 0;
+}
+size_t mab_saved_bytes_any(const pca_mab_shape& s) {
+  return mab_kind(s) == 1 ? mab1_bf16_saved_bytes(s) : mab_f32_saved_bytes(s);
+}
+size_t mab_fwd_ws_bytes_any(const pca_mab_shape& s) {
+  // inference (saved == NULL) keeps the intermediates in the scratch block instead
+  return mab_kind(s) == 1 ? mab1_bf16_fwd_ws_bytes(s) : mab_f32_saved_bytes(s);
+}
+size_t mab_bwd_ws_bytes_any(const pca_mab_shape& s) {
+  return mab_kind(s) == 1 ? mab1_bf16_bwd_ws_bytes(s) : mab_f32_bwd_ws_bytes(s);
+}
+int mab_fwd_any(const pca_mab_shape& s, const float* Q, const float* K, const pca_mab_params& p,
+                float* Y, void* saved, void* ws, hipStream_t st) {
+  if (mab_kind(s) == 1) return mab1_bf16_fwd(s, Q, K, p, Y, saved, ws, st);
+  return mab_f32_fwd(s, Q, K, p, Y, saved ? saved : ws, st);
+}
+int mab_bwd_any(const pca_mab_shape& s, const float* Q, const float* K, const pca_mab_params& p,
+                const void* saved, const float* dY, float* dQ, float* dK, int dk_accumulate,
+                const pca_mab_grads& g, void* ws, hipStream_t st) {
+  if (mab_kind(s) == 1)
+    return mab1_bf16_bwd(s, Q, K, p, saved, dY, dQ, dK, dk_accumulate, g, ws, st);
+  return mab_f32_bwd(s, Q, K, p, saved, dY, dQ, dK, dk_accumulate, g, ws, st);
 }
 }  // namespace pca
 
 extern "C" {
 
+// An explicit PCA_MODE_BF16 request must be served by a fused kernel (no silent change of
+// arithmetic at this level); callers that want "bf16 where available" query
+// pca_mab_saved_bytes() first, which returns 0 for unsupported bf16 shapes.
+static int bf16_demand(const pca_mab_shape* s) {
+  if (s->mode == PCA_MODE_BF16 && pca::mab_kind(*s) != 1) {
+    pca::set_error("mab: no bf16 kernel for B=%d nq=%d nk=%d dq=%d dk=%d d=%d h=%d q_shared=%d",
+                   s->B, s->nq, s->nk, s->dq, s->dk, s->d, s->h, s->q_shared);
+    return PCA_EUNSUPPORTED;
+  }
+  if (s->mode != PCA_MODE_BF16 && s->mode != PCA_MODE_F32) {
+    pca::set_error("mab: unknown mode %d", s->mode);
+    return PCA_EINVAL;
+  }
+  return PCA_OK;
+}
+
 size_t pca_mab_saved_bytes(const pca_mab_shape* s) {
-  if (pca::validate_shape(s) != PCA_OK) return 0;
-  if (s->mode == PCA_MODE_F32) return pca::mab_f32_saved_bytes(*s);
-  return 0;
+  if (pca::validate_shape(s) != PCA_OK || bf16_demand(s) != PCA_OK) return 0;
+  return pca::mab_saved_bytes_any(*s);
 }
 size_t pca_mab_fwd_ws_bytes(const pca_mab_shape* s) {
-  // inference (saved == NULL) keeps the intermediates in the scratch block instead
-  return pca_mab_saved_bytes(s);
+  if (pca::validate_shape(s) != PCA_OK || bf16_demand(s) != PCA_OK) return 0;
+  return pca::mab_fwd_ws_bytes_any(*s);
 }
 size_t pca_mab_bwd_ws_bytes(const pca_mab_shape* s) {
-  if (pca::validate_shape(s) != PCA_OK) return 0;
-  if (s->mode == PCA_MODE_F32) return pca::mab_f32_bwd_ws_bytes(*s);
-  return 0;
+  if (pca::validate_shape(s) != PCA_OK || bf16_demand(s) != PCA_OK) return 0;
+  return pca::mab_bwd_ws_bytes_any(*s);
 }
 
 int pca_mab_fwd(const pca_mab_shape* s, const void* Q, const void* K,
@@ -47,14 +102,12 @@ int pca_mab_fwd(const pca_mab_shape* s, const void* Q, const void* K,
   PCA_REQUIRE(Q && K && p && Y, "mab_fwd: null pointer");
   PCA_REQUIRE(p->wq && p->bq && p->wk && p->bk && p->wv && p->bv && p->wo && p->bo,
               "mab_fwd: null parameter");
-  PCA_REQUIRE(saved || ws, "mab_fwd: need a saved block or a scratch block");
-  if (s->mode == PCA_MODE_F32) {
-    PCA_TRY(pca::check_f32(s));
-    return pca::mab_f32_fwd(*s, (const float*)Q, (const float*)K, *p, (float*)Y,
-                            saved ? saved : ws, pca::as_stream(stream));
-  }
-  pca::set_error("mab_fwd: mode %d not built", s->mode);
-  return PCA_EUNSUPPORTED;
+  PCA_TRY(bf16_demand(s));
+  PCA_TRY(pca::check_f32(s));
+  PCA_REQUIRE(ws != nullptr || (saved != nullptr && pca::mab_kind(*s) == 0),
+              "mab_fwd: scratch block required");
+  return pca::mab_fwd_any(*s, (const float*)Q, (const float*)K, *p, (float*)Y, saved, ws,
+                          pca::as_stream(stream));
 }
 
 int pca_mab_bwd(const pca_mab_shape* s, const void* Q, const void* K,
@@ -64,14 +117,11 @@ int pca_mab_bwd(const pca_mab_shape* s, const void* Q, const void* K,
   PCA_REQUIRE(Q && K && p && saved && dY && g && ws, "mab_bwd: null pointer");
   PCA_REQUIRE(g->wq && g->bq && g->wk && g->bk && g->wv && g->bv && g->wo && g->bo,
               "mab_bwd: null gradient buffer");
-  if (s->mode == PCA_MODE_F32) {
-    PCA_TRY(pca::check_f32(s));
-    return pca::mab_f32_bwd(*s, (const float*)Q, (const float*)K, *p, saved,
-                            (const float*)dY, (float*)dQ, (float*)dK, dk_accumulate, *g, ws,
-                            pca::as_stream(stream));
-  }
-  pca::set_error("mab_bwd: mode %d not built", s->mode);
-  return PCA_EUNSUPPORTED;
+  PCA_TRY(bf16_demand(s));
+  PCA_TRY(pca::check_f32(s));
+  return pca::mab_bwd_any(*s, (const float*)Q, (const float*)K, *p, saved, (const float*)dY,
+                          (float*)dQ, (float*)dK, dk_accumulate, *g, ws,
+                          pca::as_stream(stream));
 }
 
 int pca_linear_fwd(const float* X, const float* W, const float* b, float* Y, int64_t M,

@@ -1,0 +1,457 @@
+// Fused bf16-MFMA forward of the "many queries, few keys" MAB -- ISAB's mab1(X, H)
+// (set_transformer-master/modules.py:53 with modules.py:19-33 inside): per point
+//     Qp = fc_q(x) ; per head: A = softmax(Qp_h Kp_h^T / sqrt(d)) over the m inducing keys ;
+//     O = Qp + A Vp ; Y = O + relu(fc_o(O))
+// in ONE kernel.  Each wave owns 32 points and runs the whole chain in registers in the
+// transposed layout of mfma_common.hpp: GEMM1 (Wq . X^T) -> scores (Kp_h . Qp_h^T) -> softmax
+// (4 registers + 2 cross-lane steps per point) -> A.V accumulated ONTO the Qp accumulators
+// (the residual is the accumulator's initial value) -> GEMM2 (Wo . O^T) -> ReLU/residual
+// epilogue.  Nothing but the X tile, the weights and the set's Kp/Vp ever touches LDS, and
+// the N x m attention matrix never exists in memory.  bf16 MFMA operands, fp32 accumulate,
+// fp32 softmax / bias / residual.
+//
+// Roofline unit: per point 2*(2 d^2 + 2 m d) FLOP forward.
+#include "mab1_bf16.hpp"
+
+#include <math.h>
+
+#include <mutex>
+
+namespace pca {
+
+namespace {
+
+constexpr int TP = M1_TP;
+constexpr int NB = M1_NB;
+
+// ---------------------------------------------------------------------------------
+// weight preparation (once per call; d^2 elements): fp32 nn.Linear weights -> bf16 images
+//   natural : dst[n][k]            = src[n][k]
+//   permK   : dst[n][32s + p]      = src[n][32s + perm32(p)]
+//   transposed+permK: dst[i][32s+p]= src[32s + perm32(p)][i]
+// ---------------------------------------------------------------------------------
+__global__ void k_prep_weight(const float* __restrict__ src, __bf16* __restrict__ dst, int rows,
+                              int cols, int mode) {
+  const int idx = blockIdx.x * blockDim.x + threadIdx.x;
+  if (idx >= rows * cols) return;
+  const int n = idx / cols, k = idx - n * cols;
+  const int kp = (k & ~31) + perm32(k & 31);
+  float v;
+  if (mode == 0) v = src[n * cols + k];
+  else if (mode == 1) v = src[n * cols + kp];
+  else v = src[kp * rows + n];            // square only (rows == cols)
+  dst[idx] = (__bf16)v;
+}
+
+// ---------------------------------------------------------------------------------
+// K/V projection of the m inducing-point outputs of one set (tiny): Kp = H Wk^T + bk,
+// Vp = H Wv^T + bv, written in the four bf16 images the chain kernels read:
+//   KpP[b][key][32j + p] = Kp[key][32j + perm32(p)]     (A operand of S^T = Kp_j . Qp_j^T)
+//   VpP[b][key][32j + p] = Vp[key][32j + perm32(p)]     (A operand of dA^T = Vp_j . dO_j^T)
+//   Kt [b][feat][kp]     = Kp[key(kp)][feat]            (A operand of dQp^T += Kp_j^T . dS^T)
+//   Vt [b][feat][kp]     = Vp[key(kp)][feat]            (A operand of O^T  += Vp_j^T . P^T)
+// with key(kp) = kp for m = 16 (16x16x16 MFMA, natural k) and perm32(kp) for m = 32.
+// ---------------------------------------------------------------------------------
+template <int MI>
+__global__ __launch_bounds__(256) void k_kv_proj(const float* __restrict__ H,
+                                                 const float* __restrict__ Wk,
+                                                 const float* __restrict__ bk,
+                                                 const float* __restrict__ Wv,
+                                                 const float* __restrict__ bv, int d,
+                                                 __bf16* __restrict__ KpP,
+                                                 __bf16* __restrict__ VpP,
+                                                 __bf16* __restrict__ Kt,
+                                                 __bf16* __restrict__ Vt) {
+  extern __shared__ __attribute__((aligned(16))) float sH[];   // [MI][d]
+  const int b = blockIdx.x;
+  for (int i = threadIdx.x; i < MI * d; i += 256) sH[i] = H[(int64_t)b * MI * d + i];
+  __syncthreads();
+  for (int f = threadIdx.x; f < d; f += 256) {
+    float ak[MI], av[MI];
+#pragma unroll
+    for (int i = 0; i < MI; ++i) { ak[i] = bk[f]; av[i] = bv[f]; }
+    const float* wk = Wk + (int64_t)f * d;
+    const float* wv = Wv + (int64_t)f * d;
+    for (int c = 0; c < d; c += 4) {
+      const float4 k4 = *reinterpret_cast<const float4*>(wk + c);
+      const float4 v4 = *reinterpret_cast<const float4*>(wv + c);
+#pragma unroll
+      for (int i = 0; i < MI; ++i) {
+        const float4 h4 = *reinterpret_cast<const float4*>(&sH[i * d + c]);
+        ak[i] += h4.x * k4.x + h4.y * k4.y + h4.z * k4.z + h4.w * k4.w;
+        av[i] += h4.x * v4.x + h4.y * v4.y + h4.z * v4.z + h4.w * v4.w;
+      }
+    }
+    // feature f sits at position pos inside its 32-block: f = 32j + perm32(pos)
+    const int jb = f & ~31, fo = f & 31;
+    int pos = 0;
+#pragma unroll
+    for (int p = 0; p < 32; ++p)
+      if (perm32(p) == fo) pos = p;
+#pragma unroll
+    for (int i = 0; i < MI; ++i) {
+      KpP[((int64_t)b * MI + i) * d + jb + pos] = (__bf16)ak[i];
+      VpP[((int64_t)b * MI + i) * d + jb + pos] = (__bf16)av[i];
+    }
+#pragma unroll
+    for (int kp = 0; kp < MI; ++kp) {
+      const int key = (MI == 32) ? perm32(kp) : kp;
+      Kt[((int64_t)b * d + f) * MI + kp] = (__bf16)ak[key];
+      Vt[((int64_t)b * d + f) * MI + kp] = (__bf16)av[key];
+    }
+  }
+}
+
+// ---------------------------------------------------------------------------------
+// the fused forward kernel
+// ---------------------------------------------------------------------------------
+struct Mab1FwdArgs {
+  const float* X;        // [B, N, dq] fp32
+  const __bf16* WqB;     // [D][D] natural (dq == D) ...
+  const float* WqF;      // ... or fp32 [D][dq] for dq <= 4 (layer 1: exact VALU projection)
+  const float* bq;
+  const __bf16* KpP;     // [B][MI][D]
+  const __bf16* Vt;      // [B][D][MI]
+  const __bf16* WoP;     // [D][D] K-permuted
+  const float* bo;
+  float* Y;              // [B, N, D] fp32
+  __bf16* QpS;           // [B*N][D] saved for backward (nullable)
+  __bf16* OS;            // [B*N][D]
+  uint32_t* mask;        // ReLU mask bits, see mask_index()
+  int B, N, dq;
+  int tiles_per_set;
+  float scale_log2e;     // log2(e) / sqrt(d)
+};
+
+template <int D, int MI, bool DIN_SMALL>
+__global__ __launch_bounds__(256, 1) void k_mab1_fwd(const Mab1FwdArgs a) {
+  constexpr int DT = D / 16;          // feature tiles
+  constexpr int KS = D / 32;          // 32-wide K steps = heads (dh == 32)
+  constexpr int ROWB = D * 2;         // bytes per row of a [.][D] bf16 image
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  char* sWo = smem;                                   // D x D bf16, swizzled
+  char* sKp = sWo + D * ROWB;                         // MI x D
+  char* sVt = sKp + MI * ROWB;                        // D x MI
+  char* sWq = sVt + D * MI * 2;                       // D x D (absent when DIN_SMALL)
+  char* sX = sWq + (DIN_SMALL ? 0 : D * ROWB);        // TP x D (absent when DIN_SMALL)
+
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int r = lane & 15, g = lane >> 4;
+
+  // ---- weights -> LDS once per workgroup (16-byte chunks, swizzled rows) ----
+  for (int c = tid; c < D * (D / 8); c += 256) {
+    const int row = c / (D / 8), c16 = c % (D / 8);
+    *reinterpret_cast<uint4*>(sWo + swz(row, c16, ROWB)) =
+        *reinterpret_cast<const uint4*>(a.WoP + (int64_t)row * D + c16 * 8);
+    if (!DIN_SMALL)
+      *reinterpret_cast<uint4*>(sWq + swz(row, c16, ROWB)) =
+          *reinterpret_cast<const uint4*>(a.WqB + (int64_t)row * D + c16 * 8);
+  }
+
+  const int total_tiles = a.B * a.tiles_per_set;
+  int cur_b = -1;
+  for (int tile_id = blockIdx.x; tile_id < total_tiles; tile_id += gridDim.x) {
+    const int b = tile_id / a.tiles_per_set, tile = tile_id - b * a.tiles_per_set;
+    if (b != cur_b) {                       // this set's Kp / Vp images
+      __syncthreads();
+      for (int c = tid; c < MI * (D / 8); c += 256) {
+        const int row = c / (D / 8), c16 = c % (D / 8);
+        *reinterpret_cast<uint4*>(sKp + swz(row, c16, ROWB)) = *reinterpret_cast<const uint4*>(
+            a.KpP + ((int64_t)b * MI + row) * D + c16 * 8);
+      }
+      for (int c = tid; c < D * MI / 8; c += 256)
+        reinterpret_cast<uint4*>(sVt)[c] =
+            reinterpret_cast<const uint4*>(a.Vt + (int64_t)b * D * MI)[c];
+      cur_b = b;
+    }
+    __syncthreads();
+
+    const int n_base = tile * TP + wave * 32;           // first point of this wave
+    f32x4 acc[DT][NB];
+
+    if (DIN_SMALL) {
+      // layer 1: Qp = x Wq^T + bq with dq in 1..4, exact fp32 on the vector ALU
+      float xv[NB][4];
+#pragma unroll
+      for (int nb = 0; nb < NB; ++nb) {
+        const int n = n_base + 16 * nb + r;
+#pragma unroll
+        for (int c = 0; c < 4; ++c)
+          xv[nb][c] = (n < a.N && c < a.dq) ? a.X[((int64_t)b * a.N + n) * a.dq + c] : 0.f;
+      }
+#pragma unroll
+      for (int t = 0; t < DT; ++t) {
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+          const int f = 16 * t + 4 * g + e;
+          float w[4];
+#pragma unroll
+          for (int c = 0; c < 4; ++c) w[c] = c < a.dq ? a.WqF[f * a.dq + c] : 0.f;
+          const float bias = a.bq[f];
+#pragma unroll
+          for (int nb = 0; nb < NB; ++nb)
+            acc[t][nb][e] = bias + w[0] * xv[nb][0] + w[1] * xv[nb][1] + w[2] * xv[nb][2] +
+                            w[3] * xv[nb][3];
+        }
+      }
+    } else {
+      // stage this wave's 32 rows of X (fp32 -> bf16) into its private slice of sX
+      char* myX = sX + wave * 32 * ROWB;
+      for (int c = lane; c < 32 * (D / 8); c += 64) {
+        const int row = c / (D / 8), c16 = c % (D / 8);
+        const int n = n_base + row;
+        bf16x8 v;
+        if (n < a.N) {
+          const float4* src =
+              reinterpret_cast<const float4*>(a.X + ((int64_t)b * a.N + n) * D + c16 * 8);
+          const float4 lo = src[0], hi = src[1];
+          v[0] = (__bf16)lo.x; v[1] = (__bf16)lo.y; v[2] = (__bf16)lo.z; v[3] = (__bf16)lo.w;
+          v[4] = (__bf16)hi.x; v[5] = (__bf16)hi.y; v[6] = (__bf16)hi.z; v[7] = (__bf16)hi.w;
+        } else {
+#pragma unroll
+          for (int e = 0; e < 8; ++e) v[e] = (__bf16)0.f;
+        }
+        *reinterpret_cast<bf16x8*>(myX + swz(row, c16, ROWB)) = v;
+      }
+      // (wave-private: the LDS writes above are ordered before the reads below by the
+      //  compiler's s_waitcnt; no workgroup barrier needed)
+#pragma unroll
+      for (int t = 0; t < DT; ++t) {
+        const float4 b4 = *reinterpret_cast<const float4*>(a.bq + 16 * t + 4 * g);
+#pragma unroll
+        for (int nb = 0; nb < NB; ++nb) acc[t][nb] = f32x4{b4.x, b4.y, b4.z, b4.w};
+      }
+#pragma unroll
+      for (int s = 0; s < KS; ++s) {
+        bf16x8 bx[NB];
+#pragma unroll
+        for (int nb = 0; nb < NB; ++nb)
+          bx[nb] = *reinterpret_cast<const bf16x8*>(myX + swz(16 * nb + r, 4 * s + g, ROWB));
+#pragma unroll
+        for (int t = 0; t < DT; ++t) {
+          const bf16x8 wa =
+              *reinterpret_cast<const bf16x8*>(sWq + swz(16 * t + r, 4 * s + g, ROWB));
+#pragma unroll
+          for (int nb = 0; nb < NB; ++nb) acc[t][nb] = mfma32(wa, bx[nb], acc[t][nb]);
+        }
+      }
+    }
+
+    // ---- save Qp for the backward (bf16, [point][feature]) ----
+    if (a.QpS != nullptr) {
+#pragma unroll
+      for (int nb = 0; nb < NB; ++nb) {
+        const int n = n_base + 16 * nb + r;
+        if (n < a.N) {
+#pragma unroll
+          for (int t = 0; t < DT; ++t)
+            *reinterpret_cast<bf16x4*>(a.QpS + ((int64_t)b * a.N + n) * D + 16 * t + 4 * g) =
+                pack4(acc[t][nb]);
+        }
+      }
+    }
+
+    // ---- attention over the MI inducing keys, head j = feature tiles 2j, 2j+1 ----
+#pragma unroll
+    for (int j = 0; j < KS; ++j) {
+#pragma unroll
+      for (int nb = 0; nb < NB; ++nb) {
+        const bf16x8 qb = pack8(acc[2 * j][nb], acc[2 * j + 1][nb]);
+        f32x4 s0 = {0.f, 0.f, 0.f, 0.f}, s1 = {0.f, 0.f, 0.f, 0.f};
+        s0 = mfma32(*reinterpret_cast<const bf16x8*>(sKp + swz(r, 4 * j + g, ROWB)), qb, s0);
+        if (MI == 32)
+          s1 = mfma32(*reinterpret_cast<const bf16x8*>(sKp + swz(16 + r, 4 * j + g, ROWB)), qb,
+                      s1);
+        float mx = fmaxf(fmaxf(s0[0], s0[1]), fmaxf(s0[2], s0[3]));
+        if (MI == 32) mx = fmaxf(mx, fmaxf(fmaxf(s1[0], s1[1]), fmaxf(s1[2], s1[3])));
+        mx = wave16_max(mx);
+        float sum = 0.f;
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+          s0[e] = exp2f((s0[e] - mx) * a.scale_log2e);
+          sum += s0[e];
+          if (MI == 32) {
+            s1[e] = exp2f((s1[e] - mx) * a.scale_log2e);
+            sum += s1[e];
+          }
+        }
+        sum = wave16_sum(sum);
+        const float inv = 1.0f / sum;
+#pragma unroll
+        for (int e = 0; e < 4; ++e) { s0[e] *= inv; s1[e] *= inv; }
+#pragma unroll
+        for (int tt = 0; tt < 2; ++tt) {
+          const int t = 2 * j + tt;
+          const char* vrow = sVt + (16 * t + r) * (MI * 2);
+          if (MI == 16) {
+            acc[t][nb] = mfma16(*reinterpret_cast<const bf16x4*>(vrow + 8 * g), pack4(s0),
+                                acc[t][nb]);
+          } else {
+            acc[t][nb] = mfma32(*reinterpret_cast<const bf16x8*>(vrow + 16 * g), pack8(s0, s1),
+                                acc[t][nb]);
+          }
+        }
+      }
+    }
+
+    // ---- save O ----
+    if (a.OS != nullptr) {
+#pragma unroll
+      for (int nb = 0; nb < NB; ++nb) {
+        const int n = n_base + 16 * nb + r;
+        if (n < a.N) {
+#pragma unroll
+          for (int t = 0; t < DT; ++t)
+            *reinterpret_cast<bf16x4*>(a.OS + ((int64_t)b * a.N + n) * D + 16 * t + 4 * g) =
+                pack4(acc[t][nb]);
+        }
+      }
+    }
+
+    // ---- GEMM2: Z^T = Wo . O^T ; Y = O + relu(Z + bo) ----
+    f32x4 z[DT][NB];
+#pragma unroll
+    for (int t = 0; t < DT; ++t) {
+      const float4 b4 = *reinterpret_cast<const float4*>(a.bo + 16 * t + 4 * g);
+#pragma unroll
+      for (int nb = 0; nb < NB; ++nb) z[t][nb] = f32x4{b4.x, b4.y, b4.z, b4.w};
+    }
+#pragma unroll
+    for (int s = 0; s < KS; ++s) {
+      bf16x8 ob[NB];
+#pragma unroll
+      for (int nb = 0; nb < NB; ++nb) ob[nb] = pack8(acc[2 * s][nb], acc[2 * s + 1][nb]);
+#pragma unroll
+      for (int t = 0; t < DT; ++t) {
+        const bf16x8 wa =
+            *reinterpret_cast<const bf16x8*>(sWo + swz(16 * t + r, 4 * s + g, ROWB));
+#pragma unroll
+        for (int nb = 0; nb < NB; ++nb) z[t][nb] = mfma32(wa, ob[nb], z[t][nb]);
+      }
+    }
+
+#pragma unroll
+    for (int nb = 0; nb < NB; ++nb) {
+      const int n = n_base + 16 * nb + r;
+      uint32_t bits[D / 128];
+#pragma unroll
+      for (int w = 0; w < D / 128; ++w) bits[w] = 0u;
+#pragma unroll
+      for (int t = 0; t < DT; ++t) {
+        f32x4 y;
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+          const float zz = z[t][nb][e];
+          y[e] = acc[t][nb][e] + fmaxf(zz, 0.f);
+          if (zz > 0.f) bits[t / 8] |= 1u << ((t & 7) * 4 + e);
+        }
+        if (n < a.N)
+          *reinterpret_cast<float4*>(a.Y + ((int64_t)b * a.N + n) * D + 16 * t + 4 * g) =
+              float4{y[0], y[1], y[2], y[3]};
+      }
+      if (a.mask != nullptr) {
+#pragma unroll
+        for (int w = 0; w < D / 128; ++w)
+          a.mask[mab1_mask_index<D>(b, a.tiles_per_set, tile, wave, nb, w, lane)] = bits[w];
+      }
+    }
+  }
+}
+
+template <int D, int MI, bool DS>
+int launch_fwd(const Mab1FwdArgs& a, hipStream_t st) {
+  const size_t lds = (size_t)D * D * 2 + (size_t)MI * D * 2 + (size_t)D * MI * 2 +
+                     (DS ? 0 : (size_t)D * D * 2 + (size_t)TP * D * 2);
+  static std::once_flag once;
+  std::call_once(once, [] {
+    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(k_mab1_fwd<D, MI, DS>),
+                              hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+  });
+  const int total = a.B * a.tiles_per_set;
+  const int grid = total < 256 ? total : 256;
+  const double pts = (double)a.B * a.N;
+  ProfScope ps(PCA_K_MAB1_FWD, st,
+               2.0 * pts * ((double)a.dq * D + (double)D * D + 2.0 * MI * D),
+               pts * (4.0 * a.dq + 4.0 * D));
+  hipLaunchKernelGGL((k_mab1_fwd<D, MI, DS>), dim3(grid), dim3(256), lds, st, a);
+  ps.end();
+  return check_launch("k_mab1_fwd");
+}
+
+}  // namespace
+
+// ---- host side --------------------------------------------------------------------
+int prep_weight(const float* src, __bf16* dst, int rows, int cols, int mode, hipStream_t st) {
+  hipLaunchKernelGGL(k_prep_weight, dim3((unsigned)cdiv((int64_t)rows * cols, 256)), dim3(256), 0,
+                     st, src, dst, rows, cols, mode);
+  return check_launch("k_prep_weight");
+}
+
+bool mab1_bf16_supported(const pca_mab_shape& s) {
+  return s.q_shared == 0 && s.d == 128 && s.h * 32 == s.d && (s.nk == 16 || s.nk == 32) &&
+         s.dk == s.d && (s.dq == s.d || s.dq <= 4) && s.q_dtype == PCA_F32 &&
+         s.k_dtype == PCA_F32 && s.y_dtype == PCA_F32;
+}
+
+size_t mab1_carve_saved(const pca_mab_shape& s, Mab1Saved* out, void* base) {
+  Carver c(base);
+  Mab1Saved v;
+  const size_t kv = (size_t)s.B * s.nk * s.d;
+  const int tiles = (int)cdiv(s.nq, TP);
+  v.KpP = c.take<__bf16>(kv);
+  v.VpP = c.take<__bf16>(kv);
+  v.Kt = c.take<__bf16>(kv);
+  v.Vt = c.take<__bf16>(kv);
+  v.QpS = c.take<__bf16>((size_t)s.B * s.nq * s.d);
+  v.OS = c.take<__bf16>((size_t)s.B * s.nq * s.d);
+  v.mask = c.take<uint32_t>((size_t)s.B * tiles * (TP / 16) * (s.d / 128) * 64);
+  if (out) *out = v;
+  return c.off;
+}
+
+size_t mab1_bf16_saved_bytes(const pca_mab_shape& s) {
+  return mab1_carve_saved(s, nullptr, nullptr);
+}
+size_t mab1_bf16_fwd_ws_bytes(const pca_mab_shape& s) {
+  return 2 * align256((size_t)s.d * s.d * 2) + mab1_carve_saved(s, nullptr, nullptr);
+}
+
+// Q = X [B, nq, dq] fp32, K = H [B, nk, d] fp32 -> Y [B, nq, d] fp32
+int mab1_bf16_fwd(const pca_mab_shape& s, const float* X, const float* H,
+                  const pca_mab_params& p, float* Y, void* saved, void* ws, hipStream_t st) {
+  PCA_REQUIRE(mab1_bf16_supported(s), "mab1_bf16_fwd: unsupported shape");
+  PCA_REQUIRE(ws != nullptr, "mab1_bf16_fwd: scratch required");
+  Carver cw(ws);
+  __bf16* WqB = cw.take<__bf16>((size_t)s.d * s.d);
+  __bf16* WoP = cw.take<__bf16>((size_t)s.d * s.d);
+  Mab1Saved v;
+  const bool training = saved != nullptr;
+  mab1_carve_saved(s, &v, training ? saved : (void*)(cw.base + cw.off));
+  const int d = s.d;
+  const bool small = s.dq <= 4;
+
+  if (!small) PCA_TRY(prep_weight(p.wq, WqB, d, d, 0, st));
+  PCA_TRY(prep_weight(p.wo, WoP, d, d, 1, st));
+  const size_t hl = (size_t)s.nk * d * sizeof(float);
+  if (s.nk == 16)
+    hipLaunchKernelGGL((k_kv_proj<16>), dim3(s.B), dim3(256), hl, st, H, p.wk, p.bk, p.wv, p.bv,
+                       d, v.KpP, v.VpP, v.Kt, v.Vt);
+  else
+    hipLaunchKernelGGL((k_kv_proj<32>), dim3(s.B), dim3(256), hl, st, H, p.wk, p.bk, p.wv, p.bv,
+                       d, v.KpP, v.VpP, v.Kt, v.Vt);
+  PCA_TRY(check_launch("k_kv_proj"));
+
+  Mab1FwdArgs a{};
+  a.X = X; a.WqB = WqB; a.WqF = p.wq; a.bq = p.bq; a.KpP = v.KpP; a.Vt = v.Vt; a.WoP = WoP;
+  a.bo = p.bo; a.Y = Y;
+  a.QpS = training ? v.QpS : nullptr;
+  a.OS = training ? v.OS : nullptr;
+  a.mask = training ? v.mask : nullptr;
+  a.B = s.B; a.N = s.nq; a.dq = s.dq;
+  a.tiles_per_set = (int)cdiv(s.nq, TP);
+  a.scale_log2e = 1.4426950408889634f / sqrtf((float)d);
+  if (s.nk == 16) return small ? launch_fwd<128, 16, true>(a, st) : launch_fwd<128, 16, false>(a, st);
+  return small ? launch_fwd<128, 32, true>(a, st) : launch_fwd<128, 32, false>(a, st);
+}
+
+}  // namespace pca

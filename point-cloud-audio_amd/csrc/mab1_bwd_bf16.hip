@@ -1,0 +1,557 @@
+// Fused bf16-MFMA backward of ISAB's mab1(X, H) (adjoint of set_transformer-master/
+// modules.py:19-33 in the "many queries, few keys" orientation; math in SURVEY.md 3c).
+//
+//   k_mab1_bwd   per 32 points of one wave, all in registers in the transposed layout:
+//                dZ = dY.mask ; dO^T = dY^T + Wo^T.dZ^T ; per head: P^T recomputed from the
+//                saved Qp, dA^T = Vp_h.dO_h^T, dS^T = P^T.(dA^T - rowsum) / sqrt(d),
+//                dQp_h^T = dO_h^T + Kp_h^T.dS^T ; dX^T = Wq^T.dQp^T.
+//                Writes dX and bf16 copies of dZ, dO, dQp, dS, P for the reductions over
+//                points, which need the point index on the MFMA K axis:
+//   k_wgrad      dW[DG x DA] += G^T.A over a row range (G = dZ|dQp, A = O|X): both operands
+//                come from row-major [point][feature] LDS images through ds_read_tr16_b64
+//                (hardware transpose), fp32 partials added with atomics; column sums of G
+//                (bias gradients) ride along.
+//   k_kv_grad    per (set, head): dKp = dS^T.Qp, dVp = P^T.dO (m x 32 outputs, N-long sums).
+// The tiny [B*m, d] projections of H (fc_k, fc_v) are differentiated with the fp32 GEMMs.
+#include "mab1_bf16.hpp"
+
+#include <math.h>
+
+#include <mutex>
+
+namespace pca {
+
+int linear_bwd_f32(const float* X, const float* W, const float* dY, float* dX, float* dW,
+                   float* db, int64_t M, int din, int dout, hipStream_t st);
+int linear_dx_acc_f32(const float* dY, const float* W, float* dX, int64_t M, int din, int dout,
+                      int accumulate, hipStream_t st);
+
+namespace {
+
+constexpr int TP = M1_TP;
+constexpr int NB = M1_NB;
+
+struct Mab1BwdArgs {
+  const float* dY;          // [B, N, D]
+  const __bf16* QpS;        // [B*N][D]
+  const uint32_t* mask;
+  const __bf16 *KpP, *VpP;  // [B][MI][D]  (K-permuted features)
+  const __bf16* Kt;         // [B][D][MI]
+  const __bf16 *WoTP, *WqTP;
+  __bf16 *dZ, *dQp, *dOs;   // [B*N][D]
+  __bf16 *dS, *P;           // [B*N][H*MI]
+  float* dX;                // [B, N, D] or null
+  int B, N, tiles_per_set;
+  float scale, scale_log2e;
+};
+
+template <int D, int MI, bool WANT_DX>
+__global__ __launch_bounds__(256, 1) void k_mab1_bwd(const Mab1BwdArgs a) {
+  constexpr int DT = D / 16, KS = D / 32, ROWB = D * 2, HM = KS * MI;
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  char* sWoT = smem;
+  char* sKp = sWoT + D * ROWB;
+  char* sVp = sKp + MI * ROWB;
+  char* sKt = sVp + MI * ROWB;
+  char* sWqT = sKt + D * MI * 2;
+
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int r = lane & 15, g = lane >> 4;
+
+  for (int c = tid; c < D * (D / 8); c += 256) {
+    const int row = c / (D / 8), c16 = c % (D / 8);
+    *reinterpret_cast<uint4*>(sWoT + swz(row, c16, ROWB)) =
+        *reinterpret_cast<const uint4*>(a.WoTP + (int64_t)row * D + c16 * 8);
+    if (WANT_DX)
+      *reinterpret_cast<uint4*>(sWqT + swz(row, c16, ROWB)) =
+          *reinterpret_cast<const uint4*>(a.WqTP + (int64_t)row * D + c16 * 8);
+  }
+
+  const int total_tiles = a.B * a.tiles_per_set;
+  int cur_b = -1;
+  for (int tile_id = blockIdx.x; tile_id < total_tiles; tile_id += gridDim.x) {
+    const int b = tile_id / a.tiles_per_set, tile = tile_id - b * a.tiles_per_set;
+    if (b != cur_b) {
+      __syncthreads();
+      for (int c = tid; c < MI * (D / 8); c += 256) {
+        const int row = c / (D / 8), c16 = c % (D / 8);
+        const int64_t src = ((int64_t)b * MI + row) * D + c16 * 8;
+        *reinterpret_cast<uint4*>(sKp + swz(row, c16, ROWB)) =
+            *reinterpret_cast<const uint4*>(a.KpP + src);
+        *reinterpret_cast<uint4*>(sVp + swz(row, c16, ROWB)) =
+            *reinterpret_cast<const uint4*>(a.VpP + src);
+      }
+      for (int c = tid; c < D * MI / 8; c += 256)
+        reinterpret_cast<uint4*>(sKt)[c] =
+            reinterpret_cast<const uint4*>(a.Kt + (int64_t)b * D * MI)[c];
+      cur_b = b;
+    }
+    __syncthreads();
+
+    const int n_base = tile * TP + wave * 32;
+    int nn[NB];
+    bool live[NB];
+    int64_t row[NB];
+#pragma unroll
+    for (int nb = 0; nb < NB; ++nb) {
+      nn[nb] = n_base + 16 * nb + r;
+      live[nb] = nn[nb] < a.N;
+      row[nb] = (int64_t)b * a.N + (live[nb] ? nn[nb] : 0);
+    }
+
+    // ---- dY^T tiles and dZ = dY . [Z > 0] ----
+    f32x4 dO[DT][NB];
+    bf16x8 dzb[KS][NB];
+#pragma unroll
+    for (int nb = 0; nb < NB; ++nb) {
+      uint32_t bits[D / 128];
+#pragma unroll
+      for (int w = 0; w < D / 128; ++w)
+        bits[w] = a.mask[mab1_mask_index<D>(b, a.tiles_per_set, tile, wave, nb, w, lane)];
+      f32x4 dz[DT];
+#pragma unroll
+      for (int t = 0; t < DT; ++t) {
+        float4 v = float4{0.f, 0.f, 0.f, 0.f};
+        if (live[nb]) v = *reinterpret_cast<const float4*>(a.dY + row[nb] * D + 16 * t + 4 * g);
+        dO[t][nb] = f32x4{v.x, v.y, v.z, v.w};
+#pragma unroll
+        for (int e = 0; e < 4; ++e)
+          dz[t][e] = ((bits[t / 8] >> ((t & 7) * 4 + e)) & 1u) ? dO[t][nb][e] : 0.f;
+        if (live[nb])
+          *reinterpret_cast<bf16x4*>(a.dZ + row[nb] * D + 16 * t + 4 * g) = pack4(dz[t]);
+      }
+#pragma unroll
+      for (int s = 0; s < KS; ++s) dzb[s][nb] = pack8(dz[2 * s], dz[2 * s + 1]);
+    }
+
+    // ---- dO^T = dY^T + Wo^T . dZ^T ----
+#pragma unroll
+    for (int s = 0; s < KS; ++s) {
+#pragma unroll
+      for (int t = 0; t < DT; ++t) {
+        const bf16x8 wa =
+            *reinterpret_cast<const bf16x8*>(sWoT + swz(16 * t + r, 4 * s + g, ROWB));
+#pragma unroll
+        for (int nb = 0; nb < NB; ++nb) dO[t][nb] = mfma32(wa, dzb[s][nb], dO[t][nb]);
+      }
+    }
+#pragma unroll
+    for (int nb = 0; nb < NB; ++nb)
+      if (live[nb]) {
+#pragma unroll
+        for (int t = 0; t < DT; ++t)
+          *reinterpret_cast<bf16x4*>(a.dOs + row[nb] * D + 16 * t + 4 * g) = pack4(dO[t][nb]);
+      }
+
+    // ---- attention backward per head; dO tiles of the head become dQp in place ----
+#pragma unroll
+    for (int j = 0; j < KS; ++j) {
+#pragma unroll
+      for (int nb = 0; nb < NB; ++nb) {
+        // saved Qp of this point, features 32j + perm32(8g + .)
+        const bf16x4 qlo =
+            *reinterpret_cast<const bf16x4*>(a.QpS + row[nb] * D + 32 * j + 4 * g);
+        const bf16x4 qhi =
+            *reinterpret_cast<const bf16x4*>(a.QpS + row[nb] * D + 32 * j + 16 + 4 * g);
+        bf16x8 qb;
+#pragma unroll
+        for (int e = 0; e < 4; ++e) { qb[e] = qlo[e]; qb[4 + e] = qhi[e]; }
+        const bf16x8 dob = pack8(dO[2 * j][nb], dO[2 * j + 1][nb]);
+        f32x4 p0 = {0.f, 0.f, 0.f, 0.f}, p1 = {0.f, 0.f, 0.f, 0.f};
+        f32x4 da0 = {0.f, 0.f, 0.f, 0.f}, da1 = {0.f, 0.f, 0.f, 0.f};
+        p0 = mfma32(*reinterpret_cast<const bf16x8*>(sKp + swz(r, 4 * j + g, ROWB)), qb, p0);
+        da0 = mfma32(*reinterpret_cast<const bf16x8*>(sVp + swz(r, 4 * j + g, ROWB)), dob, da0);
+        if (MI == 32) {
+          p1 = mfma32(*reinterpret_cast<const bf16x8*>(sKp + swz(16 + r, 4 * j + g, ROWB)), qb,
+                      p1);
+          da1 = mfma32(*reinterpret_cast<const bf16x8*>(sVp + swz(16 + r, 4 * j + g, ROWB)), dob,
+                       da1);
+        }
+        float mx = fmaxf(fmaxf(p0[0], p0[1]), fmaxf(p0[2], p0[3]));
+        if (MI == 32) mx = fmaxf(mx, fmaxf(fmaxf(p1[0], p1[1]), fmaxf(p1[2], p1[3])));
+        mx = wave16_max(mx);
+        float sum = 0.f;
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+          p0[e] = exp2f((p0[e] - mx) * a.scale_log2e);
+          sum += p0[e];
+          if (MI == 32) {
+            p1[e] = exp2f((p1[e] - mx) * a.scale_log2e);
+            sum += p1[e];
+          }
+        }
+        sum = wave16_sum(sum);
+        const float inv = 1.0f / sum;
+        float delta = 0.f;
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+          p0[e] *= inv;
+          p1[e] *= inv;
+          delta += p0[e] * da0[e] + p1[e] * da1[e];
+        }
+        delta = wave16_sum(delta);
+        f32x4 ds0, ds1;
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+          ds0[e] = p0[e] * (da0[e] - delta) * a.scale;
+          ds1[e] = p1[e] * (da1[e] - delta) * a.scale;
+        }
+        if (live[nb]) {
+          *reinterpret_cast<bf16x4*>(a.P + row[nb] * HM + j * MI + 4 * g) = pack4(p0);
+          *reinterpret_cast<bf16x4*>(a.dS + row[nb] * HM + j * MI + 4 * g) = pack4(ds0);
+          if (MI == 32) {
+            *reinterpret_cast<bf16x4*>(a.P + row[nb] * HM + j * MI + 16 + 4 * g) = pack4(p1);
+            *reinterpret_cast<bf16x4*>(a.dS + row[nb] * HM + j * MI + 16 + 4 * g) = pack4(ds1);
+          }
+        }
+#pragma unroll
+        for (int tt = 0; tt < 2; ++tt) {
+          const int t = 2 * j + tt;
+          const char* krow = sKt + (16 * t + r) * (MI * 2);
+          if (MI == 16)
+            dO[t][nb] = mfma16(*reinterpret_cast<const bf16x4*>(krow + 8 * g), pack4(ds0),
+                               dO[t][nb]);
+          else
+            dO[t][nb] = mfma32(*reinterpret_cast<const bf16x8*>(krow + 16 * g), pack8(ds0, ds1),
+                               dO[t][nb]);
+        }
+      }
+    }
+    // dO now holds dQp^T
+#pragma unroll
+    for (int nb = 0; nb < NB; ++nb)
+      if (live[nb]) {
+#pragma unroll
+        for (int t = 0; t < DT; ++t)
+          *reinterpret_cast<bf16x4*>(a.dQp + row[nb] * D + 16 * t + 4 * g) = pack4(dO[t][nb]);
+      }
+
+    if (WANT_DX) {
+      f32x4 dx[DT][NB];
+#pragma unroll
+      for (int t = 0; t < DT; ++t)
+#pragma unroll
+        for (int nb = 0; nb < NB; ++nb) dx[t][nb] = f32x4{0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+      for (int s = 0; s < KS; ++s) {
+        bf16x8 qb2[NB];
+#pragma unroll
+        for (int nb = 0; nb < NB; ++nb) qb2[nb] = pack8(dO[2 * s][nb], dO[2 * s + 1][nb]);
+#pragma unroll
+        for (int t = 0; t < DT; ++t) {
+          const bf16x8 wa =
+              *reinterpret_cast<const bf16x8*>(sWqT + swz(16 * t + r, 4 * s + g, ROWB));
+#pragma unroll
+          for (int nb = 0; nb < NB; ++nb) dx[t][nb] = mfma32(wa, qb2[nb], dx[t][nb]);
+        }
+      }
+#pragma unroll
+      for (int nb = 0; nb < NB; ++nb)
+        if (live[nb]) {
+#pragma unroll
+          for (int t = 0; t < DT; ++t)
+            *reinterpret_cast<float4*>(a.dX + row[nb] * D + 16 * t + 4 * g) =
+                float4{dx[t][nb][0], dx[t][nb][1], dx[t][nb][2], dx[t][nb][3]};
+        }
+    }
+  }
+}
+
+// ---------------------------------------------------------------------------------
+// dW[DG x DA] += G[rows, DG]^T . A[rows, DA]  (+ db[DG] += column sums of G)
+// ---------------------------------------------------------------------------------
+// LDS image of a 32-row tile with 256-byte rows; 16-byte chunk ch of row `row` sits at
+// (cdna_hip_programming.md T10, image (b)): serves the transposed reads conflict-free
+__device__ __forceinline__ int tr_off(int row, int ch) {
+  return 256 * row + 16 * (ch ^ (((row & 3) << 2) | ((row >> 2) & 3)));
+}
+
+typedef __attribute__((address_space(3))) s16x4 lds_s16x4;
+
+// A/B fragment with k = the 32 points of the tile (k-slot (g, j): j<4 -> point 4g+j,
+// else 16+4g+j-4) for the 16 features of tile t
+__device__ __forceinline__ bf16x8 tr_frag(const char* img, int t, int lane) {
+  const int g = lane >> 4, i16 = lane & 15, q = i16 >> 2, p = i16 & 3;
+  const int a0 = tr_off(4 * g + q, 2 * t + (p >> 1)) + 8 * (p & 1);
+  const int a1 = tr_off(16 + 4 * g + q, 2 * t + (p >> 1)) + 8 * (p & 1);
+  const s16x4 lo = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_s16x4*)(img + a0));
+  const s16x4 hi = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_s16x4*)(img + a1));
+  const bf16x4 l4 = __builtin_bit_cast(bf16x4, lo), h4 = __builtin_bit_cast(bf16x4, hi);
+  bf16x8 r;
+#pragma unroll
+  for (int e = 0; e < 4; ++e) { r[e] = l4[e]; r[4 + e] = h4[e]; }
+  return r;
+}
+
+__device__ __forceinline__ bf16x8 load8(const __bf16* p) {
+  return *reinterpret_cast<const bf16x8*>(p);
+}
+__device__ __forceinline__ bf16x8 load8(const float* p) {
+  const float4 lo = reinterpret_cast<const float4*>(p)[0], hi = reinterpret_cast<const float4*>(p)[1];
+  bf16x8 v;
+  v[0] = (__bf16)lo.x; v[1] = (__bf16)lo.y; v[2] = (__bf16)lo.z; v[3] = (__bf16)lo.w;
+  v[4] = (__bf16)hi.x; v[5] = (__bf16)hi.y; v[6] = (__bf16)hi.z; v[7] = (__bf16)hi.w;
+  return v;
+}
+
+template <typename AT>
+__global__ __launch_bounds__(256) void k_wgrad128(const __bf16* __restrict__ G,
+                                                  const AT* __restrict__ A, int64_t M,
+                                                  int rows_per_wg, float* __restrict__ dW,
+                                                  float* __restrict__ db) {
+  constexpr int D = 128;
+  __shared__ __attribute__((aligned(16))) char sG[32 * 256];
+  __shared__ __attribute__((aligned(16))) char sA[32 * 256];
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int r = lane & 15, g = lane >> 4;
+  const int64_t r0 = (int64_t)blockIdx.x * rows_per_wg;
+  const int64_t r1 = (r0 + rows_per_wg < M) ? r0 + rows_per_wg : M;
+  f32x4 acc[2][8];
+#pragma unroll
+  for (int i = 0; i < 2; ++i)
+#pragma unroll
+    for (int t = 0; t < 8; ++t) acc[i][t] = f32x4{0.f, 0.f, 0.f, 0.f};
+  float bsum = 0.f;
+
+  for (int64_t base = r0; base < r1; base += 32) {
+#pragma unroll
+    for (int e = 0; e < 2; ++e) {
+      const int c = tid + e * 256;
+      const int row = c >> 4, ch = c & 15;
+      bf16x8 vg, va;
+      if (base + row < r1) {
+        vg = load8(G + (base + row) * D + ch * 8);
+        va = load8(A + (base + row) * D + ch * 8);
+      } else {
+#pragma unroll
+        for (int k = 0; k < 8; ++k) { vg[k] = (__bf16)0.f; va[k] = (__bf16)0.f; }
+      }
+      *reinterpret_cast<bf16x8*>(sG + tr_off(row, ch)) = vg;
+      *reinterpret_cast<bf16x8*>(sA + tr_off(row, ch)) = va;
+    }
+    __syncthreads();
+    if (db != nullptr && tid < D) {
+#pragma unroll 8
+      for (int row = 0; row < 32; ++row)
+        bsum += (float)*reinterpret_cast<const __bf16*>(sG + tr_off(row, tid >> 3) + (tid & 7) * 2);
+    }
+    bf16x8 ga[2];
+#pragma unroll
+    for (int i = 0; i < 2; ++i) ga[i] = tr_frag(sG, 2 * wave + i, lane);
+#pragma unroll
+    for (int t = 0; t < 8; ++t) {
+      const bf16x8 ab = tr_frag(sA, t, lane);
+#pragma unroll
+      for (int i = 0; i < 2; ++i) acc[i][t] = mfma32(ga[i], ab, acc[i][t]);
+    }
+    __syncthreads();
+  }
+#pragma unroll
+  for (int i = 0; i < 2; ++i)
+#pragma unroll
+    for (int t = 0; t < 8; ++t)
+#pragma unroll
+      for (int e = 0; e < 4; ++e)
+        atomicAdd(&dW[(16 * (2 * wave + i) + 4 * g + e) * D + 16 * t + r], acc[i][t][e]);
+  if (db != nullptr && tid < D) atomicAdd(&db[tid], bsum);
+}
+
+// layer 1: dW[D x dq] += dQp^T . X with dq <= 4 (fp32 X), db += colsum(dQp)
+__global__ __launch_bounds__(128) void k_wgrad_small(const __bf16* __restrict__ G,
+                                                     const float* __restrict__ X, int64_t M,
+                                                     int dq, int rows_per_wg,
+                                                     float* __restrict__ dW,
+                                                     float* __restrict__ db) {
+  constexpr int D = 128;
+  const int f = threadIdx.x;
+  const int64_t r0 = (int64_t)blockIdx.x * rows_per_wg;
+  const int64_t r1 = (r0 + rows_per_wg < M) ? r0 + rows_per_wg : M;
+  float acc[4] = {0.f, 0.f, 0.f, 0.f}, bs = 0.f;
+  for (int64_t row = r0; row < r1; ++row) {
+    const float gv = (float)G[row * D + f];
+    bs += gv;
+#pragma unroll
+    for (int c = 0; c < 4; ++c)
+      if (c < dq) acc[c] += gv * X[row * dq + c];
+  }
+  for (int c = 0; c < dq; ++c) atomicAdd(&dW[f * dq + c], acc[c]);
+  atomicAdd(&db[f], bs);
+}
+
+// per (set, head): dKp[b][key][32j + c] = sum_n dS[n][j*MI + key] Qp[n][32j + c]
+//                  dVp[b][key][32j + c] = sum_n  P[n][j*MI + key] dO[n][32j + c]
+template <int MI>
+__global__ __launch_bounds__(256) void k_kv_grad(const __bf16* __restrict__ dS,
+                                                 const __bf16* __restrict__ P,
+                                                 const __bf16* __restrict__ Qp,
+                                                 const __bf16* __restrict__ dO, int N, int D,
+                                                 int H, float* __restrict__ dKp,
+                                                 float* __restrict__ dVp) {
+  constexpr int CH = 64;                   // points per staged chunk
+  __shared__ float sS[CH][MI + 1], sP[CH][MI + 1], sQ[CH][33], sO[CH][33];
+  const int b = blockIdx.x / H, j = blockIdx.x % H;
+  const int HM = H * MI;
+  const int tid = threadIdx.x;
+  const int c = tid & 31, k0 = tid >> 5;         // outputs (key = k0 + 8*i, c)
+  constexpr int KPT = MI / 8;
+  float ak[KPT], av[KPT];
+#pragma unroll
+  for (int i = 0; i < KPT; ++i) ak[i] = av[i] = 0.f;
+  for (int n0 = 0; n0 < N; n0 += CH) {
+    for (int i = tid; i < CH * MI; i += 256) {
+      const int pnt = i / MI, key = i % MI;
+      const int64_t row = (int64_t)b * N + n0 + pnt;
+      const bool ok = n0 + pnt < N;
+      sS[pnt][key] = ok ? (float)dS[row * HM + j * MI + key] : 0.f;
+      sP[pnt][key] = ok ? (float)P[row * HM + j * MI + key] : 0.f;
+    }
+    for (int i = tid; i < CH * 32; i += 256) {
+      const int pnt = i >> 5, cc = i & 31;
+      const int64_t row = (int64_t)b * N + n0 + pnt;
+      const bool ok = n0 + pnt < N;
+      sQ[pnt][cc] = ok ? (float)Qp[row * D + 32 * j + cc] : 0.f;
+      sO[pnt][cc] = ok ? (float)dO[row * D + 32 * j + cc] : 0.f;
+    }
+    __syncthreads();
+#pragma unroll 4
+    for (int pnt = 0; pnt < CH; ++pnt) {
+      const float q = sQ[pnt][c], o = sO[pnt][c];
+#pragma unroll
+      for (int i = 0; i < KPT; ++i) {
+        ak[i] += sS[pnt][k0 + 8 * i] * q;
+        av[i] += sP[pnt][k0 + 8 * i] * o;
+      }
+    }
+    __syncthreads();
+  }
+#pragma unroll
+  for (int i = 0; i < KPT; ++i) {
+    const int64_t o = ((int64_t)b * MI + k0 + 8 * i) * D + 32 * j + c;
+    dKp[o] = ak[i];
+    dVp[o] = av[i];
+  }
+}
+
+template <int D, int MI, bool DX>
+int launch_bwd(const Mab1BwdArgs& a, hipStream_t st, double flops, double bytes) {
+  const size_t lds = (size_t)D * D * 2 + 2 * (size_t)MI * D * 2 + (size_t)D * MI * 2 +
+                     (DX ? (size_t)D * D * 2 : 0);
+  static std::once_flag once;
+  std::call_once(once, [] {
+    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(k_mab1_bwd<D, MI, DX>),
+                              hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+  });
+  const int total = a.B * a.tiles_per_set;
+  const int grid = total < 256 ? total : 256;
+  ProfScope ps(PCA_K_MAB1_BWD, st, flops, bytes);
+  hipLaunchKernelGGL((k_mab1_bwd<D, MI, DX>), dim3(grid), dim3(256), lds, st, a);
+  ps.end();
+  return check_launch("k_mab1_bwd");
+}
+
+struct BwdWs {
+  __bf16 *WoTP, *WqTP, *dZ, *dQp, *dOs, *dS, *P;
+  float *dKp, *dVp;
+};
+size_t carve_bwd_ws(const pca_mab_shape& s, BwdWs* out, void* base) {
+  Carver c(base);
+  BwdWs w;
+  const size_t M = (size_t)s.B * s.nq, d = s.d;
+  w.WoTP = c.take<__bf16>(d * d);
+  w.WqTP = c.take<__bf16>(d * d);
+  w.dZ = c.take<__bf16>(M * d);
+  w.dQp = c.take<__bf16>(M * d);
+  w.dOs = c.take<__bf16>(M * d);
+  w.dS = c.take<__bf16>(M * s.h * s.nk);
+  w.P = c.take<__bf16>(M * s.h * s.nk);
+  w.dKp = c.take<float>((size_t)s.B * s.nk * d);
+  w.dVp = c.take<float>((size_t)s.B * s.nk * d);
+  if (out) *out = w;
+  return c.off;
+}
+
+}  // namespace
+
+size_t mab1_bf16_bwd_ws_bytes(const pca_mab_shape& s) { return carve_bwd_ws(s, nullptr, nullptr); }
+
+// dQ -> dX [B, nq, dq] (written; may be null), dK -> dH [B, nk, d] (written or accumulated)
+int mab1_bf16_bwd(const pca_mab_shape& s, const float* X, const float* H,
+                  const pca_mab_params& p, const void* saved, const float* dY, float* dX,
+                  float* dH, int dk_accumulate, const pca_mab_grads& gr, void* ws,
+                  hipStream_t st) {
+  Mab1Saved v;
+  mab1_carve_saved(s, &v, const_cast<void*>(saved));
+  BwdWs w;
+  carve_bwd_ws(s, &w, ws);
+  const int d = s.d, MI = s.nk;
+  const int64_t M = (int64_t)s.B * s.nq;
+  const bool small = s.dq <= 4;
+  const bool want_dx = dX != nullptr && !small;
+  if (dX != nullptr && small) {
+    // the ST model never needs it (the set itself is the input of layer 1)
+    set_error("mab1_bf16_bwd: dQ for dq <= 4 is not built");
+    return PCA_EUNSUPPORTED;
+  }
+
+  PCA_TRY(prep_weight(p.wo, w.WoTP, d, d, 2, st));
+  if (want_dx) PCA_TRY(prep_weight(p.wq, w.WqTP, d, d, 2, st));
+
+  Mab1BwdArgs a{};
+  a.dY = dY; a.QpS = v.QpS; a.mask = v.mask; a.KpP = v.KpP; a.VpP = v.VpP; a.Kt = v.Kt;
+  a.WoTP = w.WoTP; a.WqTP = w.WqTP; a.dZ = w.dZ; a.dQp = w.dQp; a.dOs = w.dOs; a.dS = w.dS;
+  a.P = w.P; a.dX = want_dx ? dX : nullptr;
+  a.B = s.B; a.N = s.nq; a.tiles_per_set = (int)cdiv(s.nq, TP);
+  a.scale = 1.0f / sqrtf((float)d);
+  a.scale_log2e = 1.4426950408889634f * a.scale;
+  // reference-formulation backward FLOPs of the block: 2x forward
+  const double flops = 4.0 * M * ((double)s.dq * d + (double)d * d + 2.0 * MI * d);
+  const double bytes = (double)M * (4.0 * d + (want_dx ? 4.0 * d : 0.0));
+  int rc;
+  if (MI == 16)
+    rc = want_dx ? launch_bwd<128, 16, true>(a, st, flops, bytes)
+                 : launch_bwd<128, 16, false>(a, st, flops, bytes);
+  else
+    rc = want_dx ? launch_bwd<128, 32, true>(a, st, flops, bytes)
+                 : launch_bwd<128, 32, false>(a, st, flops, bytes);
+  PCA_TRY(rc);
+  // ---- reductions over points ----
+  const int rows_per_wg = 1024;
+  const unsigned nwg = (unsigned)cdiv(M, rows_per_wg);
+  {
+    ProfScope ps(PCA_K_WGRAD, st, 2.0 * M * d * d, 4.0 * M * d);
+    hipLaunchKernelGGL((k_wgrad128<__bf16>), dim3(nwg), dim3(256), 0, st, w.dZ, v.OS, M,
+                       rows_per_wg, gr.wo, gr.bo);
+    ps.end();
+  }
+  PCA_TRY(check_launch("k_wgrad128(wo)"));
+  if (small) {
+    hipLaunchKernelGGL(k_wgrad_small, dim3((unsigned)cdiv(M, 512)), dim3(128), 0, st, w.dQp, X, M,
+                       s.dq, 512, gr.wq, gr.bq);
+    PCA_TRY(check_launch("k_wgrad_small"));
+  } else {
+    ProfScope ps(PCA_K_WGRAD, st, 2.0 * M * d * d, 6.0 * M * d);
+    hipLaunchKernelGGL((k_wgrad128<float>), dim3(nwg), dim3(256), 0, st, w.dQp, X, M,
+                       rows_per_wg, gr.wq, gr.bq);
+    ps.end();
+    PCA_TRY(check_launch("k_wgrad128(wq)"));
+  }
+  if (MI == 16)
+    hipLaunchKernelGGL((k_kv_grad<16>), dim3(s.B * s.h), dim3(256), 0, st, w.dS, w.P, v.QpS,
+                       w.dOs, s.nq, d, s.h, w.dKp, w.dVp);
+  else
+    hipLaunchKernelGGL((k_kv_grad<32>), dim3(s.B * s.h), dim3(256), 0, st, w.dS, w.P, v.QpS,
+                       w.dOs, s.nq, d, s.h, w.dKp, w.dVp);
+  PCA_TRY(check_launch("k_kv_grad"));
+
+  // ---- fc_k / fc_v of the m inducing-point outputs (tiny [B*m, d] GEMMs, fp32) ----
+  const int64_t Mk = (int64_t)s.B * MI;
+  PCA_TRY(linear_bwd_f32(H, p.wk, w.dKp, nullptr, gr.wk, gr.bk, Mk, d, d, st));
+  PCA_TRY(linear_bwd_f32(H, p.wv, w.dVp, nullptr, gr.wv, gr.bv, Mk, d, d, st));
+  if (dH != nullptr) {
+    PCA_TRY(linear_dx_acc_f32(w.dKp, p.wk, dH, Mk, d, d, dk_accumulate ? 1 : 0, st));
+    PCA_TRY(linear_dx_acc_f32(w.dVp, p.wv, dH, Mk, d, d, 1, st));
+  }
+  return PCA_OK;
+}
+
+}  // namespace pca

@@ -220,6 +220,10 @@ int linear_fwd_f32(const float* X, const float* W, const float* b, float* Y, int
                    int din, int dout, hipStream_t st) {
   return linear(X, W, b, Y, M, din, dout, 0, st);
 }
+int linear_dx_acc_f32(const float* dY, const float* W, float* dX, int64_t M, int din, int dout,
+                      int accumulate, hipStream_t st) {
+  return linear_dx(dY, W, dX, M, din, dout, accumulate, st);
+}
 int linear_bwd_f32(const float* X, const float* W, const float* dY, float* dX, float* dW,
                    float* db, int64_t M, int din, int dout, hipStream_t st) {
   if (dW) PCA_TRY(linear_dw(dY, X, dW, M, din, dout, st));

@@ -1,0 +1,67 @@
+// Shared device helpers of the fused bf16 MFMA kernels (gfx950).
+//
+// Layout convention of the "transposed chain" (verified by scripts/probe/mfma_probe.hip):
+// every intermediate lives in accumulator tiles T[t][nb] (f32x4) that hold a 16x16 block of
+// X^T: row = feature 16t + 4g + e (e = register index), column = point 16nb + (lane & 15),
+// g = lane >> 4.  With v_mfma_f32_16x16x32_bf16 (A[row = lane&15][k = 8g+j],
+// B[k = 8g+j][col = lane&15], D[row = 4g+e][col = lane&15]) two such tiles (features
+// 32s .. 32s+31) convert in registers into the B operand of the NEXT product that sums over
+// features; the k-slot (g, j) then means feature 32s + perm32(8g + j), so the A operand
+// (always a weight-like matrix) is stored with its K axis permuted the same way.
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+namespace pca {
+
+typedef __attribute__((ext_vector_type(8))) __bf16 bf16x8;
+typedef __attribute__((ext_vector_type(4))) __bf16 bf16x4;
+typedef __attribute__((ext_vector_type(4))) short s16x4;
+typedef __attribute__((ext_vector_type(4))) float f32x4;
+
+// position p = 8g + j inside a 32-wide K block -> index of the element that k-slot (g, j)
+// carries when the B operand is built from two accumulator tiles
+__host__ __device__ __forceinline__ int perm32(int p) {
+  const int g = p >> 3, j = p & 7;
+  return j < 4 ? 4 * g + j : 16 + 4 * g + (j - 4);
+}
+
+__device__ __forceinline__ f32x4 mfma32(bf16x8 a, bf16x8 b, f32x4 c) {
+  return __builtin_amdgcn_mfma_f32_16x16x32_bf16(a, b, c, 0, 0, 0);
+}
+__device__ __forceinline__ f32x4 mfma16(bf16x4 a, bf16x4 b, f32x4 c) {
+  return __builtin_amdgcn_mfma_f32_16x16x16bf16_1k(__builtin_bit_cast(s16x4, a),
+                                                   __builtin_bit_cast(s16x4, b), c, 0, 0, 0);
+}
+
+__device__ __forceinline__ bf16x8 pack8(f32x4 lo, f32x4 hi) {
+  bf16x8 r;
+  r[0] = (__bf16)lo[0]; r[1] = (__bf16)lo[1]; r[2] = (__bf16)lo[2]; r[3] = (__bf16)lo[3];
+  r[4] = (__bf16)hi[0]; r[5] = (__bf16)hi[1]; r[6] = (__bf16)hi[2]; r[7] = (__bf16)hi[3];
+  return r;
+}
+__device__ __forceinline__ bf16x4 pack4(f32x4 v) {
+  bf16x4 r;
+  r[0] = (__bf16)v[0]; r[1] = (__bf16)v[1]; r[2] = (__bf16)v[2]; r[3] = (__bf16)v[3];
+  return r;
+}
+
+// byte offset of 16-byte chunk c16 of row `row` in a row-major bf16 LDS image with
+// `row_bytes` per row, XOR-swizzled so that 16 lanes reading the same chunk of 16 different
+// rows hit 16 different bank groups (cdna_hip_programming.md T2)
+__device__ __forceinline__ int swz(int row, int c16, int row_bytes) {
+  return row * row_bytes + (((c16 & ~15) | ((c16 ^ row) & 15)) << 4);
+}
+
+__device__ __forceinline__ float wave16_max(float v) {   // over the 4 lane groups g
+  v = fmaxf(v, __shfl_xor(v, 16, 64));
+  v = fmaxf(v, __shfl_xor(v, 32, 64));
+  return v;
+}
+__device__ __forceinline__ float wave16_sum(float v) {
+  v += __shfl_xor(v, 16, 64);
+  v += __shfl_xor(v, 32, 64);
+  return v;
+}
+
+}  // namespace pca

@@ -7,15 +7,16 @@
 
 namespace pca {
 
-int validate_shape(const pca_mab_shape* s);
-size_t mab_f32_saved_bytes(const pca_mab_shape& s);
-size_t mab_f32_bwd_ws_bytes(const pca_mab_shape& s);
-int mab_f32_fwd(const pca_mab_shape& s, const float* Q, const float* K,
-                const pca_mab_params& p, float* Y, void* saved, hipStream_t st);
-int mab_f32_bwd(const pca_mab_shape& s, const float* Q, const float* K,
-                const pca_mab_params& p, const void* saved, const float* dY, float* dQ,
-                float* dK, int dk_accumulate, const pca_mab_grads& g, void* ws,
-                hipStream_t st);
+// per-block dispatch (api_mab.hip): fused bf16 kernel where one exists for the block's shape
+// and the config asks for PCA_MODE_BF16, exact fp32 GEMM chain otherwise
+size_t mab_saved_bytes_any(const pca_mab_shape& s);
+size_t mab_fwd_ws_bytes_any(const pca_mab_shape& s);
+size_t mab_bwd_ws_bytes_any(const pca_mab_shape& s);
+int mab_fwd_any(const pca_mab_shape& s, const float* Q, const float* K, const pca_mab_params& p,
+                float* Y, void* saved, void* ws, hipStream_t st);
+int mab_bwd_any(const pca_mab_shape& s, const float* Q, const float* K, const pca_mab_params& p,
+                const void* saved, const float* dY, float* dQ, float* dK, int dk_accumulate,
+                const pca_mab_grads& g, void* ws, hipStream_t st);
 int linear_fwd_f32(const float* X, const float* W, const float* b, float* Y, int64_t M,
                    int din, int dout, hipStream_t st);
 int linear_bwd_f32(const float* X, const float* W, const float* dY, float* dX, float* dW,
@@ -113,13 +114,15 @@ inline size_t carve(const pca_st_config& c, int training, Ws* out, void* base) {
   Carver cv(base);
   Ws w{};
   const pca_mab_shape* order[5] = {&s.m0[0], &s.m1[0], &s.m0[1], &s.m1[1], &s.pma};
-  size_t max_saved = 0, max_bwd = 0;
+  size_t max_scratch = 0;
   for (int i = 0; i < 5; ++i) {
-    const size_t sb = mab_f32_saved_bytes(*order[i]);
-    max_saved = sb > max_saved ? sb : max_saved;
-    const size_t bb = mab_f32_bwd_ws_bytes(*order[i]);
-    max_bwd = bb > max_bwd ? bb : max_bwd;
-    if (training) w.saved[i] = cv.take<char>(sb);
+    const size_t fb = mab_fwd_ws_bytes_any(*order[i]);
+    max_scratch = fb > max_scratch ? fb : max_scratch;
+    if (training) {
+      const size_t bb = mab_bwd_ws_bytes_any(*order[i]);
+      max_scratch = bb > max_scratch ? bb : max_scratch;
+      w.saved[i] = cv.take<char>(mab_saved_bytes_any(*order[i]));
+    }
   }
   const size_t BN = (size_t)c.B * c.N, Bm = (size_t)c.B * c.m;
   w.H[0] = cv.take<float>(Bm * c.d);
@@ -134,10 +137,8 @@ inline size_t carve(const pca_st_config& c, int training, Ws* out, void* base) {
     w.dY2 = cv.take<float>(BN * c.d);
     w.dY1 = cv.take<float>(BN * c.d);
     w.dH = cv.take<float>(Bm * c.d);
-    w.scratch = cv.take<char>(max_bwd);
-  } else {
-    w.scratch = cv.take<char>(max_saved);   // inference: intermediates live in scratch
   }
+  w.scratch = cv.take<char>(max_scratch);   // per-call scratch, reused by every block
   if (out) *out = w;
   return cv.off;
 }
@@ -148,10 +149,8 @@ int validate(const pca_st_config* c) {
                   c->k > 0 && c->C > 0,
               "st: non-positive extent");
   PCA_REQUIRE(c->d % c->h == 0, "st: d=%d not divisible by h=%d", c->d, c->h);
-  if (c->mode != PCA_MODE_F32) {
-    set_error("st: mode %d not built", c->mode);
-    return PCA_EUNSUPPORTED;
-  }
+  PCA_REQUIRE(c->mode == PCA_MODE_F32 || c->mode == PCA_MODE_BF16, "st: unknown mode %d",
+              c->mode);
   return PCA_OK;
 }
 
@@ -159,16 +158,16 @@ int forward(const pca_st_config& c, const Layout& L, const Shapes& s, const floa
             const float* X, Ws& w, bool training, hipStream_t st) {
   const float* in = X;
   for (int li = 0; li < 2; ++li) {
-    void* sv0 = training ? w.saved[2 * li] : w.scratch;
-    void* sv1 = training ? w.saved[2 * li + 1] : w.scratch;
-    PCA_TRY(mab_f32_fwd(s.m0[li], p + L.I[li], in, params_at(p, L.mab0[li]), w.H[li], sv0,
-                        st));                                       // modules.py:52
-    PCA_TRY(mab_f32_fwd(s.m1[li], in, w.H[li], params_at(p, L.mab1[li]), w.Y[li], sv1,
-                        st));                                       // modules.py:53
+    void* sv0 = training ? w.saved[2 * li] : nullptr;
+    void* sv1 = training ? w.saved[2 * li + 1] : nullptr;
+    PCA_TRY(mab_fwd_any(s.m0[li], p + L.I[li], in, params_at(p, L.mab0[li]), w.H[li], sv0,
+                        w.scratch, st));                            // modules.py:52
+    PCA_TRY(mab_fwd_any(s.m1[li], in, w.H[li], params_at(p, L.mab1[li]), w.Y[li], sv1,
+                        w.scratch, st));                            // modules.py:53
     in = w.Y[li];
   }
-  PCA_TRY(mab_f32_fwd(s.pma, p + L.S, w.Y[1], params_at(p, L.pma), w.P,
-                      training ? w.saved[4] : w.scratch, st));      // modules.py:63
+  PCA_TRY(mab_fwd_any(s.pma, p + L.S, w.Y[1], params_at(p, L.pma), w.P,
+                      training ? w.saved[4] : nullptr, w.scratch, st));   // modules.py:63
   PCA_TRY(linear_fwd_f32(w.P, p + L.wc, p + L.bc, w.logits, (int64_t)c.B * c.k, c.d, c.C,
                          st));                                      // models.py:40
   return PCA_OK;
@@ -234,23 +233,23 @@ int pca_st_train_fwd_bwd(const pca_st_config* c, const float* params, const floa
     // dec.1 (Linear), dec.0 (PMA)
     PCA_TRY(pca::linear_bwd_f32(w.P, p + L.wc, w.dlogits, w.dP, g + L.wc, g + L.bc,
                                 (int64_t)c->B, c->d, c->C, st));
-    PCA_TRY(pca::mab_f32_bwd(s.pma, p + L.S, w.Y[1], pca::params_at(p, L.pma), w.saved[4],
+    PCA_TRY(pca::mab_bwd_any(s.pma, p + L.S, w.Y[1], pca::params_at(p, L.pma), w.saved[4],
                              w.dP, g + L.S, w.dY2, 0, pca::grads_at(g, L.pma), w.scratch,
                              st));
     // enc.1: mab1(Y1, H2) then mab0(I2, Y1); Y1 feeds both, so dY1 accumulates
-    PCA_TRY(pca::mab_f32_bwd(s.m1[1], w.Y[0], w.H[1], pca::params_at(p, L.mab1[1]),
+    PCA_TRY(pca::mab_bwd_any(s.m1[1], w.Y[0], w.H[1], pca::params_at(p, L.mab1[1]),
                              w.saved[3], w.dY2, w.dY1, w.dH, 0, pca::grads_at(g, L.mab1[1]),
                              w.scratch, st));
-    PCA_TRY(pca::mab_f32_bwd(s.m0[1], p + L.I[1], w.Y[0], pca::params_at(p, L.mab0[1]),
+    PCA_TRY(pca::mab_bwd_any(s.m0[1], p + L.I[1], w.Y[0], pca::params_at(p, L.mab0[1]),
                              w.saved[2], w.dH, g + L.I[1], w.dY1, 1,
                              pca::grads_at(g, L.mab0[1]), w.scratch, st));
   }
   if (phase != 0) {
     // enc.0: the set itself needs no gradient
-    PCA_TRY(pca::mab_f32_bwd(s.m1[0], X, w.H[0], pca::params_at(p, L.mab1[0]), w.saved[1],
+    PCA_TRY(pca::mab_bwd_any(s.m1[0], X, w.H[0], pca::params_at(p, L.mab1[0]), w.saved[1],
                              w.dY1, nullptr, w.dH, 0, pca::grads_at(g, L.mab1[0]),
                              w.scratch, st));
-    PCA_TRY(pca::mab_f32_bwd(s.m0[0], p + L.I[0], X, pca::params_at(p, L.mab0[0]),
+    PCA_TRY(pca::mab_bwd_any(s.m0[0], p + L.I[0], X, pca::params_at(p, L.mab0[0]),
                              w.saved[0], w.dH, g + L.I[0], nullptr, 0,
                              pca::grads_at(g, L.mab0[0]), w.scratch, st));
   }

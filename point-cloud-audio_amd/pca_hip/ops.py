@@ -62,6 +62,17 @@ def _shape(B, nq, nk, dq, dk, d, h, q_shared, mode=_lib.MODE_F32) -> MabShape:
                     _lib.PCA_F32, _lib.PCA_F32)
 
 
+def _pick_mode(s: MabShape) -> MabShape:
+    """Resolve the arithmetic mode of one block: 'bf16' demands the fused kernel, 'auto' takes
+    it where the library has one for this shape (pca_mab_saved_bytes() > 0) else exact fp32."""
+    if _MODE == "f32":
+        return s
+    s.mode = _lib.MODE_BF16
+    if _MODE == "auto" and lib().pca_mab_saved_bytes(C.byref(s)) == 0:
+        s.mode = _lib.MODE_F32
+    return s
+
+
 class _MabFn(torch.autograd.Function):
     """set_transformer-master/modules.py:19-33 MAB.forward + its adjoint."""
 
@@ -80,14 +91,18 @@ class _MabFn(torch.autograd.Function):
         d = params[0].shape[0]
         if params[0].shape[1] != dq or params[2].shape[1] != dk:
             raise RuntimeError("MAB: input width does not match fc_q / fc_k")
-        s = _shape(B, nq, nk, dq, dk, d, num_heads, q_shared)
+        s = _pick_mode(_shape(B, nq, nk, dq, dk, d, num_heads, q_shared))
         L = lib()
         with torch.cuda.device(K.device):
             Y = torch.empty((B, nq, d), dtype=torch.float32, device=K.device)
-            saved = _bytes(L.pca_mab_saved_bytes(C.byref(s)), K)
+            nsaved = L.pca_mab_saved_bytes(C.byref(s))
+            if nsaved == 0:
+                raise _lib.PcaHipError("pca_mab_saved_bytes: " + L.pca_last_error().decode())
+            saved = _bytes(nsaved, K)
+            ws = _bytes(L.pca_mab_fwd_ws_bytes(C.byref(s)), K)
             pp = MabParams(*[_ptr(p) for p in params])
             check(L.pca_mab_fwd(C.byref(s), _ptr(Q), _ptr(K), C.byref(pp), _ptr(Y),
-                                _ptr(saved), None, _stream(K)), "pca_mab_fwd")
+                                _ptr(saved), _ptr(ws), _stream(K)), "pca_mab_fwd")
         ctx.s = s
         ctx.save_for_backward(Q, K, saved, *params)
         return Y
@@ -130,7 +145,7 @@ def mab_infer(Q, K, params, num_heads: int, q_shared: bool = False) -> torch.Ten
     B, nk, dk = K.shape
     nq, dq = Q.shape[-2], Q.shape[-1]
     d = params[0].shape[0]
-    s = _shape(B, nq, nk, dq, dk, d, num_heads, q_shared)
+    s = _pick_mode(_shape(B, nq, nk, dq, dk, d, num_heads, q_shared))
     L = lib()
     with torch.cuda.device(K.device):
         Y = torch.empty((B, nq, d), dtype=torch.float32, device=K.device)

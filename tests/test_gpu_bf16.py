@@ -1,0 +1,153 @@
+"""GPU parity of the fused bf16 MFMA kernels (PCA_MODE_BF16) against the CPU oracle.
+
+Tolerance: bf16 MFMA operands (8 significant bits) with fp32 accumulation, softmax, biases
+and residuals.  Measured error of the fused block is ~3e-3 of max|Y|; the tests allow 1.5e-2
+relative to max(1, max|ref|) for activations and 3e-2 for gradients.
+"""
+import numpy as np
+import pytest
+import torch
+
+from util import T, close, close_robust
+
+pytestmark = pytest.mark.gpu
+
+FWD_TOL = 1.5e-2
+BWD_TOL = 3e-2
+
+
+@pytest.fixture(scope="module")
+def dev():
+    import pca_hip
+    pca_hip.lib()
+    yield torch.device("cuda", 0)
+    pca_hip.set_mode("f32")
+
+
+def _mab_params(dq, dk, d, seed):
+    g = torch.Generator().manual_seed(seed)
+    p = {}
+    for nm, din in (("fc_q", dq), ("fc_k", dk), ("fc_v", dk), ("fc_o", d)):
+        bound = 1.0 / np.sqrt(din)
+        p[nm + ".weight"] = (torch.rand(d, din, generator=g) * 2 - 1) * bound
+        p[nm + ".bias"] = (torch.rand(d, generator=g) * 2 - 1) * bound
+    return p
+
+
+MAB1_CASES = [      # B, N, m, dq, d, h
+    (3, 200, 16, 128, 128, 4),        # ragged N (tile of 128)
+    (2, 128, 32, 128, 128, 4),
+    (2, 77, 16, 2, 128, 4),           # layer 1: exact VALU projection of (f, logmag)
+    (1, 1, 16, 3, 128, 4),            # a single point
+    (5, 512, 16, 128, 128, 4),
+]
+
+
+@pytest.mark.parametrize("case", MAB1_CASES, ids=[str(c) for c in MAB1_CASES])
+def test_mab1_fwd_bf16(dev, case):
+    import modules
+    import pca_hip
+    from oracle import st_oracle as orc
+    B, N, m, dq, d, h = case
+    p = _mab_params(dq, d, d, seed=sum(case))
+    g = torch.Generator().manual_seed(1 + sum(case))
+    X = torch.randn(B, N, dq, generator=g)
+    if dq <= 4:
+        X[..., -1] = X[..., -1] * 3 - 9                      # log-magnitude-like column
+    H = torch.randn(B, m, d, generator=g)
+    ref = orc.mab_forward(X, H, p, h)
+    mab = modules.MAB(dq, d, d, h).to(dev)
+    mab.load_state_dict(p)
+    pca_hip.set_mode("bf16")
+    with torch.no_grad():
+        Y = mab(X.to(dev), H.to(dev))
+    pca_hip.set_mode("f32")
+    err = close(Y, ref, FWD_TOL, f"mab1 fwd {case}")
+    print(f"mab1 fwd {case}: max err {err:.3e} (max|ref| {float(ref.abs().max()):.2f})")
+
+
+@pytest.mark.parametrize("case", MAB1_CASES, ids=[str(c) for c in MAB1_CASES])
+def test_mab1_bwd_bf16(dev, case):
+    """Fused backward chain + MFMA weight-gradient reductions.
+
+    Checked against autograd of the oracle's bf16-operand emulation (same rounding points as
+    the kernel, hence the same ReLU mask): that isolates kernel correctness from the
+    discontinuity of ReLU' under reduced precision.  The emulation itself is held to the exact
+    fp32 oracle in rms (the precision statement of the bf16 mode)."""
+    import modules
+    import pca_hip
+    from oracle import st_oracle as orc
+    B, N, m, dq, d, h = case
+    p = _mab_params(dq, d, d, seed=sum(case))
+    g = torch.Generator().manual_seed(1 + sum(case))
+    X = torch.randn(B, N, dq, generator=g)
+    if dq <= 4:
+        X[..., -1] = X[..., -1] * 3 - 9
+    H = torch.randn(B, m, d, generator=g)
+    G = torch.randn(B, N, d, generator=g)
+    exact = orc.mab_backward(G, X, H, p, h)
+    leaves = {k: v.clone().requires_grad_(True) for k, v in p.items()}
+    Xe, He = X.clone().requires_grad_(True), H.clone().requires_grad_(True)
+    Ye = orc.mab1_forward_bf16emu(Xe, He, leaves, h)
+    (Ye * G).sum().backward()
+    emu = {k: v.grad for k, v in leaves.items()}
+    emu["dQ"], emu["dK"] = Xe.grad, He.grad
+
+    mab = modules.MAB(dq, d, d, h).to(dev)
+    mab.load_state_dict(p)
+    Xd = X.to(dev).requires_grad_(dq > 4)
+    Hd = H.to(dev).requires_grad_(True)
+    pca_hip.set_mode("bf16")
+    Y = mab(Xd, Hd)
+    (Y * G.to(dev)).sum().backward()
+    pca_hip.set_mode("f32")
+    close(Y, Ye, 2e-3, "Y vs bf16 emulation")
+    got = {"dK": Hd.grad}
+    if dq > 4:
+        got["dQ"] = Xd.grad
+    for k, prm in mab.named_parameters():
+        got[k] = prm.grad
+    errs = {}
+    for k, v in got.items():
+        if k == "fc_k.bias":
+            # d/d(bk) is identically 0 (softmax is shift invariant): what is left is the
+            # rounding noise of sums of dKp rows, so judge it on the scale of d/d(Wk)
+            sc = max(1.0, float(emu["fc_k.weight"].abs().max()))
+            assert float((v.cpu() - emu[k]).abs().max()) <= 1.5e-2 * sc
+        else:
+            errs[k] = close_robust(v, emu[k], 1.5e-2, k)
+        sc = max(1.0, float(exact[k].abs().max()))
+        if k == "fc_k.bias":
+            sc = max(1.0, float(exact["fc_k.weight"].abs().max()))
+        rms = float((emu[k] - exact[k]).pow(2).mean().sqrt()) / sc
+        assert rms < 3e-2, (k, rms)     # bf16 emulation vs exact fp32 (incl. ReLU-mask flips)
+    print(f"mab1 bwd {case}: " + " ".join(f"{k}={v:.1e}" for k, v in errs.items()))
+
+
+def test_engine_bf16_vs_golden(dev, golden_st):
+    """Whole ST (BASELINE cfg1/2 architecture) with mode = BF16: fused kernels where built,
+    exact fp32 elsewhere; logits and all gradients vs the reference's golden vectors."""
+    import inputs as gi
+    import models
+    from pca_hip import _lib, trainer
+    ci = 2
+    name, B, N, din, d, h, m, C, full = gi.ST_CASES[ci]
+    net = models.ST(dim_input=din, num_outputs=1, dim_output=C, num_inds=m, dim_hidden=d,
+                    num_heads=h).to(dev)
+    net.load_state_dict({k: T(v) for k, v in golden_st.sub(f"{name}/p/").items()})
+    X = T(gi.pc_input(600 + ci, B, N, din), dev)
+    y = T(gi.labels(700 + ci, B, C), dev)
+    eng = trainer.STEngine(net, B, N, mode=_lib.MODE_BF16, training=True)
+    eng.fwd_bwd(X, y, phase=-1)
+    ref = golden_st[f"{name}/logits"]
+    err = close(eng.logits, ref, FWD_TOL, "logits")
+    assert (eng.logits.argmax(1).cpu().numpy() == ref.argmax(1)).all()
+    off, worst = 0, 0.0
+    for k, prm in net.named_parameters():
+        gr = eng.grads[off:off + prm.numel()].view_as(prm)
+        off += prm.numel()
+        worst = max(worst, close_robust(gr, golden_st[f"{name}/g/{k}"], BWD_TOL, k,
+                                        outlier_frac=2e-3))
+    print(f"engine bf16: logits err {err:.2e}, worst grad err {worst:.2e}")
+    inf = trainer.STEngine(net, B, N, mode=_lib.MODE_BF16, training=False)
+    close(inf.forward(X), ref, FWD_TOL, "logits(inference)")
