@@ -23,6 +23,16 @@ size_t mab1_bf16_fwd_ws_bytes(const pca_mab_shape& s);
 int mab1_bf16_fwd(const pca_mab_shape& s, const float* X, const float* H,
                   const pca_mab_params& p, float* Y, void* saved, void* ws, hipStream_t st);
 
+bool mab0_bf16_supported(const pca_mab_shape& s);
+size_t mab0_bf16_saved_bytes(const pca_mab_shape& s);
+size_t mab0_bf16_fwd_ws_bytes(const pca_mab_shape& s);
+int mab0_bf16_fwd(const pca_mab_shape& s, const float* I, const float* X,
+                  const pca_mab_params& p, float* H, void* saved, void* ws, hipStream_t st);
+size_t mab0_bf16_bwd_ws_bytes(const pca_mab_shape& s);
+int mab0_bf16_bwd(const pca_mab_shape& s, const float* I, const float* X,
+                  const pca_mab_params& p, const void* saved, const float* dH, float* dI,
+                  float* dX, int dk_accumulate, const pca_mab_grads& gr, void* ws,
+                  hipStream_t st);
 size_t mab1_bf16_bwd_ws_bytes(const pca_mab_shape& s);
 int mab1_bf16_bwd(const pca_mab_shape& s, const float* X, const float* H,
                   const pca_mab_params& p, const void* saved, const float* dY, float* dX,
@@ -36,30 +46,43 @@ static int check_f32(const pca_mab_shape* s) {
 }
 
 // ---- mode resolution + dispatch, shared by the C entry points and the ST engine ----
-// kind: 0 = exact fp32 chain of GEMMs, 1 = fused bf16 mab1 (many queries, few keys)
+// kind: 0 = exact fp32 chain of GEMMs, 1 = fused bf16 mab1 (many queries, few keys),
+//       2 = fused bf16 mab0 (few shared queries, many keys)
 int mab_kind(const pca_mab_shape& s) {
   if (s.mode == PCA_MODE_BF16 && mab1_bf16_supported(s)) return 1;
+  if (s.mode == PCA_MODE_BF16 && mab0_bf16_supported(s)) return 2;
   return 0;
 }
 size_t mab_saved_bytes_any(const pca_mab_shape& s) {
-  return mab_kind(s) == 1 ? mab1_bf16_saved_bytes(s) : mab_f32_saved_bytes(s);
+  const int k = mab_kind(s);
+  return k == 1 ? mab1_bf16_saved_bytes(s) : k == 2 ? mab0_bf16_saved_bytes(s)
+                                                    : mab_f32_saved_bytes(s);
 }
 size_t mab_fwd_ws_bytes_any(const pca_mab_shape& s) {
   // inference (saved == NULL) keeps the intermediates in the scratch block instead
-  return mab_kind(s) == 1 ? mab1_bf16_fwd_ws_bytes(s) : mab_f32_saved_bytes(s);
+  const int k = mab_kind(s);
+  return k == 1 ? mab1_bf16_fwd_ws_bytes(s) : k == 2 ? mab0_bf16_fwd_ws_bytes(s)
+                                                     : mab_f32_saved_bytes(s);
 }
 size_t mab_bwd_ws_bytes_any(const pca_mab_shape& s) {
-  return mab_kind(s) == 1 ? mab1_bf16_bwd_ws_bytes(s) : mab_f32_bwd_ws_bytes(s);
+  const int k = mab_kind(s);
+  return k == 1 ? mab1_bf16_bwd_ws_bytes(s) : k == 2 ? mab0_bf16_bwd_ws_bytes(s)
+                                                     : mab_f32_bwd_ws_bytes(s);
 }
 int mab_fwd_any(const pca_mab_shape& s, const float* Q, const float* K, const pca_mab_params& p,
                 float* Y, void* saved, void* ws, hipStream_t st) {
-  if (mab_kind(s) == 1) return mab1_bf16_fwd(s, Q, K, p, Y, saved, ws, st);
+  const int k = mab_kind(s);
+  if (k == 1) return mab1_bf16_fwd(s, Q, K, p, Y, saved, ws, st);
+  if (k == 2) return mab0_bf16_fwd(s, Q, K, p, Y, saved, ws, st);
   return mab_f32_fwd(s, Q, K, p, Y, saved ? saved : ws, st);
 }
 int mab_bwd_any(const pca_mab_shape& s, const float* Q, const float* K, const pca_mab_params& p,
                 const void* saved, const float* dY, float* dQ, float* dK, int dk_accumulate,
                 const pca_mab_grads& g, void* ws, hipStream_t st) {
-  if (mab_kind(s) == 1)
+  const int k = mab_kind(s);
+  if (k == 2)
+    return mab0_bf16_bwd(s, Q, K, p, saved, dY, dQ, dK, dk_accumulate, g, ws, st);
+  if (k == 1)
     return mab1_bf16_bwd(s, Q, K, p, saved, dY, dQ, dK, dk_accumulate, g, ws, st);
   return mab_f32_bwd(s, Q, K, p, saved, dY, dQ, dK, dk_accumulate, g, ws, st);
 }
@@ -71,7 +94,7 @@ extern "C" {
 // arithmetic at this level); callers that want "bf16 where available" query
 // pca_mab_saved_bytes() first, which returns 0 for unsupported bf16 shapes.
 static int bf16_demand(const pca_mab_shape* s) {
-  if (s->mode == PCA_MODE_BF16 && pca::mab_kind(*s) != 1) {
+  if (s->mode == PCA_MODE_BF16 && pca::mab_kind(*s) == 0) {
     pca::set_error("mab: no bf16 kernel for B=%d nq=%d nk=%d dq=%d dk=%d d=%d h=%d q_shared=%d",
                    s->B, s->nq, s->nk, s->dq, s->dk, s->d, s->h, s->q_shared);
     return PCA_EUNSUPPORTED;

@@ -1,0 +1,435 @@
+// Fused bf16-MFMA forward of the "few queries, many keys" MAB: ISAB's mab0(I, X)
+// (set_transformer-master/modules.py:52) and PMA's mab(S, X) (modules.py:63), where the
+// query is a learned [m, d] tensor shared by all sets.
+//
+// Reassociation (exact algebra, SURVEY.md 8d "reassociation caveat"): with Qp = fc_q(I),
+//   scores_h = Qp_h (X Wk_h^T + bk_h)^T = (Qp_h Wk_h) X^T + const_per_query
+//   A_h (X Wv_h^T + bv_h)               = (A_h X) Wv_h^T + bv_h        (rows of A sum to 1)
+// and the per-query constant cancels in the softmax, so the N keys are never projected:
+//   G = [Qp_h Wk_h]_h   (R = h*m rows, batch invariant)   S = G X^T   A = softmax_N(S/sqrt d)
+//   T = A X  [R, dk]    O_h = Qp_h + T_h Wv_h^T + bv_h     H = O + relu(fc_o(O))
+// This is flash attention whose keys AND values are the same X tile: X is read once.
+//
+//   k_mab0_prep   Qp, G (bf16, scale*log2e folded in) -- once per call, tiny
+//   k_mab0_attn   one workgroup per set; each wave streams 32-point tiles: S = X G^T on the
+//                 MFMA (points on accumulator rows, so the softmax statistics of a query row
+//                 are lane-local + 2 cross-lane steps), online softmax, T += P^T X with the
+//                 probability tile fed back as the A operand straight from the accumulators
+//                 and X^T read from the same LDS tile through ds_read_tr16_b64
+//   k_mab0_attn_small   layer 1 (dk = din <= 4): exact fp32 on the vector ALU
+//   k_mab0_epi    per set: O, Z, H (fp32 VALU; 2*m*d*(dk+d) MACs)
+#include "mab1_bf16.hpp"
+
+#include <math.h>
+
+#include <mutex>
+
+namespace pca {
+
+namespace {
+
+__device__ __forceinline__ int tr_off(int row, int ch) {
+  return 256 * row + 16 * (ch ^ (((row & 3) << 2) | ((row >> 2) & 3)));
+}
+typedef __attribute__((address_space(3))) s16x4 lds_s16x4;
+__device__ __forceinline__ bf16x8 tr_frag(const char* img, int t, int lane) {
+  const int g = lane >> 4, i16 = lane & 15, q = i16 >> 2, p = i16 & 3;
+  const int a0 = tr_off(4 * g + q, 2 * t + (p >> 1)) + 8 * (p & 1);
+  const int a1 = tr_off(16 + 4 * g + q, 2 * t + (p >> 1)) + 8 * (p & 1);
+  const s16x4 lo = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_s16x4*)(img + a0));
+  const s16x4 hi = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_s16x4*)(img + a1));
+  const bf16x4 l4 = __builtin_bit_cast(bf16x4, lo), h4 = __builtin_bit_cast(bf16x4, hi);
+  bf16x8 r;
+#pragma unroll
+  for (int e = 0; e < 4; ++e) { r[e] = l4[e]; r[4 + e] = h4[e]; }
+  return r;
+}
+
+// ---------------------------------------------------------------------------------
+// Qp[m][d] = I Wq^T + bq (fp32) ; G[h*m][dk] = scale*log2(e) * Qp_h Wk_h   (bf16 + fp32)
+// one block per query row q; threads over output columns
+// ---------------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void k_mab0_prep(const float* __restrict__ I,
+                                                   const float* __restrict__ Wq,
+                                                   const float* __restrict__ bq,
+                                                   const float* __restrict__ Wk, int m, int d,
+                                                   int dq, int dk, int h, float sl2e,
+                                                   float* __restrict__ Qp,
+                                                   float* __restrict__ Gf,
+                                                   __bf16* __restrict__ Gb, int Rpad) {
+  extern __shared__ float sq[];            // Qp row [d]
+  const int q = blockIdx.x;
+  for (int f = threadIdx.x; f < d; f += 256) {
+    float a = bq[f];
+    for (int c = 0; c < dq; ++c) a += I[q * dq + c] * Wq[f * dq + c];
+    sq[f] = a;
+    Qp[q * d + f] = a;
+  }
+  __syncthreads();
+  const int dh = d / h;
+  for (int o = threadIdx.x; o < h * dk; o += 256) {
+    const int j = o / dk, c = o - j * dk;
+    float a = 0.f;
+    for (int f = 0; f < dh; ++f) a += sq[j * dh + f] * Wk[(j * dh + f) * dk + c];
+    a *= sl2e;
+    const int r = j * m + q;
+    Gf[r * dk + c] = a;
+    if (Gb != nullptr) Gb[r * dk + c] = (__bf16)a;
+  }
+  // padding rows (PMA: R = h < 16) are zeroed by the host once
+  (void)Rpad;
+}
+
+// ---------------------------------------------------------------------------------
+// attention over the points, dk == 128
+// ---------------------------------------------------------------------------------
+struct Mab0AttnArgs {
+  const float* X;       // [B, N, 128] fp32
+  const __bf16* Gb;     // [16*RB][128]  (scale*log2e folded in; padding rows zero)
+  float* T;             // [B][R][128] fp32, normalised
+  float* LSE;           // [B][R]  log2-domain logsumexp of the scaled scores
+  int B, N, R;
+};
+
+template <int RB>
+__global__ __launch_bounds__(256, 1) void k_mab0_attn(const Mab0AttnArgs a) {
+  constexpr int DK = 128, FT = DK / 16, KS = DK / 32;
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  char* sG = smem;                                    // [16 RB][256 B] tr_off image rows
+  char* sX = sG + 16 * RB * 256;                      // 4 waves x 32 rows x 256 B
+  constexpr int XBYTES = (4 * 32 * 256 > 16 * RB * DK * 4) ? 4 * 32 * 256 : 16 * RB * DK * 4;
+  float* sAl = reinterpret_cast<float*>(sX + XBYTES);   // 4 waves x 16 RB
+  float* sM = sAl + 4 * 16 * RB;                      // merge: [4][16 RB] m, then l
+  float* sL = sM + 4 * 16 * RB;
+  float* sT = reinterpret_cast<float*>(sX);           // merge buffer aliases the X tiles
+
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int r = lane & 15, g = lane >> 4;
+  const int b = blockIdx.x;
+
+  for (int c = tid; c < 16 * RB * 16; c += 256) {
+    const int row = c >> 4, ch = c & 15;
+    *reinterpret_cast<uint4*>(sG + tr_off(row, ch)) =
+        *reinterpret_cast<const uint4*>(a.Gb + (int64_t)row * DK + ch * 8);
+  }
+  __syncthreads();
+
+  char* myX = sX + wave * 32 * 256;
+  float* myAl = sAl + wave * 16 * RB;
+  float mrow[RB], lrow[RB];
+  f32x4 T[RB][FT];
+#pragma unroll
+  for (int rb = 0; rb < RB; ++rb) {
+    mrow[rb] = -INFINITY;
+    lrow[rb] = 0.f;
+#pragma unroll
+    for (int ft = 0; ft < FT; ++ft) T[rb][ft] = f32x4{0.f, 0.f, 0.f, 0.f};
+  }
+
+  for (int n0 = wave * 32; n0 < a.N; n0 += 128) {
+    // stage 32 rows of X (fp32 -> bf16)
+#pragma unroll
+    for (int e = 0; e < 8; ++e) {
+      const int c = lane + 64 * e;
+      const int row = c >> 4, ch = c & 15;
+      bf16x8 v;
+      if (n0 + row < a.N) {
+        const float4* src = reinterpret_cast<const float4*>(
+            a.X + ((int64_t)b * a.N + n0 + row) * DK + ch * 8);
+        const float4 lo = src[0], hi = src[1];
+        v[0] = (__bf16)lo.x; v[1] = (__bf16)lo.y; v[2] = (__bf16)lo.z; v[3] = (__bf16)lo.w;
+        v[4] = (__bf16)hi.x; v[5] = (__bf16)hi.y; v[6] = (__bf16)hi.z; v[7] = (__bf16)hi.w;
+      } else {
+#pragma unroll
+        for (int k = 0; k < 8; ++k) v[k] = (__bf16)0.f;
+      }
+      *reinterpret_cast<bf16x8*>(myX + tr_off(row, ch)) = v;
+    }
+    bf16x8 xrow[2][KS], xtr[FT];
+#pragma unroll
+    for (int pb = 0; pb < 2; ++pb)
+#pragma unroll
+      for (int ks = 0; ks < KS; ++ks)
+        xrow[pb][ks] = *reinterpret_cast<const bf16x8*>(myX + tr_off(16 * pb + r, 4 * ks + g));
+#pragma unroll
+    for (int ft = 0; ft < FT; ++ft) xtr[ft] = tr_frag(myX, ft, lane);
+
+#pragma unroll
+    for (int rb = 0; rb < RB; ++rb) {
+      f32x4 s[2];
+#pragma unroll
+      for (int pb = 0; pb < 2; ++pb) {
+        s[pb] = f32x4{0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+        for (int ks = 0; ks < KS; ++ks)
+          s[pb] = mfma32(xrow[pb][ks],
+                         *reinterpret_cast<const bf16x8*>(sG + tr_off(16 * rb + r, 4 * ks + g)),
+                         s[pb]);
+      }
+      // rows of s = points 16 pb + 4 g + e ; column = query row 16 rb + r
+      float mt = -INFINITY;
+#pragma unroll
+      for (int pb = 0; pb < 2; ++pb)
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+          if (n0 + 16 * pb + 4 * g + e >= a.N) s[pb][e] = -INFINITY;
+          mt = fmaxf(mt, s[pb][e]);
+        }
+      mt = wave16_max(mt);
+      const float mnew = fmaxf(mrow[rb], mt);      // finite: every tile has >= 1 live point
+      const float alpha = exp2f(mrow[rb] - mnew);
+      float ls = 0.f;
+#pragma unroll
+      for (int pb = 0; pb < 2; ++pb)
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+          s[pb][e] = exp2f(s[pb][e] - mnew);
+          ls += s[pb][e];
+        }
+      ls = wave16_sum(ls);
+      lrow[rb] = lrow[rb] * alpha + ls;
+      mrow[rb] = mnew;
+      // the T tiles hold query rows 4g+e on their accumulator rows: fetch their alphas
+      if (g == 0) myAl[16 * rb + r] = alpha;
+      const float4 a4 = *reinterpret_cast<const float4*>(&myAl[16 * rb + 4 * g]);
+      const bf16x8 pa = pack8(s[0], s[1]);
+#pragma unroll
+      for (int ft = 0; ft < FT; ++ft) {
+        T[rb][ft][0] *= a4.x; T[rb][ft][1] *= a4.y; T[rb][ft][2] *= a4.z; T[rb][ft][3] *= a4.w;
+        T[rb][ft] = mfma32(pa, xtr[ft], T[rb][ft]);
+      }
+    }
+  }
+
+  // ---- merge the four waves' partial (m, l, T) ----
+  __syncthreads();                       // X tiles are dead: sT may alias them
+  if (g == 0) {
+#pragma unroll
+    for (int rb = 0; rb < RB; ++rb) {
+      sM[wave * 16 * RB + 16 * rb + r] = mrow[rb];
+      sL[wave * 16 * RB + 16 * rb + r] = lrow[rb];
+    }
+  }
+  for (int i = tid; i < 16 * RB * DK; i += 256) sT[i] = 0.f;
+  __syncthreads();
+#pragma unroll
+  for (int rb = 0; rb < RB; ++rb) {
+    // factor of this wave for query rows 4g+e of block rb (accumulator-row layout)
+    float f4[4];
+#pragma unroll
+    for (int e = 0; e < 4; ++e) {
+      const int rr = 16 * rb + 4 * g + e;
+      const float M = fmaxf(fmaxf(sM[rr], sM[16 * RB + rr]),
+                            fmaxf(sM[2 * 16 * RB + rr], sM[3 * 16 * RB + rr]));
+      const float mine = sM[wave * 16 * RB + rr];
+      f4[e] = (mine == -INFINITY) ? 0.f : exp2f(mine - M);
+    }
+#pragma unroll
+    for (int ft = 0; ft < FT; ++ft)
+#pragma unroll
+      for (int e = 0; e < 4; ++e)
+        atomicAdd(&sT[(16 * rb + 4 * g + e) * DK + 16 * ft + r], T[rb][ft][e] * f4[e]);
+  }
+  __syncthreads();
+  for (int i = tid; i < a.R * DK; i += 256) {
+    const int rr = i / DK;
+    float M = -INFINITY;
+#pragma unroll
+    for (int w = 0; w < 4; ++w) M = fmaxf(M, sM[w * 16 * RB + rr]);
+    float L = 0.f;
+#pragma unroll
+    for (int w = 0; w < 4; ++w) {
+      const float mw = sM[w * 16 * RB + rr];
+      if (mw != -INFINITY) L += sL[w * 16 * RB + rr] * exp2f(mw - M);
+    }
+    a.T[((int64_t)b * a.R + rr) * DK + (i - rr * DK)] = sT[i] / L;
+    if (i == rr * DK) a.LSE[(int64_t)b * a.R + rr] = M + log2f(L);
+  }
+}
+
+// ---------------------------------------------------------------------------------
+// layer 1: dk = din <= 4, exact fp32.  One workgroup per set; thread = (query row r,
+// point partition); R <= 256.
+// ---------------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void k_mab0_attn_small(const float* __restrict__ X,
+                                                         const float* __restrict__ Gf, int N,
+                                                         int R, int dk, float* __restrict__ T,
+                                                         float* __restrict__ LSE) {
+  __shared__ float sM[256], sL[256], sT[256][4];
+  const int b = blockIdx.x, tid = threadIdx.x;
+  const int parts = 256 / R;                 // R in {64, 128, 256}
+  const int r = tid % R, part = tid / R;
+  float gk[4];
+#pragma unroll
+  for (int c = 0; c < 4; ++c) gk[c] = c < dk ? Gf[r * dk + c] : 0.f;
+  float m = -INFINITY, l = 0.f, t[4] = {0.f, 0.f, 0.f, 0.f};
+  if (part < parts) {
+    for (int n = part; n < N; n += parts) {
+      float x[4];
+#pragma unroll
+      for (int c = 0; c < 4; ++c) x[c] = c < dk ? X[((int64_t)b * N + n) * dk + c] : 0.f;
+      const float s = gk[0] * x[0] + gk[1] * x[1] + gk[2] * x[2] + gk[3] * x[3];
+      const float mn = fmaxf(m, s);
+      const float al = exp2f(m - mn), p = exp2f(s - mn);
+      l = l * al + p;
+#pragma unroll
+      for (int c = 0; c < 4; ++c) t[c] = t[c] * al + p * x[c];
+      m = mn;
+    }
+  }
+  sM[tid] = m; sL[tid] = l;
+#pragma unroll
+  for (int c = 0; c < 4; ++c) sT[tid][c] = t[c];
+  __syncthreads();
+  if (tid < R) {
+    float M = -INFINITY;
+    for (int p = 0; p < parts; ++p) M = fmaxf(M, sM[p * R + tid]);
+    float L = 0.f, tt[4] = {0.f, 0.f, 0.f, 0.f};
+    for (int p = 0; p < parts; ++p) {
+      const float mw = sM[p * R + tid];
+      if (mw == -INFINITY) continue;
+      const float f = exp2f(mw - M);
+      L += sL[p * R + tid] * f;
+#pragma unroll
+      for (int c = 0; c < 4; ++c) tt[c] += sT[p * R + tid][c] * f;
+    }
+    for (int c = 0; c < dk; ++c) T[((int64_t)b * R + tid) * dk + c] = tt[c] / L;
+    LSE[(int64_t)b * R + tid] = M + log2f(L);
+  }
+}
+
+// ---------------------------------------------------------------------------------
+// per-set epilogue: O[q][32j+f] = Qp[q][.] + T[j*m+q][:] . Wv[32j+f][:] + bv ; Z = O Wo^T + bo
+// H = O + relu(Z).  O and Z are saved for the backward.
+// ---------------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void k_mab0_epi(const float* __restrict__ T,
+                                                  const float* __restrict__ Qp,
+                                                  const float* __restrict__ Wv,
+                                                  const float* __restrict__ bv,
+                                                  const float* __restrict__ Wo,
+                                                  const float* __restrict__ bo, int m, int d,
+                                                  int dk, int h, float* __restrict__ H,
+                                                  float* __restrict__ Osave,
+                                                  float* __restrict__ Zsave) {
+  extern __shared__ float sm[];
+  float* sT = sm;                 // [h*m][dk]
+  float* sO = sT + h * m * dk;    // [m][d]
+  const int b = blockIdx.x, tid = threadIdx.x;
+  const int R = h * m, dh = d / h;
+  for (int i = tid; i < R * dk; i += 256) sT[i] = T[(int64_t)b * R * dk + i];
+  __syncthreads();
+  for (int o = tid; o < m * d; o += 256) {
+    const int q = o / d, f = o - q * d, j = f / dh;
+    const float* trow = sT + (j * m + q) * dk;
+    const float* w = Wv + (int64_t)f * dk;
+    float acc = Qp[q * d + f] + bv[f];
+    for (int c = 0; c < dk; ++c) acc += trow[c] * w[c];
+    sO[o] = acc;
+  }
+  __syncthreads();
+  for (int o = tid; o < m * d; o += 256) {
+    const int q = o / d, f = o - q * d;
+    const float* orow = sO + q * d;
+    const float* w = Wo + (int64_t)f * d;
+    float z = bo[f];
+    for (int c = 0; c < d; c += 4) {
+      const float4 w4 = *reinterpret_cast<const float4*>(w + c);
+      z += orow[c] * w4.x + orow[c + 1] * w4.y + orow[c + 2] * w4.z + orow[c + 3] * w4.w;
+    }
+    const float ov = sO[o];
+    H[(int64_t)b * m * d + o] = ov + fmaxf(z, 0.f);
+    if (Osave != nullptr) {
+      Osave[(int64_t)b * m * d + o] = ov;
+      Zsave[(int64_t)b * m * d + o] = z;
+    }
+  }
+}
+
+}  // namespace
+
+// ---- host side --------------------------------------------------------------------
+bool mab0_bf16_supported(const pca_mab_shape& s) {
+  const int R = s.h * s.nq;
+  return s.q_shared == 1 && s.d == 128 && s.h * 32 == s.d && s.dq == s.d &&
+         ((s.dk == s.d && (R <= 16 || R == 64)) ||
+          (s.dk <= 4 && (R == 64 || R == 128 || R == 256))) &&
+         s.q_dtype == PCA_F32 && s.k_dtype == PCA_F32 && s.y_dtype == PCA_F32;
+}
+
+size_t mab0_carve_saved(const pca_mab_shape& s, Mab0Saved* out, void* base) {
+  Carver c(base);
+  Mab0Saved v;
+  const int R = s.h * s.nq;
+  const int Rpad = (int)cdiv(R, 32) * 32;     // the backward contracts 32 rows per MFMA
+  v.Qp = c.take<float>((size_t)s.nq * s.d);
+  v.Gf = c.take<float>((size_t)Rpad * s.dk);
+  v.Gb = c.take<__bf16>((size_t)Rpad * s.dk);
+  v.T = c.take<float>((size_t)s.B * R * s.dk);
+  v.LSE = c.take<float>((size_t)s.B * R);
+  v.O = c.take<float>((size_t)s.B * s.nq * s.d);
+  v.Z = c.take<float>((size_t)s.B * s.nq * s.d);
+  if (out) *out = v;
+  return c.off;
+}
+
+size_t mab0_bf16_saved_bytes(const pca_mab_shape& s) {
+  return mab0_carve_saved(s, nullptr, nullptr);
+}
+size_t mab0_bf16_fwd_ws_bytes(const pca_mab_shape& s) {
+  return mab0_carve_saved(s, nullptr, nullptr);
+}
+
+int mab0_bf16_fwd(const pca_mab_shape& s, const float* I, const float* X,
+                  const pca_mab_params& p, float* H, void* saved, void* ws, hipStream_t st) {
+  PCA_REQUIRE(mab0_bf16_supported(s), "mab0_bf16_fwd: unsupported shape");
+  const bool training = saved != nullptr;
+  PCA_REQUIRE(training || ws != nullptr, "mab0_bf16_fwd: scratch required");
+  Mab0Saved v;
+  mab0_carve_saved(s, &v, training ? saved : ws);
+  const int d = s.d, m = s.nq, h = s.h, dk = s.dk, R = h * m;
+  const int Rpad = (int)cdiv(R, 16) * 16;
+  const int Rpad32 = (int)cdiv(R, 32) * 32;
+  const float sl2e = 1.4426950408889634f / sqrtf((float)d);
+  const bool small = dk <= 4;
+
+  if (!small && Rpad32 != R) {          // PMA: zero the padding rows of G
+    PCA_TRY(fill_zero(reinterpret_cast<float*>(v.Gb), (int64_t)Rpad32 * dk / 2, st));
+  }
+  hipLaunchKernelGGL(k_mab0_prep, dim3(m), dim3(256), d * sizeof(float), st, I, p.wq, p.bq, p.wk,
+                     m, d, s.dq, dk, h, sl2e, v.Qp, v.Gf, small ? nullptr : v.Gb, Rpad);
+  PCA_TRY(check_launch("k_mab0_prep"));
+
+  const double pts = (double)s.B * s.nk;
+  if (small) {
+    hipLaunchKernelGGL(k_mab0_attn_small, dim3(s.B), dim3(256), 0, st, X, v.Gf, s.nk, R, dk, v.T,
+                       v.LSE);
+    PCA_TRY(check_launch("k_mab0_attn_small"));
+  } else {
+    Mab0AttnArgs a{X, v.Gb, v.T, v.LSE, s.B, s.nk, R};
+    const int RB = Rpad / 16;
+    const size_t xbytes = (size_t)Rpad * 128 * 4 > 4 * 32 * 256 ? (size_t)Rpad * 128 * 4
+                                                                 : (size_t)4 * 32 * 256;
+    const size_t lds = (size_t)Rpad * 256 + xbytes + 3 * 4 * Rpad * sizeof(float);
+    // reference-formulation FLOPs of the block: fc_k, fc_v over the keys + QK^T + AV
+    ProfScope ps(PCA_K_MAB0_FWD, st, 2.0 * pts * (2.0 * dk * d + 2.0 * m * d),
+                 pts * 4.0 * dk);
+    static std::once_flag once;
+    std::call_once(once, [] {
+      (void)hipFuncSetAttribute(reinterpret_cast<const void*>(k_mab0_attn<8>),
+                                hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+      (void)hipFuncSetAttribute(reinterpret_cast<const void*>(k_mab0_attn<4>),
+                                hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+    });
+    if (RB == 1) hipLaunchKernelGGL((k_mab0_attn<1>), dim3(s.B), dim3(256), lds, st, a);
+    else if (RB == 4) hipLaunchKernelGGL((k_mab0_attn<4>), dim3(s.B), dim3(256), lds, st, a);
+    else hipLaunchKernelGGL((k_mab0_attn<8>), dim3(s.B), dim3(256), lds, st, a);
+    ps.end();
+    PCA_TRY(check_launch("k_mab0_attn"));
+  }
+  const size_t el = ((size_t)R * dk + (size_t)m * d) * sizeof(float);
+  hipLaunchKernelGGL(k_mab0_epi, dim3(s.B), dim3(256), el, st, v.T, v.Qp, p.wv, p.bv, p.wo, p.bo,
+                     m, d, dk, h, H, training ? v.O : nullptr, training ? v.Z : nullptr);
+  return check_launch("k_mab0_epi");
+}
+
+}  // namespace pca

@@ -1,0 +1,527 @@
+// Fused bf16-MFMA backward of the "few shared queries, many keys" MAB (ISAB mab0 / PMA) in
+// the reassociated form of mab0_bf16.hip.  With G' = sl2e * Qp_h Wk_h (sl2e = log2(e)/sqrt d),
+// P = exp2(G' X^T - lse), T = P X and the forward's epilogue O_h = Qp_h + T_h Wv_h^T + bv_h,
+// H = O + relu(O Wo^T + bo):
+//
+//   k_mab0_epi_bwd (per set, fp32 VALU)   dZ = dH.[Z>0] ; dO = dH + dZ Wo ; dT_h = dO_h Wv_h ;
+//                                         Delta = rowdot(dT, T)
+//   k_mab0_bwd     (per set, MFMA)        per 32-point tile of a wave, transposed layout
+//        S^T = G' X^T, dA^T = dT X^T  ->  P^T, dS^T = ln2 . P^T (dA^T - Delta)
+//        dX^T += dT^T P^T + G'^T dS^T        (both sums run over accumulator ROWS: in registers)
+//        dG   += dS X                         (sum over points: dS^T goes through a wave-private
+//                                              LDS tile and comes back transposed, X^T through
+//                                              ds_read_tr16_b64 of the X tile)
+//   k_mab0_bwd_small                      layer 1 (dk <= 4): fp32 VALU, no dX needed
+//   parameter gradients of the epilogue (dWo, dWv, dbo, dbv) are [B*m]-row reductions done with
+//   the fp32 GEMM; k_mab0_post turns sum_b dO and dG into dWk, dWq, dbq, dI.  d(bk) is
+//   identically zero (softmax shift invariance) and is left untouched.
+#include "mab1_bf16.hpp"
+
+#include <math.h>
+
+#include <mutex>
+
+namespace pca {
+
+namespace {
+
+__device__ __forceinline__ int tr_off(int row, int ch) {
+  return 256 * row + 16 * (ch ^ (((row & 3) << 2) | ((row >> 2) & 3)));
+}
+typedef __attribute__((address_space(3))) s16x4 lds_s16x4;
+__device__ __forceinline__ bf16x8 tr_frag(const char* img, int t, int lane) {
+  const int g = lane >> 4, i16 = lane & 15, q = i16 >> 2, p = i16 & 3;
+  const int a0 = tr_off(4 * g + q, 2 * t + (p >> 1)) + 8 * (p & 1);
+  const int a1 = tr_off(16 + 4 * g + q, 2 * t + (p >> 1)) + 8 * (p & 1);
+  const s16x4 lo = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_s16x4*)(img + a0));
+  const s16x4 hi = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_s16x4*)(img + a1));
+  const bf16x4 l4 = __builtin_bit_cast(bf16x4, lo), h4 = __builtin_bit_cast(bf16x4, hi);
+  bf16x8 r;
+#pragma unroll
+  for (int e = 0; e < 4; ++e) { r[e] = l4[e]; r[4 + e] = h4[e]; }
+  return r;
+}
+// [rows][RP] bf16 image (RP*2 bytes per row), 16-byte chunks XOR-swizzled by the row
+template <int RP>
+__device__ __forceinline__ int rp_off(int row, int ch) {
+  constexpr int NCH = RP / 8;
+  return row * RP * 2 + ((ch ^ (row & (NCH - 1))) << 4);
+}
+
+// ---------------------------------------------------------------------------------
+// per-set epilogue adjoint (fp32)
+// ---------------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void k_mab0_epi_bwd(
+    const float* __restrict__ dH, const float* __restrict__ Z, const float* __restrict__ T,
+    const float* __restrict__ LSE, const float* __restrict__ Wo, const float* __restrict__ Wv,
+    int m, int d, int dk, int h, int Rp, float* __restrict__ dZ, float* __restrict__ dO,
+    float* __restrict__ Th,      // [h][B*m][dk] head-major copy of T (for dWv)
+    float* __restrict__ dTf,     // [B][R][dk] fp32 (small-dk path)
+    __bf16* __restrict__ dTb,    // [B][Rp][dk] natural rows
+    __bf16* __restrict__ dTt,    // [B][dk][Rp] r-permuted
+    float* __restrict__ Delta,   // [B][Rp]
+    float* __restrict__ LSEp,    // [B][Rp] padded with +1e30
+    int B) {
+  extern __shared__ float sm[];
+  float* sdZ = sm;               // [m][d]
+  float* sdO = sdZ + m * d;      // [m][d]
+  float* sdT = sdO + m * d;      // [R][dk]
+  const int b = blockIdx.x, tid = threadIdx.x;
+  const int R = h * m, dh = d / h;
+  for (int o = tid; o < m * d; o += 256) {
+    const float g = dH[(int64_t)b * m * d + o];
+    const float z = Z[(int64_t)b * m * d + o];
+    const float v = z > 0.f ? g : 0.f;
+    sdZ[o] = v;
+    dZ[(int64_t)b * m * d + o] = v;
+  }
+  __syncthreads();
+  for (int o = tid; o < m * d; o += 256) {
+    const int q = o / d, c = o - q * d;
+    float acc = dH[(int64_t)b * m * d + o];
+    const float* zr = sdZ + q * d;
+    for (int f = 0; f < d; ++f) acc += zr[f] * Wo[(int64_t)f * d + c];
+    sdO[o] = acc;
+    dO[(int64_t)b * m * d + o] = acc;
+  }
+  __syncthreads();
+  for (int o = tid; o < R * dk; o += 256) {
+    const int r = o / dk, c = o - r * dk, j = r / m, q = r - j * m;
+    const float* orow = sdO + q * d + j * dh;
+    float acc = 0.f;
+    for (int f = 0; f < dh; ++f) acc += orow[f] * Wv[(int64_t)(j * dh + f) * dk + c];
+    sdT[o] = acc;
+    const float tv = T[((int64_t)b * R + r) * dk + c];
+    Th[((int64_t)j * B * m + (int64_t)b * m + q) * dk + c] = tv;
+    if (dTf != nullptr) dTf[((int64_t)b * R + r) * dk + c] = acc;
+    if (dTb != nullptr) {
+      dTb[((int64_t)b * Rp + r) * dk + c] = (__bf16)acc;
+      // position of row r inside its 32-block: r = 32 s + perm32(pos)
+      const int rb32 = r & ~31, ro = r & 31;
+      int pos = 0;
+#pragma unroll
+      for (int p = 0; p < 32; ++p)
+        if (perm32(p) == ro) pos = p;
+      dTt[((int64_t)b * dk + c) * Rp + rb32 + pos] = (__bf16)acc;
+    }
+  }
+  __syncthreads();
+  for (int r = tid; r < Rp; r += 256) {
+    float dl = 0.f;
+    if (r < R)
+      for (int c = 0; c < dk; ++c) dl += sdT[r * dk + c] * T[((int64_t)b * R + r) * dk + c];
+    Delta[(int64_t)b * Rp + r] = dl;
+    LSEp[(int64_t)b * Rp + r] = r < R ? LSE[(int64_t)b * R + r] : 1.0e30f;
+  }
+  if (dTb != nullptr) {          // zero the padding rows / columns of the bf16 images
+    for (int o = tid; o < (Rp - R) * dk; o += 256) {
+      const int r = R + o / dk, c = o % dk;
+      dTb[((int64_t)b * Rp + r) * dk + c] = (__bf16)0.f;
+      const int rb32 = r & ~31, ro = r & 31;
+      int pos = 0;
+#pragma unroll
+      for (int p = 0; p < 32; ++p)
+        if (perm32(p) == ro) pos = p;
+      dTt[((int64_t)b * dk + c) * Rp + rb32 + pos] = (__bf16)0.f;
+    }
+  }
+}
+
+// G'^T image shared by all sets: GtP[c][32 s + p] = G'[32 s + perm32(p)][c]  (zero padding)
+__global__ void k_mab0_gt(const float* __restrict__ Gf, int R, int Rp, int dk,
+                          __bf16* __restrict__ GtP) {
+  const int idx = blockIdx.x * blockDim.x + threadIdx.x;
+  if (idx >= dk * Rp) return;
+  const int c = idx / Rp, k = idx - c * Rp;
+  const int r = (k & ~31) + perm32(k & 31);
+  GtP[idx] = (__bf16)(r < R ? Gf[r * dk + c] : 0.f);
+}
+
+// ---------------------------------------------------------------------------------
+// main backward over the points, dk == 128
+// ---------------------------------------------------------------------------------
+struct Mab0BwdArgs {
+  const float* X;        // [B, N, 128]
+  const __bf16* Gb;      // [Rp][128] natural rows (sl2e folded in)
+  const __bf16* GtP;     // [128][Rp]
+  const __bf16* dTb;     // [B][Rp][128]
+  const __bf16* dTt;     // [B][128][Rp]
+  const float* LSEp;     // [B][Rp]
+  const float* Delta;    // [B][Rp]
+  float* dX;             // [B, N, 128] or null
+  float* DG;             // [Rp][128] fp32, accumulated over sets (ln2-scaled dS units)
+  int B, N, accumulate_dx;
+};
+
+template <int RP>
+__global__ __launch_bounds__(256, 1) void k_mab0_bwd(const Mab0BwdArgs a) {
+  constexpr int DK = 128, FT = DK / 16, KS = DK / 32, RB = RP / 16, RS = RP / 32;
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  char* sG = smem;                           // [RP][256]   tr_off rows
+  char* sdT = sG + RP * 256;                 // [RP][256]
+  char* sGt = sdT + RP * 256;                // [128][RP*2] rp_off
+  char* sdTt = sGt + DK * RP * 2;            // [128][RP*2]
+  char* sX = sdTt + DK * RP * 2;             // 4 x 32 x 256
+  char* sDS = sX + 4 * 32 * 256;             // 4 x 32 x 256 (first RP*2 bytes of a row used)
+  float* sLSE = reinterpret_cast<float*>(sDS + 4 * 32 * 256);
+  float* sDel = sLSE + RP;
+  float* sRed = reinterpret_cast<float*>(sX);     // [RP][128] fp32 merge buffer (aliases sX+sDS)
+
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int r = lane & 15, g = lane >> 4;
+  const int b = blockIdx.x;
+
+  for (int c = tid; c < RP * 16; c += 256) {
+    const int row = c >> 4, ch = c & 15;
+    *reinterpret_cast<uint4*>(sG + tr_off(row, ch)) =
+        *reinterpret_cast<const uint4*>(a.Gb + (int64_t)row * DK + ch * 8);
+    *reinterpret_cast<uint4*>(sdT + tr_off(row, ch)) =
+        *reinterpret_cast<const uint4*>(a.dTb + ((int64_t)b * RP + row) * DK + ch * 8);
+  }
+  for (int c = tid; c < DK * (RP / 8); c += 256) {
+    const int row = c / (RP / 8), ch = c % (RP / 8);
+    *reinterpret_cast<uint4*>(sGt + rp_off<RP>(row, ch)) =
+        *reinterpret_cast<const uint4*>(a.GtP + (int64_t)row * RP + ch * 8);
+    *reinterpret_cast<uint4*>(sdTt + rp_off<RP>(row, ch)) =
+        *reinterpret_cast<const uint4*>(a.dTt + ((int64_t)b * DK + row) * RP + ch * 8);
+  }
+  for (int i = tid; i < RP; i += 256) {
+    sLSE[i] = a.LSEp[(int64_t)b * RP + i];
+    sDel[i] = a.Delta[(int64_t)b * RP + i];
+  }
+  __syncthreads();
+
+  char* myX = sX + wave * 32 * 256;
+  char* myDS = sDS + wave * 32 * 256;
+  f32x4 dG[RB][FT];
+#pragma unroll
+  for (int rb = 0; rb < RB; ++rb)
+#pragma unroll
+    for (int ft = 0; ft < FT; ++ft) dG[rb][ft] = f32x4{0.f, 0.f, 0.f, 0.f};
+  constexpr float LN2 = 0.6931471805599453f;
+
+  for (int n0 = wave * 32; n0 < a.N; n0 += 128) {
+#pragma unroll
+    for (int e = 0; e < 8; ++e) {
+      const int c = lane + 64 * e;
+      const int row = c >> 4, ch = c & 15;
+      bf16x8 v;
+      if (n0 + row < a.N) {
+        const float4* src = reinterpret_cast<const float4*>(
+            a.X + ((int64_t)b * a.N + n0 + row) * DK + ch * 8);
+        const float4 lo = src[0], hi = src[1];
+        v[0] = (__bf16)lo.x; v[1] = (__bf16)lo.y; v[2] = (__bf16)lo.z; v[3] = (__bf16)lo.w;
+        v[4] = (__bf16)hi.x; v[5] = (__bf16)hi.y; v[6] = (__bf16)hi.z; v[7] = (__bf16)hi.w;
+      } else {
+#pragma unroll
+        for (int k = 0; k < 8; ++k) v[k] = (__bf16)0.f;
+      }
+      *reinterpret_cast<bf16x8*>(myX + tr_off(row, ch)) = v;
+    }
+    bf16x8 xrow[2][KS];
+#pragma unroll
+    for (int pb = 0; pb < 2; ++pb)
+#pragma unroll
+      for (int ks = 0; ks < KS; ++ks)
+        xrow[pb][ks] = *reinterpret_cast<const bf16x8*>(myX + tr_off(16 * pb + r, 4 * ks + g));
+    bool live[2];
+#pragma unroll
+    for (int pb = 0; pb < 2; ++pb) live[pb] = n0 + 16 * pb + r < a.N;
+
+    f32x4 dx[FT][2];
+#pragma unroll
+    for (int ft = 0; ft < FT; ++ft)
+#pragma unroll
+      for (int pb = 0; pb < 2; ++pb) dx[ft][pb] = f32x4{0.f, 0.f, 0.f, 0.f};
+
+#pragma unroll
+    for (int s = 0; s < RS; ++s) {
+      f32x4 pt[2][2], dst[2][2];          // [row block within the 32][point block]
+#pragma unroll
+      for (int rbi = 0; rbi < 2; ++rbi) {
+        const int rb = 2 * s + rbi;
+        const float4 l4 = *reinterpret_cast<const float4*>(&sLSE[16 * rb + 4 * g]);
+        const float4 d4 = *reinterpret_cast<const float4*>(&sDel[16 * rb + 4 * g]);
+        const float lse[4] = {l4.x, l4.y, l4.z, l4.w}, del[4] = {d4.x, d4.y, d4.z, d4.w};
+#pragma unroll
+        for (int pb = 0; pb < 2; ++pb) {
+          f32x4 sv = {0.f, 0.f, 0.f, 0.f}, da = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+          for (int ks = 0; ks < KS; ++ks) {
+            sv = mfma32(*reinterpret_cast<const bf16x8*>(sG + tr_off(16 * rb + r, 4 * ks + g)),
+                        xrow[pb][ks], sv);
+            da = mfma32(*reinterpret_cast<const bf16x8*>(sdT + tr_off(16 * rb + r, 4 * ks + g)),
+                        xrow[pb][ks], da);
+          }
+#pragma unroll
+          for (int e = 0; e < 4; ++e) {
+            const float p = live[pb] ? exp2f(sv[e] - lse[e]) : 0.f;
+            pt[rbi][pb][e] = p;
+            dst[rbi][pb][e] = LN2 * p * (da[e] - del[e]);
+          }
+          // dS^T tile -> wave-private [point][r] image (for the sum over points below)
+          *reinterpret_cast<bf16x4*>(myDS + tr_off(16 * pb + r, 2 * rb + (g >> 1)) + 8 * (g & 1)) =
+              pack4(dst[rbi][pb]);
+        }
+      }
+      if (a.dX != nullptr) {
+        bf16x8 pf[2], df[2];
+#pragma unroll
+        for (int pb = 0; pb < 2; ++pb) {
+          pf[pb] = pack8(pt[0][pb], pt[1][pb]);
+          df[pb] = pack8(dst[0][pb], dst[1][pb]);
+        }
+#pragma unroll
+        for (int ft = 0; ft < FT; ++ft) {
+          const bf16x8 ta =
+              *reinterpret_cast<const bf16x8*>(sdTt + rp_off<RP>(16 * ft + r, 4 * s + g));
+          const bf16x8 ga =
+              *reinterpret_cast<const bf16x8*>(sGt + rp_off<RP>(16 * ft + r, 4 * s + g));
+#pragma unroll
+          for (int pb = 0; pb < 2; ++pb) {
+            dx[ft][pb] = mfma32(ta, pf[pb], dx[ft][pb]);
+            dx[ft][pb] = mfma32(ga, df[pb], dx[ft][pb]);
+          }
+        }
+      }
+    }
+
+    // dG[r][c] += sum_points dS[r][pt] X[pt][c]
+    bf16x8 xtr[FT];
+#pragma unroll
+    for (int ft = 0; ft < FT; ++ft) xtr[ft] = tr_frag(myX, ft, lane);
+#pragma unroll
+    for (int rb = 0; rb < RB; ++rb) {
+      const bf16x8 da = tr_frag(myDS, rb, lane);
+#pragma unroll
+      for (int ft = 0; ft < FT; ++ft) dG[rb][ft] = mfma32(da, xtr[ft], dG[rb][ft]);
+    }
+
+    if (a.dX != nullptr) {
+#pragma unroll
+      for (int pb = 0; pb < 2; ++pb)
+        if (live[pb]) {
+          float* dst_row = a.dX + ((int64_t)b * a.N + n0 + 16 * pb + r) * DK;
+#pragma unroll
+          for (int ft = 0; ft < FT; ++ft) {
+            float4* pd = reinterpret_cast<float4*>(dst_row + 16 * ft + 4 * g);
+            float4 v = float4{dx[ft][pb][0], dx[ft][pb][1], dx[ft][pb][2], dx[ft][pb][3]};
+            if (a.accumulate_dx) {
+              const float4 o = *pd;
+              v.x += o.x; v.y += o.y; v.z += o.z; v.w += o.w;
+            }
+            *pd = v;
+          }
+        }
+    }
+  }
+
+  // ---- dG: reduce the four waves in LDS, then one atomic per element per set ----
+  __syncthreads();
+  for (int i = tid; i < RP * DK; i += 256) sRed[i] = 0.f;
+  __syncthreads();
+#pragma unroll
+  for (int rb = 0; rb < RB; ++rb)
+#pragma unroll
+    for (int ft = 0; ft < FT; ++ft)
+#pragma unroll
+      for (int e = 0; e < 4; ++e)
+        atomicAdd(&sRed[(16 * rb + 4 * g + e) * DK + 16 * ft + r], dG[rb][ft][e]);
+  __syncthreads();
+  for (int i = tid; i < RP * DK; i += 256) atomicAdd(&a.DG[i], sRed[i]);
+}
+
+// layer 1 (dk <= 4): thread = (query row r, point partition); accumulates DG only
+__global__ __launch_bounds__(256) void k_mab0_bwd_small(
+    const float* __restrict__ X, const float* __restrict__ Gf, const float* __restrict__ dTf,
+    const float* __restrict__ LSE, const float* __restrict__ Delta, int N, int R, int Rp, int dk,
+    float* __restrict__ DG) {
+  __shared__ float sD[256][4];
+  const int b = blockIdx.x, tid = threadIdx.x;
+  const int parts = 256 / R;
+  const int r = tid % R, part = tid / R;
+  constexpr float LN2 = 0.6931471805599453f;
+  float gk[4], dt[4], acc[4] = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+  for (int c = 0; c < 4; ++c) {
+    gk[c] = c < dk ? Gf[r * dk + c] : 0.f;
+    dt[c] = c < dk ? dTf[((int64_t)b * R + r) * dk + c] : 0.f;
+  }
+  const float lse = LSE[(int64_t)b * R + r], del = Delta[(int64_t)b * Rp + r];
+  if (part < parts) {
+    for (int n = part; n < N; n += parts) {
+      float x[4];
+#pragma unroll
+      for (int c = 0; c < 4; ++c) x[c] = c < dk ? X[((int64_t)b * N + n) * dk + c] : 0.f;
+      const float s = gk[0] * x[0] + gk[1] * x[1] + gk[2] * x[2] + gk[3] * x[3];
+      const float da = dt[0] * x[0] + dt[1] * x[1] + dt[2] * x[2] + dt[3] * x[3];
+      const float ds = LN2 * exp2f(s - lse) * (da - del);
+#pragma unroll
+      for (int c = 0; c < 4; ++c) acc[c] += ds * x[c];
+    }
+  }
+#pragma unroll
+  for (int c = 0; c < 4; ++c) sD[tid][c] = acc[c];
+  __syncthreads();
+  if (tid < R) {
+    for (int c = 0; c < dk; ++c) {
+      float v = 0.f;
+      for (int p = 0; p < parts; ++p) v += sD[p * R + tid][c];
+      atomicAdd(&DG[tid * dk + c], v);
+    }
+  }
+}
+
+// ---------------------------------------------------------------------------------
+// shared-query parameters.  dQs = sum_b dO[b] ([m][d]); DG = sum over sets of dS X in
+// "ln2 units": dG_raw = sl2e * DG.   One workgroup.
+//   dWk[f][c]  += sum_q Qp[q][f] dG_raw[j m + q][c]            (j = head of f)
+//   dQp[q][f]   = dQs[q][f] + sum_c dG_raw[j m + q][c] Wk[f][c]
+//   dWq += dQp^T I ; dbq += colsum(dQp) ; dI += dQp Wq
+// ---------------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void k_mab0_post(
+    const float* __restrict__ dQs, const float* __restrict__ DG, const float* __restrict__ Qp,
+    const float* __restrict__ I, const float* __restrict__ Wq, const float* __restrict__ Wk,
+    int m, int d, int dq, int dk, int h, float sl2e, float* __restrict__ dWk,
+    float* __restrict__ dWq, float* __restrict__ dbq, float* __restrict__ dI) {
+  extern __shared__ float sm[];
+  float* sdQ = sm;                 // [m][d]
+  const int tid = threadIdx.x, dh = d / h;
+  for (int o = tid; o < d * dk; o += 256) {
+    const int f = o / dk, c = o - f * dk, j = f / dh;
+    float acc = 0.f;
+    for (int q = 0; q < m; ++q) acc += Qp[q * d + f] * DG[(j * m + q) * dk + c];
+    dWk[o] += sl2e * acc;
+  }
+  for (int o = tid; o < m * d; o += 256) {
+    const int q = o / d, f = o - q * d, j = f / dh;
+    float acc = 0.f;
+    for (int c = 0; c < dk; ++c) acc += DG[(j * m + q) * dk + c] * Wk[(int64_t)f * dk + c];
+    sdQ[o] = dQs[o] + sl2e * acc;
+  }
+  __syncthreads();
+  for (int o = tid; o < d * dq; o += 256) {
+    const int f = o / dq, c = o - f * dq;
+    float acc = 0.f;
+    for (int q = 0; q < m; ++q) acc += sdQ[q * d + f] * I[q * dq + c];
+    dWq[o] += acc;
+  }
+  for (int f = tid; f < d; f += 256) {
+    float acc = 0.f;
+    for (int q = 0; q < m; ++q) acc += sdQ[q * d + f];
+    dbq[f] += acc;
+  }
+  if (dI != nullptr)
+    for (int o = tid; o < m * dq; o += 256) {
+      const int q = o / dq, c = o - q * dq;
+      float acc = 0.f;
+      for (int f = 0; f < d; ++f) acc += sdQ[q * d + f] * Wq[(int64_t)f * dq + c];
+      dI[o] += acc;
+    }
+}
+
+struct BwdWs0 {
+  float *dZ, *dO, *Th, *dTf, *Delta, *LSEp, *DG, *dQs;
+  __bf16 *dTb, *dTt, *GtP;
+};
+size_t carve_ws0(const pca_mab_shape& s, BwdWs0* out, void* base) {
+  Carver c(base);
+  BwdWs0 w;
+  const int R = s.h * s.nq, Rp = (int)cdiv(R, 32) * 32;
+  const size_t Bm = (size_t)s.B * s.nq;
+  w.dZ = c.take<float>(Bm * s.d);
+  w.dO = c.take<float>(Bm * s.d);
+  w.Th = c.take<float>((size_t)s.B * R * s.dk);
+  w.dTf = c.take<float>((size_t)s.B * R * s.dk);
+  w.Delta = c.take<float>((size_t)s.B * Rp);
+  w.LSEp = c.take<float>((size_t)s.B * Rp);
+  w.DG = c.take<float>((size_t)Rp * s.dk);
+  w.dQs = c.take<float>((size_t)s.nq * s.d);
+  w.dTb = c.take<__bf16>((size_t)s.B * Rp * s.dk);
+  w.dTt = c.take<__bf16>((size_t)s.B * Rp * s.dk);
+  w.GtP = c.take<__bf16>((size_t)Rp * s.dk);
+  if (out) *out = w;
+  return c.off;
+}
+
+}  // namespace
+
+size_t mab0_bf16_bwd_ws_bytes(const pca_mab_shape& s) { return carve_ws0(s, nullptr, nullptr); }
+
+// dQ -> dI [m, dq] (ACCUMULATED, may be null), dK -> dX [B, N, dk] (written or accumulated)
+int mab0_bf16_bwd(const pca_mab_shape& s, const float* I, const float* X,
+                  const pca_mab_params& p, const void* saved, const float* dH, float* dI,
+                  float* dX, int dk_accumulate, const pca_mab_grads& gr, void* ws,
+                  hipStream_t st) {
+  Mab0Saved v;
+  mab0_carve_saved(s, &v, const_cast<void*>(saved));
+  BwdWs0 w;
+  carve_ws0(s, &w, ws);
+  const int d = s.d, m = s.nq, h = s.h, dk = s.dk, R = h * m, Rp = (int)cdiv(R, 32) * 32;
+  const int64_t Bm = (int64_t)s.B * m;
+  const bool small = dk <= 4;
+  const float sl2e = 1.4426950408889634f / sqrtf((float)d);
+  if (small && dX != nullptr) {
+    set_error("mab0_bf16_bwd: dK for dk <= 4 is not built (the set is the model input)");
+    return PCA_EUNSUPPORTED;
+  }
+
+  const size_t el = (2 * (size_t)m * d + (size_t)R * dk) * sizeof(float);
+  hipLaunchKernelGGL(k_mab0_epi_bwd, dim3(s.B), dim3(256), el, st, dH, v.Z, v.T, v.LSE, p.wo, p.wv,
+                     m, d, dk, h, Rp, w.dZ, w.dO, w.Th, small ? w.dTf : nullptr,
+                     small ? nullptr : w.dTb, small ? nullptr : w.dTt, w.Delta, w.LSEp, s.B);
+  PCA_TRY(check_launch("k_mab0_epi_bwd"));
+  PCA_TRY(fill_zero(w.DG, (int64_t)Rp * dk, st));
+
+  if (small) {
+    hipLaunchKernelGGL(k_mab0_bwd_small, dim3(s.B), dim3(256), 0, st, X, v.Gf, w.dTf, v.LSE,
+                       w.Delta, s.nk, R, Rp, dk, w.DG);
+    PCA_TRY(check_launch("k_mab0_bwd_small"));
+  } else {
+    hipLaunchKernelGGL(k_mab0_gt, dim3((unsigned)cdiv(dk * Rp, 256)), dim3(256), 0, st, v.Gf, R, Rp,
+                       dk, w.GtP);
+    PCA_TRY(check_launch("k_mab0_gt"));
+    Mab0BwdArgs a{X, v.Gb, w.GtP, w.dTb, w.dTt, w.LSEp, w.Delta, dX, w.DG, s.B, s.nk,
+                  dk_accumulate ? 1 : 0};
+    const size_t lds = 2 * (size_t)Rp * 256 + 2 * (size_t)128 * Rp * 2 + 2 * 4 * 32 * 256 +
+                       2 * Rp * sizeof(float);
+    static std::once_flag once;
+    std::call_once(once, [] {
+      (void)hipFuncSetAttribute(reinterpret_cast<const void*>(k_mab0_bwd<64>),
+                                hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+      (void)hipFuncSetAttribute(reinterpret_cast<const void*>(k_mab0_bwd<32>),
+                                hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+    });
+    const double pts = (double)s.B * s.nk;
+    ProfScope ps(PCA_K_MAB0_BWD, st, 4.0 * pts * (2.0 * dk * d + 2.0 * m * d), pts * 8.0 * dk);
+    if (Rp == 32) hipLaunchKernelGGL((k_mab0_bwd<32>), dim3(s.B), dim3(256), lds, st, a);
+    else hipLaunchKernelGGL((k_mab0_bwd<64>), dim3(s.B), dim3(256), lds, st, a);
+    ps.end();
+    PCA_TRY(check_launch("k_mab0_bwd"));
+  }
+
+  // ---- parameter gradients of the epilogue: [B*m]-row reductions on the fp32 GEMM ----
+  {
+    pca_gemm_desc g{};                         // dWo += dZ^T O
+    g.M = d; g.N = d; g.K = Bm; g.sa_m = 1; g.sa_k = d; g.sb_k = d; g.sb_n = 1; g.sc_m = d;
+    g.nb1 = g.nb2 = 1; g.accumulate = 1; g.split_k = 0; g.alpha = 1.f;
+    PCA_TRY(gemm_f32(g, w.dZ, v.O, nullptr, gr.wo, st));
+    PCA_TRY(colsum(w.dZ, Bm, d, gr.bo, 1, st));
+    PCA_TRY(colsum(w.dO, Bm, d, gr.bv, 1, st));
+  }
+  {                                            // dWv_j += dO_j^T Th_j   (batched over heads)
+    pca_gemm_desc g{};
+    const int dh = d / h;
+    g.M = dh; g.N = dk; g.K = Bm; g.sa_m = 1; g.sa_k = d; g.sb_k = dk; g.sb_n = 1; g.sc_m = dk;
+    g.nb1 = 1; g.nb2 = h;
+    g.sa_b2 = dh; g.sb_b2 = (int64_t)Bm * dk; g.sc_b2 = (int64_t)dh * dk;
+    g.accumulate = 1; g.split_k = 0; g.alpha = 1.f;
+    PCA_TRY(gemm_f32(g, w.dO, w.Th, nullptr, gr.wv, st));
+  }
+  PCA_TRY(colsum(w.dO, s.B, m * d, w.dQs, 0, st));        // sum over sets
+  hipLaunchKernelGGL(k_mab0_post, dim3(1), dim3(256), (size_t)m * d * sizeof(float), st, w.dQs,
+                     w.DG, v.Qp, I, p.wq, p.wk, m, d, s.dq, dk, h, sl2e, gr.wk, gr.wq, gr.bq, dI);
+  return check_launch("k_mab0_post");
+}
+
+}  // namespace pca

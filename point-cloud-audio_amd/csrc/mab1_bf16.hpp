@@ -22,6 +22,17 @@ __host__ __device__ __forceinline__ int64_t mab1_mask_index(int b, int tiles_per
   return (pb * (D / 128) + w) * 64 + lane;
 }
 
+// saved-for-backward block of the fused mab0 (few queries, many keys)
+struct Mab0Saved {
+  float* Qp;      // [m][d]     fc_q(I)
+  float* Gf;      // [Rpad][dk] scale*log2e * Qp_h Wk_h   (fp32)
+  __bf16* Gb;     // same, bf16 (MFMA operand)
+  float* T;       // [B][R][dk] A X
+  float* LSE;     // [B][R]     log2-domain
+  float *O, *Z;   // [B][m][d]
+};
+size_t mab0_carve_saved(const pca_mab_shape& s, Mab0Saved* out, void* base);
+
 // fp32 weight -> bf16 image; mode 0 natural, 1 K-permuted, 2 transposed + K-permuted
 int prep_weight(const float* src, __bf16* dst, int rows, int cols, int mode, hipStream_t st);
 

@@ -151,3 +151,111 @@ def test_engine_bf16_vs_golden(dev, golden_st):
     print(f"engine bf16: logits err {err:.2e}, worst grad err {worst:.2e}")
     inf = trainer.STEngine(net, B, N, mode=_lib.MODE_BF16, training=False)
     close(inf.forward(X), ref, FWD_TOL, "logits(inference)")
+
+
+MAB0_CASES = [      # B, N, m, dk, d, h   (query = learned [m, d], shared by all sets)
+    (3, 200, 16, 128, 128, 4),      # ISAB mab0, ragged N
+    (4, 130, 1, 128, 128, 4),       # PMA: one seed, 4 score rows padded to 16
+    (3, 77, 16, 2, 128, 4),         # layer 1 (f, logmag): exact fp32
+    (2, 33, 16, 3, 128, 4),
+    (2, 1, 16, 128, 128, 4),        # a single key
+]
+
+
+@pytest.mark.parametrize("case", MAB0_CASES, ids=[str(c) for c in MAB0_CASES])
+def test_mab0_fwd_bf16(dev, case):
+    import modules
+    import pca_hip
+    from oracle import st_oracle as orc
+    B, N, m, dk, d, h = case
+    p = _mab_params(d, dk, d, seed=sum(case) + 7)
+    g = torch.Generator().manual_seed(3 + sum(case))
+    I = torch.randn(1, m, d, generator=g) * 0.5
+    X = torch.randn(B, N, dk, generator=g)
+    if dk <= 4:
+        X[..., -1] = X[..., -1] * 3 - 9
+    ref = orc.mab_forward(I.expand(B, -1, -1), X, p, h)
+    mab = modules.MAB(d, dk, d, h).to(dev)
+    mab.load_state_dict(p)
+    pca_hip.set_mode("bf16")
+    with torch.no_grad():
+        Y = mab(I.to(dev), X.to(dev), q_shared=True)
+    pca_hip.set_mode("f32")
+    err = close(Y, ref, FWD_TOL if dk > 4 else 2e-4, f"mab0 fwd {case}")
+    print(f"mab0 fwd {case}: max err {err:.3e} (max|ref| {float(ref.abs().max()):.2f})")
+
+
+def mab0_forward_bf16emu(I, X, p, h):
+    """Reassociated mab0 with the MFMA operands (G' = sl2e Qp_h Wk_h, X, P) rounded to bf16 as
+    csrc/mab0_bf16.hip does; epilogue fp32.  Returns H."""
+    import math
+    from oracle.st_oracle import rb
+    B, N, dk = X.shape
+    m = I.shape[1]
+    d = p["fc_q.weight"].shape[0]
+    dh = d // h
+    sl2e = math.log2(math.e) / math.sqrt(d)
+    Qp = I[0] @ p["fc_q.weight"].t() + p["fc_q.bias"]                  # [m, d]
+    Wk = p["fc_k.weight"].view(h, dh, dk)
+    G = torch.einsum("qjf,jfc->jqc", Qp.view(m, h, dh), Wk) * sl2e      # [h, m, dk]
+    small = dk <= 4
+    Gs, Xs = (G, X) if small else (rb(G), rb(X))
+    S2 = torch.einsum("jqc,bnc->bjqn", Gs, Xs)                           # log2-domain scores
+    P = torch.softmax(S2 * math.log(2.0), dim=-1)
+    T = torch.einsum("bjqn,bnc->bjqc", P if small else rb(P), Xs)
+    Wv = p["fc_v.weight"].view(h, dh, dk)
+    O = Qp.view(1, m, h, dh) + torch.einsum("bjqc,jfc->bqjf", T, Wv) + p["fc_v.bias"].view(1, 1, h, dh)
+    O = O.reshape(B, m, d)
+    Z = O @ p["fc_o.weight"].t() + p["fc_o.bias"]
+    return O + torch.relu(Z)
+
+
+@pytest.mark.parametrize("case", MAB0_CASES, ids=[str(c) for c in MAB0_CASES])
+def test_mab0_bwd_bf16(dev, case):
+    import modules
+    import pca_hip
+    from oracle import st_oracle as orc
+    B, N, m, dk, d, h = case
+    p = _mab_params(d, dk, d, seed=sum(case) + 7)
+    g = torch.Generator().manual_seed(3 + sum(case))
+    I = torch.randn(1, m, d, generator=g) * 0.5
+    X = torch.randn(B, N, dk, generator=g)
+    if dk <= 4:
+        X[..., -1] = X[..., -1] * 3 - 9
+    G = torch.randn(B, m, d, generator=g)
+    # reference 1: exact fp32 oracle (explicit adjoint); dQ summed over the shared query
+    exact = orc.mab_backward(G, I.expand(B, -1, -1).contiguous(), X, p, h)
+    exact["dQ"] = exact["dQ"].sum(0, keepdim=True)
+    # reference 2: autograd of the bf16-operand emulation
+    leaves = {k: v.clone().requires_grad_(True) for k, v in p.items()}
+    Ie, Xe = I.clone().requires_grad_(True), X.clone().requires_grad_(True)
+    He = mab0_forward_bf16emu(Ie, Xe, leaves, h)
+    (He * G).sum().backward()
+    emu = {k: v.grad for k, v in leaves.items()}
+    emu["dQ"], emu["dK"] = Ie.grad, Xe.grad
+    emu["fc_k.bias"] = torch.zeros(d)
+
+    mab = modules.MAB(d, dk, d, h).to(dev)
+    mab.load_state_dict(p)
+    Id = I.to(dev).requires_grad_(True)
+    Xd = X.to(dev).requires_grad_(dk > 4)
+    pca_hip.set_mode("bf16")
+    H = mab(Id, Xd, q_shared=True)
+    (H * G.to(dev)).sum().backward()
+    pca_hip.set_mode("f32")
+    close(H, He, 2e-3, "H vs emulation")
+    got = {"dQ": Id.grad}
+    if dk > 4:
+        got["dK"] = Xd.grad
+    for k, prm in mab.named_parameters():
+        got[k] = prm.grad if prm.grad is not None else torch.zeros_like(prm)
+    errs = {}
+    for k, v in got.items():
+        if k == "fc_k.bias":
+            assert float(v.abs().max()) == 0.0           # exactly zero by construction
+            continue
+        errs[k] = close_robust(v, emu[k], 1.5e-2, k)
+        sc = max(1.0, float(exact[k].abs().max()))
+        rms = float((emu[k] - exact[k]).pow(2).mean().sqrt()) / sc
+        assert rms < 3e-2, (k, rms)
+    print(f"mab0 bwd {case}: " + " ".join(f"{k}={v:.1e}" for k, v in errs.items()))
