@@ -210,7 +210,8 @@ int pca_st_train_fwd_bwd(const pca_st_config* c, const float* params, const floa
  * z = z1*nb2 + z2 ; X[z] = X + z1*sX_b1 + z2*sX_b2 ; op(A)[i,k] = A[i*sa_m + k*sa_k],
  * op(B)[k,j] = B[k*sb_k + j*sb_n], C[i,j] = C[i*sc_m + j].  accumulate != 0 adds to C.
  * split_k > 1 splits K over workgroups and accumulates atomically (C must hold the
- * initial value: zeros or the tensor being accumulated into). */
+ * initial value: zeros or the tensor being accumulated into); split_k == 0 lets the
+ * library choose (it only splits when accumulate != 0). */
 typedef struct pca_gemm_desc {
   int64_t M, N, K;
   int64_t sa_m, sa_k, sb_k, sb_n, sc_m;

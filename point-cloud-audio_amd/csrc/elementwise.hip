@@ -109,11 +109,11 @@ __global__ __launch_bounds__(256) void k_softmax_bwd_rows(const float* __restric
 // out[j] += sum_i X[i,j]; block = 64 column lanes x 4 row lanes; grid.x tiles the rows
 // (256 per block), grid.y tiles the columns (64 per block)
 __global__ __launch_bounds__(256) void k_colsum(const float* __restrict__ X, int64_t rows,
-                                                 int cols, float* __restrict__ out) {
+                                                 int cols, float* __restrict__ out, int rpb) {
   __shared__ float red[4][64];
   const int tx = threadIdx.x & 63, ty = threadIdx.x >> 6;
-  const int64_t r0 = (int64_t)blockIdx.x * 256;
-  const int64_t r1 = (r0 + 256 < rows) ? r0 + 256 : rows;
+  const int64_t r0 = (int64_t)blockIdx.x * rpb;
+  const int64_t r1 = (r0 + rpb < rows) ? r0 + rpb : rows;
   const int j = blockIdx.y * 64 + tx;
   float s = 0.f;
   if (j < cols)
@@ -219,8 +219,9 @@ int colsum(const float* X, int64_t rows, int cols, float* out, int accumulate,
   PCA_REQUIRE(X && out && cols > 0 && rows >= 0, "colsum: bad arguments");
   if (!accumulate) PCA_TRY(fill_zero(out, cols, st));
   if (rows == 0) return PCA_OK;
-  hipLaunchKernelGGL(k_colsum, dim3((unsigned)cdiv(rows, 256), (unsigned)cdiv(cols, 64)),
-                     dim3(256), 0, st, X, rows, cols, out);
+  const int rpb = rows * cdiv(cols, 64) < 256 * 512 ? 32 : 256;   // rows per block
+  hipLaunchKernelGGL(k_colsum, dim3((unsigned)cdiv(rows, rpb), (unsigned)cdiv(cols, 64)),
+                     dim3(256), 0, st, X, rows, cols, out, rpb);
   return check_launch("k_colsum");
 }
 

@@ -112,12 +112,13 @@ int gemm_f32(const pca_gemm_desc& gin, const float* A, const float* B, const flo
   const int64_t nbatch = (int64_t)g.nb1 * g.nb2;
   int split = g.split_k;
   if (split <= 0) {
-    // heuristic: fill ~1024 workgroups when the output is small and K is long
+    // small outputs with a long K (weight gradients over B*N or B*m rows): split K until the
+    // launch has ~512 workgroups, but keep at least 64 of K per workgroup
     split = 1;
     const int64_t wgs = tiles_m * tiles_n * nbatch;
-    if (wgs < 512 && g.K >= 2048) {
-      int64_t want = 1024 / wgs;
-      int64_t maxs = g.K / 512;
+    if (g.accumulate && wgs < 256 && g.K >= 256) {   // atomics need an initialised C
+      int64_t want = 512 / wgs;
+      int64_t maxs = g.K / 64;
       split = (int)(want < maxs ? want : maxs);
       if (split < 1) split = 1;
     }

@@ -86,9 +86,10 @@ __global__ __launch_bounds__(256) void k_mab0_prep(const float* __restrict__ I,
 struct Mab0AttnArgs {
   const float* X;       // [B, N, 128] fp32
   const __bf16* Gb;     // [16*RB][128]  (scale*log2e folded in; padding rows zero)
-  float* T;             // [B][R][128] fp32, normalised
-  float* LSE;           // [B][R]  log2-domain logsumexp of the scaled scores
-  int B, N, R;
+  float* Tp;            // [B][S][R][128] fp32 partial sums  sum_n 2^(s_n - M) x_n
+  float* Mp;            // [B][S][R]      partial maxima M (log2 domain)
+  float* Lp;            // [B][S][R]      partial sums    sum_n 2^(s_n - M)
+  int B, N, R, S;       // S = point splits per set (gridDim.y); merged by k_mab0_epi
 };
 
 template <int RB>
@@ -105,7 +106,10 @@ __global__ __launch_bounds__(256, 1) void k_mab0_attn(const Mab0AttnArgs a) {
 
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int r = lane & 15, g = lane >> 4;
-  const int b = blockIdx.x;
+  const int b = blockIdx.x, sp = blockIdx.y;
+  // this workgroup's point range (multiples of 128 so that tiles stay aligned)
+  const int per = (int)(((int64_t)(a.N + 127) / 128 + a.S - 1) / a.S) * 128;
+  const int n_lo = sp * per, n_hi = (n_lo + per < a.N) ? n_lo + per : a.N;
 
   for (int c = tid; c < 16 * RB * 16; c += 256) {
     const int row = c >> 4, ch = c & 15;
@@ -126,14 +130,14 @@ __global__ __launch_bounds__(256, 1) void k_mab0_attn(const Mab0AttnArgs a) {
     for (int ft = 0; ft < FT; ++ft) T[rb][ft] = f32x4{0.f, 0.f, 0.f, 0.f};
   }
 
-  for (int n0 = wave * 32; n0 < a.N; n0 += 128) {
+  for (int n0 = n_lo + wave * 32; n0 < n_hi; n0 += 128) {
     // stage 32 rows of X (fp32 -> bf16)
 #pragma unroll
     for (int e = 0; e < 8; ++e) {
       const int c = lane + 64 * e;
       const int row = c >> 4, ch = c & 15;
       bf16x8 v;
-      if (n0 + row < a.N) {
+      if (n0 + row < n_hi) {
         const float4* src = reinterpret_cast<const float4*>(
             a.X + ((int64_t)b * a.N + n0 + row) * DK + ch * 8);
         const float4 lo = src[0], hi = src[1];
@@ -172,7 +176,7 @@ __global__ __launch_bounds__(256, 1) void k_mab0_attn(const Mab0AttnArgs a) {
       for (int pb = 0; pb < 2; ++pb)
 #pragma unroll
         for (int e = 0; e < 4; ++e) {
-          if (n0 + 16 * pb + 4 * g + e >= a.N) s[pb][e] = -INFINITY;
+          if (n0 + 16 * pb + 4 * g + e >= n_hi) s[pb][e] = -INFINITY;
           mt = fmaxf(mt, s[pb][e]);
         }
       mt = wave16_max(mt);
@@ -231,19 +235,23 @@ __global__ __launch_bounds__(256, 1) void k_mab0_attn(const Mab0AttnArgs a) {
         atomicAdd(&sT[(16 * rb + 4 * g + e) * DK + 16 * ft + r], T[rb][ft][e] * f4[e]);
   }
   __syncthreads();
+  const int64_t pbase = ((int64_t)b * a.S + sp) * a.R;
   for (int i = tid; i < a.R * DK; i += 256) {
     const int rr = i / DK;
-    float M = -INFINITY;
+    a.Tp[(pbase + rr) * DK + (i - rr * DK)] = sT[i];
+    if (i == rr * DK) {
+      float M = -INFINITY;
 #pragma unroll
-    for (int w = 0; w < 4; ++w) M = fmaxf(M, sM[w * 16 * RB + rr]);
-    float L = 0.f;
+      for (int w = 0; w < 4; ++w) M = fmaxf(M, sM[w * 16 * RB + rr]);
+      float L = 0.f;
 #pragma unroll
-    for (int w = 0; w < 4; ++w) {
-      const float mw = sM[w * 16 * RB + rr];
-      if (mw != -INFINITY) L += sL[w * 16 * RB + rr] * exp2f(mw - M);
+      for (int w = 0; w < 4; ++w) {
+        const float mw = sM[w * 16 * RB + rr];
+        if (mw != -INFINITY) L += sL[w * 16 * RB + rr] * exp2f(mw - M);
+      }
+      a.Mp[pbase + rr] = M;
+      a.Lp[pbase + rr] = L;
     }
-    a.T[((int64_t)b * a.R + rr) * DK + (i - rr * DK)] = sT[i] / L;
-    if (i == rr * DK) a.LSE[(int64_t)b * a.R + rr] = M + log2f(L);
   }
 }
 
@@ -302,11 +310,18 @@ __global__ __launch_bounds__(256) void k_mab0_attn_small(const float* __restrict
 // per-set epilogue: O[q][32j+f] = Qp[q][.] + T[j*m+q][:] . Wv[32j+f][:] + bv ; Z = O Wo^T + bo
 // H = O + relu(Z).  O and Z are saved for the backward.
 // ---------------------------------------------------------------------------------
-__global__ __launch_bounds__(256) void k_mab0_epi(const float* __restrict__ T,
+// thread = (output feature f, half of the queries); weights pre-transposed ([in][out]) so
+// that consecutive threads read consecutive addresses; T / O rows broadcast from LDS.
+template <int MQ>   // queries per thread: m/2 for ISAB (m = 16), 1 for PMA
+__global__ __launch_bounds__(256) void k_mab0_epi(const float* __restrict__ Tp,   // [B][S][R][dk]
+                                                  const float* __restrict__ Mp,
+                                                  const float* __restrict__ Lp, int S,
+                                                  float* __restrict__ T,      // merged, saved
+                                                  float* __restrict__ LSE,
                                                   const float* __restrict__ Qp,
-                                                  const float* __restrict__ Wv,
+                                                  const float* __restrict__ WvT,   // [dk][d]
                                                   const float* __restrict__ bv,
-                                                  const float* __restrict__ Wo,
+                                                  const float* __restrict__ WoT,   // [d][d]
                                                   const float* __restrict__ bo, int m, int d,
                                                   int dk, int h, float* __restrict__ H,
                                                   float* __restrict__ Osave,
@@ -316,31 +331,57 @@ __global__ __launch_bounds__(256) void k_mab0_epi(const float* __restrict__ T,
   float* sO = sT + h * m * dk;    // [m][d]
   const int b = blockIdx.x, tid = threadIdx.x;
   const int R = h * m, dh = d / h;
-  for (int i = tid; i < R * dk; i += 256) sT[i] = T[(int64_t)b * R * dk + i];
-  __syncthreads();
-  for (int o = tid; o < m * d; o += 256) {
-    const int q = o / d, f = o - q * d, j = f / dh;
-    const float* trow = sT + (j * m + q) * dk;
-    const float* w = Wv + (int64_t)f * dk;
-    float acc = Qp[q * d + f] + bv[f];
-    for (int c = 0; c < dk; ++c) acc += trow[c] * w[c];
-    sO[o] = acc;
+  if (S == 0) {                 // T already merged (layer-1 path)
+    for (int i = tid; i < R * dk; i += 256) sT[i] = T[(int64_t)b * R * dk + i];
+  } else {
+    // merge the S point-range partials: T = sum_s f_s Tp_s / sum_s f_s Lp_s, f_s = 2^(M_s - M)
+    for (int i = tid; i < R * dk; i += 256) {
+      const int r = i / dk, c = i - r * dk;
+      float M = -INFINITY;
+      for (int s = 0; s < S; ++s) M = fmaxf(M, Mp[((int64_t)b * S + s) * R + r]);
+      float L = 0.f, t = 0.f;
+      for (int s = 0; s < S; ++s) {
+        const float ms = Mp[((int64_t)b * S + s) * R + r];
+        if (ms == -INFINITY) continue;
+        const float fs = exp2f(ms - M);
+        L += fs * Lp[((int64_t)b * S + s) * R + r];
+        t += fs * Tp[(((int64_t)b * S + s) * R + r) * dk + c];
+      }
+      const float v = t / L;
+      sT[i] = v;
+      T[(int64_t)b * R * dk + i] = v;
+      if (c == 0) LSE[(int64_t)b * R + r] = M + log2f(L);
+    }
   }
   __syncthreads();
-  for (int o = tid; o < m * d; o += 256) {
-    const int q = o / d, f = o - q * d;
-    const float* orow = sO + q * d;
-    const float* w = Wo + (int64_t)f * d;
-    float z = bo[f];
-    for (int c = 0; c < d; c += 4) {
-      const float4 w4 = *reinterpret_cast<const float4*>(w + c);
-      z += orow[c] * w4.x + orow[c + 1] * w4.y + orow[c + 2] * w4.z + orow[c + 3] * w4.w;
-    }
-    const float ov = sO[o];
-    H[(int64_t)b * m * d + o] = ov + fmaxf(z, 0.f);
-    if (Osave != nullptr) {
-      Osave[(int64_t)b * m * d + o] = ov;
-      Zsave[(int64_t)b * m * d + o] = z;
+  const int f = tid % d, qh = tid / d;          // d == 128: two query halves
+  const int q0 = qh * MQ;
+  const bool act = q0 < m;
+  float acc[MQ];
+  if (act) {
+    const int j = f / dh;
+#pragma unroll
+    for (int q = 0; q < MQ; ++q) acc[q] = (q0 + q < m) ? Qp[(q0 + q) * d + f] + bv[f] : 0.f;
+    col_gemm<MQ>(sT + (j * m + q0) * dk, dk, WvT, d, dk, f, acc);
+#pragma unroll
+    for (int q = 0; q < MQ; ++q)
+      if (q0 + q < m) sO[(q0 + q) * d + f] = acc[q];
+  }
+  __syncthreads();
+  if (act) {
+    float z[MQ];
+#pragma unroll
+    for (int q = 0; q < MQ; ++q) z[q] = bo[f];
+    col_gemm<MQ>(sO + q0 * d, d, WoT, d, d, f, z);
+#pragma unroll
+    for (int q = 0; q < MQ; ++q) {
+      if (q0 + q >= m) continue;
+      const int64_t o = (int64_t)b * m * d + (q0 + q) * d + f;
+      H[o] = acc[q] + fmaxf(z[q], 0.f);
+      if (Osave != nullptr) {
+        Osave[o] = acc[q];
+        Zsave[o] = z[q];
+      }
     }
   }
 }
@@ -350,10 +391,20 @@ __global__ __launch_bounds__(256) void k_mab0_epi(const float* __restrict__ T,
 // ---- host side --------------------------------------------------------------------
 bool mab0_bf16_supported(const pca_mab_shape& s) {
   const int R = s.h * s.nq;
+  if (!(s.nq == 16 || s.nq <= 2)) return false;      // epilogue: 8 or 1 queries per thread
   return s.q_shared == 1 && s.d == 128 && s.h * 32 == s.d && s.dq == s.d &&
          ((s.dk == s.d && (R <= 16 || R == 64)) ||
           (s.dk <= 4 && (R == 64 || R == 128 || R == 256))) &&
          s.q_dtype == PCA_F32 && s.k_dtype == PCA_F32 && s.y_dtype == PCA_F32;
+}
+
+// point-range splits per set so that B*S workgroups cover the 256 CUs
+int mab0_splits(const pca_mab_shape& s) {
+  if (s.dk <= 4) return 1;
+  int S = 1;
+  const int tiles = (int)cdiv(s.nk, 128);
+  while (S * 2 <= tiles && s.B * S < 256 && S < 8) S *= 2;
+  return S;
 }
 
 size_t mab0_carve_saved(const pca_mab_shape& s, Mab0Saved* out, void* base) {
@@ -368,6 +419,12 @@ size_t mab0_carve_saved(const pca_mab_shape& s, Mab0Saved* out, void* base) {
   v.LSE = c.take<float>((size_t)s.B * R);
   v.O = c.take<float>((size_t)s.B * s.nq * s.d);
   v.Z = c.take<float>((size_t)s.B * s.nq * s.d);
+  v.WvT = c.take<float>((size_t)s.dk * s.d);
+  v.WoT = c.take<float>((size_t)s.d * s.d);
+  const int S = mab0_splits(s);
+  v.Tp = c.take<float>((size_t)s.B * S * R * s.dk);
+  v.Mp = c.take<float>((size_t)s.B * S * R);
+  v.Lp = c.take<float>((size_t)s.B * S * R);
   if (out) *out = v;
   return c.off;
 }
@@ -405,7 +462,8 @@ int mab0_bf16_fwd(const pca_mab_shape& s, const float* I, const float* X,
                        v.LSE);
     PCA_TRY(check_launch("k_mab0_attn_small"));
   } else {
-    Mab0AttnArgs a{X, v.Gb, v.T, v.LSE, s.B, s.nk, R};
+    const int S = mab0_splits(s);
+    Mab0AttnArgs a{X, v.Gb, v.Tp, v.Mp, v.Lp, s.B, s.nk, R, S};
     const int RB = Rpad / 16;
     const size_t xbytes = (size_t)Rpad * 128 * 4 > 4 * 32 * 256 ? (size_t)Rpad * 128 * 4
                                                                  : (size_t)4 * 32 * 256;
@@ -420,15 +478,25 @@ int mab0_bf16_fwd(const pca_mab_shape& s, const float* I, const float* X,
       (void)hipFuncSetAttribute(reinterpret_cast<const void*>(k_mab0_attn<4>),
                                 hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
     });
-    if (RB == 1) hipLaunchKernelGGL((k_mab0_attn<1>), dim3(s.B), dim3(256), lds, st, a);
-    else if (RB == 4) hipLaunchKernelGGL((k_mab0_attn<4>), dim3(s.B), dim3(256), lds, st, a);
-    else hipLaunchKernelGGL((k_mab0_attn<8>), dim3(s.B), dim3(256), lds, st, a);
+    const dim3 grid(s.B, S);
+    if (RB == 1) hipLaunchKernelGGL((k_mab0_attn<1>), grid, dim3(256), lds, st, a);
+    else if (RB == 4) hipLaunchKernelGGL((k_mab0_attn<4>), grid, dim3(256), lds, st, a);
+    else hipLaunchKernelGGL((k_mab0_attn<8>), grid, dim3(256), lds, st, a);
     ps.end();
     PCA_TRY(check_launch("k_mab0_attn"));
   }
+  PCA_TRY(transpose_f32(p.wv, v.WvT, d, dk, st));
+  PCA_TRY(transpose_f32(p.wo, v.WoT, d, d, st));
   const size_t el = ((size_t)R * dk + (size_t)m * d) * sizeof(float);
-  hipLaunchKernelGGL(k_mab0_epi, dim3(s.B), dim3(256), el, st, v.T, v.Qp, p.wv, p.bv, p.wo, p.bo,
-                     m, d, dk, h, H, training ? v.O : nullptr, training ? v.Z : nullptr);
+  float* Os = training ? v.O : nullptr;
+  float* Zs = training ? v.Z : nullptr;
+  const int Sm = small ? 0 : mab0_splits(s);
+  if (m > 2)
+    hipLaunchKernelGGL((k_mab0_epi<8>), dim3(s.B), dim3(256), el, st, v.Tp, v.Mp, v.Lp, Sm, v.T,
+                       v.LSE, v.Qp, v.WvT, p.bv, v.WoT, p.bo, m, d, dk, h, H, Os, Zs);
+  else
+    hipLaunchKernelGGL((k_mab0_epi<1>), dim3(s.B), dim3(256), el, st, v.Tp, v.Mp, v.Lp, Sm, v.T,
+                       v.LSE, v.Qp, v.WvT, p.bv, v.WoT, p.bo, m, d, dk, h, H, Os, Zs);
   return check_launch("k_mab0_epi");
 }
 

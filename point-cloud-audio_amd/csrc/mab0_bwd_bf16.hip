@@ -51,6 +51,9 @@ __device__ __forceinline__ int rp_off(int row, int ch) {
 // ---------------------------------------------------------------------------------
 // per-set epilogue adjoint (fp32)
 // ---------------------------------------------------------------------------------
+// thread = (output column, half of the queries); weights are read in their natural nn.Linear
+// layout, which is already coalesced for these products (sum over the OUTPUT index).
+template <int MQ>
 __global__ __launch_bounds__(256) void k_mab0_epi_bwd(
     const float* __restrict__ dH, const float* __restrict__ Z, const float* __restrict__ T,
     const float* __restrict__ LSE, const float* __restrict__ Wo, const float* __restrict__ Wv,
@@ -65,7 +68,7 @@ __global__ __launch_bounds__(256) void k_mab0_epi_bwd(
   extern __shared__ float sm[];
   float* sdZ = sm;               // [m][d]
   float* sdO = sdZ + m * d;      // [m][d]
-  float* sdT = sdO + m * d;      // [R][dk]
+  float* sDl = sdO + m * d;      // [Rp] partial Delta
   const int b = blockIdx.x, tid = threadIdx.x;
   const int R = h * m, dh = d / h;
   for (int o = tid; o < m * d; o += 256) {
@@ -75,54 +78,66 @@ __global__ __launch_bounds__(256) void k_mab0_epi_bwd(
     sdZ[o] = v;
     dZ[(int64_t)b * m * d + o] = v;
   }
+  for (int i = tid; i < Rp; i += 256) sDl[i] = 0.f;
   __syncthreads();
-  for (int o = tid; o < m * d; o += 256) {
-    const int q = o / d, c = o - q * d;
-    float acc = dH[(int64_t)b * m * d + o];
-    const float* zr = sdZ + q * d;
-    for (int f = 0; f < d; ++f) acc += zr[f] * Wo[(int64_t)f * d + c];
-    sdO[o] = acc;
-    dO[(int64_t)b * m * d + o] = acc;
+  const int c = tid % d, q0 = (tid / d) * MQ;
+  const bool act = q0 < m;
+  if (act) {
+    float acc[MQ];
+#pragma unroll
+    for (int q = 0; q < MQ; ++q)
+      acc[q] = (q0 + q < m) ? dH[(int64_t)b * m * d + (q0 + q) * d + c] : 0.f;
+    col_gemm<MQ>(sdZ + q0 * d, d, Wo, d, d, c, acc);
+#pragma unroll
+    for (int q = 0; q < MQ; ++q)
+      if (q0 + q < m) {
+        sdO[(q0 + q) * d + c] = acc[q];
+        dO[(int64_t)b * m * d + (q0 + q) * d + c] = acc[q];
+      }
   }
   __syncthreads();
-  for (int o = tid; o < R * dk; o += 256) {
-    const int r = o / dk, c = o - r * dk, j = r / m, q = r - j * m;
-    const float* orow = sdO + q * d + j * dh;
-    float acc = 0.f;
-    for (int f = 0; f < dh; ++f) acc += orow[f] * Wv[(int64_t)(j * dh + f) * dk + c];
-    sdT[o] = acc;
-    const float tv = T[((int64_t)b * R + r) * dk + c];
-    Th[((int64_t)j * B * m + (int64_t)b * m + q) * dk + c] = tv;
-    if (dTf != nullptr) dTf[((int64_t)b * R + r) * dk + c] = acc;
-    if (dTb != nullptr) {
-      dTb[((int64_t)b * Rp + r) * dk + c] = (__bf16)acc;
-      // position of row r inside its 32-block: r = 32 s + perm32(pos)
-      const int rb32 = r & ~31, ro = r & 31;
-      int pos = 0;
+  // dT[j m + q][cc] = sum_f dO[q][j dh + f] Wv[j dh + f][cc] ; thread owns column cc of dk
+  for (int cc = tid % d; cc < dk && act; cc += d) {
+    for (int j = 0; j < h; ++j) {
+      float acc[MQ];
 #pragma unroll
-      for (int p = 0; p < 32; ++p)
-        if (perm32(p) == ro) pos = p;
-      dTt[((int64_t)b * dk + c) * Rp + rb32 + pos] = (__bf16)acc;
+      for (int q = 0; q < MQ; ++q) acc[q] = 0.f;
+      col_gemm<MQ>(sdO + q0 * d + j * dh, d, Wv + (int64_t)j * dh * dk, dk, dh, cc, acc);
+#pragma unroll
+      for (int q = 0; q < MQ; ++q) {
+        if (q0 + q >= m) continue;
+        const int r = j * m + q0 + q;
+        const float tv = T[((int64_t)b * R + r) * dk + cc];
+        Th[((int64_t)j * B * m + (int64_t)b * m + q0 + q) * dk + cc] = tv;
+        atomicAdd(&sDl[r], acc[q] * tv);
+        if (dTf != nullptr) dTf[((int64_t)b * R + r) * dk + cc] = acc[q];
+        if (dTb != nullptr) {
+          dTb[((int64_t)b * Rp + r) * dk + cc] = (__bf16)acc[q];
+          const int rb32 = r & ~31, ro = r & 31;
+          int pos = 0;
+#pragma unroll
+          for (int p = 0; p < 32; ++p)
+            if (perm32(p) == ro) pos = p;
+          dTt[((int64_t)b * dk + cc) * Rp + rb32 + pos] = (__bf16)acc[q];
+        }
+      }
     }
   }
   __syncthreads();
   for (int r = tid; r < Rp; r += 256) {
-    float dl = 0.f;
-    if (r < R)
-      for (int c = 0; c < dk; ++c) dl += sdT[r * dk + c] * T[((int64_t)b * R + r) * dk + c];
-    Delta[(int64_t)b * Rp + r] = dl;
+    Delta[(int64_t)b * Rp + r] = r < R ? sDl[r] : 0.f;
     LSEp[(int64_t)b * Rp + r] = r < R ? LSE[(int64_t)b * R + r] : 1.0e30f;
   }
   if (dTb != nullptr) {          // zero the padding rows / columns of the bf16 images
     for (int o = tid; o < (Rp - R) * dk; o += 256) {
-      const int r = R + o / dk, c = o % dk;
-      dTb[((int64_t)b * Rp + r) * dk + c] = (__bf16)0.f;
+      const int r = R + o / dk, cc = o % dk;
+      dTb[((int64_t)b * Rp + r) * dk + cc] = (__bf16)0.f;
       const int rb32 = r & ~31, ro = r & 31;
       int pos = 0;
 #pragma unroll
       for (int p = 0; p < 32; ++p)
         if (perm32(p) == ro) pos = p;
-      dTt[((int64_t)b * dk + c) * Rp + rb32 + pos] = (__bf16)0.f;
+      dTt[((int64_t)b * dk + cc) * Rp + rb32 + pos] = (__bf16)0.f;
     }
   }
 }
@@ -150,7 +165,7 @@ struct Mab0BwdArgs {
   const float* Delta;    // [B][Rp]
   float* dX;             // [B, N, 128] or null
   float* DG;             // [Rp][128] fp32, accumulated over sets (ln2-scaled dS units)
-  int B, N, accumulate_dx;
+  int B, N, accumulate_dx, S;
 };
 
 template <int RP>
@@ -169,7 +184,9 @@ __global__ __launch_bounds__(256, 1) void k_mab0_bwd(const Mab0BwdArgs a) {
 
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int r = lane & 15, g = lane >> 4;
-  const int b = blockIdx.x;
+  const int b = blockIdx.x, sp = blockIdx.y;
+  const int per = (int)(((int64_t)(a.N + 127) / 128 + a.S - 1) / a.S) * 128;
+  const int n_lo = sp * per, n_hi = (n_lo + per < a.N) ? n_lo + per : a.N;
 
   for (int c = tid; c < RP * 16; c += 256) {
     const int row = c >> 4, ch = c & 15;
@@ -200,13 +217,13 @@ __global__ __launch_bounds__(256, 1) void k_mab0_bwd(const Mab0BwdArgs a) {
     for (int ft = 0; ft < FT; ++ft) dG[rb][ft] = f32x4{0.f, 0.f, 0.f, 0.f};
   constexpr float LN2 = 0.6931471805599453f;
 
-  for (int n0 = wave * 32; n0 < a.N; n0 += 128) {
+  for (int n0 = n_lo + wave * 32; n0 < n_hi; n0 += 128) {
 #pragma unroll
     for (int e = 0; e < 8; ++e) {
       const int c = lane + 64 * e;
       const int row = c >> 4, ch = c & 15;
       bf16x8 v;
-      if (n0 + row < a.N) {
+      if (n0 + row < n_hi) {
         const float4* src = reinterpret_cast<const float4*>(
             a.X + ((int64_t)b * a.N + n0 + row) * DK + ch * 8);
         const float4 lo = src[0], hi = src[1];
@@ -226,7 +243,7 @@ __global__ __launch_bounds__(256, 1) void k_mab0_bwd(const Mab0BwdArgs a) {
         xrow[pb][ks] = *reinterpret_cast<const bf16x8*>(myX + tr_off(16 * pb + r, 4 * ks + g));
     bool live[2];
 #pragma unroll
-    for (int pb = 0; pb < 2; ++pb) live[pb] = n0 + 16 * pb + r < a.N;
+    for (int pb = 0; pb < 2; ++pb) live[pb] = n0 + 16 * pb + r < n_hi;
 
     f32x4 dx[FT][2];
 #pragma unroll
@@ -374,54 +391,68 @@ __global__ __launch_bounds__(256) void k_mab0_bwd_small(
 
 // ---------------------------------------------------------------------------------
 // shared-query parameters.  dQs = sum_b dO[b] ([m][d]); DG = sum over sets of dS X in
-// "ln2 units": dG_raw = sl2e * DG.   One workgroup.
+// "ln2 units": dG_raw = sl2e * DG.
 //   dWk[f][c]  += sum_q Qp[q][f] dG_raw[j m + q][c]            (j = head of f)
 //   dQp[q][f]   = dQs[q][f] + sum_c dG_raw[j m + q][c] Wk[f][c]
 //   dWq += dQp^T I ; dbq += colsum(dQp) ; dI += dQp Wq
 // ---------------------------------------------------------------------------------
-__global__ __launch_bounds__(256) void k_mab0_post(
+// dot of two strided sequences with 16 independent loads in flight
+__device__ __forceinline__ float dot_strided(const float* __restrict__ a, int64_t sa,
+                                             const float* __restrict__ b, int64_t sb, int n) {
+  float acc = 0.f;
+  int i = 0;
+  for (; i + 16 <= n; i += 16) {
+    float x[16], y[16];
+#pragma unroll
+    for (int u = 0; u < 16; ++u) { x[u] = a[(i + u) * sa]; y[u] = b[(i + u) * sb]; }
+#pragma unroll
+    for (int u = 0; u < 16; ++u) acc = fmaf(x[u], y[u], acc);
+  }
+  for (; i < n; ++i) acc = fmaf(a[i * sa], b[i * sb], acc);
+  return acc;
+}
+
+// stage 1 (grid-parallel): dWk and dQp = dQs + (dG_raw Wk_h^T)
+__global__ __launch_bounds__(256) void k_mab0_post1(
     const float* __restrict__ dQs, const float* __restrict__ DG, const float* __restrict__ Qp,
-    const float* __restrict__ I, const float* __restrict__ Wq, const float* __restrict__ Wk,
-    int m, int d, int dq, int dk, int h, float sl2e, float* __restrict__ dWk,
-    float* __restrict__ dWq, float* __restrict__ dbq, float* __restrict__ dI) {
-  extern __shared__ float sm[];
-  float* sdQ = sm;                 // [m][d]
-  const int tid = threadIdx.x, dh = d / h;
-  for (int o = tid; o < d * dk; o += 256) {
+    const float* __restrict__ Wk, int m, int d, int dk, int h, float sl2e,
+    float* __restrict__ dWk, float* __restrict__ dQp) {
+  const int dh = d / h;
+  const int o = blockIdx.x * 256 + threadIdx.x;
+  if (o < d * dk) {
     const int f = o / dk, c = o - f * dk, j = f / dh;
-    float acc = 0.f;
-    for (int q = 0; q < m; ++q) acc += Qp[q * d + f] * DG[(j * m + q) * dk + c];
-    dWk[o] += sl2e * acc;
+    dWk[o] += sl2e * dot_strided(Qp + f, d, DG + (int64_t)j * m * dk + c, dk, m);
+  } else if (o < d * dk + m * d) {
+    const int oo = o - d * dk;
+    const int q = oo / d, f = oo - q * d, j = f / dh;
+    dQp[oo] = dQs[oo] + sl2e * dot_strided(DG + (int64_t)(j * m + q) * dk, 1,
+                                           Wk + (int64_t)f * dk, 1, dk);
   }
-  for (int o = tid; o < m * d; o += 256) {
-    const int q = o / d, f = o - q * d, j = f / dh;
-    float acc = 0.f;
-    for (int c = 0; c < dk; ++c) acc += DG[(j * m + q) * dk + c] * Wk[(int64_t)f * dk + c];
-    sdQ[o] = dQs[o] + sl2e * acc;
-  }
-  __syncthreads();
-  for (int o = tid; o < d * dq; o += 256) {
+}
+// stage 2: dWq += dQp^T I ; dbq += colsum(dQp) ; dI += dQp Wq
+__global__ __launch_bounds__(256) void k_mab0_post2(
+    const float* __restrict__ dQp, const float* __restrict__ I, const float* __restrict__ Wq,
+    int m, int d, int dq, float* __restrict__ dWq, float* __restrict__ dbq,
+    float* __restrict__ dI) {
+  const int o = blockIdx.x * 256 + threadIdx.x;
+  const int n1 = d * dq, n2 = n1 + d, n3 = n2 + (dI != nullptr ? m * dq : 0);
+  if (o < n1) {
     const int f = o / dq, c = o - f * dq;
+    dWq[o] += dot_strided(dQp + f, d, I + c, dq, m);
+  } else if (o < n2) {
+    const int f = o - n1;
     float acc = 0.f;
-    for (int q = 0; q < m; ++q) acc += sdQ[q * d + f] * I[q * dq + c];
-    dWq[o] += acc;
-  }
-  for (int f = tid; f < d; f += 256) {
-    float acc = 0.f;
-    for (int q = 0; q < m; ++q) acc += sdQ[q * d + f];
+    for (int q = 0; q < m; ++q) acc += dQp[q * d + f];
     dbq[f] += acc;
+  } else if (o < n3) {
+    const int oo = o - n2;
+    const int q = oo / dq, c = oo - q * dq;
+    dI[oo] += dot_strided(dQp + (int64_t)q * d, 1, Wq + c, dq, d);
   }
-  if (dI != nullptr)
-    for (int o = tid; o < m * dq; o += 256) {
-      const int q = o / dq, c = o - q * dq;
-      float acc = 0.f;
-      for (int f = 0; f < d; ++f) acc += sdQ[q * d + f] * Wq[(int64_t)f * dq + c];
-      dI[o] += acc;
-    }
 }
 
 struct BwdWs0 {
-  float *dZ, *dO, *Th, *dTf, *Delta, *LSEp, *DG, *dQs;
+  float *dZ, *dO, *Th, *dTf, *Delta, *LSEp, *DG, *dQs, *dQp;
   __bf16 *dTb, *dTt, *GtP;
 };
 size_t carve_ws0(const pca_mab_shape& s, BwdWs0* out, void* base) {
@@ -437,6 +468,7 @@ size_t carve_ws0(const pca_mab_shape& s, BwdWs0* out, void* base) {
   w.LSEp = c.take<float>((size_t)s.B * Rp);
   w.DG = c.take<float>((size_t)Rp * s.dk);
   w.dQs = c.take<float>((size_t)s.nq * s.d);
+  w.dQp = c.take<float>((size_t)s.nq * s.d);
   w.dTb = c.take<__bf16>((size_t)s.B * Rp * s.dk);
   w.dTt = c.take<__bf16>((size_t)s.B * Rp * s.dk);
   w.GtP = c.take<__bf16>((size_t)Rp * s.dk);
@@ -466,10 +498,15 @@ int mab0_bf16_bwd(const pca_mab_shape& s, const float* I, const float* X,
     return PCA_EUNSUPPORTED;
   }
 
-  const size_t el = (2 * (size_t)m * d + (size_t)R * dk) * sizeof(float);
-  hipLaunchKernelGGL(k_mab0_epi_bwd, dim3(s.B), dim3(256), el, st, dH, v.Z, v.T, v.LSE, p.wo, p.wv,
-                     m, d, dk, h, Rp, w.dZ, w.dO, w.Th, small ? w.dTf : nullptr,
-                     small ? nullptr : w.dTb, small ? nullptr : w.dTt, w.Delta, w.LSEp, s.B);
+  const size_t el = (2 * (size_t)m * d + (size_t)Rp) * sizeof(float);
+  if (m > 2)
+    hipLaunchKernelGGL((k_mab0_epi_bwd<8>), dim3(s.B), dim3(256), el, st, dH, v.Z, v.T, v.LSE, p.wo,
+                       p.wv, m, d, dk, h, Rp, w.dZ, w.dO, w.Th, small ? w.dTf : nullptr,
+                       small ? nullptr : w.dTb, small ? nullptr : w.dTt, w.Delta, w.LSEp, s.B);
+  else
+    hipLaunchKernelGGL((k_mab0_epi_bwd<1>), dim3(s.B), dim3(256), el, st, dH, v.Z, v.T, v.LSE, p.wo,
+                       p.wv, m, d, dk, h, Rp, w.dZ, w.dO, w.Th, small ? w.dTf : nullptr,
+                       small ? nullptr : w.dTb, small ? nullptr : w.dTt, w.Delta, w.LSEp, s.B);
   PCA_TRY(check_launch("k_mab0_epi_bwd"));
   PCA_TRY(fill_zero(w.DG, (int64_t)Rp * dk, st));
 
@@ -481,8 +518,9 @@ int mab0_bf16_bwd(const pca_mab_shape& s, const float* I, const float* X,
     hipLaunchKernelGGL(k_mab0_gt, dim3((unsigned)cdiv(dk * Rp, 256)), dim3(256), 0, st, v.Gf, R, Rp,
                        dk, w.GtP);
     PCA_TRY(check_launch("k_mab0_gt"));
+    const int S = mab0_splits(s);
     Mab0BwdArgs a{X, v.Gb, w.GtP, w.dTb, w.dTt, w.LSEp, w.Delta, dX, w.DG, s.B, s.nk,
-                  dk_accumulate ? 1 : 0};
+                  dk_accumulate ? 1 : 0, S};
     const size_t lds = 2 * (size_t)Rp * 256 + 2 * (size_t)128 * Rp * 2 + 2 * 4 * 32 * 256 +
                        2 * Rp * sizeof(float);
     static std::once_flag once;
@@ -494,34 +532,35 @@ int mab0_bf16_bwd(const pca_mab_shape& s, const float* I, const float* X,
     });
     const double pts = (double)s.B * s.nk;
     ProfScope ps(PCA_K_MAB0_BWD, st, 4.0 * pts * (2.0 * dk * d + 2.0 * m * d), pts * 8.0 * dk);
-    if (Rp == 32) hipLaunchKernelGGL((k_mab0_bwd<32>), dim3(s.B), dim3(256), lds, st, a);
-    else hipLaunchKernelGGL((k_mab0_bwd<64>), dim3(s.B), dim3(256), lds, st, a);
+    if (Rp == 32) hipLaunchKernelGGL((k_mab0_bwd<32>), dim3(s.B, S), dim3(256), lds, st, a);
+    else hipLaunchKernelGGL((k_mab0_bwd<64>), dim3(s.B, S), dim3(256), lds, st, a);
     ps.end();
     PCA_TRY(check_launch("k_mab0_bwd"));
   }
 
-  // ---- parameter gradients of the epilogue: [B*m]-row reductions on the fp32 GEMM ----
+  // ---- parameter gradients of the epilogue: [B*m]-row reductions, ONE MFMA launch ----
   {
-    pca_gemm_desc g{};                         // dWo += dZ^T O
-    g.M = d; g.N = d; g.K = Bm; g.sa_m = 1; g.sa_k = d; g.sb_k = d; g.sb_n = 1; g.sc_m = d;
-    g.nb1 = g.nb2 = 1; g.accumulate = 1; g.split_k = 0; g.alpha = 1.f;
-    PCA_TRY(gemm_f32(g, w.dZ, v.O, nullptr, gr.wo, st));
-    PCA_TRY(colsum(w.dZ, Bm, d, gr.bo, 1, st));
-    PCA_TRY(colsum(w.dO, Bm, d, gr.bv, 1, st));
-  }
-  {                                            // dWv_j += dO_j^T Th_j   (batched over heads)
-    pca_gemm_desc g{};
-    const int dh = d / h;
-    g.M = dh; g.N = dk; g.K = Bm; g.sa_m = 1; g.sa_k = d; g.sb_k = dk; g.sb_n = 1; g.sc_m = dk;
-    g.nb1 = 1; g.nb2 = h;
-    g.sa_b2 = dh; g.sb_b2 = (int64_t)Bm * dk; g.sc_b2 = (int64_t)dh * dk;
-    g.accumulate = 1; g.split_k = 0; g.alpha = 1.f;
-    PCA_TRY(gemm_f32(g, w.dO, w.Th, nullptr, gr.wv, st));
+    WgradJobs jobs{};
+    jobs.j[0] = WgradJob{w.dZ, v.O, gr.wo, gr.bo, Bm, 0, 128};
+    jobs.n = 1;
+    if (!small) {
+      const int dh = d / h;
+      for (int j = 0; j < h; ++j)          // dWv rows of head j  <-  dO^T . T_j
+        jobs.j[jobs.n++] = WgradJob{w.dO, w.Th + (int64_t)j * Bm * dk, gr.wv,
+                                    j == 0 ? gr.bv : nullptr, Bm, j * dh, (j + 1) * dh};
+    }
+    PCA_TRY(wgrad128_launch(jobs, false, false, 64, st));
+    if (small)
+      PCA_TRY(wgrad_small_f32_launch(w.dO, w.Th, Bm, dk, (int64_t)Bm * dk, gr.wv, gr.bv, st));
   }
   PCA_TRY(colsum(w.dO, s.B, m * d, w.dQs, 0, st));        // sum over sets
-  hipLaunchKernelGGL(k_mab0_post, dim3(1), dim3(256), (size_t)m * d * sizeof(float), st, w.dQs,
-                     w.DG, v.Qp, I, p.wq, p.wk, m, d, s.dq, dk, h, sl2e, gr.wk, gr.wq, gr.bq, dI);
-  return check_launch("k_mab0_post");
+  hipLaunchKernelGGL(k_mab0_post1, dim3((unsigned)cdiv(d * dk + m * d, 256)), dim3(256), 0, st,
+                     w.dQs, w.DG, v.Qp, p.wk, m, d, dk, h, sl2e, gr.wk, w.dQp);
+  PCA_TRY(check_launch("k_mab0_post1"));
+  hipLaunchKernelGGL(k_mab0_post2,
+                     dim3((unsigned)cdiv(d * s.dq + d + (dI ? m * s.dq : 0), 256)), dim3(256), 0,
+                     st, w.dQp, I, p.wq, m, d, s.dq, gr.wq, gr.bq, dI);
+  return check_launch("k_mab0_post2");
 }
 
 }  // namespace pca

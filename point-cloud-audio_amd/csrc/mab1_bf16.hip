@@ -43,6 +43,21 @@ __global__ void k_prep_weight(const float* __restrict__ src, __bf16* __restrict_
   dst[idx] = (__bf16)v;
 }
 
+__global__ void k_transpose_f32(const float* __restrict__ src, float* __restrict__ dst, int rows,
+                                int cols) {
+  __shared__ float t[32][33];
+  const int r0 = blockIdx.y * 32, c0 = blockIdx.x * 32;
+  for (int i = threadIdx.y; i < 32; i += 8) {
+    const int r = r0 + i, c = c0 + threadIdx.x;
+    t[i][threadIdx.x] = (r < rows && c < cols) ? src[(int64_t)r * cols + c] : 0.f;
+  }
+  __syncthreads();
+  for (int i = threadIdx.y; i < 32; i += 8) {
+    const int c = c0 + i, r = r0 + threadIdx.x;
+    if (r < rows && c < cols) dst[(int64_t)c * rows + r] = t[threadIdx.x][i];
+  }
+}
+
 // ---------------------------------------------------------------------------------
 // K/V projection of the m inducing-point outputs of one set (tiny): Kp = H Wk^T + bk,
 // Vp = H Wv^T + bv, written in the four bf16 images the chain kernels read:
@@ -54,9 +69,9 @@ __global__ void k_prep_weight(const float* __restrict__ src, __bf16* __restrict_
 // ---------------------------------------------------------------------------------
 template <int MI>
 __global__ __launch_bounds__(256) void k_kv_proj(const float* __restrict__ H,
-                                                 const float* __restrict__ Wk,
+                                                 const float* __restrict__ WkT,   // [d][d] in x out
                                                  const float* __restrict__ bk,
-                                                 const float* __restrict__ Wv,
+                                                 const float* __restrict__ WvT,
                                                  const float* __restrict__ bv, int d,
                                                  __bf16* __restrict__ KpP,
                                                  __bf16* __restrict__ VpP,
@@ -66,38 +81,28 @@ __global__ __launch_bounds__(256) void k_kv_proj(const float* __restrict__ H,
   const int b = blockIdx.x;
   for (int i = threadIdx.x; i < MI * d; i += 256) sH[i] = H[(int64_t)b * MI * d + i];
   __syncthreads();
-  for (int f = threadIdx.x; f < d; f += 256) {
-    float ak[MI], av[MI];
+  // thread = (output feature f, K or V); d == 128 -> 256 threads cover both
+  for (int o = threadIdx.x; o < 2 * d; o += 256) {
+    const int f = o % d, isv = o / d;
+    float acc[MI];
+    const float bias = isv ? bv[f] : bk[f];
 #pragma unroll
-    for (int i = 0; i < MI; ++i) { ak[i] = bk[f]; av[i] = bv[f]; }
-    const float* wk = Wk + (int64_t)f * d;
-    const float* wv = Wv + (int64_t)f * d;
-    for (int c = 0; c < d; c += 4) {
-      const float4 k4 = *reinterpret_cast<const float4*>(wk + c);
-      const float4 v4 = *reinterpret_cast<const float4*>(wv + c);
-#pragma unroll
-      for (int i = 0; i < MI; ++i) {
-        const float4 h4 = *reinterpret_cast<const float4*>(&sH[i * d + c]);
-        ak[i] += h4.x * k4.x + h4.y * k4.y + h4.z * k4.z + h4.w * k4.w;
-        av[i] += h4.x * v4.x + h4.y * v4.y + h4.z * v4.z + h4.w * v4.w;
-      }
-    }
+    for (int i = 0; i < MI; ++i) acc[i] = bias;
+    col_gemm<MI>(sH, d, isv ? WvT : WkT, d, d, f, acc);
     // feature f sits at position pos inside its 32-block: f = 32j + perm32(pos)
     const int jb = f & ~31, fo = f & 31;
     int pos = 0;
 #pragma unroll
     for (int p = 0; p < 32; ++p)
       if (perm32(p) == fo) pos = p;
+    __bf16* PP = isv ? VpP : KpP;
+    __bf16* TT = isv ? Vt : Kt;
 #pragma unroll
-    for (int i = 0; i < MI; ++i) {
-      KpP[((int64_t)b * MI + i) * d + jb + pos] = (__bf16)ak[i];
-      VpP[((int64_t)b * MI + i) * d + jb + pos] = (__bf16)av[i];
-    }
+    for (int i = 0; i < MI; ++i) PP[((int64_t)b * MI + i) * d + jb + pos] = (__bf16)acc[i];
 #pragma unroll
     for (int kp = 0; kp < MI; ++kp) {
       const int key = (MI == 32) ? perm32(kp) : kp;
-      Kt[((int64_t)b * d + f) * MI + kp] = (__bf16)ak[key];
-      Vt[((int64_t)b * d + f) * MI + kp] = (__bf16)av[key];
+      TT[((int64_t)b * d + f) * MI + kp] = (__bf16)acc[key];
     }
   }
 }
@@ -381,6 +386,11 @@ int launch_fwd(const Mab1FwdArgs& a, hipStream_t st) {
 }  // namespace
 
 // ---- host side --------------------------------------------------------------------
+int transpose_f32(const float* src, float* dst, int rows, int cols, hipStream_t st) {
+  hipLaunchKernelGGL(k_transpose_f32, dim3((unsigned)cdiv(cols, 32), (unsigned)cdiv(rows, 32)),
+                     dim3(32, 8), 0, st, src, dst, rows, cols);
+  return check_launch("k_transpose_f32");
+}
 int prep_weight(const float* src, __bf16* dst, int rows, int cols, int mode, hipStream_t st) {
   hipLaunchKernelGGL(k_prep_weight, dim3((unsigned)cdiv((int64_t)rows * cols, 256)), dim3(256), 0,
                      st, src, dst, rows, cols, mode);
@@ -413,7 +423,8 @@ size_t mab1_bf16_saved_bytes(const pca_mab_shape& s) {
   return mab1_carve_saved(s, nullptr, nullptr);
 }
 size_t mab1_bf16_fwd_ws_bytes(const pca_mab_shape& s) {
-  return 2 * align256((size_t)s.d * s.d * 2) + mab1_carve_saved(s, nullptr, nullptr);
+  return 2 * align256((size_t)s.d * s.d * 2) + 2 * align256((size_t)s.d * s.d * 4) +
+         mab1_carve_saved(s, nullptr, nullptr);
 }
 
 // Q = X [B, nq, dq] fp32, K = H [B, nk, d] fp32 -> Y [B, nq, d] fp32
@@ -424,6 +435,8 @@ int mab1_bf16_fwd(const pca_mab_shape& s, const float* X, const float* H,
   Carver cw(ws);
   __bf16* WqB = cw.take<__bf16>((size_t)s.d * s.d);
   __bf16* WoP = cw.take<__bf16>((size_t)s.d * s.d);
+  float* WkT = cw.take<float>((size_t)s.d * s.d);
+  float* WvT = cw.take<float>((size_t)s.d * s.d);
   Mab1Saved v;
   const bool training = saved != nullptr;
   mab1_carve_saved(s, &v, training ? saved : (void*)(cw.base + cw.off));
@@ -432,12 +445,14 @@ int mab1_bf16_fwd(const pca_mab_shape& s, const float* X, const float* H,
 
   if (!small) PCA_TRY(prep_weight(p.wq, WqB, d, d, 0, st));
   PCA_TRY(prep_weight(p.wo, WoP, d, d, 1, st));
+  PCA_TRY(transpose_f32(p.wk, WkT, d, d, st));
+  PCA_TRY(transpose_f32(p.wv, WvT, d, d, st));
   const size_t hl = (size_t)s.nk * d * sizeof(float);
   if (s.nk == 16)
-    hipLaunchKernelGGL((k_kv_proj<16>), dim3(s.B), dim3(256), hl, st, H, p.wk, p.bk, p.wv, p.bv,
+    hipLaunchKernelGGL((k_kv_proj<16>), dim3(s.B), dim3(256), hl, st, H, WkT, p.bk, WvT, p.bv,
                        d, v.KpP, v.VpP, v.Kt, v.Vt);
   else
-    hipLaunchKernelGGL((k_kv_proj<32>), dim3(s.B), dim3(256), hl, st, H, p.wk, p.bk, p.wv, p.bv,
+    hipLaunchKernelGGL((k_kv_proj<32>), dim3(s.B), dim3(256), hl, st, H, WkT, p.bk, WvT, p.bv,
                        d, v.KpP, v.VpP, v.Kt, v.Vt);
   PCA_TRY(check_launch("k_kv_proj"));
 

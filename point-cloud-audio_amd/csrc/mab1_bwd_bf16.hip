@@ -294,17 +294,21 @@ __device__ __forceinline__ bf16x8 load8(const float* p) {
   return v;
 }
 
-template <typename AT>
-__global__ __launch_bounds__(256) void k_wgrad128(const __bf16* __restrict__ G,
-                                                  const AT* __restrict__ A, int64_t M,
-                                                  int rows_per_wg, float* __restrict__ dW,
-                                                  float* __restrict__ db) {
+// Software-pipelined: the next 32-row tile is fetched into registers while the current one is
+// consumed from LDS; two LDS buffers -> one barrier per tile.  blockIdx.y selects the job.
+template <typename GT, typename AT>
+__global__ __launch_bounds__(256) void k_wgrad128(const WgradJobs jobs, int rows_per_wg) {
   constexpr int D = 128;
-  __shared__ __attribute__((aligned(16))) char sG[32 * 256];
-  __shared__ __attribute__((aligned(16))) char sA[32 * 256];
+  __shared__ __attribute__((aligned(16))) char sG[2][32 * 256];
+  __shared__ __attribute__((aligned(16))) char sA[2][32 * 256];
+  const WgradJob job = jobs.j[blockIdx.y];
+  const GT* __restrict__ G = reinterpret_cast<const GT*>(job.G);
+  const AT* __restrict__ A = reinterpret_cast<const AT*>(job.A);
+  const int64_t M = job.M;
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int r = lane & 15, g = lane >> 4;
   const int64_t r0 = (int64_t)blockIdx.x * rows_per_wg;
+  if (r0 >= M) return;
   const int64_t r1 = (r0 + rows_per_wg < M) ? r0 + rows_per_wg : M;
   f32x4 acc[2][8];
 #pragma unroll
@@ -313,69 +317,134 @@ __global__ __launch_bounds__(256) void k_wgrad128(const __bf16* __restrict__ G,
     for (int t = 0; t < 8; ++t) acc[i][t] = f32x4{0.f, 0.f, 0.f, 0.f};
   float bsum = 0.f;
 
-  for (int64_t base = r0; base < r1; base += 32) {
+  bf16x8 vg[2], va[2];
+  auto fetch = [&](int64_t base) {
 #pragma unroll
     for (int e = 0; e < 2; ++e) {
       const int c = tid + e * 256;
       const int row = c >> 4, ch = c & 15;
-      bf16x8 vg, va;
       if (base + row < r1) {
-        vg = load8(G + (base + row) * D + ch * 8);
-        va = load8(A + (base + row) * D + ch * 8);
+        vg[e] = load8(G + (base + row) * D + ch * 8);
+        va[e] = load8(A + (base + row) * D + ch * 8);
       } else {
 #pragma unroll
-        for (int k = 0; k < 8; ++k) { vg[k] = (__bf16)0.f; va[k] = (__bf16)0.f; }
+        for (int k = 0; k < 8; ++k) { vg[e][k] = (__bf16)0.f; va[e][k] = (__bf16)0.f; }
       }
-      *reinterpret_cast<bf16x8*>(sG + tr_off(row, ch)) = vg;
-      *reinterpret_cast<bf16x8*>(sA + tr_off(row, ch)) = va;
+    }
+  };
+  fetch(r0);
+  int buf = 0;
+  for (int64_t base = r0; base < r1; base += 32, buf ^= 1) {
+#pragma unroll
+    for (int e = 0; e < 2; ++e) {
+      const int c = tid + e * 256;
+      const int row = c >> 4, ch = c & 15;
+      *reinterpret_cast<bf16x8*>(sG[buf] + tr_off(row, ch)) = vg[e];
+      *reinterpret_cast<bf16x8*>(sA[buf] + tr_off(row, ch)) = va[e];
     }
     __syncthreads();
-    if (db != nullptr && tid < D) {
+    if (base + 32 < r1) fetch(base + 32);
+    if (job.db != nullptr && tid < D) {
 #pragma unroll 8
       for (int row = 0; row < 32; ++row)
-        bsum += (float)*reinterpret_cast<const __bf16*>(sG + tr_off(row, tid >> 3) + (tid & 7) * 2);
+        bsum += (float)*reinterpret_cast<const __bf16*>(sG[buf] + tr_off(row, tid >> 3) +
+                                                        (tid & 7) * 2);
     }
     bf16x8 ga[2];
 #pragma unroll
-    for (int i = 0; i < 2; ++i) ga[i] = tr_frag(sG, 2 * wave + i, lane);
+    for (int i = 0; i < 2; ++i) ga[i] = tr_frag(sG[buf], 2 * wave + i, lane);
 #pragma unroll
     for (int t = 0; t < 8; ++t) {
-      const bf16x8 ab = tr_frag(sA, t, lane);
+      const bf16x8 ab = tr_frag(sA[buf], t, lane);
 #pragma unroll
       for (int i = 0; i < 2; ++i) acc[i][t] = mfma32(ga[i], ab, acc[i][t]);
     }
-    __syncthreads();
   }
 #pragma unroll
   for (int i = 0; i < 2; ++i)
 #pragma unroll
-    for (int t = 0; t < 8; ++t)
+    for (int e = 0; e < 4; ++e) {
+      const int grow = 16 * (2 * wave + i) + 4 * g + e;
+      if (grow < job.g_lo || grow >= job.g_hi) continue;
 #pragma unroll
-      for (int e = 0; e < 4; ++e)
-        atomicAdd(&dW[(16 * (2 * wave + i) + 4 * g + e) * D + 16 * t + r], acc[i][t][e]);
-  if (db != nullptr && tid < D) atomicAdd(&db[tid], bsum);
+      for (int t = 0; t < 8; ++t) atomicAdd(&job.dW[grow * D + 16 * t + r], acc[i][t][e]);
+    }
+  if (job.db != nullptr && tid < D) atomicAdd(&job.db[tid], bsum);
 }
 
-// layer 1: dW[D x dq] += dQp^T . X with dq <= 4 (fp32 X), db += colsum(dQp)
-__global__ __launch_bounds__(128) void k_wgrad_small(const __bf16* __restrict__ G,
+// dH[q][c] (+)= sum_f dKp[q][f] Wk[f][c] + dVp[q][f] Wv[f][c]; thread = (column c, query half)
+__global__ __launch_bounds__(256) void k_kv_dh(const float* __restrict__ dKp,
+                                               const float* __restrict__ dVp,
+                                               const float* __restrict__ Wk,
+                                               const float* __restrict__ Wv,
+                                               float* __restrict__ dH, int m, int d,
+                                               int accumulate) {
+  extern __shared__ float sm[];
+  float* sK = sm;
+  float* sV = sm + m * d;
+  const int b = blockIdx.x, tid = threadIdx.x;
+  for (int i = tid; i < m * d; i += 256) {
+    sK[i] = dKp[(int64_t)b * m * d + i];
+    sV[i] = dVp[(int64_t)b * m * d + i];
+  }
+  __syncthreads();
+  const int c = tid % d, q0 = (tid / d) * 8;
+  if (q0 >= m) return;
+  float acc[8];
+#pragma unroll
+  for (int q = 0; q < 8; ++q)
+    acc[q] = (accumulate && q0 + q < m) ? dH[(int64_t)b * m * d + (q0 + q) * d + c] : 0.f;
+  col_gemm<8>(sK + q0 * d, d, Wk, d, d, c, acc);
+  col_gemm<8>(sV + q0 * d, d, Wv, d, d, c, acc);
+#pragma unroll
+  for (int q = 0; q < 8; ++q)
+    if (q0 + q < m) dH[(int64_t)b * m * d + (q0 + q) * d + c] = acc[q];
+}
+
+// layer 1: dW[D x dq] += dQp^T . X with dq <= 4 (fp32 X), db += colsum(dQp).
+// 256 threads = 128 features x 2 row phases; 128 rows per workgroup, loads unrolled.
+template <typename GT>
+__global__ __launch_bounds__(256) void k_wgrad_small(const GT* __restrict__ G,
                                                      const float* __restrict__ X, int64_t M,
                                                      int dq, int rows_per_wg,
+                                                     int64_t x_head_stride,   // A = X + (f/32)*stride
                                                      float* __restrict__ dW,
                                                      float* __restrict__ db) {
   constexpr int D = 128;
-  const int f = threadIdx.x;
+  __shared__ float red[128][5];
+  const int f = threadIdx.x & 127, ph = threadIdx.x >> 7;
+  const float* __restrict__ Xh = X + (int64_t)(f >> 5) * x_head_stride;
   const int64_t r0 = (int64_t)blockIdx.x * rows_per_wg;
   const int64_t r1 = (r0 + rows_per_wg < M) ? r0 + rows_per_wg : M;
   float acc[4] = {0.f, 0.f, 0.f, 0.f}, bs = 0.f;
-  for (int64_t row = r0; row < r1; ++row) {
-    const float gv = (float)G[row * D + f];
-    bs += gv;
+  // batches of 8 rows: 8 independent G loads (+ the broadcast X rows) in flight
+  for (int64_t row = r0 + ph; row < r1; row += 16) {
+    float gv[8], xv[8][4];
 #pragma unroll
-    for (int c = 0; c < 4; ++c)
-      if (c < dq) acc[c] += gv * X[row * dq + c];
+    for (int u = 0; u < 8; ++u) {
+      const int64_t rr = row + 2 * u;
+      const bool ok = rr < r1;
+      gv[u] = ok ? (float)G[rr * D + f] : 0.f;
+#pragma unroll
+      for (int c = 0; c < 4; ++c) xv[u][c] = (ok && c < dq) ? Xh[rr * dq + c] : 0.f;
+    }
+#pragma unroll
+    for (int u = 0; u < 8; ++u) {
+      bs += gv[u];
+#pragma unroll
+      for (int c = 0; c < 4; ++c) acc[c] = fmaf(gv[u], xv[u][c], acc[c]);
+    }
   }
-  for (int c = 0; c < dq; ++c) atomicAdd(&dW[f * dq + c], acc[c]);
-  atomicAdd(&db[f], bs);
+  if (ph == 1) {
+#pragma unroll
+    for (int c = 0; c < 4; ++c) red[f][c] = acc[c];
+    red[f][4] = bs;
+  }
+  __syncthreads();
+  if (ph == 0) {
+    for (int c = 0; c < dq; ++c) atomicAdd(&dW[f * dq + c], acc[c] + red[f][c]);
+    if (db != nullptr) atomicAdd(&db[f], bs + red[f][4]);
+  }
 }
 
 // per (set, head): dKp[b][key][32j + c] = sum_n dS[n][j*MI + key] Qp[n][32j + c]
@@ -474,6 +543,40 @@ size_t carve_bwd_ws(const pca_mab_shape& s, BwdWs* out, void* base) {
 
 size_t mab1_bf16_bwd_ws_bytes(const pca_mab_shape& s) { return carve_bwd_ws(s, nullptr, nullptr); }
 
+int wgrad128_launch(const WgradJobs& jobs, bool g_bf16, bool a_bf16, int rows_per_wg,
+                    hipStream_t st) {
+  int64_t maxM = 0;
+  for (int i = 0; i < jobs.n; ++i) maxM = jobs.j[i].M > maxM ? jobs.j[i].M : maxM;
+  if (maxM == 0 || jobs.n == 0) return PCA_OK;
+  const dim3 grid((unsigned)cdiv(maxM, rows_per_wg), (unsigned)jobs.n);
+  if (g_bf16 && a_bf16)
+    hipLaunchKernelGGL((k_wgrad128<__bf16, __bf16>), grid, dim3(256), 0, st, jobs, rows_per_wg);
+  else if (g_bf16)
+    hipLaunchKernelGGL((k_wgrad128<__bf16, float>), grid, dim3(256), 0, st, jobs, rows_per_wg);
+  else if (!a_bf16)
+    hipLaunchKernelGGL((k_wgrad128<float, float>), grid, dim3(256), 0, st, jobs, rows_per_wg);
+  else {
+    set_error("wgrad128: fp32 G with bf16 A is not instantiated");
+    return PCA_EUNSUPPORTED;
+  }
+  return check_launch("k_wgrad128");
+}
+
+int wgrad_small_f32_launch(const float* G, const float* X, int64_t M, int dq,
+                           int64_t x_head_stride, float* dW, float* db, hipStream_t st) {
+  hipLaunchKernelGGL((k_wgrad_small<float>), dim3((unsigned)cdiv(M, 64)), dim3(256), 0, st, G, X, M,
+                     dq, 64, x_head_stride, dW, db);
+  return check_launch("k_wgrad_small<float>");
+}
+
+int kv_dh_launch(const float* dKp, const float* dVp, const float* Wk, const float* Wv, float* dH,
+                 int B, int m, int d, int accumulate, hipStream_t st) {
+  PCA_REQUIRE(d == 128 && m <= 16, "kv_dh: d=%d m=%d", d, m);
+  hipLaunchKernelGGL(k_kv_dh, dim3(B), dim3(256), 2 * (size_t)m * d * sizeof(float), st, dKp, dVp,
+                     Wk, Wv, dH, m, d, accumulate);
+  return check_launch("k_kv_dh");
+}
+
 // dQ -> dX [B, nq, dq] (written; may be null), dK -> dH [B, nk, d] (written or accumulated)
 int mab1_bf16_bwd(const pca_mab_shape& s, const float* X, const float* H,
                   const pca_mab_params& p, const void* saved, const float* dY, float* dX,
@@ -514,26 +617,27 @@ int mab1_bf16_bwd(const pca_mab_shape& s, const float* X, const float* H,
     rc = want_dx ? launch_bwd<128, 32, true>(a, st, flops, bytes)
                  : launch_bwd<128, 32, false>(a, st, flops, bytes);
   PCA_TRY(rc);
-  // ---- reductions over points ----
-  const int rows_per_wg = 1024;
-  const unsigned nwg = (unsigned)cdiv(M, rows_per_wg);
+  // ---- reductions over points (one launch for dWo / dWq) ----
+  const int rows_per_wg = 512;
   {
+    WgradJobs jobs{};
+    jobs.j[0] = WgradJob{w.dZ, v.OS, gr.wo, gr.bo, M, 0, 128};
+    jobs.n = 1;
     ProfScope ps(PCA_K_WGRAD, st, 2.0 * M * d * d, 4.0 * M * d);
-    hipLaunchKernelGGL((k_wgrad128<__bf16>), dim3(nwg), dim3(256), 0, st, w.dZ, v.OS, M,
-                       rows_per_wg, gr.wo, gr.bo);
+    PCA_TRY(wgrad128_launch(jobs, true, true, rows_per_wg, st));
     ps.end();
   }
-  PCA_TRY(check_launch("k_wgrad128(wo)"));
   if (small) {
-    hipLaunchKernelGGL(k_wgrad_small, dim3((unsigned)cdiv(M, 512)), dim3(128), 0, st, w.dQp, X, M,
-                       s.dq, 512, gr.wq, gr.bq);
+    hipLaunchKernelGGL((k_wgrad_small<__bf16>), dim3((unsigned)cdiv(M, 128)), dim3(256), 0, st,
+                       w.dQp, X, M, s.dq, 128, (int64_t)0, gr.wq, gr.bq);
     PCA_TRY(check_launch("k_wgrad_small"));
   } else {
+    WgradJobs jobs{};
+    jobs.j[0] = WgradJob{w.dQp, X, gr.wq, gr.bq, M, 0, 128};
+    jobs.n = 1;
     ProfScope ps(PCA_K_WGRAD, st, 2.0 * M * d * d, 6.0 * M * d);
-    hipLaunchKernelGGL((k_wgrad128<float>), dim3(nwg), dim3(256), 0, st, w.dQp, X, M,
-                       rows_per_wg, gr.wq, gr.bq);
+    PCA_TRY(wgrad128_launch(jobs, true, false, rows_per_wg, st));
     ps.end();
-    PCA_TRY(check_launch("k_wgrad128(wq)"));
   }
   if (MI == 16)
     hipLaunchKernelGGL((k_kv_grad<16>), dim3(s.B * s.h), dim3(256), 0, st, w.dS, w.P, v.QpS,
@@ -543,13 +647,22 @@ int mab1_bf16_bwd(const pca_mab_shape& s, const float* X, const float* H,
                        w.dOs, s.nq, d, s.h, w.dKp, w.dVp);
   PCA_TRY(check_launch("k_kv_grad"));
 
-  // ---- fc_k / fc_v of the m inducing-point outputs (tiny [B*m, d] GEMMs, fp32) ----
+  // ---- fc_k / fc_v of the m inducing-point outputs: [B*m]-row reductions, one launch ----
   const int64_t Mk = (int64_t)s.B * MI;
-  PCA_TRY(linear_bwd_f32(H, p.wk, w.dKp, nullptr, gr.wk, gr.bk, Mk, d, d, st));
-  PCA_TRY(linear_bwd_f32(H, p.wv, w.dVp, nullptr, gr.wv, gr.bv, Mk, d, d, st));
+  {
+    WgradJobs jobs{};
+    jobs.j[0] = WgradJob{w.dKp, H, gr.wk, gr.bk, Mk, 0, 128};
+    jobs.j[1] = WgradJob{w.dVp, H, gr.wv, gr.bv, Mk, 0, 128};
+    jobs.n = 2;
+    PCA_TRY(wgrad128_launch(jobs, false, false, 64, st));
+  }
   if (dH != nullptr) {
-    PCA_TRY(linear_dx_acc_f32(w.dKp, p.wk, dH, Mk, d, d, dk_accumulate ? 1 : 0, st));
-    PCA_TRY(linear_dx_acc_f32(w.dVp, p.wv, dH, Mk, d, d, 1, st));
+    if (MI <= 16) {
+      PCA_TRY(kv_dh_launch(w.dKp, w.dVp, p.wk, p.wv, dH, s.B, MI, d, dk_accumulate ? 1 : 0, st));
+    } else {
+      PCA_TRY(linear_dx_acc_f32(w.dKp, p.wk, dH, Mk, d, d, dk_accumulate ? 1 : 0, st));
+      PCA_TRY(linear_dx_acc_f32(w.dVp, p.wv, dH, Mk, d, d, 1, st));
+    }
   }
   return PCA_OK;
 }
