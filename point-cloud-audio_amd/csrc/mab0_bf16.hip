@@ -436,8 +436,16 @@ size_t mab0_bf16_fwd_ws_bytes(const pca_mab_shape& s) {
   return mab0_carve_saved(s, nullptr, nullptr);
 }
 
+int mab0_bf16_fwd_ex(const pca_mab_shape& s, const float* I, const float* X,
+                     const pca_mab_params& p, float* H, void* saved, void* ws, int flags,
+                     hipStream_t st);
 int mab0_bf16_fwd(const pca_mab_shape& s, const float* I, const float* X,
                   const pca_mab_params& p, float* H, void* saved, void* ws, hipStream_t st) {
+  return mab0_bf16_fwd_ex(s, I, X, p, H, saved, ws, 0, st);
+}
+int mab0_bf16_fwd_ex(const pca_mab_shape& s, const float* I, const float* X,
+                     const pca_mab_params& p, float* H, void* saved, void* ws, int flags,
+                     hipStream_t st) {
   PCA_REQUIRE(mab0_bf16_supported(s), "mab0_bf16_fwd: unsupported shape");
   const bool training = saved != nullptr;
   PCA_REQUIRE(training || ws != nullptr, "mab0_bf16_fwd: scratch required");
@@ -485,6 +493,7 @@ int mab0_bf16_fwd(const pca_mab_shape& s, const float* I, const float* X,
     ps.end();
     PCA_TRY(check_launch("k_mab0_attn"));
   }
+  if (flags & PCA_F_SKIP_EPILOGUE) return PCA_OK;
   PCA_TRY(transpose_f32(p.wv, v.WvT, d, dk, st));
   PCA_TRY(transpose_f32(p.wo, v.WoT, d, d, st));
   const size_t el = ((size_t)R * dk + (size_t)m * d) * sizeof(float);

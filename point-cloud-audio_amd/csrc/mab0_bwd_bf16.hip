@@ -451,13 +451,10 @@ __global__ __launch_bounds__(256) void k_mab0_post2(
   }
 }
 
-struct BwdWs0 {
-  float *dZ, *dO, *Th, *dTf, *Delta, *LSEp, *DG, *dQs, *dQp;
-  __bf16 *dTb, *dTt, *GtP;
-};
-size_t carve_ws0(const pca_mab_shape& s, BwdWs0* out, void* base) {
+}  // namespace
+size_t mab0_carve_bwd_ws(const pca_mab_shape& s, Mab0BwdWs* out, void* base) {
   Carver c(base);
-  BwdWs0 w;
+  Mab0BwdWs w;
   const int R = s.h * s.nq, Rp = (int)cdiv(R, 32) * 32;
   const size_t Bm = (size_t)s.B * s.nq;
   w.dZ = c.take<float>(Bm * s.d);
@@ -476,19 +473,30 @@ size_t carve_ws0(const pca_mab_shape& s, BwdWs0* out, void* base) {
   return c.off;
 }
 
-}  // namespace
-
-size_t mab0_bf16_bwd_ws_bytes(const pca_mab_shape& s) { return carve_ws0(s, nullptr, nullptr); }
+size_t mab0_bf16_bwd_ws_bytes(const pca_mab_shape& s) {
+  return mab0_carve_bwd_ws(s, nullptr, nullptr);
+}
 
 // dQ -> dI [m, dq] (ACCUMULATED, may be null), dK -> dX [B, N, dk] (written or accumulated)
+int mab0_bf16_bwd_ex(const pca_mab_shape& s, const float* I, const float* X,
+                     const pca_mab_params& p, const void* saved, const float* dH, float* dI,
+                     float* dX, int dk_accumulate, const pca_mab_grads& gr, void* ws, int flags,
+                     hipStream_t st);
 int mab0_bf16_bwd(const pca_mab_shape& s, const float* I, const float* X,
                   const pca_mab_params& p, const void* saved, const float* dH, float* dI,
                   float* dX, int dk_accumulate, const pca_mab_grads& gr, void* ws,
                   hipStream_t st) {
+  return mab0_bf16_bwd_ex(s, I, X, p, saved, dH, dI, dX, dk_accumulate, gr, ws, 0, st);
+}
+int mab0_bf16_bwd_ex(const pca_mab_shape& s, const float* I, const float* X,
+                     const pca_mab_params& p, const void* saved, const float* dH, float* dI,
+                     float* dX, int dk_accumulate, const pca_mab_grads& gr, void* ws, int flags,
+                     hipStream_t st) {
   Mab0Saved v;
   mab0_carve_saved(s, &v, const_cast<void*>(saved));
-  BwdWs0 w;
-  carve_ws0(s, &w, ws);
+  Mab0BwdWs w;
+  mab0_carve_bwd_ws(s, &w, ws);
+  const bool head_done = (flags & PCA_F_SKIP_HEAD) != 0;
   const int d = s.d, m = s.nq, h = s.h, dk = s.dk, R = h * m, Rp = (int)cdiv(R, 32) * 32;
   const int64_t Bm = (int64_t)s.B * m;
   const bool small = dk <= 4;
@@ -499,7 +507,9 @@ int mab0_bf16_bwd(const pca_mab_shape& s, const float* I, const float* X,
   }
 
   const size_t el = (2 * (size_t)m * d + (size_t)Rp) * sizeof(float);
-  if (m > 2)
+  if (head_done) {
+    // dZ, dO, Th, dT images, Delta, LSEp and dQs come from k_mid_bwd
+  } else if (m > 2)
     hipLaunchKernelGGL((k_mab0_epi_bwd<8>), dim3(s.B), dim3(256), el, st, dH, v.Z, v.T, v.LSE, p.wo,
                        p.wv, m, d, dk, h, Rp, w.dZ, w.dO, w.Th, small ? w.dTf : nullptr,
                        small ? nullptr : w.dTb, small ? nullptr : w.dTt, w.Delta, w.LSEp, s.B);
@@ -553,7 +563,7 @@ int mab0_bf16_bwd(const pca_mab_shape& s, const float* I, const float* X,
     if (small)
       PCA_TRY(wgrad_small_f32_launch(w.dO, w.Th, Bm, dk, (int64_t)Bm * dk, gr.wv, gr.bv, st));
   }
-  PCA_TRY(colsum(w.dO, s.B, m * d, w.dQs, 0, st));        // sum over sets
+  if (!head_done) PCA_TRY(colsum(w.dO, s.B, m * d, w.dQs, 0, st));   // sum over sets
   hipLaunchKernelGGL(k_mab0_post1, dim3((unsigned)cdiv(d * dk + m * d, 256)), dim3(256), 0, st,
                      w.dQs, w.DG, v.Qp, p.wk, m, d, dk, h, sl2e, gr.wk, w.dQp);
   PCA_TRY(check_launch("k_mab0_post1"));

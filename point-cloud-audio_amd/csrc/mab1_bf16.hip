@@ -32,15 +32,39 @@ constexpr int NB = M1_NB;
 // ---------------------------------------------------------------------------------
 __global__ void k_prep_weight(const float* __restrict__ src, __bf16* __restrict__ dst, int rows,
                               int cols, int mode) {
+  // src is [rows][cols] fp32.  mode 0: dst[rows][cols] natural; 1: K-permuted;
+  // 2: dst[cols][rows] = src^T with its K axis (the src row index) permuted; 3: src^T natural
   const int idx = blockIdx.x * blockDim.x + threadIdx.x;
   if (idx >= rows * cols) return;
-  const int n = idx / cols, k = idx - n * cols;
-  const int kp = (k & ~31) + perm32(k & 31);
   float v;
-  if (mode == 0) v = src[n * cols + k];
-  else if (mode == 1) v = src[n * cols + kp];
-  else v = src[kp * rows + n];            // square only (rows == cols)
+  if (mode <= 1) {
+    const int n = idx / cols, k = idx - n * cols;
+    const int kk = mode == 1 ? (k & ~31) + perm32(k & 31) : k;
+    v = src[(int64_t)n * cols + kk];
+  } else {
+    const int n = idx / rows, k = idx - n * rows;       // dst row n = src column n
+    const int kk = mode == 2 ? (k & ~31) + perm32(k & 31) : k;
+    v = src[(int64_t)kk * cols + n];
+  }
   dst[idx] = (__bf16)v;
+}
+
+__global__ void k_prep_jobs(const PrepJobs jobs) {
+  const PrepJob jb = jobs.j[blockIdx.y];
+  const int rows = jb.rows, cols = jb.cols, mode = jb.mode;
+  const int idx = blockIdx.x * blockDim.x + threadIdx.x;
+  if (idx >= rows * cols) return;
+  float v;
+  if (mode <= 1) {
+    const int n = idx / cols, k = idx - n * cols;
+    const int kk = mode == 1 ? (k & ~31) + perm32(k & 31) : k;
+    v = jb.src[(int64_t)n * cols + kk];
+  } else {
+    const int n = idx / rows, k = idx - n * rows;
+    const int kk = mode == 2 ? (k & ~31) + perm32(k & 31) : k;
+    v = jb.src[(int64_t)kk * cols + n];
+  }
+  jb.dst[idx] = (__bf16)v;
 }
 
 __global__ void k_transpose_f32(const float* __restrict__ src, float* __restrict__ dst, int rows,
@@ -391,6 +415,17 @@ int transpose_f32(const float* src, float* dst, int rows, int cols, hipStream_t 
                      dim3(32, 8), 0, st, src, dst, rows, cols);
   return check_launch("k_transpose_f32");
 }
+int prep_jobs_launch(const PrepJobs& jobs, hipStream_t st) {
+  if (jobs.n == 0) return PCA_OK;
+  int maxe = 0;
+  for (int i = 0; i < jobs.n; ++i) {
+    const int e = jobs.j[i].rows * jobs.j[i].cols;
+    maxe = e > maxe ? e : maxe;
+  }
+  hipLaunchKernelGGL(k_prep_jobs, dim3((unsigned)cdiv(maxe, 256), (unsigned)jobs.n), dim3(256), 0,
+                     st, jobs);
+  return check_launch("k_prep_jobs");
+}
 int prep_weight(const float* src, __bf16* dst, int rows, int cols, int mode, hipStream_t st) {
   hipLaunchKernelGGL(k_prep_weight, dim3((unsigned)cdiv((int64_t)rows * cols, 256)), dim3(256), 0,
                      st, src, dst, rows, cols, mode);
@@ -428,8 +463,16 @@ size_t mab1_bf16_fwd_ws_bytes(const pca_mab_shape& s) {
 }
 
 // Q = X [B, nq, dq] fp32, K = H [B, nk, d] fp32 -> Y [B, nq, d] fp32
+int mab1_bf16_fwd_ex(const pca_mab_shape& s, const float* X, const float* H,
+                     const pca_mab_params& p, float* Y, void* saved, void* ws, int flags,
+                     hipStream_t st, const IsabImg* img = nullptr);
 int mab1_bf16_fwd(const pca_mab_shape& s, const float* X, const float* H,
                   const pca_mab_params& p, float* Y, void* saved, void* ws, hipStream_t st) {
+  return mab1_bf16_fwd_ex(s, X, H, p, Y, saved, ws, 0, st);
+}
+int mab1_bf16_fwd_ex(const pca_mab_shape& s, const float* X, const float* H,
+                     const pca_mab_params& p, float* Y, void* saved, void* ws, int flags,
+                     hipStream_t st, const IsabImg* img) {
   PCA_REQUIRE(mab1_bf16_supported(s), "mab1_bf16_fwd: unsupported shape");
   PCA_REQUIRE(ws != nullptr, "mab1_bf16_fwd: scratch required");
   Carver cw(ws);
@@ -443,8 +486,14 @@ int mab1_bf16_fwd(const pca_mab_shape& s, const float* X, const float* H,
   const int d = s.d;
   const bool small = s.dq <= 4;
 
-  if (!small) PCA_TRY(prep_weight(p.wq, WqB, d, d, 0, st));
-  PCA_TRY(prep_weight(p.wo, WoP, d, d, 1, st));
+  if (img != nullptr) {
+    WqB = img->WqB;
+    WoP = img->WoP;
+  } else {
+    if (!small) PCA_TRY(prep_weight(p.wq, WqB, d, d, 0, st));
+    PCA_TRY(prep_weight(p.wo, WoP, d, d, 1, st));
+  }
+  if (!(flags & PCA_F_KV_READY)) {
   PCA_TRY(transpose_f32(p.wk, WkT, d, d, st));
   PCA_TRY(transpose_f32(p.wv, WvT, d, d, st));
   const size_t hl = (size_t)s.nk * d * sizeof(float);
@@ -455,6 +504,7 @@ int mab1_bf16_fwd(const pca_mab_shape& s, const float* X, const float* H,
     hipLaunchKernelGGL((k_kv_proj<32>), dim3(s.B), dim3(256), hl, st, H, WkT, p.bk, WvT, p.bv,
                        d, v.KpP, v.VpP, v.Kt, v.Vt);
   PCA_TRY(check_launch("k_kv_proj"));
+  }
 
   Mab1FwdArgs a{};
   a.X = X; a.WqB = WqB; a.WqF = p.wq; a.bq = p.bq; a.KpP = v.KpP; a.Vt = v.Vt; a.WoP = WoP;

@@ -88,7 +88,74 @@ int wgrad_small_f32_launch(const float* G, const float* X, int64_t M, int dq,
 int kv_dh_launch(const float* dKp, const float* dVp, const float* Wk, const float* Wv, float* dH,
                  int B, int m, int d, int accumulate, hipStream_t st);
 
-// fp32 weight -> bf16 image; mode 0 natural, 1 K-permuted, 2 transposed + K-permuted
+// ---- batched weight-image preparation (one launch per step) -----------------------------
+// bf16 images of one ISAB's weights, owned by the caller (the ST engine) for a whole step
+struct IsabImg {
+  __bf16 *Wv0, *Wo0, *Wk1, *Wv1;                     // natural: k_mid_fwd
+  __bf16 *WqB, *WoP;                                 // k_mab1_fwd (natural Wq, K-permuted Wo)
+  __bf16 *Wk1T, *Wv1T, *Wo0TP, *Wv0TP, *Wv0T;        // k_mid_bwd
+  __bf16 *WoTP, *WqTP;                               // k_mab1_bwd
+};
+struct PrepJob {
+  const float* src;
+  __bf16* dst;
+  int rows, cols, mode;      // modes of prep_weight
+};
+struct PrepJobs {
+  PrepJob j[32];
+  int n;
+};
+int prep_jobs_launch(const PrepJobs& jobs, hipStream_t st);
+
+// scratch layouts of the two backward passes (shared with the ISAB-level orchestration)
+struct Mab1BwdWs {
+  __bf16 *WoTP, *WqTP, *dZ, *dQp, *dOs, *dS, *P;
+  float *dKp, *dVp;
+};
+size_t mab1_carve_bwd_ws(const pca_mab_shape& s, Mab1BwdWs* out, void* base);
+struct Mab0BwdWs {
+  float *dZ, *dO, *Th, *dTf, *Delta, *LSEp, *DG, *dQs, *dQp;
+  __bf16 *dTb, *dTt, *GtP;
+};
+size_t mab0_carve_bwd_ws(const pca_mab_shape& s, Mab0BwdWs* out, void* base);
+
+// flags of the *_ex host entry points used by the fused ISAB path
+enum {
+  PCA_F_SKIP_EPILOGUE = 1,   // mab0 fwd: stop after the attention partials (mid_fwd follows)
+  PCA_F_KV_READY = 2,        // mab1 fwd: Kp/Vp images already written (by mid_fwd)
+  PCA_F_SKIP_KV_TAIL = 4,    // mab1 bwd: stop after dKp/dVp (mid_bwd + batched wgrad follow)
+  PCA_F_SKIP_HEAD = 8,       // mab0 bwd: dT/Delta images, dZ, dO, dQs already produced
+  PCA_F_IMAGES_READY = 16    // weight images were prepared by the caller (IsabImg)
+};
+
+// ---- per-set mid kernels of a fused ISAB (mid_bf16.hip); m = 16, d = 128, h = 4 ----------
+struct MidFwdLaunch {
+  int B, dk, S;
+  const float *Tp, *Mp, *Lp;
+  float *T, *LSE;
+  const float* Qp;
+  const __bf16* Wv0;
+  const float* Wv0f;
+  const float *bv0, *bo0;
+  const __bf16 *Wo0, *Wk1, *Wv1;
+  const float *bk1, *bv1;
+  float *O, *Z, *H;
+  __bf16 *KpP, *VpP, *Kt, *Vt;
+};
+int mid_fwd_launch(const MidFwdLaunch& L, hipStream_t st);
+struct MidBwdLaunch {
+  int B, dk;
+  const float *dKp, *dVp, *Z, *T, *LSE;
+  const __bf16 *Wk1T, *Wv1T, *Wo0TP, *Wv0TP, *Wv0T;
+  const float* Wv0f;
+  float *dZ, *dO, *Th, *dQs, *dTf;
+  __bf16 *dTb, *dTt;
+  float *Delta, *LSEp;
+};
+int mid_bwd_launch(const MidBwdLaunch& L, hipStream_t st);
+
+// fp32 weight [rows][cols] -> bf16 image; mode 0 natural, 1 K-permuted, 2 transposed +
+// K-permuted ([cols][rows]), 3 transposed natural
 int prep_weight(const float* src, __bf16* dst, int rows, int cols, int mode, hipStream_t st);
 
 }  // namespace pca

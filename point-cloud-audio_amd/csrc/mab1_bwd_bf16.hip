@@ -518,13 +518,10 @@ int launch_bwd(const Mab1BwdArgs& a, hipStream_t st, double flops, double bytes)
   return check_launch("k_mab1_bwd");
 }
 
-struct BwdWs {
-  __bf16 *WoTP, *WqTP, *dZ, *dQp, *dOs, *dS, *P;
-  float *dKp, *dVp;
-};
-size_t carve_bwd_ws(const pca_mab_shape& s, BwdWs* out, void* base) {
+}  // namespace
+size_t mab1_carve_bwd_ws(const pca_mab_shape& s, Mab1BwdWs* out, void* base) {
   Carver c(base);
-  BwdWs w;
+  Mab1BwdWs w;
   const size_t M = (size_t)s.B * s.nq, d = s.d;
   w.WoTP = c.take<__bf16>(d * d);
   w.WqTP = c.take<__bf16>(d * d);
@@ -539,9 +536,9 @@ size_t carve_bwd_ws(const pca_mab_shape& s, BwdWs* out, void* base) {
   return c.off;
 }
 
-}  // namespace
-
-size_t mab1_bf16_bwd_ws_bytes(const pca_mab_shape& s) { return carve_bwd_ws(s, nullptr, nullptr); }
+size_t mab1_bf16_bwd_ws_bytes(const pca_mab_shape& s) {
+  return mab1_carve_bwd_ws(s, nullptr, nullptr);
+}
 
 int wgrad128_launch(const WgradJobs& jobs, bool g_bf16, bool a_bf16, int rows_per_wg,
                     hipStream_t st) {
@@ -578,14 +575,24 @@ int kv_dh_launch(const float* dKp, const float* dVp, const float* Wk, const floa
 }
 
 // dQ -> dX [B, nq, dq] (written; may be null), dK -> dH [B, nk, d] (written or accumulated)
+int mab1_bf16_bwd_ex(const pca_mab_shape& s, const float* X, const float* H,
+                     const pca_mab_params& p, const void* saved, const float* dY, float* dX,
+                     float* dH, int dk_accumulate, const pca_mab_grads& gr, void* ws, int flags,
+                     hipStream_t st, const IsabImg* img = nullptr);
 int mab1_bf16_bwd(const pca_mab_shape& s, const float* X, const float* H,
                   const pca_mab_params& p, const void* saved, const float* dY, float* dX,
                   float* dH, int dk_accumulate, const pca_mab_grads& gr, void* ws,
                   hipStream_t st) {
+  return mab1_bf16_bwd_ex(s, X, H, p, saved, dY, dX, dH, dk_accumulate, gr, ws, 0, st);
+}
+int mab1_bf16_bwd_ex(const pca_mab_shape& s, const float* X, const float* H,
+                     const pca_mab_params& p, const void* saved, const float* dY, float* dX,
+                     float* dH, int dk_accumulate, const pca_mab_grads& gr, void* ws, int flags,
+                     hipStream_t st, const IsabImg* img) {
   Mab1Saved v;
   mab1_carve_saved(s, &v, const_cast<void*>(saved));
-  BwdWs w;
-  carve_bwd_ws(s, &w, ws);
+  Mab1BwdWs w;
+  mab1_carve_bwd_ws(s, &w, ws);
   const int d = s.d, MI = s.nk;
   const int64_t M = (int64_t)s.B * s.nq;
   const bool small = s.dq <= 4;
@@ -596,8 +603,13 @@ int mab1_bf16_bwd(const pca_mab_shape& s, const float* X, const float* H,
     return PCA_EUNSUPPORTED;
   }
 
-  PCA_TRY(prep_weight(p.wo, w.WoTP, d, d, 2, st));
-  if (want_dx) PCA_TRY(prep_weight(p.wq, w.WqTP, d, d, 2, st));
+  if (img != nullptr) {
+    w.WoTP = img->WoTP;
+    w.WqTP = img->WqTP;
+  } else {
+    PCA_TRY(prep_weight(p.wo, w.WoTP, d, d, 2, st));
+    if (want_dx) PCA_TRY(prep_weight(p.wq, w.WqTP, d, d, 2, st));
+  }
 
   Mab1BwdArgs a{};
   a.dY = dY; a.QpS = v.QpS; a.mask = v.mask; a.KpP = v.KpP; a.VpP = v.VpP; a.Kt = v.Kt;
@@ -647,6 +659,7 @@ int mab1_bf16_bwd(const pca_mab_shape& s, const float* X, const float* H,
                        w.dOs, s.nq, d, s.h, w.dKp, w.dVp);
   PCA_TRY(check_launch("k_kv_grad"));
 
+  if (flags & PCA_F_SKIP_KV_TAIL) return PCA_OK;
   // ---- fc_k / fc_v of the m inducing-point outputs: [B*m]-row reductions, one launch ----
   const int64_t Mk = (int64_t)s.B * MI;
   {

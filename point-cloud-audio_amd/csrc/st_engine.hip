@@ -3,7 +3,7 @@
 // forward -> cross-entropy -> backward against flat parameter / gradient vectors laid out
 // in state_dict order.  No Python, autograd or allocator sits between the kernels, so the
 // caller can capture the call in a hipGraph.
-#include "pca_common.h"
+#include "mab1_bf16.hpp"
 
 namespace pca {
 
@@ -17,6 +17,23 @@ int mab_fwd_any(const pca_mab_shape& s, const float* Q, const float* K, const pc
 int mab_bwd_any(const pca_mab_shape& s, const float* Q, const float* K, const pca_mab_params& p,
                 const void* saved, const float* dY, float* dQ, float* dK, int dk_accumulate,
                 const pca_mab_grads& g, void* ws, hipStream_t st);
+bool isab_bf16_supported(const pca_mab_shape& s0, const pca_mab_shape& s1);
+size_t isab_bf16_fwd_ws_bytes(const pca_mab_shape& s0, const pca_mab_shape& s1);
+size_t isab_bf16_bwd_ws_bytes(const pca_mab_shape& s0, const pca_mab_shape& s1);
+size_t isab_img_bytes();
+void isab_img_carve(void* base, IsabImg* im);
+void isab_collect_prep(const pca_mab_shape& s0, const pca_mab_params& p0,
+                       const pca_mab_params& p1, const IsabImg& im, bool training,
+                       bool need_dx, PrepJobs* J);
+int isab_bf16_fwd(const pca_mab_shape& s0, const pca_mab_shape& s1, const float* I,
+                  const float* X, const pca_mab_params& p0, const pca_mab_params& p1, float* H,
+                  float* Y, void* saved0, void* saved1, void* ws, const IsabImg& im,
+                  hipStream_t st);
+int isab_bf16_bwd(const pca_mab_shape& s0, const pca_mab_shape& s1, const float* I,
+                  const float* X, const float* H, const pca_mab_params& p0,
+                  const pca_mab_params& p1, const void* saved0, const void* saved1,
+                  const float* dY, float* dI, float* dX, const pca_mab_grads& g0,
+                  const pca_mab_grads& g1, void* ws, const IsabImg& im, hipStream_t st);
 int linear_fwd_f32(const float* X, const float* W, const float* b, float* Y, int64_t M,
                    int din, int dout, hipStream_t st);
 int linear_bwd_f32(const float* X, const float* W, const float* dY, float* dX, float* dW,
@@ -107,6 +124,8 @@ struct Ws {
   float *H[2], *Y[2], *P, *logits, *dlogits;
   float *dP, *dY2, *dY1, *dH;
   void* scratch;
+  IsabImg img[2];            // weight images of the two ISABs (fused bf16 path)
+  bool fused[2];
 };
 
 inline size_t carve(const pca_st_config& c, int training, Ws* out, void* base) {
@@ -122,6 +141,17 @@ inline size_t carve(const pca_st_config& c, int training, Ws* out, void* base) {
       const size_t bb = mab_bwd_ws_bytes_any(*order[i]);
       max_scratch = bb > max_scratch ? bb : max_scratch;
       w.saved[i] = cv.take<char>(mab_saved_bytes_any(*order[i]));
+    }
+  }
+  for (int li = 0; li < 2; ++li) {
+    w.fused[li] = training && isab_bf16_supported(s.m0[li], s.m1[li]);
+    if (w.fused[li]) {
+      const size_t fb = isab_bf16_fwd_ws_bytes(s.m0[li], s.m1[li]);
+      const size_t bb = isab_bf16_bwd_ws_bytes(s.m0[li], s.m1[li]);
+      max_scratch = fb > max_scratch ? fb : max_scratch;
+      max_scratch = bb > max_scratch ? bb : max_scratch;
+      char* ib = cv.take<char>(isab_img_bytes());
+      if (base != nullptr) isab_img_carve(ib, &w.img[li]);
     }
   }
   const size_t BN = (size_t)c.B * c.N, Bm = (size_t)c.B * c.m;
@@ -157,9 +187,24 @@ int validate(const pca_st_config* c) {
 int forward(const pca_st_config& c, const Layout& L, const Shapes& s, const float* p,
             const float* X, Ws& w, bool training, hipStream_t st) {
   const float* in = X;
+  if (training) {               // all weight images of the step in ONE launch
+    PrepJobs J{};
+    for (int li = 0; li < 2; ++li)
+      if (w.fused[li])
+        isab_collect_prep(s.m0[li], params_at(p, L.mab0[li]), params_at(p, L.mab1[li]),
+                          w.img[li], true, li == 1, &J);
+    PCA_TRY(prep_jobs_launch(J, st));
+  }
   for (int li = 0; li < 2; ++li) {
     void* sv0 = training ? w.saved[2 * li] : nullptr;
     void* sv1 = training ? w.saved[2 * li + 1] : nullptr;
+    if (training && w.fused[li]) {
+      PCA_TRY(isab_bf16_fwd(s.m0[li], s.m1[li], p + L.I[li], in, params_at(p, L.mab0[li]),
+                            params_at(p, L.mab1[li]), w.H[li], w.Y[li], sv0, sv1, w.scratch,
+                            w.img[li], st));
+      in = w.Y[li];
+      continue;
+    }
     PCA_TRY(mab_fwd_any(s.m0[li], p + L.I[li], in, params_at(p, L.mab0[li]), w.H[li], sv0,
                         w.scratch, st));                            // modules.py:52
     PCA_TRY(mab_fwd_any(s.m1[li], in, w.H[li], params_at(p, L.mab1[li]), w.Y[li], sv1,
@@ -237,15 +282,31 @@ int pca_st_train_fwd_bwd(const pca_st_config* c, const float* params, const floa
                              w.dP, g + L.S, w.dY2, 0, pca::grads_at(g, L.pma), w.scratch,
                              st));
     // enc.1: mab1(Y1, H2) then mab0(I2, Y1); Y1 feeds both, so dY1 accumulates
+    if (w.fused[1]) {
+      PCA_TRY(pca::isab_bf16_bwd(s.m0[1], s.m1[1], p + L.I[1], w.Y[0], w.H[1],
+                                 pca::params_at(p, L.mab0[1]), pca::params_at(p, L.mab1[1]),
+                                 w.saved[2], w.saved[3], w.dY2, g + L.I[1], w.dY1,
+                                 pca::grads_at(g, L.mab0[1]), pca::grads_at(g, L.mab1[1]),
+                                 w.scratch, w.img[1], st));
+    } else {
     PCA_TRY(pca::mab_bwd_any(s.m1[1], w.Y[0], w.H[1], pca::params_at(p, L.mab1[1]),
                              w.saved[3], w.dY2, w.dY1, w.dH, 0, pca::grads_at(g, L.mab1[1]),
                              w.scratch, st));
     PCA_TRY(pca::mab_bwd_any(s.m0[1], p + L.I[1], w.Y[0], pca::params_at(p, L.mab0[1]),
                              w.saved[2], w.dH, g + L.I[1], w.dY1, 1,
                              pca::grads_at(g, L.mab0[1]), w.scratch, st));
+    }
   }
   if (phase != 0) {
     // enc.0: the set itself needs no gradient
+    if (w.fused[0]) {
+      PCA_TRY(pca::isab_bf16_bwd(s.m0[0], s.m1[0], p + L.I[0], X, w.H[0],
+                                 pca::params_at(p, L.mab0[0]), pca::params_at(p, L.mab1[0]),
+                                 w.saved[0], w.saved[1], w.dY1, g + L.I[0], nullptr,
+                                 pca::grads_at(g, L.mab0[0]), pca::grads_at(g, L.mab1[0]),
+                                 w.scratch, w.img[0], st));
+      return PCA_OK;
+    }
     PCA_TRY(pca::mab_bwd_any(s.m1[0], X, w.H[0], pca::params_at(p, L.mab1[0]), w.saved[1],
                              w.dY1, nullptr, w.dH, 0, pca::grads_at(g, L.mab1[0]),
                              w.scratch, st));
