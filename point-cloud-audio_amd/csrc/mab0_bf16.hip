@@ -98,7 +98,8 @@ __global__ __launch_bounds__(256, 1) void k_mab0_attn(const Mab0AttnArgs a) {
   extern __shared__ __attribute__((aligned(16))) char smem[];
   char* sG = smem;                                    // [16 RB][256 B] tr_off image rows
   char* sX = sG + 16 * RB * 256;                      // 4 waves x 32 rows x 256 B
-  constexpr int XBYTES = (4 * 32 * 256 > 16 * RB * DK * 4) ? 4 * 32 * 256 : 16 * RB * DK * 4;
+  // X tiles during the loop; afterwards one fp32 [16 RB][128] slab per wave for the merge
+  constexpr int XBYTES = (4 * 32 * 256 > 4 * 16 * RB * DK * 4) ? 4 * 32 * 256 : 4 * 16 * RB * DK * 4;
   float* sAl = reinterpret_cast<float*>(sX + XBYTES);   // 4 waves x 16 RB
   float* sM = sAl + 4 * 16 * RB;                      // merge: [4][16 RB] m, then l
   float* sL = sM + 4 * 16 * RB;
@@ -205,8 +206,8 @@ __global__ __launch_bounds__(256, 1) void k_mab0_attn(const Mab0AttnArgs a) {
     }
   }
 
-  // ---- merge the four waves' partial (m, l, T) ----
-  __syncthreads();                       // X tiles are dead: sT may alias them
+  // ---- merge the four waves' partial (m, l, T): per-wave slabs, plain LDS stores ----
+  __syncthreads();                       // X tiles are dead: the slabs alias them
   if (g == 0) {
 #pragma unroll
     for (int rb = 0; rb < RB; ++rb) {
@@ -214,8 +215,8 @@ __global__ __launch_bounds__(256, 1) void k_mab0_attn(const Mab0AttnArgs a) {
       sL[wave * 16 * RB + 16 * rb + r] = lrow[rb];
     }
   }
-  for (int i = tid; i < 16 * RB * DK; i += 256) sT[i] = 0.f;
   __syncthreads();
+  float* mySlab = sT + wave * 16 * RB * DK;
 #pragma unroll
   for (int rb = 0; rb < RB; ++rb) {
     // factor of this wave for query rows 4g+e of block rb (accumulator-row layout)
@@ -232,13 +233,14 @@ __global__ __launch_bounds__(256, 1) void k_mab0_attn(const Mab0AttnArgs a) {
     for (int ft = 0; ft < FT; ++ft)
 #pragma unroll
       for (int e = 0; e < 4; ++e)
-        atomicAdd(&sT[(16 * rb + 4 * g + e) * DK + 16 * ft + r], T[rb][ft][e] * f4[e]);
+        mySlab[(16 * rb + 4 * g + e) * DK + 16 * ft + r] = T[rb][ft][e] * f4[e];
   }
   __syncthreads();
   const int64_t pbase = ((int64_t)b * a.S + sp) * a.R;
   for (int i = tid; i < a.R * DK; i += 256) {
     const int rr = i / DK;
-    a.Tp[(pbase + rr) * DK + (i - rr * DK)] = sT[i];
+    a.Tp[(pbase + rr) * DK + (i - rr * DK)] = sT[i] + sT[16 * RB * DK + i] +
+                                              sT[2 * 16 * RB * DK + i] + sT[3 * 16 * RB * DK + i];
     if (i == rr * DK) {
       float M = -INFINITY;
 #pragma unroll
@@ -473,8 +475,8 @@ int mab0_bf16_fwd_ex(const pca_mab_shape& s, const float* I, const float* X,
     const int S = mab0_splits(s);
     Mab0AttnArgs a{X, v.Gb, v.Tp, v.Mp, v.Lp, s.B, s.nk, R, S};
     const int RB = Rpad / 16;
-    const size_t xbytes = (size_t)Rpad * 128 * 4 > 4 * 32 * 256 ? (size_t)Rpad * 128 * 4
-                                                                 : (size_t)4 * 32 * 256;
+    const size_t xbytes = (size_t)4 * Rpad * 128 * 4 > 4 * 32 * 256 ? (size_t)4 * Rpad * 128 * 4
+                                                                     : (size_t)4 * 32 * 256;
     const size_t lds = (size_t)Rpad * 256 + xbytes + 3 * 4 * Rpad * sizeof(float);
     // reference-formulation FLOPs of the block: fc_k, fc_v over the keys + QK^T + AV
     ProfScope ps(PCA_K_MAB0_FWD, st, 2.0 * pts * (2.0 * dk * d + 2.0 * m * d),

@@ -180,7 +180,6 @@ __global__ __launch_bounds__(256, 1) void k_mab0_bwd(const Mab0BwdArgs a) {
   char* sDS = sX + 4 * 32 * 256;             // 4 x 32 x 256 (first RP*2 bytes of a row used)
   float* sLSE = reinterpret_cast<float*>(sDS + 4 * 32 * 256);
   float* sDel = sLSE + RP;
-  float* sRed = reinterpret_cast<float*>(sX);     // [RP][128] fp32 merge buffer (aliases sX+sDS)
 
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int r = lane & 15, g = lane >> 4;
@@ -333,19 +332,21 @@ __global__ __launch_bounds__(256, 1) void k_mab0_bwd(const Mab0BwdArgs a) {
     }
   }
 
-  // ---- dG: reduce the four waves in LDS, then one atomic per element per set ----
+  // ---- dG: per-wave slabs (plain LDS stores over the dead images), then one global atomic
+  //      per element per workgroup ----
   __syncthreads();
-  for (int i = tid; i < RP * DK; i += 256) sRed[i] = 0.f;
-  __syncthreads();
+  float* slab = reinterpret_cast<float*>(smem) + wave * RP * DK;      // 4 x RP x 128 fp32
 #pragma unroll
   for (int rb = 0; rb < RB; ++rb)
 #pragma unroll
     for (int ft = 0; ft < FT; ++ft)
 #pragma unroll
       for (int e = 0; e < 4; ++e)
-        atomicAdd(&sRed[(16 * rb + 4 * g + e) * DK + 16 * ft + r], dG[rb][ft][e]);
+        slab[(16 * rb + 4 * g + e) * DK + 16 * ft + r] = dG[rb][ft][e];
   __syncthreads();
-  for (int i = tid; i < RP * DK; i += 256) atomicAdd(&a.DG[i], sRed[i]);
+  const float* s0 = reinterpret_cast<const float*>(smem);
+  for (int i = tid; i < RP * DK; i += 256)
+    atomicAdd(&a.DG[i], s0[i] + s0[RP * DK + i] + s0[2 * RP * DK + i] + s0[3 * RP * DK + i]);
 }
 
 // layer 1 (dk <= 4): thread = (query row r, point partition); accumulates DG only
@@ -531,8 +532,9 @@ int mab0_bf16_bwd_ex(const pca_mab_shape& s, const float* I, const float* X,
     const int S = mab0_splits(s);
     Mab0BwdArgs a{X, v.Gb, w.GtP, w.dTb, w.dTt, w.LSEp, w.Delta, dX, w.DG, s.B, s.nk,
                   dk_accumulate ? 1 : 0, S};
-    const size_t lds = 2 * (size_t)Rp * 256 + 2 * (size_t)128 * Rp * 2 + 2 * 4 * 32 * 256 +
-                       2 * Rp * sizeof(float);
+    size_t lds = 2 * (size_t)Rp * 256 + 2 * (size_t)128 * Rp * 2 + 2 * 4 * 32 * 256 +
+                 2 * Rp * sizeof(float);
+    if (lds < (size_t)4 * Rp * 128 * 4) lds = (size_t)4 * Rp * 128 * 4;     // merge slabs
     static std::once_flag once;
     std::call_once(once, [] {
       (void)hipFuncSetAttribute(reinterpret_cast<const void*>(k_mab0_bwd<64>),

@@ -41,11 +41,30 @@ struct Mab1BwdArgs {
   __bf16 *dZ, *dQp, *dOs;   // [B*N][D]
   __bf16 *dS, *P;           // [B*N][H*MI]
   float* dX;                // [B, N, D] or null
+  float *dKpG, *dVpG;       // [B][MI][D] fp32, atomically accumulated (fused K/V gradients)
   int B, N, tiles_per_set;
+  int tpw;                  // consecutive tiles of ONE set per workgroup (fused mode)
   float scale, scale_log2e;
 };
 
-template <int D, int MI, bool WANT_DX>
+typedef __attribute__((address_space(3))) s16x4 lds_s16x4;
+
+// transposed fragment (k = the 32 points of a wave tile) from a small row-major bf16 image
+// with `rb` bytes per row, for the 16 columns starting at col0
+__device__ __forceinline__ bf16x8 tr_frag_small(const char* img, int rb, int col0, int lane) {
+  const int g = lane >> 4, i16 = lane & 15, q = i16 >> 2, p = i16 & 3;
+  const int a0 = (4 * g + q) * rb + (col0 + 4 * p) * 2;
+  const int a1 = (16 + 4 * g + q) * rb + (col0 + 4 * p) * 2;
+  const s16x4 lo = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_s16x4*)(img + a0));
+  const s16x4 hi = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_s16x4*)(img + a1));
+  const bf16x4 l4 = __builtin_bit_cast(bf16x4, lo), h4 = __builtin_bit_cast(bf16x4, hi);
+  bf16x8 r;
+#pragma unroll
+  for (int e = 0; e < 4; ++e) { r[e] = l4[e]; r[4 + e] = h4[e]; }
+  return r;
+}
+
+template <int D, int MI, bool WANT_DX, bool FUSE_KV>
 __global__ __launch_bounds__(256, 1) void k_mab1_bwd(const Mab1BwdArgs a) {
   constexpr int DT = D / 16, KS = D / 32, ROWB = D * 2, HM = KS * MI;
   extern __shared__ __attribute__((aligned(16))) char smem[];
@@ -54,6 +73,8 @@ __global__ __launch_bounds__(256, 1) void k_mab1_bwd(const Mab1BwdArgs a) {
   char* sVp = sKp + MI * ROWB;
   char* sKt = sVp + MI * ROWB;
   char* sWqT = sKt + D * MI * 2;
+  // fused K/V gradients: per wave [32][16] dS, [32][16] P, [32][32] Qp_j, [32][32] dO_j images
+  char* sKV = sWqT + (WANT_DX ? D * ROWB : 0);
 
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int r = lane & 15, g = lane >> 4;
@@ -69,7 +90,25 @@ __global__ __launch_bounds__(256, 1) void k_mab1_bwd(const Mab1BwdArgs a) {
 
   const int total_tiles = a.B * a.tiles_per_set;
   int cur_b = -1;
-  for (int tile_id = blockIdx.x; tile_id < total_tiles; tile_id += gridDim.x) {
+  char* myDS = sKV + wave * 6144;
+  char* myP = myDS + 1024;
+  char* myQ = myP + 1024;
+  char* myO = myQ + 2048;
+  f32x4 dkp[FUSE_KV ? KS : 1][2], dvp[FUSE_KV ? KS : 1][2];
+  if (FUSE_KV) {
+#pragma unroll
+    for (int j = 0; j < KS; ++j)
+#pragma unroll
+      for (int tt = 0; tt < 2; ++tt) {
+        dkp[j][tt] = f32x4{0.f, 0.f, 0.f, 0.f};
+        dvp[j][tt] = f32x4{0.f, 0.f, 0.f, 0.f};
+      }
+  }
+  // fused mode: a workgroup owns `tpw` consecutive tiles of one set; otherwise grid-stride
+  const int t_first = FUSE_KV ? blockIdx.x * a.tpw : blockIdx.x;
+  const int t_step = FUSE_KV ? 1 : gridDim.x;
+  const int t_last = FUSE_KV ? t_first + a.tpw : total_tiles;
+  for (int tile_id = t_first; tile_id < t_last && tile_id < total_tiles; tile_id += t_step) {
     const int b = tile_id / a.tiles_per_set, tile = tile_id - b * a.tiles_per_set;
     if (b != cur_b) {
       __syncthreads();
@@ -135,13 +174,15 @@ __global__ __launch_bounds__(256, 1) void k_mab1_bwd(const Mab1BwdArgs a) {
         for (int nb = 0; nb < NB; ++nb) dO[t][nb] = mfma32(wa, dzb[s][nb], dO[t][nb]);
       }
     }
+    if (!FUSE_KV) {
 #pragma unroll
-    for (int nb = 0; nb < NB; ++nb)
-      if (live[nb]) {
+      for (int nb = 0; nb < NB; ++nb)
+        if (live[nb]) {
 #pragma unroll
-        for (int t = 0; t < DT; ++t)
-          *reinterpret_cast<bf16x4*>(a.dOs + row[nb] * D + 16 * t + 4 * g) = pack4(dO[t][nb]);
-      }
+          for (int t = 0; t < DT; ++t)
+            *reinterpret_cast<bf16x4*>(a.dOs + row[nb] * D + 16 * t + 4 * g) = pack4(dO[t][nb]);
+        }
+    }
 
     // ---- attention backward per head; dO tiles of the head become dQp in place ----
 #pragma unroll
@@ -196,7 +237,18 @@ __global__ __launch_bounds__(256, 1) void k_mab1_bwd(const Mab1BwdArgs a) {
           ds0[e] = p0[e] * (da0[e] - delta) * a.scale;
           ds1[e] = p1[e] * (da1[e] - delta) * a.scale;
         }
-        if (live[nb]) {
+        if (FUSE_KV) {
+          // wave-private images [point][.] of this head: dS, P (16 keys), Qp_j, dO_j (32 feats);
+          // padding points contribute zeros
+          const int pt = 16 * nb + r;
+          f32x4 zero4 = {0.f, 0.f, 0.f, 0.f};
+          *reinterpret_cast<bf16x4*>(myDS + pt * 32 + 8 * g) = pack4(live[nb] ? ds0 : zero4);
+          *reinterpret_cast<bf16x4*>(myP + pt * 32 + 8 * g) = pack4(live[nb] ? p0 : zero4);
+          *reinterpret_cast<bf16x4*>(myQ + pt * 64 + 8 * g) = qlo;
+          *reinterpret_cast<bf16x4*>(myQ + pt * 64 + 32 + 8 * g) = qhi;
+          *reinterpret_cast<bf16x4*>(myO + pt * 64 + 8 * g) = pack4(dO[2 * j][nb]);
+          *reinterpret_cast<bf16x4*>(myO + pt * 64 + 32 + 8 * g) = pack4(dO[2 * j + 1][nb]);
+        } else if (live[nb]) {
           *reinterpret_cast<bf16x4*>(a.P + row[nb] * HM + j * MI + 4 * g) = pack4(p0);
           *reinterpret_cast<bf16x4*>(a.dS + row[nb] * HM + j * MI + 4 * g) = pack4(ds0);
           if (MI == 32) {
@@ -214,6 +266,16 @@ __global__ __launch_bounds__(256, 1) void k_mab1_bwd(const Mab1BwdArgs a) {
           else
             dO[t][nb] = mfma32(*reinterpret_cast<const bf16x8*>(krow + 16 * g), pack8(ds0, ds1),
                                dO[t][nb]);
+        }
+      }
+      if (FUSE_KV) {
+        // dKp_j[key][f] += sum_pt dS[key][pt] Qp[pt][f] ; dVp_j[key][f] += sum_pt P[key][pt] dO[pt][f]
+        const bf16x8 ads = tr_frag_small(myDS, 32, 0, lane);
+        const bf16x8 ap = tr_frag_small(myP, 32, 0, lane);
+#pragma unroll
+        for (int tt = 0; tt < 2; ++tt) {
+          dkp[j][tt] = mfma32(ads, tr_frag_small(myQ, 64, 16 * tt, lane), dkp[j][tt]);
+          dvp[j][tt] = mfma32(ap, tr_frag_small(myO, 64, 16 * tt, lane), dvp[j][tt]);
         }
       }
     }
@@ -255,6 +317,29 @@ __global__ __launch_bounds__(256, 1) void k_mab1_bwd(const Mab1BwdArgs a) {
         }
     }
   }
+  if (FUSE_KV && cur_b >= 0) {
+    // reduce the four waves' [MI][D] partials in LDS (the weight images are dead), then one
+    // atomic per element per workgroup
+    __syncthreads();
+    float* red = reinterpret_cast<float*>(smem);            // [4][2][MI*D] = 64 KiB
+#pragma unroll
+    for (int j = 0; j < KS; ++j)
+#pragma unroll
+      for (int tt = 0; tt < 2; ++tt)
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+          const int o = (4 * g + e) * D + 32 * j + 16 * tt + r;
+          red[(wave * 2 + 0) * MI * D + o] = dkp[j][tt][e];
+          red[(wave * 2 + 1) * MI * D + o] = dvp[j][tt][e];
+        }
+    __syncthreads();
+    for (int i = tid; i < 2 * MI * D; i += 256) {
+      const int which = i / (MI * D), o = i - which * MI * D;
+      const float v = red[(0 * 2 + which) * MI * D + o] + red[(1 * 2 + which) * MI * D + o] +
+                      red[(2 * 2 + which) * MI * D + o] + red[(3 * 2 + which) * MI * D + o];
+      atomicAdd((which ? a.dVpG : a.dKpG) + (int64_t)cur_b * MI * D + o, v);
+    }
+  }
 }
 
 // ---------------------------------------------------------------------------------
@@ -266,7 +351,6 @@ __device__ __forceinline__ int tr_off(int row, int ch) {
   return 256 * row + 16 * (ch ^ (((row & 3) << 2) | ((row >> 2) & 3)));
 }
 
-typedef __attribute__((address_space(3))) s16x4 lds_s16x4;
 
 // A/B fragment with k = the 32 points of the tile (k-slot (g, j): j<4 -> point 4g+j,
 // else 16+4g+j-4) for the 16 features of tile t
@@ -501,19 +585,20 @@ __global__ __launch_bounds__(256) void k_kv_grad(const __bf16* __restrict__ dS,
   }
 }
 
-template <int D, int MI, bool DX>
+template <int D, int MI, bool DX, bool FUSE>
 int launch_bwd(const Mab1BwdArgs& a, hipStream_t st, double flops, double bytes) {
-  const size_t lds = (size_t)D * D * 2 + 2 * (size_t)MI * D * 2 + (size_t)D * MI * 2 +
-                     (DX ? (size_t)D * D * 2 : 0);
+  size_t lds = (size_t)D * D * 2 + 2 * (size_t)MI * D * 2 + (size_t)D * MI * 2 +
+               (DX ? (size_t)D * D * 2 : 0) + (FUSE ? 4 * 6144 : 0);
+  if (FUSE && lds < (size_t)8 * MI * D * 4) lds = (size_t)8 * MI * D * 4;   // flush buffer
   static std::once_flag once;
   std::call_once(once, [] {
-    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(k_mab1_bwd<D, MI, DX>),
+    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(k_mab1_bwd<D, MI, DX, FUSE>),
                               hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
   });
   const int total = a.B * a.tiles_per_set;
-  const int grid = total < 256 ? total : 256;
+  const int grid = FUSE ? (int)cdiv(total, a.tpw) : (total < 256 ? total : 256);
   ProfScope ps(PCA_K_MAB1_BWD, st, flops, bytes);
-  hipLaunchKernelGGL((k_mab1_bwd<D, MI, DX>), dim3(grid), dim3(256), lds, st, a);
+  hipLaunchKernelGGL((k_mab1_bwd<D, MI, DX, FUSE>), dim3(grid), dim3(256), lds, st, a);
   ps.end();
   return check_launch("k_mab1_bwd");
 }
@@ -622,12 +707,23 @@ int mab1_bf16_bwd_ex(const pca_mab_shape& s, const float* X, const float* H,
   const double flops = 4.0 * M * ((double)s.dq * d + (double)d * d + 2.0 * MI * d);
   const double bytes = (double)M * (4.0 * d + (want_dx ? 4.0 * d : 0.0));
   int rc;
-  if (MI == 16)
-    rc = want_dx ? launch_bwd<128, 16, true>(a, st, flops, bytes)
-                 : launch_bwd<128, 16, false>(a, st, flops, bytes);
-  else
-    rc = want_dx ? launch_bwd<128, 32, true>(a, st, flops, bytes)
-                 : launch_bwd<128, 32, false>(a, st, flops, bytes);
+  const bool fuse = MI == 16;
+  if (fuse) {
+    // consecutive tiles per workgroup: the largest divisor of tiles_per_set that still
+    // leaves >= 256 workgroups
+    int tpw = 1;
+    for (int c = 1; c <= a.tiles_per_set; ++c)
+      if (a.tiles_per_set % c == 0 && (int64_t)a.B * a.tiles_per_set / c >= 256) tpw = c;
+    a.tpw = tpw;
+    a.dKpG = w.dKp;
+    a.dVpG = w.dVp;
+    PCA_TRY(fill_zero(w.dKp, 2 * (int64_t)align256((size_t)s.B * MI * d * 4) / 4, st));
+    rc = want_dx ? launch_bwd<128, 16, true, true>(a, st, flops, bytes)
+                 : launch_bwd<128, 16, false, true>(a, st, flops, bytes);
+  } else {
+    rc = want_dx ? launch_bwd<128, 32, true, false>(a, st, flops, bytes)
+                 : launch_bwd<128, 32, false, false>(a, st, flops, bytes);
+  }
   PCA_TRY(rc);
   // ---- reductions over points (one launch for dWo / dWq) ----
   const int rows_per_wg = 512;
@@ -651,13 +747,11 @@ int mab1_bf16_bwd_ex(const pca_mab_shape& s, const float* X, const float* H,
     PCA_TRY(wgrad128_launch(jobs, true, false, rows_per_wg, st));
     ps.end();
   }
-  if (MI == 16)
-    hipLaunchKernelGGL((k_kv_grad<16>), dim3(s.B * s.h), dim3(256), 0, st, w.dS, w.P, v.QpS,
-                       w.dOs, s.nq, d, s.h, w.dKp, w.dVp);
-  else
+  if (!fuse) {
     hipLaunchKernelGGL((k_kv_grad<32>), dim3(s.B * s.h), dim3(256), 0, st, w.dS, w.P, v.QpS,
                        w.dOs, s.nq, d, s.h, w.dKp, w.dVp);
-  PCA_TRY(check_launch("k_kv_grad"));
+    PCA_TRY(check_launch("k_kv_grad"));
+  }
 
   if (flags & PCA_F_SKIP_KV_TAIL) return PCA_OK;
   // ---- fc_k / fc_v of the m inducing-point outputs: [B*m]-row reductions, one launch ----
