@@ -17,7 +17,8 @@ int mab1_bf16_fwd_ex(const pca_mab_shape& s, const float* X, const float* H,
 int mab1_bf16_bwd_ex(const pca_mab_shape& s, const float* X, const float* H,
                      const pca_mab_params& p, const void* saved, const float* dY, float* dX,
                      float* dH, int dk_accumulate, const pca_mab_grads& gr, void* ws, int flags,
-                     hipStream_t st, const IsabImg* img);
+                     hipStream_t st, const IsabImg* img, float* zero_ptr, int zero_n,
+                     int* nparts_out);
 int mab0_bf16_bwd_ex(const pca_mab_shape& s, const float* I, const float* X,
                      const pca_mab_params& p, const void* saved, const float* dH, float* dI,
                      float* dX, int dk_accumulate, const pca_mab_grads& gr, void* ws, int flags,
@@ -86,7 +87,8 @@ int isab_bf16_fwd(const pca_mab_shape& s0, const pca_mab_shape& s1, const float*
   Mab1Saved v1;
   mab1_carve_saved(s1, &v1, saved1);
 
-  PCA_TRY(mab0_bf16_fwd_ex(s0, I, X, p0, H, saved0, nullptr, PCA_F_SKIP_EPILOGUE, st));
+  PCA_TRY(mab0_bf16_fwd_ex(s0, I, X, p0, H, saved0, nullptr,
+                           PCA_F_SKIP_EPILOGUE | PCA_F_PREP_DONE, st));
   MidFwdLaunch L{};
   L.B = s0.B; L.dk = dk; L.S = dk > 4 ? mab0_splits(s0) : 0;
   L.Tp = v0.Tp; L.Mp = v0.Mp; L.Lp = v0.Lp; L.T = v0.T; L.LSE = v0.LSE; L.Qp = v0.Qp;
@@ -116,27 +118,38 @@ int isab_bf16_bwd(const pca_mab_shape& s0, const pca_mab_shape& s1, const float*
   Mab0Saved v0;
   mab0_carve_saved(s0, &v0, const_cast<void*>(saved0));
 
+  int nparts = 0;
+  // the chain kernel also clears dQs, which k_mid_bwd accumulates into
   PCA_TRY(mab1_bf16_bwd_ex(s1, X, H, p1, saved1, dY, dX, nullptr, 0, g1, ws1,
-                           PCA_F_SKIP_KV_TAIL, st, &im));
+                           PCA_F_SKIP_KV_TAIL, st, &im, w0.dQs, m * d, &nparts));
   const int64_t Bm = (int64_t)s0.B * m;
-  {
-    WgradJobs jobs{};
-    jobs.j[0] = WgradJob{w1.dKp, H, g1.wk, g1.bk, Bm, 0, 128};
-    jobs.j[1] = WgradJob{w1.dVp, H, g1.wv, g1.bv, Bm, 0, 128};
-    jobs.n = 2;
-    PCA_TRY(wgrad128_launch(jobs, false, false, 64, st));
-  }
-  PCA_TRY(fill_zero(w0.dQs, (int64_t)m * d, st));
+  const int Rp = 64;
   MidBwdLaunch L{};
   L.B = s0.B; L.dk = dk;
-  L.dKp = w1.dKp; L.dVp = w1.dVp; L.Z = v0.Z; L.T = v0.T; L.LSE = v0.LSE;
+  L.dKpPart = w1.dKpPart; L.dVpPart = w1.dVpPart; L.nparts = nparts;
+  L.dKp = w1.dKp; L.dVp = w1.dVp;
+  L.zero_ptr = w0.DG; L.zero_n = Rp * dk;         // cleared for k_mab0_bwd's atomics
+  L.Z = v0.Z; L.T = v0.T; L.LSE = v0.LSE;
   L.Wk1T = im.Wk1T; L.Wv1T = im.Wv1T; L.Wo0TP = im.Wo0TP; L.Wv0TP = im.Wv0TP; L.Wv0T = im.Wv0T;
   L.Wv0f = p0.wv;
   L.dZ = w0.dZ; L.dO = w0.dO; L.Th = w0.Th; L.dQs = w0.dQs; L.dTf = w0.dTf; L.dTb = w0.dTb;
   L.dTt = w0.dTt; L.Delta = w0.Delta; L.LSEp = w0.LSEp;
   PCA_TRY(mid_bwd_launch(L, st));
+  {   // every [B*m]-row weight gradient of the ISAB in ONE launch
+    WgradJobs jobs{};
+    jobs.j[jobs.n++] = WgradJob{w1.dKp, H, g1.wk, g1.bk, Bm, 0, 128};
+    jobs.j[jobs.n++] = WgradJob{w1.dVp, H, g1.wv, g1.bv, Bm, 0, 128};
+    jobs.j[jobs.n++] = WgradJob{w0.dZ, v0.O, g0.wo, g0.bo, Bm, 0, 128};
+    if (dk > 4)
+      for (int j = 0; j < 4; ++j)
+        jobs.j[jobs.n++] = WgradJob{w0.dO, w0.Th + (int64_t)j * Bm * dk, g0.wv,
+                                    j == 0 ? g0.bv : nullptr, Bm, 32 * j, 32 * (j + 1)};
+    PCA_TRY(wgrad128_launch(jobs, false, false, 64, st));
+    if (dk <= 4)
+      PCA_TRY(wgrad_small_f32_launch(w0.dO, w0.Th, Bm, dk, (int64_t)Bm * dk, g0.wv, g0.bv, st));
+  }
   return mab0_bf16_bwd_ex(s0, I, X, p0, saved0, nullptr, dI, dX, dX != nullptr ? 1 : 0, g0, ws0,
-                          PCA_F_SKIP_HEAD, st);
+                          PCA_F_SKIP_HEAD | PCA_F_SKIP_WGRAD, st);
 }
 
 }  // namespace pca

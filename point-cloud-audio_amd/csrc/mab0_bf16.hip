@@ -46,38 +46,57 @@ __device__ __forceinline__ bf16x8 tr_frag(const char* img, int t, int lane) {
 }
 
 // ---------------------------------------------------------------------------------
-// Qp[m][d] = I Wq^T + bq (fp32) ; G[h*m][dk] = scale*log2(e) * Qp_h Wk_h   (bf16 + fp32)
-// one block per query row q; threads over output columns
+// Query-side preparation of up to 3 MABs in ONE launch (they only depend on parameters):
+//   Qp[m][d] = I Wq^T + bq (fp32) ; G[h*m][dk] = scale*log2(e) * Qp_h Wk_h (fp32 + bf16, padding
+//   rows zero) ; GtP[dk][Rp] = K-permuted transpose of G for the backward.
+// blockIdx.y = MAB, blockIdx.x = query row q (blocks beyond m exit).
 // ---------------------------------------------------------------------------------
-__global__ __launch_bounds__(256) void k_mab0_prep(const float* __restrict__ I,
-                                                   const float* __restrict__ Wq,
-                                                   const float* __restrict__ bq,
-                                                   const float* __restrict__ Wk, int m, int d,
-                                                   int dq, int dk, int h, float sl2e,
-                                                   float* __restrict__ Qp,
-                                                   float* __restrict__ Gf,
-                                                   __bf16* __restrict__ Gb, int Rpad) {
+__global__ __launch_bounds__(256) void k_mab0_prep(const Mab0PrepJobs jobs) {
   extern __shared__ float sq[];            // Qp row [d]
+  const Mab0PrepJob a = jobs.j[blockIdx.y];
   const int q = blockIdx.x;
+  if (q >= a.m) return;
+  const int m = a.m, d = a.d, dq = a.dq, dk = a.dk, h = a.h;
+  const int R = h * m;
   for (int f = threadIdx.x; f < d; f += 256) {
-    float a = bq[f];
-    for (int c = 0; c < dq; ++c) a += I[q * dq + c] * Wq[f * dq + c];
-    sq[f] = a;
-    Qp[q * d + f] = a;
+    float acc = a.bq[f];
+    for (int c = 0; c < dq; ++c) acc += a.I[q * dq + c] * a.Wq[f * dq + c];
+    sq[f] = acc;
+    a.Qp[q * d + f] = acc;
   }
   __syncthreads();
   const int dh = d / h;
   for (int o = threadIdx.x; o < h * dk; o += 256) {
     const int j = o / dk, c = o - j * dk;
-    float a = 0.f;
-    for (int f = 0; f < dh; ++f) a += sq[j * dh + f] * Wk[(j * dh + f) * dk + c];
-    a *= sl2e;
+    float acc = 0.f;
+    for (int f = 0; f < dh; ++f) acc += sq[j * dh + f] * a.Wk[(j * dh + f) * dk + c];
+    acc *= a.sl2e;
     const int r = j * m + q;
-    Gf[r * dk + c] = a;
-    if (Gb != nullptr) Gb[r * dk + c] = (__bf16)a;
+    a.Gf[r * dk + c] = acc;
+    if (a.Gb != nullptr) a.Gb[r * dk + c] = (__bf16)acc;
+    if (a.GtP != nullptr) {
+      const int rb32 = r & ~31, ro = r & 31;
+      int pos = 0;
+#pragma unroll
+      for (int p = 0; p < 32; ++p)
+        if (perm32(p) == ro) pos = p;
+      a.GtP[c * a.Rp + rb32 + pos] = (__bf16)acc;
+    }
   }
-  // padding rows (PMA: R = h < 16) are zeroed by the host once
-  (void)Rpad;
+  if (q == 0 && a.Gb != nullptr) {         // zero the padding rows (PMA: R = h < 32)
+    for (int o = threadIdx.x; o < (a.Rp - R) * dk; o += 256) {
+      const int r = R + o / dk, c = o % dk;
+      a.Gb[r * dk + c] = (__bf16)0.f;
+      if (a.GtP != nullptr) {
+        const int rb32 = r & ~31, ro = r & 31;
+        int pos = 0;
+#pragma unroll
+        for (int p = 0; p < 32; ++p)
+          if (perm32(p) == ro) pos = p;
+        a.GtP[c * a.Rp + rb32 + pos] = (__bf16)0.f;
+      }
+    }
+  }
 }
 
 // ---------------------------------------------------------------------------------
@@ -400,6 +419,29 @@ bool mab0_bf16_supported(const pca_mab_shape& s) {
          s.q_dtype == PCA_F32 && s.k_dtype == PCA_F32 && s.y_dtype == PCA_F32;
 }
 
+void mab0_collect_prep(const pca_mab_shape& s, const float* I, const pca_mab_params& p,
+                       const Mab0Saved& v, bool training, Mab0PrepJobs* J) {
+  Mab0PrepJob a{};
+  a.I = I; a.Wq = p.wq; a.bq = p.bq; a.Wk = p.wk;
+  a.m = s.nq; a.d = s.d; a.dq = s.dq; a.dk = s.dk; a.h = s.h;
+  a.Rp = (int)cdiv(s.h * s.nq, 32) * 32;
+  a.sl2e = 1.4426950408889634f / sqrtf((float)s.d);
+  a.Qp = v.Qp; a.Gf = v.Gf;
+  a.Gb = s.dk <= 4 ? nullptr : v.Gb;
+  a.GtP = (s.dk <= 4 || !training) ? nullptr : v.GtP;
+  J->j[J->n++] = a;
+}
+int mab0_prep_launch(const Mab0PrepJobs& J, hipStream_t st) {
+  if (J.n == 0) return PCA_OK;
+  int maxm = 0, maxd = 0;
+  for (int i = 0; i < J.n; ++i) {
+    maxm = J.j[i].m > maxm ? J.j[i].m : maxm;
+    maxd = J.j[i].d > maxd ? J.j[i].d : maxd;
+  }
+  hipLaunchKernelGGL(k_mab0_prep, dim3(maxm, J.n), dim3(256), maxd * sizeof(float), st, J);
+  return check_launch("k_mab0_prep");
+}
+
 // point-range splits per set so that B*S workgroups cover the 256 CUs
 int mab0_splits(const pca_mab_shape& s) {
   if (s.dk <= 4) return 1;
@@ -417,6 +459,7 @@ size_t mab0_carve_saved(const pca_mab_shape& s, Mab0Saved* out, void* base) {
   v.Qp = c.take<float>((size_t)s.nq * s.d);
   v.Gf = c.take<float>((size_t)Rpad * s.dk);
   v.Gb = c.take<__bf16>((size_t)Rpad * s.dk);
+  v.GtP = c.take<__bf16>((size_t)Rpad * s.dk);
   v.T = c.take<float>((size_t)s.B * R * s.dk);
   v.LSE = c.take<float>((size_t)s.B * R);
   v.O = c.take<float>((size_t)s.B * s.nq * s.d);
@@ -459,12 +502,12 @@ int mab0_bf16_fwd_ex(const pca_mab_shape& s, const float* I, const float* X,
   const float sl2e = 1.4426950408889634f / sqrtf((float)d);
   const bool small = dk <= 4;
 
-  if (!small && Rpad32 != R) {          // PMA: zero the padding rows of G
-    PCA_TRY(fill_zero(reinterpret_cast<float*>(v.Gb), (int64_t)Rpad32 * dk / 2, st));
+  if (!(flags & PCA_F_PREP_DONE)) {
+    Mab0PrepJobs J{};
+    mab0_collect_prep(s, I, p, v, training, &J);
+    PCA_TRY(mab0_prep_launch(J, st));
   }
-  hipLaunchKernelGGL(k_mab0_prep, dim3(m), dim3(256), d * sizeof(float), st, I, p.wq, p.bq, p.wk,
-                     m, d, s.dq, dk, h, sl2e, v.Qp, v.Gf, small ? nullptr : v.Gb, Rpad);
-  PCA_TRY(check_launch("k_mab0_prep"));
+  (void)Rpad32;
 
   const double pts = (double)s.B * s.nk;
   if (small) {

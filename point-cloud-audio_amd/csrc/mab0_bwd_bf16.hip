@@ -519,18 +519,15 @@ int mab0_bf16_bwd_ex(const pca_mab_shape& s, const float* I, const float* X,
                        p.wv, m, d, dk, h, Rp, w.dZ, w.dO, w.Th, small ? w.dTf : nullptr,
                        small ? nullptr : w.dTb, small ? nullptr : w.dTt, w.Delta, w.LSEp, s.B);
   PCA_TRY(check_launch("k_mab0_epi_bwd"));
-  PCA_TRY(fill_zero(w.DG, (int64_t)Rp * dk, st));
+  if (!(flags & PCA_F_SKIP_WGRAD)) PCA_TRY(fill_zero(w.DG, (int64_t)Rp * dk, st));
 
   if (small) {
     hipLaunchKernelGGL(k_mab0_bwd_small, dim3(s.B), dim3(256), 0, st, X, v.Gf, w.dTf, v.LSE,
                        w.Delta, s.nk, R, Rp, dk, w.DG);
     PCA_TRY(check_launch("k_mab0_bwd_small"));
   } else {
-    hipLaunchKernelGGL(k_mab0_gt, dim3((unsigned)cdiv(dk * Rp, 256)), dim3(256), 0, st, v.Gf, R, Rp,
-                       dk, w.GtP);
-    PCA_TRY(check_launch("k_mab0_gt"));
     const int S = mab0_splits(s);
-    Mab0BwdArgs a{X, v.Gb, w.GtP, w.dTb, w.dTt, w.LSEp, w.Delta, dX, w.DG, s.B, s.nk,
+    Mab0BwdArgs a{X, v.Gb, v.GtP, w.dTb, w.dTt, w.LSEp, w.Delta, dX, w.DG, s.B, s.nk,
                   dk_accumulate ? 1 : 0, S};
     size_t lds = 2 * (size_t)Rp * 256 + 2 * (size_t)128 * Rp * 2 + 2 * 4 * 32 * 256 +
                  2 * Rp * sizeof(float);
@@ -551,7 +548,7 @@ int mab0_bf16_bwd_ex(const pca_mab_shape& s, const float* I, const float* X,
   }
 
   // ---- parameter gradients of the epilogue: [B*m]-row reductions, ONE MFMA launch ----
-  {
+  if (!(flags & PCA_F_SKIP_WGRAD)) {
     WgradJobs jobs{};
     jobs.j[0] = WgradJob{w.dZ, v.O, gr.wo, gr.bo, Bm, 0, 128};
     jobs.n = 1;

@@ -27,6 +27,7 @@ struct Mab0Saved {
   float* Qp;      // [m][d]     fc_q(I)
   float* Gf;      // [Rpad][dk] scale*log2e * Qp_h Wk_h   (fp32)
   __bf16* Gb;     // same, bf16 (MFMA operand)
+  __bf16* GtP;    // [dk][Rp] K-permuted transpose of G (backward)
   float* T;       // [B][R][dk] A X
   float* LSE;     // [B][R]     log2-domain
   float *O, *Z;   // [B][m][d]
@@ -34,6 +35,20 @@ struct Mab0Saved {
   float *Tp, *Mp, *Lp;   // per point-range partials of the attention (merged by the epilogue)
 };
 int mab0_splits(const pca_mab_shape& s);
+struct Mab0PrepJob {
+  const float *I, *Wq, *bq, *Wk;
+  int m, d, dq, dk, h, Rp;
+  float sl2e;
+  float *Qp, *Gf;
+  __bf16 *Gb, *GtP;
+};
+struct Mab0PrepJobs {
+  Mab0PrepJob j[3];
+  int n;
+};
+void mab0_collect_prep(const pca_mab_shape& s, const float* I, const pca_mab_params& p,
+                       const Mab0Saved& v, bool training, Mab0PrepJobs* J);
+int mab0_prep_launch(const Mab0PrepJobs& J, hipStream_t st);
 size_t mab0_carve_saved(const pca_mab_shape& s, Mab0Saved* out, void* base);
 
 // dst[c][r] = src[r][c]  (fp32): gives the per-set row-GEMM kernels coalesced weight reads
@@ -75,7 +90,7 @@ struct WgradJob {
   int g_lo, g_hi;
 };
 struct WgradJobs {
-  WgradJob j[6];
+  WgradJob j[8];
   int n;
 };
 // g_bf16 / a_bf16: element type of every job's G / A (bf16 or fp32)
@@ -110,7 +125,8 @@ int prep_jobs_launch(const PrepJobs& jobs, hipStream_t st);
 // scratch layouts of the two backward passes (shared with the ISAB-level orchestration)
 struct Mab1BwdWs {
   __bf16 *WoTP, *WqTP, *dZ, *dQp, *dOs, *dS, *P;
-  float *dKp, *dVp;
+  float *dKp, *dVp;            // [B][MI][D]
+  float *dKpPart, *dVpPart;    // [B][nparts][MI][D] per-workgroup partials (fused mode)
 };
 size_t mab1_carve_bwd_ws(const pca_mab_shape& s, Mab1BwdWs* out, void* base);
 struct Mab0BwdWs {
@@ -125,7 +141,9 @@ enum {
   PCA_F_KV_READY = 2,        // mab1 fwd: Kp/Vp images already written (by mid_fwd)
   PCA_F_SKIP_KV_TAIL = 4,    // mab1 bwd: stop after dKp/dVp (mid_bwd + batched wgrad follow)
   PCA_F_SKIP_HEAD = 8,       // mab0 bwd: dT/Delta images, dZ, dO, dQs already produced
-  PCA_F_IMAGES_READY = 16    // weight images were prepared by the caller (IsabImg)
+  PCA_F_IMAGES_READY = 16,   // weight images were prepared by the caller (IsabImg)
+  PCA_F_PREP_DONE = 32,      // mab0 fwd: Qp / G images were prepared by the caller
+  PCA_F_SKIP_WGRAD = 64      // mab0 bwd: dWo / dWv reductions are done by the caller; DG is clear
 };
 
 // ---- per-set mid kernels of a fused ISAB (mid_bf16.hip); m = 16, d = 128, h = 4 ----------
@@ -145,7 +163,12 @@ struct MidFwdLaunch {
 int mid_fwd_launch(const MidFwdLaunch& L, hipStream_t st);
 struct MidBwdLaunch {
   int B, dk;
-  const float *dKp, *dVp, *Z, *T, *LSE;
+  const float *dKpPart, *dVpPart;   // [B][nparts][16][128] partials from k_mab1_bwd
+  int nparts;
+  float *dKp, *dVp;                 // [B][16][128] sums (written; read by the wgrad jobs)
+  float* zero_ptr;                  // optional accumulator cleared by this launch (DG)
+  int zero_n;
+  const float *Z, *T, *LSE;
   const __bf16 *Wk1T, *Wv1T, *Wo0TP, *Wv0TP, *Wv0T;
   const float* Wv0f;
   float *dZ, *dO, *Th, *dQs, *dTf;

@@ -41,7 +41,9 @@ struct Mab1BwdArgs {
   __bf16 *dZ, *dQp, *dOs;   // [B*N][D]
   __bf16 *dS, *P;           // [B*N][H*MI]
   float* dX;                // [B, N, D] or null
-  float *dKpG, *dVpG;       // [B][MI][D] fp32, atomically accumulated (fused K/V gradients)
+  float *dKpG, *dVpG;       // [B][nparts][MI][D] fp32 partial K/V gradients (fused mode)
+  float* zero_ptr;          // optional: zero_n floats cleared by this launch (consumer's
+  int zero_n;               //           accumulator, e.g. the dQs of k_mid_bwd)
   int B, N, tiles_per_set;
   int tpw;                  // consecutive tiles of ONE set per workgroup (fused mode)
   float scale, scale_log2e;
@@ -90,6 +92,8 @@ __global__ __launch_bounds__(256, 1) void k_mab1_bwd(const Mab1BwdArgs a) {
 
   const int total_tiles = a.B * a.tiles_per_set;
   int cur_b = -1;
+  if (a.zero_ptr != nullptr)
+    for (int i = blockIdx.x * 256 + tid; i < a.zero_n; i += gridDim.x * 256) a.zero_ptr[i] = 0.f;
   char* myDS = sKV + wave * 6144;
   char* myP = myDS + 1024;
   char* myQ = myP + 1024;
@@ -333,11 +337,13 @@ __global__ __launch_bounds__(256, 1) void k_mab1_bwd(const Mab1BwdArgs a) {
           red[(wave * 2 + 1) * MI * D + o] = dvp[j][tt][e];
         }
     __syncthreads();
+    const int nparts = a.tiles_per_set / a.tpw;
+    const int part = (t_first - cur_b * a.tiles_per_set) / a.tpw;
     for (int i = tid; i < 2 * MI * D; i += 256) {
       const int which = i / (MI * D), o = i - which * MI * D;
       const float v = red[(0 * 2 + which) * MI * D + o] + red[(1 * 2 + which) * MI * D + o] +
                       red[(2 * 2 + which) * MI * D + o] + red[(3 * 2 + which) * MI * D + o];
-      atomicAdd((which ? a.dVpG : a.dKpG) + (int64_t)cur_b * MI * D + o, v);
+      (which ? a.dVpG : a.dKpG)[((int64_t)cur_b * nparts + part) * MI * D + o] = v;
     }
   }
 }
@@ -585,6 +591,21 @@ __global__ __launch_bounds__(256) void k_kv_grad(const __bf16* __restrict__ dS,
   }
 }
 
+__global__ void k_sum_parts(const float* __restrict__ kp, const float* __restrict__ vp,
+                            float* __restrict__ dk, float* __restrict__ dv, int B, int nparts,
+                            int n) {
+  const int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x;
+  if (i >= (int64_t)B * n) return;
+  const int64_t b = i / n, o = i - b * n;
+  float a = 0.f, c = 0.f;
+  for (int p = 0; p < nparts; ++p) {
+    a += kp[(b * nparts + p) * n + o];
+    c += vp[(b * nparts + p) * n + o];
+  }
+  dk[i] = a;
+  dv[i] = c;
+}
+
 template <int D, int MI, bool DX, bool FUSE>
 int launch_bwd(const Mab1BwdArgs& a, hipStream_t st, double flops, double bytes) {
   size_t lds = (size_t)D * D * 2 + 2 * (size_t)MI * D * 2 + (size_t)D * MI * 2 +
@@ -617,6 +638,9 @@ size_t mab1_carve_bwd_ws(const pca_mab_shape& s, Mab1BwdWs* out, void* base) {
   w.P = c.take<__bf16>(M * s.h * s.nk);
   w.dKp = c.take<float>((size_t)s.B * s.nk * d);
   w.dVp = c.take<float>((size_t)s.B * s.nk * d);
+  const size_t tiles = (size_t)cdiv(s.nq, M1_TP);
+  w.dKpPart = c.take<float>((size_t)s.B * tiles * s.nk * d);
+  w.dVpPart = c.take<float>((size_t)s.B * tiles * s.nk * d);
   if (out) *out = w;
   return c.off;
 }
@@ -663,7 +687,8 @@ int kv_dh_launch(const float* dKp, const float* dVp, const float* Wk, const floa
 int mab1_bf16_bwd_ex(const pca_mab_shape& s, const float* X, const float* H,
                      const pca_mab_params& p, const void* saved, const float* dY, float* dX,
                      float* dH, int dk_accumulate, const pca_mab_grads& gr, void* ws, int flags,
-                     hipStream_t st, const IsabImg* img = nullptr);
+                     hipStream_t st, const IsabImg* img = nullptr, float* zero_ptr = nullptr,
+                     int zero_n = 0, int* nparts_out = nullptr);
 int mab1_bf16_bwd(const pca_mab_shape& s, const float* X, const float* H,
                   const pca_mab_params& p, const void* saved, const float* dY, float* dX,
                   float* dH, int dk_accumulate, const pca_mab_grads& gr, void* ws,
@@ -673,7 +698,8 @@ int mab1_bf16_bwd(const pca_mab_shape& s, const float* X, const float* H,
 int mab1_bf16_bwd_ex(const pca_mab_shape& s, const float* X, const float* H,
                      const pca_mab_params& p, const void* saved, const float* dY, float* dX,
                      float* dH, int dk_accumulate, const pca_mab_grads& gr, void* ws, int flags,
-                     hipStream_t st, const IsabImg* img) {
+                     hipStream_t st, const IsabImg* img, float* zero_ptr, int zero_n,
+                     int* nparts_out) {
   Mab1Saved v;
   mab1_carve_saved(s, &v, const_cast<void*>(saved));
   Mab1BwdWs w;
@@ -715,9 +741,10 @@ int mab1_bf16_bwd_ex(const pca_mab_shape& s, const float* X, const float* H,
     for (int c = 1; c <= a.tiles_per_set; ++c)
       if (a.tiles_per_set % c == 0 && (int64_t)a.B * a.tiles_per_set / c >= 256) tpw = c;
     a.tpw = tpw;
-    a.dKpG = w.dKp;
-    a.dVpG = w.dVp;
-    PCA_TRY(fill_zero(w.dKp, 2 * (int64_t)align256((size_t)s.B * MI * d * 4) / 4, st));
+    a.dKpG = w.dKpPart;
+    a.dVpG = w.dVpPart;
+    a.zero_ptr = zero_ptr;
+    a.zero_n = zero_n;
     rc = want_dx ? launch_bwd<128, 16, true, true>(a, st, flops, bytes)
                  : launch_bwd<128, 16, false, true>(a, st, flops, bytes);
   } else {
@@ -725,6 +752,7 @@ int mab1_bf16_bwd_ex(const pca_mab_shape& s, const float* X, const float* H,
                  : launch_bwd<128, 32, false, false>(a, st, flops, bytes);
   }
   PCA_TRY(rc);
+  if (nparts_out != nullptr) *nparts_out = fuse ? a.tiles_per_set / a.tpw : 0;
   // ---- reductions over points (one launch for dWo / dWq) ----
   const int rows_per_wg = 512;
   {
@@ -754,6 +782,12 @@ int mab1_bf16_bwd_ex(const pca_mab_shape& s, const float* X, const float* H,
   }
 
   if (flags & PCA_F_SKIP_KV_TAIL) return PCA_OK;
+  if (fuse) {        // stand-alone MAB: sum the per-workgroup partials
+    const int nparts = a.tiles_per_set / a.tpw;
+    hipLaunchKernelGGL(k_sum_parts, dim3((unsigned)cdiv((int64_t)s.B * MI * d, 256)), dim3(256), 0,
+                       st, w.dKpPart, w.dVpPart, w.dKp, w.dVp, s.B, nparts, MI * d);
+    PCA_TRY(check_launch("k_sum_parts"));
+  }
   // ---- fc_k / fc_v of the m inducing-point outputs: [B*m]-row reductions, one launch ----
   const int64_t Mk = (int64_t)s.B * MI;
   {

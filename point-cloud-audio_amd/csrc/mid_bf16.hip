@@ -173,7 +173,11 @@ __global__ __launch_bounds__(256) void k_mid_fwd(const MidFwdArgs a) {
 }
 
 struct MidBwdArgs {
-  const float *dKp, *dVp;       // [B][16][128] fp32
+  const float *dKpPart, *dVpPart;   // [B][nparts][16][128] fp32
+  int nparts;
+  float *dKp, *dVp;             // [B][16][128] fp32 sums (out)
+  float* zero_ptr;
+  int zero_n;
   const float *Z, *T, *LSE;     // saved by the forward
   const __bf16 *Wk1T, *Wv1T;    // [128][128] transposed natural:  W^T[c][f]
   const __bf16* Wo0TP;          // [128][128] transposed, K-permuted
@@ -198,16 +202,29 @@ __global__ __launch_bounds__(256) void k_mid_bwd(const MidBwdArgs a) {
   const int r = lane & 15, g = lane >> 4;
   const int dk = a.dk;
 
+  if (a.zero_ptr != nullptr)
+    for (int i = blockIdx.x * 256 + tid; i < a.zero_n; i += gridDim.x * 256) a.zero_ptr[i] = 0.f;
   for (int i = tid; i < 16 * 16; i += 256) {
     const int row = i >> 4, ch = i & 15;
-    const float4* pk = reinterpret_cast<const float4*>(a.dKp + ((int64_t)b * MQ + row) * D + ch * 8);
-    const float4* pv = reinterpret_cast<const float4*>(a.dVp + ((int64_t)b * MQ + row) * D + ch * 8);
-    const float4 k0 = pk[0], k1 = pk[1], v0 = pv[0], v1 = pv[1];
+    float k[8] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f}, v[8] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+    for (int pp = 0; pp < a.nparts; ++pp) {
+      const int64_t off = (((int64_t)b * a.nparts + pp) * MQ + row) * D + ch * 8;
+      const float4* pk = reinterpret_cast<const float4*>(a.dKpPart + off);
+      const float4* pv = reinterpret_cast<const float4*>(a.dVpPart + off);
+      const float4 k0 = pk[0], k1 = pk[1], v0 = pv[0], v1 = pv[1];
+      k[0] += k0.x; k[1] += k0.y; k[2] += k0.z; k[3] += k0.w;
+      k[4] += k1.x; k[5] += k1.y; k[6] += k1.z; k[7] += k1.w;
+      v[0] += v0.x; v[1] += v0.y; v[2] += v0.z; v[3] += v0.w;
+      v[4] += v1.x; v[5] += v1.y; v[6] += v1.z; v[7] += v1.w;
+    }
+    const int64_t so = ((int64_t)b * MQ + row) * D + ch * 8;
+    reinterpret_cast<float4*>(a.dKp + so)[0] = float4{k[0], k[1], k[2], k[3]};
+    reinterpret_cast<float4*>(a.dKp + so)[1] = float4{k[4], k[5], k[6], k[7]};
+    reinterpret_cast<float4*>(a.dVp + so)[0] = float4{v[0], v[1], v[2], v[3]};
+    reinterpret_cast<float4*>(a.dVp + so)[1] = float4{v[4], v[5], v[6], v[7]};
     bf16x8 kb, vb;
-    kb[0] = (__bf16)k0.x; kb[1] = (__bf16)k0.y; kb[2] = (__bf16)k0.z; kb[3] = (__bf16)k0.w;
-    kb[4] = (__bf16)k1.x; kb[5] = (__bf16)k1.y; kb[6] = (__bf16)k1.z; kb[7] = (__bf16)k1.w;
-    vb[0] = (__bf16)v0.x; vb[1] = (__bf16)v0.y; vb[2] = (__bf16)v0.z; vb[3] = (__bf16)v0.w;
-    vb[4] = (__bf16)v1.x; vb[5] = (__bf16)v1.y; vb[6] = (__bf16)v1.z; vb[7] = (__bf16)v1.w;
+#pragma unroll
+    for (int e = 0; e < 8; ++e) { kb[e] = (__bf16)k[e]; vb[e] = (__bf16)v[e]; }
     *reinterpret_cast<bf16x8*>(sK + swz(row, ch, ROWB)) = kb;
     *reinterpret_cast<bf16x8*>(sV + swz(row, ch, ROWB)) = vb;
   }
@@ -329,7 +346,8 @@ int mid_fwd_launch(const MidFwdLaunch& L, hipStream_t st) {
 
 int mid_bwd_launch(const MidBwdLaunch& L, hipStream_t st) {
   MidBwdArgs a{};
-  a.dKp = L.dKp; a.dVp = L.dVp; a.Z = L.Z; a.T = L.T; a.LSE = L.LSE; a.Wk1T = L.Wk1T;
+  a.dKpPart = L.dKpPart; a.dVpPart = L.dVpPart; a.nparts = L.nparts; a.dKp = L.dKp;
+  a.dVp = L.dVp; a.zero_ptr = L.zero_ptr; a.zero_n = L.zero_n; a.Z = L.Z; a.T = L.T; a.LSE = L.LSE; a.Wk1T = L.Wk1T;
   a.Wv1T = L.Wv1T; a.Wo0TP = L.Wo0TP; a.Wv0TP = L.Wv0TP; a.Wv0T = L.Wv0T; a.Wv0f = L.Wv0f;
   a.dZ = L.dZ; a.dO = L.dO; a.Th = L.Th; a.dQs = L.dQs; a.dTf = L.dTf; a.dTb = L.dTb;
   a.dTt = L.dTt; a.Delta = L.Delta; a.LSEp = L.LSEp; a.dk = L.dk; a.B = L.B;

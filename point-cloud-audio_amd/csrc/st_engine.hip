@@ -20,6 +20,10 @@ int mab_bwd_any(const pca_mab_shape& s, const float* Q, const float* K, const pc
 bool isab_bf16_supported(const pca_mab_shape& s0, const pca_mab_shape& s1);
 size_t isab_bf16_fwd_ws_bytes(const pca_mab_shape& s0, const pca_mab_shape& s1);
 size_t isab_bf16_bwd_ws_bytes(const pca_mab_shape& s0, const pca_mab_shape& s1);
+int mab_kind(const pca_mab_shape& s);
+int mab0_bf16_fwd_ex(const pca_mab_shape& s, const float* I, const float* X,
+                     const pca_mab_params& p, float* H, void* saved, void* ws, int flags,
+                     hipStream_t st);
 size_t isab_img_bytes();
 void isab_img_carve(void* base, IsabImg* im);
 void isab_collect_prep(const pca_mab_shape& s0, const pca_mab_params& p0,
@@ -194,6 +198,20 @@ int forward(const pca_st_config& c, const Layout& L, const Shapes& s, const floa
         isab_collect_prep(s.m0[li], params_at(p, L.mab0[li]), params_at(p, L.mab1[li]),
                           w.img[li], true, li == 1, &J);
     PCA_TRY(prep_jobs_launch(J, st));
+    // query-side preparation (Qp, G images) of every fused mab0 / PMA, also one launch
+    Mab0PrepJobs MJ{};
+    for (int li = 0; li < 2; ++li)
+      if (w.fused[li]) {
+        Mab0Saved v;
+        mab0_carve_saved(s.m0[li], &v, w.saved[2 * li]);
+        mab0_collect_prep(s.m0[li], p + L.I[li], params_at(p, L.mab0[li]), v, true, &MJ);
+      }
+    if (mab_kind(s.pma) == 2) {
+      Mab0Saved v;
+      mab0_carve_saved(s.pma, &v, w.saved[4]);
+      mab0_collect_prep(s.pma, p + L.S, params_at(p, L.pma), v, true, &MJ);
+    }
+    PCA_TRY(mab0_prep_launch(MJ, st));
   }
   for (int li = 0; li < 2; ++li) {
     void* sv0 = training ? w.saved[2 * li] : nullptr;
@@ -211,8 +229,12 @@ int forward(const pca_st_config& c, const Layout& L, const Shapes& s, const floa
                         w.scratch, st));                            // modules.py:53
     in = w.Y[li];
   }
-  PCA_TRY(mab_fwd_any(s.pma, p + L.S, w.Y[1], params_at(p, L.pma), w.P,
-                      training ? w.saved[4] : nullptr, w.scratch, st));   // modules.py:63
+  if (training && mab_kind(s.pma) == 2)                                   // modules.py:63
+    PCA_TRY(mab0_bf16_fwd_ex(s.pma, p + L.S, w.Y[1], params_at(p, L.pma), w.P, w.saved[4],
+                             w.scratch, PCA_F_PREP_DONE, st));
+  else
+    PCA_TRY(mab_fwd_any(s.pma, p + L.S, w.Y[1], params_at(p, L.pma), w.P,
+                        training ? w.saved[4] : nullptr, w.scratch, st));
   PCA_TRY(linear_fwd_f32(w.P, p + L.wc, p + L.bc, w.logits, (int64_t)c.B * c.k, c.d, c.C,
                          st));                                      // models.py:40
   return PCA_OK;
