@@ -42,6 +42,9 @@ struct Mab1BwdArgs {
   __bf16 *dS, *P;           // [B*N][H*MI]
   float* dX;                // [B, N, D] or null
   float *dKpG, *dVpG;       // [B][nparts][MI][D] fp32 partial K/V gradients (fused mode)
+  const float* Xs;          // layer 1 (dq <= 3): the fp32 points [B, N, dq] ...
+  float *dWqS, *dbqS;       // ... and fc_q gradients accumulated here (fused reduction)
+  int dq;
   float* zero_ptr;          // optional: zero_n floats cleared by this launch (consumer's
   int zero_n;               //           accumulator, e.g. the dQs of k_mid_bwd)
   int B, N, tiles_per_set;
@@ -66,7 +69,7 @@ __device__ __forceinline__ bf16x8 tr_frag_small(const char* img, int rb, int col
   return r;
 }
 
-template <int D, int MI, bool WANT_DX, bool FUSE_KV>
+template <int D, int MI, bool WANT_DX, bool FUSE_KV, bool FUSE_WQ>
 __global__ __launch_bounds__(256, 1) void k_mab1_bwd(const Mab1BwdArgs a) {
   constexpr int DT = D / 16, KS = D / 32, ROWB = D * 2, HM = KS * MI;
   extern __shared__ __attribute__((aligned(16))) char smem[];
@@ -106,6 +109,18 @@ __global__ __launch_bounds__(256, 1) void k_mab1_bwd(const Mab1BwdArgs a) {
       for (int tt = 0; tt < 2; ++tt) {
         dkp[j][tt] = f32x4{0.f, 0.f, 0.f, 0.f};
         dvp[j][tt] = f32x4{0.f, 0.f, 0.f, 0.f};
+      }
+  }
+  // layer 1: per-lane partial sums of dWq[f][c] = sum_pt dQp[f][pt] x[pt][c] and dbq[f]
+  float wq_acc[FUSE_WQ ? D / 16 : 1][4][3], bq_acc[FUSE_WQ ? D / 16 : 1][4];
+  if (FUSE_WQ) {
+#pragma unroll
+    for (int t = 0; t < D / 16; ++t)
+#pragma unroll
+      for (int e = 0; e < 4; ++e) {
+        bq_acc[t][e] = 0.f;
+#pragma unroll
+        for (int c = 0; c < 3; ++c) wq_acc[t][e][c] = 0.f;
       }
   }
   // fused mode: a workgroup owns `tpw` consecutive tiles of one set; otherwise grid-stride
@@ -284,13 +299,34 @@ __global__ __launch_bounds__(256, 1) void k_mab1_bwd(const Mab1BwdArgs a) {
       }
     }
     // dO now holds dQp^T
+    if (FUSE_WQ) {
 #pragma unroll
-    for (int nb = 0; nb < NB; ++nb)
-      if (live[nb]) {
+      for (int nb = 0; nb < NB; ++nb) {
+        float xv[3];
 #pragma unroll
-        for (int t = 0; t < DT; ++t)
-          *reinterpret_cast<bf16x4*>(a.dQp + row[nb] * D + 16 * t + 4 * g) = pack4(dO[t][nb]);
+        for (int c = 0; c < 3; ++c)
+          xv[c] = (live[nb] && c < a.dq) ? a.Xs[row[nb] * a.dq + c] : 0.f;
+        if (live[nb]) {
+#pragma unroll
+          for (int t = 0; t < DT; ++t)
+#pragma unroll
+            for (int e = 0; e < 4; ++e) {
+              const float gq = dO[t][nb][e];
+              bq_acc[t][e] += gq;
+#pragma unroll
+              for (int c = 0; c < 3; ++c) wq_acc[t][e][c] = fmaf(gq, xv[c], wq_acc[t][e][c]);
+            }
+        }
       }
+    } else {
+#pragma unroll
+      for (int nb = 0; nb < NB; ++nb)
+        if (live[nb]) {
+#pragma unroll
+          for (int t = 0; t < DT; ++t)
+            *reinterpret_cast<bf16x4*>(a.dQp + row[nb] * D + 16 * t + 4 * g) = pack4(dO[t][nb]);
+        }
+    }
 
     if (WANT_DX) {
       f32x4 dx[DT][NB];
@@ -320,6 +356,37 @@ __global__ __launch_bounds__(256, 1) void k_mab1_bwd(const Mab1BwdArgs a) {
                 float4{dx[t][nb][0], dx[t][nb][1], dx[t][nb][2], dx[t][nb][3]};
         }
     }
+  }
+  if (FUSE_WQ) {
+    // sum over the 16 point lanes of each lane group, then over the waves, then one atomic
+    // per element per workgroup
+    __syncthreads();
+    float* red = reinterpret_cast<float*>(smem);             // [4 waves][D][4]
+#pragma unroll
+    for (int t = 0; t < DT; ++t)
+#pragma unroll
+      for (int e = 0; e < 4; ++e) {
+        float v[4] = {wq_acc[t][e][0], wq_acc[t][e][1], wq_acc[t][e][2], bq_acc[t][e]};
+#pragma unroll
+        for (int k = 0; k < 4; ++k) {
+          v[k] += __shfl_xor(v[k], 1, 64);
+          v[k] += __shfl_xor(v[k], 2, 64);
+          v[k] += __shfl_xor(v[k], 4, 64);
+          v[k] += __shfl_xor(v[k], 8, 64);
+        }
+        if (r == 0) {
+          float* dst = red + ((wave * D) + 16 * t + 4 * g + e) * 4;
+          dst[0] = v[0]; dst[1] = v[1]; dst[2] = v[2]; dst[3] = v[3];
+        }
+      }
+    __syncthreads();
+    for (int i = tid; i < D * 4; i += 256) {
+      const float v = red[i] + red[D * 4 + i] + red[2 * D * 4 + i] + red[3 * D * 4 + i];
+      const int f = i >> 2, c = i & 3;
+      if (c < a.dq) atomicAdd(&a.dWqS[f * a.dq + c], v);
+      else if (c == 3) atomicAdd(&a.dbqS[f], v);
+    }
+    __syncthreads();
   }
   if (FUSE_KV && cur_b >= 0) {
     // reduce the four waves' [MI][D] partials in LDS (the weight images are dead), then one
@@ -606,20 +673,20 @@ __global__ void k_sum_parts(const float* __restrict__ kp, const float* __restric
   dv[i] = c;
 }
 
-template <int D, int MI, bool DX, bool FUSE>
+template <int D, int MI, bool DX, bool FUSE, bool FWQ = false>
 int launch_bwd(const Mab1BwdArgs& a, hipStream_t st, double flops, double bytes) {
   size_t lds = (size_t)D * D * 2 + 2 * (size_t)MI * D * 2 + (size_t)D * MI * 2 +
                (DX ? (size_t)D * D * 2 : 0) + (FUSE ? 4 * 6144 : 0);
   if (FUSE && lds < (size_t)8 * MI * D * 4) lds = (size_t)8 * MI * D * 4;   // flush buffer
   static std::once_flag once;
   std::call_once(once, [] {
-    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(k_mab1_bwd<D, MI, DX, FUSE>),
+    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(k_mab1_bwd<D, MI, DX, FUSE, FWQ>),
                               hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
   });
   const int total = a.B * a.tiles_per_set;
   const int grid = FUSE ? (int)cdiv(total, a.tpw) : (total < 256 ? total : 256);
   ProfScope ps(PCA_K_MAB1_BWD, st, flops, bytes);
-  hipLaunchKernelGGL((k_mab1_bwd<D, MI, DX, FUSE>), dim3(grid), dim3(256), lds, st, a);
+  hipLaunchKernelGGL((k_mab1_bwd<D, MI, DX, FUSE, FWQ>), dim3(grid), dim3(256), lds, st, a);
   ps.end();
   return check_launch("k_mab1_bwd");
 }
@@ -745,7 +812,10 @@ int mab1_bf16_bwd_ex(const pca_mab_shape& s, const float* X, const float* H,
     a.dVpG = w.dVpPart;
     a.zero_ptr = zero_ptr;
     a.zero_n = zero_n;
+    const bool fwq = small && s.dq <= 3;
+    a.Xs = X; a.dWqS = gr.wq; a.dbqS = gr.bq; a.dq = s.dq;
     rc = want_dx ? launch_bwd<128, 16, true, true>(a, st, flops, bytes)
+         : fwq   ? launch_bwd<128, 16, false, true, true>(a, st, flops, bytes)
                  : launch_bwd<128, 16, false, true>(a, st, flops, bytes);
   } else {
     rc = want_dx ? launch_bwd<128, 32, true, false>(a, st, flops, bytes)
@@ -763,7 +833,9 @@ int mab1_bf16_bwd_ex(const pca_mab_shape& s, const float* X, const float* H,
     PCA_TRY(wgrad128_launch(jobs, true, true, rows_per_wg, st));
     ps.end();
   }
-  if (small) {
+  if (small && fuse && s.dq <= 3) {
+    // dWq / dbq were reduced inside the chain kernel
+  } else if (small) {
     hipLaunchKernelGGL((k_wgrad_small<__bf16>), dim3((unsigned)cdiv(M, 128)), dim3(256), 0, st,
                        w.dQp, X, M, s.dq, 128, (int64_t)0, gr.wq, gr.bq);
     PCA_TRY(check_launch("k_wgrad_small"));

@@ -20,6 +20,10 @@ int mab_bwd_any(const pca_mab_shape& s, const float* Q, const float* K, const pc
 bool isab_bf16_supported(const pca_mab_shape& s0, const pca_mab_shape& s1);
 size_t isab_bf16_fwd_ws_bytes(const pca_mab_shape& s0, const pca_mab_shape& s1);
 size_t isab_bf16_bwd_ws_bytes(const pca_mab_shape& s0, const pca_mab_shape& s1);
+int cls_train_head(const float* P, const float* Wc, const float* bc, const int64_t* labels,
+                   int B, int d, int C, float grad_scale, float* logits, float* dlogits,
+                   float* dP, float* dWc, float* dbc, float* loss_out, float* stats, float* ws,
+                   hipStream_t st);
 int mab_kind(const pca_mab_shape& s);
 int mab0_bf16_fwd_ex(const pca_mab_shape& s, const float* I, const float* X,
                      const pca_mab_params& p, float* H, void* saved, void* ws, int flags,
@@ -126,7 +130,7 @@ inline Shapes shapes(const pca_st_config& c) {
 struct Ws {
   void* saved[5];            // mab0[0], mab1[0], mab0[1], mab1[1], pma
   float *H[2], *Y[2], *P, *logits, *dlogits;
-  float *dP, *dY2, *dY1, *dH;
+  float *dP, *dY2, *dY1, *dH, *clsws;
   void* scratch;
   IsabImg img[2];            // weight images of the two ISABs (fused bf16 path)
   bool fused[2];
@@ -171,6 +175,7 @@ inline size_t carve(const pca_st_config& c, int training, Ws* out, void* base) {
     w.dY2 = cv.take<float>(BN * c.d);
     w.dY1 = cv.take<float>(BN * c.d);
     w.dH = cv.take<float>(Bm * c.d);
+    w.clsws = cv.take<float>(2 * (size_t)c.B);
   }
   w.scratch = cv.take<char>(max_scratch);   // per-call scratch, reused by every block
   if (out) *out = w;
@@ -235,8 +240,9 @@ int forward(const pca_st_config& c, const Layout& L, const Shapes& s, const floa
   else
     PCA_TRY(mab_fwd_any(s.pma, p + L.S, w.Y[1], params_at(p, L.pma), w.P,
                         training ? w.saved[4] : nullptr, w.scratch, st));
-  PCA_TRY(linear_fwd_f32(w.P, p + L.wc, p + L.bc, w.logits, (int64_t)c.B * c.k, c.d, c.C,
-                         st));                                      // models.py:40
+  if (!training)
+    PCA_TRY(linear_fwd_f32(w.P, p + L.wc, p + L.bc, w.logits, (int64_t)c.B * c.k, c.d, c.C,
+                           st));                                    // models.py:40
   return PCA_OK;
 }
 
@@ -295,11 +301,11 @@ int pca_st_train_fwd_bwd(const pca_st_config* c, const float* params, const floa
 
   if (phase != 1) {
     PCA_TRY(pca::forward(*c, L, s, p, X, w, true, st));
-    PCA_TRY(pca_cross_entropy(w.logits, labels, c->B, c->C, grad_scale, loss_out, w.dlogits,
-                              stats, stream));
-    // dec.1 (Linear), dec.0 (PMA)
-    PCA_TRY(pca::linear_bwd_f32(w.P, p + L.wc, w.dlogits, w.dP, g + L.wc, g + L.bc,
-                                (int64_t)c->B, c->d, c->C, st));
+    // dec.1 (Linear) + mean cross-entropy, forward and backward, two launches
+    PCA_TRY(pca::cls_train_head(w.P, p + L.wc, p + L.bc, labels, c->B, c->d, c->C, grad_scale,
+                                w.logits, w.dlogits, w.dP, g + L.wc, g + L.bc, loss_out, stats,
+                                w.clsws, st));
+    // dec.0 (PMA)
     PCA_TRY(pca::mab_bwd_any(s.pma, p + L.S, w.Y[1], pca::params_at(p, L.pma), w.saved[4],
                              w.dP, g + L.S, w.dY2, 0, pca::grads_at(g, L.pma), w.scratch,
                              st));

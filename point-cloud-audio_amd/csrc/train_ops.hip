@@ -52,6 +52,129 @@ __global__ __launch_bounds__(256) void k_cross_entropy(const float* __restrict__
   }
 }
 
+// ---------------------------------------------------------------------------------
+// Fused classifier head of the train step (Code/models.py:40 + Code/settransformer.py:104):
+//   k_cls_fwd_bwd  one 128-thread workgroup per sample: logits = P Wc^T + bc, softmax,
+//                  per-sample loss / correctness, dlogits = (softmax - onehot) gs / B,
+//                  dP = dlogits Wc
+//   k_cls_wgrad    dWc += dlogits^T P, dbc += colsum(dlogits); block 0 also reduces the
+//                  per-sample losses (deterministic sum) into loss_out and the counters
+// ---------------------------------------------------------------------------------
+__global__ __launch_bounds__(128) void k_cls_fwd_bwd(
+    const float* __restrict__ P, const float* __restrict__ Wc, const float* __restrict__ bc,
+    const int64_t* __restrict__ labels, int B, int d, int C, float grad_scale,
+    float* __restrict__ logits, float* __restrict__ dlogits, float* __restrict__ dP,
+    float* __restrict__ lossv, float* __restrict__ corrv) {
+  extern __shared__ float sm[];
+  float* sP = sm;            // [d]
+  float* sL = sP + d;        // [C] logits, then dlogits
+  __shared__ float red[2];
+  __shared__ int ramax;
+  const int b = blockIdx.x, tid = threadIdx.x;
+  for (int f = tid; f < d; f += 128) sP[f] = P[(int64_t)b * d + f];
+  __syncthreads();
+  for (int c = tid; c < C; c += 128) {
+    const float* w = Wc + (int64_t)c * d;
+    float acc = bc[c];
+    for (int f = 0; f < d; f += 4) {
+      const float4 w4 = *reinterpret_cast<const float4*>(w + f);
+      acc += sP[f] * w4.x + sP[f + 1] * w4.y + sP[f + 2] * w4.z + sP[f + 3] * w4.w;
+    }
+    sL[c] = acc;
+    logits[(int64_t)b * C + c] = acc;
+  }
+  __syncthreads();
+  if (tid < 64) {            // one wave: max / argmax / sum over the C logits
+    float m = -INFINITY;
+    int am = 0x7fffffff;
+    for (int j = tid; j < C; j += 64)
+      if (sL[j] > m) { m = sL[j]; am = j; }
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) {
+      const float om = __shfl_xor(m, o, 64);
+      const int oa = __shfl_xor(am, o, 64);
+      if (om > m || (om == m && oa < am)) { m = om; am = oa; }
+    }
+    float s = 0.f;
+    for (int j = tid; j < C; j += 64) s += expf(sL[j] - m);
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) s += __shfl_xor(s, o, 64);
+    if (tid == 0) { red[0] = m; red[1] = s; ramax = am; }
+  }
+  __syncthreads();
+  const float m = red[0], s = red[1];
+  const int64_t y = labels[b];
+  const float gs = grad_scale / (float)B;
+  if (tid == 0) {
+    lossv[b] = m + logf(s) - sL[y];
+    corrv[b] = ramax == (int)y ? 1.f : 0.f;
+  }
+  __syncthreads();
+  for (int c = tid; c < C; c += 128) {
+    const float g = (expf(sL[c] - m) / s - (c == y ? 1.f : 0.f)) * gs;
+    sL[c] = g;
+    dlogits[(int64_t)b * C + c] = g;
+  }
+  __syncthreads();
+  for (int f = tid; f < d; f += 128) {
+    float acc = 0.f;
+    for (int c = 0; c < C; ++c) acc += sL[c] * Wc[(int64_t)c * d + f];
+    dP[(int64_t)b * d + f] = acc;
+  }
+}
+
+__global__ __launch_bounds__(128) void k_cls_wgrad(
+    const float* __restrict__ dlogits, const float* __restrict__ P,
+    const float* __restrict__ lossv, const float* __restrict__ corrv, int B, int d, int C,
+    float* __restrict__ dWc, float* __restrict__ dbc, float* __restrict__ loss_out,
+    float* __restrict__ stats) {
+  const int c = blockIdx.x, tid = threadIdx.x;
+  for (int f = tid; f < d; f += 128) {
+    float acc = 0.f;
+    int bb = 0;
+    for (; bb + 8 <= B; bb += 8) {
+      float g[8], pv[8];
+#pragma unroll
+      for (int u = 0; u < 8; ++u) {
+        g[u] = dlogits[(int64_t)(bb + u) * C + c];
+        pv[u] = P[(int64_t)(bb + u) * d + f];
+      }
+#pragma unroll
+      for (int u = 0; u < 8; ++u) acc = fmaf(g[u], pv[u], acc);
+    }
+    for (; bb < B; ++bb) acc = fmaf(dlogits[(int64_t)bb * C + c], P[(int64_t)bb * d + f], acc);
+    dWc[(int64_t)c * d + f] += acc;
+  }
+  __shared__ float red[128];
+  float part = 0.f;
+  for (int bb = tid; bb < B; bb += 128) part += dlogits[(int64_t)bb * C + c];
+  red[tid] = part;
+  __syncthreads();
+  if (tid == 0) {
+    float t = 0.f;
+    for (int i = 0; i < 128; ++i) t += red[i];
+    dbc[c] += t;
+  }
+  if (c == 0) {              // loss / accuracy counters, summed in a fixed order
+    __syncthreads();
+    float l = 0.f, k = 0.f;
+    for (int bb = tid; bb < B; bb += 128) { l += lossv[bb]; k += corrv[bb]; }
+    red[tid] = l;
+    __syncthreads();
+    float lt = 0.f;
+    if (tid == 0) for (int i = 0; i < 128; ++i) lt += red[i];
+    __syncthreads();
+    red[tid] = k;
+    __syncthreads();
+    if (tid == 0) {
+      float kt = 0.f;
+      for (int i = 0; i < 128; ++i) kt += red[i];
+      loss_out[0] = lt / (float)B;
+      if (stats != nullptr) { stats[0] += lt; stats[1] += kt; }
+    }
+  }
+}
+
 __global__ void k_inc_step(int32_t* step) { *step += 1; }
 
 __global__ __launch_bounds__(256) void k_adam(float* __restrict__ p,
@@ -80,6 +203,21 @@ __global__ __launch_bounds__(256) void k_adam(float* __restrict__ p,
 }
 
 }  // namespace
+
+// classifier head of the train step; ws needs 2*B floats
+int cls_train_head(const float* P, const float* Wc, const float* bc, const int64_t* labels,
+                   int B, int d, int C, float grad_scale, float* logits, float* dlogits,
+                   float* dP, float* dWc, float* dbc, float* loss_out, float* stats, float* ws,
+                   hipStream_t st) {
+  float* lossv = ws;
+  float* corrv = ws + B;
+  hipLaunchKernelGGL(k_cls_fwd_bwd, dim3(B), dim3(128), (size_t)(d + C) * sizeof(float), st, P, Wc,
+                     bc, labels, B, d, C, grad_scale, logits, dlogits, dP, lossv, corrv);
+  PCA_TRY(check_launch("k_cls_fwd_bwd"));
+  hipLaunchKernelGGL(k_cls_wgrad, dim3(C), dim3(128), 0, st, dlogits, P, lossv, corrv, B, d, C,
+                     dWc, dbc, loss_out, stats);
+  return check_launch("k_cls_wgrad");
+}
 
 }  // namespace pca
 
