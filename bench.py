@@ -124,7 +124,9 @@ def main():
     ap.add_argument("--warmup", type=int, default=20)
     ap.add_argument("--config", default="cfg2", choices=sorted(CONFIGS))
     ap.add_argument("--batch", type=int, default=0, help="sets per GPU per step (0 = config)")
-    ap.add_argument("--mode", default="f32", choices=["f32", "bf16"])
+    ap.add_argument("--mode", default="bf16", choices=["f32", "bf16"],
+                    help="bf16 = fused MFMA kernels (bf16 operands, fp32 accumulate); f32 = exact "
+                         "parity path")
     ap.add_argument("--clips", type=int, default=48, help="synthetic clips in the corpus")
     ap.add_argument("--no-graph", action="store_true")
     ap.add_argument("--no-cpu-baseline", action="store_true")
@@ -139,7 +141,7 @@ def main():
     dev = torch.device("cuda", local_rank)
     if world > 1:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        dist.init_process_group("nccl", device_id=dev)
+        dist.init_process_group(os.environ.get("PCA_DIST_BACKEND", "nccl"), device_id=dev)
 
     import models
     import pca_hip
@@ -201,9 +203,12 @@ def main():
     if not args.no_roofline:
         kid = _lib.K_GEMM_F32 if args.mode == "f32" else _lib.K_MAB1_BWD
         ksteps = min(args.steps, 20)
-        # eager (un-captured) steps of the same workload so the events bracket real launches
+        # un-captured steps of the same workload so that the events bracket real launches
         tr_use_graph = tr.use_graph
         tr.use_graph = False
+        for _ in range(3):
+            tr.step()
+        torch.cuda.synchronize(dev)
         _lib.check(L.pca_prof_start(kid, 4096 * ksteps), "prof_start")
         for _ in range(ksteps):
             tr.step()
@@ -215,14 +220,24 @@ def main():
         if n.value > 0 and ms.value > 0:
             tflops = fl.value / (ms.value * 1e-3) / 1e12
             peak = FP32_VALU_PEAK_TFLOPS if args.mode == "f32" else MFMA_BF16_PEAK_TFLOPS
+            traffic = None
+            tpath = os.path.join(ROOT, "profiles", "r01_hbm_traffic.json")
+            if args.mode == "bf16" and args.config == "cfg2" and os.path.exists(tpath):
+                traffic = json.load(open(tpath)).get("k_mab1_bwd_bytes_per_launch")
             out["roofline"] = {
-                "kernel": "k_gemm_f32" if args.mode == "f32" else "k_mab1_bwd_bf16",
+                "kernel": "k_gemm_f32" if args.mode == "f32" else "k_mab1_bwd (fused ISAB mab1 "
+                          "backward chain, both layers)",
                 "bound": "mfma", "achieved": round(tflops, 3), "peak": peak,
-                "unit": "TFLOP/s", "frac": round(tflops / peak, 5), "traffic": None,
+                "unit": "TFLOP/s", "frac": round(tflops / peak, 5), "traffic": traffic,
                 "launches": int(n.value), "avg_us": round(ms.value * 1e3 / n.value, 3),
+                "alg_flops_per_launch": round(fl.value / n.value),
+                "alg_bytes_per_launch": round(by.value / n.value),
                 "note": ("exact-fp32 parity path: strided VALU GEMMs, priced against the fp32 "
                          "vector/matrix peak (157.3 TFLOP/s)" if args.mode == "f32" else
-                         "fused bf16 MFMA kernel, reference-formulation FLOPs"),
+                         "reference-formulation FLOPs 4*M*(dq*d + d^2 + 2*m*d) per launch "
+                         "(SURVEY 8d, backward = 2x forward); traffic = HBM bytes per launch from "
+                         "rocprofv3 PMC (profiles/r01_hbm_traffic.json), FETCH_SIZE doubled per "
+                         "MI355X_MICROARCH.md"),
             }
         fwd = st_fwd_macs(N, cfg["din"], cfg["d"], cfg["m"], 1, cfg["C"]) * 2
         out["model_tflops_ref_formulation"] = round(

@@ -65,6 +65,54 @@ def flatten_parameters(model) -> torch.Tensor:
     return flat
 
 
+class ShardedIndexStream:
+    """Per-rank stream of set indices with DistributedSampler semantics: one
+    seeded permutation per epoch, shared by all ranks; rank r takes elements r::world of it
+    (the tail that does not divide evenly is dropped so that every rank runs the same number
+    of steps).  Pure index logic: works on any device, tested on CPU with gloo."""
+
+    def __init__(self, n: int, batch: int, rank: int = 0, world: int = 1, seed: int = 0,
+                 shuffle: bool = True, device="cpu"):
+        self.n, self.B, self.rank, self.world = int(n), int(batch), rank, world
+        self.seed, self.shuffle, self.device = seed, shuffle, device
+        self.epoch = 0
+        self._perm = None
+        self._cursor = 0
+        if self.n // self.world < self.B:
+            raise ValueError(f"dataset of {n} sets is too small for batch {batch} x {world} ranks")
+
+    def per_rank(self) -> int:
+        return self.n // self.world
+
+    def next(self) -> torch.Tensor:
+        per = self.per_rank()
+        if self._perm is None or self._cursor + self.B > per:
+            if self.shuffle:
+                g = torch.Generator(device="cpu").manual_seed(self.seed + self.epoch)
+                perm = torch.randperm(self.n, generator=g)
+            else:
+                perm = torch.arange(self.n)
+            self._perm = perm[self.rank:per * self.world:self.world].contiguous().to(self.device)
+            self._cursor = 0
+            self.epoch += 1
+        out = self._perm[self._cursor:self._cursor + self.B]
+        self._cursor += self.B
+        return out
+
+
+def allreduce_buckets(grads: torch.Tensor, split: int, group=None, first_stream=None):
+    """Sum the flat gradient vector over the ranks in the two buckets of SURVEY.md 8e:
+    [split, end) (enc.1 + dec, complete after backward phase 0) and [0, split) (enc.0).
+    With ``first_stream`` the first bucket is reduced on that (side) stream so that it overlaps
+    the remaining backward; the caller joins the streams before the optimiser."""
+    if first_stream is not None:
+        with torch.cuda.stream(first_stream):
+            dist.all_reduce(grads[split:], group=group)
+    else:
+        dist.all_reduce(grads[split:], group=group)
+    return lambda: dist.all_reduce(grads[:split], group=group)
+
+
 class STEngine:
     """Forward / train-step of an ``models.ST`` through the pca_st_* entry points."""
 
@@ -147,27 +195,14 @@ class Trainer:
             self.labels = torch.zeros(self.B, dtype=torch.int64, device=self.dev)
             self.comm_stream = torch.cuda.Stream(self.dev) if self.world > 1 else None
         self.g0 = self.g1 = self.g2 = None
-        self.epoch = 0
-        self._perm = None
-        self._cursor = 0
+        self.indices = ShardedIndexStream(len(dataset), self.B, self.rank, self.world, seed,
+                                          shuffle, self.dev)
         if self.world > 1:      # identical initial weights on every rank (rank 0's)
             dist.broadcast(self.eng.flat, src=0, group=self.pg)
 
     # ---- index stream ------------------------------------------------------------
     def _next_indices(self) -> torch.Tensor:
-        per = len(self.ds) // self.world
-        if self._perm is None or self._cursor + self.B > per:
-            if self.shuffle:
-                g = torch.Generator(device="cpu").manual_seed(self.seed + self.epoch)
-                perm = torch.randperm(len(self.ds), generator=g).to(self.dev)
-            else:
-                perm = torch.arange(len(self.ds), device=self.dev)
-            self._perm = perm[self.rank:per * self.world:self.world].contiguous()
-            self._cursor = 0
-            self.epoch += 1
-        out = self._perm[self._cursor:self._cursor + self.B]
-        self._cursor += self.B
-        return out
+        return self.indices.next()
 
     # ---- the three device segments of a step ---------------------------------------
     def _seg0(self):     # pack + zero grads + forward + loss + backward(dec, enc.1)
@@ -230,10 +265,9 @@ class Trainer:
         self.g0.replay() if self.use_graph else self._seg0()
         # bucket A (enc.1 + dec) is final: reduce it while enc.0's backward runs
         self.comm_stream.wait_stream(main)
-        with torch.cuda.stream(self.comm_stream):
-            dist.all_reduce(e.grads[e.split:], group=self.pg)
+        second = allreduce_buckets(e.grads, e.split, self.pg, self.comm_stream)
         self.g1.replay() if self.use_graph else self._seg1()
-        dist.all_reduce(e.grads[:e.split], group=self.pg)
+        second()
         main.wait_stream(self.comm_stream)
         self.g2.replay() if self.use_graph else self._seg2()
 

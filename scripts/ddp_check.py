@@ -1,0 +1,48 @@
+"""Launched by tests/test_gpu_ddp.py under torch.distributed.run with 2 ranks on ONE GPU
+(backend gloo): the multi-rank step (phase-0 graph, bucket-A all-reduce on the side stream,
+phase-1 graph, bucket-B all-reduce, Adam) must reproduce a single-rank run on the union batch."""
+import os, sys
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path[:0] = [ROOT, os.path.join(ROOT, "point-cloud-audio_amd")]
+import numpy as np, torch, torch.distributed as dist
+import dataset, models
+from pca_hip import _lib, trainer
+
+mode = _lib.MODE_BF16 if os.environ.get("PCA_MODE", "f32") == "bf16" else _lib.MODE_F32
+use_graph = os.environ.get("PCA_GRAPH", "1") == "1"
+rank, world = int(os.environ["RANK"]), int(os.environ["WORLD_SIZE"])
+dev = torch.device("cuda", 0)
+torch.cuda.set_device(0)
+dist.init_process_group("gloo")
+rng = np.random.Generator(np.random.PCG64(5))
+F, T, C, B = 256, 640, 10, 32
+x = rng.normal(-9, 3, size=(F, T)).astype(np.float32)
+y = rng.integers(0, C, size=(T,))
+farr = np.linspace(0, 0.5, F)
+
+def run(world_sim, rank_sim, batch, pg):
+    torch.manual_seed(3)
+    net = models.ST(dim_input=2, dim_output=C, num_inds=16, dim_hidden=128, num_heads=4).to(dev)
+    ds = dataset.ESC_pc(x, y, farr, device=dev)
+    tr = trainer.Trainer(net, ds, batch, mode=mode, use_graph=use_graph, seed=11, shuffle=True,
+                         process_group=pg)
+    if pg is None:                      # force a single-rank trainer inside the 2-rank job
+        tr.world, tr.rank = 1, 0
+        tr.indices = trainer.ShardedIndexStream(len(ds), batch, 0, 1, 11, True, dev)
+        tr.comm_stream = None
+    for _ in range(4):
+        tr.step()
+    torch.cuda.synchronize()
+    return tr.eng.flat.detach().cpu().clone(), tr.read_stats() if pg is not None else None
+
+flat2, stats2 = run(world, rank, B, dist.group.WORLD)
+dist.barrier()
+# every rank holds identical parameters after the steps
+gathered = [torch.zeros_like(flat2) for _ in range(world)]
+dist.all_gather(gathered, flat2)
+same = all(torch.equal(gathered[0], g) for g in gathered)
+if rank == 0:
+    print("RANKS_IDENTICAL", same)
+    print("FLAT_NORM", float(flat2.norm()))
+    torch.save(flat2, os.environ["PCA_OUT"])
+dist.destroy_process_group()
