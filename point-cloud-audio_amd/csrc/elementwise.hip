@@ -2,6 +2,7 @@
 // the exact fp32 MAB path, plus the library's error-string plumbing.
 #include "pca_common.h"
 
+#include <stdlib.h>
 #include <string.h>
 
 #include <mutex>
@@ -48,6 +49,56 @@ void ProfScope::end() {
   if (slot < 0) return;
   (void)hipEventRecord(g_prof.ev[2 * slot + 1], st);
   slot = -1;
+}
+
+// ---- helper stream (see pca_common.h) ------------------------------------------------
+namespace {
+struct SideCtx {
+  bool enabled = false;
+  bool forked = false;
+  hipStream_t side = nullptr;
+  hipEvent_t ev[32] = {};
+  int k = 0;
+  bool init() {          // everything is created on first use (an eager call), never mid-capture
+    if (side != nullptr) return true;
+    if (hipStreamCreateWithFlags(&side, hipStreamNonBlocking) != hipSuccess) return false;
+    for (auto& e : ev)
+      if (hipEventCreateWithFlags(&e, hipEventDisableTiming) != hipSuccess) return false;
+    return true;
+  }
+  hipEvent_t next() {
+    hipEvent_t e = ev[k];
+    k = (k + 1) % 32;
+    return e;
+  }
+};
+thread_local SideCtx g_side;
+}  // namespace
+
+void terminal_enable(bool on) {
+  static const bool allowed = [] {
+    const char* e = getenv("PCA_SIDE_STREAM");
+    return e != nullptr && e[0] == '1';       // opt-in: measured slower on MI355X
+  }();
+  g_side.enabled = on && allowed;
+}
+
+hipStream_t terminal_stream(hipStream_t main) {
+  if (!g_side.enabled) return main;
+  if (!g_side.init()) return main;
+  hipEvent_t e = g_side.next();
+  if (hipEventRecord(e, main) != hipSuccess || hipStreamWaitEvent(g_side.side, e, 0) != hipSuccess)
+    return main;
+  g_side.forked = true;
+  return g_side.side;
+}
+
+void terminal_join(hipStream_t main) {
+  if (!g_side.forked) return;
+  hipEvent_t e = g_side.next();
+  (void)hipEventRecord(e, g_side.side);
+  (void)hipStreamWaitEvent(main, e, 0);
+  g_side.forked = false;
 }
 
 namespace {

@@ -558,17 +558,19 @@ int mab0_bf16_bwd_ex(const pca_mab_shape& s, const float* I, const float* X,
         jobs.j[jobs.n++] = WgradJob{w.dO, w.Th + (int64_t)j * Bm * dk, gr.wv,
                                     j == 0 ? gr.bv : nullptr, Bm, j * dh, (j + 1) * dh};
     }
-    PCA_TRY(wgrad128_launch(jobs, false, false, 64, st));
+    hipStream_t ts = terminal_stream(st);
+    PCA_TRY(wgrad128_launch(jobs, false, false, 64, ts));
     if (small)
-      PCA_TRY(wgrad_small_f32_launch(w.dO, w.Th, Bm, dk, (int64_t)Bm * dk, gr.wv, gr.bv, st));
+      PCA_TRY(wgrad_small_f32_launch(w.dO, w.Th, Bm, dk, (int64_t)Bm * dk, gr.wv, gr.bv, ts));
   }
   if (!head_done) PCA_TRY(colsum(w.dO, s.B, m * d, w.dQs, 0, st));   // sum over sets
-  hipLaunchKernelGGL(k_mab0_post1, dim3((unsigned)cdiv(d * dk + m * d, 256)), dim3(256), 0, st,
+  hipStream_t ts = terminal_stream(st);     // dWk, dWq, dbq, dI: off the critical path
+  hipLaunchKernelGGL(k_mab0_post1, dim3((unsigned)cdiv(d * dk + m * d, 256)), dim3(256), 0, ts,
                      w.dQs, w.DG, v.Qp, p.wk, m, d, dk, h, sl2e, gr.wk, w.dQp);
   PCA_TRY(check_launch("k_mab0_post1"));
   hipLaunchKernelGGL(k_mab0_post2,
                      dim3((unsigned)cdiv(d * s.dq + d + (dI ? m * s.dq : 0), 256)), dim3(256), 0,
-                     st, w.dQp, I, p.wq, m, d, s.dq, gr.wq, gr.bq, dI);
+                     ts, w.dQp, I, p.wq, m, d, s.dq, gr.wq, gr.bq, dI);
   return check_launch("k_mab0_post2");
 }
 

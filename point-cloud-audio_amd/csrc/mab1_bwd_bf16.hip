@@ -467,12 +467,15 @@ __global__ __launch_bounds__(256) void k_wgrad128(const WgradJobs jobs, int rows
   const int64_t r0 = (int64_t)blockIdx.x * rows_per_wg;
   if (r0 >= M) return;
   const int64_t r1 = (r0 + rows_per_wg < M) ? r0 + rows_per_wg : M;
-  f32x4 acc[2][8];
+  // wave w owns the 64 x 64 output block (G features 64*(w>>1).., A features 64*(w&1)..):
+  // 4 + 4 transposed fragments feed 16 MFMAs per 32-row tile
+  const int gt0 = 4 * (wave >> 1), at0 = 4 * (wave & 1);
+  f32x4 acc[4][4];
 #pragma unroll
-  for (int i = 0; i < 2; ++i)
+  for (int i = 0; i < 4; ++i)
 #pragma unroll
-    for (int t = 0; t < 8; ++t) acc[i][t] = f32x4{0.f, 0.f, 0.f, 0.f};
-  float bsum = 0.f;
+    for (int t = 0; t < 4; ++t) acc[i][t] = f32x4{0.f, 0.f, 0.f, 0.f};
+  float bs[8] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};   // column sums of G, columns 8*(tid&15)..
 
   bf16x8 vg[2], va[2];
   auto fetch = [&](int64_t base) {
@@ -498,35 +501,46 @@ __global__ __launch_bounds__(256) void k_wgrad128(const WgradJobs jobs, int rows
       const int row = c >> 4, ch = c & 15;
       *reinterpret_cast<bf16x8*>(sG[buf] + tr_off(row, ch)) = vg[e];
       *reinterpret_cast<bf16x8*>(sA[buf] + tr_off(row, ch)) = va[e];
+      if (job.db != nullptr) {
+#pragma unroll
+        for (int k = 0; k < 8; ++k) bs[k] += (float)vg[e][k];
+      }
     }
     __syncthreads();
     if (base + 32 < r1) fetch(base + 32);
-    if (job.db != nullptr && tid < D) {
-#pragma unroll 8
-      for (int row = 0; row < 32; ++row)
-        bsum += (float)*reinterpret_cast<const __bf16*>(sG[buf] + tr_off(row, tid >> 3) +
-                                                        (tid & 7) * 2);
-    }
-    bf16x8 ga[2];
+    bf16x8 ga[4];
 #pragma unroll
-    for (int i = 0; i < 2; ++i) ga[i] = tr_frag(sG[buf], 2 * wave + i, lane);
+    for (int i = 0; i < 4; ++i) ga[i] = tr_frag(sG[buf], gt0 + i, lane);
 #pragma unroll
-    for (int t = 0; t < 8; ++t) {
-      const bf16x8 ab = tr_frag(sA[buf], t, lane);
+    for (int t = 0; t < 4; ++t) {
+      const bf16x8 ab = tr_frag(sA[buf], at0 + t, lane);
 #pragma unroll
-      for (int i = 0; i < 2; ++i) acc[i][t] = mfma32(ga[i], ab, acc[i][t]);
+      for (int i = 0; i < 4; ++i) acc[i][t] = mfma32(ga[i], ab, acc[i][t]);
     }
   }
 #pragma unroll
-  for (int i = 0; i < 2; ++i)
+  for (int i = 0; i < 4; ++i)
 #pragma unroll
     for (int e = 0; e < 4; ++e) {
-      const int grow = 16 * (2 * wave + i) + 4 * g + e;
+      const int grow = 16 * (gt0 + i) + 4 * g + e;
       if (grow < job.g_lo || grow >= job.g_hi) continue;
 #pragma unroll
-      for (int t = 0; t < 8; ++t) atomicAdd(&job.dW[grow * D + 16 * t + r], acc[i][t][e]);
+      for (int t = 0; t < 4; ++t) atomicAdd(&job.dW[grow * D + 16 * (at0 + t) + r], acc[i][t][e]);
     }
-  if (job.db != nullptr && tid < D) atomicAdd(&job.db[tid], bsum);
+  if (job.db != nullptr) {
+    // threads with equal (tid & 15) hold partial sums of the same 8 columns
+    __syncthreads();
+    float* red = reinterpret_cast<float*>(sG[0]);       // [16 groups][128 columns]
+#pragma unroll
+    for (int k = 0; k < 8; ++k) red[(tid >> 4) * D + (tid & 15) * 8 + k] = bs[k];
+    __syncthreads();
+    if (tid < D) {
+      float t = 0.f;
+#pragma unroll
+      for (int q = 0; q < 16; ++q) t += red[q * D + tid];
+      atomicAdd(&job.db[tid], t);
+    }
+  }
 }
 
 // dH[q][c] (+)= sum_f dKp[q][f] Wk[f][c] + dVp[q][f] Wv[f][c]; thread = (column c, query half)
@@ -829,8 +843,9 @@ int mab1_bf16_bwd_ex(const pca_mab_shape& s, const float* X, const float* H,
     WgradJobs jobs{};
     jobs.j[0] = WgradJob{w.dZ, v.OS, gr.wo, gr.bo, M, 0, 128};
     jobs.n = 1;
-    ProfScope ps(PCA_K_WGRAD, st, 2.0 * M * d * d, 4.0 * M * d);
-    PCA_TRY(wgrad128_launch(jobs, true, true, rows_per_wg, st));
+    hipStream_t ts = terminal_stream(st);
+    ProfScope ps(PCA_K_WGRAD, ts, 2.0 * M * d * d, 4.0 * M * d);
+    PCA_TRY(wgrad128_launch(jobs, true, true, rows_per_wg, ts));
     ps.end();
   }
   if (small && fuse && s.dq <= 3) {
@@ -843,8 +858,9 @@ int mab1_bf16_bwd_ex(const pca_mab_shape& s, const float* X, const float* H,
     WgradJobs jobs{};
     jobs.j[0] = WgradJob{w.dQp, X, gr.wq, gr.bq, M, 0, 128};
     jobs.n = 1;
-    ProfScope ps(PCA_K_WGRAD, st, 2.0 * M * d * d, 6.0 * M * d);
-    PCA_TRY(wgrad128_launch(jobs, true, false, rows_per_wg, st));
+    hipStream_t ts = terminal_stream(st);
+    ProfScope ps(PCA_K_WGRAD, ts, 2.0 * M * d * d, 6.0 * M * d);
+    PCA_TRY(wgrad128_launch(jobs, true, false, rows_per_wg, ts));
     ps.end();
   }
   if (!fuse) {

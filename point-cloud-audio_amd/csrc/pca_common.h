@@ -63,6 +63,17 @@ struct ProfScope {
   void end();
 };
 
+// ---- helper stream for work that is off the critical path ------------------------------
+// While enabled (by the ST engine, per calling thread), launch sites of terminal gradient
+// reductions call terminal_stream(main): it makes the helper stream wait for everything
+// enqueued on `main` so far (event fork) and returns the helper stream, so the reduction
+// overlaps whatever `main` does next.  terminal_join(main) makes `main` wait for the helper
+// stream.  Both are plain event record / wait operations, so a stream capture of `main`
+// captures the fork and the join as graph edges.  Disabled: returns `main` itself.
+void terminal_enable(bool on);
+hipStream_t terminal_stream(hipStream_t main);
+void terminal_join(hipStream_t main);
+
 // ---- internal launchers used across translation units -------------------
 int gemm_f32(const pca_gemm_desc& g, const float* A, const float* B, const float* bias,
              float* C, hipStream_t st);

@@ -131,7 +131,9 @@ struct Ws {
   void* saved[5];            // mab0[0], mab1[0], mab0[1], mab1[1], pma
   float *H[2], *Y[2], *P, *logits, *dlogits;
   float *dP, *dY2, *dY1, *dH, *clsws;
-  void* scratch;
+  void* scratch;             // forward + PMA backward
+  void* scratch_bw[2];       // backward of enc.0 / enc.1: separate, because their terminal
+                             // reductions run on the helper stream while the main stream moves on
   IsabImg img[2];            // weight images of the two ISABs (fused bf16 path)
   bool fused[2];
 };
@@ -177,7 +179,9 @@ inline size_t carve(const pca_st_config& c, int training, Ws* out, void* base) {
     w.dH = cv.take<float>(Bm * c.d);
     w.clsws = cv.take<float>(2 * (size_t)c.B);
   }
-  w.scratch = cv.take<char>(max_scratch);   // per-call scratch, reused by every block
+  w.scratch = cv.take<char>(max_scratch);
+  for (int li = 0; li < 2; ++li)
+    w.scratch_bw[li] = training ? (void*)cv.take<char>(max_scratch) : w.scratch;
   if (out) *out = w;
   return cv.off;
 }
@@ -298,6 +302,13 @@ int pca_st_train_fwd_bwd(const pca_st_config* c, const float* params, const floa
   const float* p = params;
   float* g = grads;
   if (logits != nullptr) w.logits = logits;
+  // terminal gradient reductions overlap the critical path on the helper stream; the guard
+  // joins it back into `st` on every exit path
+  struct SideGuard {
+    hipStream_t st;
+    explicit SideGuard(hipStream_t s) : st(s) { pca::terminal_enable(true); }
+    ~SideGuard() { pca::terminal_join(st); pca::terminal_enable(false); }
+  } side_guard(st);
 
   if (phase != 1) {
     PCA_TRY(pca::forward(*c, L, s, p, X, w, true, st));
@@ -315,14 +326,14 @@ int pca_st_train_fwd_bwd(const pca_st_config* c, const float* params, const floa
                                  pca::params_at(p, L.mab0[1]), pca::params_at(p, L.mab1[1]),
                                  w.saved[2], w.saved[3], w.dY2, g + L.I[1], w.dY1,
                                  pca::grads_at(g, L.mab0[1]), pca::grads_at(g, L.mab1[1]),
-                                 w.scratch, w.img[1], st));
+                                 w.scratch_bw[1], w.img[1], st));
     } else {
     PCA_TRY(pca::mab_bwd_any(s.m1[1], w.Y[0], w.H[1], pca::params_at(p, L.mab1[1]),
                              w.saved[3], w.dY2, w.dY1, w.dH, 0, pca::grads_at(g, L.mab1[1]),
-                             w.scratch, st));
+                             w.scratch_bw[1], st));
     PCA_TRY(pca::mab_bwd_any(s.m0[1], p + L.I[1], w.Y[0], pca::params_at(p, L.mab0[1]),
                              w.saved[2], w.dH, g + L.I[1], w.dY1, 1,
-                             pca::grads_at(g, L.mab0[1]), w.scratch, st));
+                             pca::grads_at(g, L.mab0[1]), w.scratch_bw[1], st));
     }
   }
   if (phase != 0) {
@@ -332,15 +343,15 @@ int pca_st_train_fwd_bwd(const pca_st_config* c, const float* params, const floa
                                  pca::params_at(p, L.mab0[0]), pca::params_at(p, L.mab1[0]),
                                  w.saved[0], w.saved[1], w.dY1, g + L.I[0], nullptr,
                                  pca::grads_at(g, L.mab0[0]), pca::grads_at(g, L.mab1[0]),
-                                 w.scratch, w.img[0], st));
-      return PCA_OK;
-    }
+                                 w.scratch_bw[0], w.img[0], st));
+    } else {
     PCA_TRY(pca::mab_bwd_any(s.m1[0], X, w.H[0], pca::params_at(p, L.mab1[0]), w.saved[1],
                              w.dY1, nullptr, w.dH, 0, pca::grads_at(g, L.mab1[0]),
-                             w.scratch, st));
+                             w.scratch_bw[0], st));
     PCA_TRY(pca::mab_bwd_any(s.m0[0], p + L.I[0], X, pca::params_at(p, L.mab0[0]),
                              w.saved[0], w.dH, g + L.I[0], nullptr, 0,
-                             pca::grads_at(g, L.mab0[0]), w.scratch, st));
+                             pca::grads_at(g, L.mab0[0]), w.scratch_bw[0], st));
+    }
   }
   return PCA_OK;
 }

@@ -214,8 +214,8 @@ int cls_train_head(const float* P, const float* Wc, const float* bc, const int64
   hipLaunchKernelGGL(k_cls_fwd_bwd, dim3(B), dim3(128), (size_t)(d + C) * sizeof(float), st, P, Wc,
                      bc, labels, B, d, C, grad_scale, logits, dlogits, dP, lossv, corrv);
   PCA_TRY(check_launch("k_cls_fwd_bwd"));
-  hipLaunchKernelGGL(k_cls_wgrad, dim3(C), dim3(128), 0, st, dlogits, P, lossv, corrv, B, d, C,
-                     dWc, dbc, loss_out, stats);
+  hipLaunchKernelGGL(k_cls_wgrad, dim3(C), dim3(128), 0, terminal_stream(st), dlogits, P, lossv,
+                     corrv, B, d, C, dWc, dbc, loss_out, stats);
   return check_launch("k_cls_wgrad");
 }
 

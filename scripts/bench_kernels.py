@@ -1,30 +1,28 @@
-"""Micro-benchmark of single MAB entry points with the library's HIP-event hook."""
+"""Micro-benchmark of the fused engine at several sizes (HIP-event hook per kernel class)."""
 import ctypes as C, os, sys
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path[:0] = [ROOT, os.path.join(ROOT, "point-cloud-audio_amd")]
 import torch
-import modules, pca_hip
-from pca_hip import _lib
+import models, pca_hip
+from pca_hip import _lib, trainer
 L = pca_hip.lib()
 dev = torch.device("cuda", 0)
-
-def prof(kid, fn, iters=20):
-    for _ in range(3): fn()
+KN = {_lib.K_MAB1_FWD: "mab1_fwd", _lib.K_MAB1_BWD: "mab1_bwd", _lib.K_MAB0_FWD: "mab0_attn",
+      _lib.K_MAB0_BWD: "mab0_bwd", _lib.K_WGRAD: "wgrad128"}
+for (B, N) in [(128, 512), (512, 512), (128, 2048), (512, 2048)]:
+    torch.manual_seed(0)
+    net = models.ST(dim_input=2, dim_output=50, num_inds=16, dim_hidden=128, num_heads=4).to(dev)
+    eng = trainer.STEngine(net, B, N, mode=_lib.MODE_BF16, training=True)
+    X = torch.randn(B, N, 2, device=dev); y = torch.randint(0, 50, (B,), device=dev)
+    for _ in range(3): eng.grads.zero_(); eng.fwd_bwd(X, y)
     torch.cuda.synchronize()
-    _lib.check(L.pca_prof_start(kid, 100000))
-    for _ in range(iters): fn()
-    torch.cuda.synchronize()
-    ms, n, fl, by = C.c_double(), C.c_int64(), C.c_double(), C.c_double()
-    _lib.check(L.pca_prof_stop(C.byref(ms), C.byref(n), C.byref(fl), C.byref(by)))
-    us = ms.value * 1e3 / max(n.value, 1)
-    return us, fl.value / max(ms.value, 1e-9) / 1e9, by.value / max(ms.value, 1e-9) / 1e6, n.value
-
-for (B, N, m, dq, d, h) in [(128, 512, 16, 128, 128, 4), (128, 512, 16, 2, 128, 4), (32, 2048, 16, 128, 128, 4),
-                            (128, 2048, 16, 128, 128, 4), (512, 512, 16, 128, 128, 4)]:
-    mab = modules.MAB(dq, d, d, h).to(dev)
-    X = torch.randn(B, N, dq, device=dev); H = torch.randn(B, m, d, device=dev)
-    pca_hip.set_mode("bf16")
-    with torch.no_grad():
-        us, tf, gbs, n = prof(_lib.K_MAB1_FWD, lambda: mab(X, H))
-    print(f"mab1_fwd bf16 B={B} N={N} m={m} dq={dq} d={d}: {us:8.2f} us  {tf:8.1f} TFLOP/s  {gbs:7.1f} GB/s (alg)  launches {n}")
-    pca_hip.set_mode("f32")
+    line = f"B={B:4d} N={N:5d}: "
+    for kid, nm in KN.items():
+        _lib.check(L.pca_prof_start(kid, 10000))
+        for _ in range(10): eng.grads.zero_(); eng.fwd_bwd(X, y)
+        torch.cuda.synchronize()
+        ms, n, fl, by = C.c_double(), C.c_int64(), C.c_double(), C.c_double()
+        _lib.check(L.pca_prof_stop(C.byref(ms), C.byref(n), C.byref(fl), C.byref(by)))
+        if n.value:
+            line += f"{nm} {ms.value*1e3/n.value:7.1f}us {fl.value/ms.value/1e9:6.0f}TF | "
+    print(line)
