@@ -1,47 +1,16 @@
 // extern "C" entry points for the multihead attention block: argument validation and
 // dispatch on the arithmetic mode.  (set_transformer-master/modules.py:19-33)
-#include "pca_common.h"
+#include "mab1_bf16.hpp"
 
 namespace pca {
-int validate_shape(const pca_mab_shape* s);
-size_t mab_f32_saved_bytes(const pca_mab_shape& s);
-size_t mab_f32_bwd_ws_bytes(const pca_mab_shape& s);
-int mab_f32_fwd(const pca_mab_shape& s, const float* Q, const float* K,
-                const pca_mab_params& p, float* Y, void* saved, hipStream_t st);
-int mab_f32_bwd(const pca_mab_shape& s, const float* Q, const float* K,
-                const pca_mab_params& p, const void* saved, const float* dY, float* dQ,
-                float* dK, int dk_accumulate, const pca_mab_grads& g, void* ws,
-                hipStream_t st);
-int linear_fwd_f32(const float* X, const float* W, const float* b, float* Y, int64_t M,
-                   int din, int dout, hipStream_t st);
-int linear_bwd_f32(const float* X, const float* W, const float* dY, float* dX, float* dW,
-                   float* db, int64_t M, int din, int dout, hipStream_t st);
 
-bool mab1_bf16_supported(const pca_mab_shape& s);
-size_t mab1_bf16_saved_bytes(const pca_mab_shape& s);
-size_t mab1_bf16_fwd_ws_bytes(const pca_mab_shape& s);
-int mab1_bf16_fwd(const pca_mab_shape& s, const float* X, const float* H,
-                  const pca_mab_params& p, float* Y, void* saved, void* ws, hipStream_t st);
 
-bool mab0_bf16_supported(const pca_mab_shape& s);
-size_t mab0_bf16_saved_bytes(const pca_mab_shape& s);
-size_t mab0_bf16_fwd_ws_bytes(const pca_mab_shape& s);
-int mab0_bf16_fwd(const pca_mab_shape& s, const float* I, const float* X,
-                  const pca_mab_params& p, float* H, void* saved, void* ws, hipStream_t st);
-size_t mab0_bf16_bwd_ws_bytes(const pca_mab_shape& s);
-int mab0_bf16_bwd(const pca_mab_shape& s, const float* I, const float* X,
-                  const pca_mab_params& p, const void* saved, const float* dH, float* dI,
-                  float* dX, int dk_accumulate, const pca_mab_grads& gr, void* ws,
-                  hipStream_t st);
-size_t mab1_bf16_bwd_ws_bytes(const pca_mab_shape& s);
-int mab1_bf16_bwd(const pca_mab_shape& s, const float* X, const float* H,
-                  const pca_mab_params& p, const void* saved, const float* dY, float* dX,
-                  float* dH, int dk_accumulate, const pca_mab_grads& gr, void* ws,
-                  hipStream_t st);
 
 static int check_f32(const pca_mab_shape* s) {
-  PCA_REQUIRE(s->q_dtype == PCA_F32 && s->k_dtype == PCA_F32 && s->y_dtype == PCA_F32,
-              "mab: this build exchanges fp32 Q, K and Y");
+  // the exact path exchanges fp32 only; the fused kernels validate their own dtypes
+  PCA_REQUIRE(mab_kind(*s) != 0 || (s->q_dtype == PCA_F32 && s->k_dtype == PCA_F32 &&
+                                    s->y_dtype == PCA_F32),
+              "mab: the exact fp32 path needs fp32 Q, K and Y");
   return PCA_OK;
 }
 
@@ -69,22 +38,25 @@ size_t mab_bwd_ws_bytes_any(const pca_mab_shape& s) {
   return k == 1 ? mab1_bf16_bwd_ws_bytes(s) : k == 2 ? mab0_bf16_bwd_ws_bytes(s)
                                                      : mab_f32_bwd_ws_bytes(s);
 }
-int mab_fwd_any(const pca_mab_shape& s, const float* Q, const float* K, const pca_mab_params& p,
-                float* Y, void* saved, void* ws, hipStream_t st) {
+int mab_fwd_any(const pca_mab_shape& s, const void* Q, const void* K, const pca_mab_params& p,
+                void* Y, void* saved, void* ws, hipStream_t st) {
   const int k = mab_kind(s);
-  if (k == 1) return mab1_bf16_fwd(s, Q, K, p, Y, saved, ws, st);
-  if (k == 2) return mab0_bf16_fwd(s, Q, K, p, Y, saved, ws, st);
-  return mab_f32_fwd(s, Q, K, p, Y, saved ? saved : ws, st);
+  if (k == 1) return mab1_bf16_fwd(s, Q, (const float*)K, p, Y, saved, ws, st);
+  if (k == 2) return mab0_bf16_fwd(s, (const float*)Q, K, p, (float*)Y, saved, ws, st);
+  return mab_f32_fwd(s, (const float*)Q, (const float*)K, p, (float*)Y, saved ? saved : ws, st);
 }
-int mab_bwd_any(const pca_mab_shape& s, const float* Q, const float* K, const pca_mab_params& p,
-                const void* saved, const float* dY, float* dQ, float* dK, int dk_accumulate,
+int mab_bwd_any(const pca_mab_shape& s, const void* Q, const void* K, const pca_mab_params& p,
+                const void* saved, const void* dY, void* dQ, void* dK, int dk_accumulate,
                 const pca_mab_grads& g, void* ws, hipStream_t st) {
   const int k = mab_kind(s);
   if (k == 2)
-    return mab0_bf16_bwd(s, Q, K, p, saved, dY, dQ, dK, dk_accumulate, g, ws, st);
+    return mab0_bf16_bwd(s, (const float*)Q, K, p, saved, (const float*)dY, (float*)dQ, dK,
+                         dk_accumulate, g, ws, st);
   if (k == 1)
-    return mab1_bf16_bwd(s, Q, K, p, saved, dY, dQ, dK, dk_accumulate, g, ws, st);
-  return mab_f32_bwd(s, Q, K, p, saved, dY, dQ, dK, dk_accumulate, g, ws, st);
+    return mab1_bf16_bwd(s, Q, (const float*)K, p, saved, dY, dQ, (float*)dK, dk_accumulate, g,
+                         ws, st);
+  return mab_f32_bwd(s, (const float*)Q, (const float*)K, p, saved, (const float*)dY,
+                     (float*)dQ, (float*)dK, dk_accumulate, g, ws, st);
 }
 }  // namespace pca
 
@@ -129,8 +101,7 @@ int pca_mab_fwd(const pca_mab_shape* s, const void* Q, const void* K,
   PCA_TRY(pca::check_f32(s));
   PCA_REQUIRE(ws != nullptr || (saved != nullptr && pca::mab_kind(*s) == 0),
               "mab_fwd: scratch block required");
-  return pca::mab_fwd_any(*s, (const float*)Q, (const float*)K, *p, (float*)Y, saved, ws,
-                          pca::as_stream(stream));
+  return pca::mab_fwd_any(*s, Q, K, *p, Y, saved, ws, pca::as_stream(stream));
 }
 
 int pca_mab_bwd(const pca_mab_shape* s, const void* Q, const void* K,
@@ -142,8 +113,7 @@ int pca_mab_bwd(const pca_mab_shape* s, const void* Q, const void* K,
               "mab_bwd: null gradient buffer");
   PCA_TRY(bf16_demand(s));
   PCA_TRY(pca::check_f32(s));
-  return pca::mab_bwd_any(*s, (const float*)Q, (const float*)K, *p, saved, (const float*)dY,
-                          (float*)dQ, (float*)dK, dk_accumulate, *g, ws,
+  return pca::mab_bwd_any(*s, Q, K, *p, saved, dY, dQ, dK, dk_accumulate, *g, ws,
                           pca::as_stream(stream));
 }
 

@@ -20,5 +20,5 @@ for src in "$HERE"/*.hip; do
   fi
 done
 for p in "${pids[@]:-}"; do [ -n "$p" ] && wait "$p"; done
-$HIPCC -shared -fPIC --offload-arch=gfx950 "${objs[@]}" -o "$OUT"
+$HIPCC -shared -fPIC --offload-arch=gfx950 -Wl,-z,defs "${objs[@]}" -o "$OUT"
 echo "built $OUT"

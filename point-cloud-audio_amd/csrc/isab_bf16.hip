@@ -6,23 +6,6 @@
 
 namespace pca {
 
-int mab_kind(const pca_mab_shape& s);
-size_t mab1_bf16_fwd_ws_bytes(const pca_mab_shape& s);
-int mab0_bf16_fwd_ex(const pca_mab_shape& s, const float* I, const float* X,
-                     const pca_mab_params& p, float* H, void* saved, void* ws, int flags,
-                     hipStream_t st);
-int mab1_bf16_fwd_ex(const pca_mab_shape& s, const float* X, const float* H,
-                     const pca_mab_params& p, float* Y, void* saved, void* ws, int flags,
-                     hipStream_t st, const IsabImg* img);
-int mab1_bf16_bwd_ex(const pca_mab_shape& s, const float* X, const float* H,
-                     const pca_mab_params& p, const void* saved, const float* dY, float* dX,
-                     float* dH, int dk_accumulate, const pca_mab_grads& gr, void* ws, int flags,
-                     hipStream_t st, const IsabImg* img, float* zero_ptr, int zero_n,
-                     int* nparts_out);
-int mab0_bf16_bwd_ex(const pca_mab_shape& s, const float* I, const float* X,
-                     const pca_mab_params& p, const void* saved, const float* dH, float* dI,
-                     float* dX, int dk_accumulate, const pca_mab_grads& gr, void* ws, int flags,
-                     hipStream_t st);
 
 // s0 = mab0(I, X) shape, s1 = mab1(X, H) shape of the same ISAB
 bool isab_bf16_supported(const pca_mab_shape& s0, const pca_mab_shape& s1) {
@@ -77,8 +60,8 @@ size_t isab_bf16_bwd_ws_bytes(const pca_mab_shape& s0, const pca_mab_shape& s1) 
 }
 
 int isab_bf16_fwd(const pca_mab_shape& s0, const pca_mab_shape& s1, const float* I,
-                  const float* X, const pca_mab_params& p0, const pca_mab_params& p1, float* H,
-                  float* Y, void* saved0, void* saved1, void* ws, const IsabImg& im,
+                  const void* X, const pca_mab_params& p0, const pca_mab_params& p1, float* H,
+                  void* Y, void* saved0, void* saved1, void* ws, const IsabImg& im,
                   hipStream_t st) {
   PCA_REQUIRE(saved0 && saved1 && ws, "isab_bf16_fwd: null block");
   const int dk = s0.dk;
@@ -103,9 +86,9 @@ int isab_bf16_fwd(const pca_mab_shape& s0, const pca_mab_shape& s1, const float*
 // dX: gradient w.r.t. the ISAB input (null for the first layer, whose input is the data);
 // written here (mab1's dQ) and then accumulated into (mab0's dK).  dI accumulated.
 int isab_bf16_bwd(const pca_mab_shape& s0, const pca_mab_shape& s1, const float* I,
-                  const float* X, const float* H, const pca_mab_params& p0,
+                  const void* X, const float* H, const pca_mab_params& p0,
                   const pca_mab_params& p1, const void* saved0, const void* saved1,
-                  const float* dY, float* dI, float* dX, const pca_mab_grads& g0,
+                  const void* dY, float* dI, void* dX, const pca_mab_grads& g0,
                   const pca_mab_grads& g1, void* ws, const IsabImg& im, hipStream_t st) {
   const int d = 128, dk = s0.dk, m = 16;
   Carver c(ws);

@@ -103,7 +103,7 @@ __global__ __launch_bounds__(256) void k_mab0_prep(const Mab0PrepJobs jobs) {
 // attention over the points, dk == 128
 // ---------------------------------------------------------------------------------
 struct Mab0AttnArgs {
-  const float* X;       // [B, N, 128] fp32
+  const void* X;        // [B, N, 128] fp32, or bf16 when ABF
   const __bf16* Gb;     // [16*RB][128]  (scale*log2e folded in; padding rows zero)
   float* Tp;            // [B][S][R][128] fp32 partial sums  sum_n 2^(s_n - M) x_n
   float* Mp;            // [B][S][R]      partial maxima M (log2 domain)
@@ -111,7 +111,7 @@ struct Mab0AttnArgs {
   int B, N, R, S;       // S = point splits per set (gridDim.y); merged by k_mab0_epi
 };
 
-template <int RB>
+template <int RB, bool ABF>
 __global__ __launch_bounds__(256, 1) void k_mab0_attn(const Mab0AttnArgs a) {
   constexpr int DK = 128, FT = DK / 16, KS = DK / 32;
   extern __shared__ __attribute__((aligned(16))) char smem[];
@@ -157,9 +157,12 @@ __global__ __launch_bounds__(256, 1) void k_mab0_attn(const Mab0AttnArgs a) {
       const int c = lane + 64 * e;
       const int row = c >> 4, ch = c & 15;
       bf16x8 v;
-      if (n0 + row < n_hi) {
+      if (n0 + row < n_hi && ABF) {
+        v = *reinterpret_cast<const bf16x8*>(reinterpret_cast<const __bf16*>(a.X) +
+                                             ((int64_t)b * a.N + n0 + row) * DK + ch * 8);
+      } else if (n0 + row < n_hi) {
         const float4* src = reinterpret_cast<const float4*>(
-            a.X + ((int64_t)b * a.N + n0 + row) * DK + ch * 8);
+            reinterpret_cast<const float*>(a.X) + ((int64_t)b * a.N + n0 + row) * DK + ch * 8);
         const float4 lo = src[0], hi = src[1];
         v[0] = (__bf16)lo.x; v[1] = (__bf16)lo.y; v[2] = (__bf16)lo.z; v[3] = (__bf16)lo.w;
         v[4] = (__bf16)hi.x; v[5] = (__bf16)hi.y; v[6] = (__bf16)hi.z; v[7] = (__bf16)hi.w;
@@ -413,10 +416,12 @@ __global__ __launch_bounds__(256) void k_mab0_epi(const float* __restrict__ Tp, 
 bool mab0_bf16_supported(const pca_mab_shape& s) {
   const int R = s.h * s.nq;
   if (!(s.nq == 16 || s.nq <= 2)) return false;      // epilogue: 8 or 1 queries per thread
+  // the keys X may be bf16 when they are a hidden tensor (dk == d)
+  const bool dt_ok = s.q_dtype == PCA_F32 && s.y_dtype == PCA_F32 &&
+                     (s.k_dtype == PCA_F32 || (s.k_dtype == PCA_BF16 && s.dk == s.d));
   return s.q_shared == 1 && s.d == 128 && s.h * 32 == s.d && s.dq == s.d &&
          ((s.dk == s.d && (R <= 16 || R == 64)) ||
-          (s.dk <= 4 && (R == 64 || R == 128 || R == 256))) &&
-         s.q_dtype == PCA_F32 && s.k_dtype == PCA_F32 && s.y_dtype == PCA_F32;
+          (s.dk <= 4 && (R == 64 || R == 128 || R == 256))) && dt_ok;
 }
 
 void mab0_collect_prep(const pca_mab_shape& s, const float* I, const pca_mab_params& p,
@@ -481,14 +486,11 @@ size_t mab0_bf16_fwd_ws_bytes(const pca_mab_shape& s) {
   return mab0_carve_saved(s, nullptr, nullptr);
 }
 
-int mab0_bf16_fwd_ex(const pca_mab_shape& s, const float* I, const float* X,
-                     const pca_mab_params& p, float* H, void* saved, void* ws, int flags,
-                     hipStream_t st);
-int mab0_bf16_fwd(const pca_mab_shape& s, const float* I, const float* X,
+int mab0_bf16_fwd(const pca_mab_shape& s, const float* I, const void* X,
                   const pca_mab_params& p, float* H, void* saved, void* ws, hipStream_t st) {
   return mab0_bf16_fwd_ex(s, I, X, p, H, saved, ws, 0, st);
 }
-int mab0_bf16_fwd_ex(const pca_mab_shape& s, const float* I, const float* X,
+int mab0_bf16_fwd_ex(const pca_mab_shape& s, const float* I, const void* X,
                      const pca_mab_params& p, float* H, void* saved, void* ws, int flags,
                      hipStream_t st) {
   PCA_REQUIRE(mab0_bf16_supported(s), "mab0_bf16_fwd: unsupported shape");
@@ -511,8 +513,8 @@ int mab0_bf16_fwd_ex(const pca_mab_shape& s, const float* I, const float* X,
 
   const double pts = (double)s.B * s.nk;
   if (small) {
-    hipLaunchKernelGGL(k_mab0_attn_small, dim3(s.B), dim3(256), 0, st, X, v.Gf, s.nk, R, dk, v.T,
-                       v.LSE);
+    hipLaunchKernelGGL(k_mab0_attn_small, dim3(s.B), dim3(256), 0, st,
+                       reinterpret_cast<const float*>(X), v.Gf, s.nk, R, dk, v.T, v.LSE);
     PCA_TRY(check_launch("k_mab0_attn_small"));
   } else {
     const int S = mab0_splits(s);
@@ -526,15 +528,18 @@ int mab0_bf16_fwd_ex(const pca_mab_shape& s, const float* I, const float* X,
                  pts * 4.0 * dk);
     static std::once_flag once;
     std::call_once(once, [] {
-      (void)hipFuncSetAttribute(reinterpret_cast<const void*>(k_mab0_attn<8>),
+      (void)hipFuncSetAttribute(reinterpret_cast<const void*>(k_mab0_attn<4, false>),
                                 hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
-      (void)hipFuncSetAttribute(reinterpret_cast<const void*>(k_mab0_attn<4>),
+      (void)hipFuncSetAttribute(reinterpret_cast<const void*>(k_mab0_attn<4, true>),
                                 hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
     });
     const dim3 grid(s.B, S);
-    if (RB == 1) hipLaunchKernelGGL((k_mab0_attn<1>), grid, dim3(256), lds, st, a);
-    else if (RB == 4) hipLaunchKernelGGL((k_mab0_attn<4>), grid, dim3(256), lds, st, a);
-    else hipLaunchKernelGGL((k_mab0_attn<8>), grid, dim3(256), lds, st, a);
+    const bool abf = s.k_dtype == PCA_BF16;
+    PCA_REQUIRE(RB == 1 || RB == 4, "mab0_bf16_fwd: %d score rows not built", Rpad);
+    if (RB == 1 && abf) hipLaunchKernelGGL((k_mab0_attn<1, true>), grid, dim3(256), lds, st, a);
+    else if (RB == 1) hipLaunchKernelGGL((k_mab0_attn<1, false>), grid, dim3(256), lds, st, a);
+    else if (abf) hipLaunchKernelGGL((k_mab0_attn<4, true>), grid, dim3(256), lds, st, a);
+    else hipLaunchKernelGGL((k_mab0_attn<4, false>), grid, dim3(256), lds, st, a);
     ps.end();
     PCA_TRY(check_launch("k_mab0_attn"));
   }

@@ -156,19 +156,19 @@ __global__ void k_mab0_gt(const float* __restrict__ Gf, int R, int Rp, int dk,
 // main backward over the points, dk == 128
 // ---------------------------------------------------------------------------------
 struct Mab0BwdArgs {
-  const float* X;        // [B, N, 128]
+  const void* X;         // [B, N, 128] fp32, or bf16 when ABF
   const __bf16* Gb;      // [Rp][128] natural rows (sl2e folded in)
   const __bf16* GtP;     // [128][Rp]
   const __bf16* dTb;     // [B][Rp][128]
   const __bf16* dTt;     // [B][128][Rp]
   const float* LSEp;     // [B][Rp]
   const float* Delta;    // [B][Rp]
-  float* dX;             // [B, N, 128] or null
+  void* dX;              // [B, N, 128] (fp32 / bf16 when ABF) or null
   float* DG;             // [Rp][128] fp32, accumulated over sets (ln2-scaled dS units)
   int B, N, accumulate_dx, S;
 };
 
-template <int RP>
+template <int RP, bool ABF>
 __global__ __launch_bounds__(256, 1) void k_mab0_bwd(const Mab0BwdArgs a) {
   constexpr int DK = 128, FT = DK / 16, KS = DK / 32, RB = RP / 16, RS = RP / 32;
   extern __shared__ __attribute__((aligned(16))) char smem[];
@@ -222,9 +222,12 @@ __global__ __launch_bounds__(256, 1) void k_mab0_bwd(const Mab0BwdArgs a) {
       const int c = lane + 64 * e;
       const int row = c >> 4, ch = c & 15;
       bf16x8 v;
-      if (n0 + row < n_hi) {
+      if (n0 + row < n_hi && ABF) {
+        v = *reinterpret_cast<const bf16x8*>(reinterpret_cast<const __bf16*>(a.X) +
+                                             ((int64_t)b * a.N + n0 + row) * DK + ch * 8);
+      } else if (n0 + row < n_hi) {
         const float4* src = reinterpret_cast<const float4*>(
-            a.X + ((int64_t)b * a.N + n0 + row) * DK + ch * 8);
+            reinterpret_cast<const float*>(a.X) + ((int64_t)b * a.N + n0 + row) * DK + ch * 8);
         const float4 lo = src[0], hi = src[1];
         v[0] = (__bf16)lo.x; v[1] = (__bf16)lo.y; v[2] = (__bf16)lo.z; v[3] = (__bf16)lo.w;
         v[4] = (__bf16)hi.x; v[5] = (__bf16)hi.y; v[6] = (__bf16)hi.z; v[7] = (__bf16)hi.w;
@@ -317,16 +320,28 @@ __global__ __launch_bounds__(256, 1) void k_mab0_bwd(const Mab0BwdArgs a) {
 #pragma unroll
       for (int pb = 0; pb < 2; ++pb)
         if (live[pb]) {
-          float* dst_row = a.dX + ((int64_t)b * a.N + n0 + 16 * pb + r) * DK;
+          const int64_t ro = ((int64_t)b * a.N + n0 + 16 * pb + r) * DK;
 #pragma unroll
           for (int ft = 0; ft < FT; ++ft) {
-            float4* pd = reinterpret_cast<float4*>(dst_row + 16 * ft + 4 * g);
-            float4 v = float4{dx[ft][pb][0], dx[ft][pb][1], dx[ft][pb][2], dx[ft][pb][3]};
-            if (a.accumulate_dx) {
-              const float4 o = *pd;
-              v.x += o.x; v.y += o.y; v.z += o.z; v.w += o.w;
+            f32x4 v = dx[ft][pb];
+            if (ABF) {
+              bf16x4* pd = reinterpret_cast<bf16x4*>(reinterpret_cast<__bf16*>(a.dX) + ro +
+                                                     16 * ft + 4 * g);
+              if (a.accumulate_dx) {
+                const bf16x4 o = *pd;
+                v[0] += (float)o[0]; v[1] += (float)o[1]; v[2] += (float)o[2]; v[3] += (float)o[3];
+              }
+              *pd = pack4(v);
+            } else {
+              float4* pd = reinterpret_cast<float4*>(reinterpret_cast<float*>(a.dX) + ro +
+                                                     16 * ft + 4 * g);
+              float4 o4 = float4{v[0], v[1], v[2], v[3]};
+              if (a.accumulate_dx) {
+                const float4 o = *pd;
+                o4.x += o.x; o4.y += o.y; o4.z += o.z; o4.w += o.w;
+              }
+              *pd = o4;
             }
-            *pd = v;
           }
         }
     }
@@ -479,19 +494,15 @@ size_t mab0_bf16_bwd_ws_bytes(const pca_mab_shape& s) {
 }
 
 // dQ -> dI [m, dq] (ACCUMULATED, may be null), dK -> dX [B, N, dk] (written or accumulated)
-int mab0_bf16_bwd_ex(const pca_mab_shape& s, const float* I, const float* X,
-                     const pca_mab_params& p, const void* saved, const float* dH, float* dI,
-                     float* dX, int dk_accumulate, const pca_mab_grads& gr, void* ws, int flags,
-                     hipStream_t st);
-int mab0_bf16_bwd(const pca_mab_shape& s, const float* I, const float* X,
+int mab0_bf16_bwd(const pca_mab_shape& s, const float* I, const void* X,
                   const pca_mab_params& p, const void* saved, const float* dH, float* dI,
-                  float* dX, int dk_accumulate, const pca_mab_grads& gr, void* ws,
+                  void* dX, int dk_accumulate, const pca_mab_grads& gr, void* ws,
                   hipStream_t st) {
   return mab0_bf16_bwd_ex(s, I, X, p, saved, dH, dI, dX, dk_accumulate, gr, ws, 0, st);
 }
-int mab0_bf16_bwd_ex(const pca_mab_shape& s, const float* I, const float* X,
+int mab0_bf16_bwd_ex(const pca_mab_shape& s, const float* I, const void* X,
                      const pca_mab_params& p, const void* saved, const float* dH, float* dI,
-                     float* dX, int dk_accumulate, const pca_mab_grads& gr, void* ws, int flags,
+                     void* dX, int dk_accumulate, const pca_mab_grads& gr, void* ws, int flags,
                      hipStream_t st) {
   Mab0Saved v;
   mab0_carve_saved(s, &v, const_cast<void*>(saved));
@@ -522,7 +533,8 @@ int mab0_bf16_bwd_ex(const pca_mab_shape& s, const float* I, const float* X,
   if (!(flags & PCA_F_SKIP_WGRAD)) PCA_TRY(fill_zero(w.DG, (int64_t)Rp * dk, st));
 
   if (small) {
-    hipLaunchKernelGGL(k_mab0_bwd_small, dim3(s.B), dim3(256), 0, st, X, v.Gf, w.dTf, v.LSE,
+    hipLaunchKernelGGL(k_mab0_bwd_small, dim3(s.B), dim3(256), 0, st,
+                       reinterpret_cast<const float*>(X), v.Gf, w.dTf, v.LSE,
                        w.Delta, s.nk, R, Rp, dk, w.DG);
     PCA_TRY(check_launch("k_mab0_bwd_small"));
   } else {
@@ -534,15 +546,23 @@ int mab0_bf16_bwd_ex(const pca_mab_shape& s, const float* I, const float* X,
     if (lds < (size_t)4 * Rp * 128 * 4) lds = (size_t)4 * Rp * 128 * 4;     // merge slabs
     static std::once_flag once;
     std::call_once(once, [] {
-      (void)hipFuncSetAttribute(reinterpret_cast<const void*>(k_mab0_bwd<64>),
+      (void)hipFuncSetAttribute(reinterpret_cast<const void*>(k_mab0_bwd<64, false>),
                                 hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
-      (void)hipFuncSetAttribute(reinterpret_cast<const void*>(k_mab0_bwd<32>),
+      (void)hipFuncSetAttribute(reinterpret_cast<const void*>(k_mab0_bwd<64, true>),
+                                hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+      (void)hipFuncSetAttribute(reinterpret_cast<const void*>(k_mab0_bwd<32, false>),
+                                hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+      (void)hipFuncSetAttribute(reinterpret_cast<const void*>(k_mab0_bwd<32, true>),
                                 hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
     });
     const double pts = (double)s.B * s.nk;
+    const bool abf = s.k_dtype == PCA_BF16;
     ProfScope ps(PCA_K_MAB0_BWD, st, 4.0 * pts * (2.0 * dk * d + 2.0 * m * d), pts * 8.0 * dk);
-    if (Rp == 32) hipLaunchKernelGGL((k_mab0_bwd<32>), dim3(s.B, S), dim3(256), lds, st, a);
-    else hipLaunchKernelGGL((k_mab0_bwd<64>), dim3(s.B, S), dim3(256), lds, st, a);
+    const dim3 grid(s.B, S);
+    if (Rp == 32 && abf) hipLaunchKernelGGL((k_mab0_bwd<32, true>), grid, dim3(256), lds, st, a);
+    else if (Rp == 32) hipLaunchKernelGGL((k_mab0_bwd<32, false>), grid, dim3(256), lds, st, a);
+    else if (abf) hipLaunchKernelGGL((k_mab0_bwd<64, true>), grid, dim3(256), lds, st, a);
+    else hipLaunchKernelGGL((k_mab0_bwd<64, false>), grid, dim3(256), lds, st, a);
     ps.end();
     PCA_TRY(check_launch("k_mab0_bwd"));
   }

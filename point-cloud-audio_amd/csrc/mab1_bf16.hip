@@ -135,7 +135,7 @@ __global__ __launch_bounds__(256) void k_kv_proj(const float* __restrict__ H,
 // the fused forward kernel
 // ---------------------------------------------------------------------------------
 struct Mab1FwdArgs {
-  const float* X;        // [B, N, dq] fp32
+  const void* X;         // [B, N, dq]: fp32, or bf16 when ABF (dq == D)
   const __bf16* WqB;     // [D][D] natural (dq == D) ...
   const float* WqF;      // ... or fp32 [D][dq] for dq <= 4 (layer 1: exact VALU projection)
   const float* bq;
@@ -143,7 +143,7 @@ struct Mab1FwdArgs {
   const __bf16* Vt;      // [B][D][MI]
   const __bf16* WoP;     // [D][D] K-permuted
   const float* bo;
-  float* Y;              // [B, N, D] fp32
+  void* Y;               // [B, N, D] fp32, or bf16 when ABF
   __bf16* QpS;           // [B*N][D] saved for backward (nullable)
   __bf16* OS;            // [B*N][D]
   uint32_t* mask;        // ReLU mask bits, see mask_index()
@@ -152,7 +152,8 @@ struct Mab1FwdArgs {
   float scale_log2e;     // log2(e) / sqrt(d)
 };
 
-template <int D, int MI, bool DIN_SMALL>
+// ABF: activations (X when dq == D, and Y) are bf16 in memory
+template <int D, int MI, bool DIN_SMALL, bool ABF>
 __global__ __launch_bounds__(256, 1) void k_mab1_fwd(const Mab1FwdArgs a) {
   constexpr int DT = D / 16;          // feature tiles
   constexpr int KS = D / 32;          // 32-wide K steps = heads (dh == 32)
@@ -206,7 +207,9 @@ __global__ __launch_bounds__(256, 1) void k_mab1_fwd(const Mab1FwdArgs a) {
         const int n = n_base + 16 * nb + r;
 #pragma unroll
         for (int c = 0; c < 4; ++c)
-          xv[nb][c] = (n < a.N && c < a.dq) ? a.X[((int64_t)b * a.N + n) * a.dq + c] : 0.f;
+          xv[nb][c] = (n < a.N && c < a.dq)
+                          ? reinterpret_cast<const float*>(a.X)[((int64_t)b * a.N + n) * a.dq + c]
+                          : 0.f;
       }
 #pragma unroll
       for (int t = 0; t < DT; ++t) {
@@ -230,9 +233,12 @@ __global__ __launch_bounds__(256, 1) void k_mab1_fwd(const Mab1FwdArgs a) {
         const int row = c / (D / 8), c16 = c % (D / 8);
         const int n = n_base + row;
         bf16x8 v;
-        if (n < a.N) {
-          const float4* src =
-              reinterpret_cast<const float4*>(a.X + ((int64_t)b * a.N + n) * D + c16 * 8);
+        if (n < a.N && ABF) {
+          v = *reinterpret_cast<const bf16x8*>(reinterpret_cast<const __bf16*>(a.X) +
+                                               ((int64_t)b * a.N + n) * D + c16 * 8);
+        } else if (n < a.N) {
+          const float4* src = reinterpret_cast<const float4*>(
+              reinterpret_cast<const float*>(a.X) + ((int64_t)b * a.N + n) * D + c16 * 8);
           const float4 lo = src[0], hi = src[1];
           v[0] = (__bf16)lo.x; v[1] = (__bf16)lo.y; v[2] = (__bf16)lo.z; v[3] = (__bf16)lo.w;
           v[4] = (__bf16)hi.x; v[5] = (__bf16)hi.y; v[6] = (__bf16)hi.z; v[7] = (__bf16)hi.w;
@@ -374,9 +380,12 @@ __global__ __launch_bounds__(256, 1) void k_mab1_fwd(const Mab1FwdArgs a) {
           y[e] = acc[t][nb][e] + fmaxf(zz, 0.f);
           if (zz > 0.f) bits[t / 8] |= 1u << ((t & 7) * 4 + e);
         }
-        if (n < a.N)
-          *reinterpret_cast<float4*>(a.Y + ((int64_t)b * a.N + n) * D + 16 * t + 4 * g) =
-              float4{y[0], y[1], y[2], y[3]};
+        if (n < a.N) {
+          const int64_t yo = ((int64_t)b * a.N + n) * D + 16 * t + 4 * g;
+          if (ABF) *reinterpret_cast<bf16x4*>(reinterpret_cast<__bf16*>(a.Y) + yo) = pack4(y);
+          else *reinterpret_cast<float4*>(reinterpret_cast<float*>(a.Y) + yo) =
+                   float4{y[0], y[1], y[2], y[3]};
+        }
       }
       if (a.mask != nullptr) {
 #pragma unroll
@@ -387,13 +396,13 @@ __global__ __launch_bounds__(256, 1) void k_mab1_fwd(const Mab1FwdArgs a) {
   }
 }
 
-template <int D, int MI, bool DS>
+template <int D, int MI, bool DS, bool ABF>
 int launch_fwd(const Mab1FwdArgs& a, hipStream_t st) {
   const size_t lds = (size_t)D * D * 2 + (size_t)MI * D * 2 + (size_t)D * MI * 2 +
                      (DS ? 0 : (size_t)D * D * 2 + (size_t)TP * D * 2);
   static std::once_flag once;
   std::call_once(once, [] {
-    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(k_mab1_fwd<D, MI, DS>),
+    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(k_mab1_fwd<D, MI, DS, ABF>),
                               hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
   });
   const int total = a.B * a.tiles_per_set;
@@ -401,8 +410,8 @@ int launch_fwd(const Mab1FwdArgs& a, hipStream_t st) {
   const double pts = (double)a.B * a.N;
   ProfScope ps(PCA_K_MAB1_FWD, st,
                2.0 * pts * ((double)a.dq * D + (double)D * D + 2.0 * MI * D),
-               pts * (4.0 * a.dq + 4.0 * D));
-  hipLaunchKernelGGL((k_mab1_fwd<D, MI, DS>), dim3(grid), dim3(256), lds, st, a);
+               pts * ((ABF && !DS ? 2.0 : 4.0) * a.dq + (ABF ? 2.0 : 4.0) * D));
+  hipLaunchKernelGGL((k_mab1_fwd<D, MI, DS, ABF>), dim3(grid), dim3(256), lds, st, a);
   ps.end();
   return check_launch("k_mab1_fwd");
 }
@@ -433,9 +442,11 @@ int prep_weight(const float* src, __bf16* dst, int rows, int cols, int mode, hip
 }
 
 bool mab1_bf16_supported(const pca_mab_shape& s) {
+  // activations: fp32 everywhere, or bf16 for Y (and for X when it is a hidden tensor)
+  const bool dt_ok = s.k_dtype == PCA_F32 &&
+                     (s.dq <= 4 ? s.q_dtype == PCA_F32 : s.q_dtype == s.y_dtype);
   return s.q_shared == 0 && s.d == 128 && s.h * 32 == s.d && (s.nk == 16 || s.nk == 32) &&
-         s.dk == s.d && (s.dq == s.d || s.dq <= 4) && s.q_dtype == PCA_F32 &&
-         s.k_dtype == PCA_F32 && s.y_dtype == PCA_F32;
+         s.dk == s.d && (s.dq == s.d || s.dq <= 4) && dt_ok;
 }
 
 size_t mab1_carve_saved(const pca_mab_shape& s, Mab1Saved* out, void* base) {
@@ -463,15 +474,12 @@ size_t mab1_bf16_fwd_ws_bytes(const pca_mab_shape& s) {
 }
 
 // Q = X [B, nq, dq] fp32, K = H [B, nk, d] fp32 -> Y [B, nq, d] fp32
-int mab1_bf16_fwd_ex(const pca_mab_shape& s, const float* X, const float* H,
-                     const pca_mab_params& p, float* Y, void* saved, void* ws, int flags,
-                     hipStream_t st, const IsabImg* img = nullptr);
-int mab1_bf16_fwd(const pca_mab_shape& s, const float* X, const float* H,
-                  const pca_mab_params& p, float* Y, void* saved, void* ws, hipStream_t st) {
+int mab1_bf16_fwd(const pca_mab_shape& s, const void* X, const float* H,
+                  const pca_mab_params& p, void* Y, void* saved, void* ws, hipStream_t st) {
   return mab1_bf16_fwd_ex(s, X, H, p, Y, saved, ws, 0, st);
 }
-int mab1_bf16_fwd_ex(const pca_mab_shape& s, const float* X, const float* H,
-                     const pca_mab_params& p, float* Y, void* saved, void* ws, int flags,
+int mab1_bf16_fwd_ex(const pca_mab_shape& s, const void* X, const float* H,
+                     const pca_mab_params& p, void* Y, void* saved, void* ws, int flags,
                      hipStream_t st, const IsabImg* img) {
   PCA_REQUIRE(mab1_bf16_supported(s), "mab1_bf16_fwd: unsupported shape");
   PCA_REQUIRE(ws != nullptr, "mab1_bf16_fwd: scratch required");
@@ -515,8 +523,15 @@ int mab1_bf16_fwd_ex(const pca_mab_shape& s, const float* X, const float* H,
   a.B = s.B; a.N = s.nq; a.dq = s.dq;
   a.tiles_per_set = (int)cdiv(s.nq, TP);
   a.scale_log2e = 1.4426950408889634f / sqrtf((float)d);
-  if (s.nk == 16) return small ? launch_fwd<128, 16, true>(a, st) : launch_fwd<128, 16, false>(a, st);
-  return small ? launch_fwd<128, 32, true>(a, st) : launch_fwd<128, 32, false>(a, st);
+  const bool abf = s.y_dtype == PCA_BF16;
+  if (s.nk == 16) {
+    if (abf) return small ? launch_fwd<128, 16, true, true>(a, st)
+                          : launch_fwd<128, 16, false, true>(a, st);
+    return small ? launch_fwd<128, 16, true, false>(a, st)
+                 : launch_fwd<128, 16, false, false>(a, st);
+  }
+  PCA_REQUIRE(!abf, "mab1_bf16_fwd: bf16 activations need m = 16");
+  return small ? launch_fwd<128, 32, true, false>(a, st) : launch_fwd<128, 32, false, false>(a, st);
 }
 
 }  // namespace pca

@@ -181,4 +181,93 @@ int mid_bwd_launch(const MidBwdLaunch& L, hipStream_t st);
 // K-permuted ([cols][rows]), 3 transposed natural
 int prep_weight(const float* src, __bf16* dst, int rows, int cols, int mode, hipStream_t st);
 
+// ---- host entry points of the fused blocks (single source of truth for every TU) --------
+// exact fp32 path (mab_f32.hip)
+int validate_shape(const pca_mab_shape* s);
+size_t mab_f32_saved_bytes(const pca_mab_shape& s);
+size_t mab_f32_bwd_ws_bytes(const pca_mab_shape& s);
+int mab_f32_fwd(const pca_mab_shape& s, const float* Q, const float* K,
+                const pca_mab_params& p, float* Y, void* saved, hipStream_t st);
+int mab_f32_bwd(const pca_mab_shape& s, const float* Q, const float* K,
+                const pca_mab_params& p, const void* saved, const float* dY, float* dQ,
+                float* dK, int dk_accumulate, const pca_mab_grads& g, void* ws,
+                hipStream_t st);
+int linear_fwd_f32(const float* X, const float* W, const float* b, float* Y, int64_t M,
+                   int din, int dout, hipStream_t st);
+int linear_bwd_f32(const float* X, const float* W, const float* dY, float* dX, float* dW,
+                   float* db, int64_t M, int din, int dout, hipStream_t st);
+int linear_dx_acc_f32(const float* dY, const float* W, float* dX, int64_t M, int din, int dout,
+                      int accumulate, hipStream_t st);
+// fused mab1 (many queries X, few keys H).  X / Y / dY / dX are fp32 or bf16 per the shape's
+// q_dtype / y_dtype; H and dH are fp32
+bool mab1_bf16_supported(const pca_mab_shape& s);
+size_t mab1_bf16_saved_bytes(const pca_mab_shape& s);
+size_t mab1_bf16_fwd_ws_bytes(const pca_mab_shape& s);
+size_t mab1_bf16_bwd_ws_bytes(const pca_mab_shape& s);
+int mab1_bf16_fwd(const pca_mab_shape& s, const void* X, const float* H,
+                  const pca_mab_params& p, void* Y, void* saved, void* ws, hipStream_t st);
+int mab1_bf16_fwd_ex(const pca_mab_shape& s, const void* X, const float* H,
+                     const pca_mab_params& p, void* Y, void* saved, void* ws, int flags,
+                     hipStream_t st, const IsabImg* img = nullptr);
+int mab1_bf16_bwd(const pca_mab_shape& s, const void* X, const float* H,
+                  const pca_mab_params& p, const void* saved, const void* dY, void* dX,
+                  float* dH, int dk_accumulate, const pca_mab_grads& gr, void* ws,
+                  hipStream_t st);
+int mab1_bf16_bwd_ex(const pca_mab_shape& s, const void* X, const float* H,
+                     const pca_mab_params& p, const void* saved, const void* dY, void* dX,
+                     float* dH, int dk_accumulate, const pca_mab_grads& gr, void* ws, int flags,
+                     hipStream_t st, const IsabImg* img = nullptr, float* zero_ptr = nullptr,
+                     int zero_n = 0, int* nparts_out = nullptr);
+// fused mab0 / PMA (few shared queries I, many keys X).  X / dX fp32 or bf16 per k_dtype
+bool mab0_bf16_supported(const pca_mab_shape& s);
+size_t mab0_bf16_saved_bytes(const pca_mab_shape& s);
+size_t mab0_bf16_fwd_ws_bytes(const pca_mab_shape& s);
+size_t mab0_bf16_bwd_ws_bytes(const pca_mab_shape& s);
+int mab0_bf16_fwd(const pca_mab_shape& s, const float* I, const void* X,
+                  const pca_mab_params& p, float* H, void* saved, void* ws, hipStream_t st);
+int mab0_bf16_fwd_ex(const pca_mab_shape& s, const float* I, const void* X,
+                     const pca_mab_params& p, float* H, void* saved, void* ws, int flags,
+                     hipStream_t st);
+int mab0_bf16_bwd(const pca_mab_shape& s, const float* I, const void* X,
+                  const pca_mab_params& p, const void* saved, const float* dH, float* dI,
+                  void* dX, int dk_accumulate, const pca_mab_grads& gr, void* ws,
+                  hipStream_t st);
+int mab0_bf16_bwd_ex(const pca_mab_shape& s, const float* I, const void* X,
+                     const pca_mab_params& p, const void* saved, const float* dH, float* dI,
+                     void* dX, int dk_accumulate, const pca_mab_grads& gr, void* ws, int flags,
+                     hipStream_t st);
+// per-block dispatch (api_mab.hip): kind 0 exact fp32, 1 fused mab1, 2 fused mab0
+int mab_kind(const pca_mab_shape& s);
+size_t mab_saved_bytes_any(const pca_mab_shape& s);
+size_t mab_fwd_ws_bytes_any(const pca_mab_shape& s);
+size_t mab_bwd_ws_bytes_any(const pca_mab_shape& s);
+int mab_fwd_any(const pca_mab_shape& s, const void* Q, const void* K, const pca_mab_params& p,
+                void* Y, void* saved, void* ws, hipStream_t st);
+int mab_bwd_any(const pca_mab_shape& s, const void* Q, const void* K, const pca_mab_params& p,
+                const void* saved, const void* dY, void* dQ, void* dK, int dk_accumulate,
+                const pca_mab_grads& g, void* ws, hipStream_t st);
+// fused ISAB (isab_bf16.hip)
+bool isab_bf16_supported(const pca_mab_shape& s0, const pca_mab_shape& s1);
+size_t isab_bf16_fwd_ws_bytes(const pca_mab_shape& s0, const pca_mab_shape& s1);
+size_t isab_bf16_bwd_ws_bytes(const pca_mab_shape& s0, const pca_mab_shape& s1);
+size_t isab_img_bytes();
+void isab_img_carve(void* base, IsabImg* im);
+void isab_collect_prep(const pca_mab_shape& s0, const pca_mab_params& p0,
+                       const pca_mab_params& p1, const IsabImg& im, bool training,
+                       bool need_dx, PrepJobs* J);
+int isab_bf16_fwd(const pca_mab_shape& s0, const pca_mab_shape& s1, const float* I,
+                  const void* X, const pca_mab_params& p0, const pca_mab_params& p1, float* H,
+                  void* Y, void* saved0, void* saved1, void* ws, const IsabImg& im,
+                  hipStream_t st);
+int isab_bf16_bwd(const pca_mab_shape& s0, const pca_mab_shape& s1, const float* I,
+                  const void* X, const float* H, const pca_mab_params& p0,
+                  const pca_mab_params& p1, const void* saved0, const void* saved1,
+                  const void* dY, float* dI, void* dX, const pca_mab_grads& g0,
+                  const pca_mab_grads& g1, void* ws, const IsabImg& im, hipStream_t st);
+// classifier head (train_ops.hip)
+int cls_train_head(const float* P, const float* Wc, const float* bc, const int64_t* labels,
+                   int B, int d, int C, float grad_scale, float* logits, float* dlogits,
+                   float* dP, float* dWc, float* dbc, float* loss_out, float* stats, float* ws,
+                   hipStream_t st);
+
 }  // namespace pca

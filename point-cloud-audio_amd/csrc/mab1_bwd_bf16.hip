@@ -21,10 +21,6 @@
 
 namespace pca {
 
-int linear_bwd_f32(const float* X, const float* W, const float* dY, float* dX, float* dW,
-                   float* db, int64_t M, int din, int dout, hipStream_t st);
-int linear_dx_acc_f32(const float* dY, const float* W, float* dX, int64_t M, int din, int dout,
-                      int accumulate, hipStream_t st);
 
 namespace {
 
@@ -32,7 +28,7 @@ constexpr int TP = M1_TP;
 constexpr int NB = M1_NB;
 
 struct Mab1BwdArgs {
-  const float* dY;          // [B, N, D]
+  const void* dY;           // [B, N, D] fp32, or bf16 when ABF
   const __bf16* QpS;        // [B*N][D]
   const uint32_t* mask;
   const __bf16 *KpP, *VpP;  // [B][MI][D]  (K-permuted features)
@@ -40,7 +36,7 @@ struct Mab1BwdArgs {
   const __bf16 *WoTP, *WqTP;
   __bf16 *dZ, *dQp, *dOs;   // [B*N][D]
   __bf16 *dS, *P;           // [B*N][H*MI]
-  float* dX;                // [B, N, D] or null
+  void* dX;                 // [B, N, D] (fp32 / bf16 when ABF) or null
   float *dKpG, *dVpG;       // [B][nparts][MI][D] fp32 partial K/V gradients (fused mode)
   const float* Xs;          // layer 1 (dq <= 3): the fp32 points [B, N, dq] ...
   float *dWqS, *dbqS;       // ... and fc_q gradients accumulated here (fused reduction)
@@ -69,7 +65,7 @@ __device__ __forceinline__ bf16x8 tr_frag_small(const char* img, int rb, int col
   return r;
 }
 
-template <int D, int MI, bool WANT_DX, bool FUSE_KV, bool FUSE_WQ>
+template <int D, int MI, bool WANT_DX, bool FUSE_KV, bool FUSE_WQ, bool ABF>
 __global__ __launch_bounds__(256, 1) void k_mab1_bwd(const Mab1BwdArgs a) {
   constexpr int DT = D / 16, KS = D / 32, ROWB = D * 2, HM = KS * MI;
   extern __shared__ __attribute__((aligned(16))) char smem[];
@@ -170,7 +166,16 @@ __global__ __launch_bounds__(256, 1) void k_mab1_bwd(const Mab1BwdArgs a) {
 #pragma unroll
       for (int t = 0; t < DT; ++t) {
         float4 v = float4{0.f, 0.f, 0.f, 0.f};
-        if (live[nb]) v = *reinterpret_cast<const float4*>(a.dY + row[nb] * D + 16 * t + 4 * g);
+        if (live[nb]) {
+          if (ABF) {
+            const bf16x4 h4 = *reinterpret_cast<const bf16x4*>(
+                reinterpret_cast<const __bf16*>(a.dY) + row[nb] * D + 16 * t + 4 * g);
+            v = float4{(float)h4[0], (float)h4[1], (float)h4[2], (float)h4[3]};
+          } else {
+            v = *reinterpret_cast<const float4*>(reinterpret_cast<const float*>(a.dY) +
+                                                 row[nb] * D + 16 * t + 4 * g);
+          }
+        }
         dO[t][nb] = f32x4{v.x, v.y, v.z, v.w};
 #pragma unroll
         for (int e = 0; e < 4; ++e)
@@ -351,9 +356,13 @@ __global__ __launch_bounds__(256, 1) void k_mab1_bwd(const Mab1BwdArgs a) {
       for (int nb = 0; nb < NB; ++nb)
         if (live[nb]) {
 #pragma unroll
-          for (int t = 0; t < DT; ++t)
-            *reinterpret_cast<float4*>(a.dX + row[nb] * D + 16 * t + 4 * g) =
-                float4{dx[t][nb][0], dx[t][nb][1], dx[t][nb][2], dx[t][nb][3]};
+          for (int t = 0; t < DT; ++t) {
+            const int64_t xo = row[nb] * D + 16 * t + 4 * g;
+            if (ABF) *reinterpret_cast<bf16x4*>(reinterpret_cast<__bf16*>(a.dX) + xo) =
+                         pack4(dx[t][nb]);
+            else *reinterpret_cast<float4*>(reinterpret_cast<float*>(a.dX) + xo) =
+                     float4{dx[t][nb][0], dx[t][nb][1], dx[t][nb][2], dx[t][nb][3]};
+          }
         }
     }
   }
@@ -687,20 +696,20 @@ __global__ void k_sum_parts(const float* __restrict__ kp, const float* __restric
   dv[i] = c;
 }
 
-template <int D, int MI, bool DX, bool FUSE, bool FWQ = false>
+template <int D, int MI, bool DX, bool FUSE, bool FWQ, bool ABF>
 int launch_bwd(const Mab1BwdArgs& a, hipStream_t st, double flops, double bytes) {
   size_t lds = (size_t)D * D * 2 + 2 * (size_t)MI * D * 2 + (size_t)D * MI * 2 +
                (DX ? (size_t)D * D * 2 : 0) + (FUSE ? 4 * 6144 : 0);
   if (FUSE && lds < (size_t)8 * MI * D * 4) lds = (size_t)8 * MI * D * 4;   // flush buffer
   static std::once_flag once;
   std::call_once(once, [] {
-    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(k_mab1_bwd<D, MI, DX, FUSE, FWQ>),
+    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(k_mab1_bwd<D, MI, DX, FUSE, FWQ, ABF>),
                               hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
   });
   const int total = a.B * a.tiles_per_set;
   const int grid = FUSE ? (int)cdiv(total, a.tpw) : (total < 256 ? total : 256);
   ProfScope ps(PCA_K_MAB1_BWD, st, flops, bytes);
-  hipLaunchKernelGGL((k_mab1_bwd<D, MI, DX, FUSE, FWQ>), dim3(grid), dim3(256), lds, st, a);
+  hipLaunchKernelGGL((k_mab1_bwd<D, MI, DX, FUSE, FWQ, ABF>), dim3(grid), dim3(256), lds, st, a);
   ps.end();
   return check_launch("k_mab1_bwd");
 }
@@ -765,19 +774,14 @@ int kv_dh_launch(const float* dKp, const float* dVp, const float* Wk, const floa
 }
 
 // dQ -> dX [B, nq, dq] (written; may be null), dK -> dH [B, nk, d] (written or accumulated)
-int mab1_bf16_bwd_ex(const pca_mab_shape& s, const float* X, const float* H,
-                     const pca_mab_params& p, const void* saved, const float* dY, float* dX,
-                     float* dH, int dk_accumulate, const pca_mab_grads& gr, void* ws, int flags,
-                     hipStream_t st, const IsabImg* img = nullptr, float* zero_ptr = nullptr,
-                     int zero_n = 0, int* nparts_out = nullptr);
-int mab1_bf16_bwd(const pca_mab_shape& s, const float* X, const float* H,
-                  const pca_mab_params& p, const void* saved, const float* dY, float* dX,
+int mab1_bf16_bwd(const pca_mab_shape& s, const void* X, const float* H,
+                  const pca_mab_params& p, const void* saved, const void* dY, void* dX,
                   float* dH, int dk_accumulate, const pca_mab_grads& gr, void* ws,
                   hipStream_t st) {
   return mab1_bf16_bwd_ex(s, X, H, p, saved, dY, dX, dH, dk_accumulate, gr, ws, 0, st);
 }
-int mab1_bf16_bwd_ex(const pca_mab_shape& s, const float* X, const float* H,
-                     const pca_mab_params& p, const void* saved, const float* dY, float* dX,
+int mab1_bf16_bwd_ex(const pca_mab_shape& s, const void* X, const float* H,
+                     const pca_mab_params& p, const void* saved, const void* dY, void* dX,
                      float* dH, int dk_accumulate, const pca_mab_grads& gr, void* ws, int flags,
                      hipStream_t st, const IsabImg* img, float* zero_ptr, int zero_n,
                      int* nparts_out) {
@@ -789,6 +793,7 @@ int mab1_bf16_bwd_ex(const pca_mab_shape& s, const float* X, const float* H,
   const int64_t M = (int64_t)s.B * s.nq;
   const bool small = s.dq <= 4;
   const bool want_dx = dX != nullptr && !small;
+  const bool abf = s.y_dtype == PCA_BF16;
   if (dX != nullptr && small) {
     // the ST model never needs it (the set itself is the input of layer 1)
     set_error("mab1_bf16_bwd: dQ for dq <= 4 is not built");
@@ -827,13 +832,19 @@ int mab1_bf16_bwd_ex(const pca_mab_shape& s, const float* X, const float* H,
     a.zero_ptr = zero_ptr;
     a.zero_n = zero_n;
     const bool fwq = small && s.dq <= 3;
-    a.Xs = X; a.dWqS = gr.wq; a.dbqS = gr.bq; a.dq = s.dq;
-    rc = want_dx ? launch_bwd<128, 16, true, true>(a, st, flops, bytes)
-         : fwq   ? launch_bwd<128, 16, false, true, true>(a, st, flops, bytes)
-                 : launch_bwd<128, 16, false, true>(a, st, flops, bytes);
+    a.Xs = reinterpret_cast<const float*>(X); a.dWqS = gr.wq; a.dbqS = gr.bq; a.dq = s.dq;
+    if (abf)
+      rc = want_dx ? launch_bwd<128, 16, true, true, false, true>(a, st, flops, bytes)
+           : fwq   ? launch_bwd<128, 16, false, true, true, true>(a, st, flops, bytes)
+                   : launch_bwd<128, 16, false, true, false, true>(a, st, flops, bytes);
+    else
+      rc = want_dx ? launch_bwd<128, 16, true, true, false, false>(a, st, flops, bytes)
+           : fwq   ? launch_bwd<128, 16, false, true, true, false>(a, st, flops, bytes)
+                   : launch_bwd<128, 16, false, true, false, false>(a, st, flops, bytes);
   } else {
-    rc = want_dx ? launch_bwd<128, 32, true, false>(a, st, flops, bytes)
-                 : launch_bwd<128, 32, false, false>(a, st, flops, bytes);
+    PCA_REQUIRE(!abf, "mab1_bf16_bwd: bf16 activations need m = 16");
+    rc = want_dx ? launch_bwd<128, 32, true, false, false, false>(a, st, flops, bytes)
+                 : launch_bwd<128, 32, false, false, false, false>(a, st, flops, bytes);
   }
   PCA_TRY(rc);
   if (nparts_out != nullptr) *nparts_out = fuse ? a.tiles_per_set / a.tpw : 0;
@@ -852,7 +863,8 @@ int mab1_bf16_bwd_ex(const pca_mab_shape& s, const float* X, const float* H,
     // dWq / dbq were reduced inside the chain kernel
   } else if (small) {
     hipLaunchKernelGGL((k_wgrad_small<__bf16>), dim3((unsigned)cdiv(M, 128)), dim3(256), 0, st,
-                       w.dQp, X, M, s.dq, 128, (int64_t)0, gr.wq, gr.bq);
+                       w.dQp, reinterpret_cast<const float*>(X), M, s.dq, 128, (int64_t)0, gr.wq,
+                       gr.bq);
     PCA_TRY(check_launch("k_wgrad_small"));
   } else {
     WgradJobs jobs{};
@@ -860,7 +872,7 @@ int mab1_bf16_bwd_ex(const pca_mab_shape& s, const float* X, const float* H,
     jobs.n = 1;
     hipStream_t ts = terminal_stream(st);
     ProfScope ps(PCA_K_WGRAD, ts, 2.0 * M * d * d, 6.0 * M * d);
-    PCA_TRY(wgrad128_launch(jobs, true, false, rows_per_wg, ts));
+    PCA_TRY(wgrad128_launch(jobs, true, abf, rows_per_wg, ts));
     ps.end();
   }
   if (!fuse) {

@@ -7,7 +7,7 @@
 // projection, so no head-major copy is ever made.  The learned query of ISAB / PMA
 // (modules.py:52,63 `I.repeat(B,1,1)`) is projected once (q_shared) and broadcast through
 // a zero batch stride.
-#include "pca_common.h"
+#include "mab1_bf16.hpp"
 
 #include <math.h>
 

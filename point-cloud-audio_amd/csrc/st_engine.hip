@@ -9,43 +9,6 @@ namespace pca {
 
 // per-block dispatch (api_mab.hip): fused bf16 kernel where one exists for the block's shape
 // and the config asks for PCA_MODE_BF16, exact fp32 GEMM chain otherwise
-size_t mab_saved_bytes_any(const pca_mab_shape& s);
-size_t mab_fwd_ws_bytes_any(const pca_mab_shape& s);
-size_t mab_bwd_ws_bytes_any(const pca_mab_shape& s);
-int mab_fwd_any(const pca_mab_shape& s, const float* Q, const float* K, const pca_mab_params& p,
-                float* Y, void* saved, void* ws, hipStream_t st);
-int mab_bwd_any(const pca_mab_shape& s, const float* Q, const float* K, const pca_mab_params& p,
-                const void* saved, const float* dY, float* dQ, float* dK, int dk_accumulate,
-                const pca_mab_grads& g, void* ws, hipStream_t st);
-bool isab_bf16_supported(const pca_mab_shape& s0, const pca_mab_shape& s1);
-size_t isab_bf16_fwd_ws_bytes(const pca_mab_shape& s0, const pca_mab_shape& s1);
-size_t isab_bf16_bwd_ws_bytes(const pca_mab_shape& s0, const pca_mab_shape& s1);
-int cls_train_head(const float* P, const float* Wc, const float* bc, const int64_t* labels,
-                   int B, int d, int C, float grad_scale, float* logits, float* dlogits,
-                   float* dP, float* dWc, float* dbc, float* loss_out, float* stats, float* ws,
-                   hipStream_t st);
-int mab_kind(const pca_mab_shape& s);
-int mab0_bf16_fwd_ex(const pca_mab_shape& s, const float* I, const float* X,
-                     const pca_mab_params& p, float* H, void* saved, void* ws, int flags,
-                     hipStream_t st);
-size_t isab_img_bytes();
-void isab_img_carve(void* base, IsabImg* im);
-void isab_collect_prep(const pca_mab_shape& s0, const pca_mab_params& p0,
-                       const pca_mab_params& p1, const IsabImg& im, bool training,
-                       bool need_dx, PrepJobs* J);
-int isab_bf16_fwd(const pca_mab_shape& s0, const pca_mab_shape& s1, const float* I,
-                  const float* X, const pca_mab_params& p0, const pca_mab_params& p1, float* H,
-                  float* Y, void* saved0, void* saved1, void* ws, const IsabImg& im,
-                  hipStream_t st);
-int isab_bf16_bwd(const pca_mab_shape& s0, const pca_mab_shape& s1, const float* I,
-                  const float* X, const float* H, const pca_mab_params& p0,
-                  const pca_mab_params& p1, const void* saved0, const void* saved1,
-                  const float* dY, float* dI, float* dX, const pca_mab_grads& g0,
-                  const pca_mab_grads& g1, void* ws, const IsabImg& im, hipStream_t st);
-int linear_fwd_f32(const float* X, const float* W, const float* b, float* Y, int64_t M,
-                   int din, int dout, hipStream_t st);
-int linear_bwd_f32(const float* X, const float* W, const float* dY, float* dX, float* dW,
-                   float* db, int64_t M, int din, int dout, hipStream_t st);
 
 namespace {
 
@@ -115,8 +78,9 @@ inline pca_mab_shape shape(const pca_st_config& c, int nq, int nk, int dq, int d
 
 struct Shapes {
   pca_mab_shape m0[2], m1[2], pma;
+  bool act_bf16;      // hidden activations Y1, Y2 (and their gradients) travel in bf16
 };
-inline Shapes shapes(const pca_st_config& c) {
+inline Shapes shapes(const pca_st_config& c, bool training) {
   Shapes s;
   for (int li = 0; li < 2; ++li) {
     const int din = li == 0 ? c.din : c.d;
@@ -124,6 +88,21 @@ inline Shapes shapes(const pca_st_config& c) {
     s.m1[li] = shape(c, c.N, c.m, din, c.d, 0);
   }
   s.pma = shape(c, c.k, c.N, c.d, c.d, 1);
+  s.act_bf16 = false;
+  if (training && c.mode == PCA_MODE_BF16) {
+    // bf16 activations only when EVERY block runs on a fused kernel that understands them
+    Shapes t = s;
+    t.m1[0].y_dtype = PCA_BF16;
+    t.m0[1].k_dtype = PCA_BF16;
+    t.m1[1].q_dtype = PCA_BF16;
+    t.m1[1].y_dtype = PCA_BF16;
+    t.pma.k_dtype = PCA_BF16;
+    if (isab_bf16_supported(t.m0[0], t.m1[0]) && isab_bf16_supported(t.m0[1], t.m1[1]) &&
+        mab_kind(t.pma) == 2) {
+      s = t;
+      s.act_bf16 = true;
+    }
+  }
   return s;
 }
 
@@ -139,7 +118,7 @@ struct Ws {
 };
 
 inline size_t carve(const pca_st_config& c, int training, Ws* out, void* base) {
-  const Shapes s = shapes(c);
+  const Shapes s = shapes(c, training != 0);
   Carver cv(base);
   Ws w{};
   const pca_mab_shape* order[5] = {&s.m0[0], &s.m1[0], &s.m0[1], &s.m1[1], &s.pma};
@@ -199,7 +178,7 @@ int validate(const pca_st_config* c) {
 
 int forward(const pca_st_config& c, const Layout& L, const Shapes& s, const float* p,
             const float* X, Ws& w, bool training, hipStream_t st) {
-  const float* in = X;
+  const void* in = X;
   if (training) {               // all weight images of the step in ONE launch
     PrepJobs J{};
     for (int li = 0; li < 2; ++li)
@@ -278,7 +257,7 @@ int pca_st_forward(const pca_st_config* c, const float* params, const float* X,
   pca::Ws w;
   pca::carve(*c, 0, &w, ws);
   const pca::Layout L = pca::layout(*c);
-  const pca::Shapes s = pca::shapes(*c);
+  const pca::Shapes s = pca::shapes(*c, false);
   float* own = w.logits;
   w.logits = logits;
   (void)own;
@@ -298,7 +277,7 @@ int pca_st_train_fwd_bwd(const pca_st_config* c, const float* params, const floa
   pca::Ws w;
   pca::carve(*c, 1, &w, ws);
   const pca::Layout L = pca::layout(*c);
-  const pca::Shapes s = pca::shapes(*c);
+  const pca::Shapes s = pca::shapes(*c, true);
   const float* p = params;
   float* g = grads;
   if (logits != nullptr) w.logits = logits;

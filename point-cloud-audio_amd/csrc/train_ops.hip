@@ -1,7 +1,7 @@
 // Loss and optimiser of the train step (Code/settransformer.py:88-91,104-108):
 // nn.CrossEntropyLoss (mean) forward+gradient in one launch, and torch.optim.Adam with
 // coupled weight decay as one fused pass over a flat parameter vector.
-#include "pca_common.h"
+#include "mab1_bf16.hpp"
 
 namespace pca {
 namespace {

@@ -13,6 +13,13 @@ import torch.multiprocessing as mp
 from conftest import PKG, ROOT
 
 
+def _free_port():
+    import socket
+    with socket.socket() as sk:
+        sk.bind(("127.0.0.1", 0))
+        return sk.getsockname()[1]
+
+
 def _worker(rank, world, port, q):
     for p in (ROOT, PKG):
         if p not in sys.path:
@@ -64,7 +71,7 @@ def _worker(rank, world, port, q):
 def test_sharding_and_bucketed_allreduce_world2():
     ctx = mp.get_context("spawn")
     q = ctx.Queue()
-    port = 29500 + (os.getpid() % 1000)
+    port = _free_port()
     procs = [ctx.Process(target=_worker, args=(r, 2, port, q)) for r in range(2)]
     for p in procs:
         p.start()

@@ -10,6 +10,13 @@ import pytest
 import torch
 
 from conftest import PKG, ROOT
+
+
+def _free_port():
+    import socket
+    with socket.socket() as sk:
+        sk.bind(("127.0.0.1", 0))
+        return sk.getsockname()[1]
 from util import close
 
 pytestmark = pytest.mark.gpu
@@ -22,7 +29,7 @@ def test_two_ranks_equal_one_rank_double_batch(tmp_path, mode, graph):
                HSA_ENABLE_IPC_MODE_LEGACY="0")
     r = subprocess.run([sys.executable, "-m", "torch.distributed.run", "--nnodes=1",
                         "--nproc-per-node", "2", "--master-addr", "127.0.0.1",
-                        "--master-port", str(29600 + os.getpid() % 300),
+                        "--master-port", str(_free_port()),
                         os.path.join(ROOT, "scripts", "ddp_check.py")],
                        env=env, capture_output=True, text=True, timeout=600)
     assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-3000:]
