@@ -60,7 +60,15 @@ __global__ __launch_bounds__(256) void k_mab0_prep(const Mab0PrepJobs jobs) {
   const int R = h * m;
   for (int f = threadIdx.x; f < d; f += 256) {
     float acc = a.bq[f];
-    for (int c = 0; c < dq; ++c) acc += a.I[q * dq + c] * a.Wq[f * dq + c];
+    int c = 0;
+    for (; c + 16 <= dq; c += 16) {          // 16 independent loads in flight
+      float wv[16];
+#pragma unroll
+      for (int u = 0; u < 16; ++u) wv[u] = a.Wq[f * dq + c + u];
+#pragma unroll
+      for (int u = 0; u < 16; ++u) acc = fmaf(a.I[q * dq + c + u], wv[u], acc);
+    }
+    for (; c < dq; ++c) acc += a.I[q * dq + c] * a.Wq[f * dq + c];
     sq[f] = acc;
     a.Qp[q * d + f] = acc;
   }
@@ -69,7 +77,14 @@ __global__ __launch_bounds__(256) void k_mab0_prep(const Mab0PrepJobs jobs) {
   for (int o = threadIdx.x; o < h * dk; o += 256) {
     const int j = o / dk, c = o - j * dk;
     float acc = 0.f;
-    for (int f = 0; f < dh; ++f) acc += sq[j * dh + f] * a.Wk[(j * dh + f) * dk + c];
+    for (int f = 0; f < dh; f += 16) {
+      float wv[16];
+#pragma unroll
+      for (int u = 0; u < 16; ++u) wv[u] = (f + u < dh) ? a.Wk[(j * dh + f + u) * dk + c] : 0.f;
+#pragma unroll
+      for (int u = 0; u < 16; ++u)
+        if (f + u < dh) acc = fmaf(sq[j * dh + f + u], wv[u], acc);
+    }
     acc *= a.sl2e;
     const int r = j * m + q;
     a.Gf[r * dk + c] = acc;
@@ -287,7 +302,9 @@ __global__ __launch_bounds__(256) void k_mab0_attn_small(const float* __restrict
                                                          const float* __restrict__ Gf, int N,
                                                          int R, int dk, float* __restrict__ T,
                                                          float* __restrict__ LSE) {
+  constexpr int CH = 2048;                    // points staged per chunk (<= 32 KiB of LDS)
   __shared__ float sM[256], sL[256], sT[256][4];
+  __shared__ __attribute__((aligned(16))) float sX[CH * 4];
   const int b = blockIdx.x, tid = threadIdx.x;
   const int parts = 256 / R;                 // R in {64, 128, 256}
   const int r = tid % R, part = tid / R;
@@ -295,20 +312,42 @@ __global__ __launch_bounds__(256) void k_mab0_attn_small(const float* __restrict
 #pragma unroll
   for (int c = 0; c < 4; ++c) gk[c] = c < dk ? Gf[r * dk + c] : 0.f;
   float m = -INFINITY, l = 0.f, t[4] = {0.f, 0.f, 0.f, 0.f};
-  if (part < parts) {
-    for (int n = part; n < N; n += parts) {
-      float x[4];
+  for (int n0 = 0; n0 < N; n0 += CH) {
+    const int cn = (N - n0 < CH) ? N - n0 : CH;
+    __syncthreads();
+    // coalesced copy of cn*dk floats, re-laid out as [point][4]
+    for (int i = tid; i < cn * dk; i += 256) {
+      const int pt = i / dk, c = i - pt * dk;
+      sX[pt * 4 + c] = X[((int64_t)b * N + n0) * dk + i];
+    }
+    __syncthreads();
+    // online softmax over this thread's points of the chunk, 4 at a time (one rescale per 4)
+    for (int n = part; n < cn; n += 4 * parts) {
+      float sv[4], xv[4][4];
 #pragma unroll
-      for (int c = 0; c < 4; ++c) x[c] = c < dk ? X[((int64_t)b * N + n) * dk + c] : 0.f;
-      const float s = gk[0] * x[0] + gk[1] * x[1] + gk[2] * x[2] + gk[3] * x[3];
-      const float mn = fmaxf(m, s);
-      const float al = exp2f(m - mn), p = exp2f(s - mn);
-      l = l * al + p;
+      for (int u = 0; u < 4; ++u) {
+        const int nn = n + u * parts;
+        const float4 x4 = nn < cn ? *reinterpret_cast<const float4*>(&sX[nn * 4])
+                                  : float4{0.f, 0.f, 0.f, 0.f};
+        xv[u][0] = x4.x; xv[u][1] = x4.y; xv[u][2] = x4.z; xv[u][3] = x4.w;
+        sv[u] = nn < cn ? gk[0] * x4.x + gk[1] * x4.y + gk[2] * x4.z + gk[3] * x4.w : -INFINITY;
+      }
+      const float mn = fmaxf(fmaxf(m, fmaxf(sv[0], sv[1])), fmaxf(sv[2], sv[3]));
+      const float al = exp2f(m - mn);
+      l *= al;
 #pragma unroll
-      for (int c = 0; c < 4; ++c) t[c] = t[c] * al + p * x[c];
+      for (int c = 0; c < 4; ++c) t[c] *= al;
+#pragma unroll
+      for (int u = 0; u < 4; ++u) {
+        const float p = exp2f(sv[u] - mn);          // exp2(-inf) = 0 for padding
+        l += p;
+#pragma unroll
+        for (int c = 0; c < 4; ++c) t[c] = fmaf(p, xv[u][c], t[c]);
+      }
       m = mn;
     }
   }
+  if (part >= parts) { m = -INFINITY; l = 0.f; }
   sM[tid] = m; sL[tid] = l;
 #pragma unroll
   for (int c = 0; c < 4; ++c) sT[tid][c] = t[c];

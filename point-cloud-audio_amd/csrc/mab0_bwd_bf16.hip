@@ -364,12 +364,15 @@ __global__ __launch_bounds__(256, 1) void k_mab0_bwd(const Mab0BwdArgs a) {
     atomicAdd(&a.DG[i], s0[i] + s0[RP * DK + i] + s0[2 * RP * DK + i] + s0[3 * RP * DK + i]);
 }
 
-// layer 1 (dk <= 4): thread = (query row r, point partition); accumulates DG only
+// layer 1 (dk <= 4): thread = (query row r, point partition); accumulates DG only.  The
+// set's points are staged in LDS chunk by chunk (coalesced) and re-read from there.
 __global__ __launch_bounds__(256) void k_mab0_bwd_small(
     const float* __restrict__ X, const float* __restrict__ Gf, const float* __restrict__ dTf,
     const float* __restrict__ LSE, const float* __restrict__ Delta, int N, int R, int Rp, int dk,
     float* __restrict__ DG) {
+  constexpr int CH = 2048;
   __shared__ float sD[256][4];
+  __shared__ __attribute__((aligned(16))) float sX[CH * 4];
   const int b = blockIdx.x, tid = threadIdx.x;
   const int parts = 256 / R;
   const int r = tid % R, part = tid / R;
@@ -381,16 +384,24 @@ __global__ __launch_bounds__(256) void k_mab0_bwd_small(
     dt[c] = c < dk ? dTf[((int64_t)b * R + r) * dk + c] : 0.f;
   }
   const float lse = LSE[(int64_t)b * R + r], del = Delta[(int64_t)b * Rp + r];
-  if (part < parts) {
-    for (int n = part; n < N; n += parts) {
-      float x[4];
-#pragma unroll
-      for (int c = 0; c < 4; ++c) x[c] = c < dk ? X[((int64_t)b * N + n) * dk + c] : 0.f;
-      const float s = gk[0] * x[0] + gk[1] * x[1] + gk[2] * x[2] + gk[3] * x[3];
-      const float da = dt[0] * x[0] + dt[1] * x[1] + dt[2] * x[2] + dt[3] * x[3];
-      const float ds = LN2 * exp2f(s - lse) * (da - del);
-#pragma unroll
-      for (int c = 0; c < 4; ++c) acc[c] += ds * x[c];
+  for (int n0 = 0; n0 < N; n0 += CH) {
+    const int cn = (N - n0 < CH) ? N - n0 : CH;
+    __syncthreads();
+    for (int i = tid; i < cn * dk; i += 256) {
+      const int pt = i / dk, c = i - pt * dk;
+      sX[pt * 4 + c] = X[((int64_t)b * N + n0) * dk + i];
+    }
+    __syncthreads();
+    if (part < parts) {
+#pragma unroll 4
+      for (int n = part; n < cn; n += parts) {
+        const float4 x4 = *reinterpret_cast<const float4*>(&sX[n * 4]);
+        const float s = gk[0] * x4.x + gk[1] * x4.y + gk[2] * x4.z + gk[3] * x4.w;
+        const float da = dt[0] * x4.x + dt[1] * x4.y + dt[2] * x4.z + dt[3] * x4.w;
+        const float ds = LN2 * exp2f(s - lse) * (da - del);
+        acc[0] = fmaf(ds, x4.x, acc[0]); acc[1] = fmaf(ds, x4.y, acc[1]);
+        acc[2] = fmaf(ds, x4.z, acc[2]); acc[3] = fmaf(ds, x4.w, acc[3]);
+      }
     }
   }
 #pragma unroll

@@ -198,10 +198,23 @@ __global__ __launch_bounds__(256) void k_mid_bwd(const MidBwdArgs a) {
   __shared__ __attribute__((aligned(16))) char sK[16 * ROWB];    // dKp bf16 [q][f]
   __shared__ __attribute__((aligned(16))) char sV[16 * ROWB];    // dVp
   __shared__ __attribute__((aligned(16))) char sO[4][16 * 64];   // per wave: dO_j bf16 [q][32]
+  // every wave needs ALL of Wk1^T and Wv1^T: stage them once, cooperatively (coalesced,
+  // 16 loads of 16 B in flight per thread) instead of 4 waves chasing fragments through L2
+  __shared__ __attribute__((aligned(16))) char sWk[128 * ROWB];
+  __shared__ __attribute__((aligned(16))) char sWv[128 * ROWB];
   const int b = blockIdx.x, tid = threadIdx.x, lane = tid & 63, w = tid >> 6;
   const int r = lane & 15, g = lane >> 4;
   const int dk = a.dk;
 
+#pragma unroll
+  for (int e = 0; e < 8; ++e) {
+    const int c = tid + 256 * e;                 // 2048 chunks of 16 B per matrix
+    const int row = c >> 4, ch = c & 15;
+    const uint4 kv = *reinterpret_cast<const uint4*>(a.Wk1T + (int64_t)row * D + ch * 8);
+    const uint4 vv = *reinterpret_cast<const uint4*>(a.Wv1T + (int64_t)row * D + ch * 8);
+    *reinterpret_cast<uint4*>(sWk + swz(row, ch, ROWB)) = kv;
+    *reinterpret_cast<uint4*>(sWv + swz(row, ch, ROWB)) = vv;
+  }
   if (a.zero_ptr != nullptr)
     for (int i = blockIdx.x * 256 + tid; i < a.zero_n; i += gridDim.x * 256) a.zero_ptr[i] = 0.f;
   for (int i = tid; i < 16 * 16; i += 256) {
@@ -243,8 +256,10 @@ __global__ __launch_bounds__(256) void k_mid_bwd(const MidBwdArgs a) {
     dh[t] = f32x4{0.f, 0.f, 0.f, 0.f};
 #pragma unroll
     for (int ks = 0; ks < 4; ++ks) {
-      dh[t] = mfma32(gload8(a.Wk1T + (int64_t)(16 * t + r) * D + 32 * ks + 8 * g), kb[ks], dh[t]);
-      dh[t] = mfma32(gload8(a.Wv1T + (int64_t)(16 * t + r) * D + 32 * ks + 8 * g), vb[ks], dh[t]);
+      dh[t] = mfma32(*reinterpret_cast<const bf16x8*>(sWk + swz(16 * t + r, 4 * ks + g, ROWB)),
+                     kb[ks], dh[t]);
+      dh[t] = mfma32(*reinterpret_cast<const bf16x8*>(sWv + swz(16 * t + r, 4 * ks + g, ROWB)),
+                     vb[ks], dh[t]);
     }
     const int64_t off = ((int64_t)b * MQ + r) * D + 16 * t + 4 * g;
     const float4 z4 = *reinterpret_cast<const float4*>(a.Z + off);
