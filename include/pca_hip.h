@@ -153,14 +153,19 @@ int pca_cross_entropy(const float* logits, const int64_t* labels, int B, int C,
                       float* stats_out, void* stream);
 
 /* torch.optim.Adam(lr, betas, eps, weight_decay) with COUPLED L2, one fused pass
- * over a flat parameter vector.  replaces: Code/settransformer.py:89-91,108.
- * step_count_dev: device int32 incremented by the kernel (bias correction uses the
- * incremented value) so that a captured graph replays correctly.
- * grad_scale multiplies the gradient first (1/world_size after an all-reduce SUM). */
-int pca_adam_step(float* param, const float* grad, float* exp_avg, float* exp_avg_sq,
+ * over a flat parameter vector.  replaces: Code/settransformer.py:89-91,106,108
+ * (optimizer.zero_grad + optimizer.step).
+ * step_count_dev: device int32[2], zero-initialised by the caller.  [0] is the step
+ *   count: the launch uses [0]+1 for the bias correction and publishes it, so that a
+ *   captured graph replays correctly; [1] is an arrival ticket owned by the kernel
+ *   (zero again when the launch has finished).
+ * grad_scale multiplies the gradient first (1/world_size after an all-reduce SUM).
+ * zero_grad != 0: the gradient vector is cleared in the same pass, ready for the next
+ *   step's accumulation. */
+int pca_adam_step(float* param, float* grad, float* exp_avg, float* exp_avg_sq,
                   int64_t n, float lr, float beta1, float beta2, float eps,
                   float weight_decay, float grad_scale, int32_t* step_count_dev,
-                  void* stream);
+                  int zero_grad, void* stream);
 
 /* ------------------------------------------------------------------------- *
  * Whole-model engine: the train / eval step of Code/settransformer.py:100-108  *

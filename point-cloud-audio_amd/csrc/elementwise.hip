@@ -177,6 +177,25 @@ __global__ __launch_bounds__(256) void k_colsum(const float* __restrict__ X, int
   }
 }
 
+// out[j] (=|+=) sum_i X[i,j] for a few rows: one thread per column, no atomics, no pre-clear
+__global__ __launch_bounds__(256) void k_colsum_small(const float* __restrict__ X, int rows,
+                                                      int cols, float* __restrict__ out,
+                                                      int accumulate) {
+  const int j = blockIdx.x * 256 + threadIdx.x;
+  if (j >= cols) return;
+  float s = accumulate ? out[j] : 0.f;
+  int i = 0;
+  for (; i + 16 <= rows; i += 16) {
+    float v[16];
+#pragma unroll
+    for (int u = 0; u < 16; ++u) v[u] = X[(int64_t)(i + u) * cols + j];
+#pragma unroll
+    for (int u = 0; u < 16; ++u) s += v[u];
+  }
+  for (; i < rows; ++i) s += X[(int64_t)i * cols + j];
+  out[j] = s;
+}
+
 __global__ void k_add_relu(const float* __restrict__ O, const float* __restrict__ Z,
                            float* __restrict__ Y, int64_t n) {
   int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
@@ -268,6 +287,11 @@ int fill_zero(float* dst, int64_t n, hipStream_t st) {
 int colsum(const float* X, int64_t rows, int cols, float* out, int accumulate,
            hipStream_t st) {
   PCA_REQUIRE(X && out && cols > 0 && rows >= 0, "colsum: bad arguments");
+  if (rows > 0 && rows <= 256 && cols >= 64) {       // latency-bound: one launch, no atomics
+    hipLaunchKernelGGL(k_colsum_small, dim3((unsigned)cdiv(cols, 256)), dim3(256), 0, st, X,
+                       (int)rows, cols, out, accumulate);
+    return check_launch("k_colsum_small");
+  }
   if (!accumulate) PCA_TRY(fill_zero(out, cols, st));
   if (rows == 0) return PCA_OK;
   const int rpb = rows * cdiv(cols, 64) < 256 * 512 ? 32 : 256;   // rows per block

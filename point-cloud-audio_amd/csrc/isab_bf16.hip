@@ -89,7 +89,8 @@ int isab_bf16_bwd(const pca_mab_shape& s0, const pca_mab_shape& s1, const float*
                   const void* X, const float* H, const pca_mab_params& p0,
                   const pca_mab_params& p1, const void* saved0, const void* saved1,
                   const void* dY, float* dI, void* dX, const pca_mab_grads& g0,
-                  const pca_mab_grads& g1, void* ws, const IsabImg& im, hipStream_t st) {
+                  const pca_mab_grads& g1, void* ws, const IsabImg& im, hipStream_t st,
+                  Mab0PostJobs* defer) {
   const int d = 128, dk = s0.dk, m = 16;
   Carver c(ws);
   void* ws1 = c.take<char>(mab1_carve_bwd_ws(s1, nullptr, nullptr));
@@ -133,7 +134,7 @@ int isab_bf16_bwd(const pca_mab_shape& s0, const pca_mab_shape& s1, const float*
       PCA_TRY(wgrad_small_f32_launch(w0.dO, w0.Th, Bm, dk, (int64_t)Bm * dk, g0.wv, g0.bv, ts));
   }
   return mab0_bf16_bwd_ex(s0, I, X, p0, saved0, nullptr, dI, dX, dX != nullptr ? 1 : 0, g0, ws0,
-                          PCA_F_SKIP_HEAD | PCA_F_SKIP_WGRAD, st);
+                          PCA_F_SKIP_HEAD | PCA_F_SKIP_WGRAD, st, defer);
 }
 
 }  // namespace pca

@@ -51,11 +51,28 @@ __device__ __forceinline__ bf16x8 tr_frag(const char* img, int t, int lane) {
 //   rows zero) ; GtP[dk][Rp] = K-permuted transpose of G for the backward.
 // blockIdx.y = MAB, blockIdx.x = query row q (blocks beyond m exit).
 // ---------------------------------------------------------------------------------
+constexpr int PREP_SPARE = 16;
 __global__ __launch_bounds__(256) void k_mab0_prep(const Mab0PrepJobs jobs) {
   extern __shared__ float sq[];            // Qp row [d]
   const Mab0PrepJob a = jobs.j[blockIdx.y];
   const int q = blockIdx.x;
-  if (q >= a.m) return;
+  if (q >= a.m) {
+    // spare workgroups: WvT[c][f] = Wv[f][c], WoT[c][f] = Wo[f][c]
+    const int sp = q - a.m;
+    if (sp >= PREP_SPARE || a.WvT == nullptr) return;
+    const int nv = a.d * a.dk, no = a.d * a.d;
+    for (int o = sp * 256 + threadIdx.x; o < nv + no; o += PREP_SPARE * 256) {
+      if (o < nv) {
+        const int c = o / a.d, f = o - c * a.d;
+        a.WvT[o] = a.Wv[f * a.dk + c];
+      } else {
+        const int oo = o - nv;
+        const int c = oo / a.d, f = oo - c * a.d;
+        a.WoT[oo] = a.Wo[f * a.d + c];
+      }
+    }
+    return;
+  }
   const int m = a.m, d = a.d, dq = a.dq, dk = a.dk, h = a.h;
   const int R = h * m;
   for (int f = threadIdx.x; f < d; f += 256) {
@@ -464,7 +481,8 @@ bool mab0_bf16_supported(const pca_mab_shape& s) {
 }
 
 void mab0_collect_prep(const pca_mab_shape& s, const float* I, const pca_mab_params& p,
-                       const Mab0Saved& v, bool training, Mab0PrepJobs* J) {
+                       const Mab0Saved& v, bool training, bool epilogue_images,
+                       Mab0PrepJobs* J) {
   Mab0PrepJob a{};
   a.I = I; a.Wq = p.wq; a.bq = p.bq; a.Wk = p.wk;
   a.m = s.nq; a.d = s.d; a.dq = s.dq; a.dk = s.dk; a.h = s.h;
@@ -473,6 +491,7 @@ void mab0_collect_prep(const pca_mab_shape& s, const float* I, const pca_mab_par
   a.Qp = v.Qp; a.Gf = v.Gf;
   a.Gb = s.dk <= 4 ? nullptr : v.Gb;
   a.GtP = (s.dk <= 4 || !training) ? nullptr : v.GtP;
+  if (epilogue_images) { a.Wv = p.wv; a.Wo = p.wo; a.WvT = v.WvT; a.WoT = v.WoT; }
   J->j[J->n++] = a;
 }
 int mab0_prep_launch(const Mab0PrepJobs& J, hipStream_t st) {
@@ -482,7 +501,10 @@ int mab0_prep_launch(const Mab0PrepJobs& J, hipStream_t st) {
     maxm = J.j[i].m > maxm ? J.j[i].m : maxm;
     maxd = J.j[i].d > maxd ? J.j[i].d : maxd;
   }
-  hipLaunchKernelGGL(k_mab0_prep, dim3(maxm, J.n), dim3(256), maxd * sizeof(float), st, J);
+  bool spare = false;
+  for (int i = 0; i < J.n; ++i) spare = spare || J.j[i].WvT != nullptr;
+  hipLaunchKernelGGL(k_mab0_prep, dim3(maxm + (spare ? PREP_SPARE : 0), J.n), dim3(256),
+                     maxd * sizeof(float), st, J);
   return check_launch("k_mab0_prep");
 }
 
@@ -545,7 +567,7 @@ int mab0_bf16_fwd_ex(const pca_mab_shape& s, const float* I, const void* X,
 
   if (!(flags & PCA_F_PREP_DONE)) {
     Mab0PrepJobs J{};
-    mab0_collect_prep(s, I, p, v, training, &J);
+    mab0_collect_prep(s, I, p, v, training, !(flags & PCA_F_SKIP_EPILOGUE), &J);
     PCA_TRY(mab0_prep_launch(J, st));
   }
   (void)Rpad32;
@@ -583,8 +605,7 @@ int mab0_bf16_fwd_ex(const pca_mab_shape& s, const float* I, const void* X,
     PCA_TRY(check_launch("k_mab0_attn"));
   }
   if (flags & PCA_F_SKIP_EPILOGUE) return PCA_OK;
-  PCA_TRY(transpose_f32(p.wv, v.WvT, d, dk, st));
-  PCA_TRY(transpose_f32(p.wo, v.WoT, d, d, st));
+  // WvT / WoT were written by the spare workgroups of k_mab0_prep
   const size_t el = ((size_t)R * dk + (size_t)m * d) * sizeof(float);
   float* Os = training ? v.O : nullptr;
   float* Zs = training ? v.Z : nullptr;

@@ -64,8 +64,11 @@ __global__ __launch_bounds__(256) void k_mab0_epi_bwd(
     __bf16* __restrict__ dTt,    // [B][dk][Rp] r-permuted
     float* __restrict__ Delta,   // [B][Rp]
     float* __restrict__ LSEp,    // [B][Rp] padded with +1e30
-    int B) {
+    int B, float* __restrict__ zero_ptr, int zero_n) {   // optional: clears the DG accumulator
   extern __shared__ float sm[];
+  if (zero_ptr != nullptr)
+    for (int i = blockIdx.x * 256 + threadIdx.x; i < zero_n; i += gridDim.x * 256)
+      zero_ptr[i] = 0.f;
   float* sdZ = sm;               // [m][d]
   float* sdO = sdZ + m * d;      // [m][d]
   float* sDl = sdO + m * d;      // [Rp] partial Delta
@@ -439,46 +442,60 @@ __device__ __forceinline__ float dot_strided(const float* __restrict__ a, int64_
   return acc;
 }
 
-// stage 1 (grid-parallel): dWk and dQp = dQs + (dG_raw Wk_h^T)
-__global__ __launch_bounds__(256) void k_mab0_post1(
-    const float* __restrict__ dQs, const float* __restrict__ DG, const float* __restrict__ Qp,
-    const float* __restrict__ Wk, int m, int d, int dk, int h, float sl2e,
-    float* __restrict__ dWk, float* __restrict__ dQp) {
-  const int dh = d / h;
+// stage 1 (grid-parallel): dWk and dQp = dQs + (dG_raw Wk_h^T); blockIdx.y = MAB
+__global__ __launch_bounds__(256) void k_mab0_post1(const Mab0PostJobs jobs) {
+  const Mab0PostJob a = jobs.j[blockIdx.y];
+  const int m = a.m, d = a.d, dk = a.dk;
+  const int dh = d / a.h;
   const int o = blockIdx.x * 256 + threadIdx.x;
   if (o < d * dk) {
     const int f = o / dk, c = o - f * dk, j = f / dh;
-    dWk[o] += sl2e * dot_strided(Qp + f, d, DG + (int64_t)j * m * dk + c, dk, m);
+    a.dWk[o] += a.sl2e * dot_strided(a.Qp + f, d, a.DG + (int64_t)j * m * dk + c, dk, m);
   } else if (o < d * dk + m * d) {
     const int oo = o - d * dk;
     const int q = oo / d, f = oo - q * d, j = f / dh;
-    dQp[oo] = dQs[oo] + sl2e * dot_strided(DG + (int64_t)(j * m + q) * dk, 1,
-                                           Wk + (int64_t)f * dk, 1, dk);
+    a.dQp[oo] = a.dQs[oo] + a.sl2e * dot_strided(a.DG + (int64_t)(j * m + q) * dk, 1,
+                                                 a.Wk + (int64_t)f * dk, 1, dk);
   }
 }
 // stage 2: dWq += dQp^T I ; dbq += colsum(dQp) ; dI += dQp Wq
-__global__ __launch_bounds__(256) void k_mab0_post2(
-    const float* __restrict__ dQp, const float* __restrict__ I, const float* __restrict__ Wq,
-    int m, int d, int dq, float* __restrict__ dWq, float* __restrict__ dbq,
-    float* __restrict__ dI) {
+__global__ __launch_bounds__(256) void k_mab0_post2(const Mab0PostJobs jobs) {
+  const Mab0PostJob a = jobs.j[blockIdx.y];
+  const int m = a.m, d = a.d, dq = a.dq;
   const int o = blockIdx.x * 256 + threadIdx.x;
-  const int n1 = d * dq, n2 = n1 + d, n3 = n2 + (dI != nullptr ? m * dq : 0);
+  const int n1 = d * dq, n2 = n1 + d, n3 = n2 + (a.dI != nullptr ? m * dq : 0);
   if (o < n1) {
     const int f = o / dq, c = o - f * dq;
-    dWq[o] += dot_strided(dQp + f, d, I + c, dq, m);
+    a.dWq[o] += dot_strided(a.dQp + f, d, a.I + c, dq, m);
   } else if (o < n2) {
     const int f = o - n1;
     float acc = 0.f;
-    for (int q = 0; q < m; ++q) acc += dQp[q * d + f];
-    dbq[f] += acc;
+    for (int q = 0; q < m; ++q) acc += a.dQp[q * d + f];
+    a.dbq[f] += acc;
   } else if (o < n3) {
     const int oo = o - n2;
     const int q = oo / dq, c = oo - q * dq;
-    dI[oo] += dot_strided(dQp + (int64_t)q * d, 1, Wq + c, dq, d);
+    a.dI[oo] += dot_strided(a.dQp + (int64_t)q * d, 1, a.Wq + c, dq, d);
   }
 }
 
 }  // namespace
+int mab0_post_launch(const Mab0PostJobs& J, hipStream_t st) {
+  if (J.n == 0) return PCA_OK;
+  int n1 = 0, n2 = 0;
+  for (int i = 0; i < J.n; ++i) {
+    const Mab0PostJob& a = J.j[i];
+    const int e1 = a.d * a.dk + a.m * a.d, e2 = a.d * a.dq + a.d + (a.dI ? a.m * a.dq : 0);
+    n1 = e1 > n1 ? e1 : n1;
+    n2 = e2 > n2 ? e2 : n2;
+  }
+  hipStream_t ts = terminal_stream(st);     // off the critical path
+  hipLaunchKernelGGL(k_mab0_post1, dim3((unsigned)cdiv(n1, 256), J.n), dim3(256), 0, ts, J);
+  PCA_TRY(check_launch("k_mab0_post1"));
+  hipLaunchKernelGGL(k_mab0_post2, dim3((unsigned)cdiv(n2, 256), J.n), dim3(256), 0, ts, J);
+  return check_launch("k_mab0_post2");
+}
+
 size_t mab0_carve_bwd_ws(const pca_mab_shape& s, Mab0BwdWs* out, void* base) {
   Carver c(base);
   Mab0BwdWs w;
@@ -514,7 +531,7 @@ int mab0_bf16_bwd(const pca_mab_shape& s, const float* I, const void* X,
 int mab0_bf16_bwd_ex(const pca_mab_shape& s, const float* I, const void* X,
                      const pca_mab_params& p, const void* saved, const float* dH, float* dI,
                      void* dX, int dk_accumulate, const pca_mab_grads& gr, void* ws, int flags,
-                     hipStream_t st) {
+                     hipStream_t st, Mab0PostJobs* defer) {
   Mab0Saved v;
   mab0_carve_saved(s, &v, const_cast<void*>(saved));
   Mab0BwdWs w;
@@ -535,13 +552,15 @@ int mab0_bf16_bwd_ex(const pca_mab_shape& s, const float* I, const void* X,
   } else if (m > 2)
     hipLaunchKernelGGL((k_mab0_epi_bwd<8>), dim3(s.B), dim3(256), el, st, dH, v.Z, v.T, v.LSE, p.wo,
                        p.wv, m, d, dk, h, Rp, w.dZ, w.dO, w.Th, small ? w.dTf : nullptr,
-                       small ? nullptr : w.dTb, small ? nullptr : w.dTt, w.Delta, w.LSEp, s.B);
+                       small ? nullptr : w.dTb, small ? nullptr : w.dTt, w.Delta, w.LSEp, s.B,
+                       w.DG, Rp * dk);
   else
     hipLaunchKernelGGL((k_mab0_epi_bwd<1>), dim3(s.B), dim3(256), el, st, dH, v.Z, v.T, v.LSE, p.wo,
                        p.wv, m, d, dk, h, Rp, w.dZ, w.dO, w.Th, small ? w.dTf : nullptr,
-                       small ? nullptr : w.dTb, small ? nullptr : w.dTt, w.Delta, w.LSEp, s.B);
+                       small ? nullptr : w.dTb, small ? nullptr : w.dTt, w.Delta, w.LSEp, s.B,
+                       w.DG, Rp * dk);
   PCA_TRY(check_launch("k_mab0_epi_bwd"));
-  if (!(flags & PCA_F_SKIP_WGRAD)) PCA_TRY(fill_zero(w.DG, (int64_t)Rp * dk, st));
+  // (with head_done the caller's k_mid_bwd has cleared DG)
 
   if (small) {
     hipLaunchKernelGGL(k_mab0_bwd_small, dim3(s.B), dim3(256), 0, st,
@@ -595,14 +614,16 @@ int mab0_bf16_bwd_ex(const pca_mab_shape& s, const float* I, const void* X,
       PCA_TRY(wgrad_small_f32_launch(w.dO, w.Th, Bm, dk, (int64_t)Bm * dk, gr.wv, gr.bv, ts));
   }
   if (!head_done) PCA_TRY(colsum(w.dO, s.B, m * d, w.dQs, 0, st));   // sum over sets
-  hipStream_t ts = terminal_stream(st);     // dWk, dWq, dbq, dI: off the critical path
-  hipLaunchKernelGGL(k_mab0_post1, dim3((unsigned)cdiv(d * dk + m * d, 256)), dim3(256), 0, ts,
-                     w.dQs, w.DG, v.Qp, p.wk, m, d, dk, h, sl2e, gr.wk, w.dQp);
-  PCA_TRY(check_launch("k_mab0_post1"));
-  hipLaunchKernelGGL(k_mab0_post2,
-                     dim3((unsigned)cdiv(d * s.dq + d + (dI ? m * s.dq : 0), 256)), dim3(256), 0,
-                     ts, w.dQp, I, p.wq, m, d, s.dq, gr.wq, gr.bq, dI);
-  return check_launch("k_mab0_post2");
+  Mab0PostJob pj{w.dQs, w.DG, v.Qp, p.wk, I, p.wq, gr.wk, w.dQp, gr.wq, gr.bq, dI,
+                 m, d, dk, s.dq, h, sl2e};
+  if (defer != nullptr) {
+    PCA_REQUIRE(defer->n < 3, "mab0_bf16_bwd: post-job table full");
+    defer->j[defer->n++] = pj;
+    return PCA_OK;
+  }
+  Mab0PostJobs one{};
+  one.j[one.n++] = pj;
+  return mab0_post_launch(one, st);
 }
 
 }  // namespace pca

@@ -41,13 +41,18 @@ struct Mab0PrepJob {
   float sl2e;
   float *Qp, *Gf;
   __bf16 *Gb, *GtP;
+  // epilogue weights transposed to [in][out] fp32 by spare workgroups of the same launch
+  // (null when the epilogue runs elsewhere, e.g. inside k_mid_fwd)
+  const float *Wv, *Wo;
+  float *WvT, *WoT;
 };
 struct Mab0PrepJobs {
   Mab0PrepJob j[3];
   int n;
 };
 void mab0_collect_prep(const pca_mab_shape& s, const float* I, const pca_mab_params& p,
-                       const Mab0Saved& v, bool training, Mab0PrepJobs* J);
+                       const Mab0Saved& v, bool training, bool epilogue_images,
+                       Mab0PrepJobs* J);
 int mab0_prep_launch(const Mab0PrepJobs& J, hipStream_t st);
 size_t mab0_carve_saved(const pca_mab_shape& s, Mab0Saved* out, void* base);
 
@@ -232,10 +237,24 @@ int mab0_bf16_bwd(const pca_mab_shape& s, const float* I, const void* X,
                   const pca_mab_params& p, const void* saved, const float* dH, float* dI,
                   void* dX, int dk_accumulate, const pca_mab_grads& gr, void* ws,
                   hipStream_t st);
+// shared-query parameter gradients (dWk, dWq, dbq, dI) of up to 3 MABs: tiny, latency-bound
+// kernels, so callers may collect them and run ONE pair of launches at the end of a phase
+struct Mab0PostJob {
+  const float *dQs, *DG, *Qp, *Wk, *I, *Wq;
+  float *dWk, *dQp, *dWq, *dbq, *dI;
+  int m, d, dk, dq, h;
+  float sl2e;
+};
+struct Mab0PostJobs {
+  Mab0PostJob j[3];
+  int n;
+};
+int mab0_post_launch(const Mab0PostJobs& J, hipStream_t st);
+// `defer` non-null: the post job is appended there instead of being launched
 int mab0_bf16_bwd_ex(const pca_mab_shape& s, const float* I, const void* X,
                      const pca_mab_params& p, const void* saved, const float* dH, float* dI,
                      void* dX, int dk_accumulate, const pca_mab_grads& gr, void* ws, int flags,
-                     hipStream_t st);
+                     hipStream_t st, Mab0PostJobs* defer = nullptr);
 // per-block dispatch (api_mab.hip): kind 0 exact fp32, 1 fused mab1, 2 fused mab0
 int mab_kind(const pca_mab_shape& s);
 size_t mab_saved_bytes_any(const pca_mab_shape& s);
@@ -263,7 +282,8 @@ int isab_bf16_bwd(const pca_mab_shape& s0, const pca_mab_shape& s1, const float*
                   const void* X, const float* H, const pca_mab_params& p0,
                   const pca_mab_params& p1, const void* saved0, const void* saved1,
                   const void* dY, float* dI, void* dX, const pca_mab_grads& g0,
-                  const pca_mab_grads& g1, void* ws, const IsabImg& im, hipStream_t st);
+                  const pca_mab_grads& g1, void* ws, const IsabImg& im, hipStream_t st,
+                  Mab0PostJobs* defer = nullptr);
 // classifier head (train_ops.hip)
 int cls_train_head(const float* P, const float* Wc, const float* bc, const int64_t* labels,
                    int B, int d, int C, float grad_scale, float* logits, float* dlogits,

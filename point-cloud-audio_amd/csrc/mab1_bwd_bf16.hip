@@ -848,14 +848,17 @@ int mab1_bf16_bwd_ex(const pca_mab_shape& s, const void* X, const float* H,
   }
   PCA_TRY(rc);
   if (nparts_out != nullptr) *nparts_out = fuse ? a.tiles_per_set / a.tpw : 0;
-  // ---- reductions over points (one launch for dWo / dWq) ----
+  // ---- reductions over points (one launch for dWo / dWq when both operands are bf16) ----
+  // 512 rows per workgroup: the fp32 atomics of the [128 x 128] result cost ~1 lane-op per
+  // clock per L2 channel, so fewer, longer workgroups win (256 rows: +50 %, 64 rows: 4x)
   const int rows_per_wg = 512;
+  const bool wq_big = !small;
   {
     WgradJobs jobs{};
-    jobs.j[0] = WgradJob{w.dZ, v.OS, gr.wo, gr.bo, M, 0, 128};
-    jobs.n = 1;
+    jobs.j[jobs.n++] = WgradJob{w.dZ, v.OS, gr.wo, gr.bo, M, 0, 128};
+    if (wq_big && abf) jobs.j[jobs.n++] = WgradJob{w.dQp, X, gr.wq, gr.bq, M, 0, 128};
     hipStream_t ts = terminal_stream(st);
-    ProfScope ps(PCA_K_WGRAD, ts, 2.0 * M * d * d, 4.0 * M * d);
+    ProfScope ps(PCA_K_WGRAD, ts, 2.0 * jobs.n * M * d * d, 4.0 * jobs.n * M * d);
     PCA_TRY(wgrad128_launch(jobs, true, true, rows_per_wg, ts));
     ps.end();
   }
@@ -866,13 +869,13 @@ int mab1_bf16_bwd_ex(const pca_mab_shape& s, const void* X, const float* H,
                        w.dQp, reinterpret_cast<const float*>(X), M, s.dq, 128, (int64_t)0, gr.wq,
                        gr.bq);
     PCA_TRY(check_launch("k_wgrad_small"));
-  } else {
+  } else if (!abf) {
     WgradJobs jobs{};
     jobs.j[0] = WgradJob{w.dQp, X, gr.wq, gr.bq, M, 0, 128};
     jobs.n = 1;
     hipStream_t ts = terminal_stream(st);
     ProfScope ps(PCA_K_WGRAD, ts, 2.0 * M * d * d, 6.0 * M * d);
-    PCA_TRY(wgrad128_launch(jobs, true, abf, rows_per_wg, ts));
+    PCA_TRY(wgrad128_launch(jobs, true, false, rows_per_wg, ts));
     ps.end();
   }
   if (!fuse) {

@@ -192,12 +192,12 @@ int forward(const pca_st_config& c, const Layout& L, const Shapes& s, const floa
       if (w.fused[li]) {
         Mab0Saved v;
         mab0_carve_saved(s.m0[li], &v, w.saved[2 * li]);
-        mab0_collect_prep(s.m0[li], p + L.I[li], params_at(p, L.mab0[li]), v, true, &MJ);
+        mab0_collect_prep(s.m0[li], p + L.I[li], params_at(p, L.mab0[li]), v, true, false, &MJ);
       }
     if (mab_kind(s.pma) == 2) {
       Mab0Saved v;
       mab0_carve_saved(s.pma, &v, w.saved[4]);
-      mab0_collect_prep(s.pma, p + L.S, params_at(p, L.pma), v, true, &MJ);
+      mab0_collect_prep(s.pma, p + L.S, params_at(p, L.pma), v, true, true, &MJ);
     }
     PCA_TRY(mab0_prep_launch(MJ, st));
   }
@@ -289,6 +289,9 @@ int pca_st_train_fwd_bwd(const pca_st_config* c, const float* params, const floa
     ~SideGuard() { pca::terminal_join(st); pca::terminal_enable(false); }
   } side_guard(st);
 
+  // shared-query gradients of the fused blocks of this call: one pair of launches at the end
+  // (their inputs live in per-block workspaces, which stay untouched until then)
+  pca::Mab0PostJobs posts{};
   if (phase != 1) {
     PCA_TRY(pca::forward(*c, L, s, p, X, w, true, st));
     // dec.1 (Linear) + mean cross-entropy, forward and backward, two launches
@@ -296,6 +299,11 @@ int pca_st_train_fwd_bwd(const pca_st_config* c, const float* params, const floa
                                 w.logits, w.dlogits, w.dP, g + L.wc, g + L.bc, loss_out, stats,
                                 w.clsws, st));
     // dec.0 (PMA)
+    if (pca::mab_kind(s.pma) == 2)
+      PCA_TRY(pca::mab0_bf16_bwd_ex(s.pma, p + L.S, w.Y[1], pca::params_at(p, L.pma),
+                                    w.saved[4], w.dP, g + L.S, w.dY2, 0,
+                                    pca::grads_at(g, L.pma), w.scratch, 0, st, &posts));
+    else
     PCA_TRY(pca::mab_bwd_any(s.pma, p + L.S, w.Y[1], pca::params_at(p, L.pma), w.saved[4],
                              w.dP, g + L.S, w.dY2, 0, pca::grads_at(g, L.pma), w.scratch,
                              st));
@@ -305,7 +313,7 @@ int pca_st_train_fwd_bwd(const pca_st_config* c, const float* params, const floa
                                  pca::params_at(p, L.mab0[1]), pca::params_at(p, L.mab1[1]),
                                  w.saved[2], w.saved[3], w.dY2, g + L.I[1], w.dY1,
                                  pca::grads_at(g, L.mab0[1]), pca::grads_at(g, L.mab1[1]),
-                                 w.scratch_bw[1], w.img[1], st));
+                                 w.scratch_bw[1], w.img[1], st, &posts));
     } else {
     PCA_TRY(pca::mab_bwd_any(s.m1[1], w.Y[0], w.H[1], pca::params_at(p, L.mab1[1]),
                              w.saved[3], w.dY2, w.dY1, w.dH, 0, pca::grads_at(g, L.mab1[1]),
@@ -322,7 +330,7 @@ int pca_st_train_fwd_bwd(const pca_st_config* c, const float* params, const floa
                                  pca::params_at(p, L.mab0[0]), pca::params_at(p, L.mab1[0]),
                                  w.saved[0], w.saved[1], w.dY1, g + L.I[0], nullptr,
                                  pca::grads_at(g, L.mab0[0]), pca::grads_at(g, L.mab1[0]),
-                                 w.scratch_bw[0], w.img[0], st));
+                                 w.scratch_bw[0], w.img[0], st, &posts));
     } else {
     PCA_TRY(pca::mab_bwd_any(s.m1[0], X, w.H[0], pca::params_at(p, L.mab1[0]), w.saved[1],
                              w.dY1, nullptr, w.dH, 0, pca::grads_at(g, L.mab1[0]),
@@ -332,6 +340,6 @@ int pca_st_train_fwd_bwd(const pca_st_config* c, const float* params, const floa
                              pca::grads_at(g, L.mab0[0]), w.scratch_bw[0], st));
     }
   }
-  return PCA_OK;
+  return pca::mab0_post_launch(posts, st);
 }
 }

@@ -175,21 +175,27 @@ __global__ __launch_bounds__(128) void k_cls_wgrad(
   }
 }
 
-__global__ void k_inc_step(int32_t* step) { *step += 1; }
-
-__global__ __launch_bounds__(256) void k_adam(float* __restrict__ p,
-                                              const float* __restrict__ g,
+// step[0] = optimiser step count, step[1] = arrival ticket (zero between launches).  Every
+// workgroup reads step[0] before it draws its ticket; the workgroup drawing the last ticket
+// publishes step[0] + 1 and clears the ticket, so the count advances inside this launch
+// (graph replays stay correct) without a second kernel.
+__global__ __launch_bounds__(256) void k_adam(float* __restrict__ p, float* __restrict__ g,
                                               float* __restrict__ m, float* __restrict__ v,
                                               int64_t n, float lr, float b1, float b2,
                                               float eps, float wd, float gscale,
-                                              const int32_t* __restrict__ step) {
-  const float t = (float)(*step);
+                                              int32_t* __restrict__ step, int zero_grad) {
+  __shared__ int s_t;
+  if (threadIdx.x == 0) s_t = step[0] + 1;
+  __syncthreads();
+  const int ti = s_t;
+  const float t = (float)ti;
   const float bc1 = 1.f - powf(b1, t);
   const float bc2 = 1.f - powf(b2, t);
   const float step_size = lr / bc1;
   const float inv_sqrt_bc2 = 1.f / sqrtf(bc2);
   int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
   const int64_t stride = (int64_t)gridDim.x * blockDim.x;
+#pragma unroll 4
   for (; i < n; i += stride) {
     const float w = p[i];
     const float gi = g[i] * gscale + wd * w;         // coupled L2 (torch.optim.Adam)
@@ -199,6 +205,14 @@ __global__ __launch_bounds__(256) void k_adam(float* __restrict__ p,
     v[i] = vi;
     const float denom = sqrtf(vi) * inv_sqrt_bc2 + eps;
     p[i] = w - step_size * (mi / denom);
+    if (zero_grad) g[i] = 0.f;
+  }
+  if (threadIdx.x == 0) {
+    const int ticket = atomicAdd(&step[1], 1);
+    if (ticket == (int)gridDim.x - 1) {
+      step[1] = 0;
+      step[0] = ti;
+    }
   }
 }
 
@@ -235,22 +249,20 @@ int pca_cross_entropy(const float* logits, const int64_t* labels, int B, int C,
   return pca::check_launch("k_cross_entropy");
 }
 
-int pca_adam_step(float* param, const float* grad, float* exp_avg, float* exp_avg_sq,
-                  int64_t n, float lr, float beta1, float beta2, float eps,
-                  float weight_decay, float grad_scale, int32_t* step_count_dev,
-                  void* stream) {
+int pca_adam_step(float* param, float* grad, float* exp_avg, float* exp_avg_sq, int64_t n,
+                  float lr, float beta1, float beta2, float eps, float weight_decay,
+                  float grad_scale, int32_t* step_count_dev, int zero_grad, void* stream) {
   PCA_REQUIRE(param && grad && exp_avg && exp_avg_sq && step_count_dev,
               "adam_step: null pointer");
   PCA_REQUIRE(n >= 0, "adam_step: n=%lld", (long long)n);
   hipStream_t st = pca::as_stream(stream);
-  hipLaunchKernelGGL(pca::k_inc_step, dim3(1), dim3(1), 0, st, step_count_dev);
-  PCA_TRY(pca::check_launch("k_inc_step"));
-  if (n == 0) return PCA_OK;
-  int64_t blocks = pca::cdiv(n, 256);
-  if (blocks > 2048) blocks = 2048;
+  // few, longer workgroups: the arrival tickets are serialised atomics on one address
+  int64_t blocks = pca::cdiv(n, 256 * 8);
+  if (blocks > 1024) blocks = 1024;
+  if (blocks < 1) blocks = 1;                      // n == 0 still advances the step count
   hipLaunchKernelGGL(pca::k_adam, dim3((unsigned)blocks), dim3(256), 0, st, param, grad,
                      exp_avg, exp_avg_sq, n, lr, beta1, beta2, eps, weight_decay, grad_scale,
-                     step_count_dev);
+                     step_count_dev, zero_grad);
   return pca::check_launch("k_adam");
 }
 }

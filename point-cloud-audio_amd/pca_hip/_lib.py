@@ -75,7 +75,7 @@ SIGNATURES = {
     "pca_cross_entropy": (C.c_int, [c_fp, c_i64p, C.c_int, C.c_int, C.c_float, c_fp, c_fp,
                                     c_fp, c_vp]),
     "pca_adam_step": (C.c_int, [c_fp, c_fp, c_fp, c_fp, C.c_int64, C.c_float, C.c_float,
-                                C.c_float, C.c_float, C.c_float, C.c_float, c_vp, c_vp]),
+                                C.c_float, C.c_float, C.c_float, C.c_float, c_vp, C.c_int, c_vp]),
     "pca_st_param_count": (C.c_int64, [C.POINTER(StConfig)]),
     "pca_st_bucket_split": (C.c_int64, [C.POINTER(StConfig)]),
     "pca_st_ws_bytes": (C.c_size_t, [C.POINTER(StConfig), C.c_int]),

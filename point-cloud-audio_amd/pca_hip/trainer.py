@@ -171,8 +171,9 @@ class Trainer:
     def __init__(self, model, dataset, batch_size: int, lr: float = 1e-3,
                  weight_decay: float = 1e-3, betas=(0.9, 0.999), eps: float = 1e-8,
                  mode: int = _lib.MODE_F32, use_graph: bool = True, seed: int = 0,
-                 shuffle: bool = True, process_group=None):
+                 shuffle: bool = True, process_group=None, keep_grads: bool = False):
         self.ds = dataset
+        self.keep_grads = keep_grads    # True: gradients of the last step stay readable
         self.B = int(batch_size)
         self.N = int(dataset.num_points)
         self.eng = STEngine(model, self.B, self.N, mode, training=True)
@@ -188,7 +189,7 @@ class Trainer:
         with torch.cuda.device(self.dev):
             self.m = torch.zeros(n, dtype=torch.float32, device=self.dev)
             self.v = torch.zeros(n, dtype=torch.float32, device=self.dev)
-            self.step_count = torch.zeros(1, dtype=torch.int32, device=self.dev)
+            self.step_count = torch.zeros(2, dtype=torch.int32, device=self.dev)  # [count, ticket]
             self.idx = torch.zeros(self.B, dtype=torch.int64, device=self.dev)
             self.X = torch.empty((self.B, self.N, self.eng.cfg.din), dtype=torch.float32,
                                  device=self.dev)
@@ -207,7 +208,8 @@ class Trainer:
     # ---- the three device segments of a step ---------------------------------------
     def _seg0(self):     # pack + zero grads + forward + loss + backward(dec, enc.1)
         self.ds.batch(self.idx, out=self.X, labels_out=self.labels)
-        self.eng.grads.zero_()
+        if self.keep_grads:           # otherwise the Adam pass leaves them cleared
+            self.eng.grads.zero_()
         self.eng.fwd_bwd(self.X, self.labels, phase=0)
 
     def _seg1(self):     # backward(enc.0)
@@ -218,7 +220,8 @@ class Trainer:
         check(lib().pca_adam_step(e.flat.data_ptr(), e.grads.data_ptr(), self.m.data_ptr(),
                                   self.v.data_ptr(), e.flat.numel(), self.lr, self.betas[0],
                                   self.betas[1], self.eps, self.wd, 1.0 / self.world,
-                                  self.step_count.data_ptr(), e._stream()), "pca_adam_step")
+                                  self.step_count.data_ptr(), int(not self.keep_grads),
+                                  e._stream()), "pca_adam_step")
 
     def _capture(self):
         """Warm up eagerly on a side stream, then capture the segments."""

@@ -15,6 +15,6 @@ for s in range(12):
     tr.step()
     if sync:
         torch.cuda.synchronize()
-        print(s, float(tr.eng.loss), tr.eng.stats.tolist(), int(tr.step_count), float(tr.eng.flat.abs().max()), float(tr.eng.grads.abs().max()))
+        print(s, float(tr.eng.loss), tr.eng.stats.tolist(), int(tr.step_count[0]), float(tr.eng.flat.abs().max()), float(tr.eng.grads.abs().max()))
 torch.cuda.synchronize()
-print("final", float(tr.eng.loss), tr.eng.stats.tolist(), int(tr.step_count))
+print("final", float(tr.eng.loss), tr.eng.stats.tolist(), int(tr.step_count[0]))

@@ -56,3 +56,55 @@ def labels(seed: int, B: int, C: int) -> np.ndarray:
 
 CKPT_2D_N = [1, 51, 501, 1025]
 CKPT_3D_N = [1, 2551, 5120, 10240]
+
+
+# --------------------------------------------------------------------------- #
+# accuracy-parity corpus (SURVEY.md section 8d "Accuracy parity")               #
+# --------------------------------------------------------------------------- #
+ACC = dict(C=10, clips_per_class=5, seconds=0.5, fs=44100, n_fft=1024, B=128, epochs=46,
+           d=128, h=4, m=16, lr=1e-3, wd=1e-3, seed=4242, init_seed=77)
+
+
+def level_clip(clip_id: int, cls: int, seconds: float, fs: int) -> np.ndarray:
+    """Class-conditional clip whose class is readable from set-level statistics: white noise
+    at -3 dB per class index.  (SURVEY.md 8d's harmonic clips keep the reference ST on the
+    ln(C) loss plateau for thousands of steps - measured - which makes an accuracy comparison
+    vacuous; the loudness classes are learnt within a few hundred steps.)"""
+    rng = np.random.Generator(np.random.PCG64(5000 + clip_id))
+    L = int(round(seconds * fs))
+    return (0.5 * 10.0 ** (-0.15 * cls) * rng.standard_normal(L)).astype(np.float32)
+
+
+def accuracy_corpus():
+    """ESC-shaped synthetic corpus at the cfg1/2 framing (n_fft 1024, hop 512, Nyquist
+    dropped: F = 512 points per set, one set per frame).  Clip j of class c is
+    ``level_clip(clip_id=5c+j, cls=c)``; the last clip of every class is the test clip
+    (80/20 split by clip, Code/data_processing.py:40-65).  Built with the CPU oracle's
+    float64 STFT so that the reference (fixture time) and the HIP path (test time) train on
+    identical arrays.  Returns dict(x_train [F,T], y_train [T], x_test, y_test, farr [F])."""
+    from oracle import st_oracle as so
+    a = ACC
+    xs = {"train": [], "test": []}
+    ys = {"train": [], "test": []}
+    for c in range(a["C"]):
+        for j in range(a["clips_per_class"]):
+            w = level_clip(a["clips_per_class"] * c + j, c, a["seconds"], a["fs"])
+            s = so.stft_logmag(w, a["n_fft"], drop_nyquist=True)
+            part = "test" if j == a["clips_per_class"] - 1 else "train"
+            xs[part].append(s)
+            ys[part].append(np.full(s.shape[1], c, dtype=np.int64))
+    F = a["n_fft"] // 2
+    farr = (np.linspace(0, a["fs"] / 2, F + 1) / a["fs"])[:F]
+    return dict(x_train=np.concatenate(xs["train"], axis=1), y_train=np.concatenate(ys["train"]),
+                x_test=np.concatenate(xs["test"], axis=1), y_test=np.concatenate(ys["test"]),
+                farr=farr)
+
+
+def agreement_sets(seed: int, n: int, N: int, din: int, chunk: int = 100):
+    """Yield (start, X[chunk, N, din]) blocks of the >= 10 000 seeded synthetic sets of the
+    weights->predictions agreement test; block i uses seed ``seed + i``."""
+    i = 0
+    for s in range(0, n, chunk):
+        b = min(chunk, n - s)
+        yield s, pc_input(seed + i, b, N, din)
+        i += 1

@@ -1,0 +1,118 @@
+"""Accuracy parity of the HIP path against fixtures made by the REAL
+reference on CPU (tests/golden/make_accuracy.py):
+
+(i)  weights -> predictions: identical weights, >= 10 000 seeded synthetic sets per model;
+     argmax agreement >= 99.8 % and, in fp32 mode, max|dlogit| <= 1e-3 * max|logit|;
+(ii) train from scratch: same initial weights, same corpus, same batch order, same number of
+     Adam steps; early loss curve and final test accuracy against the reference's.
+"""
+import os
+
+import numpy as np
+import pytest
+import torch
+
+import inputs as gi
+from util import T
+
+pytestmark = pytest.mark.gpu
+HERE = os.path.dirname(os.path.abspath(__file__))
+
+
+def _npz(name):
+    path = os.path.join(HERE, "golden", name)
+    if not os.path.exists(path):
+        pytest.skip(f"{name} not generated")
+    return np.load(path)
+
+
+@pytest.fixture(scope="module")
+def dev():
+    return torch.device("cuda", 0)
+
+
+def _agreement(net, ref_logits, seed, n, N, din, mode, dev, chunk=100):
+    from pca_hip import trainer
+    eng = trainer.STEngine(net, chunk, N, mode, training=False)
+    agree, worst, scale = 0, 0.0, float(np.abs(ref_logits).max())
+    for s, X in gi.agreement_sets(seed, n, N, din, chunk):
+        lg = eng.forward(T(X, dev)).cpu().numpy()
+        ref = ref_logits[s:s + chunk]
+        agree += int((lg.argmax(1) == ref.argmax(1)).sum())
+        worst = max(worst, float(np.abs(lg - ref).max()))
+    return agree / n, worst / scale
+
+
+@pytest.mark.parametrize("tag,N,din,seed", [("fst", 1025, 2, 9000), ("3st", 5120, 3, 9500)])
+def test_shipped_weights_agreement(tag, N, din, seed, dev, golden_ckpt):
+    """Shipped FST / 3ST weights on 10 000 synthetic sets each (exact fp32 path: the shipped
+    architecture d=64, dh=8, m=64 has no fused bf16 kernels)."""
+    import models
+    from pca_hip import _lib
+    ref = _npz("golden_agree.npz")[f"{tag}/logits"]
+    net = models.ST(dim_input=din, num_outputs=1, dim_output=10, num_inds=64, dim_hidden=64,
+                    num_heads=8).to(dev)
+    sd = {k[len("module."):] if k.startswith("module.") else k: T(v)
+          for k, v in golden_ckpt.sub(f"{tag}/p/").items()}     # saved from a DP-wrapped model
+    net.load_state_dict(sd)
+    frac, rel = _agreement(net, ref, seed, ref.shape[0], N, din, _lib.MODE_F32, dev)
+    print(f"{tag}: agreement {frac:.5f}, max|dlogit|/max|logit| {rel:.2e}")
+    assert ref.shape[0] >= 10000
+    assert frac >= 0.998
+    assert rel <= 1e-3
+
+
+@pytest.mark.parametrize("mode", ["f32", "bf16"])
+def test_trained_cfg1_weights_agreement(mode, dev):
+    """The reference-trained cfg1/2 model (d=128, h=4, m=16) on 10 000 synthetic sets, in the
+    exact fp32 mode and through the fused bf16 MFMA kernels."""
+    import models
+    from pca_hip import _lib
+    g = _npz("golden_acc_train.npz")
+    ref = _npz("golden_agree.npz")["cfg1/logits"]
+    a = gi.ACC
+    net = models.ST(dim_input=2, num_outputs=1, dim_output=a["C"], num_inds=a["m"],
+                    dim_hidden=a["d"], num_heads=a["h"]).to(dev)
+    net.load_state_dict({k[len("final/"):]: T(g[k]) for k in g.files if k.startswith("final/")})
+    m = _lib.MODE_F32 if mode == "f32" else _lib.MODE_BF16
+    frac, rel = _agreement(net, ref, 9900, ref.shape[0], 512, 2, m, dev)
+    print(f"cfg1 {mode}: agreement {frac:.5f}, max|dlogit|/max|logit| {rel:.2e}")
+    assert frac >= 0.998
+    if mode == "f32":
+        assert rel <= 1e-3
+
+
+@pytest.mark.parametrize("mode", ["f32", "bf16"])
+def test_train_from_scratch_accuracy(mode, dev):
+    import dataset
+    import models
+    from pca_hip import _lib, trainer
+    g = _npz("golden_acc_train.npz")
+    a = gi.ACC
+    cp = gi.accuracy_corpus()
+    # the regenerated corpus must be the one the reference trained on
+    np.testing.assert_allclose(cp["x_train"][::97, ::211], g["corpus_probe"], rtol=0, atol=2e-6)
+    net = models.ST(dim_input=2, num_outputs=1, dim_output=a["C"], num_inds=a["m"],
+                    dim_hidden=a["d"], num_heads=a["h"]).to(dev)
+    net.load_state_dict({k[len("init/"):]: T(g[k]) for k in g.files if k.startswith("init/")})
+    ds = dataset.ESC_pc(cp["x_train"], cp["y_train"], cp["farr"], device=dev)
+    m = _lib.MODE_F32 if mode == "f32" else _lib.MODE_BF16
+    tr = trainer.Trainer(net, ds, a["B"], lr=a["lr"], weight_decay=a["wd"], mode=m,
+                         seed=a["seed"], shuffle=True)
+    steps = int(g["steps"])
+    losses = np.zeros(steps)
+    for s in range(steps):
+        tr.step()
+        losses[s] = float(tr.eng.loss)
+    ref_losses = g["losses"]
+    early = 25
+    tol = 2e-3 if mode == "f32" else 3e-2
+    assert np.abs(losses[:early] - ref_losses[:early]).max() < tol, \
+        (losses[:early], ref_losses[:early])
+    dt = dataset.ESC_pc(cp["x_test"], cp["y_test"], cp["farr"], device=dev)
+    acc, n = trainer.evaluate(net, dt, 110, m)
+    ref_acc = float(g["test_acc"])
+    print(f"{mode}: test accuracy {acc:.4f} (reference {ref_acc:.4f}) over {n} sets; "
+          f"final loss {losses[-10:].mean():.4f} (reference {ref_losses[-10:].mean():.4f})")
+    assert n == cp["x_test"].shape[1]
+    assert abs(acc - ref_acc) <= float(os.environ.get("PCA_ACC_TOL", "0.002")) + 1e-9

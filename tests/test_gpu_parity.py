@@ -284,15 +284,15 @@ def test_cross_entropy_and_adam(dev):
     pd = p.clone().to(dev)
     m = torch.zeros(n, device=dev)
     v = torch.zeros(n, device=dev)
-    step = torch.zeros(1, dtype=torch.int32, device=dev)
+    step = torch.zeros(2, dtype=torch.int32, device=dev)       # [count, ticket]
     L = _lib.lib()
     for it in range(5):
         gr = torch.randn(n, generator=g)
         opt.step(P, {"w": gr})
         gd = gr.to(dev)
         _lib.check(L.pca_adam_step(pd.data_ptr(), gd.data_ptr(), m.data_ptr(), v.data_ptr(), n,
-                                   1e-3, 0.9, 0.999, 1e-8, 1e-3, 1.0, step.data_ptr(), None))
-    assert int(step) == 5
+                                   1e-3, 0.9, 0.999, 1e-8, 1e-3, 1.0, step.data_ptr(), 0, None))
+    assert step.tolist() == [5, 0]
     close(pd, P["w"], 1e-6, "adam params")
 
 
@@ -309,7 +309,7 @@ def test_train_trajectory_golden(dev, golden_train):
     params = list(net.parameters())
     ms = [torch.zeros_like(p) for p in params]
     vs = [torch.zeros_like(p) for p in params]
-    stepc = [torch.zeros(1, dtype=torch.int32, device=dev) for _ in params]
+    stepc = [torch.zeros(2, dtype=torch.int32, device=dev) for _ in params]
     L = _lib.lib()
     losses = []
     for s in range(steps):
@@ -321,7 +321,7 @@ def test_train_trajectory_golden(dev, golden_train):
         for p, mm, vv, sc in zip(params, ms, vs, stepc):
             _lib.check(L.pca_adam_step(p.data_ptr(), p.grad.contiguous().data_ptr(),
                                        mm.data_ptr(), vv.data_ptr(), p.numel(), 1e-3, 0.9,
-                                       0.999, 1e-8, 1e-3, 1.0, sc.data_ptr(), None))
+                                       0.999, 1e-8, 1e-3, 1.0, sc.data_ptr(), 0, None))
         losses.append(float(loss))
     np.testing.assert_allclose(losses, golden_train["losses"], rtol=0, atol=5e-4)
     for k, v in net.state_dict().items():
@@ -415,7 +415,7 @@ def test_trainer_full_size_graph_vs_eager_vs_oracle(dev):
         torch.manual_seed(1)
         net = models.ST(dim_input=2, dim_output=50, num_inds=16, dim_hidden=128,
                         num_heads=4).to(dev)
-        return net, trainer.Trainer(net, ds, 128, use_graph=graph, seed=1)
+        return net, trainer.Trainer(net, ds, 128, use_graph=graph, seed=1, keep_grads=True)
 
     net_g, tr_g = make(True)
     net_e, tr_e = make(False)
