@@ -179,6 +179,9 @@ def main():
         elapsed = float(t)
     loss_sum, correct = tr.read_stats()
     n_seen = (args.warmup + args.steps) * cfg["B"] * world
+    if not np.isfinite(loss_sum) or not bool(torch.isfinite(tr.eng.flat).all()):
+        raise SystemExit(f"bench: non-finite training state (loss sum {loss_sum}): the timed "
+                         "steps are invalid")
 
     sets_per_s = args.steps * cfg["B"] * world / elapsed
     out = {

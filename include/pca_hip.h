@@ -46,6 +46,10 @@ enum { PCA_F32 = 0, PCA_BF16 = 1 };
 enum { PCA_MODE_F32 = 0, PCA_MODE_BF16 = 1 };
 
 int pca_abi_version(void);
+/* Test aid (no reference counterpart): overwrites the LDS of every CU with NaN bit patterns.
+ * The parity tests call it before each case so that a kernel reading LDS it has not written
+ * cannot pass on leftover finite values. */
+int pca_debug_poison_lds(void* stream);
 const char* pca_last_error(void);
 
 /* ------------------------------------------------------------------------- *

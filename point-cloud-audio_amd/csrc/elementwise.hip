@@ -217,6 +217,15 @@ __global__ void k_copy_rows(const float* __restrict__ src, int64_t src_elems,
   for (; i < n; i += stride) dst[i] = src[i % src_elems];
 }
 
+// test aid: fill the whole LDS of every CU with NaN patterns, so that a kernel that reads LDS
+// it never wrote fails a parity test instead of passing on leftover finite values
+__global__ __launch_bounds__(256) void k_poison_lds() {
+  extern __shared__ uint32_t junk[];
+  for (int i = threadIdx.x; i < 160 * 1024 / 4; i += 256) junk[i] = 0x7fc00000u | (uint32_t)i;
+  __syncthreads();
+  if (junk[(threadIdx.x * 97) % (160 * 1024 / 4)] == 1u) junk[0] = 0;   // keep the stores alive
+}
+
 // zero fill (a kernel rather than hipMemsetAsync: identical behaviour eager and captured)
 __global__ void k_fill_zero(float* __restrict__ dst, int64_t n) {
   int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
@@ -332,6 +341,18 @@ int add_inplace(float* dst, const float* src, int64_t n, hipStream_t st) {
 extern "C" {
 
 int pca_abi_version(void) { return PCA_ABI_VERSION; }
+
+int pca_debug_poison_lds(void* stream) {
+  static std::once_flag once;
+  std::call_once(once, [] {
+    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(pca::k_poison_lds),
+                              hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+  });
+  // one 160 KiB workgroup per CU at a time; 4 rounds over 256 CUs reach every CU
+  hipLaunchKernelGGL(pca::k_poison_lds, dim3(1024), dim3(256), 160 * 1024,
+                     pca::as_stream(stream));
+  return pca::check_launch("k_poison_lds");
+}
 const char* pca_last_error(void) { return pca::g_err; }
 
 int pca_prof_start(int kernel_id, int max_launches) {

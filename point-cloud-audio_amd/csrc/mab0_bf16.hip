@@ -333,9 +333,9 @@ __global__ __launch_bounds__(256) void k_mab0_attn_small(const float* __restrict
     const int cn = (N - n0 < CH) ? N - n0 : CH;
     __syncthreads();
     // coalesced copy of cn*dk floats, re-laid out as [point][4]
-    for (int i = tid; i < cn * dk; i += 256) {
-      const int pt = i / dk, c = i - pt * dk;
-      sX[pt * 4 + c] = X[((int64_t)b * N + n0) * dk + i];
+    for (int i = tid; i < cn * 4; i += 256) {       // unused components must be zero, not stale LDS
+      const int pt = i >> 2, c = i & 3;
+      sX[i] = c < dk ? X[((int64_t)b * N + n0 + pt) * dk + c] : 0.f;
     }
     __syncthreads();
     // online softmax over this thread's points of the chunk, 4 at a time (one rescale per 4)

@@ -390,9 +390,9 @@ __global__ __launch_bounds__(256) void k_mab0_bwd_small(
   for (int n0 = 0; n0 < N; n0 += CH) {
     const int cn = (N - n0 < CH) ? N - n0 : CH;
     __syncthreads();
-    for (int i = tid; i < cn * dk; i += 256) {
-      const int pt = i / dk, c = i - pt * dk;
-      sX[pt * 4 + c] = X[((int64_t)b * N + n0) * dk + i];
+    for (int i = tid; i < cn * 4; i += 256) {       // unused components must be zero, not stale LDS
+      const int pt = i >> 2, c = i & 3;
+      sX[i] = c < dk ? X[((int64_t)b * N + n0 + pt) * dk + c] : 0.f;
     }
     __syncthreads();
     if (part < parts) {

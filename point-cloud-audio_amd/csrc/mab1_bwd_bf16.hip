@@ -43,6 +43,7 @@ struct Mab1BwdArgs {
   int dq;
   float* zero_ptr;          // optional: zero_n floats cleared by this launch (consumer's
   int zero_n;               //           accumulator, e.g. the dQs of k_mid_bwd)
+  long long* dbg;           // PCA_DEBUG_CLOCKS builds: phase time stamps of workgroup 0
   int B, N, tiles_per_set;
   int tpw;                  // consecutive tiles of ONE set per workgroup (fused mode)
   float scale, scale_log2e;
@@ -65,6 +66,11 @@ __device__ __forceinline__ bf16x8 tr_frag_small(const char* img, int rb, int col
   return r;
 }
 
+#ifdef PCA_DEBUG_CLOCKS
+#define PCA_STAMP(i) do { if (a.dbg && blockIdx.x == 0 && threadIdx.x == 0) a.dbg[dbg_n++] = ((long long)(i) << 48) | (wall_clock64() & 0xffffffffffffLL); } while (0)
+#else
+#define PCA_STAMP(i) do {} while (0)
+#endif
 template <int D, int MI, bool WANT_DX, bool FUSE_KV, bool FUSE_WQ, bool ABF>
 __global__ __launch_bounds__(256, 1) void k_mab1_bwd(const Mab1BwdArgs a) {
   constexpr int DT = D / 16, KS = D / 32, ROWB = D * 2, HM = KS * MI;
@@ -79,6 +85,8 @@ __global__ __launch_bounds__(256, 1) void k_mab1_bwd(const Mab1BwdArgs a) {
 
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int r = lane & 15, g = lane >> 4;
+  int dbg_n = 0; (void)dbg_n;
+  PCA_STAMP(0);
 
   for (int c = tid; c < D * (D / 8); c += 256) {
     const int row = c / (D / 8), c16 = c % (D / 8);
@@ -107,17 +115,16 @@ __global__ __launch_bounds__(256, 1) void k_mab1_bwd(const Mab1BwdArgs a) {
         dvp[j][tt] = f32x4{0.f, 0.f, 0.f, 0.f};
       }
   }
-  // layer 1: per-lane partial sums of dWq[f][c] = sum_pt dQp[f][pt] x[pt][c] and dbq[f]
-  float wq_acc[FUSE_WQ ? D / 16 : 1][4][3], bq_acc[FUSE_WQ ? D / 16 : 1][4];
+  // layer 1: fc_q gradients on the matrix core.  wqa[j][tt] = Xa . dQp_j with the augmented
+  // point matrix Xa[16][32 points]: rows 0..2 = bf16 high parts of x, row 3 = ones (bias),
+  // rows 4..6 = bf16 low parts (x = hi + lo to ~2^-17), so that
+  // dWq[f][c] = row c + row 4+c and dbq[f] = row 3 of column f.
+  f32x4 wqa[FUSE_WQ ? KS : 1][2];
   if (FUSE_WQ) {
 #pragma unroll
-    for (int t = 0; t < D / 16; ++t)
+    for (int j = 0; j < KS; ++j)
 #pragma unroll
-      for (int e = 0; e < 4; ++e) {
-        bq_acc[t][e] = 0.f;
-#pragma unroll
-        for (int c = 0; c < 3; ++c) wq_acc[t][e][c] = 0.f;
-      }
+      for (int tt = 0; tt < 2; ++tt) wqa[j][tt] = f32x4{0.f, 0.f, 0.f, 0.f};
   }
   // fused mode: a workgroup owns `tpw` consecutive tiles of one set; otherwise grid-stride
   const int t_first = FUSE_KV ? blockIdx.x * a.tpw : blockIdx.x;
@@ -141,6 +148,7 @@ __global__ __launch_bounds__(256, 1) void k_mab1_bwd(const Mab1BwdArgs a) {
       cur_b = b;
     }
     __syncthreads();
+    PCA_STAMP(1);
 
     const int n_base = tile * TP + wave * 32;
     int nn[NB];
@@ -153,6 +161,24 @@ __global__ __launch_bounds__(256, 1) void k_mab1_bwd(const Mab1BwdArgs a) {
       row[nb] = (int64_t)b * a.N + (live[nb] ? nn[nb] : 0);
     }
 
+    bf16x8 xaug;
+    if (FUSE_WQ) {
+      // A operand: lane (row c' = r, k-slots 8g..8g+7 <-> points perm32(8g + .)) of this tile
+      const int c = r & 3, part = r >> 2;          // part 0: hi / ones, 1: lo
+#pragma unroll
+      for (int k = 0; k < 8; ++k) {
+        const int pt = n_base + (k < 4 ? 4 * g + k : 16 + 4 * g + k - 4);
+        float v = 0.f;
+        if (part <= 1 && r < 7 && r != 3 && c < a.dq) {
+          const float x = a.Xs[((int64_t)b * a.N + (pt < a.N ? pt : 0)) * a.dq + c];
+          const float hi = (float)(__bf16)x;
+          v = part == 0 ? hi : x - hi;
+        } else if (r == 3) {
+          v = 1.f;
+        }
+        xaug[k] = (__bf16)v;
+      }
+    }
     // ---- dY^T tiles and dZ = dY . [Z > 0] ----
     f32x4 dO[DT][NB];
     bf16x8 dzb[KS][NB];
@@ -187,6 +213,7 @@ __global__ __launch_bounds__(256, 1) void k_mab1_bwd(const Mab1BwdArgs a) {
       for (int s = 0; s < KS; ++s) dzb[s][nb] = pack8(dz[2 * s], dz[2 * s + 1]);
     }
 
+    PCA_STAMP(2);
     // ---- dO^T = dY^T + Wo^T . dZ^T ----
 #pragma unroll
     for (int s = 0; s < KS; ++s) {
@@ -208,6 +235,7 @@ __global__ __launch_bounds__(256, 1) void k_mab1_bwd(const Mab1BwdArgs a) {
         }
     }
 
+    PCA_STAMP(3);
     // ---- attention backward per head; dO tiles of the head become dQp in place ----
 #pragma unroll
     for (int j = 0; j < KS; ++j) {
@@ -301,28 +329,24 @@ __global__ __launch_bounds__(256, 1) void k_mab1_bwd(const Mab1BwdArgs a) {
           dkp[j][tt] = mfma32(ads, tr_frag_small(myQ, 64, 16 * tt, lane), dkp[j][tt]);
           dvp[j][tt] = mfma32(ap, tr_frag_small(myO, 64, 16 * tt, lane), dvp[j][tt]);
         }
-      }
-    }
-    // dO now holds dQp^T
-    if (FUSE_WQ) {
+        if (FUSE_WQ) {
+          // the dO_j image is consumed: overwrite it with dQp_j (padding points carry zeros)
 #pragma unroll
-      for (int nb = 0; nb < NB; ++nb) {
-        float xv[3];
+          for (int nb = 0; nb < NB; ++nb) {
+            const int pt = 16 * nb + r;
+            *reinterpret_cast<bf16x4*>(myO + pt * 64 + 8 * g) = pack4(dO[2 * j][nb]);
+            *reinterpret_cast<bf16x4*>(myO + pt * 64 + 32 + 8 * g) = pack4(dO[2 * j + 1][nb]);
+          }
 #pragma unroll
-        for (int c = 0; c < 3; ++c)
-          xv[c] = (live[nb] && c < a.dq) ? a.Xs[row[nb] * a.dq + c] : 0.f;
-        if (live[nb]) {
-#pragma unroll
-          for (int t = 0; t < DT; ++t)
-#pragma unroll
-            for (int e = 0; e < 4; ++e) {
-              const float gq = dO[t][nb][e];
-              bq_acc[t][e] += gq;
-#pragma unroll
-              for (int c = 0; c < 3; ++c) wq_acc[t][e][c] = fmaf(gq, xv[c], wq_acc[t][e][c]);
-            }
+          for (int tt = 0; tt < 2; ++tt)
+            wqa[j][tt] = mfma32(xaug, tr_frag_small(myO, 64, 16 * tt, lane), wqa[j][tt]);
         }
       }
+    }
+    PCA_STAMP(4);
+    // dO now holds dQp^T
+    if (FUSE_WQ) {
+      // reduced per head above
     } else {
 #pragma unroll
       for (int nb = 0; nb < NB; ++nb)
@@ -366,25 +390,24 @@ __global__ __launch_bounds__(256, 1) void k_mab1_bwd(const Mab1BwdArgs a) {
         }
     }
   }
+  PCA_STAMP(5);
   if (FUSE_WQ) {
-    // sum over the 16 point lanes of each lane group, then over the waves, then one atomic
-    // per element per workgroup
+    // wqa rows (4g + e) = augmented-point rows, columns = features 32j + 16tt + r: combine
+    // the hi (g = 0) and lo (g = 1) rows, sum the waves through LDS, one atomic per element
     __syncthreads();
     float* red = reinterpret_cast<float*>(smem);             // [4 waves][D][4]
 #pragma unroll
-    for (int t = 0; t < DT; ++t)
+    for (int j = 0; j < KS; ++j)
 #pragma unroll
-      for (int e = 0; e < 4; ++e) {
-        float v[4] = {wq_acc[t][e][0], wq_acc[t][e][1], wq_acc[t][e][2], bq_acc[t][e]};
+      for (int tt = 0; tt < 2; ++tt) {
+        float v[4];
 #pragma unroll
-        for (int k = 0; k < 4; ++k) {
-          v[k] += __shfl_xor(v[k], 1, 64);
-          v[k] += __shfl_xor(v[k], 2, 64);
-          v[k] += __shfl_xor(v[k], 4, 64);
-          v[k] += __shfl_xor(v[k], 8, 64);
+        for (int e = 0; e < 4; ++e) {
+          const float lo = __shfl(wqa[j][tt][e], 16 + r, 64);     // row 4 + e of column r
+          v[e] = wqa[j][tt][e] + (e < 3 ? lo : 0.f);
         }
-        if (r == 0) {
-          float* dst = red + ((wave * D) + 16 * t + 4 * g + e) * 4;
+        if (g == 0) {
+          float* dst = red + ((wave * D) + 32 * j + 16 * tt + r) * 4;
           dst[0] = v[0]; dst[1] = v[1]; dst[2] = v[2]; dst[3] = v[3];
         }
       }
@@ -397,6 +420,7 @@ __global__ __launch_bounds__(256, 1) void k_mab1_bwd(const Mab1BwdArgs a) {
     }
     __syncthreads();
   }
+  PCA_STAMP(6);
   if (FUSE_KV && cur_b >= 0) {
     // reduce the four waves' [MI][D] partials in LDS (the weight images are dead), then one
     // atomic per element per workgroup
@@ -422,6 +446,7 @@ __global__ __launch_bounds__(256, 1) void k_mab1_bwd(const Mab1BwdArgs a) {
       (which ? a.dVpG : a.dKpG)[((int64_t)cur_b * nparts + part) * MI * D + o] = v;
     }
   }
+  PCA_STAMP(7);
 }
 
 // ---------------------------------------------------------------------------------
@@ -696,6 +721,26 @@ __global__ void k_sum_parts(const float* __restrict__ kp, const float* __restric
   dv[i] = c;
 }
 
+#ifdef PCA_DEBUG_CLOCKS
+// diagnostic build: the last launch's phase stamps of workgroup 0 are printed at exit
+long long* debug_clock_buffer(int which) {
+  static long long* buf[2] = {nullptr, nullptr};
+  if (buf[which] == nullptr) {
+    (void)hipHostMalloc(reinterpret_cast<void**>(&buf[which]), 64 * sizeof(long long), 0);
+    for (int i = 0; i < 64; ++i) buf[which][i] = 0;
+    static int reg[2] = {0, 1};
+    struct P { static void dump(int w) {
+      long long* b = buf[w]; long long t0 = b[0] & 0xffffffffffffLL;
+      fprintf(stderr, "k_mab1_bwd[%d] stamps (phase:us):", w);
+      for (int i = 0; i < 64 && (i == 0 || b[i]); ++i)
+        fprintf(stderr, " %lld:%.2f", b[i] >> 48, ((b[i] & 0xffffffffffffLL) - t0) / 100.0);
+      fprintf(stderr, "\n"); } };
+    if (which == 0) atexit([] { P::dump(0); }); else atexit([] { P::dump(1); });
+    (void)reg;
+  }
+  return buf[which];
+}
+#endif
 template <int D, int MI, bool DX, bool FUSE, bool FWQ, bool ABF>
 int launch_bwd(const Mab1BwdArgs& a, hipStream_t st, double flops, double bytes) {
   size_t lds = (size_t)D * D * 2 + 2 * (size_t)MI * D * 2 + (size_t)D * MI * 2 +
@@ -823,14 +868,21 @@ int mab1_bf16_bwd_ex(const pca_mab_shape& s, const void* X, const float* H,
   if (fuse) {
     // consecutive tiles per workgroup: the largest divisor of tiles_per_set that still
     // leaves >= 256 workgroups
+    static const int min_wg = [] {
+      const char* e = getenv("PCA_BWD_MIN_WG");
+      return e ? atoi(e) : 256;
+    }();
     int tpw = 1;
     for (int c = 1; c <= a.tiles_per_set; ++c)
-      if (a.tiles_per_set % c == 0 && (int64_t)a.B * a.tiles_per_set / c >= 256) tpw = c;
+      if (a.tiles_per_set % c == 0 && (int64_t)a.B * a.tiles_per_set / c >= min_wg) tpw = c;
     a.tpw = tpw;
     a.dKpG = w.dKpPart;
     a.dVpG = w.dVpPart;
     a.zero_ptr = zero_ptr;
     a.zero_n = zero_n;
+#ifdef PCA_DEBUG_CLOCKS
+    a.dbg = debug_clock_buffer(want_dx ? 1 : 0);
+#endif
     const bool fwq = small && s.dq <= 3;
     a.Xs = reinterpret_cast<const float*>(X); a.dWqS = gr.wq; a.dbqS = gr.bq; a.dq = s.dq;
     if (abf)

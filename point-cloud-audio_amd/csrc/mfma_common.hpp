@@ -53,15 +53,22 @@ __device__ __forceinline__ int swz(int row, int c16, int row_bytes) {
   return row * row_bytes + (((c16 & ~15) | ((c16 ^ row) & 15)) << 4);
 }
 
-__device__ __forceinline__ float wave16_max(float v) {   // over the 4 lane groups g
-  v = fmaxf(v, __shfl_xor(v, 16, 64));
-  v = fmaxf(v, __shfl_xor(v, 32, 64));
-  return v;
+// Reductions over the 4 lane groups g (lanes l, l^16, l^32, l^48), result in every lane.
+// gfx950's v_permlane32_swap / v_permlane16_swap exchange half-waves / odd-even rows in the
+// VALU (no trip through the LDS crossbar as ds_bpermute / __shfl_xor would take):
+//   permlane32_swap(v, v) -> ([lo, lo], [hi, hi]);  permlane16_swap(v, v) -> ([r0,r0,r2,r2],
+//   [r1,r1,r3,r3]); combining the two results of each is the xor-32 / xor-16 butterfly step.
+__device__ __forceinline__ float wave16_max(float v) {
+  auto a = __builtin_amdgcn_permlane32_swap(__float_as_uint(v), __float_as_uint(v), false, false);
+  v = fmaxf(__uint_as_float(a[0]), __uint_as_float(a[1]));
+  auto b = __builtin_amdgcn_permlane16_swap(__float_as_uint(v), __float_as_uint(v), false, false);
+  return fmaxf(__uint_as_float(b[0]), __uint_as_float(b[1]));
 }
 __device__ __forceinline__ float wave16_sum(float v) {
-  v += __shfl_xor(v, 16, 64);
-  v += __shfl_xor(v, 32, 64);
-  return v;
+  auto a = __builtin_amdgcn_permlane32_swap(__float_as_uint(v), __float_as_uint(v), false, false);
+  v = __uint_as_float(a[0]) + __uint_as_float(a[1]);
+  auto b = __builtin_amdgcn_permlane16_swap(__float_as_uint(v), __float_as_uint(v), false, false);
+  return __uint_as_float(b[0]) + __uint_as_float(b[1]);
 }
 
 }  // namespace pca

@@ -33,6 +33,18 @@ def pytest_collection_modifyitems(config, items):
             it.add_marker(skip)
 
 
+@pytest.fixture(autouse=True)
+def _poison_lds(request):
+    """Before every GPU test: fill the LDS of all CUs with NaNs (pca_debug_poison_lds), so a
+    kernel that reads LDS it did not write cannot pass on leftover values."""
+    if "gpu" in request.keywords and _has_gpu():
+        import torch
+        from pca_hip import _lib
+        _lib.check(_lib.lib().pca_debug_poison_lds(None), "pca_debug_poison_lds")
+        torch.cuda.synchronize()
+    yield
+
+
 class Golden:
     """Lazy view over one golden .npz with '/'-separated keys."""
 
