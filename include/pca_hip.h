@@ -90,6 +90,32 @@ int pca_pack_points_3d(const float* spec, int64_t stride_f, int64_t stride_t,
                        const int64_t* idx, int B, int F, int Nt, float* out,
                        const int64_t* labels, int64_t* labels_out, void* stream);
 
+/* Sub-sampled point sets for a batch of frames / frame chunks, selected on the device
+ * replaces: Code/dataset.py:189-199  ESC_pc_temp_maxKSS.__getitem__  (mode 0)
+ *           Code/dataset.py:229-239  ESC_pc_temp_randKSS.__getitem__ (mode 1)
+ *           Code/utils.py:25-82      pc_maxK / pc_randK (Nt = 1, tarr = NULL)
+ * Addressing as pca_pack_points_3d; N = F*Nt <= 16384 points per set, 1 <= K <= N.
+ * mode 0: the K largest values in descending order; equal values keep ascending point
+ *         order p = t*F + f (a stable argsort of the negated values; NaNs last).
+ * mode 1: the first K entries of a uniformly random permutation of the points, drawn from
+ *         the counter-based stream (seed, draw, batch slot b, set index); the reference uses the global
+ *         numpy RNG, so only the distribution is reproducible.
+ * out[B, K, 3] = (farr[f], tarr[t], value), or out[B, K, 2] = (farr[f], value) when tarr is
+ * NULL.  sel (nullable) [B, K] int32 receives the selected point indices p. */
+int pca_subsample_points(const float* spec, int64_t stride_f, int64_t stride_t,
+                         int64_t stride_s, const float* farr, const float* tarr,
+                         const int64_t* idx, int B, int F, int Nt, int K, int mode,
+                         uint64_t seed, uint64_t draw, float* out, int32_t* sel,
+                         const int64_t* labels, int64_t* labels_out, void* stream);
+
+/* 2-D point sets from per-frame tables (the output of pc_maxK / pc_randK)
+ * replaces: Code/dataset.py:76-80  ESC_pc_ss.__getitem__ (+ default_collate)
+ * x_tk[T, K] values and f_tk[T, K] coordinates, frame-major; out[B, K, 2] =
+ * (f_tk[idx[b], q], x_tk[idx[b], q]). */
+int pca_pack_points_2d_ss(const float* x_tk, const float* f_tk, const int64_t* idx, int B,
+                          int K, float* out, const int64_t* labels, int64_t* labels_out,
+                          void* stream);
+
 /* ------------------------------------------------------------------------- *
  * Multihead attention block                                                  *
  * replaces: set_transformer-master/modules.py:19-33 MAB.forward and the       *

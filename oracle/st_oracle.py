@@ -305,8 +305,31 @@ def pc_maxk_3d(x: np.ndarray, farr: np.ndarray, tarr: np.ndarray, idx: int, K: i
         pc[t * F:(t + 1) * F, 0] = farr
         pc[t * F:(t + 1) * F, 1] = tarr[t]
         pc[t * F:(t + 1) * F, 2] = xt[:, t]
-    order = np.argsort(-pc[:, 2])[:K]
+    order = np.argsort(-pc[:, 2], kind="stable")[:K]     # ties: ascending point order
     return pc[order]
+
+
+def pc_maxk_2d(x: np.ndarray, farr: np.ndarray, K: int):
+    """Code/utils.py:25-53 (pc_maxK): per frame the K largest bins, descending, and their
+    frequencies: ([K, T], [K, T]).  utils.py itself cannot be imported here (prettytable is
+    absent); its selection is the same ``(-v).argsort()[:K]`` that ESC_pc_temp_maxKSS uses,
+    which the golden items pin."""
+    order = np.argsort(-x, axis=0, kind="stable")[:K]
+    return np.take_along_axis(x, order, axis=0), farr[order]
+
+
+def pc_maxk_replace(x: np.ndarray, K: int) -> np.ndarray:
+    """Code/utils.py:86-96 (pc_maxK_replace): float64 [N, T], all but the K largest bins of
+    every frame zeroed."""
+    order = np.argsort(-x, axis=0, kind="stable")[:K]
+    out = np.zeros(x.shape, dtype=np.float64)
+    np.put_along_axis(out, order, np.take_along_axis(x, order, axis=0), axis=0)
+    return out
+
+
+def pack_points_2d_ss(x: np.ndarray, farr: np.ndarray, idx: int) -> np.ndarray:
+    """Code/dataset.py:76-80 (ESC_pc_ss.__getitem__): x, farr [K, T] -> float32 [K, 2]."""
+    return np.stack((farr[:, idx], x[:, idx]), axis=1).astype(np.float32)
 
 
 # --------------------------------------------------------------------------- #

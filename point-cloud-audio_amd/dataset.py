@@ -18,7 +18,8 @@ from torch.utils.data import Dataset
 
 import pca_hip
 
-__all__ = ["ESC_pc", "ESC_pc_temp", "DeviceBatchLoader"]
+__all__ = ["ESC_pc", "ESC_pc_ss", "ESC_pc_temp", "ESC_pc_temp_maxKSS", "ESC_pc_temp_randKSS",
+           "DeviceBatchLoader"]
 
 
 def _dev(device) -> torch.device:
@@ -139,6 +140,97 @@ class ESC_pc_temp(Dataset):
         i = torch.tensor([int(idx)], dtype=torch.int64, device=spec.device)
         pts, lbl = self.batch(i)
         return pts[0].cpu(), lbl[0].cpu()
+
+
+class ESC_pc_ss(Dataset):
+    """2-D point sets of the sub-sampling experiments (Code/dataset.py:58-80): ``x`` and
+    ``farr`` are the [K, T] outputs of ``utils.pc_maxK`` / ``pc_randK`` (per-frame values and
+    per-frame frequency coordinates); item idx = stack(farr[:, idx], x[:, idx]).T float32."""
+
+    def __init__(self, x, y, farr, device=None):
+        self.x = x
+        self.labels = y
+        self.farr = farr
+        self._device = device
+        self._res = None
+
+    def __len__(self):
+        return self.x.shape[1]
+
+    @property
+    def num_points(self) -> int:
+        return int(self.x.shape[0])
+
+    def _resident(self):
+        if self._res is None:
+            dev = _dev(self._device)
+            x_tk = torch.as_tensor(np.asarray(self.x)).to(dev, torch.float32).t().contiguous()
+            f_tk = torch.as_tensor(np.asarray(self.farr)).to(dev, torch.float32).t().contiguous()
+            lab = torch.as_tensor(np.asarray(self.labels)).to(dev, torch.int64)
+            self._res = (x_tk, f_tk, lab)
+        return self._res
+
+    def batch(self, idx: torch.Tensor, out=None, labels_out=None
+              ) -> Tuple[torch.Tensor, torch.Tensor]:
+        x_tk, f_tk, lab = self._resident()
+        return pca_hip.pack_points_2d_ss(x_tk, f_tk, idx, lab, out=out, labels_out=labels_out)
+
+    def __getitem__(self, idx):
+        x_tk = self._resident()[0]
+        i = torch.tensor([int(idx)], dtype=torch.int64, device=x_tk.device)
+        pts, lbl = self.batch(i)
+        return pts[0].cpu(), lbl[0].cpu()
+
+
+class _TempSS(ESC_pc_temp):
+    """3-D point sets reduced to K points per set on the device (one launch per batch)."""
+    _mode = pca_hip.MAXK
+
+    def __init__(self, x, y, farr, tarr, K, device=None, seed: int = 0):
+        super().__init__(x, y, farr, tarr, device=device)
+        self.K = int(K)
+        self.seed = int(seed)
+        self._draw = 0
+
+    @property
+    def num_points(self) -> int:
+        return self.K
+
+    def batch(self, idx: torch.Tensor, out=None, labels_out=None, want_sel: bool = False):
+        spec, f32, t32, lab = self._resident()
+        self._draw += 1
+        return pca_hip.subsample_points(spec, f32, t32, idx, self.K, self._mode, self.seed,
+                                        self._draw, lab, out=out, labels_out=labels_out,
+                                        want_sel=want_sel)
+
+    def __getitem__(self, idx):
+        """float64 [K, 3] exactly as the reference builds it (float64 farr / tarr, the float32
+        spectrogram widened): the device picks the points, the host gathers the rows."""
+        spec = self._resident()[0]
+        i = torch.tensor([int(idx)], dtype=torch.int64, device=spec.device)
+        _, lbl, sel = self.batch(i, want_sel=True)
+        p = sel[0].cpu().numpy().astype(np.int64)
+        F = int(spec.shape[0])
+        f, t = p % F, p // F
+        farr = np.asarray(self.farr, dtype=np.float64)
+        tarr = np.asarray(self.tarr, dtype=np.float64)
+        v = spec[:, :, int(idx)].cpu().numpy().astype(np.float64)[f, t]
+        pc = np.stack((farr[f], tarr[t], v), axis=1)
+        return torch.tensor(pc), lbl[0].cpu()
+
+
+class ESC_pc_temp_maxKSS(_TempSS):
+    """The K largest-magnitude points of chunk idx in descending order (Code/dataset.py:169-199:
+    ``(-pc[:, -1]).argsort()[:K]``); equal values keep ascending point order."""
+    _mode = pca_hip.MAXK
+
+
+class ESC_pc_temp_randKSS(_TempSS):
+    """K points of a uniformly random permutation of chunk idx (Code/dataset.py:201-239).  The
+    reference draws from the global numpy RNG; here every draw comes from the counter-based
+    device stream (seed, draw number, set), so runs are reproducible per ``seed`` and only
+    the distribution matches the reference."""
+    _mode = pca_hip.RANDK
 
 
 class DeviceBatchLoader:

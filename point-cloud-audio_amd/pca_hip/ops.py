@@ -295,3 +295,68 @@ def pack_points_3d(spec: torch.Tensor, farr: torch.Tensor, tarr: torch.Tensor,
                                        F, Nt, _ptr(out), _ptr(labels), _ptr(labels_out),
                                        _stream(spec)), "pca_pack_points_3d")
     return out, labels_out
+
+
+MAXK, RANDK = 0, 1
+
+
+def subsample_points(spec: torch.Tensor, farr: torch.Tensor, tarr: Optional[torch.Tensor],
+                     idx: torch.Tensor, K: int, mode: int = MAXK, seed: int = 0,
+                     draw: int = 0, labels: Optional[torch.Tensor] = None,
+                     out: Optional[torch.Tensor] = None,
+                     labels_out: Optional[torch.Tensor] = None, want_sel: bool = False):
+    """Batch of sub-sampled point sets selected on the device (pca_subsample_points).
+
+    spec indexed [f, t, s] through its strides ([F, T] with tarr=None for the framewise
+    2-D case); idx int64[B].  mode MAXK: the K largest values per set, descending
+    (Code/dataset.py:196, Code/utils.py:42); RANDK: K points of a random permutation
+    (Code/dataset.py:236, Code/utils.py:70) from the stream (seed, draw).
+    Returns (points [B, K, din] float32, labels[idx] or None[, sel int32 [B, K]])."""
+    _need_cuda(spec, farr, idx)
+    assert spec.dtype == torch.float32 and idx.dtype == torch.int64
+    if tarr is None:
+        assert spec.dim() == 2
+        F, Nt = spec.shape[0], 1
+        sf, st, ss = spec.stride(0), 0, spec.stride(1)
+        din = 2
+    else:
+        _need_cuda(tarr)
+        F, Nt, _ = spec.shape
+        sf, st, ss = spec.stride(0), spec.stride(1), spec.stride(2)
+        din = 3
+    B = idx.numel()
+    with torch.cuda.device(spec.device):
+        if out is None:
+            out = torch.empty((B, K, din), dtype=torch.float32, device=spec.device)
+        if labels is not None and labels_out is None:
+            labels_out = torch.empty(B, dtype=torch.int64, device=spec.device)
+        sel = torch.empty((B, K), dtype=torch.int32, device=spec.device) if want_sel else None
+        check(lib().pca_subsample_points(_ptr(spec), sf, st, ss, _ptr(farr), _ptr(tarr),
+                                         _ptr(idx), B, F, Nt, int(K), int(mode),
+                                         int(seed) & (2 ** 64 - 1), int(draw) & (2 ** 64 - 1),
+                                         _ptr(out), _ptr(sel), _ptr(labels), _ptr(labels_out),
+                                         _stream(spec)), "pca_subsample_points")
+    return (out, labels_out, sel) if want_sel else (out, labels_out)
+
+
+def pack_points_2d_ss(x_tk: torch.Tensor, f_tk: torch.Tensor, idx: torch.Tensor,
+                      labels: Optional[torch.Tensor] = None,
+                      out: Optional[torch.Tensor] = None,
+                      labels_out: Optional[torch.Tensor] = None
+                      ) -> Tuple[torch.Tensor, Optional[torch.Tensor]]:
+    """Batch of ESC_pc_ss items from frame-major tables x_tk, f_tk [T, K] (contiguous):
+    ([B, K, 2] float32, labels[idx])."""
+    _need_cuda(x_tk, f_tk, idx)
+    assert x_tk.dtype == torch.float32 and f_tk.dtype == torch.float32
+    assert x_tk.is_contiguous() and f_tk.is_contiguous() and x_tk.shape == f_tk.shape
+    K = x_tk.shape[1]
+    B = idx.numel()
+    with torch.cuda.device(x_tk.device):
+        if out is None:
+            out = torch.empty((B, K, 2), dtype=torch.float32, device=x_tk.device)
+        if labels is not None and labels_out is None:
+            labels_out = torch.empty(B, dtype=torch.int64, device=x_tk.device)
+        check(lib().pca_pack_points_2d_ss(_ptr(x_tk), _ptr(f_tk), _ptr(idx), B, K, _ptr(out),
+                                          _ptr(labels), _ptr(labels_out), _stream(x_tk)),
+              "pca_pack_points_2d_ss")
+    return out, labels_out

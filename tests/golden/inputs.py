@@ -61,8 +61,11 @@ CKPT_3D_N = [1, 2551, 5120, 10240]
 # --------------------------------------------------------------------------- #
 # accuracy-parity corpus (SURVEY.md section 8d "Accuracy parity")               #
 # --------------------------------------------------------------------------- #
-ACC = dict(C=10, clips_per_class=5, seconds=0.5, fs=44100, n_fft=1024, B=128, epochs=46,
+ACC = dict(C=10, clips_per_class=4, test_clips_per_class=5, seconds=0.5, fs=44100, n_fft=1024, B=128, epochs=46,
            d=128, h=4, m=16, lr=1e-3, wd=1e-3, seed=4242, init_seed=77)
+
+
+ACC_EVAL_EVERY = 5     # epochs between test evaluations of the accuracy-parity run
 
 
 def level_clip(clip_id: int, cls: int, seconds: float, fs: int) -> np.ndarray:
@@ -78,8 +81,9 @@ def level_clip(clip_id: int, cls: int, seconds: float, fs: int) -> np.ndarray:
 def accuracy_corpus():
     """ESC-shaped synthetic corpus at the cfg1/2 framing (n_fft 1024, hop 512, Nyquist
     dropped: F = 512 points per set, one set per frame).  Clip j of class c is
-    ``level_clip(clip_id=5c+j, cls=c)``; the last clip of every class is the test clip
-    (80/20 split by clip, Code/data_processing.py:40-65).  Built with the CPU oracle's
+    ``level_clip(clip_id=5c+j, cls=c)`` for j < 4 (training); the test clips of class c are
+    ``level_clip(1000+5c+j, c)``, j < 5: a split by clip as Code/data_processing.py:40-65
+    makes, with a test set large enough (2200 sets) to resolve 0.05 % of accuracy.  Built with the CPU oracle's
     float64 STFT so that the reference (fixture time) and the HIP path (test time) train on
     identical arrays.  Returns dict(x_train [F,T], y_train [T], x_test, y_test, farr [F])."""
     from oracle import st_oracle as so
@@ -87,12 +91,13 @@ def accuracy_corpus():
     xs = {"train": [], "test": []}
     ys = {"train": [], "test": []}
     for c in range(a["C"]):
-        for j in range(a["clips_per_class"]):
-            w = level_clip(a["clips_per_class"] * c + j, c, a["seconds"], a["fs"])
-            s = so.stft_logmag(w, a["n_fft"], drop_nyquist=True)
-            part = "test" if j == a["clips_per_class"] - 1 else "train"
-            xs[part].append(s)
-            ys[part].append(np.full(s.shape[1], c, dtype=np.int64))
+        for part, n, first in (("train", a["clips_per_class"], 5 * c),
+                               ("test", a["test_clips_per_class"], 1000 + 5 * c)):
+            for j in range(n):
+                w = level_clip(first + j, c, a["seconds"], a["fs"])
+                s = so.stft_logmag(w, a["n_fft"], drop_nyquist=True)
+                xs[part].append(s)
+                ys[part].append(np.full(s.shape[1], c, dtype=np.int64))
     F = a["n_fft"] // 2
     farr = (np.linspace(0, a["fs"] / 2, F + 1) / a["fs"])[:F]
     return dict(x_train=np.concatenate(xs["train"], axis=1), y_train=np.concatenate(ys["train"]),
@@ -108,3 +113,22 @@ def agreement_sets(seed: int, n: int, N: int, din: int, chunk: int = 100):
         b = min(chunk, n - s)
         yield s, pc_input(seed + i, b, N, din)
         i += 1
+
+
+# --------------------------------------------------------------------------- #
+# sub-sampling datasets at the shipped 3ST framing                             #
+# --------------------------------------------------------------------------- #
+SS_K = [1, 51, 2551, 5120]
+
+
+def ss_inputs(F: int = 512, Nt: int = 10, S: int = 3, seed: int = 8080):
+    """x [F, Nt, S] float32 log-magnitudes, y [S], farr [F], tarr [Nt] as
+    Code/settransformertemp.py:40-41 builds them.  5120 float32 draws contain a few exactly
+    equal values; the reference orders such ties by numpy's unstable introsort, so the tests
+    compare selections up to permutations inside runs of equal values."""
+    rng = np.random.Generator(np.random.PCG64(seed))
+    x = rng.normal(-9.0, 3.0, size=(F, Nt, S)).astype(np.float32)
+    y = rng.integers(0, 10, size=(S,)).astype(np.int64)
+    farr = (np.linspace(0, 44100 / 2, F + 1) / 44100)[:F]
+    tarr = np.linspace(0, ((0.5 * 1024) / 44100) * Nt, Nt)
+    return x, y, farr, tarr

@@ -62,8 +62,22 @@ def gen_train():
     stream = ShardedIndexStream(T, a["B"], 0, 1, a["seed"], True, "cpu")
     steps = a["epochs"] * (T // a["B"])
     losses = np.zeros(steps, dtype=np.float64)
+    per_epoch = T // a["B"]
+    Tt = cp["x_test"].shape[1]
+
+    def test_logits():
+        net.eval()
+        lg = np.zeros((Tt, a["C"]), dtype=np.float32)
+        with torch.no_grad():
+            for s0 in range(0, Tt, 220):
+                idx = np.arange(s0, min(s0 + 220, Tt))
+                lg[idx] = net(pack2d(cp["x_test"], farr32, idx)).numpy().reshape(len(idx), -1)
+        net.train()
+        return lg
+
     net.train()
     t0 = time.time()
+    eval_steps, eval_acc = [], []
     for s in range(steps):
         idx = stream.next().numpy()
         imgs, labels = pack2d(cp["x_train"], farr32, idx), torch.from_numpy(cp["y_train"][idx])
@@ -75,15 +89,19 @@ def gen_train():
         losses[s] = loss.item()
         if s % 20 == 0:
             print(f"step {s}/{steps} loss {losses[s]:.4f}  {time.time() - t0:.0f}s", flush=True)
-    net.eval()
-    Tt = cp["x_test"].shape[1]
-    logits = np.zeros((Tt, a["C"]), dtype=np.float32)
-    with torch.no_grad():
-        for s in range(0, Tt, 200):
-            idx = np.arange(s, min(s + 200, Tt))
-            logits[idx] = net(pack2d(cp["x_test"], farr32, idx)).numpy().reshape(len(idx), -1)
+        # periodic test evaluation (the reference evaluates every 10 epochs,
+        # Code/settransformer.py:117-131; every EVAL_EVERY epochs here) and after the last step
+        ep_done = (s + 1) // per_epoch
+        if (s + 1) % per_epoch == 0 and (ep_done % gi.ACC_EVAL_EVERY == 0 or s + 1 == steps):
+            acc_e = float((test_logits().argmax(1) == cp["y_test"]).mean())
+            eval_steps.append(s + 1)
+            eval_acc.append(acc_e)
+            print(f"  epoch {ep_done}: test acc {acc_e:.4f}", flush=True)
+    logits = test_logits()
     acc = float((logits.argmax(1) == cp["y_test"]).mean())
     print("test accuracy", acc, "steps", steps)
+    out["eval_steps"] = np.asarray(eval_steps, dtype=np.int64)
+    out["eval_acc"] = np.asarray(eval_acc, dtype=np.float64)
     for k, v in net.state_dict().items():
         out[f"final/{k}"] = v.detach().numpy().copy()
     out["losses"] = losses

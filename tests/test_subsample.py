@@ -1,0 +1,206 @@
+"""Sub-sampling datasets: the CPU oracle against the items the
+REAL reference produced (golden_ss.npz, golden_dataset.npz), and the HIP selection kernel
+against both."""
+import numpy as np
+import pytest
+import torch
+
+import inputs as gi
+from conftest import Golden
+from util import T, same_up_to_ties
+
+
+@pytest.fixture(scope="module")
+def golden_ss():
+    return Golden("golden_ss.npz")
+
+
+def _sel_of(pc, farr, tarr):
+    F = farr.shape[0]
+    f = np.searchsorted(farr, pc[:, 0])
+    t = np.searchsorted(tarr, pc[:, 1])
+    return (t * F + f).astype(np.int32)
+
+
+def test_oracle_maxk_full_size(golden_ss):
+    from oracle import st_oracle as orc
+    x, y, farr, tarr = gi.ss_inputs()
+    for K in gi.SS_K:
+        for i in range(x.shape[2]):
+            pc = orc.pc_maxk_3d(x, farr, tarr, i, K)
+            assert pc.dtype == np.float64 and pc.shape == (K, 3)
+            np.testing.assert_array_equal(pc[:, 2].astype(np.float32),
+                                          golden_ss[f"maxK{K}/val{i}"])
+            same_up_to_ties(_sel_of(pc, farr, tarr), golden_ss[f"maxK{K}/sel{i}"], pc[:, 2],
+                            f"K={K} item {i}")
+
+
+def test_oracle_pc_ss_and_utils(golden_ss):
+    from oracle import st_oracle as orc
+    x, y, farr, tarr = gi.ss_inputs()
+    x2 = x[:, 0, :]
+    xs, fs = orc.pc_maxk_2d(x2, farr, 51)
+    assert xs.shape == fs.shape == (51, x2.shape[1])
+    assert int(golden_ss["ss2d/len"]) == x2.shape[1]
+    for i in range(x2.shape[1]):
+        np.testing.assert_array_equal(orc.pack_points_2d_ss(xs, fs, i), golden_ss[f"ss2d/item{i}"])
+    rep = orc.pc_maxk_replace(x2, 51)
+    assert rep.dtype == np.float64 and rep.shape == x2.shape
+    for i in range(x2.shape[1]):
+        keep = np.zeros(x2.shape[0], bool)
+        keep[golden_ss[f"ss2d/sel{i}"]] = True
+        np.testing.assert_array_equal(rep[keep, i], x2[keep, i].astype(np.float64))
+        assert (rep[~keep, i] == 0).all()
+
+
+# ------------------------------------------------------------------------------------- GPU
+@pytest.fixture(scope="module")
+def dev():
+    return torch.device("cuda", 0)
+
+
+@pytest.mark.gpu
+def test_maxkss_items_and_batches(dev, golden_ss, golden_dataset):
+    """ESC_pc_temp_maxKSS: items float64 [K, 3] equal to the reference's; batches float32."""
+    import dataset
+    x, y, farr, tarr = gi.ss_inputs()
+    F = farr.shape[0]
+    for K in gi.SS_K:
+        ds = dataset.ESC_pc_temp_maxKSS(x, y, farr, tarr, K, device=dev)
+        assert len(ds) == x.shape[2] and ds.num_points == K
+        idx = torch.arange(x.shape[2], device=dev)
+        pts, lab, sel = ds.batch(idx, want_sel=True)
+        assert pts.shape == (x.shape[2], K, 3) and pts.dtype == torch.float32
+        assert lab.cpu().tolist() == y.tolist()
+        for i in range(x.shape[2]):
+            ref_sel, ref_val = golden_ss[f"maxK{K}/sel{i}"], golden_ss[f"maxK{K}/val{i}"]
+            np.testing.assert_array_equal(pts[i, :, 2].cpu().numpy(), ref_val)
+            s = sel[i].cpu().numpy()
+            same_up_to_ties(s, ref_sel, ref_val, f"K={K} set {i}")
+            np.testing.assert_array_equal(pts[i, :, 0].cpu().numpy(),
+                                          farr[s % F].astype(np.float32))
+            np.testing.assert_array_equal(pts[i, :, 1].cpu().numpy(),
+                                          tarr[s // F].astype(np.float32))
+            pc, lbl = ds[i]
+            assert pc.dtype == torch.float64 and tuple(pc.shape) == (K, 3)
+            assert int(lbl) == int(golden_ss[f"maxK{K}/label{i}"])
+            np.testing.assert_array_equal(pc[:, 2].numpy().astype(np.float32), ref_val)
+    # the small fixture of golden_dataset.npz (exact float64 items, no ties)
+    g = golden_dataset
+    x3, y3, f3, t3 = g["pc3d/x"], g["pc3d/y"], g["pc3d/farr"], g["pc3d/tarr"]
+    for K in (1, 7, 24):
+        ds = dataset.ESC_pc_temp_maxKSS(x3, y3, f3, t3, K, device=dev)
+        for i in range(3):
+            np.testing.assert_array_equal(ds[i][0].numpy(), g[f"pc3d/maxK{K}/item{i}"])
+
+
+@pytest.mark.gpu
+def test_maxk_ties_and_ragged_sizes(dev):
+    """Equal values keep ascending point order (the oracle's stable argsort); N that is not a
+    power of two, K = 1, K = N, NaN last, -0 == +0."""
+    import pca_hip
+    from oracle import st_oracle as orc
+    rng = np.random.Generator(np.random.PCG64(5))
+    for F, Nt in ((7, 3), (100, 1), (1025, 1), (513, 9), (512, 20), (16384, 1)):
+        S = 4
+        x = rng.integers(-6, 3, size=(F, Nt, S)).astype(np.float32)       # many ties
+        x[0, 0, 1] = -0.0
+        farr = np.linspace(0, 0.5, F)
+        tarr = np.linspace(0, 0.1, Nt)
+        N = F * Nt
+        for K in sorted({1, min(5, N), N // 2, N}):
+            pts, _, sel = pca_hip.subsample_points(
+                T(x, dev), T(farr.astype(np.float32), dev),
+                T(tarr.astype(np.float32), dev) if Nt > 1 else None,
+                torch.arange(S, device=dev), K, want_sel=True) if Nt > 1 else \
+                pca_hip.subsample_points(T(x[:, 0, :], dev), T(farr.astype(np.float32), dev),
+                                         None, torch.arange(S, device=dev), K, want_sel=True)
+            for i in range(S):
+                ref = orc.pc_maxk_3d(x, farr, tarr, i, K)
+                np.testing.assert_array_equal(sel[i].cpu().numpy(), _sel_of(ref, farr, tarr),
+                                              err_msg=f"F={F} Nt={Nt} K={K} set {i}")
+                np.testing.assert_array_equal(pts[i, :, -1].cpu().numpy(),
+                                              ref[:, 2].astype(np.float32))
+    xn = np.array([[1.0, np.nan, 3.0, -np.inf, np.inf, 2.0]], dtype=np.float32).T   # [6, 1]
+    _, _, sel = pca_hip.subsample_points(T(xn, dev), T(np.zeros(6, np.float32), dev), None,
+                                         torch.zeros(1, dtype=torch.int64, device=dev), 6,
+                                         want_sel=True)
+    assert sel[0].cpu().tolist() == [4, 2, 5, 0, 3, 1]                    # NaN last (numpy)
+
+
+@pytest.mark.gpu
+def test_randk_is_a_uniform_subset(dev):
+    """ESC_pc_temp_randKSS: every item is K distinct points of the set with their own values;
+    over many draws each point is kept with probability K/N and first positions are uniform
+    (the reference's np.random.permutation(N)[:K], Code/dataset.py:236; stream differs)."""
+    import dataset
+    F, Nt, S, K = 32, 4, 2, 16
+    N = F * Nt
+    rng = np.random.Generator(np.random.PCG64(9))
+    x = rng.normal(-9, 3, size=(F, Nt, S)).astype(np.float32)
+    farr, tarr = np.linspace(0, 0.5, F), np.linspace(0, 0.1, Nt)
+    ds = dataset.ESC_pc_temp_randKSS(x, np.arange(S), farr, tarr, K, device=dev, seed=3)
+    idx = torch.zeros(2048, dtype=torch.int64, device=dev)
+    counts, first = np.zeros(N), np.zeros(N)
+    draws = 8
+    for _ in range(draws):
+        pts, lab, sel = ds.batch(idx, want_sel=True)
+        s = sel.cpu().numpy()
+        assert ((s >= 0) & (s < N)).all()
+        assert all(len(set(r)) == K for r in s[:64])
+        np.testing.assert_array_equal(pts[:, :, 2].cpu().numpy(),
+                                      x[:, :, 0].T.reshape(-1)[s])          # p = t*F + f
+        np.testing.assert_array_equal(pts[:, :, 0].cpu().numpy(),
+                                      farr.astype(np.float32)[s % F])
+        counts += np.bincount(s.reshape(-1), minlength=N)
+        first += np.bincount(s[:, 0], minlength=N)
+    n = draws * 2048
+    p = K / N
+    z = (counts - n * p) / np.sqrt(n * p * (1 - p))
+    assert np.abs(z).max() < 5.0, np.abs(z).max()
+    zf = (first - n / N) / np.sqrt(n / N * (1 - 1 / N))
+    assert np.abs(zf).max() < 5.0, np.abs(zf).max()
+    # a different draw number gives a different selection; the same (seed, draw) repeats
+    a = ds.batch(idx[:4], want_sel=True)[2].cpu().numpy()
+    ds2 = dataset.ESC_pc_temp_randKSS(x, np.arange(S), farr, tarr, K, device=dev, seed=3)
+    for _ in range(draws):
+        ds2.batch(idx[:4])
+    b = ds2.batch(idx[:4], want_sel=True)[2].cpu().numpy()
+    np.testing.assert_array_equal(a, b)
+    item, lbl = ds[1]
+    assert item.dtype == torch.float64 and tuple(item.shape) == (K, 3) and int(lbl) == 1
+
+
+@pytest.mark.gpu
+def test_utils_and_pc_ss(dev, golden_ss):
+    """utils.pc_maxK / pc_randK / *_replace and ESC_pc_ss against the oracle and the items the
+    reference's ESC_pc_ss produced."""
+    import dataset
+    import utils
+    from oracle import st_oracle as orc
+    x, y, farr, tarr = gi.ss_inputs()
+    x2 = x[:, 0, :]
+    xs, fs = utils.pc_maxK(x2, farr, 51)
+    oxs, ofs = orc.pc_maxk_2d(x2, farr, 51)
+    assert xs.dtype == x2.dtype and fs.dtype == farr.dtype
+    np.testing.assert_array_equal(xs, oxs)
+    np.testing.assert_array_equal(fs, ofs)
+    ds = dataset.ESC_pc_ss(xs, y, fs, device=dev)
+    assert len(ds) == int(golden_ss["ss2d/len"])
+    pts, lab = ds.batch(torch.arange(x2.shape[1], device=dev))
+    for i in range(x2.shape[1]):
+        np.testing.assert_array_equal(pts[i].cpu().numpy(), golden_ss[f"ss2d/item{i}"])
+        np.testing.assert_array_equal(ds[i][0].numpy(), golden_ss[f"ss2d/item{i}"])
+    assert lab.cpu().tolist() == y.tolist()
+    np.testing.assert_array_equal(utils.pc_maxK_replace(x2, 51), orc.pc_maxk_replace(x2, 51))
+    xr, fr = utils.pc_randK(x2, farr, 40, seed=1)
+    assert xr.shape == fr.shape == (40, x2.shape[1])
+    for i in range(x2.shape[1]):
+        pos = np.searchsorted(farr, fr[:, i])
+        assert len(set(pos)) == 40
+        np.testing.assert_array_equal(xr[:, i], x2[pos, i])
+    rr = utils.pc_randK_replace(x2, 40, seed=2)
+    assert rr.dtype == np.float64 and ((rr != 0).sum(0) == 40).all()
+    assert ((rr == 0) | (rr == x2)).all()
+    model = torch.nn.Linear(3, 2)
+    assert utils.count_parameters(model) == 8

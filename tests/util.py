@@ -49,3 +49,24 @@ def close_robust(a, b, tol, what="", outlier_frac=2e-4):
     assert rms <= tol / 2, f"{what}: rms {rms:.3e} > {tol / 2:.1e}"
     assert bad <= outlier_frac, f"{what}: {bad:.2e} of elements off by > {tol:.1e} (max {d.max():.2e})"
     return float(d.max()) if d.size else 0.0
+
+
+def same_up_to_ties(sel, ref_sel, vals, what=""):
+    """Selections agree except for permutations inside runs of equal values (which the
+    reference orders by an unstable sort); a run cut by the K boundary may pick different
+    members, so there only the values are compared."""
+    sel, ref_sel, vals = np.asarray(sel), np.asarray(ref_sel), np.asarray(vals)
+    assert sel.shape == ref_sel.shape == vals.shape, (what, sel.shape, ref_sel.shape)
+    K = len(vals)
+    q = 0
+    while q < K:
+        e = q + 1
+        while e < K and vals[e] == vals[q]:
+            e += 1
+        if e < K or e - q == 1:
+            if e - q == 1:
+                ok = sel[q] == ref_sel[q] or (e == K)     # last single may be a cut tie
+            else:
+                ok = sorted(sel[q:e]) == sorted(ref_sel[q:e])
+            assert ok, f"{what}: rows {q}..{e} differ: {sel[q:e]} vs {ref_sel[q:e]}"
+        q = e
