@@ -108,6 +108,23 @@ int pca_subsample_points(const float* spec, int64_t stride_f, int64_t stride_t,
                          uint64_t seed, uint64_t draw, float* out, int32_t* sel,
                          const int64_t* labels, int64_t* labels_out, void* stream);
 
+/* Importance-sampled point sets for a batch of frame chunks
+ * replaces: Code/dataset.py:243-289  ESC_pc_temp_importancerandKSS.__getitem__
+ * heat[f, t] = (|d/df x| + |d/dt x|, torch.gradient) correlated with kern[2][winF] (the
+ * caller passes kaiser(2) (x) kaiser(winF), beta 5.09, periodic, as the reference builds it),
+ * zero 'same' padding, + 1e-6.  choice 1: the K flat heat indices i = f*Nt + t of largest
+ * heat, descending (K <= N); choice 0: K draws with replacement from heat / sum(heat), stream
+ * (seed, draw, batch slot, set).  As in the reference, index i then addresses ROW i of the
+ * time-major point table: out[b, q] = (farr[i % F], tarr[i / F], x[i % F, i / F]).
+ * sel (nullable) [B, K] int32 = i; heat (nullable) [B, F, Nt] receives the heat maps.
+ * Requires F >= 2, Nt >= 2, F*Nt <= 16384. */
+int pca_importance_points(const float* spec, int64_t stride_f, int64_t stride_t,
+                          int64_t stride_s, const float* farr, const float* tarr,
+                          const int64_t* idx, int B, int F, int Nt, int K, int choice,
+                          const float* kern, int winF, uint64_t seed, uint64_t draw,
+                          float* out, int32_t* sel, float* heat, const int64_t* labels,
+                          int64_t* labels_out, void* stream);
+
 /* 2-D point sets from per-frame tables (the output of pc_maxK / pc_randK)
  * replaces: Code/dataset.py:76-80  ESC_pc_ss.__getitem__ (+ default_collate)
  * x_tk[T, K] values and f_tk[T, K] coordinates, frame-major; out[B, K, 2] =

@@ -332,6 +332,46 @@ def pack_points_2d_ss(x: np.ndarray, farr: np.ndarray, idx: int) -> np.ndarray:
     return np.stack((farr[:, idx], x[:, idx]), axis=1).astype(np.float32)
 
 
+def kaiser_periodic(n: int, beta: float = 5.09) -> np.ndarray:
+    """torch.kaiser_window(n, periodic=True, beta): the symmetric window of n+1 samples
+    without its last one."""
+    k = np.arange(n, dtype=np.float64)
+    return np.i0(beta * np.sqrt(np.maximum(0.0, 1.0 - (2.0 * k / n - 1.0) ** 2))) / np.i0(beta)
+
+
+def importance_heat(xt: np.ndarray, winF: int) -> np.ndarray:
+    """Heat map of Code/dataset.py:281-284 in float64: |d/df| + |d/dt| (central differences,
+    one-sided at the edges = torch.gradient), cross-correlated with kaiser(2) (x)
+    kaiser(winF) under zero 'same' padding (F.conv2d pads (k-1)//2 before, the rest after),
+    + 1e-6.  xt [F, Nt]."""
+    xt = xt.astype(np.float64)
+    g0, g1 = np.gradient(xt)
+    g = np.abs(g0) + np.abs(g1)
+    k = np.outer(kaiser_periodic(2), kaiser_periodic(winF))
+    F, Nt = g.shape
+    padl = (winF - 1) // 2
+    gp = np.zeros((F + 1, Nt + winF - 1))
+    gp[:F, padl:padl + Nt] = g
+    out = np.zeros((F, Nt))
+    for a in range(2):
+        for c in range(winF):
+            out += k[a, c] * gp[a:a + F, c:c + Nt]
+    return out + 1.0e-6
+
+
+def pc_importance_topk(x: np.ndarray, farr: np.ndarray, tarr: np.ndarray, idx: int, K: int,
+                       winF: int) -> np.ndarray:
+    """Code/dataset.py:275-289 with choice = 1: rows (-heat.flatten()).argsort()[:K] of the
+    time-major point table (the flat heat index f*Nt + t is used as the table row, as the
+    reference does).  float64 [K, 3]."""
+    F, Nt = farr.shape[0], tarr.shape[0]
+    xt = x[:, :, idx]
+    heat = importance_heat(xt, winF)
+    order = np.argsort(-heat.reshape(-1), kind="stable")[:K]
+    f, t = order % F, order // F
+    return np.stack((farr[f], tarr[t], xt[f, t].astype(np.float64)), axis=1)
+
+
 # --------------------------------------------------------------------------- #
 # STFT + log magnitude                                                         #
 # --------------------------------------------------------------------------- #

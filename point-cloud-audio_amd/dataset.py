@@ -19,7 +19,7 @@ from torch.utils.data import Dataset
 import pca_hip
 
 __all__ = ["ESC_pc", "ESC_pc_ss", "ESC_pc_temp", "ESC_pc_temp_maxKSS", "ESC_pc_temp_randKSS",
-           "DeviceBatchLoader"]
+           "ESC_pc_temp_importancerandKSS", "DeviceBatchLoader"]
 
 
 def _dev(device) -> torch.device:
@@ -231,6 +231,33 @@ class ESC_pc_temp_randKSS(_TempSS):
     device stream (seed, draw number, set), so runs are reproducible per ``seed`` and only
     the distribution matches the reference."""
     _mode = pca_hip.RANDK
+
+
+class ESC_pc_temp_importancerandKSS(_TempSS):
+    """Importance-sampled 3-D point sets (Code/dataset.py:243-289, the rebuttal experiment):
+    a heat map (spectrogram gradient magnitude smoothed by a 2 x winF Kaiser kernel, + 1e-6)
+    picks K points per chunk: ``choice`` 0 = K draws with replacement from the normalised
+    heat map, 1 = the K hottest cells.  The selected flat heat index addresses the
+    time-major point table exactly as in the reference (see pca_importance_points).
+    Random draws come from the counter-based device stream (``seed``), not torch's global
+    generator."""
+
+    def __init__(self, x, y, farr, tarr, K, choice, winF, device=None, seed: int = 0):
+        super().__init__(x, y, farr, tarr, K, device=device, seed=seed)
+        self.choice = int(choice)
+        self.winF = int(winF)
+        self._kern = None
+
+    def batch(self, idx: torch.Tensor, out=None, labels_out=None, want_sel: bool = False,
+              want_heat: bool = False):
+        spec, f32, t32, lab = self._resident()
+        if self._kern is None:
+            self._kern = pca_hip.importance_kernel(self.winF).to(spec.device)
+        self._draw += 1
+        return pca_hip.importance_points(spec, f32, t32, idx, self.K, self.choice, self._kern,
+                                         self.seed, self._draw, lab, out=out,
+                                         labels_out=labels_out, want_sel=want_sel,
+                                         want_heat=want_heat)
 
 
 class DeviceBatchLoader:

@@ -1,6 +1,6 @@
 """pca_hip: MI355X (gfx950) kernels for the point-cloud-audio hot path, bound over the C ABI
 of libpca_hip.so (include/pca_hip.h)."""
 from ._lib import LIB_PATH, PcaHipError, lib  # noqa: F401
-from .ops import (MAXK, RANDK, cross_entropy, get_mode, linear, mab, mab_infer,  # noqa: F401
-                  pack_points_2d, pack_points_2d_ss, pack_points_3d, set_mode, stft_logmag,
+from .ops import (MAXK, RANDK, cross_entropy, get_mode, importance_kernel,  # noqa: F401
+                  importance_points, linear, mab, mab_infer, pack_points_2d, pack_points_2d_ss, pack_points_3d, set_mode, stft_logmag,
                   subsample_points)

@@ -360,3 +360,47 @@ def pack_points_2d_ss(x_tk: torch.Tensor, f_tk: torch.Tensor, idx: torch.Tensor,
                                           _ptr(labels), _ptr(labels_out), _stream(x_tk)),
               "pca_pack_points_2d_ss")
     return out, labels_out
+
+
+def importance_kernel(winF: int) -> torch.Tensor:
+    """The [2, winF] smoothing kernel of Code/dataset.py:283: outer product of two periodic
+    Kaiser windows (beta 5.09), built with the same torch calls so that the weights are
+    bit-identical to the reference's."""
+    return (torch.kaiser_window(window_length=2, periodic=True, beta=5.09)[:, None]
+            @ torch.kaiser_window(window_length=int(winF), periodic=True, beta=5.09)[None, :]
+            ).contiguous()
+
+
+def importance_points(spec: torch.Tensor, farr: torch.Tensor, tarr: torch.Tensor,
+                      idx: torch.Tensor, K: int, choice: int, kern: torch.Tensor,
+                      seed: int = 0, draw: int = 0, labels: Optional[torch.Tensor] = None,
+                      out: Optional[torch.Tensor] = None,
+                      labels_out: Optional[torch.Tensor] = None, want_sel: bool = False,
+                      want_heat: bool = False):
+    """Batch of ESC_pc_temp_importancerandKSS items (pca_importance_points): spec [F, Nt, S]
+    through its strides, kern [2, winF] float32 on the device.  Returns
+    (points [B, K, 3], labels[idx] or None[, sel int32 [B, K]][, heat [B, F, Nt]])."""
+    _need_cuda(spec, farr, tarr, idx, kern)
+    assert spec.dtype == torch.float32 and idx.dtype == torch.int64
+    assert kern.dtype == torch.float32 and kern.is_contiguous() and kern.shape[0] == 2
+    F, Nt, _ = spec.shape
+    B = idx.numel()
+    with torch.cuda.device(spec.device):
+        if out is None:
+            out = torch.empty((B, K, 3), dtype=torch.float32, device=spec.device)
+        if labels is not None and labels_out is None:
+            labels_out = torch.empty(B, dtype=torch.int64, device=spec.device)
+        sel = torch.empty((B, K), dtype=torch.int32, device=spec.device) if want_sel else None
+        heat = torch.empty((B, F, Nt), dtype=torch.float32, device=spec.device) \
+            if want_heat else None
+        check(lib().pca_importance_points(
+            _ptr(spec), spec.stride(0), spec.stride(1), spec.stride(2), _ptr(farr), _ptr(tarr),
+            _ptr(idx), B, F, Nt, int(K), int(choice), _ptr(kern), int(kern.shape[1]),
+            int(seed) & (2 ** 64 - 1), int(draw) & (2 ** 64 - 1), _ptr(out), _ptr(sel),
+            _ptr(heat), _ptr(labels), _ptr(labels_out), _stream(spec)), "pca_importance_points")
+    res = [out, labels_out]
+    if want_sel:
+        res.append(sel)
+    if want_heat:
+        res.append(heat)
+    return tuple(res)

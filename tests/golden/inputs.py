@@ -119,6 +119,7 @@ def agreement_sets(seed: int, n: int, N: int, din: int, chunk: int = 100):
 # sub-sampling datasets at the shipped 3ST framing                             #
 # --------------------------------------------------------------------------- #
 SS_K = [1, 51, 2551, 5120]
+IMP_WINF = [5, 8]
 
 
 def ss_inputs(F: int = 512, Nt: int = 10, S: int = 3, seed: int = 8080):

@@ -52,6 +52,27 @@ def main():
         pc, lbl = ds2[i]
         out[f"ss2d/item{i}"] = pc.numpy()
         out[f"ss2d/sel{i}"] = order[:, i].astype(np.int32)
+    # importance sampling (Code/dataset.py:243-289), deterministic choice = 1; the heat map is
+    # recomputed with the reference's own torch expressions to set the test tolerance
+    import torch
+    for winF in gi.IMP_WINF:
+        for K in (51, 2551):
+            ds = ref_dataset.ESC_pc_temp_importancerandKSS(x3, y3, farr, tarr, K, 1, winF)
+            for i in range(x3.shape[2]):
+                pc, lbl = ds[i]
+                pc = pc.numpy()
+                f = np.searchsorted(farr, pc[:, 0])
+                t = np.searchsorted(tarr, pc[:, 1])
+                out[f"imp{winF}/K{K}/sel{i}"] = (t * F + f).astype(np.int32)
+                out[f"imp{winF}/K{K}/val{i}"] = pc[:, 2].astype(np.float32)
+        for i in range(x3.shape[2]):
+            g = torch.gradient(torch.tensor(x3[:, :, i]))
+            g = g[0].abs() + g[1].abs()
+            k = torch.kaiser_window(window_length=2, periodic=True, beta=5.09)[:, None] @ \
+                torch.kaiser_window(window_length=winF, periodic=True, beta=5.09)[None, :]
+            g = torch.nn.functional.conv2d(g[None, None, ...], k[None, None],
+                                           padding='same')[0, 0] + 1.0e-6
+            out[f"imp{winF}/heat{i}"] = g.numpy()
     np.savez_compressed(os.path.join(HERE, "golden_ss.npz"), **out)
     print("golden_ss.npz", len(out), "arrays")
 

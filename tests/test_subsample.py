@@ -204,3 +204,92 @@ def test_utils_and_pc_ss(dev, golden_ss):
     assert ((rr == 0) | (rr == x2)).all()
     model = torch.nn.Linear(3, 2)
     assert utils.count_parameters(model) == 8
+
+
+# -------------------------------------------------------------------- importance sampling
+def test_oracle_importance(golden_ss):
+    """Oracle heat map against the reference's torch expressions; top-K rows against the
+    reference dataset's items (the q-th hottest cell must carry the same heat)."""
+    from oracle import st_oracle as orc
+    x, y, farr, tarr = gi.ss_inputs()
+    F = farr.shape[0]
+    for winF in gi.IMP_WINF:
+        for i in range(x.shape[2]):
+            heat = orc.importance_heat(x[:, :, i], winF)
+            ref_heat = golden_ss[f"imp{winF}/heat{i}"]
+            np.testing.assert_allclose(heat, ref_heat, rtol=2e-6, atol=1e-6)
+            for K in (51, 2551):
+                pc = orc.pc_importance_topk(x, farr, tarr, i, K, winF)
+                sel = _sel_of(pc, farr, tarr)
+                ref_sel = golden_ss[f"imp{winF}/K{K}/sel{i}"]
+                assert len(set(sel.tolist())) == K
+                hq = ref_heat.reshape(-1)
+                np.testing.assert_allclose(hq[sel], hq[ref_sel], rtol=5e-6, atol=0)
+                assert (sel == ref_sel).mean() > 0.99
+                same = sel == ref_sel
+                np.testing.assert_array_equal(pc[same, 2].astype(np.float32),
+                                              golden_ss[f"imp{winF}/K{K}/val{i}"][same])
+
+
+@pytest.mark.gpu
+def test_importance_topk_and_heat(dev, golden_ss):
+    import dataset
+    x, y, farr, tarr = gi.ss_inputs()
+    F = farr.shape[0]
+    idx = torch.arange(x.shape[2], device=dev)
+    for winF in gi.IMP_WINF:
+        for K in (51, 2551):
+            ds = dataset.ESC_pc_temp_importancerandKSS(x, y, farr, tarr, K, 1, winF, device=dev)
+            pts, lab, sel, heat = ds.batch(idx, want_sel=True, want_heat=True)
+            assert lab.cpu().tolist() == y.tolist()
+            for i in range(x.shape[2]):
+                ref_heat = golden_ss[f"imp{winF}/heat{i}"]
+                np.testing.assert_allclose(heat[i].cpu().numpy(), ref_heat, rtol=2e-6, atol=1e-6)
+                s = sel[i].cpu().numpy()
+                ref_sel = golden_ss[f"imp{winF}/K{K}/sel{i}"]
+                assert len(set(s.tolist())) == K
+                hq = ref_heat.reshape(-1)
+                np.testing.assert_allclose(hq[s], hq[ref_sel], rtol=5e-6, atol=0)
+                assert (s == ref_sel).mean() > 0.99
+                # rows are row s of the time-major point table, as in the reference
+                np.testing.assert_array_equal(pts[i, :, 0].cpu().numpy(),
+                                              farr.astype(np.float32)[s % F])
+                np.testing.assert_array_equal(pts[i, :, 1].cpu().numpy(),
+                                              tarr.astype(np.float32)[s // F])
+                np.testing.assert_array_equal(pts[i, :, 2].cpu().numpy(), x[s % F, s // F, i])
+                same = s == ref_sel
+                np.testing.assert_array_equal(pts[i, :, 2].cpu().numpy()[same],
+                                              golden_ss[f"imp{winF}/K{K}/val{i}"][same])
+            item, lbl = ds[1]
+            assert item.dtype == torch.float64 and tuple(item.shape) == (K, 3)
+
+
+@pytest.mark.gpu
+def test_importance_multinomial_distribution(dev):
+    """choice 0: draws with replacement follow heat / sum(heat) (torch.multinomial in the
+    reference; the stream differs).  Chi-square style check per cell on a small set."""
+    import dataset
+    from oracle import st_oracle as orc
+    F, Nt, K, winF = 16, 6, 64, 3
+    rng = np.random.Generator(np.random.PCG64(11))
+    x = rng.normal(-9, 3, size=(F, Nt, 1)).astype(np.float32)
+    farr, tarr = np.linspace(0, 0.5, F), np.linspace(0, 0.1, Nt)
+    ds = dataset.ESC_pc_temp_importancerandKSS(x, np.zeros(1, np.int64), farr, tarr, K, 0, winF,
+                                               device=dev, seed=5)
+    idx = torch.zeros(4096, dtype=torch.int64, device=dev)
+    counts = np.zeros(F * Nt)
+    for _ in range(4):
+        pts, lab, sel = ds.batch(idx, want_sel=True)
+        s = sel.cpu().numpy()
+        assert ((s >= 0) & (s < F * Nt)).all()
+        counts += np.bincount(s.reshape(-1), minlength=F * Nt)
+        np.testing.assert_array_equal(pts[:, :, 2].cpu().numpy(), x[s % F, s // F, 0])
+    heat = orc.importance_heat(x[:, :, 0], winF).reshape(-1)
+    p = heat / heat.sum()
+    n = counts.sum()
+    z = (counts - n * p) / np.sqrt(n * p * (1 - p))
+    assert np.abs(z).max() < 5.0, np.abs(z).max()
+    # K may exceed the number of points when drawing with replacement
+    big = dataset.ESC_pc_temp_importancerandKSS(x, np.zeros(1, np.int64), farr, tarr, 500, 0,
+                                                winF, device=dev)
+    assert tuple(big.batch(idx[:2])[0].shape) == (2, 500, 3)
