@@ -90,6 +90,17 @@ int pca_pack_points_3d(const float* spec, int64_t stride_f, int64_t stride_t,
                        const int64_t* idx, int B, int F, int Nt, float* out,
                        const int64_t* labels, int64_t* labels_out, void* stream);
 
+/* Padded batch of variable-size 3-D point sets (no reference counterpart: the reference
+ * discards short chunks, Code/settransformertemp.py:54-58).  Chunk s holds nt_valid[s] <= Nt
+ * frames; its nt_valid[s]*F points are the prefix of the padded set (time-major order), the
+ * remaining rows are written as zeros and lengths_out[b] = nt_valid[idx[b]]*F is what
+ * pca_st_forward / pca_st_train_fwd_bwd take as `lengths`. */
+int pca_pack_points_3d_var(const float* spec, int64_t stride_f, int64_t stride_t,
+                           int64_t stride_s, const float* farr, const float* tarr,
+                           const int32_t* nt_valid, const int64_t* idx, int B, int F, int Nt,
+                           float* out, int32_t* lengths_out, const int64_t* labels,
+                           int64_t* labels_out, void* stream);
+
 /* Sub-sampled point sets for a batch of frames / frame chunks, selected on the device
  * replaces: Code/dataset.py:189-199  ESC_pc_temp_maxKSS.__getitem__  (mode 0)
  *           Code/dataset.py:229-239  ESC_pc_temp_randKSS.__getitem__ (mode 1)
@@ -149,6 +160,12 @@ typedef struct pca_mab_shape {
   int32_t q_shared;  /* 1: Q is [nq, dq] shared by all sets; 0: Q is [B, nq, dq] */
   int32_t mode;      /* PCA_MODE_F32 | PCA_MODE_BF16                             */
   int32_t q_dtype, k_dtype, y_dtype;   /* PCA_F32 | PCA_BF16 of Q, K and Y       */
+  /* Variable-size sets (no reference counterpart: the reference batches are dense).
+   * Device int32[B] or NULL: set b has k_lengths[b] valid keys (1 <= k_lengths[b] <= nk);
+   * keys at and beyond it take no part in the softmax, so the block's output equals the
+   * output on the truncated set.  Padding rows of K must hold finite values (the pack
+   * kernels write zeros); their gradient rows come out as exact zeros. */
+  const int32_t* k_lengths;
 } pca_mab_shape;
 
 /* nn.Linear layout: weight [d_out, d_in] row-major, y = x W^T + b.  fp32. */
@@ -241,18 +258,21 @@ int64_t pca_st_param_count(const pca_st_config* c);
 int64_t pca_st_bucket_split(const pca_st_config* c);
 size_t pca_st_ws_bytes(const pca_st_config* c, int training);
 
-/* logits[B*k, C] = ST(X[B, N, din]) -- inference, nothing saved */
+/* logits[B*k, C] = ST(X[B, N, din]) -- inference, nothing saved.
+ * lengths: NULL (dense batches, as the reference's), or device int32[B] with the number of
+ * valid points of each set (1 <= lengths[b] <= N, padding rows of X finite): the logits of
+ * set b then equal those of its first lengths[b] points alone (see pca_mab_shape). */
 int pca_st_forward(const pca_st_config* c, const float* params, const float* X,
-                   float* logits, void* ws, void* stream);
+                   const int32_t* lengths, float* logits, void* ws, void* stream);
 
 /* phase 0: forward, mean cross-entropy (loss_out[0]; stats += {sum loss, #correct}),
  *          backward through dec and enc.1 ; phase 1: backward through enc.0.
  * phase -1 runs both.  grads is ACCUMULATED into (caller zeroes it once per step).
  * grad_scale multiplies dlogits (1.0 normally).  labels int64[B]. */
 int pca_st_train_fwd_bwd(const pca_st_config* c, const float* params, const float* X,
-                         const int64_t* labels, float* grads, float* loss_out,
-                         float* stats, float* logits, float grad_scale, int phase,
-                         void* ws, void* stream);
+                         const int32_t* lengths, const int64_t* labels, float* grads,
+                         float* loss_out, float* stats, float* logits, float grad_scale,
+                         int phase, void* ws, void* stream);
 
 /* ------------------------------------------------------------------------- *
  * Building blocks (exported for unit tests and for composing other blocks)   *

@@ -18,7 +18,9 @@ static int check_f32(const pca_mab_shape* s) {
 // kind: 0 = exact fp32 chain of GEMMs, 1 = fused bf16 mab1 (many queries, few keys),
 //       2 = fused bf16 mab0 (few shared queries, many keys)
 int mab_kind(const pca_mab_shape& s) {
-  if (s.mode == PCA_MODE_BF16 && mab1_bf16_supported(s)) return 1;
+  // (a fused mab1 has the m inducing-point outputs as keys: always all of them; a caller that
+  // masks keys of such a shape gets the exact path, whose softmax honours k_lengths)
+  if (s.mode == PCA_MODE_BF16 && s.k_lengths == nullptr && mab1_bf16_supported(s)) return 1;
   if (s.mode == PCA_MODE_BF16 && mab0_bf16_supported(s)) return 2;
   return 0;
 }

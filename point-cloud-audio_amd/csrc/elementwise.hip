@@ -121,22 +121,30 @@ __device__ __forceinline__ float group_sum(float v) {
 // (set_transformer-master/modules.py:28)
 template <int G>
 __global__ __launch_bounds__(256) void k_softmax_rows(float* __restrict__ X, int64_t rows,
-                                                       int n, float scale) {
+                                                       int n, float scale,
+                                                       const int32_t* __restrict__ lengths,
+                                                       int64_t rows_per_set) {
   const int lane = threadIdx.x % G;
   const int64_t row = ((int64_t)blockIdx.x * 256 + threadIdx.x) / G;
   const bool live = row < rows;
   float* x = X + (live ? row : 0) * (int64_t)n;
+  // variable-size sets: only the first lengths[set] columns are keys; the rest become 0
+  int nv = n;
+  if (lengths != nullptr && live) {
+    nv = lengths[row / rows_per_set];
+    nv = nv < n ? nv : n;
+  }
   float m = -INFINITY;
   if (live)
-    for (int j = lane; j < n; j += G) m = fmaxf(m, x[j] * scale);
+    for (int j = lane; j < nv; j += G) m = fmaxf(m, x[j] * scale);
   m = group_max<G>(m);
   float s = 0.f;
   if (live)
-    for (int j = lane; j < n; j += G) s += expf(x[j] * scale - m);
+    for (int j = lane; j < nv; j += G) s += expf(x[j] * scale - m);
   s = group_sum<G>(s);
   const float inv = 1.f / s;
   if (live)
-    for (int j = lane; j < n; j += G) x[j] = expf(x[j] * scale - m) * inv;
+    for (int j = lane; j < n; j += G) x[j] = j < nv ? expf(x[j] * scale - m) * inv : 0.f;
 }
 
 // dS = A * (dA - sum_j dA_j A_j) * scale, in place on dA
@@ -264,12 +272,14 @@ inline unsigned ew_blocks(int64_t n) {
     else { CALL(8); }               \
   } while (0)
 
-int softmax_rows(float* X, int64_t rows, int n, float scale, hipStream_t st) {
+int softmax_rows(float* X, int64_t rows, int n, float scale, hipStream_t st,
+                 const int32_t* lengths, int64_t rows_per_set) {
   PCA_REQUIRE(X && n > 0 && rows >= 0, "softmax_rows: bad arguments");
+  PCA_REQUIRE(lengths == nullptr || rows_per_set > 0, "softmax_rows: rows_per_set");
   if (rows == 0) return PCA_OK;
 #define CALL(G)                                                                       \
   hipLaunchKernelGGL(k_softmax_rows<G>, dim3((unsigned)cdiv(rows * G, 256)), dim3(256), \
-                     0, st, X, rows, n, scale)
+                     0, st, X, rows, n, scale, lengths, rows_per_set)
   PCA_DISPATCH_G(n, CALL);
 #undef CALL
   return check_launch("k_softmax_rows");

@@ -107,18 +107,26 @@ __global__ __launch_bounds__(256) void k_pack_3d(const float* __restrict__ spec,
                                                   const int64_t* __restrict__ idx, int F,
                                                   int Nt, float* __restrict__ out,
                                                   const int64_t* __restrict__ labels,
-                                                  int64_t* __restrict__ labels_out) {
+                                                  int64_t* __restrict__ labels_out,
+                                                  const int32_t* __restrict__ nt_valid,
+                                                  int32_t* __restrict__ lengths_out) {
   const int b = blockIdx.y;
   const int64_t chunk = idx[b];
-  if (labels != nullptr && labels_out != nullptr && blockIdx.x == 0 && threadIdx.x == 0)
-    labels_out[b] = labels[chunk];
+  // variable-size sets: chunk s holds nt_valid[s] <= Nt frames; time-major point order makes
+  // its points a prefix of the padded set, the padding rows are written as zeros
+  const int nt = nt_valid != nullptr ? (nt_valid[chunk] < Nt ? nt_valid[chunk] : Nt) : Nt;
+  if (blockIdx.x == 0 && threadIdx.x == 0) {
+    if (labels != nullptr && labels_out != nullptr) labels_out[b] = labels[chunk];
+    if (lengths_out != nullptr) lengths_out[b] = nt * F;
+  }
   const int p = blockIdx.x * 256 + threadIdx.x;      // point index = t*F + f (time-major)
   if (p >= F * Nt) return;
   const int t = p / F, f = p - t * F;
   float* o = out + ((int64_t)b * F * Nt + p) * 3;
-  o[0] = farr[f];
-  o[1] = tarr[t];
-  o[2] = spec[f * stride_f + t * stride_t + chunk * stride_s];
+  const bool ok = t < nt;
+  o[0] = ok ? farr[f] : 0.f;
+  o[1] = ok ? tarr[t] : 0.f;
+  o[2] = ok ? spec[f * stride_f + t * stride_t + chunk * stride_s] : 0.f;
 }
 
 }  // namespace
@@ -175,7 +183,23 @@ int pca_pack_points_3d(const float* spec, int64_t stride_f, int64_t stride_t,
   hipLaunchKernelGGL(pca::k_pack_3d,
                      dim3((unsigned)pca::cdiv((int64_t)F * Nt, 256), (unsigned)B), dim3(256),
                      0, pca::as_stream(stream), spec, stride_f, stride_t, stride_s, farr,
-                     tarr, idx, F, Nt, out, labels, labels_out);
+                     tarr, idx, F, Nt, out, labels, labels_out, nullptr, nullptr);
+  return pca::check_launch("k_pack_3d");
+}
+
+int pca_pack_points_3d_var(const float* spec, int64_t stride_f, int64_t stride_t,
+                           int64_t stride_s, const float* farr, const float* tarr,
+                           const int32_t* nt_valid, const int64_t* idx, int B, int F, int Nt,
+                           float* out, int32_t* lengths_out, const int64_t* labels,
+                           int64_t* labels_out, void* stream) {
+  PCA_REQUIRE(spec && farr && tarr && nt_valid && idx && out && lengths_out,
+              "pack_points_3d_var: null pointer");
+  PCA_REQUIRE(B > 0 && F > 0 && Nt > 0 && B <= 65535, "pack_points_3d_var: B=%d F=%d Nt=%d",
+              B, F, Nt);
+  hipLaunchKernelGGL(pca::k_pack_3d,
+                     dim3((unsigned)pca::cdiv((int64_t)F * Nt, 256), (unsigned)B), dim3(256),
+                     0, pca::as_stream(stream), spec, stride_f, stride_t, stride_s, farr,
+                     tarr, idx, F, Nt, out, labels, labels_out, nt_valid, lengths_out);
   return pca::check_launch("k_pack_3d");
 }
 }

@@ -141,6 +141,7 @@ struct Mab0AttnArgs {
   float* Mp;            // [B][S][R]      partial maxima M (log2 domain)
   float* Lp;            // [B][S][R]      partial sums    sum_n 2^(s_n - M)
   int B, N, R, S;       // S = point splits per set (gridDim.y); merged by k_mab0_epi
+  const int32_t* lengths;   // [B] valid points per set, or null
 };
 
 template <int RB, bool ABF>
@@ -161,7 +162,11 @@ __global__ __launch_bounds__(256, 1) void k_mab0_attn(const Mab0AttnArgs a) {
   const int b = blockIdx.x, sp = blockIdx.y;
   // this workgroup's point range (multiples of 128 so that tiles stay aligned)
   const int per = (int)(((int64_t)(a.N + 127) / 128 + a.S - 1) / a.S) * 128;
-  const int n_lo = sp * per, n_hi = (n_lo + per < a.N) ? n_lo + per : a.N;
+  // variable-size sets: points at and beyond len never enter; a range without any point
+  // leaves the (-inf, 0, 0) partial, which the merge skips
+  int len = a.N;
+  if (a.lengths != nullptr) len = a.lengths[b] < a.N ? a.lengths[b] : a.N;
+  const int n_lo = sp * per, n_hi = (n_lo + per < len) ? n_lo + per : len;
 
   for (int c = tid; c < 16 * RB * 16; c += 256) {
     const int row = c >> 4, ch = c & 15;
@@ -318,7 +323,8 @@ __global__ __launch_bounds__(256, 1) void k_mab0_attn(const Mab0AttnArgs a) {
 __global__ __launch_bounds__(256) void k_mab0_attn_small(const float* __restrict__ X,
                                                          const float* __restrict__ Gf, int N,
                                                          int R, int dk, float* __restrict__ T,
-                                                         float* __restrict__ LSE) {
+                                                         float* __restrict__ LSE,
+                                                         const int32_t* __restrict__ lengths) {
   constexpr int CH = 2048;                    // points staged per chunk (<= 32 KiB of LDS)
   __shared__ float sM[256], sL[256], sT[256][4];
   __shared__ __attribute__((aligned(16))) float sX[CH * 4];
@@ -329,8 +335,10 @@ __global__ __launch_bounds__(256) void k_mab0_attn_small(const float* __restrict
 #pragma unroll
   for (int c = 0; c < 4; ++c) gk[c] = c < dk ? Gf[r * dk + c] : 0.f;
   float m = -INFINITY, l = 0.f, t[4] = {0.f, 0.f, 0.f, 0.f};
-  for (int n0 = 0; n0 < N; n0 += CH) {
-    const int cn = (N - n0 < CH) ? N - n0 : CH;
+  int len = N;
+  if (lengths != nullptr) len = lengths[b] < N ? lengths[b] : N;
+  for (int n0 = 0; n0 < len; n0 += CH) {
+    const int cn = (len - n0 < CH) ? len - n0 : CH;
     __syncthreads();
     // coalesced copy of cn*dk floats, re-laid out as [point][4]
     for (int i = tid; i < cn * 4; i += 256) {       // unused components must be zero, not stale LDS
@@ -575,11 +583,12 @@ int mab0_bf16_fwd_ex(const pca_mab_shape& s, const float* I, const void* X,
   const double pts = (double)s.B * s.nk;
   if (small) {
     hipLaunchKernelGGL(k_mab0_attn_small, dim3(s.B), dim3(256), 0, st,
-                       reinterpret_cast<const float*>(X), v.Gf, s.nk, R, dk, v.T, v.LSE);
+                       reinterpret_cast<const float*>(X), v.Gf, s.nk, R, dk, v.T, v.LSE,
+                       s.k_lengths);
     PCA_TRY(check_launch("k_mab0_attn_small"));
   } else {
     const int S = mab0_splits(s);
-    Mab0AttnArgs a{X, v.Gb, v.Tp, v.Mp, v.Lp, s.B, s.nk, R, S};
+    Mab0AttnArgs a{X, v.Gb, v.Tp, v.Mp, v.Lp, s.B, s.nk, R, S, s.k_lengths};
     const int RB = Rpad / 16;
     const size_t xbytes = (size_t)4 * Rpad * 128 * 4 > 4 * 32 * 256 ? (size_t)4 * Rpad * 128 * 4
                                                                      : (size_t)4 * 32 * 256;

@@ -169,6 +169,7 @@ struct Mab0BwdArgs {
   void* dX;              // [B, N, 128] (fp32 / bf16 when ABF) or null
   float* DG;             // [Rp][128] fp32, accumulated over sets (ln2-scaled dS units)
   int B, N, accumulate_dx, S;
+  const int32_t* lengths;   // [B] valid points per set, or null
 };
 
 template <int RP, bool ABF>
@@ -189,6 +190,10 @@ __global__ __launch_bounds__(256, 1) void k_mab0_bwd(const Mab0BwdArgs a) {
   const int b = blockIdx.x, sp = blockIdx.y;
   const int per = (int)(((int64_t)(a.N + 127) / 128 + a.S - 1) / a.S) * 128;
   const int n_lo = sp * per, n_hi = (n_lo + per < a.N) ? n_lo + per : a.N;
+  // variable-size sets: points at and beyond len have P = 0 (so dS = 0 and their dX rows are
+  // written as exact zeros); the loops still cover all N rows
+  int len = a.N;
+  if (a.lengths != nullptr) len = a.lengths[b] < a.N ? a.lengths[b] : a.N;
 
   for (int c = tid; c < RP * 16; c += 256) {
     const int row = c >> 4, ch = c & 15;
@@ -246,9 +251,12 @@ __global__ __launch_bounds__(256, 1) void k_mab0_bwd(const Mab0BwdArgs a) {
 #pragma unroll
       for (int ks = 0; ks < KS; ++ks)
         xrow[pb][ks] = *reinterpret_cast<const bf16x8*>(myX + tr_off(16 * pb + r, 4 * ks + g));
-    bool live[2];
+    bool live[2], key[2];          // row exists / row is a key of the (possibly shorter) set
 #pragma unroll
-    for (int pb = 0; pb < 2; ++pb) live[pb] = n0 + 16 * pb + r < n_hi;
+    for (int pb = 0; pb < 2; ++pb) {
+      live[pb] = n0 + 16 * pb + r < n_hi;
+      key[pb] = n0 + 16 * pb + r < len;
+    }
 
     f32x4 dx[FT][2];
 #pragma unroll
@@ -277,7 +285,7 @@ __global__ __launch_bounds__(256, 1) void k_mab0_bwd(const Mab0BwdArgs a) {
           }
 #pragma unroll
           for (int e = 0; e < 4; ++e) {
-            const float p = live[pb] ? exp2f(sv[e] - lse[e]) : 0.f;
+            const float p = key[pb] ? exp2f(sv[e] - lse[e]) : 0.f;
             pt[rbi][pb][e] = p;
             dst[rbi][pb][e] = LN2 * p * (da[e] - del[e]);
           }
@@ -372,7 +380,7 @@ __global__ __launch_bounds__(256, 1) void k_mab0_bwd(const Mab0BwdArgs a) {
 __global__ __launch_bounds__(256) void k_mab0_bwd_small(
     const float* __restrict__ X, const float* __restrict__ Gf, const float* __restrict__ dTf,
     const float* __restrict__ LSE, const float* __restrict__ Delta, int N, int R, int Rp, int dk,
-    float* __restrict__ DG) {
+    float* __restrict__ DG, const int32_t* __restrict__ lengths) {
   constexpr int CH = 2048;
   __shared__ float sD[256][4];
   __shared__ __attribute__((aligned(16))) float sX[CH * 4];
@@ -387,8 +395,10 @@ __global__ __launch_bounds__(256) void k_mab0_bwd_small(
     dt[c] = c < dk ? dTf[((int64_t)b * R + r) * dk + c] : 0.f;
   }
   const float lse = LSE[(int64_t)b * R + r], del = Delta[(int64_t)b * Rp + r];
-  for (int n0 = 0; n0 < N; n0 += CH) {
-    const int cn = (N - n0 < CH) ? N - n0 : CH;
+  int len = N;
+  if (lengths != nullptr) len = lengths[b] < N ? lengths[b] : N;
+  for (int n0 = 0; n0 < len; n0 += CH) {
+    const int cn = (len - n0 < CH) ? len - n0 : CH;
     __syncthreads();
     for (int i = tid; i < cn * 4; i += 256) {       // unused components must be zero, not stale LDS
       const int pt = i >> 2, c = i & 3;
@@ -565,12 +575,12 @@ int mab0_bf16_bwd_ex(const pca_mab_shape& s, const float* I, const void* X,
   if (small) {
     hipLaunchKernelGGL(k_mab0_bwd_small, dim3(s.B), dim3(256), 0, st,
                        reinterpret_cast<const float*>(X), v.Gf, w.dTf, v.LSE,
-                       w.Delta, s.nk, R, Rp, dk, w.DG);
+                       w.Delta, s.nk, R, Rp, dk, w.DG, s.k_lengths);
     PCA_TRY(check_launch("k_mab0_bwd_small"));
   } else {
     const int S = mab0_splits(s);
     Mab0BwdArgs a{X, v.Gb, v.GtP, w.dTb, w.dTt, w.LSEp, w.Delta, dX, w.DG, s.B, s.nk,
-                  dk_accumulate ? 1 : 0, S};
+                  dk_accumulate ? 1 : 0, S, s.k_lengths};
     size_t lds = 2 * (size_t)Rp * 256 + 2 * (size_t)128 * Rp * 2 + 2 * 4 * 32 * 256 +
                  2 * Rp * sizeof(float);
     if (lds < (size_t)4 * Rp * 128 * 4) lds = (size_t)4 * Rp * 128 * 4;     // merge slabs

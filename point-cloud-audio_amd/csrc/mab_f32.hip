@@ -126,7 +126,8 @@ int mab_f32_fwd(const pca_mab_shape& s, const float* Q, const float* K,
     set_heads(g, s, qb, dh, (int64_t)nk * d, dh, (int64_t)h * nq * nk, (int64_t)nq * nk);
     PCA_TRY(gemm_f32(g, v.Qp, v.Kp, nullptr, v.A, st));
   }
-  PCA_TRY(softmax_rows(v.A, (int64_t)s.B * h * nq, nk, scale, st));         // :28
+  PCA_TRY(softmax_rows(v.A, (int64_t)s.B * h * nq, nk, scale, st, s.k_lengths,
+                       (int64_t)h * nq));                                   // :28
   PCA_TRY(copy_rows(v.Qp, Bq * nq, v.O, (int64_t)s.B * nq, d, st));         // O = Q_
   {  // O_j += A_j Vp_j                                                          :29
     pca_gemm_desc g = gd(nq, dh, nk, nk, 1, d, 1, d, 1);

@@ -80,7 +80,7 @@ struct Shapes {
   pca_mab_shape m0[2], m1[2], pma;
   bool act_bf16;      // hidden activations Y1, Y2 (and their gradients) travel in bf16
 };
-inline Shapes shapes(const pca_st_config& c, bool training) {
+inline Shapes shapes(const pca_st_config& c, bool training, const int32_t* lengths = nullptr) {
   Shapes s;
   for (int li = 0; li < 2; ++li) {
     const int din = li == 0 ? c.din : c.d;
@@ -103,6 +103,8 @@ inline Shapes shapes(const pca_st_config& c, bool training) {
       s.act_bf16 = true;
     }
   }
+  // variable-size sets: the points are the KEYS of the three blocks that attend over them
+  s.m0[0].k_lengths = s.m0[1].k_lengths = s.pma.k_lengths = lengths;
   return s;
 }
 
@@ -250,14 +252,14 @@ size_t pca_st_ws_bytes(const pca_st_config* c, int training) {
 }
 
 int pca_st_forward(const pca_st_config* c, const float* params, const float* X,
-                   float* logits, void* ws, void* stream) {
+                   const int32_t* lengths, float* logits, void* ws, void* stream) {
   PCA_TRY(pca::validate(c));
   PCA_REQUIRE(params && X && logits && ws, "st_forward: null pointer");
   hipStream_t st = pca::as_stream(stream);
   pca::Ws w;
   pca::carve(*c, 0, &w, ws);
   const pca::Layout L = pca::layout(*c);
-  const pca::Shapes s = pca::shapes(*c, false);
+  const pca::Shapes s = pca::shapes(*c, false, lengths);
   float* own = w.logits;
   w.logits = logits;
   (void)own;
@@ -265,7 +267,8 @@ int pca_st_forward(const pca_st_config* c, const float* params, const float* X,
 }
 
 int pca_st_train_fwd_bwd(const pca_st_config* c, const float* params, const float* X,
-                         const int64_t* labels, float* grads, float* loss_out, float* stats,
+                         const int32_t* lengths, const int64_t* labels, float* grads,
+                         float* loss_out, float* stats,
                          float* logits, float grad_scale, int phase, void* ws,
                          void* stream) {
   PCA_TRY(pca::validate(c));
@@ -277,7 +280,7 @@ int pca_st_train_fwd_bwd(const pca_st_config* c, const float* params, const floa
   pca::Ws w;
   pca::carve(*c, 1, &w, ws);
   const pca::Layout L = pca::layout(*c);
-  const pca::Shapes s = pca::shapes(*c, true);
+  const pca::Shapes s = pca::shapes(*c, true, lengths);
   const float* p = params;
   float* g = grads;
   if (logits != nullptr) w.logits = logits;

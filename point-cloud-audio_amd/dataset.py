@@ -89,15 +89,26 @@ class ESC_pc_temp(Dataset):
     p = t*F + f (Code/dataset.py:160-166).
 
     x [F, Nt, S], y int[S], farr [F], tarr [Nt].
+
+    ``nt_valid`` (optional int[S], extension): chunk s holds only nt_valid[s] <= Nt frames (the
+    reference discards such short chunks, Code/settransformertemp.py:54-58).  ``batch`` then
+    returns padded sets and a third value, the int32 point count of every set, which
+    ``ST.forward(X, lengths)`` / the engine take to ignore the padding.
     """
 
-    def __init__(self, x, y, farr, tarr, device=None):
+    def __init__(self, x, y, farr, tarr, device=None, nt_valid=None):
         self.x = x
         self.labels = y
         self.farr = farr
         self.tarr = tarr
         self._device = device
         self._res = None
+        self.nt_valid = nt_valid
+        self._ntv = None
+
+    @property
+    def variable_length(self) -> bool:
+        return self.nt_valid is not None
 
     @classmethod
     def from_device(cls, spec_stf: torch.Tensor, labels: torch.Tensor, farr, tarr
@@ -129,16 +140,23 @@ class ESC_pc_temp(Dataset):
                          torch.as_tensor(np.asarray(self.labels)).to(dev, torch.int64))
         return self._res
 
-    def batch(self, idx: torch.Tensor, out=None, labels_out=None
-              ) -> Tuple[torch.Tensor, torch.Tensor]:
+    def batch(self, idx: torch.Tensor, out=None, labels_out=None, lengths_out=None):
         spec, f32, t32, lab = self._resident()
-        return pca_hip.pack_points_3d(spec, f32, t32, idx, lab, out=out,
-                                      labels_out=labels_out)
+        if self.nt_valid is None:
+            return pca_hip.pack_points_3d(spec, f32, t32, idx, lab, out=out,
+                                          labels_out=labels_out)
+        if self._ntv is None:
+            self._ntv = torch.as_tensor(np.asarray(self.nt_valid)).to(spec.device, torch.int32)
+        return pca_hip.pack_points_3d(spec, f32, t32, idx, lab, out=out, labels_out=labels_out,
+                                      nt_valid=self._ntv, lengths_out=lengths_out)
 
     def __getitem__(self, idx):
         spec = self._resident()[0]
         i = torch.tensor([int(idx)], dtype=torch.int64, device=spec.device)
-        pts, lbl = self.batch(i)
+        res = self.batch(i)
+        pts, lbl = res[0], res[1]
+        if self.nt_valid is not None:            # the un-padded set
+            return pts[0, :int(res[2][0])].cpu(), lbl[0].cpu()
         return pts[0].cpu(), lbl[0].cpu()
 
 
@@ -187,7 +205,7 @@ class _TempSS(ESC_pc_temp):
     _mode = pca_hip.MAXK
 
     def __init__(self, x, y, farr, tarr, K, device=None, seed: int = 0):
-        super().__init__(x, y, farr, tarr, device=device)
+        super().__init__(x, y, farr, tarr, device=device)      # dense chunks only
         self.K = int(K)
         self.seed = int(seed)
         self._draw = 0

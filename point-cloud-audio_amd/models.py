@@ -44,5 +44,12 @@ class ST(nn.Module):
             _Linear(dim_hidden, dim_output),
         )
 
-    def forward(self, X):
-        return self.dec(self.enc(X)).squeeze()
+    def forward(self, X, lengths=None):
+        """X [B, N, dim_input] -> logits [B, dim_output] (squeezed as the reference does).
+        ``lengths`` (optional int[B]): X is a padded batch of variable-size sets; set b has
+        lengths[b] points (extension: the reference only has dense batches)."""
+        if lengths is None:
+            return self.dec(self.enc(X)).squeeze()
+        for isab in self.enc:
+            X = isab(X, lengths)
+        return self.dec[1](self.dec[0](X, lengths)).squeeze()

@@ -10,6 +10,9 @@ Differences a caller can observe:
   * tensors must live on a HIP device ('cuda'); a CPU tensor raises PcaHipError;
   * ``ln=True`` (never enabled by any reference caller, Code/models.py:31) raises
     NotImplementedError at construction;
+  * an optional ``lengths`` / ``key_lengths`` argument (int[B]) marks padded batches of
+    variable-size sets: points at and beyond ``lengths[b]`` are ignored exactly as if set b
+    had been truncated (the reference has dense batches only, so this is an extension);
   * ISAB / PMA do not materialise ``I.repeat(B,1,1)`` / ``S.repeat(B,1,1)``
     (modules.py:52,63): the learned query is projected once and shared by all sets.
 """
@@ -43,13 +46,13 @@ class MAB(nn.Module):
         return (self.fc_q.weight, self.fc_q.bias, self.fc_k.weight, self.fc_k.bias,
                 self.fc_v.weight, self.fc_v.bias, self.fc_o.weight, self.fc_o.bias)
 
-    def forward(self, Q, K, q_shared=False):
+    def forward(self, Q, K, q_shared=False, key_lengths=None):
         """Q [B,nq,dim_Q] (or the shared learned query [1,nq,dim_Q] with q_shared),
-        K [B,nk,dim_K] -> [B,nq,dim_V]."""
+        K [B,nk,dim_K] -> [B,nq,dim_V].  key_lengths int[B]: valid keys per set."""
         if torch.is_grad_enabled() and (
                 Q.requires_grad or K.requires_grad or self.fc_q.weight.requires_grad):
-            return pca_hip.mab(Q, K, *self._params(), self.num_heads, q_shared)
-        return pca_hip.mab_infer(Q, K, self._params(), self.num_heads, q_shared)
+            return pca_hip.mab(Q, K, *self._params(), self.num_heads, q_shared, key_lengths)
+        return pca_hip.mab_infer(Q, K, self._params(), self.num_heads, q_shared, key_lengths)
 
 
 class SAB(nn.Module):
@@ -59,8 +62,8 @@ class SAB(nn.Module):
         super().__init__()
         self.mab = MAB(dim_in, dim_in, dim_out, num_heads, ln=ln)
 
-    def forward(self, X):
-        return self.mab(X, X)
+    def forward(self, X, lengths=None):
+        return self.mab(X, X, key_lengths=lengths)
 
 
 class ISAB(nn.Module):
@@ -73,9 +76,9 @@ class ISAB(nn.Module):
         self.mab0 = MAB(dim_out, dim_in, dim_out, num_heads, ln=ln)
         self.mab1 = MAB(dim_in, dim_out, dim_out, num_heads, ln=ln)
 
-    def forward(self, X):
-        H = self.mab0(self.I, X, q_shared=True)     # [B, m, d]
-        return self.mab1(X, H)
+    def forward(self, X, lengths=None):
+        H = self.mab0(self.I, X, q_shared=True, key_lengths=lengths)     # [B, m, d]
+        return self.mab1(X, H)      # rows at and beyond lengths[b] are padding: never read
 
 
 class PMA(nn.Module):
@@ -87,5 +90,5 @@ class PMA(nn.Module):
         nn.init.xavier_uniform_(self.S)
         self.mab = MAB(dim, dim, dim, num_heads, ln=ln)
 
-    def forward(self, X):
-        return self.mab(self.S, X, q_shared=True)
+    def forward(self, X, lengths=None):
+        return self.mab(self.S, X, q_shared=True, key_lengths=lengths)

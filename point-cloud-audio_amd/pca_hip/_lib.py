@@ -24,7 +24,7 @@ c_i64p = C.c_void_p
 class MabShape(C.Structure):
     _fields_ = [(n, C.c_int32) for n in
                 ("B", "nq", "nk", "dq", "dk", "d", "h", "q_shared", "mode",
-                 "q_dtype", "k_dtype", "y_dtype")]
+                 "q_dtype", "k_dtype", "y_dtype")] + [("k_lengths", C.c_void_p)]
 
 
 class MabParams(C.Structure):
@@ -61,6 +61,9 @@ SIGNATURES = {
     "pca_pack_points_3d": (C.c_int, [c_fp, C.c_int64, C.c_int64, C.c_int64, c_fp, c_fp,
                                      c_i64p, C.c_int, C.c_int, C.c_int, c_fp, c_i64p, c_i64p,
                                      c_vp]),
+    "pca_pack_points_3d_var": (C.c_int, [c_fp, C.c_int64, C.c_int64, C.c_int64, c_fp, c_fp,
+                                         c_vp, c_i64p, C.c_int, C.c_int, C.c_int, c_fp, c_vp,
+                                         c_i64p, c_i64p, c_vp]),
     "pca_mab_saved_bytes": (C.c_size_t, [C.POINTER(MabShape)]),
     "pca_mab_fwd_ws_bytes": (C.c_size_t, [C.POINTER(MabShape)]),
     "pca_mab_bwd_ws_bytes": (C.c_size_t, [C.POINTER(MabShape)]),
@@ -89,9 +92,9 @@ SIGNATURES = {
     "pca_st_param_count": (C.c_int64, [C.POINTER(StConfig)]),
     "pca_st_bucket_split": (C.c_int64, [C.POINTER(StConfig)]),
     "pca_st_ws_bytes": (C.c_size_t, [C.POINTER(StConfig), C.c_int]),
-    "pca_st_forward": (C.c_int, [C.POINTER(StConfig), c_fp, c_fp, c_fp, c_vp, c_vp]),
-    "pca_st_train_fwd_bwd": (C.c_int, [C.POINTER(StConfig), c_fp, c_fp, c_i64p, c_fp, c_fp,
-                                       c_fp, c_fp, C.c_float, C.c_int, c_vp, c_vp]),
+    "pca_st_forward": (C.c_int, [C.POINTER(StConfig), c_fp, c_fp, c_vp, c_fp, c_vp, c_vp]),
+    "pca_st_train_fwd_bwd": (C.c_int, [C.POINTER(StConfig), c_fp, c_fp, c_vp, c_i64p, c_fp,
+                                       c_fp, c_fp, c_fp, C.c_float, C.c_int, c_vp, c_vp]),
     "pca_prof_start": (C.c_int, [C.c_int, C.c_int]),
     "pca_prof_stop": (C.c_int, [C.POINTER(C.c_double), C.POINTER(C.c_int64),
                                 C.POINTER(C.c_double), C.POINTER(C.c_double)]),

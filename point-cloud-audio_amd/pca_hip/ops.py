@@ -57,9 +57,19 @@ def _bytes(n: int, like: torch.Tensor) -> torch.Tensor:
     return torch.empty(max(int(n), 256), dtype=torch.uint8, device=like.device)
 
 
-def _shape(B, nq, nk, dq, dk, d, h, q_shared, mode=_lib.MODE_F32) -> MabShape:
+def _shape(B, nq, nk, dq, dk, d, h, q_shared, mode=_lib.MODE_F32, k_lengths=None) -> MabShape:
     return MabShape(B, nq, nk, dq, dk, d, h, int(q_shared), mode, _lib.PCA_F32,
-                    _lib.PCA_F32, _lib.PCA_F32)
+                    _lib.PCA_F32, _lib.PCA_F32, 0 if k_lengths is None else k_lengths.data_ptr())
+
+
+def _lengths(key_lengths, B: int, like: torch.Tensor):
+    """int32[B] on the device of ``like`` (the library reads it there), or None."""
+    if key_lengths is None:
+        return None
+    kl = torch.as_tensor(key_lengths).to(like.device, torch.int32).contiguous()
+    if kl.shape != (B,):
+        raise RuntimeError(f"key_lengths must have shape ({B},), got {tuple(kl.shape)}")
+    return kl
 
 
 def _pick_mode(s: MabShape) -> MabShape:
@@ -77,7 +87,8 @@ class _MabFn(torch.autograd.Function):
     """set_transformer-master/modules.py:19-33 MAB.forward + its adjoint."""
 
     @staticmethod
-    def forward(ctx, Q, K, wq, bq, wk, bk, wv, bv, wo, bo, num_heads: int, q_shared: bool):
+    def forward(ctx, Q, K, wq, bq, wk, bk, wv, bv, wo, bo, num_heads: int, q_shared: bool,
+                key_lengths=None):
         _need_cuda(Q, K, wq)
         Q, K = _f32c(Q), _f32c(K)
         params = [_f32c(p) for p in (wq, bq, wk, bk, wv, bv, wo, bo)]
@@ -91,7 +102,9 @@ class _MabFn(torch.autograd.Function):
         d = params[0].shape[0]
         if params[0].shape[1] != dq or params[2].shape[1] != dk:
             raise RuntimeError("MAB: input width does not match fc_q / fc_k")
-        s = _pick_mode(_shape(B, nq, nk, dq, dk, d, num_heads, q_shared))
+        kl = _lengths(key_lengths, B, K)
+        s = _pick_mode(_shape(B, nq, nk, dq, dk, d, num_heads, q_shared, k_lengths=kl))
+        ctx.kl = kl                       # keeps the device array alive for the backward
         L = lib()
         with torch.cuda.device(K.device):
             Y = torch.empty((B, nq, d), dtype=torch.float32, device=K.device)
@@ -130,14 +143,17 @@ class _MabFn(torch.autograd.Function):
                                 _ptr(dY), _ptr(dQ), _ptr(dK), 0, C.byref(gg), _ptr(ws),
                                 _stream(K)), "pca_mab_bwd")
         grads = [g.view_as(p) for g, p in zip(gviews, params)]
-        return (dQ, dK, *grads, None, None)
+        return (dQ, dK, *grads, None, None, None)
 
 
-def mab(Q, K, wq, bq, wk, bk, wv, bv, wo, bo, num_heads: int, q_shared: bool = False):
-    return _MabFn.apply(Q, K, wq, bq, wk, bk, wv, bv, wo, bo, num_heads, q_shared)
+def mab(Q, K, wq, bq, wk, bk, wv, bv, wo, bo, num_heads: int, q_shared: bool = False,
+        key_lengths=None):
+    """key_lengths (optional, int[B]): valid keys per set of a padded batch."""
+    return _MabFn.apply(Q, K, wq, bq, wk, bk, wv, bv, wo, bo, num_heads, q_shared, key_lengths)
 
 
-def mab_infer(Q, K, params, num_heads: int, q_shared: bool = False) -> torch.Tensor:
+def mab_infer(Q, K, params, num_heads: int, q_shared: bool = False,
+              key_lengths=None) -> torch.Tensor:
     """Forward only, nothing saved (used under torch.no_grad())."""
     _need_cuda(Q, K)
     Q, K = _f32c(Q), _f32c(K)
@@ -145,7 +161,8 @@ def mab_infer(Q, K, params, num_heads: int, q_shared: bool = False) -> torch.Ten
     B, nk, dk = K.shape
     nq, dq = Q.shape[-2], Q.shape[-1]
     d = params[0].shape[0]
-    s = _pick_mode(_shape(B, nq, nk, dq, dk, d, num_heads, q_shared))
+    kl = _lengths(key_lengths, B, K)
+    s = _pick_mode(_shape(B, nq, nk, dq, dk, d, num_heads, q_shared, k_lengths=kl))
     L = lib()
     with torch.cuda.device(K.device):
         Y = torch.empty((B, nq, d), dtype=torch.float32, device=K.device)
@@ -277,10 +294,13 @@ def pack_points_2d(spec: torch.Tensor, farr: torch.Tensor, idx: torch.Tensor,
 def pack_points_3d(spec: torch.Tensor, farr: torch.Tensor, tarr: torch.Tensor,
                    idx: torch.Tensor, labels: Optional[torch.Tensor] = None,
                    out: Optional[torch.Tensor] = None,
-                   labels_out: Optional[torch.Tensor] = None
-                   ) -> Tuple[torch.Tensor, Optional[torch.Tensor]]:
+                   labels_out: Optional[torch.Tensor] = None,
+                   nt_valid: Optional[torch.Tensor] = None,
+                   lengths_out: Optional[torch.Tensor] = None):
     """Batch of ESC_pc_temp items: spec indexed [f, t, s] through its strides (any
-    layout), idx int64[B] -> ([B, Nt*F, 3] float32, labels[idx])."""
+    layout), idx int64[B] -> ([B, Nt*F, 3] float32, labels[idx]).
+    With ``nt_valid`` (device int32[S], frames held by each chunk) the batch is padded:
+    returns (points, labels[idx], lengths int32[B]) (pca_pack_points_3d_var)."""
     _need_cuda(spec, farr, tarr, idx)
     assert spec.dtype == torch.float32 and idx.dtype == torch.int64
     F, Nt, S = spec.shape
@@ -290,6 +310,16 @@ def pack_points_3d(spec: torch.Tensor, farr: torch.Tensor, tarr: torch.Tensor,
             out = torch.empty((B, F * Nt, 3), dtype=torch.float32, device=spec.device)
         if labels is not None and labels_out is None:
             labels_out = torch.empty(B, dtype=torch.int64, device=spec.device)
+        if nt_valid is not None:
+            _need_cuda(nt_valid)
+            assert nt_valid.dtype == torch.int32 and nt_valid.numel() == S
+            if lengths_out is None:
+                lengths_out = torch.empty(B, dtype=torch.int32, device=spec.device)
+            check(lib().pca_pack_points_3d_var(
+                _ptr(spec), spec.stride(0), spec.stride(1), spec.stride(2), _ptr(farr),
+                _ptr(tarr), _ptr(nt_valid), _ptr(idx), B, F, Nt, _ptr(out), _ptr(lengths_out),
+                _ptr(labels), _ptr(labels_out), _stream(spec)), "pca_pack_points_3d_var")
+            return out, labels_out, lengths_out
         check(lib().pca_pack_points_3d(_ptr(spec), spec.stride(0), spec.stride(1),
                                        spec.stride(2), _ptr(farr), _ptr(tarr), _ptr(idx), B,
                                        F, Nt, _ptr(out), _ptr(labels), _ptr(labels_out),

@@ -142,17 +142,28 @@ class STEngine:
     def _stream(self):
         return C.c_void_p(torch.cuda.current_stream(self.dev).cuda_stream)
 
-    def forward(self, X: torch.Tensor) -> torch.Tensor:
+    @staticmethod
+    def _len_ptr(lengths, B):
+        if lengths is None:
+            return None
+        assert lengths.is_cuda and lengths.dtype == torch.int32 and lengths.is_contiguous()
+        assert tuple(lengths.shape) == (B,), lengths.shape
+        return lengths.data_ptr()
+
+    def forward(self, X: torch.Tensor, lengths: Optional[torch.Tensor] = None) -> torch.Tensor:
+        """lengths (optional, device int32[B]): valid points per set of a padded batch."""
         assert X.is_cuda and X.dtype == torch.float32 and X.is_contiguous()
         assert tuple(X.shape) == (self.cfg.B, self.cfg.N, self.cfg.din), X.shape
         check(lib().pca_st_forward(C.byref(self.cfg), self.flat.data_ptr(), X.data_ptr(),
-                                   self.logits.data_ptr(), self.ws.data_ptr(), self._stream()),
+                                   self._len_ptr(lengths, self.cfg.B), self.logits.data_ptr(),
+                                   self.ws.data_ptr(), self._stream()),
               "pca_st_forward")
         return self.logits
 
     def fwd_bwd(self, X: torch.Tensor, labels: torch.Tensor, phase: int = -1,
-                grad_scale: float = 1.0) -> None:
+                grad_scale: float = 1.0, lengths: Optional[torch.Tensor] = None) -> None:
         check(lib().pca_st_train_fwd_bwd(C.byref(self.cfg), self.flat.data_ptr(), X.data_ptr(),
+                                         self._len_ptr(lengths, self.cfg.B),
                                          labels.data_ptr(), self.grads.data_ptr(),
                                          self.loss.data_ptr(), self.stats.data_ptr(),
                                          self.logits.data_ptr(), grad_scale, phase,
@@ -194,6 +205,9 @@ class Trainer:
             self.X = torch.empty((self.B, self.N, self.eng.cfg.din), dtype=torch.float32,
                                  device=self.dev)
             self.labels = torch.zeros(self.B, dtype=torch.int64, device=self.dev)
+            # padded batches of variable-size sets (dataset.variable_length): point counts
+            self.lengths = (torch.zeros(self.B, dtype=torch.int32, device=self.dev)
+                            if getattr(dataset, "variable_length", False) else None)
             self.comm_stream = torch.cuda.Stream(self.dev) if self.world > 1 else None
         self.g0 = self.g1 = self.g2 = None
         self.indices = ShardedIndexStream(len(dataset), self.B, self.rank, self.world, seed,
@@ -207,13 +221,17 @@ class Trainer:
 
     # ---- the three device segments of a step ---------------------------------------
     def _seg0(self):     # pack + zero grads + forward + loss + backward(dec, enc.1)
-        self.ds.batch(self.idx, out=self.X, labels_out=self.labels)
+        if self.lengths is not None:
+            self.ds.batch(self.idx, out=self.X, labels_out=self.labels,
+                          lengths_out=self.lengths)
+        else:
+            self.ds.batch(self.idx, out=self.X, labels_out=self.labels)
         if self.keep_grads:           # otherwise the Adam pass leaves them cleared
             self.eng.grads.zero_()
-        self.eng.fwd_bwd(self.X, self.labels, phase=0)
+        self.eng.fwd_bwd(self.X, self.labels, phase=0, lengths=self.lengths)
 
     def _seg1(self):     # backward(enc.0)
-        self.eng.fwd_bwd(self.X, self.labels, phase=1)
+        self.eng.fwd_bwd(self.X, self.labels, phase=1, lengths=self.lengths)
 
     def _seg2(self):     # Adam over the flat vector
         e = self.eng
@@ -301,8 +319,9 @@ def evaluate(model, dataset, batch_size: int, mode: int = _lib.MODE_F32
         eng = STEngine(model, b, dataset.num_points, mode, training=False)
         while done + b <= n:
             idx = torch.arange(done, done + b, device=dev)
-            X, lab = dataset.batch(idx)
-            logits = eng.forward(X)
+            res = dataset.batch(idx)
+            X, lab = res[0], res[1]
+            logits = eng.forward(X, res[2] if len(res) > 2 else None)
             correct += (logits.argmax(1) == lab).sum()
             done += b
     return float(correct) / max(n, 1), n
