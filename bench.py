@@ -222,7 +222,12 @@ def main():
         tr.use_graph = tr_use_graph
         if n.value > 0 and ms.value > 0:
             tflops = fl.value / (ms.value * 1e-3) / 1e12
+            gbs = by.value / (ms.value * 1e-3) / 1e9
             peak = FP32_VALU_PEAK_TFLOPS if args.mode == "f32" else MFMA_BF16_PEAK_TFLOPS
+            # roofline model: the kernel is HBM-bound when its algorithmic intensity lies
+            # below the ridge peak_flops / peak_bandwidth
+            intensity = fl.value / max(by.value, 1.0)
+            hbm_bound = intensity < peak * 1e12 / (HBM_PEAK_GBS * 1e9)
             traffic = None
             tpath = os.path.join(ROOT, "profiles", "r01_hbm_traffic.json")
             if args.mode == "bf16" and args.config == "cfg2" and os.path.exists(tpath):
@@ -230,15 +235,24 @@ def main():
             out["roofline"] = {
                 "kernel": "k_gemm_f32" if args.mode == "f32" else "k_mab1_bwd (fused ISAB mab1 "
                           "backward chain, both layers)",
-                "bound": "mfma", "achieved": round(tflops, 3), "peak": peak,
-                "unit": "TFLOP/s", "frac": round(tflops / peak, 5), "traffic": traffic,
+                "bound": "hbm" if hbm_bound else "mfma",
+                "achieved": round(gbs, 1) if hbm_bound else round(tflops, 3),
+                "peak": HBM_PEAK_GBS if hbm_bound else peak,
+                "unit": "GB/s" if hbm_bound else "TFLOP/s",
+                "frac": round(gbs / HBM_PEAK_GBS, 5) if hbm_bound else round(tflops / peak, 5),
+                "traffic": traffic,
+                "alg_intensity_flop_per_byte": round(intensity, 1),
+                "ridge_flop_per_byte": round(peak * 1e12 / (HBM_PEAK_GBS * 1e9), 1),
+                "achieved_tflops": round(tflops, 3), "frac_of_mfma_peak": round(tflops / peak, 5),
+                "achieved_gbs": round(gbs, 1), "frac_of_hbm_peak": round(gbs / HBM_PEAK_GBS, 5),
                 "launches": int(n.value), "avg_us": round(ms.value * 1e3 / n.value, 3),
                 "alg_flops_per_launch": round(fl.value / n.value),
                 "alg_bytes_per_launch": round(by.value / n.value),
                 "note": ("exact-fp32 parity path: strided VALU GEMMs, priced against the fp32 "
                          "vector/matrix peak (157.3 TFLOP/s)" if args.mode == "f32" else
                          "reference-formulation FLOPs 4*M*(dq*d + d^2 + 2*m*d) per launch "
-                         "(SURVEY 8d, backward = 2x forward); traffic = HBM bytes per launch from "
+                         "(SURVEY 8d, backward = 2x forward); algorithmic bytes = dY in + X in + "
+                         "dX out, bf16 activations; traffic = HBM bytes per launch from "
                          "rocprofv3 PMC (profiles/r01_hbm_traffic.json), FETCH_SIZE doubled per "
                          "MI355X_MICROARCH.md"),
             }

@@ -91,7 +91,7 @@ int isab_bf16_bwd(const pca_mab_shape& s0, const pca_mab_shape& s1, const float*
                   const void* dY, float* dI, void* dX, const pca_mab_grads& g0,
                   const pca_mab_grads& g1, void* ws, const IsabImg& im, hipStream_t st,
                   Mab0PostJobs* defer) {
-  const int d = 128, dk = s0.dk, m = 16;
+  const int dk = s0.dk, m = 16;
   Carver c(ws);
   void* ws1 = c.take<char>(mab1_carve_bwd_ws(s1, nullptr, nullptr));
   void* ws0 = c.take<char>(mab0_carve_bwd_ws(s0, nullptr, nullptr));
@@ -103,9 +103,8 @@ int isab_bf16_bwd(const pca_mab_shape& s0, const pca_mab_shape& s1, const float*
   mab0_carve_saved(s0, &v0, const_cast<void*>(saved0));
 
   int nparts = 0;
-  // the chain kernel also clears dQs, which k_mid_bwd accumulates into
   PCA_TRY(mab1_bf16_bwd_ex(s1, X, H, p1, saved1, dY, dX, nullptr, 0, g1, ws1,
-                           PCA_F_SKIP_KV_TAIL, st, &im, w0.dQs, m * d, &nparts));
+                           PCA_F_SKIP_KV_TAIL, st, &im, nullptr, 0, &nparts));
   const int64_t Bm = (int64_t)s0.B * m;
   const int Rp = 64;
   MidBwdLaunch L{};

@@ -570,7 +570,6 @@ int mab0_bf16_fwd_ex(const pca_mab_shape& s, const float* I, const void* X,
   const int d = s.d, m = s.nq, h = s.h, dk = s.dk, R = h * m;
   const int Rpad = (int)cdiv(R, 16) * 16;
   const int Rpad32 = (int)cdiv(R, 32) * 32;
-  const float sl2e = 1.4426950408889634f / sqrtf((float)d);
   const bool small = dk <= 4;
 
   if (!(flags & PCA_F_PREP_DONE)) {

@@ -464,7 +464,23 @@ __global__ __launch_bounds__(256) void k_mab0_post1(const Mab0PostJobs jobs) {
   } else if (o < d * dk + m * d) {
     const int oo = o - d * dk;
     const int q = oo / d, f = oo - q * d, j = f / dh;
-    a.dQp[oo] = a.dQs[oo] + a.sl2e * dot_strided(a.DG + (int64_t)(j * m + q) * dk, 1,
+    float qs;
+    if (a.dQs != nullptr) {
+      qs = a.dQs[oo];
+    } else {                                  // sum over the sets, 16 loads in flight
+      qs = 0.f;
+      const int64_t sb = (int64_t)m * d;
+      int bb = 0;
+      for (; bb + 16 <= a.B; bb += 16) {
+        float v[16];
+#pragma unroll
+        for (int u = 0; u < 16; ++u) v[u] = a.dO[(bb + u) * sb + oo];
+#pragma unroll
+        for (int u = 0; u < 16; ++u) qs += v[u];
+      }
+      for (; bb < a.B; ++bb) qs += a.dO[bb * sb + oo];
+    }
+    a.dQp[oo] = qs + a.sl2e * dot_strided(a.DG + (int64_t)(j * m + q) * dk, 1,
                                                  a.Wk + (int64_t)f * dk, 1, dk);
   }
 }
@@ -624,8 +640,9 @@ int mab0_bf16_bwd_ex(const pca_mab_shape& s, const float* I, const void* X,
       PCA_TRY(wgrad_small_f32_launch(w.dO, w.Th, Bm, dk, (int64_t)Bm * dk, gr.wv, gr.bv, ts));
   }
   if (!head_done) PCA_TRY(colsum(w.dO, s.B, m * d, w.dQs, 0, st));   // sum over sets
-  Mab0PostJob pj{w.dQs, w.DG, v.Qp, p.wk, I, p.wq, gr.wk, w.dQp, gr.wq, gr.bq, dI,
-                 m, d, dk, s.dq, h, sl2e};
+  // fused ISAB: k_mid_bwd left dO per set, the post kernel sums it
+  Mab0PostJob pj{head_done ? nullptr : w.dQs, w.DG, v.Qp, p.wk, I, p.wq, gr.wk, w.dQp, gr.wq,
+                 gr.bq, dI, m, d, dk, s.dq, h, sl2e, w.dO, s.B};
   if (defer != nullptr) {
     PCA_REQUIRE(defer->n < 3, "mab0_bf16_bwd: post-job table full");
     defer->j[defer->n++] = pj;

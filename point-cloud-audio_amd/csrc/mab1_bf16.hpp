@@ -244,6 +244,10 @@ struct Mab0PostJob {
   float *dWk, *dQp, *dWq, *dbq, *dI;
   int m, d, dk, dq, h;
   float sl2e;
+  // dQs == null: the sum over sets of dO [B][m][d] is taken inside the post kernel (cheaper
+  // than B workgroups adding atomically into the same m*d addresses)
+  const float* dO;
+  int B;
 };
 struct Mab0PostJobs {
   Mab0PostJob j[3];

@@ -862,7 +862,10 @@ int mab1_bf16_bwd_ex(const pca_mab_shape& s, const void* X, const float* H,
   a.scale_log2e = 1.4426950408889634f * a.scale;
   // reference-formulation backward FLOPs of the block: 2x forward
   const double flops = 4.0 * M * ((double)s.dq * d + (double)d * d + 2.0 * MI * d);
-  const double bytes = (double)M * (4.0 * d + (want_dx ? 4.0 * d : 0.0));
+  // algorithmic HBM bytes (each operand once): dY in, X in, dX out
+  const double eb = abf ? 2.0 : 4.0;
+  const double bytes = (double)M * (eb * d + (small ? 4.0 * s.dq : eb * s.dq) +
+                                    (want_dx ? eb * d : 0.0));
   int rc;
   const bool fuse = MI == 16;
   if (fuse) {

@@ -57,6 +57,29 @@ __global__ __launch_bounds__(256) void k_mid_fwd(const MidFwdArgs a) {
   const int r = lane & 15, g = lane >> 4;
   const int dk = a.dk;
 
+  // every weight fragment / bias of phases A-C is fetched now (latency-bound kernel: one
+  // workgroup per set; the round trips overlap the partial merge instead of following it)
+  bf16x8 wv0_pre[2][SMALL ? 1 : 4], wo0_pre[2][4], wk1_pre[2][4], wv1_pre[2][4];
+  float4 q_pre[2], bv0_pre[2], bo0_pre[2], bk1_pre[2], bv1_pre[2];
+  float bk1c_pre[2], bv1c_pre[2];
+#pragma unroll
+  for (int tt = 0; tt < 2; ++tt) {
+    const int t = 2 * w + tt;
+    q_pre[tt] = *reinterpret_cast<const float4*>(a.Qp + r * D + 16 * t + 4 * g);
+    bv0_pre[tt] = *reinterpret_cast<const float4*>(a.bv0 + 16 * t + 4 * g);
+    bo0_pre[tt] = *reinterpret_cast<const float4*>(a.bo0 + 16 * t + 4 * g);
+    bk1_pre[tt] = *reinterpret_cast<const float4*>(a.bk1 + 16 * t + 4 * g);
+    bv1_pre[tt] = *reinterpret_cast<const float4*>(a.bv1 + 16 * t + 4 * g);
+    bk1c_pre[tt] = a.bk1[16 * t + r];
+    bv1c_pre[tt] = a.bv1[16 * t + r];
+#pragma unroll
+    for (int ks = 0; ks < 4; ++ks) {
+      if (!SMALL) wv0_pre[tt][ks] = gload8(a.Wv0 + (int64_t)(16 * t + r) * D + 32 * ks + 8 * g);
+      wo0_pre[tt][ks] = gload8(a.Wo0 + (int64_t)(16 * t + r) * D + 32 * ks + 8 * g);
+      wk1_pre[tt][ks] = gload8(a.Wk1 + (int64_t)(16 * t + r) * D + 32 * ks + 8 * g);
+      wv1_pre[tt][ks] = gload8(a.Wv1 + (int64_t)(16 * t + r) * D + 32 * ks + 8 * g);
+    }
+  }
   // ---- merge partials -> T (global fp32, saved) and its bf16 image ----
   if (SMALL) {
     for (int i = tid; i < 64 * dk; i += 256) sTf[(i / dk) * 4 + (i % dk)] = a.T[(int64_t)b * 64 * dk + i];
@@ -97,8 +120,8 @@ __global__ __launch_bounds__(256) void k_mid_fwd(const MidFwdArgs a) {
 #pragma unroll
   for (int tt = 0; tt < 2; ++tt) {
     const int t = 2 * w + tt;
-    const float4 q4 = *reinterpret_cast<const float4*>(a.Qp + r * D + 16 * t + 4 * g);
-    const float4 b4 = *reinterpret_cast<const float4*>(a.bv0 + 16 * t + 4 * g);
+    const float4 q4 = q_pre[tt];
+    const float4 b4 = bv0_pre[tt];
     o[tt] = f32x4{q4.x + b4.x, q4.y + b4.y, q4.z + b4.z, q4.w + b4.w};
     if (SMALL) {
 #pragma unroll
@@ -109,7 +132,7 @@ __global__ __launch_bounds__(256) void k_mid_fwd(const MidFwdArgs a) {
     } else {
 #pragma unroll
       for (int ks = 0; ks < 4; ++ks)
-        o[tt] = mfma32(gload8(a.Wv0 + (int64_t)(16 * t + r) * D + 32 * ks + 8 * g),
+        o[tt] = mfma32(wv0_pre[tt][ks],
                        *reinterpret_cast<const bf16x8*>(sT + swz(16 * w + r, 4 * ks + g, ROWB)),
                        o[tt]);
     }
@@ -124,11 +147,11 @@ __global__ __launch_bounds__(256) void k_mid_fwd(const MidFwdArgs a) {
 #pragma unroll
   for (int tt = 0; tt < 2; ++tt) {
     const int t = 2 * w + tt;
-    const float4 b4 = *reinterpret_cast<const float4*>(a.bo0 + 16 * t + 4 * g);
+    const float4 b4 = bo0_pre[tt];
     f32x4 z = f32x4{b4.x, b4.y, b4.z, b4.w};
 #pragma unroll
     for (int ks = 0; ks < 4; ++ks)
-      z = mfma32(gload8(a.Wo0 + (int64_t)(16 * t + r) * D + 32 * ks + 8 * g),
+      z = mfma32(wo0_pre[tt][ks],
                  *reinterpret_cast<const bf16x8*>(sA + swz(r, 4 * ks + g, ROWB)), z);
 #pragma unroll
     for (int e = 0; e < 4; ++e) hq[tt][e] = o[tt][e] + fmaxf(z[e], 0.f);
@@ -144,21 +167,19 @@ __global__ __launch_bounds__(256) void k_mid_fwd(const MidFwdArgs a) {
   // ---- phase C: Kp, Vp of mab1 in both orientations ----
 #pragma unroll
   for (int which = 0; which < 2; ++which) {
-    const __bf16* W = which ? a.Wv1 : a.Wk1;
-    const float* bias = which ? a.bv1 : a.bk1;
     __bf16* PP = which ? a.VpP : a.KpP;
     __bf16* TT = which ? a.Vt : a.Kt;
     f32x4 fr[2], kr[2];
 #pragma unroll
     for (int tt = 0; tt < 2; ++tt) {
       const int t = 2 * w + tt;
-      const float4 b4 = *reinterpret_cast<const float4*>(bias + 16 * t + 4 * g);
-      const float bc = bias[16 * t + r];
+      const float4 b4 = which ? bv1_pre[tt] : bk1_pre[tt];
+      const float bc = which ? bv1c_pre[tt] : bk1c_pre[tt];
       fr[tt] = f32x4{b4.x, b4.y, b4.z, b4.w};      // rows = features, col = key
       kr[tt] = f32x4{bc, bc, bc, bc};              // rows = keys,     col = feature
 #pragma unroll
       for (int ks = 0; ks < 4; ++ks) {
-        const bf16x8 wf = gload8(W + (int64_t)(16 * t + r) * D + 32 * ks + 8 * g);
+        const bf16x8 wf = which ? wv1_pre[tt][ks] : wk1_pre[tt][ks];
         const bf16x8 hf = *reinterpret_cast<const bf16x8*>(sA + swz(r, 4 * ks + g, ROWB));
         fr[tt] = mfma32(wf, hf, fr[tt]);
         kr[tt] = mfma32(hf, wf, kr[tt]);
@@ -215,6 +236,43 @@ __global__ __launch_bounds__(256) void k_mid_bwd(const MidBwdArgs a) {
     *reinterpret_cast<uint4*>(sWk + swz(row, ch, ROWB)) = kv;
     *reinterpret_cast<uint4*>(sWv + swz(row, ch, ROWB)) = vv;
   }
+  // Every global operand of the chain below is fetched NOW, before the first barrier: the
+  // kernel is one workgroup per set on half the CUs and purely latency-bound, so the round
+  // trips must overlap instead of queueing behind each other.
+  const int64_t trow = (int64_t)b * 64 + 16 * w + r;           // this lane's query row of T
+  float4 zpre[8];
+#pragma unroll
+  for (int t = 0; t < 8; ++t)
+    zpre[t] = *reinterpret_cast<const float4*>(a.Z + ((int64_t)b * MQ + r) * D + 16 * t + 4 * g);
+  bf16x8 wo_pre[2][4];
+#pragma unroll
+  for (int tt = 0; tt < 2; ++tt)
+#pragma unroll
+    for (int s4 = 0; s4 < 4; ++s4)
+      wo_pre[tt][s4] = gload8(a.Wo0TP + (int64_t)(16 * (2 * w + tt) + r) * D + 32 * s4 + 8 * g);
+  bf16x8 wvp_pre[SMALL ? 1 : 8], wvt_pre[SMALL ? 1 : 8];
+  float4 t_pre[SMALL ? 1 : 8];
+  float wvf_pre[SMALL ? 4 : 1][8], ts_pre[SMALL ? 4 : 1];
+  if (SMALL) {
+#pragma unroll
+    for (int c = 0; c < 4; ++c) {
+      ts_pre[c] = c < dk ? a.T[trow * dk + c] : 0.f;
+#pragma unroll
+      for (int tt = 0; tt < 2; ++tt)
+#pragma unroll
+        for (int e = 0; e < 4; ++e)
+          wvf_pre[c][4 * tt + e] =
+              c < dk ? a.Wv0f[(32 * w + 16 * tt + 4 * g + e) * dk + c] : 0.f;
+    }
+  } else {
+#pragma unroll
+    for (int ct = 0; ct < 8; ++ct) {
+      wvp_pre[ct] = gload8(a.Wv0TP + (int64_t)(16 * ct + r) * D + 32 * w + 8 * g);
+      wvt_pre[ct] = gload8(a.Wv0T + (int64_t)(16 * ct + r) * D + 32 * w + 8 * g);
+      t_pre[ct] = *reinterpret_cast<const float4*>(a.T + trow * D + 16 * ct + 4 * g);
+    }
+  }
+  const float lse_pre = a.LSE[(int64_t)b * 64 + 16 * w + r];
   if (a.zero_ptr != nullptr)
     for (int i = blockIdx.x * 256 + tid; i < a.zero_n; i += gridDim.x * 256) a.zero_ptr[i] = 0.f;
   for (int i = tid; i < 16 * 16; i += 256) {
@@ -262,7 +320,7 @@ __global__ __launch_bounds__(256) void k_mid_bwd(const MidBwdArgs a) {
                      vb[ks], dh[t]);
     }
     const int64_t off = ((int64_t)b * MQ + r) * D + 16 * t + 4 * g;
-    const float4 z4 = *reinterpret_cast<const float4*>(a.Z + off);
+    const float4 z4 = zpre[t];
     dz[t][0] = z4.x > 0.f ? dh[t][0] : 0.f;
     dz[t][1] = z4.y > 0.f ? dh[t][1] : 0.f;
     dz[t][2] = z4.z > 0.f ? dh[t][2] : 0.f;
@@ -284,30 +342,29 @@ __global__ __launch_bounds__(256) void k_mid_bwd(const MidBwdArgs a) {
     const int t = 2 * w + tt;
 #pragma unroll
     for (int s = 0; s < 4; ++s)
-      dO2[tt] = mfma32(gload8(a.Wo0TP + (int64_t)(16 * t + r) * D + 32 * s + 8 * g),
-                       pack8(dz[2 * s], dz[2 * s + 1]), dO2[tt]);
+      dO2[tt] = mfma32(wo_pre[tt][s], pack8(dz[2 * s], dz[2 * s + 1]), dO2[tt]);
     const int64_t off = ((int64_t)b * MQ + r) * D + 16 * t + 4 * g;
     *reinterpret_cast<float4*>(a.dO + off) =
         float4{dO2[tt][0], dO2[tt][1], dO2[tt][2], dO2[tt][3]};
-#pragma unroll
-    for (int e = 0; e < 4; ++e) atomicAdd(&a.dQs[r * D + 16 * t + 4 * g + e], dO2[tt][e]);
+    // (the sum of dO over the sets is taken by k_mab0_post1: B workgroups adding atomically
+    //  into the same 2048 addresses serialised for microseconds)
     // wave-private [q][32] image of dO_w (64-byte rows): feature 16tt+4g.. of query r
     *reinterpret_cast<bf16x4*>(sO[w] + r * 64 + (16 * tt + 4 * g) * 2) = pack4(dO2[tt]);
   }
 
   // ---- dT of head w (rows 16w .. 16w+15 of the [64][dk] tensor) and Delta ----
-  const int64_t trow = (int64_t)b * 64 + 16 * w + r;           // this lane's query row of T
   float dl = 0.f;
   if (SMALL) {
-    for (int c = 0; c < dk; ++c) {
+#pragma unroll
+    for (int c = 0; c < 4; ++c) {
+      if (c >= dk) break;
       float part = 0.f;
 #pragma unroll
       for (int tt = 0; tt < 2; ++tt)
 #pragma unroll
-        for (int e = 0; e < 4; ++e)
-          part += dO2[tt][e] * a.Wv0f[(32 * w + 16 * tt + 4 * g + e) * dk + c];
+        for (int e = 0; e < 4; ++e) part += dO2[tt][e] * wvf_pre[c][4 * tt + e];
       part = wave16_sum(part);
-      const float tv = a.T[trow * dk + c];
+      const float tv = ts_pre[c];
       if (g == 0) {
         a.dTf[trow * dk + c] = part;
         a.Th[((int64_t)w * a.B * MQ + (int64_t)b * MQ + r) * dk + c] = tv;
@@ -322,16 +379,16 @@ __global__ __launch_bounds__(256) void k_mid_bwd(const MidBwdArgs a) {
     for (int ct = 0; ct < 8; ++ct) {
       // (1) rows = columns c of dT, col = query: natural-row image + Delta
       f32x4 t1 = {0.f, 0.f, 0.f, 0.f};
-      t1 = mfma32(gload8(a.Wv0TP + (int64_t)(16 * ct + r) * D + 32 * w + 8 * g), dob, t1);
+      t1 = mfma32(wvp_pre[ct], dob, t1);
       const int64_t toff = trow * D + 16 * ct + 4 * g;
       *reinterpret_cast<bf16x4*>(a.dTb + toff) = pack4(t1);
-      const float4 tv = *reinterpret_cast<const float4*>(a.T + toff);
+      const float4 tv = t_pre[ct];
       dl += t1[0] * tv.x + t1[1] * tv.y + t1[2] * tv.z + t1[3] * tv.w;
       *reinterpret_cast<float4*>(a.Th + ((int64_t)w * a.B * MQ + (int64_t)b * MQ + r) * D +
                                  16 * ct + 4 * g) = tv;
       // (2) rows = queries 4g+e, col = column c = 16ct + r: the r-permuted transposed image
       f32x4 t2 = {0.f, 0.f, 0.f, 0.f};
-      t2 = mfma32(doa, gload8(a.Wv0T + (int64_t)(16 * ct + r) * D + 32 * w + 8 * g), t2);
+      t2 = mfma32(doa, wvt_pre[ct], t2);
       *reinterpret_cast<bf16x4*>(a.dTt + ((int64_t)b * D + 16 * ct + r) * 64 + 32 * (w >> 1) +
                                  8 * g + 4 * (w & 1)) = pack4(t2);
     }
@@ -342,7 +399,7 @@ __global__ __launch_bounds__(256) void k_mid_bwd(const MidBwdArgs a) {
   }
   if (g == 0) {
     a.Delta[(int64_t)b * 64 + 16 * w + r] = dl;
-    a.LSEp[(int64_t)b * 64 + 16 * w + r] = a.LSE[(int64_t)b * 64 + 16 * w + r];
+    a.LSEp[(int64_t)b * 64 + 16 * w + r] = lse_pre;
   }
 }
 

@@ -1,0 +1,55 @@
+#!/usr/bin/env python3
+"""Per-kernel HBM traffic from the two rocprofv3 PMC passes of scripts/pmc_traffic.sh.
+
+usage: python scripts/pmc_summary.py [out.json]
+FETCH_SIZE / WRITE_SIZE are in KiB; per MI355X_MICROARCH.md (HBM / rocprofv3 section) gfx950
+under-reports wide coalesced reads by 2x, so FETCH_SIZE is doubled; WRITE_SIZE is taken as
+is.  Values are averages PER LAUNCH of each kernel (template variants kept apart)."""
+import csv
+import glob
+import json
+import re
+import sys
+from collections import defaultdict
+
+ROOT = "/root/repo/gpurun_out"
+
+
+def short(name: str) -> str:
+    m = re.search(r"(k_[a-z0-9_]+)(<[^(]*>)?", name)
+    if m:
+        return m.group(1) + (m.group(2) or "")
+    return name[:40]
+
+
+def collect(counter: str):
+    f = sorted(glob.glob(f"{ROOT}/pmc_{counter}/*/*counter_collection.csv"))[-1]
+    tot, cnt = defaultdict(float), defaultdict(int)
+    for r in csv.DictReader(open(f)):
+        if r["Counter_Name"] != counter:
+            continue
+        k = short(r["Kernel_Name"])
+        tot[k] += float(r["Counter_Value"]) * 1024.0
+        cnt[k] += 1
+    return {k: tot[k] / cnt[k] for k in tot}, cnt
+
+
+fetch, nf = collect("FETCH_SIZE")
+write, _ = collect("WRITE_SIZE")
+per = {k: {"fetch_MB": round(2 * fetch[k] / 1e6, 2), "write_MB": round(write.get(k, 0) / 1e6, 2),
+           "launches_sampled": nf[k]} for k in fetch}
+per = dict(sorted(per.items(), key=lambda kv: -(kv[1]["fetch_MB"] + kv[1]["write_MB"])))
+bwd = [k for k in per if k.startswith("k_mab1_bwd")]
+agg = sum((per[k]["fetch_MB"] + per[k]["write_MB"]) * per[k]["launches_sampled"] for k in bwd) / \
+    max(1, sum(per[k]["launches_sampled"] for k in bwd))
+out = {
+    "source": "rocprofv3 --kernel-trace --pmc FETCH_SIZE / --pmc WRITE_SIZE (separate passes), "
+              "bench.py --mode bf16 --no-graph, cfg2 (scripts/pmc_traffic.sh)",
+    "correction": "FETCH_SIZE (KiB) doubled per MI355X_MICROARCH.md (gfx950 reports 1/2 of wide "
+                  "coalesced reads); WRITE_SIZE (KiB) as is",
+    "k_mab1_bwd_bytes_per_launch": round(agg * 1e6),
+    "per_kernel_per_launch": per,
+}
+dst = sys.argv[1] if len(sys.argv) > 1 else "/root/repo/profiles/r01_hbm_traffic.json"
+json.dump(out, open(dst, "w"), indent=1)
+print(json.dumps({k: per[k] for k in list(per)[:12]}, indent=1))
