@@ -317,6 +317,144 @@ __global__ __launch_bounds__(256, 1) void k_mab0_attn(const Mab0AttnArgs a) {
 }
 
 // ---------------------------------------------------------------------------------
+// ISAB mab0 (R = 4 heads x 16 queries = 64 score rows): WAVE = HEAD.  The four waves of a
+// workgroup share every X tile (staged once in LDS, double-buffered, the next tile's global
+// loads in flight during the MFMAs) and each owns the 16 query rows of one head, so there is
+// no cross-wave merge at all: 32 accumulator registers per lane instead of 128, 48 KiB of LDS
+// instead of 150 KiB (three workgroups per CU instead of one), and the partial (T, M, L) of a
+// point range leaves straight from registers.  (The one-wave-per-32-points variant above spent
+// most of its 29 us on the LDS slab merge and on a single exposed load per iteration:
+// 0.55 TB/s on a kernel whose only traffic is reading X once.)
+// ---------------------------------------------------------------------------------
+template <bool ABF>
+__global__ __launch_bounds__(256) void k_mab0_attn_h4(const Mab0AttnArgs a) {
+  constexpr int DK = 128, FT = DK / 16, KS = DK / 32, TILE = 64;
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  char* sG = smem;                                    // [64][256 B] tr_off image rows
+  char* sX = sG + 64 * 256;                           // [2 buffers][2 halves][32 rows][256 B]
+  float* sAl = reinterpret_cast<float*>(sX + 2 * 2 * 32 * 256);   // 4 waves x 16 alphas
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int r = lane & 15, g = lane >> 4;
+  const int b = blockIdx.x, sp = blockIdx.y;
+  const int per = (int)(((int64_t)(a.N + 127) / 128 + a.S - 1) / a.S) * 128;
+  int len = a.N;
+  if (a.lengths != nullptr) len = a.lengths[b] < a.N ? a.lengths[b] : a.N;
+  const int n_lo = sp * per, n_hi = (n_lo + per < len) ? n_lo + per : len;
+
+  for (int c = tid; c < 64 * 16; c += 256) {
+    const int row = c >> 4, ch = c & 15;
+    *reinterpret_cast<uint4*>(sG + tr_off(row, ch)) =
+        *reinterpret_cast<const uint4*>(a.Gb + (int64_t)row * DK + ch * 8);
+  }
+  bf16x8 v[4];
+  auto fetch = [&](int n0) {
+#pragma unroll
+    for (int e = 0; e < 4; ++e) {
+      const int c = tid + 256 * e;
+      const int row = c >> 4, ch = c & 15;
+      const int n = n0 + row;
+      if (n < n_hi && ABF) {
+        v[e] = *reinterpret_cast<const bf16x8*>(reinterpret_cast<const __bf16*>(a.X) +
+                                                ((int64_t)b * a.N + n) * DK + ch * 8);
+      } else if (n < n_hi) {
+        const float4* src = reinterpret_cast<const float4*>(
+            reinterpret_cast<const float*>(a.X) + ((int64_t)b * a.N + n) * DK + ch * 8);
+        const float4 lo = src[0], hi = src[1];
+        v[e][0] = (__bf16)lo.x; v[e][1] = (__bf16)lo.y; v[e][2] = (__bf16)lo.z; v[e][3] = (__bf16)lo.w;
+        v[e][4] = (__bf16)hi.x; v[e][5] = (__bf16)hi.y; v[e][6] = (__bf16)hi.z; v[e][7] = (__bf16)hi.w;
+      } else {
+#pragma unroll
+        for (int k = 0; k < 8; ++k) v[e][k] = (__bf16)0.f;
+      }
+    }
+  };
+  auto stash = [&](int buf) {
+#pragma unroll
+    for (int e = 0; e < 4; ++e) {
+      const int c = tid + 256 * e;
+      const int row = c >> 4, ch = c & 15;
+      *reinterpret_cast<bf16x8*>(sX + ((buf * 2 + (row >> 5)) * 32) * 256 + tr_off(row & 31, ch)) =
+          v[e];
+    }
+  };
+  fetch(n_lo);
+  stash(0);
+  __syncthreads();
+  bf16x8 gf[KS];                    // this head's G rows: B operand of the score MFMAs
+#pragma unroll
+  for (int ks = 0; ks < KS; ++ks)
+    gf[ks] = *reinterpret_cast<const bf16x8*>(sG + tr_off(16 * wave + r, 4 * ks + g));
+  float* myAl = sAl + wave * 16;
+  float mrow = -INFINITY, lrow = 0.f;
+  f32x4 T[FT];
+#pragma unroll
+  for (int ft = 0; ft < FT; ++ft) T[ft] = f32x4{0.f, 0.f, 0.f, 0.f};
+
+  int buf = 0;
+  for (int n0 = n_lo; n0 < n_hi; n0 += TILE, buf ^= 1) {
+    const bool more = n0 + TILE < n_hi;
+    if (more) fetch(n0 + TILE);
+#pragma unroll
+    for (int half = 0; half < 2; ++half) {
+      const int base = n0 + 32 * half;
+      if (base >= n_hi) break;                        // uniform over the workgroup
+      const char* img = sX + ((buf * 2 + half) * 32) * 256;
+      f32x4 s[2];
+#pragma unroll
+      for (int pb = 0; pb < 2; ++pb) {
+        s[pb] = f32x4{0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+        for (int ks = 0; ks < KS; ++ks)
+          s[pb] = mfma32(*reinterpret_cast<const bf16x8*>(img + tr_off(16 * pb + r, 4 * ks + g)),
+                         gf[ks], s[pb]);
+      }
+      // rows of s = points 16 pb + 4 g + e ; column = query row r of this head
+      float mt = -INFINITY;
+#pragma unroll
+      for (int pb = 0; pb < 2; ++pb)
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+          if (base + 16 * pb + 4 * g + e >= n_hi) s[pb][e] = -INFINITY;
+          mt = fmaxf(mt, s[pb][e]);
+        }
+      mt = wave16_max(mt);
+      const float mnew = fmaxf(mrow, mt);             // finite: the half has >= 1 live point
+      const float alpha = exp2f(mrow - mnew);
+      float ls = 0.f;
+#pragma unroll
+      for (int pb = 0; pb < 2; ++pb)
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+          s[pb][e] = exp2f(s[pb][e] - mnew);
+          ls += s[pb][e];
+        }
+      ls = wave16_sum(ls);
+      lrow = lrow * alpha + ls;
+      mrow = mnew;
+      if (g == 0) myAl[r] = alpha;                    // T rows are query rows 4g+e
+      const float4 a4 = *reinterpret_cast<const float4*>(&myAl[4 * g]);
+      const bf16x8 pa = pack8(s[0], s[1]);
+#pragma unroll
+      for (int ft = 0; ft < FT; ++ft) {
+        T[ft][0] *= a4.x; T[ft][1] *= a4.y; T[ft][2] *= a4.z; T[ft][3] *= a4.w;
+        T[ft] = mfma32(pa, tr_frag(img, ft, lane), T[ft]);
+      }
+    }
+    if (more) stash(buf ^ 1);
+    __syncthreads();
+  }
+  const int64_t pbase = ((int64_t)b * a.S + sp) * a.R + 16 * wave;
+#pragma unroll
+  for (int ft = 0; ft < FT; ++ft)
+#pragma unroll
+    for (int e = 0; e < 4; ++e) a.Tp[(pbase + 4 * g + e) * DK + 16 * ft + r] = T[ft][e];
+  if (g == 0) {
+    a.Mp[pbase + r] = mrow;
+    a.Lp[pbase + r] = lrow;
+  }
+}
+
+// ---------------------------------------------------------------------------------
 // layer 1: dk = din <= 4, exact fp32.  One workgroup per set; thread = (query row r,
 // point partition); R <= 256.
 // ---------------------------------------------------------------------------------
@@ -605,10 +743,11 @@ int mab0_bf16_fwd_ex(const pca_mab_shape& s, const float* I, const void* X,
     const dim3 grid(s.B, S);
     const bool abf = s.k_dtype == PCA_BF16;
     PCA_REQUIRE(RB == 1 || RB == 4, "mab0_bf16_fwd: %d score rows not built", Rpad);
+    const size_t lds_h4 = 64 * 256 + 2 * 2 * 32 * 256 + 4 * 16 * sizeof(float);
     if (RB == 1 && abf) hipLaunchKernelGGL((k_mab0_attn<1, true>), grid, dim3(256), lds, st, a);
     else if (RB == 1) hipLaunchKernelGGL((k_mab0_attn<1, false>), grid, dim3(256), lds, st, a);
-    else if (abf) hipLaunchKernelGGL((k_mab0_attn<4, true>), grid, dim3(256), lds, st, a);
-    else hipLaunchKernelGGL((k_mab0_attn<4, false>), grid, dim3(256), lds, st, a);
+    else if (abf) hipLaunchKernelGGL((k_mab0_attn_h4<true>), grid, dim3(256), lds_h4, st, a);
+    else hipLaunchKernelGGL((k_mab0_attn_h4<false>), grid, dim3(256), lds_h4, st, a);
     ps.end();
     PCA_TRY(check_launch("k_mab0_attn"));
   }
