@@ -490,8 +490,10 @@ __device__ __forceinline__ bf16x8 load8(const float* p) {
 template <typename GT, typename AT>
 __global__ __launch_bounds__(256) void k_wgrad128(const WgradJobs jobs, int rows_per_wg) {
   constexpr int D = 128;
-  __shared__ __attribute__((aligned(16))) char sG[2][32 * 256];
-  __shared__ __attribute__((aligned(16))) char sA[2][32 * 256];
+  // 64 KiB: the four staging tiles during the loop, the fp32 [128][128] result afterwards
+  __shared__ __attribute__((aligned(16))) char lds[4 * 32 * 256 * 2];
+  char (*sG)[32 * 256] = reinterpret_cast<char (*)[32 * 256]>(lds);
+  char (*sA)[32 * 256] = reinterpret_cast<char (*)[32 * 256]>(lds + 2 * 32 * 256);
   const WgradJob job = jobs.j[blockIdx.y];
   const GT* __restrict__ G = reinterpret_cast<const GT*>(job.G);
   const AT* __restrict__ A = reinterpret_cast<const AT*>(job.A);
@@ -552,19 +554,25 @@ __global__ __launch_bounds__(256) void k_wgrad128(const WgradJobs jobs, int rows
       for (int i = 0; i < 4; ++i) acc[i][t] = mfma32(ga[i], ab, acc[i][t]);
     }
   }
+  // The atomics cost per cache-line transaction, not per lane: stage the [128][128] block in
+  // LDS and add it with fully coalesced instructions (64 consecutive floats per wave) instead
+  // of 16-float row fragments straight from the accumulator layout.
+  __syncthreads();
+  float* res = reinterpret_cast<float*>(lds);
 #pragma unroll
   for (int i = 0; i < 4; ++i)
 #pragma unroll
     for (int e = 0; e < 4; ++e) {
       const int grow = 16 * (gt0 + i) + 4 * g + e;
-      if (grow < job.g_lo || grow >= job.g_hi) continue;
 #pragma unroll
-      for (int t = 0; t < 4; ++t) atomicAdd(&job.dW[grow * D + 16 * (at0 + t) + r], acc[i][t][e]);
+      for (int t = 0; t < 4; ++t) res[grow * D + 16 * (at0 + t) + r] = acc[i][t][e];
     }
+  __syncthreads();
+  for (int i = job.g_lo * D + tid; i < job.g_hi * D; i += 256) atomicAdd(&job.dW[i], res[i]);
   if (job.db != nullptr) {
     // threads with equal (tid & 15) hold partial sums of the same 8 columns
     __syncthreads();
-    float* red = reinterpret_cast<float*>(sG[0]);       // [16 groups][128 columns]
+    float* red = reinterpret_cast<float*>(lds);         // [16 groups][128 columns]
 #pragma unroll
     for (int k = 0; k < 8; ++k) red[(tid >> 4) * D + (tid & 15) * 8 + k] = bs[k];
     __syncthreads();
