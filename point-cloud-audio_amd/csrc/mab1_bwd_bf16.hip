@@ -101,10 +101,15 @@ __global__ __launch_bounds__(256, 1) void k_mab1_bwd(const Mab1BwdArgs a) {
   int cur_b = -1;
   if (a.zero_ptr != nullptr)
     for (int i = blockIdx.x * 256 + tid; i < a.zero_n; i += gridDim.x * 256) a.zero_ptr[i] = 0.f;
-  char* myDS = sKV + wave * 6144;
-  char* myP = myDS + 1024;
-  char* myQ = myP + 1024;
-  char* myO = myQ + 2048;
+  // row pitches padded by 8 bytes (40 / 72 instead of 32 / 64): with power-of-two pitches the
+  // 16 point rows of a store or transposed read fall on 2 resp. 4 LDS banks repeatedly
+  // (SQ_LDS_BANK_CONFLICT was 3x the LDS-active cycles of this kernel); 10 / 18 banks per row
+  // spread them over all 64
+  constexpr int PS = 40, PQ = 72, KVB = 2 * 32 * PS + 2 * 32 * PQ;
+  char* myDS = sKV + wave * KVB;
+  char* myP = myDS + 32 * PS;
+  char* myQ = myP + 32 * PS;
+  char* myO = myQ + 32 * PQ;
   f32x4 dkp[FUSE_KV ? KS : 1][2], dvp[FUSE_KV ? KS : 1][2];
   if (FUSE_KV) {
 #pragma unroll
@@ -294,12 +299,12 @@ __global__ __launch_bounds__(256, 1) void k_mab1_bwd(const Mab1BwdArgs a) {
           // padding points contribute zeros
           const int pt = 16 * nb + r;
           f32x4 zero4 = {0.f, 0.f, 0.f, 0.f};
-          *reinterpret_cast<bf16x4*>(myDS + pt * 32 + 8 * g) = pack4(live[nb] ? ds0 : zero4);
-          *reinterpret_cast<bf16x4*>(myP + pt * 32 + 8 * g) = pack4(live[nb] ? p0 : zero4);
-          *reinterpret_cast<bf16x4*>(myQ + pt * 64 + 8 * g) = qlo;
-          *reinterpret_cast<bf16x4*>(myQ + pt * 64 + 32 + 8 * g) = qhi;
-          *reinterpret_cast<bf16x4*>(myO + pt * 64 + 8 * g) = pack4(dO[2 * j][nb]);
-          *reinterpret_cast<bf16x4*>(myO + pt * 64 + 32 + 8 * g) = pack4(dO[2 * j + 1][nb]);
+          *reinterpret_cast<bf16x4*>(myDS + pt * PS + 8 * g) = pack4(live[nb] ? ds0 : zero4);
+          *reinterpret_cast<bf16x4*>(myP + pt * PS + 8 * g) = pack4(live[nb] ? p0 : zero4);
+          *reinterpret_cast<bf16x4*>(myQ + pt * PQ + 8 * g) = qlo;
+          *reinterpret_cast<bf16x4*>(myQ + pt * PQ + 32 + 8 * g) = qhi;
+          *reinterpret_cast<bf16x4*>(myO + pt * PQ + 8 * g) = pack4(dO[2 * j][nb]);
+          *reinterpret_cast<bf16x4*>(myO + pt * PQ + 32 + 8 * g) = pack4(dO[2 * j + 1][nb]);
         } else if (live[nb]) {
           *reinterpret_cast<bf16x4*>(a.P + row[nb] * HM + j * MI + 4 * g) = pack4(p0);
           *reinterpret_cast<bf16x4*>(a.dS + row[nb] * HM + j * MI + 4 * g) = pack4(ds0);
@@ -322,24 +327,24 @@ __global__ __launch_bounds__(256, 1) void k_mab1_bwd(const Mab1BwdArgs a) {
       }
       if (FUSE_KV) {
         // dKp_j[key][f] += sum_pt dS[key][pt] Qp[pt][f] ; dVp_j[key][f] += sum_pt P[key][pt] dO[pt][f]
-        const bf16x8 ads = tr_frag_small(myDS, 32, 0, lane);
-        const bf16x8 ap = tr_frag_small(myP, 32, 0, lane);
+        const bf16x8 ads = tr_frag_small(myDS, PS, 0, lane);
+        const bf16x8 ap = tr_frag_small(myP, PS, 0, lane);
 #pragma unroll
         for (int tt = 0; tt < 2; ++tt) {
-          dkp[j][tt] = mfma32(ads, tr_frag_small(myQ, 64, 16 * tt, lane), dkp[j][tt]);
-          dvp[j][tt] = mfma32(ap, tr_frag_small(myO, 64, 16 * tt, lane), dvp[j][tt]);
+          dkp[j][tt] = mfma32(ads, tr_frag_small(myQ, PQ, 16 * tt, lane), dkp[j][tt]);
+          dvp[j][tt] = mfma32(ap, tr_frag_small(myO, PQ, 16 * tt, lane), dvp[j][tt]);
         }
         if (FUSE_WQ) {
           // the dO_j image is consumed: overwrite it with dQp_j (padding points carry zeros)
 #pragma unroll
           for (int nb = 0; nb < NB; ++nb) {
             const int pt = 16 * nb + r;
-            *reinterpret_cast<bf16x4*>(myO + pt * 64 + 8 * g) = pack4(dO[2 * j][nb]);
-            *reinterpret_cast<bf16x4*>(myO + pt * 64 + 32 + 8 * g) = pack4(dO[2 * j + 1][nb]);
+            *reinterpret_cast<bf16x4*>(myO + pt * PQ + 8 * g) = pack4(dO[2 * j][nb]);
+            *reinterpret_cast<bf16x4*>(myO + pt * PQ + 32 + 8 * g) = pack4(dO[2 * j + 1][nb]);
           }
 #pragma unroll
           for (int tt = 0; tt < 2; ++tt)
-            wqa[j][tt] = mfma32(xaug, tr_frag_small(myO, 64, 16 * tt, lane), wqa[j][tt]);
+            wqa[j][tt] = mfma32(xaug, tr_frag_small(myO, PQ, 16 * tt, lane), wqa[j][tt]);
         }
       }
     }
@@ -752,7 +757,7 @@ long long* debug_clock_buffer(int which) {
 template <int D, int MI, bool DX, bool FUSE, bool FWQ, bool ABF>
 int launch_bwd(const Mab1BwdArgs& a, hipStream_t st, double flops, double bytes) {
   size_t lds = (size_t)D * D * 2 + 2 * (size_t)MI * D * 2 + (size_t)D * MI * 2 +
-               (DX ? (size_t)D * D * 2 : 0) + (FUSE ? 4 * 6144 : 0);
+               (DX ? (size_t)D * D * 2 : 0) + (FUSE ? 4 * (2 * 32 * 40 + 2 * 32 * 72) : 0);
   if (FUSE && lds < (size_t)8 * MI * D * 4) lds = (size_t)8 * MI * D * 4;   // flush buffer
   static std::once_flag once;
   std::call_once(once, [] {
