@@ -154,7 +154,7 @@ struct Mab1FwdArgs {
 
 // ABF: activations (X when dq == D, and Y) are bf16 in memory
 template <int D, int MI, bool DIN_SMALL, bool ABF>
-__global__ __launch_bounds__(256, 1) void k_mab1_fwd(const Mab1FwdArgs a) {
+__global__ __launch_bounds__(256, 2) void k_mab1_fwd(const Mab1FwdArgs a) {
   constexpr int DT = D / 16;          // feature tiles
   constexpr int KS = D / 32;          // 32-wide K steps = heads (dh == 32)
   constexpr int ROWB = D * 2;         // bytes per row of a [.][D] bf16 image
@@ -406,7 +406,9 @@ int launch_fwd(const Mab1FwdArgs& a, hipStream_t st) {
                               hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
   });
   const int total = a.B * a.tiles_per_set;
-  const int grid = total < 256 ? total : 256;
+  // layer 1 (40 KiB of LDS): two workgroups per CU
+  const int cap = DS ? 512 : 256;
+  const int grid = total < cap ? total : cap;
   const double pts = (double)a.B * a.N;
   ProfScope ps(PCA_K_MAB1_FWD, st,
                2.0 * pts * ((double)a.dq * D + (double)D * D + 2.0 * MI * D),
