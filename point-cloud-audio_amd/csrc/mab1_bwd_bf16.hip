@@ -72,7 +72,7 @@ __device__ __forceinline__ bf16x8 tr_frag_small(const char* img, int rb, int col
 #define PCA_STAMP(i) do {} while (0)
 #endif
 template <int D, int MI, bool WANT_DX, bool FUSE_KV, bool FUSE_WQ, bool ABF>
-__global__ __launch_bounds__(256, 1) void k_mab1_bwd(const Mab1BwdArgs a) {
+__global__ __launch_bounds__(256, WANT_DX ? 1 : 2) void k_mab1_bwd(const Mab1BwdArgs a) {
   constexpr int DT = D / 16, KS = D / 32, ROWB = D * 2, HM = KS * MI;
   extern __shared__ __attribute__((aligned(16))) char smem[];
   char* sWoT = smem;
@@ -884,10 +884,8 @@ int mab1_bf16_bwd_ex(const pca_mab_shape& s, const void* X, const float* H,
   if (fuse) {
     // consecutive tiles per workgroup: the largest divisor of tiles_per_set that still
     // leaves >= 256 workgroups
-    static const int min_wg = [] {
-      const char* e = getenv("PCA_BWD_MIN_WG");
-      return e ? atoi(e) : 256;
-    }();
+    // (without the dX stage the kernel needs 72 KiB of LDS: two workgroups per CU)
+    const int min_wg = want_dx ? 256 : 512;
     int tpw = 1;
     for (int c = 1; c <= a.tiles_per_set; ++c)
       if (a.tiles_per_set % c == 0 && (int64_t)a.B * a.tiles_per_set / c >= min_wg) tpw = c;
