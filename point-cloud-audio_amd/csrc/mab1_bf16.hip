@@ -153,8 +153,13 @@ struct Mab1FwdArgs {
 };
 
 // ABF: activations (X when dq == D, and Y) are bf16 in memory
-template <int D, int MI, bool DIN_SMALL, bool ABF>
-__global__ __launch_bounds__(256, 2) void k_mab1_fwd(const Mab1FwdArgs a) {
+// NW waves per workgroup (4 or 8): the d -> d variant keeps 104 KiB of weights and staging in
+// LDS, so only one workgroup fits a CU; eight waves sharing those weights give each SIMD two
+// wavefronts to interleave (the chain is a long dependent sequence: ~0.3 instructions issued
+// per wave-cycle at one wavefront per SIMD).  Waves 4..7 take the next 128-point tile.
+template <int D, int MI, bool DIN_SMALL, bool ABF, int NW>
+__global__ __launch_bounds__(64 * NW, NW == 8 ? 1 : 2) void k_mab1_fwd(const Mab1FwdArgs a) {
+  constexpr int NT = 64 * NW, SUBS = NW / 4;
   constexpr int DT = D / 16;          // feature tiles
   constexpr int KS = D / 32;          // 32-wide K steps = heads (dh == 32)
   constexpr int ROWB = D * 2;         // bytes per row of a [.][D] bf16 image
@@ -165,11 +170,12 @@ __global__ __launch_bounds__(256, 2) void k_mab1_fwd(const Mab1FwdArgs a) {
   char* sWq = sVt + D * MI * 2;                       // D x D (absent when DIN_SMALL)
   char* sX = sWq + (DIN_SMALL ? 0 : D * ROWB);        // TP x D (absent when DIN_SMALL)
 
-  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int tid = threadIdx.x, lane = tid & 63, wave8 = tid >> 6;
+  const int wave = wave8 & 3, sub = wave8 >> 2;
   const int r = lane & 15, g = lane >> 4;
 
   // ---- weights -> LDS once per workgroup (16-byte chunks, swizzled rows) ----
-  for (int c = tid; c < D * (D / 8); c += 256) {
+  for (int c = tid; c < D * (D / 8); c += NT) {
     const int row = c / (D / 8), c16 = c % (D / 8);
     *reinterpret_cast<uint4*>(sWo + swz(row, c16, ROWB)) =
         *reinterpret_cast<const uint4*>(a.WoP + (int64_t)row * D + c16 * 8);
@@ -178,24 +184,26 @@ __global__ __launch_bounds__(256, 2) void k_mab1_fwd(const Mab1FwdArgs a) {
           *reinterpret_cast<const uint4*>(a.WqB + (int64_t)row * D + c16 * 8);
   }
 
-  const int total_tiles = a.B * a.tiles_per_set;
+  const int units_per_set = (a.tiles_per_set + SUBS - 1) / SUBS;   // SUBS tiles per workgroup pass
+  const int total_units = a.B * units_per_set;
   int cur_b = -1;
-  for (int tile_id = blockIdx.x; tile_id < total_tiles; tile_id += gridDim.x) {
-    const int b = tile_id / a.tiles_per_set, tile = tile_id - b * a.tiles_per_set;
+  for (int unit = blockIdx.x; unit < total_units; unit += gridDim.x) {
+    const int b = unit / units_per_set, tile = (unit - b * units_per_set) * SUBS + sub;
     if (b != cur_b) {                       // this set's Kp / Vp images
       __syncthreads();
-      for (int c = tid; c < MI * (D / 8); c += 256) {
+      for (int c = tid; c < MI * (D / 8); c += NT) {
         const int row = c / (D / 8), c16 = c % (D / 8);
         *reinterpret_cast<uint4*>(sKp + swz(row, c16, ROWB)) = *reinterpret_cast<const uint4*>(
             a.KpP + ((int64_t)b * MI + row) * D + c16 * 8);
       }
-      for (int c = tid; c < D * MI / 8; c += 256)
+      for (int c = tid; c < D * MI / 8; c += NT)
         reinterpret_cast<uint4*>(sVt)[c] =
             reinterpret_cast<const uint4*>(a.Vt + (int64_t)b * D * MI)[c];
       cur_b = b;
     }
     __syncthreads();
-
+    if (tile >= a.tiles_per_set) continue;              // odd tile count: waves 4..7 idle
+                                                        // (no barrier below this point)
     const int n_base = tile * TP + wave * 32;           // first point of this wave
     f32x4 acc[DT][NB];
 
@@ -228,7 +236,7 @@ __global__ __launch_bounds__(256, 2) void k_mab1_fwd(const Mab1FwdArgs a) {
       }
     } else {
       // stage this wave's 32 rows of X (fp32 -> bf16) into its private slice of sX
-      char* myX = sX + wave * 32 * ROWB;
+      char* myX = sX + wave8 * 32 * ROWB;
       for (int c = lane; c < 32 * (D / 8); c += 64) {
         const int row = c / (D / 8), c16 = c % (D / 8);
         const int n = n_base + row;
@@ -398,22 +406,23 @@ __global__ __launch_bounds__(256, 2) void k_mab1_fwd(const Mab1FwdArgs a) {
 
 template <int D, int MI, bool DS, bool ABF>
 int launch_fwd(const Mab1FwdArgs& a, hipStream_t st) {
+  // layer 1 (40 KiB of LDS): 4 waves, two workgroups per CU; d -> d (104+ KiB): 8 waves
+  constexpr int NW = (DS || MI != 16) ? 4 : 8;
   const size_t lds = (size_t)D * D * 2 + (size_t)MI * D * 2 + (size_t)D * MI * 2 +
-                     (DS ? 0 : (size_t)D * D * 2 + (size_t)TP * D * 2);
+                     (DS ? 0 : (size_t)D * D * 2 + (size_t)NW * 32 * D * 2);
   static std::once_flag once;
   std::call_once(once, [] {
-    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(k_mab1_fwd<D, MI, DS, ABF>),
+    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(k_mab1_fwd<D, MI, DS, ABF, NW>),
                               hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
   });
-  const int total = a.B * a.tiles_per_set;
-  // layer 1 (40 KiB of LDS): two workgroups per CU
+  const int total = a.B * ((a.tiles_per_set + NW / 4 - 1) / (NW / 4));
   const int cap = DS ? 512 : 256;
   const int grid = total < cap ? total : cap;
   const double pts = (double)a.B * a.N;
   ProfScope ps(PCA_K_MAB1_FWD, st,
                2.0 * pts * ((double)a.dq * D + (double)D * D + 2.0 * MI * D),
                pts * ((ABF && !DS ? 2.0 : 4.0) * a.dq + (ABF ? 2.0 : 4.0) * D));
-  hipLaunchKernelGGL((k_mab1_fwd<D, MI, DS, ABF>), dim3(grid), dim3(256), lds, st, a);
+  hipLaunchKernelGGL((k_mab1_fwd<D, MI, DS, ABF, NW>), dim3(grid), dim3(64 * NW), lds, st, a);
   ps.end();
   return check_launch("k_mab1_fwd");
 }

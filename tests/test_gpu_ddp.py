@@ -55,4 +55,16 @@ def test_two_ranks_equal_one_rank_double_batch(tmp_path, mode, graph):
     for _ in range(4):
         tr.step()
     torch.cuda.synchronize()
-    close(flat2, tr.eng.flat.cpu(), 2e-5 if mode == "f32" else 2e-3, "2 ranks x B vs 1 rank x 2B")
+    # d(loss)/d(fc_k.bias) of a block whose query is shared by all sets is zero in exact
+    # arithmetic (softmax shift invariance); numerically it is +-1e-9 noise whose sign depends on
+    # the summation order, and Adam turns g / (|g| + 1e-8) of such noise into steps of 1e-4.
+    # Those entries are compared loosely, everything else tightly.
+    keep = torch.ones(flat2.numel(), dtype=torch.bool)
+    off = 0
+    for k, prm in net.named_parameters():
+        if k.endswith("fc_k.bias") and (".mab0." in k or k.startswith("dec.0.")):
+            keep[off:off + prm.numel()] = False
+        off += prm.numel()
+    mine = tr.eng.flat.cpu()
+    close(flat2[keep], mine[keep], 2e-5 if mode == "f32" else 2e-3, "2 ranks x B vs 1 rank x 2B")
+    close(flat2[~keep], mine[~keep], 5e-3, "noise-gradient biases")
