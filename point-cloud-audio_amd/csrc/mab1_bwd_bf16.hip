@@ -71,8 +71,20 @@ __device__ __forceinline__ bf16x8 tr_frag_small(const char* img, int rb, int col
 #else
 #define PCA_STAMP(i) do {} while (0)
 #endif
+// Waves per workgroup: 8 for the d -> d variant with dX (its 100+ KiB of LDS images allow one
+// workgroup per CU; eight waves sharing them give every SIMD two wavefronts to interleave, and
+// waves 4..7 take the next 128-point tile), otherwise 4 with two workgroups per CU.
+template <bool WANT_DX, bool FUSE_KV>
+struct BwdWaves {
+  static constexpr int value = (WANT_DX && FUSE_KV) ? 8 : 4;
+  static constexpr int per_cu = WANT_DX ? 1 : 2;        // workgroups per CU
+};
+
 template <int D, int MI, bool WANT_DX, bool FUSE_KV, bool FUSE_WQ, bool ABF>
-__global__ __launch_bounds__(256, WANT_DX ? 1 : 2) void k_mab1_bwd(const Mab1BwdArgs a) {
+__global__ __launch_bounds__((64 * BwdWaves<WANT_DX, FUSE_KV>::value),
+                             (BwdWaves<WANT_DX, FUSE_KV>::per_cu))
+void k_mab1_bwd(const Mab1BwdArgs a) {
+  constexpr int NW = BwdWaves<WANT_DX, FUSE_KV>::value, NT = 64 * NW, SUBS = NW / 4;
   constexpr int DT = D / 16, KS = D / 32, ROWB = D * 2, HM = KS * MI;
   extern __shared__ __attribute__((aligned(16))) char smem[];
   char* sWoT = smem;
@@ -83,12 +95,13 @@ __global__ __launch_bounds__(256, WANT_DX ? 1 : 2) void k_mab1_bwd(const Mab1Bwd
   // fused K/V gradients: per wave [32][16] dS, [32][16] P, [32][32] Qp_j, [32][32] dO_j images
   char* sKV = sWqT + (WANT_DX ? D * ROWB : 0);
 
-  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int tid = threadIdx.x, lane = tid & 63, wave8 = tid >> 6;
+  const int wave = wave8 & 3, sub = wave8 >> 2;
   const int r = lane & 15, g = lane >> 4;
   int dbg_n = 0; (void)dbg_n;
   PCA_STAMP(0);
 
-  for (int c = tid; c < D * (D / 8); c += 256) {
+  for (int c = tid; c < D * (D / 8); c += NT) {
     const int row = c / (D / 8), c16 = c % (D / 8);
     *reinterpret_cast<uint4*>(sWoT + swz(row, c16, ROWB)) =
         *reinterpret_cast<const uint4*>(a.WoTP + (int64_t)row * D + c16 * 8);
@@ -100,13 +113,13 @@ __global__ __launch_bounds__(256, WANT_DX ? 1 : 2) void k_mab1_bwd(const Mab1Bwd
   const int total_tiles = a.B * a.tiles_per_set;
   int cur_b = -1;
   if (a.zero_ptr != nullptr)
-    for (int i = blockIdx.x * 256 + tid; i < a.zero_n; i += gridDim.x * 256) a.zero_ptr[i] = 0.f;
+    for (int i = blockIdx.x * NT + tid; i < a.zero_n; i += gridDim.x * NT) a.zero_ptr[i] = 0.f;
   // row pitches padded by 8 bytes (40 / 72 instead of 32 / 64): with power-of-two pitches the
   // 16 point rows of a store or transposed read fall on 2 resp. 4 LDS banks repeatedly
   // (SQ_LDS_BANK_CONFLICT was 3x the LDS-active cycles of this kernel); 10 / 18 banks per row
   // spread them over all 64
   constexpr int PS = 40, PQ = 72, KVB = 2 * 32 * PS + 2 * 32 * PQ;
-  char* myDS = sKV + wave * KVB;
+  char* myDS = sKV + wave8 * KVB;
   char* myP = myDS + 32 * PS;
   char* myQ = myP + 32 * PS;
   char* myO = myQ + 32 * PQ;
@@ -135,11 +148,13 @@ __global__ __launch_bounds__(256, WANT_DX ? 1 : 2) void k_mab1_bwd(const Mab1Bwd
   const int t_first = FUSE_KV ? blockIdx.x * a.tpw : blockIdx.x;
   const int t_step = FUSE_KV ? 1 : gridDim.x;
   const int t_last = FUSE_KV ? t_first + a.tpw : total_tiles;
-  for (int tile_id = t_first; tile_id < t_last && tile_id < total_tiles; tile_id += t_step) {
-    const int b = tile_id / a.tiles_per_set, tile = tile_id - b * a.tiles_per_set;
+  // (fused mode with 8 waves: two consecutive tiles of the set per pass, one per wave quartet)
+  for (int tile0 = t_first; tile0 < t_last && tile0 < total_tiles; tile0 += t_step * SUBS) {
+    const int tile_id = tile0 + sub;
+    const int b = tile0 / a.tiles_per_set, tile = tile_id - b * a.tiles_per_set;
     if (b != cur_b) {
       __syncthreads();
-      for (int c = tid; c < MI * (D / 8); c += 256) {
+      for (int c = tid; c < MI * (D / 8); c += NT) {
         const int row = c / (D / 8), c16 = c % (D / 8);
         const int64_t src = ((int64_t)b * MI + row) * D + c16 * 8;
         *reinterpret_cast<uint4*>(sKp + swz(row, c16, ROWB)) =
@@ -147,13 +162,15 @@ __global__ __launch_bounds__(256, WANT_DX ? 1 : 2) void k_mab1_bwd(const Mab1Bwd
         *reinterpret_cast<uint4*>(sVp + swz(row, c16, ROWB)) =
             *reinterpret_cast<const uint4*>(a.VpP + src);
       }
-      for (int c = tid; c < D * MI / 8; c += 256)
+      for (int c = tid; c < D * MI / 8; c += NT)
         reinterpret_cast<uint4*>(sKt)[c] =
             reinterpret_cast<const uint4*>(a.Kt + (int64_t)b * D * MI)[c];
       cur_b = b;
     }
     __syncthreads();
     PCA_STAMP(1);
+    if (tile_id >= t_last || tile_id >= total_tiles) continue;   // odd count: waves 4..7 idle
+                                                                 // (no barrier below)
 
     const int n_base = tile * TP + wave * 32;
     int nn[NB];
@@ -412,13 +429,15 @@ __global__ __launch_bounds__(256, WANT_DX ? 1 : 2) void k_mab1_bwd(const Mab1Bwd
           v[e] = wqa[j][tt][e] + (e < 3 ? lo : 0.f);
         }
         if (g == 0) {
-          float* dst = red + ((wave * D) + 32 * j + 16 * tt + r) * 4;
+          float* dst = red + ((wave8 * D) + 32 * j + 16 * tt + r) * 4;
           dst[0] = v[0]; dst[1] = v[1]; dst[2] = v[2]; dst[3] = v[3];
         }
       }
     __syncthreads();
-    for (int i = tid; i < D * 4; i += 256) {
-      const float v = red[i] + red[D * 4 + i] + red[2 * D * 4 + i] + red[3 * D * 4 + i];
+    for (int i = tid; i < D * 4; i += NT) {
+      float v = 0.f;
+#pragma unroll
+      for (int w = 0; w < NW; ++w) v += red[w * D * 4 + i];
       const int f = i >> 2, c = i & 3;
       if (c < a.dq) atomicAdd(&a.dWqS[f * a.dq + c], v);
       else if (c == 3) atomicAdd(&a.dbqS[f], v);
@@ -430,7 +449,7 @@ __global__ __launch_bounds__(256, WANT_DX ? 1 : 2) void k_mab1_bwd(const Mab1Bwd
     // reduce the four waves' [MI][D] partials in LDS (the weight images are dead), then one
     // atomic per element per workgroup
     __syncthreads();
-    float* red = reinterpret_cast<float*>(smem);            // [4][2][MI*D] = 64 KiB
+    float* red = reinterpret_cast<float*>(smem);            // [NW][2][MI*D] = 64 / 128 KiB
 #pragma unroll
     for (int j = 0; j < KS; ++j)
 #pragma unroll
@@ -438,16 +457,17 @@ __global__ __launch_bounds__(256, WANT_DX ? 1 : 2) void k_mab1_bwd(const Mab1Bwd
 #pragma unroll
         for (int e = 0; e < 4; ++e) {
           const int o = (4 * g + e) * D + 32 * j + 16 * tt + r;
-          red[(wave * 2 + 0) * MI * D + o] = dkp[j][tt][e];
-          red[(wave * 2 + 1) * MI * D + o] = dvp[j][tt][e];
+          red[(wave8 * 2 + 0) * MI * D + o] = dkp[j][tt][e];
+          red[(wave8 * 2 + 1) * MI * D + o] = dvp[j][tt][e];
         }
     __syncthreads();
     const int nparts = a.tiles_per_set / a.tpw;
     const int part = (t_first - cur_b * a.tiles_per_set) / a.tpw;
-    for (int i = tid; i < 2 * MI * D; i += 256) {
+    for (int i = tid; i < 2 * MI * D; i += NT) {
       const int which = i / (MI * D), o = i - which * MI * D;
-      const float v = red[(0 * 2 + which) * MI * D + o] + red[(1 * 2 + which) * MI * D + o] +
-                      red[(2 * 2 + which) * MI * D + o] + red[(3 * 2 + which) * MI * D + o];
+      float v = 0.f;
+#pragma unroll
+      for (int w = 0; w < NW; ++w) v += red[(w * 2 + which) * MI * D + o];
       (which ? a.dVpG : a.dKpG)[((int64_t)cur_b * nparts + part) * MI * D + o] = v;
     }
   }
@@ -756,9 +776,10 @@ long long* debug_clock_buffer(int which) {
 #endif
 template <int D, int MI, bool DX, bool FUSE, bool FWQ, bool ABF>
 int launch_bwd(const Mab1BwdArgs& a, hipStream_t st, double flops, double bytes) {
+  constexpr int NW = BwdWaves<DX, FUSE>::value;
   size_t lds = (size_t)D * D * 2 + 2 * (size_t)MI * D * 2 + (size_t)D * MI * 2 +
-               (DX ? (size_t)D * D * 2 : 0) + (FUSE ? 4 * (2 * 32 * 40 + 2 * 32 * 72) : 0);
-  if (FUSE && lds < (size_t)8 * MI * D * 4) lds = (size_t)8 * MI * D * 4;   // flush buffer
+               (DX ? (size_t)D * D * 2 : 0) + (FUSE ? NW * (2 * 32 * 40 + 2 * 32 * 72) : 0);
+  if (FUSE && lds < (size_t)2 * NW * MI * D * 4) lds = (size_t)2 * NW * MI * D * 4;   // flush buffer
   static std::once_flag once;
   std::call_once(once, [] {
     (void)hipFuncSetAttribute(reinterpret_cast<const void*>(k_mab1_bwd<D, MI, DX, FUSE, FWQ, ABF>),
@@ -767,7 +788,7 @@ int launch_bwd(const Mab1BwdArgs& a, hipStream_t st, double flops, double bytes)
   const int total = a.B * a.tiles_per_set;
   const int grid = FUSE ? (int)cdiv(total, a.tpw) : (total < 256 ? total : 256);
   ProfScope ps(PCA_K_MAB1_BWD, st, flops, bytes);
-  hipLaunchKernelGGL((k_mab1_bwd<D, MI, DX, FUSE, FWQ, ABF>), dim3(grid), dim3(256), lds, st, a);
+  hipLaunchKernelGGL((k_mab1_bwd<D, MI, DX, FUSE, FWQ, ABF>), dim3(grid), dim3(64 * NW), lds, st, a);
   ps.end();
   return check_launch("k_mab1_bwd");
 }
