@@ -512,18 +512,22 @@ __device__ __forceinline__ bf16x8 load8(const float* p) {
 
 // Software-pipelined: the next 32-row tile is fetched into registers while the current one is
 // consumed from LDS; two LDS buffers -> one barrier per tile.  blockIdx.y selects the job.
-template <typename GT, typename AT>
-__global__ __launch_bounds__(256) void k_wgrad128(const WgradJobs jobs, int rows_per_wg) {
-  constexpr int D = 128;
-  // 64 KiB: the four staging tiles during the loop, the fp32 [128][128] result afterwards
+// NG row groups of four waves each (NG = 2 for the long B*N-row jobs: twice the loads in flight
+// per CU; the kernel runs on at most half the CUs because every workgroup costs 16384 atomics):
+// group q takes the 32-row tiles q, q + NG, ...; the groups' [128][128] blocks are summed in LDS.
+template <typename GT, typename AT, int NG>
+__global__ __launch_bounds__(256 * NG) void k_wgrad128(const WgradJobs jobs, int rows_per_wg) {
+  constexpr int D = 128, NT = 256 * NG;
+  // 64 KiB: 2 x 2 staging tiles per group during the loop, the fp32 [128][128] result afterwards
   __shared__ __attribute__((aligned(16))) char lds[4 * 32 * 256 * 2];
-  char (*sG)[32 * 256] = reinterpret_cast<char (*)[32 * 256]>(lds);
-  char (*sA)[32 * 256] = reinterpret_cast<char (*)[32 * 256]>(lds + 2 * 32 * 256);
+  const int tid = threadIdx.x, lane = tid & 63, wave = (tid >> 6) & 3, grp = tid >> 8;
+  const int gtid = tid & 255;
+  char (*sG)[32 * 256] = reinterpret_cast<char (*)[32 * 256]>(lds + grp * (4 * 32 * 256));
+  char (*sA)[32 * 256] = reinterpret_cast<char (*)[32 * 256]>(lds + grp * (4 * 32 * 256) + 2 * 32 * 256);
   const WgradJob job = jobs.j[blockIdx.y];
   const GT* __restrict__ G = reinterpret_cast<const GT*>(job.G);
   const AT* __restrict__ A = reinterpret_cast<const AT*>(job.A);
   const int64_t M = job.M;
-  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int r = lane & 15, g = lane >> 4;
   const int64_t r0 = (int64_t)blockIdx.x * rows_per_wg;
   if (r0 >= M) return;
@@ -539,10 +543,10 @@ __global__ __launch_bounds__(256) void k_wgrad128(const WgradJobs jobs, int rows
   float bs[8] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};   // column sums of G, columns 8*(tid&15)..
 
   bf16x8 vg[2], va[2];
-  auto fetch = [&](int64_t base) {
+  auto fetch = [&](int64_t base) {          // rows at and beyond r1 read as zeros
 #pragma unroll
     for (int e = 0; e < 2; ++e) {
-      const int c = tid + e * 256;
+      const int c = gtid + e * 256;
       const int row = c >> 4, ch = c & 15;
       if (base + row < r1) {
         vg[e] = load8(G + (base + row) * D + ch * 8);
@@ -553,12 +557,14 @@ __global__ __launch_bounds__(256) void k_wgrad128(const WgradJobs jobs, int rows
       }
     }
   };
-  fetch(r0);
+  fetch(r0 + 32 * grp);
   int buf = 0;
-  for (int64_t base = r0; base < r1; base += 32, buf ^= 1) {
+  // uniform trip count for all groups (a group whose tile lies beyond r1 multiplies zeros)
+  for (int64_t base0 = r0; base0 < r1; base0 += 32 * NG, buf ^= 1) {
+    const int64_t base = base0 + 32 * grp;
 #pragma unroll
     for (int e = 0; e < 2; ++e) {
-      const int c = tid + e * 256;
+      const int c = gtid + e * 256;
       const int row = c >> 4, ch = c & 15;
       *reinterpret_cast<bf16x8*>(sG[buf] + tr_off(row, ch)) = vg[e];
       *reinterpret_cast<bf16x8*>(sA[buf] + tr_off(row, ch)) = va[e];
@@ -568,7 +574,7 @@ __global__ __launch_bounds__(256) void k_wgrad128(const WgradJobs jobs, int rows
       }
     }
     __syncthreads();
-    if (base + 32 < r1) fetch(base + 32);
+    if (base0 + 32 * NG < r1) fetch(base + 32 * NG);
     bf16x8 ga[4];
 #pragma unroll
     for (int i = 0; i < 4; ++i) ga[i] = tr_frag(sG[buf], gt0 + i, lane);
@@ -585,26 +591,34 @@ __global__ __launch_bounds__(256) void k_wgrad128(const WgradJobs jobs, int rows
   __syncthreads();
   float* res = reinterpret_cast<float*>(lds);
 #pragma unroll
-  for (int i = 0; i < 4; ++i)
+  for (int q = NG - 1; q >= 0; --q) {       // last group stores, the others add on top
+    if (grp == q) {
 #pragma unroll
-    for (int e = 0; e < 4; ++e) {
-      const int grow = 16 * (gt0 + i) + 4 * g + e;
+      for (int i = 0; i < 4; ++i)
 #pragma unroll
-      for (int t = 0; t < 4; ++t) res[grow * D + 16 * (at0 + t) + r] = acc[i][t][e];
+        for (int e = 0; e < 4; ++e) {
+          const int grow = 16 * (gt0 + i) + 4 * g + e;
+#pragma unroll
+          for (int t = 0; t < 4; ++t) {
+            float* dst = &res[grow * D + 16 * (at0 + t) + r];
+            *dst = (q == NG - 1) ? acc[i][t][e] : *dst + acc[i][t][e];
+          }
+        }
     }
-  __syncthreads();
-  for (int i = job.g_lo * D + tid; i < job.g_hi * D; i += 256) atomicAdd(&job.dW[i], res[i]);
+    __syncthreads();
+  }
+  for (int i = job.g_lo * D + tid; i < job.g_hi * D; i += NT) atomicAdd(&job.dW[i], res[i]);
   if (job.db != nullptr) {
     // threads with equal (tid & 15) hold partial sums of the same 8 columns
     __syncthreads();
-    float* red = reinterpret_cast<float*>(lds);         // [16 groups][128 columns]
+    float* red = reinterpret_cast<float*>(lds);         // [16 NG groups][128 columns]
 #pragma unroll
     for (int k = 0; k < 8; ++k) red[(tid >> 4) * D + (tid & 15) * 8 + k] = bs[k];
     __syncthreads();
     if (tid < D) {
       float t = 0.f;
 #pragma unroll
-      for (int q = 0; q < 16; ++q) t += red[q * D + tid];
+      for (int q = 0; q < 16 * NG; ++q) t += red[q * D + tid];
       atomicAdd(&job.db[tid], t);
     }
   }
@@ -824,13 +838,18 @@ int wgrad128_launch(const WgradJobs& jobs, bool g_bf16, bool a_bf16, int rows_pe
   for (int i = 0; i < jobs.n; ++i) maxM = jobs.j[i].M > maxM ? jobs.j[i].M : maxM;
   if (maxM == 0 || jobs.n == 0) return PCA_OK;
   const dim3 grid((unsigned)cdiv(maxM, rows_per_wg), (unsigned)jobs.n);
-  if (g_bf16 && a_bf16)
-    hipLaunchKernelGGL((k_wgrad128<__bf16, __bf16>), grid, dim3(256), 0, st, jobs, rows_per_wg);
-  else if (g_bf16)
-    hipLaunchKernelGGL((k_wgrad128<__bf16, float>), grid, dim3(256), 0, st, jobs, rows_per_wg);
-  else if (!a_bf16)
-    hipLaunchKernelGGL((k_wgrad128<float, float>), grid, dim3(256), 0, st, jobs, rows_per_wg);
-  else {
+  // two row groups per workgroup when every workgroup has at least four tiles to share
+  const bool two = rows_per_wg >= 128;
+  if (g_bf16 && a_bf16) {
+    if (two) hipLaunchKernelGGL((k_wgrad128<__bf16, __bf16, 2>), grid, dim3(512), 0, st, jobs, rows_per_wg);
+    else hipLaunchKernelGGL((k_wgrad128<__bf16, __bf16, 1>), grid, dim3(256), 0, st, jobs, rows_per_wg);
+  } else if (g_bf16) {
+    if (two) hipLaunchKernelGGL((k_wgrad128<__bf16, float, 2>), grid, dim3(512), 0, st, jobs, rows_per_wg);
+    else hipLaunchKernelGGL((k_wgrad128<__bf16, float, 1>), grid, dim3(256), 0, st, jobs, rows_per_wg);
+  } else if (!a_bf16) {
+    if (two) hipLaunchKernelGGL((k_wgrad128<float, float, 2>), grid, dim3(512), 0, st, jobs, rows_per_wg);
+    else hipLaunchKernelGGL((k_wgrad128<float, float, 1>), grid, dim3(256), 0, st, jobs, rows_per_wg);
+  } else {
     set_error("wgrad128: fp32 G with bf16 A is not instantiated");
     return PCA_EUNSUPPORTED;
   }
