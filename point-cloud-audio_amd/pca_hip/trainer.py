@@ -228,10 +228,14 @@ class Trainer:
             self.ds.batch(self.idx, out=self.X, labels_out=self.labels)
         if self.keep_grads:           # otherwise the Adam pass leaves them cleared
             self.eng.grads.zero_()
-        self.eng.fwd_bwd(self.X, self.labels, phase=0, lengths=self.lengths)
+        # one GPU: the whole backward in one call (the shared-query gradient kernels of all three
+        # blocks then share one pair of launches); several GPUs: stop at the bucket boundary
+        self.eng.fwd_bwd(self.X, self.labels, phase=-1 if self.world == 1 else 0,
+                         lengths=self.lengths)
 
     def _seg1(self):     # backward(enc.0)
-        self.eng.fwd_bwd(self.X, self.labels, phase=1, lengths=self.lengths)
+        if self.world > 1:
+            self.eng.fwd_bwd(self.X, self.labels, phase=1, lengths=self.lengths)
 
     def _seg2(self):     # Adam over the flat vector
         e = self.eng
