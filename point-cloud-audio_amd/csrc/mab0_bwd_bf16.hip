@@ -170,6 +170,7 @@ struct Mab0BwdArgs {
   float* DG;             // [Rp][128] fp32, accumulated over sets (ln2-scaled dS units)
   int B, N, accumulate_dx, S;
   const int32_t* lengths;   // [B] valid points per set, or null
+  int R;                    // real score rows (<= RP): only these rows of dG are non-zero
 };
 
 template <int RP, bool ABF>
@@ -371,7 +372,8 @@ __global__ __launch_bounds__(256, 1) void k_mab0_bwd(const Mab0BwdArgs a) {
         slab[(16 * rb + 4 * g + e) * DK + 16 * ft + r] = dG[rb][ft][e];
   __syncthreads();
   const float* s0 = reinterpret_cast<const float*>(smem);
-  for (int i = tid; i < RP * DK; i += 256)
+  // (PMA: 4 of the 32 padded rows are real - 8x fewer atomics)
+  for (int i = tid; i < a.R * DK; i += 256)
     atomicAdd(&a.DG[i], s0[i] + s0[RP * DK + i] + s0[2 * RP * DK + i] + s0[3 * RP * DK + i]);
 }
 
@@ -596,7 +598,7 @@ int mab0_bf16_bwd_ex(const pca_mab_shape& s, const float* I, const void* X,
   } else {
     const int S = mab0_splits(s);
     Mab0BwdArgs a{X, v.Gb, v.GtP, w.dTb, w.dTt, w.LSEp, w.Delta, dX, w.DG, s.B, s.nk,
-                  dk_accumulate ? 1 : 0, S, s.k_lengths};
+                  dk_accumulate ? 1 : 0, S, s.k_lengths, R};
     size_t lds = 2 * (size_t)Rp * 256 + 2 * (size_t)128 * Rp * 2 + 2 * 4 * 32 * 256 +
                  2 * Rp * sizeof(float);
     if (lds < (size_t)4 * Rp * 128 * 4) lds = (size_t)4 * Rp * 128 * 4;     // merge slabs

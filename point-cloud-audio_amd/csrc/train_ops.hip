@@ -76,7 +76,17 @@ __global__ __launch_bounds__(128) void k_cls_fwd_bwd(
   for (int c = tid; c < C; c += 128) {
     const float* w = Wc + (int64_t)c * d;
     float acc = bc[c];
-    for (int f = 0; f < d; f += 4) {
+    int f = 0;
+    for (; f + 32 <= d; f += 32) {          // 8 independent 16-byte loads in flight
+      float4 w4[8];
+#pragma unroll
+      for (int u = 0; u < 8; ++u) w4[u] = *reinterpret_cast<const float4*>(w + f + 4 * u);
+#pragma unroll
+      for (int u = 0; u < 8; ++u)
+        acc += sP[f + 4 * u] * w4[u].x + sP[f + 4 * u + 1] * w4[u].y + sP[f + 4 * u + 2] * w4[u].z +
+               sP[f + 4 * u + 3] * w4[u].w;
+    }
+    for (; f < d; f += 4) {
       const float4 w4 = *reinterpret_cast<const float4*>(w + f);
       acc += sP[f] * w4.x + sP[f + 1] * w4.y + sP[f + 2] * w4.z + sP[f + 3] * w4.w;
     }
@@ -118,7 +128,15 @@ __global__ __launch_bounds__(128) void k_cls_fwd_bwd(
   __syncthreads();
   for (int f = tid; f < d; f += 128) {
     float acc = 0.f;
-    for (int c = 0; c < C; ++c) acc += sL[c] * Wc[(int64_t)c * d + f];
+    int c = 0;
+    for (; c + 10 <= C; c += 10) {          // 10 independent loads in flight
+      float wv[10];
+#pragma unroll
+      for (int u = 0; u < 10; ++u) wv[u] = Wc[(int64_t)(c + u) * d + f];
+#pragma unroll
+      for (int u = 0; u < 10; ++u) acc = fmaf(sL[c + u], wv[u], acc);
+    }
+    for (; c < C; ++c) acc += sL[c] * Wc[(int64_t)c * d + f];
     dP[(int64_t)b * d + f] = acc;
   }
 }
@@ -129,21 +147,30 @@ __global__ __launch_bounds__(128) void k_cls_wgrad(
     float* __restrict__ dWc, float* __restrict__ dbc, float* __restrict__ loss_out,
     float* __restrict__ stats) {
   const int c = blockIdx.x, tid = threadIdx.x;
-  for (int f = tid; f < d; f += 128) {
+  // this class's column of dlogits goes to LDS in one round trip (chunks of 1024 sets); the
+  // P loads are then the only global traffic of the reduction, 16 in flight
+  __shared__ float sg[1024];
+  for (int f0 = 0; f0 < d; f0 += 128) {
+    const int f = f0 + tid;
     float acc = 0.f;
-    int bb = 0;
-    for (; bb + 8 <= B; bb += 8) {
-      float g[8], pv[8];
+    for (int b0 = 0; b0 < B; b0 += 1024) {
+      const int nb = (B - b0 < 1024) ? B - b0 : 1024;
+      __syncthreads();
+      for (int i = tid; i < nb; i += 128) sg[i] = dlogits[(int64_t)(b0 + i) * C + c];
+      __syncthreads();
+      if (f < d) {
+        int bb = 0;
+        for (; bb + 16 <= nb; bb += 16) {
+          float pv[16];
 #pragma unroll
-      for (int u = 0; u < 8; ++u) {
-        g[u] = dlogits[(int64_t)(bb + u) * C + c];
-        pv[u] = P[(int64_t)(bb + u) * d + f];
+          for (int u = 0; u < 16; ++u) pv[u] = P[(int64_t)(b0 + bb + u) * d + f];
+#pragma unroll
+          for (int u = 0; u < 16; ++u) acc = fmaf(sg[bb + u], pv[u], acc);
+        }
+        for (; bb < nb; ++bb) acc = fmaf(sg[bb], P[(int64_t)(b0 + bb) * d + f], acc);
       }
-#pragma unroll
-      for (int u = 0; u < 8; ++u) acc = fmaf(g[u], pv[u], acc);
     }
-    for (; bb < B; ++bb) acc = fmaf(dlogits[(int64_t)bb * C + c], P[(int64_t)bb * d + f], acc);
-    dWc[(int64_t)c * d + f] += acc;
+    if (f < d) dWc[(int64_t)c * d + f] += acc;
   }
   __shared__ float red[128];
   float part = 0.f;
