@@ -437,3 +437,40 @@ def test_trainer_full_size_graph_vs_eager_vs_oracle(dev):
         tr_o.step()
         loss, _ = orc.train_step(tr_o.X.cpu(), tr_o.labels.cpu(), p, opt, 4)
         assert abs(float(tr_o.eng.loss) - loss) < 2e-3, (s, float(tr_o.eng.loss), loss)
+
+
+def test_reframe_sweep(dev, golden_ckpt, tmp_path):
+    """Device counterpart of the re-framing loop of Code/pceval.py:61-104 with the shipped FST
+    weights: every analysis length gives a well-formed accuracy, N = Nfft reproduces a direct
+    evaluation on the oracle's STFT, and the JSON has the reference's structure."""
+    import json
+    import evalsweep
+    import models
+    from oracle import st_oracle as orc
+    from pca_hip import trainer
+    net = models.ST(dim_input=2, dim_hidden=64, num_heads=8, num_inds=64).to(dev)
+    net.load_state_dict({k[len("module."):]: T(v) for k, v in golden_ckpt.sub("fst/p/").items()})
+    fs, Nfft = 44100, 2048
+    waves = [orc.synth_clip(i, i % 10, seconds=0.6, fs=fs) for i in range(4)]
+    labels = [i % 10 for i in range(4)]
+    clips = [T(w, dev) for w in waves]
+    list_N = [2 * Nfft, int(1.25 * Nfft), Nfft, int(0.6 * Nfft), int(0.1 * Nfft)]
+    jf = str(tmp_path / "expt1.json")
+    out = evalsweep.reframe_sweep(net, clips, labels, fs, list_N, json_file=jf)
+    assert out["list_N"] == list_N and list(out["data"].keys()) == [fs]
+    assert all(0.0 <= a <= 1.0 for a in out["data"][fs])
+    back = json.load(open(jf))
+    assert back["list_N"] == list_N and len(back["data"][str(fs)]) == len(list_N)
+    # N = Nfft against a direct evaluation on the oracle's spectrogram (same skipped tail)
+    import dataset
+    specs = [orc.stft_logmag(w, Nfft) for w in waves]
+    x = np.concatenate(specs, 1)
+    y = np.concatenate([np.full(s.shape[1], l) for s, l in zip(specs, labels)])
+    full = (x.shape[1] // 8) * 8
+    ds = dataset.ESC_pc(x[:, :full], y[:full], np.linspace(0, fs / 2, x.shape[0]) / fs, device=dev)
+    acc, n = trainer.evaluate(net, ds, 8)
+    assert n == full and abs(acc - out["data"][fs][2]) <= 1.0 / full + 1e-9
+    # shorter window than n_fft: frame count and bin count follow librosa's framing
+    d = evalsweep.framewise_dataset(clips, labels, fs, int(0.6 * Nfft))
+    assert d.num_points == 1 + 2048 // 2
+    assert len(d) == sum(1 + len(w) // int(0.6 * Nfft * 0.5) for w in waves)
