@@ -467,8 +467,12 @@ __global__ __launch_bounds__(256) void k_mab0_attn_small(const float* __restrict
   __shared__ float sM[256], sL[256], sT[256][4];
   __shared__ __attribute__((aligned(16))) float sX[CH * 4];
   const int b = blockIdx.x, tid = threadIdx.x;
-  const int parts = 256 / R;                 // R in {64, 128, 256}
-  const int r = tid % R, part = tid / R;
+  // gridDim.y workgroups share the rows of a set (fills the chip when B < #CUs and halves the
+  // points each thread walks): this one owns rows [row0, row0 + Rb)
+  const int Rb = R / gridDim.y, row0 = blockIdx.y * Rb;
+  const int parts = 256 / Rb;                // Rb in {32, 64, 128, 256}
+  const int rl = tid % Rb, part = tid / Rb;
+  const int r = row0 + rl;
   float gk[4];
 #pragma unroll
   for (int c = 0; c < 4; ++c) gk[c] = c < dk ? Gf[r * dk + c] : 0.f;
@@ -515,20 +519,20 @@ __global__ __launch_bounds__(256) void k_mab0_attn_small(const float* __restrict
 #pragma unroll
   for (int c = 0; c < 4; ++c) sT[tid][c] = t[c];
   __syncthreads();
-  if (tid < R) {
+  if (tid < Rb) {
     float M = -INFINITY;
-    for (int p = 0; p < parts; ++p) M = fmaxf(M, sM[p * R + tid]);
+    for (int p = 0; p < parts; ++p) M = fmaxf(M, sM[p * Rb + tid]);
     float L = 0.f, tt[4] = {0.f, 0.f, 0.f, 0.f};
     for (int p = 0; p < parts; ++p) {
-      const float mw = sM[p * R + tid];
+      const float mw = sM[p * Rb + tid];
       if (mw == -INFINITY) continue;
       const float f = exp2f(mw - M);
-      L += sL[p * R + tid] * f;
+      L += sL[p * Rb + tid] * f;
 #pragma unroll
-      for (int c = 0; c < 4; ++c) tt[c] += sT[p * R + tid][c] * f;
+      for (int c = 0; c < 4; ++c) tt[c] += sT[p * Rb + tid][c] * f;
     }
-    for (int c = 0; c < dk; ++c) T[((int64_t)b * R + tid) * dk + c] = tt[c] / L;
-    LSE[(int64_t)b * R + tid] = M + log2f(L);
+    for (int c = 0; c < dk; ++c) T[((int64_t)b * R + row0 + tid) * dk + c] = tt[c] / L;
+    LSE[(int64_t)b * R + row0 + tid] = M + log2f(L);
   }
 }
 
@@ -719,7 +723,8 @@ int mab0_bf16_fwd_ex(const pca_mab_shape& s, const float* I, const void* X,
 
   const double pts = (double)s.B * s.nk;
   if (small) {
-    hipLaunchKernelGGL(k_mab0_attn_small, dim3(s.B), dim3(256), 0, st,
+    // two workgroups per set when that still leaves 32 rows each
+    hipLaunchKernelGGL(k_mab0_attn_small, dim3(s.B, (R % 64 == 0 && R <= 512) ? 2 : 1), dim3(256), 0, st,
                        reinterpret_cast<const float*>(X), v.Gf, s.nk, R, dk, v.T, v.LSE,
                        s.k_lengths);
     PCA_TRY(check_launch("k_mab0_attn_small"));

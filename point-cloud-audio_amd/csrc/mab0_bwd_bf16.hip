@@ -387,8 +387,11 @@ __global__ __launch_bounds__(256) void k_mab0_bwd_small(
   __shared__ float sD[256][4];
   __shared__ __attribute__((aligned(16))) float sX[CH * 4];
   const int b = blockIdx.x, tid = threadIdx.x;
-  const int parts = 256 / R;
-  const int r = tid % R, part = tid / R;
+  // gridDim.y workgroups share the rows of a set: this one owns rows [row0, row0 + Rb)
+  const int Rb = R / gridDim.y, row0 = blockIdx.y * Rb;
+  const int parts = 256 / Rb;
+  const int rl = tid % Rb, part = tid / Rb;
+  const int r = row0 + rl;
   constexpr float LN2 = 0.6931471805599453f;
   float gk[4], dt[4], acc[4] = {0.f, 0.f, 0.f, 0.f};
 #pragma unroll
@@ -422,11 +425,11 @@ __global__ __launch_bounds__(256) void k_mab0_bwd_small(
 #pragma unroll
   for (int c = 0; c < 4; ++c) sD[tid][c] = acc[c];
   __syncthreads();
-  if (tid < R) {
+  if (tid < Rb) {
     for (int c = 0; c < dk; ++c) {
       float v = 0.f;
-      for (int p = 0; p < parts; ++p) v += sD[p * R + tid][c];
-      atomicAdd(&DG[tid * dk + c], v);
+      for (int p = 0; p < parts; ++p) v += sD[p * Rb + tid][c];
+      atomicAdd(&DG[(row0 + tid) * dk + c], v);
     }
   }
 }
@@ -591,7 +594,7 @@ int mab0_bf16_bwd_ex(const pca_mab_shape& s, const float* I, const void* X,
   // (with head_done the caller's k_mid_bwd has cleared DG)
 
   if (small) {
-    hipLaunchKernelGGL(k_mab0_bwd_small, dim3(s.B), dim3(256), 0, st,
+    hipLaunchKernelGGL(k_mab0_bwd_small, dim3(s.B, (R % 64 == 0 && R <= 512) ? 2 : 1), dim3(256), 0, st,
                        reinterpret_cast<const float*>(X), v.Gf, w.dTf, v.LSE,
                        w.Delta, s.nk, R, Rp, dk, w.DG, s.k_lengths);
     PCA_TRY(check_launch("k_mab0_bwd_small"));
