@@ -11,12 +11,16 @@
 // This is flash attention whose keys AND values are the same X tile: X is read once.
 //
 //   k_mab0_prep   Qp, G (bf16, scale*log2e folded in) -- once per call, tiny
-//   k_mab0_attn   one workgroup per set; each wave streams 32-point tiles: S = X G^T on the
-//                 MFMA (points on accumulator rows, so the softmax statistics of a query row
-//                 are lane-local + 2 cross-lane steps), online softmax, T += P^T X with the
+//   k_mab0_attn   (PMA: 4 score rows) each wave streams its own 32-point tiles: S = X G^T on
+//                 the MFMA (points on accumulator rows, so the softmax statistics of a query
+//                 row are lane-local + 2 cross-lane steps), online softmax, T += P^T X with the
 //                 probability tile fed back as the A operand straight from the accumulators
-//                 and X^T read from the same LDS tile through ds_read_tr16_b64
-//   k_mab0_attn_small   layer 1 (dk = din <= 4): exact fp32 on the vector ALU
+//                 and X^T read from the same LDS tile through ds_read_tr16_b64; the waves'
+//                 partials are merged through per-wave LDS slabs
+//   k_mab0_attn_h4 (ISAB: 4 heads x 16 queries) same arithmetic, but every wave owns one head
+//                 over X tiles shared by the workgroup: no cross-wave merge
+//   k_mab0_attn_small   layer 1 (dk = din <= 4): exact fp32 on the vector ALU, the rows of a
+//                 set shared by two workgroups
 //   k_mab0_epi    per set: O, Z, H (fp32 VALU; 2*m*d*(dk+d) MACs)
 #include "mab1_bf16.hpp"
 
@@ -738,13 +742,6 @@ int mab0_bf16_fwd_ex(const pca_mab_shape& s, const float* I, const void* X,
     // reference-formulation FLOPs of the block: fc_k, fc_v over the keys + QK^T + AV
     ProfScope ps(PCA_K_MAB0_FWD, st, 2.0 * pts * (2.0 * dk * d + 2.0 * m * d),
                  pts * 4.0 * dk);
-    static std::once_flag once;
-    std::call_once(once, [] {
-      (void)hipFuncSetAttribute(reinterpret_cast<const void*>(k_mab0_attn<4, false>),
-                                hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
-      (void)hipFuncSetAttribute(reinterpret_cast<const void*>(k_mab0_attn<4, true>),
-                                hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
-    });
     const dim3 grid(s.B, S);
     const bool abf = s.k_dtype == PCA_BF16;
     PCA_REQUIRE(RB == 1 || RB == 4, "mab0_bf16_fwd: %d score rows not built", Rpad);
