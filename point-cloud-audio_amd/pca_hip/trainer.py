@@ -258,17 +258,20 @@ class Trainer:
         for dst, src in zip((self.eng.flat, self.m, self.v, self.step_count, self.eng.stats),
                             snap):
             dst.copy_(src)
+        # thread-local capture mode: a HIP call from another thread (e.g. the RCCL watchdog of
+        # torch.distributed) must not invalidate the capture
+        mode = dict(capture_error_mode="thread_local")
         if self.world == 1:
             self.g0 = torch.cuda.CUDAGraph()
-            with torch.cuda.graph(self.g0):
+            with torch.cuda.graph(self.g0, **mode):
                 self._seg0(); self._seg1(); self._seg2()
         else:
             self.g0, self.g1, self.g2 = (torch.cuda.CUDAGraph() for _ in range(3))
-            with torch.cuda.graph(self.g0):
+            with torch.cuda.graph(self.g0, **mode):
                 self._seg0()
-            with torch.cuda.graph(self.g1, pool=self.g0.pool()):
+            with torch.cuda.graph(self.g1, pool=self.g0.pool(), **mode):
                 self._seg1()
-            with torch.cuda.graph(self.g2, pool=self.g0.pool()):
+            with torch.cuda.graph(self.g2, pool=self.g0.pool(), **mode):
                 self._seg2()
         for dst, src in zip((self.eng.flat, self.m, self.v, self.step_count, self.eng.stats),
                             snap):
