@@ -15,6 +15,20 @@ namespace pca {
 
 namespace {
 
+// PCA_MODE_BF16 on a shape without fused kernels: the same chain with bf16 MFMA operands
+thread_local bool t_bf16_operands = false;
+struct OperandMode {
+  bool prev;
+  explicit OperandMode(const pca_mab_shape& s) : prev(t_bf16_operands) {
+    t_bf16_operands = s.mode == PCA_MODE_BF16;
+  }
+  ~OperandMode() { t_bf16_operands = prev; }
+};
+inline int gemm_sel(const pca_gemm_desc& g, const float* A, const float* B, const float* bias,
+                    float* C, hipStream_t st) {
+  return t_bf16_operands ? gemm_bf16(g, A, B, bias, C, st) : gemm_f32(g, A, B, bias, C, st);
+}
+
 struct SavedF32 {
   float *Qp, *Kp, *Vp, *A, *O, *Z;
 };
@@ -68,20 +82,20 @@ inline int linear(const float* X, const float* W, const float* b, float* Y, int6
                   int din, int dout, int accumulate, hipStream_t st) {
   pca_gemm_desc g = gd(M, dout, din, din, 1, 1, din, dout, accumulate);
   g.split_k = 1;
-  return gemm_f32(g, X, W, b, Y, st);
+  return gemm_sel(g, X, W, b, Y, st);
 }
 // dX[M, din] (+)= dY[M, dout] W
 inline int linear_dx(const float* dY, const float* W, float* dX, int64_t M, int din,
                      int dout, int accumulate, hipStream_t st) {
   pca_gemm_desc g = gd(M, din, dout, dout, 1, din, 1, din, accumulate);
   g.split_k = 1;
-  return gemm_f32(g, dY, W, nullptr, dX, st);
+  return gemm_sel(g, dY, W, nullptr, dX, st);
 }
 // dW[dout, din] += dY[M, dout]^T X[M, din]   (split-K over the M rows)
 inline int linear_dw(const float* dY, const float* X, float* dW, int64_t M, int din,
                      int dout, hipStream_t st) {
   pca_gemm_desc g = gd(dout, din, M, 1, dout, din, 1, din, 1);
-  return gemm_f32(g, dY, X, nullptr, dW, st);
+  return gemm_sel(g, dY, X, nullptr, dW, st);
 }
 
 inline void set_heads(pca_gemm_desc& g, const pca_mab_shape& s, int64_t a_b, int64_t a_h,
@@ -109,6 +123,7 @@ size_t mab_f32_bwd_ws_bytes(const pca_mab_shape& s) { return bwd_ws_elems(s, nul
 
 int mab_f32_fwd(const pca_mab_shape& s, const float* Q, const float* K,
                 const pca_mab_params& p, float* Y, void* saved, hipStream_t st) {
+  OperandMode om(s);
   SavedF32 v;
   saved_elems(s, &v, saved);
   const int64_t Bq = s.q_shared ? 1 : s.B;
@@ -124,7 +139,7 @@ int mab_f32_fwd(const pca_mab_shape& s, const float* Q, const float* K,
     pca_gemm_desc g = gd(nq, nk, dh, d, 1, 1, d, nk, 0);
     g.split_k = 1;
     set_heads(g, s, qb, dh, (int64_t)nk * d, dh, (int64_t)h * nq * nk, (int64_t)nq * nk);
-    PCA_TRY(gemm_f32(g, v.Qp, v.Kp, nullptr, v.A, st));
+    PCA_TRY(gemm_sel(g, v.Qp, v.Kp, nullptr, v.A, st));
   }
   PCA_TRY(softmax_rows(v.A, (int64_t)s.B * h * nq, nk, scale, st, s.k_lengths,
                        (int64_t)h * nq));                                   // :28
@@ -134,7 +149,7 @@ int mab_f32_fwd(const pca_mab_shape& s, const float* Q, const float* K,
     g.split_k = 1;
     set_heads(g, s, (int64_t)h * nq * nk, (int64_t)nq * nk, (int64_t)nk * d, dh,
               (int64_t)nq * d, dh);
-    PCA_TRY(gemm_f32(g, v.A, v.Vp, nullptr, v.O, st));
+    PCA_TRY(gemm_sel(g, v.A, v.Vp, nullptr, v.O, st));
   }
   PCA_TRY(linear(v.O, p.wo, p.bo, v.Z, (int64_t)s.B * nq, d, d, 0, st));    // :31
   PCA_TRY(add_relu(v.O, v.Z, Y, (int64_t)s.B * nq * d, st));                // :31
@@ -145,6 +160,7 @@ int mab_f32_bwd(const pca_mab_shape& s, const float* Q, const float* K,
                 const pca_mab_params& p, const void* saved, const float* dY, float* dQ,
                 float* dK, int dk_accumulate, const pca_mab_grads& g, void* ws,
                 hipStream_t st) {
+  OperandMode om(s);
   SavedF32 v;
   saved_elems(s, &v, const_cast<void*>(saved));
   BwdWsF32 w;
@@ -168,14 +184,14 @@ int mab_f32_bwd(const pca_mab_shape& s, const float* Q, const float* K,
     pca_gemm_desc gg = gd(nk, dh, nq, 1, nk, d, 1, d, 1);
     set_heads(gg, s, (int64_t)h * nq * nk, (int64_t)nq * nk, (int64_t)nq * d, dh,
               (int64_t)nk * d, dh);
-    PCA_TRY(gemm_f32(gg, v.A, w.dO, nullptr, w.dVp, st));
+    PCA_TRY(gemm_sel(gg, v.A, w.dO, nullptr, w.dVp, st));
   }
   {  // dA = dO_j Vp_j^T
     pca_gemm_desc gg = gd(nq, nk, dh, d, 1, 1, d, nk, 0);
     gg.split_k = 1;
     set_heads(gg, s, (int64_t)nq * d, dh, (int64_t)nk * d, dh, (int64_t)h * nq * nk,
               (int64_t)nq * nk);
-    PCA_TRY(gemm_f32(gg, w.dO, v.Vp, nullptr, w.dA, st));
+    PCA_TRY(gemm_sel(gg, w.dO, v.Vp, nullptr, w.dA, st));
   }
   PCA_TRY(softmax_bwd_rows(v.A, w.dA, (int64_t)s.B * h * nq, nk, scale, st));  // dS*scale
   PCA_TRY(copy_rows(w.dO, Mq, w.dQp, Mq, d, st));                              // residual Q_
@@ -184,12 +200,12 @@ int mab_f32_bwd(const pca_mab_shape& s, const float* Q, const float* K,
     gg.split_k = 1;
     set_heads(gg, s, (int64_t)h * nq * nk, (int64_t)nq * nk, (int64_t)nk * d, dh,
               (int64_t)nq * d, dh);
-    PCA_TRY(gemm_f32(gg, w.dA, v.Kp, nullptr, w.dQp, st));
+    PCA_TRY(gemm_sel(gg, w.dA, v.Kp, nullptr, w.dQp, st));
   }
   {  // dKp_j = dS^T Qp_j
     pca_gemm_desc gg = gd(nk, dh, nq, 1, nk, d, 1, d, 1);
     set_heads(gg, s, (int64_t)h * nq * nk, (int64_t)nq * nk, qb, dh, (int64_t)nk * d, dh);
-    PCA_TRY(gemm_f32(gg, w.dA, v.Qp, nullptr, w.dKp, st));
+    PCA_TRY(gemm_sel(gg, w.dA, v.Qp, nullptr, w.dKp, st));
   }
 
   // fc_k / fc_v

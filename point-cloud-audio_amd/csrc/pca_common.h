@@ -77,6 +77,9 @@ void terminal_join(hipStream_t main);
 // ---- internal launchers used across translation units -------------------
 int gemm_f32(const pca_gemm_desc& g, const float* A, const float* B, const float* bias,
              float* C, hipStream_t st);
+// same contract, operands rounded to bf16 on the way into the MFMA (gemm_bf16.hip)
+int gemm_bf16(const pca_gemm_desc& g, const float* A, const float* B, const float* bias,
+              float* C, hipStream_t st);
 int softmax_rows(float* X, int64_t rows, int n, float scale, hipStream_t st,
                  const int32_t* lengths = nullptr, int64_t rows_per_set = 0);
 int softmax_bwd_rows(const float* A, float* dA, int64_t rows, int n, float scale,

@@ -259,3 +259,40 @@ def test_mab0_bwd_bf16(dev, case):
         rms = float((emu[k] - exact[k]).pow(2).mean().sqrt()) / sc
         assert rms < 3e-2, (k, rms)
     print(f"mab0 bwd {case}: " + " ".join(f"{k}={v:.1e}" for k, v in errs.items()))
+
+
+@pytest.mark.parametrize("ci", [1, 3], ids=["st_shipped", "st_cfg4"])
+def test_engine_bf16_generic_gemm_path(dev, golden_st, ci):
+    """mode = BF16 on architectures without fused kernels (shipped d=64 / 8 heads / 64 inducing
+    points; BASELINE configs[3] d=256 / 8 heads / 32 inducing points): the exact chain with
+    bf16 MFMA operands (k_gemm_bf16) against the reference's golden logits and gradients."""
+    import inputs as gi
+    import models
+    from pca_hip import _lib, trainer
+    name, B, N, din, d, h, m, C, full = gi.ST_CASES[ci]
+    net = models.ST(dim_input=din, num_outputs=1, dim_output=C, num_inds=m, dim_hidden=d,
+                    num_heads=h).to(dev)
+    net.load_state_dict({k: T(v) for k, v in golden_st.sub(f"{name}/p/").items()})
+    X = T(gi.pc_input(600 + ci, B, N, din), dev)
+    y = T(gi.labels(700 + ci, B, C), dev)
+    eng = trainer.STEngine(net, B, N, mode=_lib.MODE_BF16, training=True)
+    eng.fwd_bwd(X, y, phase=-1)
+    ref = golden_st[f"{name}/logits"].reshape(B, C)
+    err = close(eng.logits, ref, 3e-2, "logits")
+    exact = trainer.STEngine(net, B, N, mode=_lib.MODE_F32, training=True)
+    exact.fwd_bwd(X, y, phase=-1)
+    assert float((eng.logits - exact.logits).abs().max()) > 1e-6, "bf16 mode ran the fp32 GEMMs"
+    off, worst = 0, 0.0
+    for k, prm in net.named_parameters():
+        gr = eng.grads[off:off + prm.numel()].view_as(prm)
+        off += prm.numel()
+        if full:
+            worst = max(worst, close_robust(gr, golden_st[f"{name}/g/{k}"], 5e-2, k,
+                                            outlier_frac=5e-3))
+        else:
+            worst = max(worst, close_robust(gr.reshape(-1)[::gi.GRAD_SUBSAMPLE],
+                                            golden_st[f"{name}/gsub/{k}"], 5e-2, k,
+                                            outlier_frac=5e-3))
+    print(f"{name} bf16 generic path: logits err {err:.2e}, worst grad err {worst:.2e}")
+    inf = trainer.STEngine(net, B, N, mode=_lib.MODE_BF16, training=False)
+    close(inf.forward(X), ref, 3e-2, "logits(inference)")
