@@ -589,6 +589,33 @@ __global__ __launch_bounds__(256) void k_mab0_epi(const float* __restrict__ Tp, 
   }
   __syncthreads();
   const int f = tid % d, qh = tid / d;          // d == 128: two query halves
+  if (MQ == 1 && m == 1) {
+    // PMA (one seed): the second half of the workgroup would idle - it takes the second half
+    // of every contraction instead (these GEMVs are chains of dependent L2 round trips)
+    __shared__ float part[128];
+    const int j = f / dh;
+    float a1[1] = {qh == 0 ? Qp[f] + bv[f] : 0.f};
+    col_gemm<1>(sT + j * dk + qh * (dk / 2), dk, WvT + (int64_t)qh * (dk / 2) * d, d, dk / 2, f, a1);
+    if (qh == 1) part[f] = a1[0];
+    __syncthreads();
+    if (qh == 0) { a1[0] += part[f]; sO[f] = a1[0]; }
+    __syncthreads();
+    float z1[1] = {qh == 0 ? bo[f] : 0.f};
+    col_gemm<1>(sO + qh * (d / 2), d, WoT + (int64_t)qh * (d / 2) * d, d, d / 2, f, z1);
+    if (qh == 1) part[f] = z1[0];
+    __syncthreads();
+    if (qh == 0) {
+      z1[0] += part[f];
+      const float o1 = sO[f];
+      const int64_t o = (int64_t)b * d + f;
+      H[o] = o1 + fmaxf(z1[0], 0.f);
+      if (Osave != nullptr) {
+        Osave[o] = o1;
+        Zsave[o] = z1[0];
+      }
+    }
+    return;
+  }
   const int q0 = qh * MQ;
   const bool act = q0 < m;
   float acc[MQ];

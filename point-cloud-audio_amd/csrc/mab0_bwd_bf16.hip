@@ -83,9 +83,27 @@ __global__ __launch_bounds__(256) void k_mab0_epi_bwd(
   }
   for (int i = tid; i < Rp; i += 256) sDl[i] = 0.f;
   __syncthreads();
-  const int c = tid % d, q0 = (tid / d) * MQ;
-  const bool act = q0 < m;
-  if (act) {
+  const int c = tid % d;
+  // PMA (one seed): the second half of the workgroup takes the second half of the
+  // contraction over fc_o and the heads 2, 3 of the dT products instead of idling
+  const bool pma = MQ == 1 && m == 1 && (h % 2) == 0;
+  const int half = tid / d;
+  int q0 = half * MQ;
+  bool act = q0 < m;
+  if (pma) {
+    float* part = sDl + Rp;                 // [d] scratch behind the Delta slots
+    float a1[1] = {half == 0 ? dH[(int64_t)b * d + c] : 0.f};
+    col_gemm<1>(sdZ + half * (d / 2), d, Wo + (int64_t)half * (d / 2) * d, d, d / 2, c, a1);
+    if (half == 1) part[c] = a1[0];
+    __syncthreads();
+    if (half == 0) {
+      a1[0] += part[c];
+      sdO[c] = a1[0];
+      dO[(int64_t)b * d + c] = a1[0];
+    }
+    q0 = 0;
+    act = true;
+  } else if (act) {
     float acc[MQ];
 #pragma unroll
     for (int q = 0; q < MQ; ++q)
@@ -100,8 +118,9 @@ __global__ __launch_bounds__(256) void k_mab0_epi_bwd(
   }
   __syncthreads();
   // dT[j m + q][cc] = sum_f dO[q][j dh + f] Wv[j dh + f][cc] ; thread owns column cc of dk
+  const int j_lo = pma ? half * (h / 2) : 0, j_hi = pma ? j_lo + h / 2 : h;
   for (int cc = tid % d; cc < dk && act; cc += d) {
-    for (int j = 0; j < h; ++j) {
+    for (int j = j_lo; j < j_hi; ++j) {
       float acc[MQ];
 #pragma unroll
       for (int q = 0; q < MQ; ++q) acc[q] = 0.f;
@@ -577,7 +596,7 @@ int mab0_bf16_bwd_ex(const pca_mab_shape& s, const float* I, const void* X,
     return PCA_EUNSUPPORTED;
   }
 
-  const size_t el = (2 * (size_t)m * d + (size_t)Rp) * sizeof(float);
+  const size_t el = (2 * (size_t)m * d + (size_t)Rp + (size_t)d) * sizeof(float);   // + split scratch
   if (head_done) {
     // dZ, dO, Th, dT images, Delta, LSEp and dQs come from k_mid_bwd
   } else if (m > 2)
