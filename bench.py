@@ -57,11 +57,27 @@ def st_fwd_macs(N, din, d, m, k, C):
     return N * (3 * din * d + 7 * d * d + 8 * m * d + 2 * k * d) + 6 * m * d * d + k * d * d + k * d * C
 
 
+def synth_clip(clip_id: int, cls: int, seconds: float = 5.0, fs: int = FS) -> np.ndarray:
+    """Synthetic class-conditional clip of SURVEY.md 8d: 3 harmonics of f0(c) = 110*2^(c/12) Hz
+    with seeded phases + low-passed noise, PCG64(seed = 1000 + clip_id); float32 in [-1, 1].
+    (The bench's own generator: nothing under oracle/ is touched outside cpu_baseline().)"""
+    rng = np.random.Generator(np.random.PCG64(1000 + clip_id))
+    L = int(round(seconds * fs))
+    t = np.arange(L) / fs
+    f0 = 110.0 * 2.0 ** (cls / 12.0)
+    x = np.zeros(L)
+    for k in range(1, 4):
+        x += (0.5 / k) * np.sin(2 * np.pi * f0 * k * t + rng.uniform(0, 2 * np.pi))
+    noise = np.convolve(rng.standard_normal(L), np.ones(8) / 8.0, mode="same")
+    x = x + 0.1 * noise
+    x = x / (np.max(np.abs(x)) + 1e-9) * 0.9
+    return x.astype(np.float32)
+
+
 def build_dataset(cfg, n_clips, dev, seed):
     """Synthetic class-conditional clips -> STFT kernel -> device-resident dataset."""
     import dataset
     import pca_hip
-    from oracle import st_oracle as orc          # only for the synthetic waveform generator
     n_fft, ntemp, C_ = cfg["n_fft"], cfg["ntemp"], cfg["C"]
     hop = n_fft // 2
     drop = not (cfg["din"] == 2 and n_fft == 2048)      # FST keeps the Nyquist bin (N=1025)
@@ -70,7 +86,7 @@ def build_dataset(cfg, n_clips, dev, seed):
     t_stft = 0.0
     for i in range(n_clips):
         cls = (seed * 7919 + i) % C_
-        wave = torch.from_numpy(orc.synth_clip(seed * 100000 + i, cls)).to(dev)
+        wave = torch.from_numpy(synth_clip(seed * 100000 + i, cls)).to(dev)
         torch.cuda.synchronize(dev)
         t0 = time.perf_counter()
         s = pca_hip.stft_logmag(wave, n_fft, n_fft, hop, drop_nyquist=drop, frame_major=True)

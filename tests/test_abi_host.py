@@ -83,3 +83,24 @@ def test_cpu_tensor_fails_loudly():
     net = models.ST(dim_hidden=8, num_heads=2, num_inds=4)
     with pytest.raises(pca_hip.PcaHipError):
         net(torch.zeros(2, 5, 2))
+
+
+def test_product_never_touches_the_oracle():
+    """oracle/ is test infrastructure: the package must not import it anywhere, and bench.py
+    only inside cpu_baseline()."""
+    import ast
+    import glob
+    pkg = os.path.join(ROOT, "point-cloud-audio_amd")
+    for path in glob.glob(os.path.join(pkg, "**", "*.py"), recursive=True):
+        assert "oracle" not in open(path).read(), path
+    for path in glob.glob(os.path.join(pkg, "csrc", "*")):
+        if os.path.isfile(path) and not path.endswith(".o"):
+            assert "oracle/" not in open(path, errors="ignore").read(), path
+    tree = ast.parse(open(os.path.join(ROOT, "bench.py")).read())
+    for fn in [n for n in tree.body if isinstance(n, ast.FunctionDef)]:
+        uses = any(isinstance(n, (ast.Import, ast.ImportFrom)) and
+                   "oracle" in (getattr(n, "module", None) or "") + " ".join(a.name for a in n.names)
+                   for n in ast.walk(fn))
+        assert uses == (fn.name == "cpu_baseline"), fn.name
+    top = [n for n in tree.body if isinstance(n, (ast.Import, ast.ImportFrom))]
+    assert not any("oracle" in (getattr(n, "module", None) or "") for n in top)
