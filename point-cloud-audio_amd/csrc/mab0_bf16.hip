@@ -694,7 +694,10 @@ int mab0_splits(const pca_mab_shape& s) {
   if (s.dk <= 4) return 1;
   int S = 1;
   const int tiles = (int)cdiv(s.nk, 128);
-  while (S * 2 <= tiles && s.B * S < 256 && S < 8) S *= 2;
+  // PMA (a handful of score rows): the per-range partials are tiny and the forward needs
+  // 40 KiB of LDS, so aim for two workgroups per CU; ISAB: one per CU
+  const int want = s.h * s.nq <= 16 ? 512 : 256;
+  while (S * 2 <= tiles && s.B * S < want && S < 8) S *= 2;
   return S;
 }
 

@@ -618,7 +618,8 @@ int mab0_bf16_bwd_ex(const pca_mab_shape& s, const float* I, const void* X,
                        w.Delta, s.nk, R, Rp, dk, w.DG, s.k_lengths);
     PCA_TRY(check_launch("k_mab0_bwd_small"));
   } else {
-    const int S = mab0_splits(s);
+    int S = mab0_splits(s);
+    while (S > 1 && s.B * S > 256) S /= 2;     // 96+ KiB of LDS: one workgroup per CU
     Mab0BwdArgs a{X, v.Gb, v.GtP, w.dTb, w.dTt, w.LSEp, w.Delta, dX, w.DG, s.B, s.nk,
                   dk_accumulate ? 1 : 0, S, s.k_lengths, R};
     size_t lds = 2 * (size_t)Rp * 256 + 2 * (size_t)128 * Rp * 2 + 2 * 4 * 32 * 256 +
