@@ -153,6 +153,9 @@ def main():
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     assert world == args.gpus, f"WORLD_SIZE={world} but --gpus {args.gpus}"
+    # PCA_FORCE_DEVICE: rehearse the multi-rank path on a one-GPU box (all ranks on one card,
+    # PCA_DIST_BACKEND=gloo); never set in a real run
+    local_rank = int(os.environ.get("PCA_FORCE_DEVICE", local_rank))
     torch.cuda.set_device(local_rank)
     dev = torch.device("cuda", local_rank)
     if world > 1:
