@@ -127,10 +127,29 @@ def cpu_baseline(cfg, N, budget_s=20.0):
         orc.train_step(X, y, p, opt, cfg["h"])
         times.append(time.perf_counter() - t0)
     med = float(np.median(times))
+    # the reference's per-item host packing (Code/dataset.py:50-54 / 160-166), one core: it caps
+    # the reference's loader independently of the model (SURVEY.md 8d asks for it as its own line)
+    rng = np.random.Generator(np.random.PCG64(0))
+    if cfg["din"] == 2:
+        xs = rng.standard_normal((N, 512)).astype(np.float32)
+        farr = np.linspace(0, 0.5, N)
+        pack = lambda i: orc.pack_points_2d(xs, farr, i % 512)                  # noqa: E731
+    else:
+        F = N // cfg["ntemp"]
+        xs = rng.standard_normal((F, cfg["ntemp"], 64)).astype(np.float32)
+        farr, tarr = np.linspace(0, 0.5, F), np.linspace(0, 0.1, cfg["ntemp"])
+        pack = lambda i: orc.pack_points_3d(xs, farr, tarr, i % 64)              # noqa: E731
+    t0 = time.perf_counter()
+    n_items = 0
+    while time.perf_counter() - t0 < 1.0:
+        pack(n_items)
+        n_items += 1
+    pack_rate = n_items / (time.perf_counter() - t0)
     return dict(value=round(B / med / cfg["sets_per_clip"], 4), unit="clips/s", cores=ncore,
                 kind="port",
                 sample=f"{len(times)} train steps of B={B} sets (median {med * 1e3:.1f} ms/step, "
-                       f"{B / med:.1f} sets/s), oracle/st_oracle.py on torch CPU fp32")
+                       f"{B / med:.1f} sets/s), oracle/st_oracle.py on torch CPU fp32",
+                pack_sets_per_s_1core=round(pack_rate, 1))
 
 
 def main():
