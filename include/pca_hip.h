@@ -166,15 +166,21 @@ typedef struct pca_mab_shape {
    * output on the truncated set.  Padding rows of K must hold finite values (the pack
    * kernels write zeros); their gradient rows come out as exact zeros. */
   const int32_t* k_lengths;
+  /* 1: the block has the two LayerNorms of MAB(..., ln=True) (modules.py:14-16,30,32;
+   * nn.LayerNorm(dim_V), eps 1e-5) and pca_mab_params / pca_mab_grads carry their affine
+   * parameters.  Such blocks always run the exact strided-GEMM chain. */
+  int32_t ln;
 } pca_mab_shape;
 
 /* nn.Linear layout: weight [d_out, d_in] row-major, y = x W^T + b.  fp32. */
 typedef struct pca_mab_params {
   const float *wq, *bq, *wk, *bk, *wv, *bv, *wo, *bo;
+  const float *ln0_w, *ln0_b, *ln1_w, *ln1_b;   /* [d] each; read only when shape.ln != 0 */
 } pca_mab_params;
 
 typedef struct pca_mab_grads {      /* ACCUMULATED into (+=); caller zeroes     */
   float *wq, *bq, *wk, *bk, *wv, *bv, *wo, *bo;
+  float *ln0_w, *ln0_b, *ln1_w, *ln1_b;         /* used only when shape.ln != 0 */
 } pca_mab_grads;
 
 /* bytes of the saved-for-backward block / of the scratch block (both 256-aligned) */

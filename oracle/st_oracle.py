@@ -74,8 +74,12 @@ def mab_forward(Q: Tensor, K: Tensor, p: Params, num_heads: int,
     A = torch.softmax(S, dim=-1)                    # :28
     Oh = Qh + A @ Vh                                # :29
     O = Oh.permute(0, 2, 1, 3).reshape(B, nq, d)    # :29 (merge heads)
+    if "ln0.weight" in p:                           # :30  MAB(ln=True): nn.LayerNorm(dim_V)
+        O = torch.nn.functional.layer_norm(O, (d,), p["ln0.weight"], p["ln0.bias"], 1e-5)
     Z = _lin(O, p, "fc_o")                          # :31
     Y = O + torch.relu(Z)                           # :31
+    if "ln1.weight" in p:                           # :32
+        Y = torch.nn.functional.layer_norm(Y, (d,), p["ln1.weight"], p["ln1.bias"], 1e-5)
     if return_saved:
         return Y, dict(Qp=Qp, Kp=Kp, Vp=Vp, A=A, O=O, Z=Z)
     return Y

@@ -20,6 +20,7 @@ static int check_f32(const pca_mab_shape* s) {
 int mab_kind(const pca_mab_shape& s) {
   // (a fused mab1 has the m inducing-point outputs as keys: always all of them; a caller that
   // masks keys of such a shape gets the exact path, whose softmax honours k_lengths)
+  if (s.ln) return 0;          // LayerNorm variants: exact chain only
   if (s.mode == PCA_MODE_BF16 && s.k_lengths == nullptr && mab1_bf16_supported(s)) return 1;
   if (s.mode == PCA_MODE_BF16 && mab0_bf16_supported(s)) return 2;
   return 0;

@@ -234,6 +234,71 @@ __global__ __launch_bounds__(256) void k_poison_lds() {
   if (junk[(threadIdx.x * 97) % (160 * 1024 / 4)] == 1u) junk[0] = 0;   // keep the stores alive
 }
 
+// nn.LayerNorm(d) over the rows of X [rows, d] (modules.py:30,32): one wave per row.
+// Saves the row statistics for the backward.
+__global__ __launch_bounds__(256) void k_layernorm_fwd(const float* __restrict__ X,
+                                                        const float* __restrict__ w,
+                                                        const float* __restrict__ b,
+                                                        float* __restrict__ Y,
+                                                        float* __restrict__ mean,
+                                                        float* __restrict__ rstd, int64_t rows,
+                                                        int d, float eps) {
+  const int lane = threadIdx.x & 63;
+  const int64_t row = (int64_t)blockIdx.x * 4 + (threadIdx.x >> 6);
+  if (row >= rows) return;
+  const float* x = X + row * d;
+  float s = 0.f;
+  for (int j = lane; j < d; j += 64) s += x[j];
+  s = group_sum<64>(s);
+  const float mu = s / (float)d;
+  float v = 0.f;
+  for (int j = lane; j < d; j += 64) { const float t = x[j] - mu; v += t * t; }
+  v = group_sum<64>(v);
+  const float rs = rsqrtf(v / (float)d + eps);          // biased variance, as torch
+  for (int j = lane; j < d; j += 64) Y[row * d + j] = (x[j] - mu) * rs * w[j] + b[j];
+  if (lane == 0) { mean[row] = mu; rstd[row] = rs; }
+}
+
+// dX = rstd * (g - mean(g) - xhat * mean(g * xhat)), g = dY * w ; dw += sum_rows dY * xhat ;
+// db += sum_rows dY.  A block takes 64 rows: per-column partials in registers, one atomic
+// per column per block.
+__global__ __launch_bounds__(256) void k_layernorm_bwd(
+    const float* __restrict__ dY, const float* __restrict__ X, const float* __restrict__ mean,
+    const float* __restrict__ rstd, const float* __restrict__ w, float* __restrict__ dX,
+    float* __restrict__ dw, float* __restrict__ db, int64_t rows, int d) {
+  extern __shared__ float sred[];            // [2][d] column partials of this block
+  const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
+  for (int j = tid; j < 2 * d; j += 256) sred[j] = 0.f;
+  __syncthreads();
+  const int64_t r0 = (int64_t)blockIdx.x * 64;
+  for (int rr = wv; rr < 64; rr += 4) {
+    const int64_t row = r0 + rr;
+    if (row >= rows) break;
+    const float mu = mean[row], rs = rstd[row];
+    float sg = 0.f, sgx = 0.f;
+    for (int j = lane; j < d; j += 64) {
+      const float xh = (X[row * d + j] - mu) * rs;
+      const float g = dY[row * d + j] * w[j];
+      sg += g;
+      sgx += g * xh;
+    }
+    sg = group_sum<64>(sg) / (float)d;
+    sgx = group_sum<64>(sgx) / (float)d;
+    for (int j = lane; j < d; j += 64) {
+      const float xh = (X[row * d + j] - mu) * rs;
+      const float gy = dY[row * d + j];
+      dX[row * d + j] = rs * (gy * w[j] - sg - xh * sgx);
+      atomicAdd(&sred[j], gy * xh);
+      atomicAdd(&sred[d + j], gy);
+    }
+  }
+  __syncthreads();
+  for (int j = tid; j < d; j += 256) {
+    atomicAdd(&dw[j], sred[j]);
+    atomicAdd(&db[j], sred[d + j]);
+  }
+}
+
 // zero fill (a kernel rather than hipMemsetAsync: identical behaviour eager and captured)
 __global__ void k_fill_zero(float* __restrict__ dst, int64_t n) {
   int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
@@ -295,6 +360,26 @@ int softmax_bwd_rows(const float* A, float* dA, int64_t rows, int n, float scale
   PCA_DISPATCH_G(n, CALL);
 #undef CALL
   return check_launch("k_softmax_bwd_rows");
+}
+
+int layernorm_fwd(const float* X, const float* w, const float* b, float* Y, float* mean,
+                  float* rstd, int64_t rows, int d, hipStream_t st) {
+  PCA_REQUIRE(X && w && b && Y && mean && rstd && d > 0, "layernorm_fwd: bad arguments");
+  if (rows == 0) return PCA_OK;
+  hipLaunchKernelGGL(k_layernorm_fwd, dim3((unsigned)cdiv(rows, 4)), dim3(256), 0, st, X, w, b, Y,
+                     mean, rstd, rows, d, 1.0e-5f);
+  return check_launch("k_layernorm_fwd");
+}
+
+int layernorm_bwd(const float* dY, const float* X, const float* mean, const float* rstd,
+                  const float* w, float* dX, float* dw, float* db, int64_t rows, int d,
+                  hipStream_t st) {
+  PCA_REQUIRE(dY && X && mean && rstd && w && dX && dw && db && d > 0,
+              "layernorm_bwd: bad arguments");
+  if (rows == 0) return PCA_OK;
+  hipLaunchKernelGGL(k_layernorm_bwd, dim3((unsigned)cdiv(rows, 64)), dim3(256),
+                     2 * (size_t)d * sizeof(float), st, dY, X, mean, rstd, w, dX, dw, db, rows, d);
+  return check_launch("k_layernorm_bwd");
 }
 
 int fill_zero(float* dst, int64_t n, hipStream_t st) {

@@ -31,6 +31,8 @@ inline int gemm_sel(const pca_gemm_desc& g, const float* A, const float* B, cons
 
 struct SavedF32 {
   float *Qp, *Kp, *Vp, *A, *O, *Z;
+  // ln = 1 only: O1 = ln0(O), Ypre = O1 + relu(Z) (the input of ln1), row statistics
+  float *O1, *Ypre, *mean0, *rstd0, *mean1, *rstd1;
 };
 
 inline size_t saved_elems(const pca_mab_shape& s, SavedF32* out, void* base) {
@@ -43,12 +45,23 @@ inline size_t saved_elems(const pca_mab_shape& s, SavedF32* out, void* base) {
   v.A = c.take<float>((size_t)s.B * s.h * s.nq * s.nk);
   v.O = c.take<float>((size_t)s.B * s.nq * s.d);
   v.Z = c.take<float>((size_t)s.B * s.nq * s.d);
+  v.O1 = v.Ypre = v.mean0 = v.rstd0 = v.mean1 = v.rstd1 = nullptr;
+  if (s.ln) {
+    const size_t Mq = (size_t)s.B * s.nq;
+    v.O1 = c.take<float>(Mq * s.d);
+    v.Ypre = c.take<float>(Mq * s.d);
+    v.mean0 = c.take<float>(Mq);
+    v.rstd0 = c.take<float>(Mq);
+    v.mean1 = c.take<float>(Mq);
+    v.rstd1 = c.take<float>(Mq);
+  }
   if (out) *out = v;
   return c.off;
 }
 
 struct BwdWsF32 {
   float *dZ, *dO, *dQp, *dA, *dKp, *dVp, *dQps;
+  float* dYp;       // ln = 1: gradient w.r.t. the input of ln1
 };
 
 inline size_t bwd_ws_elems(const pca_mab_shape& s, BwdWsF32* out, void* base) {
@@ -61,6 +74,7 @@ inline size_t bwd_ws_elems(const pca_mab_shape& s, BwdWsF32* out, void* base) {
   v.dKp = c.take<float>((size_t)s.B * s.nk * s.d);
   v.dVp = c.take<float>((size_t)s.B * s.nk * s.d);
   v.dQps = c.take<float>((size_t)s.nq * s.d);
+  v.dYp = s.ln ? c.take<float>((size_t)s.B * s.nq * s.d) : nullptr;
   if (out) *out = v;
   return c.off;
 }
@@ -151,8 +165,20 @@ int mab_f32_fwd(const pca_mab_shape& s, const float* Q, const float* K,
               (int64_t)nq * d, dh);
     PCA_TRY(gemm_sel(g, v.A, v.Vp, nullptr, v.O, st));
   }
-  PCA_TRY(linear(v.O, p.wo, p.bo, v.Z, (int64_t)s.B * nq, d, d, 0, st));    // :31
-  PCA_TRY(add_relu(v.O, v.Z, Y, (int64_t)s.B * nq * d, st));                // :31
+  const int64_t Mq = (int64_t)s.B * nq;
+  const float* Oe = v.O;
+  if (s.ln) {                                                               // :30
+    PCA_REQUIRE(p.ln0_w && p.ln0_b && p.ln1_w && p.ln1_b, "mab: ln = 1 without LayerNorm parameters");
+    PCA_TRY(layernorm_fwd(v.O, p.ln0_w, p.ln0_b, v.O1, v.mean0, v.rstd0, Mq, d, st));
+    Oe = v.O1;
+  }
+  PCA_TRY(linear(Oe, p.wo, p.bo, v.Z, Mq, d, d, 0, st));                    // :31
+  if (s.ln) {
+    PCA_TRY(add_relu(Oe, v.Z, v.Ypre, Mq * d, st));                         // :31
+    PCA_TRY(layernorm_fwd(v.Ypre, p.ln1_w, p.ln1_b, Y, v.mean1, v.rstd1, Mq, d, st));   // :32
+  } else {
+    PCA_TRY(add_relu(Oe, v.Z, Y, Mq * d, st));                              // :31
+  }
   return PCA_OK;
 }
 
@@ -170,12 +196,22 @@ int mab_f32_bwd(const pca_mab_shape& s, const float* Q, const float* K,
   const int64_t qb = s.q_shared ? 0 : (int64_t)nq * d;
   const float scale = 1.0f / sqrtf((float)d);
 
-  // O + relu(fc_o(O))
-  PCA_TRY(relu_bwd(dY, v.Z, w.dZ, Mq * d, st));
-  PCA_TRY(linear_dw(w.dZ, v.O, g.wo, Mq, d, d, st));
+  // ln1, then O + relu(fc_o(O)), then ln0 (modules.py:30-32 backwards)
+  const float* dYe = dY;
+  const float* Oe = v.O;
+  if (s.ln) {
+    PCA_REQUIRE(g.ln0_w && g.ln0_b && g.ln1_w && g.ln1_b, "mab: ln = 1 without LayerNorm gradients");
+    PCA_TRY(layernorm_bwd(dY, v.Ypre, v.mean1, v.rstd1, p.ln1_w, w.dYp, g.ln1_w, g.ln1_b, Mq, d, st));
+    dYe = w.dYp;
+    Oe = v.O1;
+  }
+  PCA_TRY(relu_bwd(dYe, v.Z, w.dZ, Mq * d, st));
+  PCA_TRY(linear_dw(w.dZ, Oe, g.wo, Mq, d, d, st));
   PCA_TRY(colsum(w.dZ, Mq, d, g.bo, 1, st));
-  PCA_TRY(copy_rows(dY, Mq, w.dO, Mq, d, st));
+  PCA_TRY(copy_rows(dYe, Mq, w.dO, Mq, d, st));
   PCA_TRY(linear_dx(w.dZ, p.wo, w.dO, Mq, d, d, 1, st));
+  if (s.ln)     // in place: every element is read before it is rewritten
+    PCA_TRY(layernorm_bwd(w.dO, v.O, v.mean0, v.rstd0, p.ln0_w, w.dO, g.ln0_w, g.ln0_b, Mq, d, st));
 
   // attention: dV_j = A_j^T dO_j
   PCA_TRY(fill_zero(w.dVp, Mk * d, st));

@@ -82,6 +82,11 @@ int gemm_bf16(const pca_gemm_desc& g, const float* A, const float* B, const floa
               float* C, hipStream_t st);
 int softmax_rows(float* X, int64_t rows, int n, float scale, hipStream_t st,
                  const int32_t* lengths = nullptr, int64_t rows_per_set = 0);
+int layernorm_fwd(const float* X, const float* w, const float* b, float* Y, float* mean,
+                  float* rstd, int64_t rows, int d, hipStream_t st);
+int layernorm_bwd(const float* dY, const float* X, const float* mean, const float* rstd,
+                  const float* w, float* dX, float* dw, float* db, int64_t rows, int d,
+                  hipStream_t st);
 int softmax_bwd_rows(const float* A, float* dA, int64_t rows, int n, float scale,
                      hipStream_t st);
 int colsum(const float* X, int64_t rows, int cols, float* out, int accumulate,

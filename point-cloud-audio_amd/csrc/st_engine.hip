@@ -60,11 +60,13 @@ inline Layout layout(const pca_st_config& c) {
 
 inline pca_mab_params params_at(const float* base, const MabOff& m) {
   return pca_mab_params{base + m.wq, base + m.bq, base + m.wk, base + m.bk,
-                        base + m.wv, base + m.bv, base + m.wo, base + m.bo};
+                        base + m.wv, base + m.bv, base + m.wo, base + m.bo,
+                        nullptr, nullptr, nullptr, nullptr};
 }
 inline pca_mab_grads grads_at(float* base, const MabOff& m) {
   return pca_mab_grads{base + m.wq, base + m.bq, base + m.wk, base + m.bk,
-                       base + m.wv, base + m.bv, base + m.wo, base + m.bo};
+                       base + m.wv, base + m.bv, base + m.wo, base + m.bo,
+                       nullptr, nullptr, nullptr, nullptr};
 }
 
 inline pca_mab_shape shape(const pca_st_config& c, int nq, int nk, int dq, int dk,

@@ -8,8 +8,9 @@ PyTorch ops or to the CPU.
 
 Differences a caller can observe:
   * tensors must live on a HIP device ('cuda'); a CPU tensor raises PcaHipError;
-  * ``ln=True`` (never enabled by any reference caller, Code/models.py:31) raises
-    NotImplementedError at construction;
+  * ``ln=True`` (never enabled by any reference caller, Code/models.py:31) is supported
+    through the exact strided-GEMM chain (no fused kernels), with the reference's
+    ``ln0`` / ``ln1`` sub-modules and state_dict keys;
   * an optional ``lengths`` / ``key_lengths`` argument (int[B]) marks padded batches of
     variable-size sets: points at and beyond ``lengths[b]`` are ignored exactly as if set b
     had been truncated (the reference has dense batches only, so this is an extension);
@@ -29,10 +30,6 @@ class MAB(nn.Module):
 
     def __init__(self, dim_Q, dim_K, dim_V, num_heads, ln=False):
         super().__init__()
-        if ln:
-            raise NotImplementedError(
-                "MAB(ln=True): LayerNorm variants are not built in the HIP path "
-                "(no caller in the reference enables them)")
         if dim_V % num_heads != 0:
             raise ValueError(f"dim_V={dim_V} must be divisible by num_heads={num_heads}")
         self.dim_V = dim_V
@@ -40,19 +37,30 @@ class MAB(nn.Module):
         self.fc_q = nn.Linear(dim_Q, dim_V)
         self.fc_k = nn.Linear(dim_K, dim_V)
         self.fc_v = nn.Linear(dim_K, dim_V)
+        if ln:      # registration order of the reference (modules.py:14-17): before fc_o
+            self.ln0 = nn.LayerNorm(dim_V)
+            self.ln1 = nn.LayerNorm(dim_V)
         self.fc_o = nn.Linear(dim_V, dim_V)
 
     def _params(self):
         return (self.fc_q.weight, self.fc_q.bias, self.fc_k.weight, self.fc_k.bias,
                 self.fc_v.weight, self.fc_v.bias, self.fc_o.weight, self.fc_o.bias)
 
+    def _ln_params(self):
+        ln0 = getattr(self, "ln0", None)          # the reference probes them the same way
+        if ln0 is None:
+            return None
+        return (ln0.weight, ln0.bias, self.ln1.weight, self.ln1.bias)
+
     def forward(self, Q, K, q_shared=False, key_lengths=None):
         """Q [B,nq,dim_Q] (or the shared learned query [1,nq,dim_Q] with q_shared),
         K [B,nk,dim_K] -> [B,nq,dim_V].  key_lengths int[B]: valid keys per set."""
         if torch.is_grad_enabled() and (
                 Q.requires_grad or K.requires_grad or self.fc_q.weight.requires_grad):
-            return pca_hip.mab(Q, K, *self._params(), self.num_heads, q_shared, key_lengths)
-        return pca_hip.mab_infer(Q, K, self._params(), self.num_heads, q_shared, key_lengths)
+            return pca_hip.mab(Q, K, *self._params(), self.num_heads, q_shared, key_lengths,
+                               self._ln_params())
+        return pca_hip.mab_infer(Q, K, self._params(), self.num_heads, q_shared, key_lengths,
+                                 self._ln_params())
 
 
 class SAB(nn.Module):

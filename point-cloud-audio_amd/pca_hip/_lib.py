@@ -24,15 +24,17 @@ c_i64p = C.c_void_p
 class MabShape(C.Structure):
     _fields_ = [(n, C.c_int32) for n in
                 ("B", "nq", "nk", "dq", "dk", "d", "h", "q_shared", "mode",
-                 "q_dtype", "k_dtype", "y_dtype")] + [("k_lengths", C.c_void_p)]
+                 "q_dtype", "k_dtype", "y_dtype")] + [("k_lengths", C.c_void_p), ("ln", C.c_int32)]
 
 
 class MabParams(C.Structure):
-    _fields_ = [(n, C.c_void_p) for n in ("wq", "bq", "wk", "bk", "wv", "bv", "wo", "bo")]
+    _fields_ = [(n, C.c_void_p) for n in ("wq", "bq", "wk", "bk", "wv", "bv", "wo", "bo",
+                                          "ln0_w", "ln0_b", "ln1_w", "ln1_b")]
 
 
 class MabGrads(C.Structure):
-    _fields_ = [(n, C.c_void_p) for n in ("wq", "bq", "wk", "bk", "wv", "bv", "wo", "bo")]
+    _fields_ = [(n, C.c_void_p) for n in ("wq", "bq", "wk", "bk", "wv", "bv", "wo", "bo",
+                                          "ln0_w", "ln0_b", "ln1_w", "ln1_b")]
 
 
 class StConfig(C.Structure):

@@ -57,9 +57,11 @@ def _bytes(n: int, like: torch.Tensor) -> torch.Tensor:
     return torch.empty(max(int(n), 256), dtype=torch.uint8, device=like.device)
 
 
-def _shape(B, nq, nk, dq, dk, d, h, q_shared, mode=_lib.MODE_F32, k_lengths=None) -> MabShape:
+def _shape(B, nq, nk, dq, dk, d, h, q_shared, mode=_lib.MODE_F32, k_lengths=None,
+           ln: bool = False) -> MabShape:
     return MabShape(B, nq, nk, dq, dk, d, h, int(q_shared), mode, _lib.PCA_F32,
-                    _lib.PCA_F32, _lib.PCA_F32, 0 if k_lengths is None else k_lengths.data_ptr())
+                    _lib.PCA_F32, _lib.PCA_F32, 0 if k_lengths is None else k_lengths.data_ptr(),
+                    int(ln))
 
 
 def _lengths(key_lengths, B: int, like: torch.Tensor):
@@ -88,10 +90,13 @@ class _MabFn(torch.autograd.Function):
 
     @staticmethod
     def forward(ctx, Q, K, wq, bq, wk, bk, wv, bv, wo, bo, num_heads: int, q_shared: bool,
-                key_lengths=None):
+                key_lengths=None, ln0w=None, ln0b=None, ln1w=None, ln1b=None):
         _need_cuda(Q, K, wq)
         Q, K = _f32c(Q), _f32c(K)
         params = [_f32c(p) for p in (wq, bq, wk, bk, wv, bv, wo, bo)]
+        ln = ln0w is not None
+        if ln:
+            params += [_f32c(p) for p in (ln0w, ln0b, ln1w, ln1b)]
         B, nk, dk = K.shape
         if q_shared:
             nq, dq = Q.shape[-2], Q.shape[-1]
@@ -103,8 +108,9 @@ class _MabFn(torch.autograd.Function):
         if params[0].shape[1] != dq or params[2].shape[1] != dk:
             raise RuntimeError("MAB: input width does not match fc_q / fc_k")
         kl = _lengths(key_lengths, B, K)
-        s = _pick_mode(_shape(B, nq, nk, dq, dk, d, num_heads, q_shared, k_lengths=kl))
+        s = _pick_mode(_shape(B, nq, nk, dq, dk, d, num_heads, q_shared, k_lengths=kl, ln=ln))
         ctx.kl = kl                       # keeps the device array alive for the backward
+        ctx.ln = ln
         L = lib()
         with torch.cuda.device(K.device):
             Y = torch.empty((B, nq, d), dtype=torch.float32, device=K.device)
@@ -113,7 +119,7 @@ class _MabFn(torch.autograd.Function):
                 raise _lib.PcaHipError("pca_mab_saved_bytes: " + L.pca_last_error().decode())
             saved = _bytes(nsaved, K)
             ws = _bytes(L.pca_mab_fwd_ws_bytes(C.byref(s)), K)
-            pp = MabParams(*[_ptr(p) for p in params])
+            pp = MabParams(*[_ptr(p) for p in params])      # (ln pointers stay NULL without ln)
             check(L.pca_mab_fwd(C.byref(s), _ptr(Q), _ptr(K), C.byref(pp), _ptr(Y),
                                 _ptr(saved), _ptr(ws), _stream(K)), "pca_mab_fwd")
         ctx.s = s
@@ -143,26 +149,34 @@ class _MabFn(torch.autograd.Function):
                                 _ptr(dY), _ptr(dQ), _ptr(dK), 0, C.byref(gg), _ptr(ws),
                                 _stream(K)), "pca_mab_bwd")
         grads = [g.view_as(p) for g, p in zip(gviews, params)]
-        return (dQ, dK, *grads, None, None, None)
+        if ctx.ln:
+            return (dQ, dK, *grads[:8], None, None, None, *grads[8:])
+        return (dQ, dK, *grads, None, None, None, None, None, None, None)
 
 
 def mab(Q, K, wq, bq, wk, bk, wv, bv, wo, bo, num_heads: int, q_shared: bool = False,
-        key_lengths=None):
-    """key_lengths (optional, int[B]): valid keys per set of a padded batch."""
-    return _MabFn.apply(Q, K, wq, bq, wk, bk, wv, bv, wo, bo, num_heads, q_shared, key_lengths)
+        key_lengths=None, ln_params=None):
+    """key_lengths (optional, int[B]): valid keys per set of a padded batch.
+    ln_params (optional): (ln0.weight, ln0.bias, ln1.weight, ln1.bias) of MAB(ln=True)."""
+    extra = tuple(ln_params) if ln_params is not None else (None, None, None, None)
+    return _MabFn.apply(Q, K, wq, bq, wk, bk, wv, bv, wo, bo, num_heads, q_shared, key_lengths,
+                        *extra)
 
 
 def mab_infer(Q, K, params, num_heads: int, q_shared: bool = False,
-              key_lengths=None) -> torch.Tensor:
+              key_lengths=None, ln_params=None) -> torch.Tensor:
     """Forward only, nothing saved (used under torch.no_grad())."""
     _need_cuda(Q, K)
     Q, K = _f32c(Q), _f32c(K)
     params = [_f32c(p) for p in params]
+    ln = ln_params is not None
+    if ln:
+        params += [_f32c(p) for p in ln_params]
     B, nk, dk = K.shape
     nq, dq = Q.shape[-2], Q.shape[-1]
     d = params[0].shape[0]
     kl = _lengths(key_lengths, B, K)
-    s = _pick_mode(_shape(B, nq, nk, dq, dk, d, num_heads, q_shared, k_lengths=kl))
+    s = _pick_mode(_shape(B, nq, nk, dq, dk, d, num_heads, q_shared, k_lengths=kl, ln=ln))
     L = lib()
     with torch.cuda.device(K.device):
         Y = torch.empty((B, nq, d), dtype=torch.float32, device=K.device)

@@ -34,6 +34,9 @@ from .ops import _need_cuda
 def st_config(model, B: int, N: int, mode: int = _lib.MODE_F32) -> StConfig:
     """Read the architecture off an ``models.ST`` instance."""
     isab0 = model.enc[0]
+    if getattr(isab0.mab0, "ln0", None) is not None:
+        raise _lib.PcaHipError("the whole-model engine covers ST(ln=False) (45 tensors); a model "
+                               "with LayerNorms runs through the nn.Module path")
     d = isab0.mab0.dim_V
     return StConfig(B, N, isab0.mab1.fc_q.in_features, d, isab0.mab0.num_heads,
                     isab0.I.shape[1], model.dec[0].S.shape[1],

@@ -133,3 +133,14 @@ def ss_inputs(F: int = 512, Nt: int = 10, S: int = 3, seed: int = 8080):
     farr = (np.linspace(0, 44100 / 2, F + 1) / 44100)[:F]
     tarr = np.linspace(0, ((0.5 * 1024) / 44100) * Nt, Nt)
     return x, y, farr, tarr
+
+
+# --------------------------------------------------------------------------- #
+# LayerNorm variants (MAB(ln=True)): modules.py:14-16,30,32                      #
+# --------------------------------------------------------------------------- #
+LN_MAB_CASES = [    # name, B, nq, nk, dq, dk, d, h
+    ("ln_tiny", 2, 5, 7, 3, 2, 8, 2),
+    ("ln_mab0", 3, 16, 33, 128, 128, 128, 4),
+    ("ln_mab1", 2, 51, 4, 2, 64, 64, 8),
+]
+LN_ST_CASE = ("ln_st", 3, 40, 2, 32, 4, 8, 10)     # name, B, N, din, d, h, m, C

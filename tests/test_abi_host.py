@@ -62,8 +62,11 @@ def test_module_surface_matches_reference():
                .parameters()) == 80202
     for name in ("MAB", "SAB", "ISAB", "PMA"):
         assert hasattr(modules, name)
-    with pytest.raises(NotImplementedError):
-        modules.MAB(4, 4, 4, 2, ln=True)
+    # MAB(ln=True): the reference's sub-modules and registration order (modules.py:14-17)
+    lnm = modules.MAB(4, 4, 4, 2, ln=True)
+    assert list(lnm.state_dict().keys()) == [
+        "fc_q.weight", "fc_q.bias", "fc_k.weight", "fc_k.bias", "fc_v.weight", "fc_v.bias",
+        "ln0.weight", "ln0.bias", "ln1.weight", "ln1.bias", "fc_o.weight", "fc_o.bias"]
     # xavier bound of I: sqrt(6/(m*d+d))
     I = modules.ISAB(2, 64, 8, 64).I
     assert float(I.abs().max()) <= (6.0 / (64 * 64 + 64)) ** 0.5 + 1e-6
