@@ -65,20 +65,57 @@ __global__ __launch_bounds__(256) void k_mab0_prep(const Mab0PrepJobs jobs) {
     const int sp = q - a.m;
     if (sp >= PREP_SPARE || a.WvT == nullptr) return;
     const int nv = a.d * a.dk, no = a.d * a.d;
-    for (int o = sp * 256 + threadIdx.x; o < nv + no; o += PREP_SPARE * 256) {
-      if (o < nv) {
-        const int c = o / a.d, f = o - c * a.d;
-        a.WvT[o] = a.Wv[f * a.dk + c];
-      } else {
-        const int oo = o - nv;
-        const int c = oo / a.d, f = oo - c * a.d;
-        a.WoT[oo] = a.Wo[f * a.d + c];
+    // strided (uncoalesced) reads: keep 8 of them in flight per thread
+    for (int o0 = sp * 256 + threadIdx.x; o0 < nv + no; o0 += 8 * PREP_SPARE * 256) {
+      float v[8];
+#pragma unroll
+      for (int u = 0; u < 8; ++u) {
+        const int o = o0 + u * PREP_SPARE * 256;
+        v[u] = 0.f;
+        if (o < nv) {
+          const int c = o / a.d, f = o - c * a.d;
+          v[u] = a.Wv[f * a.dk + c];
+        } else if (o < nv + no) {
+          const int oo = o - nv;
+          const int c = oo / a.d, f = oo - c * a.d;
+          v[u] = a.Wo[f * a.d + c];
+        }
+      }
+#pragma unroll
+      for (int u = 0; u < 8; ++u) {
+        const int o = o0 + u * PREP_SPARE * 256;
+        if (o < nv) a.WvT[o] = v[u];
+        else if (o < nv + no) a.WoT[o - nv] = v[u];
       }
     }
     return;
   }
   const int m = a.m, d = a.d, dq = a.dq, dk = a.dk, h = a.h;
   const int R = h * m;
+  if (d <= 128 && dq % 32 == 0) {
+    // both halves of the workgroup work on the d outputs: half kh takes half of the
+    // contraction (the dot products are chains of dependent L2 round trips)
+    __shared__ float part[128];
+    const int f = threadIdx.x & 127, kh = threadIdx.x >> 7;
+    float acc = 0.f;
+    if (f < d) {
+      const int c0 = kh * (dq / 2), c1 = c0 + dq / 2;
+      for (int c = c0; c < c1; c += 16) {
+        float wv[16];
+#pragma unroll
+        for (int u = 0; u < 16; ++u) wv[u] = a.Wq[f * dq + c + u];
+#pragma unroll
+        for (int u = 0; u < 16; ++u) acc = fmaf(a.I[q * dq + c + u], wv[u], acc);
+      }
+      if (kh == 1) part[f] = acc;
+    }
+    __syncthreads();
+    if (kh == 0 && f < d) {
+      acc += part[f] + a.bq[f];
+      sq[f] = acc;
+      a.Qp[q * d + f] = acc;
+    }
+  } else {
   for (int f = threadIdx.x; f < d; f += 256) {
     float acc = a.bq[f];
     int c = 0;
@@ -92,6 +129,7 @@ __global__ __launch_bounds__(256) void k_mab0_prep(const Mab0PrepJobs jobs) {
     for (; c < dq; ++c) acc += a.I[q * dq + c] * a.Wq[f * dq + c];
     sq[f] = acc;
     a.Qp[q * d + f] = acc;
+  }
   }
   __syncthreads();
   const int dh = d / h;
