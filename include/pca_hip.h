@@ -81,6 +81,24 @@ int pca_pack_points_2d(const float* spec, int64_t stride_f, int64_t stride_t,
                        float* out, const int64_t* labels, int64_t* labels_out,
                        void* stream);
 
+/* The same pack driven by a device-side cursor (no reference counterpart: the reference's
+ * DataLoader hands indices over on the host, Code/settransformer.py:71).  idx_seq holds the
+ * index batches of many steps back to back ([n_steps * B]); batch number step_dev[0] -
+ * base_dev[0] is packed.  With step_dev = the optimiser's device step count (pca_adam_step)
+ * a captured step replays with no per-step host -> device traffic at all; the host rewrites
+ * idx_seq and base_dev once per epoch. */
+int pca_pack_points_2d_seq(const float* spec, int64_t stride_f, int64_t stride_t,
+                           const float* farr, const int64_t* idx_seq, const int32_t* step_dev,
+                           const int32_t* base_dev, int B, int F, float* out,
+                           const int64_t* labels, int64_t* labels_out, void* stream);
+/* 3-D counterpart; nt_valid / lengths_out as in pca_pack_points_3d_var, or both NULL. */
+int pca_pack_points_3d_seq(const float* spec, int64_t stride_f, int64_t stride_t,
+                           int64_t stride_s, const float* farr, const float* tarr,
+                           const int32_t* nt_valid, const int64_t* idx_seq,
+                           const int32_t* step_dev, const int32_t* base_dev, int B, int F,
+                           int Nt, float* out, int32_t* lengths_out, const int64_t* labels,
+                           int64_t* labels_out, void* stream);
+
 /* 3-D point sets for a batch of frame chunks
  * replaces: Code/dataset.py:160-166  ESC_pc_temp.__getitem__ (+ default_collate)
  * spec element (f, t, s) at spec[f*stride_f + t*stride_t + s*stride_s];

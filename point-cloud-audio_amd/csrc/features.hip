@@ -86,8 +86,13 @@ __global__ __launch_bounds__(256) void k_pack_2d(const float* __restrict__ spec,
                                                   const int64_t* __restrict__ idx, int F,
                                                   float* __restrict__ out,
                                                   const int64_t* __restrict__ labels,
-                                                  int64_t* __restrict__ labels_out) {
+                                                  int64_t* __restrict__ labels_out,
+                                                  const int32_t* __restrict__ step_dev,
+                                                  const int32_t* __restrict__ base_dev) {
   const int b = blockIdx.y;
+  // device cursor: batch number (step - base) of a pre-staged index sequence, so that a
+  // captured step needs no per-step index upload
+  if (step_dev != nullptr) idx += (int64_t)(step_dev[0] - base_dev[0]) * gridDim.y;
   const int64_t frame = idx[b];
   if (labels != nullptr && labels_out != nullptr && blockIdx.x == 0 && threadIdx.x == 0)
     labels_out[b] = labels[frame];
@@ -109,8 +114,11 @@ __global__ __launch_bounds__(256) void k_pack_3d(const float* __restrict__ spec,
                                                   const int64_t* __restrict__ labels,
                                                   int64_t* __restrict__ labels_out,
                                                   const int32_t* __restrict__ nt_valid,
-                                                  int32_t* __restrict__ lengths_out) {
+                                                  int32_t* __restrict__ lengths_out,
+                                                  const int32_t* __restrict__ step_dev,
+                                                  const int32_t* __restrict__ base_dev) {
   const int b = blockIdx.y;
+  if (step_dev != nullptr) idx += (int64_t)(step_dev[0] - base_dev[0]) * gridDim.y;
   const int64_t chunk = idx[b];
   // variable-size sets: chunk s holds nt_valid[s] <= Nt frames; time-major point order makes
   // its points a prefix of the padded set, the padding rows are written as zeros
@@ -165,11 +173,20 @@ int pca_stft_logmag(const float* wave, int64_t L, int n_fft, int win_length, int
 int pca_pack_points_2d(const float* spec, int64_t stride_f, int64_t stride_t,
                        const float* farr, const int64_t* idx, int B, int F, float* out,
                        const int64_t* labels, int64_t* labels_out, void* stream) {
-  PCA_REQUIRE(spec && farr && idx && out, "pack_points_2d: null pointer");
+  return pca_pack_points_2d_seq(spec, stride_f, stride_t, farr, idx, nullptr, nullptr, B, F, out,
+                                labels, labels_out, stream);
+}
+
+int pca_pack_points_2d_seq(const float* spec, int64_t stride_f, int64_t stride_t,
+                           const float* farr, const int64_t* idx_seq, const int32_t* step_dev,
+                           const int32_t* base_dev, int B, int F, float* out,
+                           const int64_t* labels, int64_t* labels_out, void* stream) {
+  PCA_REQUIRE(spec && farr && idx_seq && out, "pack_points_2d: null pointer");
+  PCA_REQUIRE((step_dev == nullptr) == (base_dev == nullptr), "pack_points_2d: cursor needs both");
   PCA_REQUIRE(B > 0 && F > 0 && B <= 65535, "pack_points_2d: B=%d F=%d", B, F);
   hipLaunchKernelGGL(pca::k_pack_2d, dim3((unsigned)pca::cdiv(F, 256), (unsigned)B),
                      dim3(256), 0, pca::as_stream(stream), spec, stride_f, stride_t, farr,
-                     idx, F, out, labels, labels_out);
+                     idx_seq, F, out, labels, labels_out, step_dev, base_dev);
   return pca::check_launch("k_pack_2d");
 }
 
@@ -183,7 +200,28 @@ int pca_pack_points_3d(const float* spec, int64_t stride_f, int64_t stride_t,
   hipLaunchKernelGGL(pca::k_pack_3d,
                      dim3((unsigned)pca::cdiv((int64_t)F * Nt, 256), (unsigned)B), dim3(256),
                      0, pca::as_stream(stream), spec, stride_f, stride_t, stride_s, farr,
-                     tarr, idx, F, Nt, out, labels, labels_out, nullptr, nullptr);
+                     tarr, idx, F, Nt, out, labels, labels_out, nullptr, nullptr, nullptr,
+                     nullptr);
+  return pca::check_launch("k_pack_3d");
+}
+
+int pca_pack_points_3d_seq(const float* spec, int64_t stride_f, int64_t stride_t,
+                           int64_t stride_s, const float* farr, const float* tarr,
+                           const int32_t* nt_valid, const int64_t* idx_seq,
+                           const int32_t* step_dev, const int32_t* base_dev, int B, int F,
+                           int Nt, float* out, int32_t* lengths_out, const int64_t* labels,
+                           int64_t* labels_out, void* stream) {
+  PCA_REQUIRE(spec && farr && tarr && idx_seq && out && step_dev && base_dev,
+              "pack_points_3d_seq: null pointer");
+  PCA_REQUIRE((nt_valid == nullptr) == (lengths_out == nullptr),
+              "pack_points_3d_seq: nt_valid and lengths_out go together");
+  PCA_REQUIRE(B > 0 && F > 0 && Nt > 0 && B <= 65535, "pack_points_3d_seq: B=%d F=%d Nt=%d", B,
+              F, Nt);
+  hipLaunchKernelGGL(pca::k_pack_3d,
+                     dim3((unsigned)pca::cdiv((int64_t)F * Nt, 256), (unsigned)B), dim3(256),
+                     0, pca::as_stream(stream), spec, stride_f, stride_t, stride_s, farr,
+                     tarr, idx_seq, F, Nt, out, labels, labels_out, nt_valid, lengths_out,
+                     step_dev, base_dev);
   return pca::check_launch("k_pack_3d");
 }
 
@@ -199,7 +237,8 @@ int pca_pack_points_3d_var(const float* spec, int64_t stride_f, int64_t stride_t
   hipLaunchKernelGGL(pca::k_pack_3d,
                      dim3((unsigned)pca::cdiv((int64_t)F * Nt, 256), (unsigned)B), dim3(256),
                      0, pca::as_stream(stream), spec, stride_f, stride_t, stride_s, farr,
-                     tarr, idx, F, Nt, out, labels, labels_out, nt_valid, lengths_out);
+                     tarr, idx, F, Nt, out, labels, labels_out, nt_valid, lengths_out, nullptr,
+                     nullptr);
   return pca::check_launch("k_pack_3d");
 }
 }

@@ -76,6 +76,13 @@ class ESC_pc(Dataset):
         return pca_hip.pack_points_2d(spec_tf, f32, idx, lab, frame_major=True, out=out,
                                       labels_out=labels_out)
 
+    def batch_seq(self, idx_seq, step_dev, base_dev, B: int, out=None, labels_out=None):
+        """Batch number ``step_dev[0] - base_dev[0]`` of a pre-staged index sequence (the
+        Trainer's device cursor: no per-step index upload)."""
+        spec_tf, f32, lab = self._resident()
+        return pca_hip.pack_points_2d_seq(spec_tf, f32, idx_seq, step_dev, base_dev, B, lab,
+                                          frame_major=True, out=out, labels_out=labels_out)
+
     def __getitem__(self, idx):
         spec_tf, _, _ = self._resident()
         i = torch.tensor([int(idx)], dtype=torch.int64, device=spec_tf.device)
@@ -150,6 +157,20 @@ class ESC_pc_temp(Dataset):
         return pca_hip.pack_points_3d(spec, f32, t32, idx, lab, out=out, labels_out=labels_out,
                                       nt_valid=self._ntv, lengths_out=lengths_out)
 
+    def batch_seq(self, idx_seq, step_dev, base_dev, B: int, out=None, labels_out=None,
+                  lengths_out=None):
+        """Batch number ``step_dev[0] - base_dev[0]`` of a pre-staged index sequence."""
+        spec, f32, t32, lab = self._resident()
+        ntv = None
+        if self.nt_valid is not None:
+            if self._ntv is None:
+                self._ntv = torch.as_tensor(np.asarray(self.nt_valid)).to(spec.device,
+                                                                          torch.int32)
+            ntv = self._ntv
+        return pca_hip.pack_points_3d_seq(spec, f32, t32, idx_seq, step_dev, base_dev, B, lab,
+                                          out=out, labels_out=labels_out, nt_valid=ntv,
+                                          lengths_out=lengths_out)
+
     def __getitem__(self, idx):
         spec = self._resident()[0]
         i = torch.tensor([int(idx)], dtype=torch.int64, device=spec.device)
@@ -213,6 +234,8 @@ class _TempSS(ESC_pc_temp):
     @property
     def num_points(self) -> int:
         return self.K
+
+    batch_seq = None        # selections are drawn per call: the Trainer uploads indices per step
 
     def batch(self, idx: torch.Tensor, out=None, labels_out=None, want_sel: bool = False):
         spec, f32, t32, lab = self._resident()

@@ -448,3 +448,61 @@ def importance_points(spec: torch.Tensor, farr: torch.Tensor, tarr: torch.Tensor
     if want_heat:
         res.append(heat)
     return tuple(res)
+
+
+def pack_points_2d_seq(spec: torch.Tensor, farr: torch.Tensor, idx_seq: torch.Tensor,
+                       step_dev: torch.Tensor, base_dev: torch.Tensor, B: int,
+                       labels: Optional[torch.Tensor] = None, frame_major: bool = False,
+                       out: Optional[torch.Tensor] = None,
+                       labels_out: Optional[torch.Tensor] = None):
+    """pack_points_2d for batch number ``step_dev[0] - base_dev[0]`` of the pre-staged index
+    sequence ``idx_seq`` ([n_steps * B] int64 on the device): the cursor lives on the device, so
+    a captured step replays without any per-step index upload (pca_pack_points_2d_seq)."""
+    _need_cuda(spec, farr, idx_seq, step_dev, base_dev)
+    assert spec.dtype == torch.float32 and idx_seq.dtype == torch.int64
+    assert step_dev.dtype == torch.int32 and base_dev.dtype == torch.int32
+    if frame_major:
+        T_, F = spec.shape
+        sf, st = spec.stride(1), spec.stride(0)
+    else:
+        F, T_ = spec.shape
+        sf, st = spec.stride(0), spec.stride(1)
+    with torch.cuda.device(spec.device):
+        if out is None:
+            out = torch.empty((B, F, 2), dtype=torch.float32, device=spec.device)
+        if labels is not None and labels_out is None:
+            labels_out = torch.empty(B, dtype=torch.int64, device=spec.device)
+        check(lib().pca_pack_points_2d_seq(_ptr(spec), sf, st, _ptr(farr), _ptr(idx_seq),
+                                           _ptr(step_dev), _ptr(base_dev), B, F, _ptr(out),
+                                           _ptr(labels), _ptr(labels_out), _stream(spec)),
+              "pca_pack_points_2d_seq")
+    return out, labels_out
+
+
+def pack_points_3d_seq(spec: torch.Tensor, farr: torch.Tensor, tarr: torch.Tensor,
+                       idx_seq: torch.Tensor, step_dev: torch.Tensor, base_dev: torch.Tensor,
+                       B: int, labels: Optional[torch.Tensor] = None,
+                       out: Optional[torch.Tensor] = None,
+                       labels_out: Optional[torch.Tensor] = None,
+                       nt_valid: Optional[torch.Tensor] = None,
+                       lengths_out: Optional[torch.Tensor] = None):
+    """3-D counterpart of pack_points_2d_seq (pca_pack_points_3d_seq); with ``nt_valid`` the
+    batch is padded and the lengths are returned as a third value."""
+    _need_cuda(spec, farr, tarr, idx_seq, step_dev, base_dev)
+    assert spec.dtype == torch.float32 and idx_seq.dtype == torch.int64
+    F, Nt, S = spec.shape
+    with torch.cuda.device(spec.device):
+        if out is None:
+            out = torch.empty((B, F * Nt, 3), dtype=torch.float32, device=spec.device)
+        if labels is not None and labels_out is None:
+            labels_out = torch.empty(B, dtype=torch.int64, device=spec.device)
+        if nt_valid is not None and lengths_out is None:
+            lengths_out = torch.empty(B, dtype=torch.int32, device=spec.device)
+        check(lib().pca_pack_points_3d_seq(
+            _ptr(spec), spec.stride(0), spec.stride(1), spec.stride(2), _ptr(farr), _ptr(tarr),
+            _ptr(nt_valid), _ptr(idx_seq), _ptr(step_dev), _ptr(base_dev), B, F, Nt, _ptr(out),
+            _ptr(lengths_out if nt_valid is not None else None), _ptr(labels), _ptr(labels_out),
+            _stream(spec)), "pca_pack_points_3d_seq")
+    if nt_valid is not None:
+        return out, labels_out, lengths_out
+    return out, labels_out

@@ -102,6 +102,19 @@ class ShardedIndexStream:
         self._cursor += self.B
         return out
 
+    def steps_per_epoch(self) -> int:
+        return self.per_rank() // self.B
+
+    def next_epoch(self) -> torch.Tensor:
+        """All index batches of this rank's next epoch back to back ([steps_per_epoch * B]) -
+        the same sequence ``next()`` would hand out one batch at a time."""
+        spe = self.steps_per_epoch()
+        first = self.next()
+        # ``next`` has just started an epoch (it only does so with the cursor at 0)
+        assert self._cursor == self.B
+        self._cursor = spe * self.B
+        return torch.cat([first, self._perm[self.B:spe * self.B]]) if spe > 1 else first
+
 
 def allreduce_buckets(grads: torch.Tensor, split: int, group=None, first_stream=None):
     """Sum the flat gradient vector over the ranks in the two buckets of SURVEY.md 8e:
@@ -211,7 +224,13 @@ class Trainer:
             # padded batches of variable-size sets (dataset.variable_length): point counts
             self.lengths = (torch.zeros(self.B, dtype=torch.int32, device=self.dev)
                             if getattr(dataset, "variable_length", False) else None)
+            # device cursor: the epoch's index batches live in ``seq``; the pack kernel takes
+            # batch (step_count - epoch_base), so a step is a bare graph replay
+            self.epoch_base = torch.zeros(1, dtype=torch.int32, device=self.dev)
+            self.seq = None
             self.comm_stream = torch.cuda.Stream(self.dev) if self.world > 1 else None
+        self._cursor_mode = callable(getattr(dataset, "batch_seq", None))
+        self._k = 0                       # optimiser steps issued so far (host copy)
         self.g0 = self.g1 = self.g2 = None
         self.indices = ShardedIndexStream(len(dataset), self.B, self.rank, self.world, seed,
                                           shuffle, self.dev)
@@ -224,7 +243,11 @@ class Trainer:
 
     # ---- the three device segments of a step ---------------------------------------
     def _seg0(self):     # pack + zero grads + forward + loss + backward(dec, enc.1)
-        if self.lengths is not None:
+        if self._cursor_mode:
+            kw = dict(lengths_out=self.lengths) if self.lengths is not None else {}
+            self.ds.batch_seq(self.seq, self.step_count, self.epoch_base, self.B, out=self.X,
+                              labels_out=self.labels, **kw)
+        elif self.lengths is not None:
             self.ds.batch(self.idx, out=self.X, labels_out=self.labels,
                           lengths_out=self.lengths)
         else:
@@ -282,7 +305,17 @@ class Trainer:
 
     def step(self) -> None:
         """One optimiser step; enqueues only (no host sync)."""
-        self.idx.copy_(self._next_indices(), non_blocking=True)
+        if self._cursor_mode:
+            spe = self.indices.steps_per_epoch()
+            if self._k % spe == 0:        # once per epoch: stage its index batches
+                ep = self.indices.next_epoch()
+                if self.seq is None:
+                    self.seq = torch.empty(spe * self.B, dtype=torch.int64, device=self.dev)
+                self.seq.copy_(ep, non_blocking=True)
+                self.epoch_base.fill_(self._k)
+            self._k += 1
+        else:
+            self.idx.copy_(self._next_indices(), non_blocking=True)
         if self.use_graph and self.g0 is None:
             self._capture()
         main = torch.cuda.current_stream(self.dev)

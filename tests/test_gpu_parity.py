@@ -474,3 +474,41 @@ def test_reframe_sweep(dev, golden_ckpt, tmp_path):
     d = evalsweep.framewise_dataset(clips, labels, fs, int(0.6 * Nfft))
     assert d.num_points == 1 + 2048 // 2
     assert len(d) == sum(1 + len(w) // int(0.6 * Nfft * 0.5) for w in waves)
+
+
+@pytest.mark.parametrize("graph", [False, True], ids=["eager", "hipgraph"])
+def test_device_cursor_equals_per_step_indices(dev, graph):
+    """The device-side batch cursor (index batches of an epoch staged once, pack kernel picks
+    batch step_count - epoch_base) against the per-step index upload, across three epoch
+    boundaries, 2-D and padded 3-D datasets."""
+    import dataset
+    import models
+    from pca_hip import trainer
+    rng = np.random.Generator(np.random.PCG64(31))
+    F, T_, C, B = 24, 83, 5, 16                       # 5 steps per epoch, ragged tail dropped
+    x = rng.normal(-9, 3, size=(F, T_)).astype(np.float32)
+    y = rng.integers(0, C, size=T_)
+    Ft, Nt, S = 8, 3, 70
+    x3 = rng.normal(-9, 3, size=(Ft, Nt, S)).astype(np.float32)
+    y3 = rng.integers(0, C, size=S)
+    ntv = rng.integers(1, Nt + 1, size=S).astype(np.int32)
+
+    def run(ds, din, cursor):
+        torch.manual_seed(4)
+        net = models.ST(dim_input=din, num_outputs=1, dim_output=C, num_inds=4, dim_hidden=16,
+                        num_heads=4).to(dev)
+        tr = trainer.Trainer(net, ds, B, use_graph=graph, seed=2, shuffle=True)
+        assert tr._cursor_mode
+        tr._cursor_mode = cursor
+        for _ in range(17):
+            tr.step()
+        torch.cuda.synchronize()
+        return tr.eng.flat.clone(), tr.read_stats()
+
+    for ds, din in ((dataset.ESC_pc(x, y, np.linspace(0, 0.5, F), device=dev), 2),
+                    (dataset.ESC_pc_temp(x3, y3, np.linspace(0, 0.5, Ft), np.linspace(0, 0.1, Nt),
+                                         device=dev, nt_valid=ntv), 3)):
+        a, sa = run(ds, din, True)
+        b, sb = run(ds, din, False)
+        close(a, b, 1e-5, "cursor vs uploaded indices")
+        assert abs(sa[0] - sb[0]) < 1e-3 * abs(sb[0]) and sa[1] == sb[1]
