@@ -528,7 +528,8 @@ int mab1_bf16_fwd_ex(const pca_mab_shape& s, const void* X, const float* H,
   Mab1FwdArgs a{};
   a.X = X; a.WqB = WqB; a.WqF = p.wq; a.bq = p.bq; a.KpP = v.KpP; a.Vt = v.Vt; a.WoP = WoP;
   a.bo = p.bo; a.Y = Y;
-  a.QpS = training ? v.QpS : nullptr;
+  // layer 1 (dq <= 3, m = 16): the backward recomputes Qp from the points - nothing to save
+  a.QpS = (training && !(small && s.nk == 16 && s.dq <= 3)) ? v.QpS : nullptr;
   a.OS = training ? v.OS : nullptr;
   a.mask = training ? v.mask : nullptr;
   a.B = s.B; a.N = s.nq; a.dq = s.dq;

@@ -40,6 +40,8 @@ struct Mab1BwdArgs {
   float *dKpG, *dVpG;       // [B][nparts][MI][D] fp32 partial K/V gradients (fused mode)
   const float* Xs;          // layer 1 (dq <= 3): the fp32 points [B, N, dq] ...
   float *dWqS, *dbqS;       // ... and fc_q gradients accumulated here (fused reduction)
+  const float *WqF, *bqF;   // ... and fc_q itself: Qp is recomputed (2..3 FMAs per element)
+                            //     instead of being saved by the forward and read back
   int dq;
   float* zero_ptr;          // optional: zero_n floats cleared by this launch (consumer's
   int zero_n;               //           accumulator, e.g. the dQs of k_mid_bwd)
@@ -119,6 +121,13 @@ void k_mab1_bwd(const Mab1BwdArgs a) {
   // (SQ_LDS_BANK_CONFLICT was 3x the LDS-active cycles of this kernel); 10 / 18 banks per row
   // spread them over all 64
   constexpr int PS = 40, PQ = 72, KVB = 2 * 32 * PS + 2 * 32 * PQ;
+  // layer 1: fc_q rows as float4 (w0, w1, w2, bias) behind the per-wave images
+  float4* sWq4 = reinterpret_cast<float4*>(sKV + NW * KVB);
+  if (FUSE_WQ) {
+    for (int f = tid; f < D; f += NT)
+      sWq4[f] = float4{a.WqF[f * a.dq], a.dq > 1 ? a.WqF[f * a.dq + 1] : 0.f,
+                       a.dq > 2 ? a.WqF[f * a.dq + 2] : 0.f, a.bqF[f]};
+  }
   char* myDS = sKV + wave8 * KVB;
   char* myP = myDS + 32 * PS;
   char* myQ = myP + 32 * PS;
@@ -183,6 +192,13 @@ void k_mab1_bwd(const Mab1BwdArgs a) {
       row[nb] = (int64_t)b * a.N + (live[nb] ? nn[nb] : 0);
     }
 
+    float xq[NB][3];                 // layer 1: this lane's points, for the Qp recomputation
+    if (FUSE_WQ) {
+#pragma unroll
+      for (int nb = 0; nb < NB; ++nb)
+#pragma unroll
+        for (int c = 0; c < 3; ++c) xq[nb][c] = c < a.dq ? a.Xs[row[nb] * a.dq + c] : 0.f;
+    }
     bf16x8 xaug;
     if (FUSE_WQ) {
       // A operand: lane (row c' = r, k-slots 8g..8g+7 <-> points perm32(8g + .)) of this tile
@@ -264,10 +280,21 @@ void k_mab1_bwd(const Mab1BwdArgs a) {
 #pragma unroll
       for (int nb = 0; nb < NB; ++nb) {
         // saved Qp of this point, features 32j + perm32(8g + .)
-        const bf16x4 qlo =
-            *reinterpret_cast<const bf16x4*>(a.QpS + row[nb] * D + 32 * j + 4 * g);
-        const bf16x4 qhi =
-            *reinterpret_cast<const bf16x4*>(a.QpS + row[nb] * D + 32 * j + 16 + 4 * g);
+        bf16x4 qlo, qhi;
+        if (FUSE_WQ) {
+          // Qp = x Wq^T + bq exactly as the forward computes it (fp32, then rounded to bf16)
+#pragma unroll
+          for (int e = 0; e < 4; ++e) {
+            const float4 wl = sWq4[32 * j + 4 * g + e], wh = sWq4[32 * j + 16 + 4 * g + e];
+            qlo[e] = (__bf16)(wl.w + wl.x * xq[nb][0] + wl.y * xq[nb][1] + wl.z * xq[nb][2] +
+                              0.f * 0.f);
+            qhi[e] = (__bf16)(wh.w + wh.x * xq[nb][0] + wh.y * xq[nb][1] + wh.z * xq[nb][2] +
+                              0.f * 0.f);
+          }
+        } else {
+          qlo = *reinterpret_cast<const bf16x4*>(a.QpS + row[nb] * D + 32 * j + 4 * g);
+          qhi = *reinterpret_cast<const bf16x4*>(a.QpS + row[nb] * D + 32 * j + 16 + 4 * g);
+        }
         bf16x8 qb;
 #pragma unroll
         for (int e = 0; e < 4; ++e) { qb[e] = qlo[e]; qb[4 + e] = qhi[e]; }
@@ -792,7 +819,8 @@ template <int D, int MI, bool DX, bool FUSE, bool FWQ, bool ABF>
 int launch_bwd(const Mab1BwdArgs& a, hipStream_t st, double flops, double bytes) {
   constexpr int NW = BwdWaves<DX, FUSE>::value;
   size_t lds = (size_t)D * D * 2 + 2 * (size_t)MI * D * 2 + (size_t)D * MI * 2 +
-               (DX ? (size_t)D * D * 2 : 0) + (FUSE ? NW * (2 * 32 * 40 + 2 * 32 * 72) : 0);
+               (DX ? (size_t)D * D * 2 : 0) + (FUSE ? NW * (2 * 32 * 40 + 2 * 32 * 72) : 0) +
+               (FWQ ? (size_t)D * sizeof(float4) : 0);
   if (FUSE && lds < (size_t)2 * NW * MI * D * 4) lds = (size_t)2 * NW * MI * D * 4;   // flush buffer
   static std::once_flag once;
   std::call_once(once, [] {
@@ -939,6 +967,7 @@ int mab1_bf16_bwd_ex(const pca_mab_shape& s, const void* X, const float* H,
 #endif
     const bool fwq = small && s.dq <= 3;
     a.Xs = reinterpret_cast<const float*>(X); a.dWqS = gr.wq; a.dbqS = gr.bq; a.dq = s.dq;
+    a.WqF = p.wq; a.bqF = p.bq;
     if (abf)
       rc = want_dx ? launch_bwd<128, 16, true, true, false, true>(a, st, flops, bytes)
            : fwq   ? launch_bwd<128, 16, false, true, true, true>(a, st, flops, bytes)
