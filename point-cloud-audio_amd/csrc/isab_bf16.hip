@@ -90,7 +90,7 @@ int isab_bf16_bwd(const pca_mab_shape& s0, const pca_mab_shape& s1, const float*
                   const pca_mab_params& p1, const void* saved0, const void* saved1,
                   const void* dY, float* dI, void* dX, const pca_mab_grads& g0,
                   const pca_mab_grads& g1, void* ws, const IsabImg& im, hipStream_t st,
-                  Mab0PostJobs* defer) {
+                  BwdDefer* defer) {
   const int dk = s0.dk, m = 16;
   Carver c(ws);
   void* ws1 = c.take<char>(mab1_carve_bwd_ws(s1, nullptr, nullptr));
@@ -104,7 +104,7 @@ int isab_bf16_bwd(const pca_mab_shape& s0, const pca_mab_shape& s1, const float*
 
   int nparts = 0;
   PCA_TRY(mab1_bf16_bwd_ex(s1, X, H, p1, saved1, dY, dX, nullptr, 0, g1, ws1,
-                           PCA_F_SKIP_KV_TAIL, st, &im, nullptr, 0, &nparts));
+                           PCA_F_SKIP_KV_TAIL, st, &im, nullptr, 0, &nparts, defer));
   const int64_t Bm = (int64_t)s0.B * m;
   const int Rp = 64;
   MidBwdLaunch L{};
@@ -128,7 +128,7 @@ int isab_bf16_bwd(const pca_mab_shape& s0, const pca_mab_shape& s1, const float*
         jobs.j[jobs.n++] = WgradJob{w0.dO, w0.Th + (int64_t)j * Bm * dk, g0.wv,
                                     j == 0 ? g0.bv : nullptr, Bm, 32 * j, 32 * (j + 1)};
     hipStream_t ts = terminal_stream(st);
-    PCA_TRY(wgrad128_launch(jobs, false, false, 64, ts));
+    PCA_TRY(wgrad128_defer(defer, jobs, false, 64, ts));
     if (dk <= 4)
       PCA_TRY(wgrad_small_f32_launch(w0.dO, w0.Th, Bm, dk, (int64_t)Bm * dk, g0.wv, g0.bv, ts));
   }

@@ -581,7 +581,7 @@ int mab0_bf16_bwd(const pca_mab_shape& s, const float* I, const void* X,
 int mab0_bf16_bwd_ex(const pca_mab_shape& s, const float* I, const void* X,
                      const pca_mab_params& p, const void* saved, const float* dH, float* dI,
                      void* dX, int dk_accumulate, const pca_mab_grads& gr, void* ws, int flags,
-                     hipStream_t st, Mab0PostJobs* defer) {
+                     hipStream_t st, BwdDefer* defer) {
   Mab0Saved v;
   mab0_carve_saved(s, &v, const_cast<void*>(saved));
   Mab0BwdWs w;
@@ -660,7 +660,7 @@ int mab0_bf16_bwd_ex(const pca_mab_shape& s, const float* I, const void* X,
                                     j == 0 ? gr.bv : nullptr, Bm, j * dh, (j + 1) * dh};
     }
     hipStream_t ts = terminal_stream(st);
-    PCA_TRY(wgrad128_launch(jobs, false, false, 64, ts));
+    PCA_TRY(wgrad128_defer(defer, jobs, false, 64, ts));
     if (small)
       PCA_TRY(wgrad_small_f32_launch(w.dO, w.Th, Bm, dk, (int64_t)Bm * dk, gr.wv, gr.bv, ts));
   }
@@ -669,8 +669,8 @@ int mab0_bf16_bwd_ex(const pca_mab_shape& s, const float* I, const void* X,
   Mab0PostJob pj{head_done ? nullptr : w.dQs, w.DG, v.Qp, p.wk, I, p.wq, gr.wk, w.dQp, gr.wq,
                  gr.bq, dI, m, d, dk, s.dq, h, sl2e, w.dO, s.B};
   if (defer != nullptr) {
-    PCA_REQUIRE(defer->n < 3, "mab0_bf16_bwd: post-job table full");
-    defer->j[defer->n++] = pj;
+    PCA_REQUIRE(defer->posts.n < 3, "mab0_bf16_bwd: post-job table full");
+    defer->posts.j[defer->posts.n++] = pj;
     return PCA_OK;
   }
   Mab0PostJobs one{};

@@ -95,7 +95,7 @@ struct WgradJob {
   int g_lo, g_hi;
 };
 struct WgradJobs {
-  WgradJob j[8];
+  WgradJob j[16];
   int n;
 };
 // g_bf16 / a_bf16: element type of every job's G / A (bf16 or fp32)
@@ -218,11 +218,12 @@ int mab1_bf16_bwd(const pca_mab_shape& s, const void* X, const float* H,
                   const pca_mab_params& p, const void* saved, const void* dY, void* dX,
                   float* dH, int dk_accumulate, const pca_mab_grads& gr, void* ws,
                   hipStream_t st);
+struct BwdDefer;
 int mab1_bf16_bwd_ex(const pca_mab_shape& s, const void* X, const float* H,
                      const pca_mab_params& p, const void* saved, const void* dY, void* dX,
                      float* dH, int dk_accumulate, const pca_mab_grads& gr, void* ws, int flags,
                      hipStream_t st, const IsabImg* img = nullptr, float* zero_ptr = nullptr,
-                     int zero_n = 0, int* nparts_out = nullptr);
+                     int zero_n = 0, int* nparts_out = nullptr, BwdDefer* defer = nullptr);
 // fused mab0 / PMA (few shared queries I, many keys X).  X / dX fp32 or bf16 per k_dtype
 bool mab0_bf16_supported(const pca_mab_shape& s);
 size_t mab0_bf16_saved_bytes(const pca_mab_shape& s);
@@ -254,11 +255,25 @@ struct Mab0PostJobs {
   int n;
 };
 int mab0_post_launch(const Mab0PostJobs& J, hipStream_t st);
+// Terminal reductions of a backward pass (only the optimiser / the all-reduce reads their
+// results): a caller that runs several blocks collects them and flushes ONCE at the end of the
+// phase - one bf16 and one fp32 weight-gradient launch (job tables) and one pair of post
+// launches instead of one set per block.  Their operands live in per-block workspaces that
+// stay untouched until then.
+struct BwdDefer {
+  Mab0PostJobs posts;
+  WgradJobs wg_bf16;      // G, A bf16, M = B*N rows   (512 rows per workgroup)
+  WgradJobs wg_f32;       // G, A fp32, M = B*m rows   (64 rows per workgroup)
+};
+int bwd_defer_flush(BwdDefer& D, hipStream_t st);
+// launch `jobs` now, or append them to the matching list of `defer`
+int wgrad128_defer(BwdDefer* defer, const WgradJobs& jobs, bool bf16, int rows_per_wg,
+                   hipStream_t st);
 // `defer` non-null: the post job is appended there instead of being launched
 int mab0_bf16_bwd_ex(const pca_mab_shape& s, const float* I, const void* X,
                      const pca_mab_params& p, const void* saved, const float* dH, float* dI,
                      void* dX, int dk_accumulate, const pca_mab_grads& gr, void* ws, int flags,
-                     hipStream_t st, Mab0PostJobs* defer = nullptr);
+                     hipStream_t st, BwdDefer* defer = nullptr);
 // per-block dispatch (api_mab.hip): kind 0 exact fp32, 1 fused mab1, 2 fused mab0
 int mab_kind(const pca_mab_shape& s);
 size_t mab_saved_bytes_any(const pca_mab_shape& s);
@@ -287,7 +302,7 @@ int isab_bf16_bwd(const pca_mab_shape& s0, const pca_mab_shape& s1, const float*
                   const pca_mab_params& p1, const void* saved0, const void* saved1,
                   const void* dY, float* dI, void* dX, const pca_mab_grads& g0,
                   const pca_mab_grads& g1, void* ws, const IsabImg& im, hipStream_t st,
-                  Mab0PostJobs* defer = nullptr);
+                  BwdDefer* defer = nullptr);
 // classifier head (train_ops.hip)
 int cls_train_head(const float* P, const float* Wc, const float* bc, const int64_t* labels,
                    int B, int d, int C, float grad_scale, float* logits, float* dlogits,

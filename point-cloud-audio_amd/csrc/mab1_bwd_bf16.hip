@@ -884,6 +884,37 @@ int wgrad128_launch(const WgradJobs& jobs, bool g_bf16, bool a_bf16, int rows_pe
   return check_launch("k_wgrad128");
 }
 
+int wgrad128_defer(BwdDefer* defer, const WgradJobs& jobs, bool bf16, int rows_per_wg,
+                   hipStream_t st) {
+  if (defer == nullptr) return wgrad128_launch(jobs, bf16, bf16, rows_per_wg, st);
+  WgradJobs& L = bf16 ? defer->wg_bf16 : defer->wg_f32;
+  if (L.n + jobs.n > 16) {                 // table full: run what has been collected
+    PCA_TRY(wgrad128_launch(L, bf16, bf16, bf16 ? 512 : 64, st));
+    L.n = 0;
+  }
+  for (int i = 0; i < jobs.n; ++i) L.j[L.n++] = jobs.j[i];
+  return PCA_OK;
+}
+
+int bwd_defer_flush(BwdDefer& D, hipStream_t st) {
+  hipStream_t ts = terminal_stream(st);
+  if (D.wg_bf16.n > 0) {
+    double rows = 0;
+    for (int i = 0; i < D.wg_bf16.n; ++i) rows += (double)D.wg_bf16.j[i].M;
+    ProfScope ps(PCA_K_WGRAD, ts, 2.0 * rows * 128 * 128, 4.0 * rows * 128);
+    PCA_TRY(wgrad128_launch(D.wg_bf16, true, true, 512, ts));
+    ps.end();
+    D.wg_bf16.n = 0;
+  }
+  if (D.wg_f32.n > 0) {
+    PCA_TRY(wgrad128_launch(D.wg_f32, false, false, 64, ts));
+    D.wg_f32.n = 0;
+  }
+  PCA_TRY(mab0_post_launch(D.posts, st));
+  D.posts.n = 0;
+  return PCA_OK;
+}
+
 int wgrad_small_f32_launch(const float* G, const float* X, int64_t M, int dq,
                            int64_t x_head_stride, float* dW, float* db, hipStream_t st) {
   hipLaunchKernelGGL((k_wgrad_small<float>), dim3((unsigned)cdiv(M, 64)), dim3(256), 0, st, G, X, M,
@@ -910,7 +941,7 @@ int mab1_bf16_bwd_ex(const pca_mab_shape& s, const void* X, const float* H,
                      const pca_mab_params& p, const void* saved, const void* dY, void* dX,
                      float* dH, int dk_accumulate, const pca_mab_grads& gr, void* ws, int flags,
                      hipStream_t st, const IsabImg* img, float* zero_ptr, int zero_n,
-                     int* nparts_out) {
+                     int* nparts_out, BwdDefer* defer) {
   Mab1Saved v;
   mab1_carve_saved(s, &v, const_cast<void*>(saved));
   Mab1BwdWs w;
@@ -993,9 +1024,13 @@ int mab1_bf16_bwd_ex(const pca_mab_shape& s, const void* X, const float* H,
     jobs.j[jobs.n++] = WgradJob{w.dZ, v.OS, gr.wo, gr.bo, M, 0, 128};
     if (wq_big && abf) jobs.j[jobs.n++] = WgradJob{w.dQp, X, gr.wq, gr.bq, M, 0, 128};
     hipStream_t ts = terminal_stream(st);
-    ProfScope ps(PCA_K_WGRAD, ts, 2.0 * jobs.n * M * d * d, 4.0 * jobs.n * M * d);
-    PCA_TRY(wgrad128_launch(jobs, true, true, rows_per_wg, ts));
-    ps.end();
+    if (defer != nullptr) {
+      PCA_TRY(wgrad128_defer(defer, jobs, true, rows_per_wg, ts));
+    } else {
+      ProfScope ps(PCA_K_WGRAD, ts, 2.0 * jobs.n * M * d * d, 4.0 * jobs.n * M * d);
+      PCA_TRY(wgrad128_launch(jobs, true, true, rows_per_wg, ts));
+      ps.end();
+    }
   }
   if (small && fuse && s.dq <= 3) {
     // dWq / dbq were reduced inside the chain kernel

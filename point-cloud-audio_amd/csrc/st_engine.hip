@@ -296,7 +296,7 @@ int pca_st_train_fwd_bwd(const pca_st_config* c, const float* params, const floa
 
   // shared-query gradients of the fused blocks of this call: one pair of launches at the end
   // (their inputs live in per-block workspaces, which stay untouched until then)
-  pca::Mab0PostJobs posts{};
+  pca::BwdDefer posts{};
   if (phase != 1) {
     PCA_TRY(pca::forward(*c, L, s, p, X, w, true, st));
     // dec.1 (Linear) + mean cross-entropy, forward and backward, two launches
@@ -345,6 +345,6 @@ int pca_st_train_fwd_bwd(const pca_st_config* c, const float* params, const floa
                              pca::grads_at(g, L.mab0[0]), w.scratch_bw[0], st));
     }
   }
-  return pca::mab0_post_launch(posts, st);
+  return pca::bwd_defer_flush(posts, st);
 }
 }
