@@ -902,7 +902,12 @@ int bwd_defer_flush(BwdDefer& D, hipStream_t st) {
     double rows = 0;
     for (int i = 0; i < D.wg_bf16.n; ++i) rows += (double)D.wg_bf16.j[i].M;
     ProfScope ps(PCA_K_WGRAD, ts, 2.0 * rows * 128 * 128, 4.0 * rows * 128);
-    PCA_TRY(wgrad128_launch(D.wg_bf16, true, true, 512, ts));
+    // every workgroup costs 16384 atomics and the atomic rate is the floor of this kernel: aim at
+    // ~200 workgroups over all jobs (512 rows for one B*N-row job, 1024 for three, ...)
+    // (measured at 3 x 65536 rows: 512 -> 41 us, 768 -> 41, 1024 -> 31, 1536 -> 31, 2048 -> 39)
+    int rpw = 512 * (int)((rows + 98303.0) / 98304.0);
+    rpw = rpw < 512 ? 512 : (rpw > 1024 ? 1024 : rpw);
+    PCA_TRY(wgrad128_launch(D.wg_bf16, true, true, rpw, ts));
     ps.end();
     D.wg_bf16.n = 0;
   }
