@@ -912,7 +912,7 @@ int bwd_defer_flush(BwdDefer& D, hipStream_t st) {
     D.wg_bf16.n = 0;
   }
   if (D.wg_f32.n > 0) {
-    PCA_TRY(wgrad128_launch(D.wg_f32, false, false, 64, ts));
+    PCA_TRY(wgrad128_launch(D.wg_f32, false, false, 128, ts));   // 64: 18.7 us, 128: 14.2, 256: 15.3
     D.wg_f32.n = 0;
   }
   PCA_TRY(mab0_post_launch(D.posts, st));
