@@ -664,9 +664,9 @@ int mab0_bf16_bwd_ex(const pca_mab_shape& s, const float* I, const void* X,
     if (small)
       PCA_TRY(wgrad_small_f32_launch(w.dO, w.Th, Bm, dk, (int64_t)Bm * dk, gr.wv, gr.bv, ts));
   }
-  if (!head_done) PCA_TRY(colsum(w.dO, s.B, m * d, w.dQs, 0, st));   // sum over sets
-  // fused ISAB: k_mid_bwd left dO per set, the post kernel sums it
-  Mab0PostJob pj{head_done ? nullptr : w.dQs, w.DG, v.Qp, p.wk, I, p.wq, gr.wk, w.dQp, gr.wq,
+  // (the sum of dO over the sets is taken inside k_mab0_post1)
+  // k_mid_bwd / k_mab0_epi_bwd left dO per set, the post kernel sums it
+  Mab0PostJob pj{nullptr, w.DG, v.Qp, p.wk, I, p.wq, gr.wk, w.dQp, gr.wq,
                  gr.bq, dI, m, d, dk, s.dq, h, sl2e, w.dO, s.B};
   if (defer != nullptr) {
     PCA_REQUIRE(defer->posts.n < 3, "mab0_bf16_bwd: post-job table full");
