@@ -56,10 +56,39 @@ __device__ __forceinline__ bf16x8 tr_frag(const char* img, int t, int lane) {
 // blockIdx.y = MAB, blockIdx.x = query row q (blocks beyond m exit).
 // ---------------------------------------------------------------------------------
 constexpr int PREP_SPARE = 16;
+__device__ __forceinline__ void mab0_prep_body(const Mab0PrepJob& a, float* sq, int q);
+
 __global__ __launch_bounds__(256) void k_mab0_prep(const Mab0PrepJobs jobs) {
   extern __shared__ float sq[];            // Qp row [d]
-  const Mab0PrepJob a = jobs.j[blockIdx.y];
-  const int q = blockIdx.x;
+  mab0_prep_body(jobs.j[blockIdx.y], sq, blockIdx.x);
+}
+
+// weight images (as k_prep_jobs, mab1_bf16.hip) and query-side tensors in one grid:
+// rows [0, Q.n) of blockIdx.y are query-side jobs, the rest weight-image jobs
+__global__ __launch_bounds__(256) void k_prep_all(const PrepJobs W, const Mab0PrepJobs Q) {
+  extern __shared__ float sq[];
+  if ((int)blockIdx.y < Q.n) {
+    mab0_prep_body(Q.j[blockIdx.y], sq, blockIdx.x);
+    return;
+  }
+  const PrepJob jb = W.j[blockIdx.y - Q.n];
+  const int rows = jb.rows, cols = jb.cols, mode = jb.mode;
+  const int idx = blockIdx.x * blockDim.x + threadIdx.x;
+  if (idx >= rows * cols) return;
+  float v;
+  if (mode <= 1) {
+    const int n = idx / cols, k = idx - n * cols;
+    const int kk = mode == 1 ? (k & ~31) + perm32(k & 31) : k;
+    v = jb.src[(int64_t)n * cols + kk];
+  } else {
+    const int n = idx / rows, k = idx - n * rows;
+    const int kk = mode == 2 ? (k & ~31) + perm32(k & 31) : k;
+    v = jb.src[(int64_t)kk * cols + n];
+  }
+  jb.dst[idx] = (__bf16)v;
+}
+
+__device__ __forceinline__ void mab0_prep_body(const Mab0PrepJob& a, float* sq, int q) {
   if (q >= a.m) {
     // spare workgroups: WvT[c][f] = Wv[f][c], WoT[c][f] = Wo[f][c]
     const int sp = q - a.m;
@@ -713,6 +742,27 @@ void mab0_collect_prep(const pca_mab_shape& s, const float* I, const pca_mab_par
   if (epilogue_images) { a.Wv = p.wv; a.Wo = p.wo; a.WvT = v.WvT; a.WoT = v.WoT; }
   J->j[J->n++] = a;
 }
+int prep_all_launch(const PrepJobs& W, const Mab0PrepJobs& Q, hipStream_t st) {
+  if (W.n == 0) return mab0_prep_launch(Q, st);
+  if (Q.n == 0) return prep_jobs_launch(W, st);
+  int maxm = 0, maxd = 0, maxe = 0;
+  bool spare = false;
+  for (int i = 0; i < Q.n; ++i) {
+    maxm = Q.j[i].m > maxm ? Q.j[i].m : maxm;
+    maxd = Q.j[i].d > maxd ? Q.j[i].d : maxd;
+    spare = spare || Q.j[i].WvT != nullptr;
+  }
+  for (int i = 0; i < W.n; ++i) {
+    const int e = W.j[i].rows * W.j[i].cols;
+    maxe = e > maxe ? e : maxe;
+  }
+  int gx = maxm + (spare ? PREP_SPARE : 0);
+  const int gw = (int)cdiv(maxe, 256);
+  gx = gx > gw ? gx : gw;
+  hipLaunchKernelGGL(k_prep_all, dim3(gx, Q.n + W.n), dim3(256), maxd * sizeof(float), st, W, Q);
+  return check_launch("k_prep_all");
+}
+
 int mab0_prep_launch(const Mab0PrepJobs& J, hipStream_t st) {
   if (J.n == 0) return PCA_OK;
   int maxm = 0, maxd = 0;

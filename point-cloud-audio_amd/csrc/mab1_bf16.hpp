@@ -126,6 +126,9 @@ struct PrepJobs {
   int n;
 };
 int prep_jobs_launch(const PrepJobs& jobs, hipStream_t st);
+// the weight images AND the query-side tensors of a step in ONE launch (both depend on the
+// parameters only; blockIdx.y selects the job, the two kinds share the grid)
+int prep_all_launch(const PrepJobs& W, const Mab0PrepJobs& Q, hipStream_t st);
 
 // scratch layouts of the two backward passes (shared with the ISAB-level orchestration)
 struct Mab1BwdWs {

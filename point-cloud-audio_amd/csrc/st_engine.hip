@@ -189,7 +189,7 @@ int forward(const pca_st_config& c, const Layout& L, const Shapes& s, const floa
       if (w.fused[li])
         isab_collect_prep(s.m0[li], params_at(p, L.mab0[li]), params_at(p, L.mab1[li]),
                           w.img[li], true, li == 1, &J);
-    PCA_TRY(prep_jobs_launch(J, st));
+    // (launched together with the query-side jobs below)
     // query-side preparation (Qp, G images) of every fused mab0 / PMA, also one launch
     Mab0PrepJobs MJ{};
     for (int li = 0; li < 2; ++li)
@@ -203,7 +203,7 @@ int forward(const pca_st_config& c, const Layout& L, const Shapes& s, const floa
       mab0_carve_saved(s.pma, &v, w.saved[4]);
       mab0_collect_prep(s.pma, p + L.S, params_at(p, L.pma), v, true, true, &MJ);
     }
-    PCA_TRY(mab0_prep_launch(MJ, st));
+    PCA_TRY(prep_all_launch(J, MJ, st));
   }
   for (int li = 0; li < 2; ++li) {
     void* sv0 = training ? w.saved[2 * li] : nullptr;
