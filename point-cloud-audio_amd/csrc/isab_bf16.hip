@@ -130,7 +130,8 @@ int isab_bf16_bwd(const pca_mab_shape& s0, const pca_mab_shape& s1, const float*
     hipStream_t ts = terminal_stream(st);
     PCA_TRY(wgrad128_defer(defer, jobs, false, 64, ts));
     if (dk <= 4)
-      PCA_TRY(wgrad_small_f32_launch(w0.dO, w0.Th, Bm, dk, (int64_t)Bm * dk, g0.wv, g0.bv, ts));
+      PCA_TRY(wgrad_small_f32_launch(w0.dO, w0.Th, Bm, dk, (int64_t)Bm * dk, g0.wv, g0.bv, ts,
+                                     defer));
   }
   return mab0_bf16_bwd_ex(s0, I, X, p0, saved0, nullptr, dI, dX, dX != nullptr ? 1 : 0, g0, ws0,
                           PCA_F_SKIP_HEAD | PCA_F_SKIP_WGRAD, st, defer);

@@ -16,6 +16,7 @@
 //   the fp32 GEMM; k_mab0_post turns sum_b dO and dG into dWk, dWq, dbq, dI.  d(bk) is
 //   identically zero (softmax shift invariance) and is left untouched.
 #include "mab1_bf16.hpp"
+#include "terminal_bodies.hpp"
 
 #include <math.h>
 
@@ -477,11 +478,14 @@ __device__ __forceinline__ float dot_strided(const float* __restrict__ a, int64_
 }
 
 // stage 1 (grid-parallel): dWk and dQp = dQs + (dG_raw Wk_h^T); blockIdx.y = MAB
+__device__ __forceinline__ void post1_body(const Mab0PostJob& a, int blk);
 __global__ __launch_bounds__(256) void k_mab0_post1(const Mab0PostJobs jobs) {
-  const Mab0PostJob a = jobs.j[blockIdx.y];
+  post1_body(jobs.j[blockIdx.y], blockIdx.x);
+}
+__device__ __forceinline__ void post1_body(const Mab0PostJob& a, int blk) {
   const int m = a.m, d = a.d, dk = a.dk;
   const int dh = d / a.h;
-  const int o = blockIdx.x * 256 + threadIdx.x;
+  const int o = blk * 256 + threadIdx.x;
   if (o < d * dk) {
     const int f = o / dk, c = o - f * dk, j = f / dh;
     a.dWk[o] += a.sl2e * dot_strided(a.Qp + f, d, a.DG + (int64_t)j * m * dk + c, dk, m);
@@ -508,6 +512,25 @@ __global__ __launch_bounds__(256) void k_mab0_post1(const Mab0PostJobs jobs) {
                                                  a.Wk + (int64_t)f * dk, 1, dk);
   }
 }
+// stage 1 + riders: rows [0, J.n) of blockIdx.y are the post-1 jobs, then (when present) the
+// classifier weight gradient (one workgroup per class) and the layer-1 fc_v gradient
+__device__ __forceinline__ void post1_body(const Mab0PostJob& a, int blk);
+__global__ __launch_bounds__(256) void k_terminal1(const Mab0PostJobs jobs, const ClsWgradArgs c,
+                                                   int has_cls, const SmallWgradArgs w,
+                                                   int has_sw) {
+  const int y = blockIdx.y;
+  if (y < jobs.n) {
+    post1_body(jobs.j[y], blockIdx.x);
+  } else if (has_cls && y == jobs.n) {
+    if ((int)blockIdx.x < c.C)
+      cls_wgrad_body(c.dlogits, c.P, c.lossv, c.corrv, c.B, c.d, c.C, c.dWc, c.dbc, c.loss_out,
+                     c.stats, blockIdx.x);
+  } else if (has_sw) {
+    if ((int64_t)blockIdx.x * w.rows_per_wg < w.M)
+      wgrad_small_body<float>(w.G, w.X, w.M, w.dq, w.rows_per_wg, w.x_head_stride, w.dW, w.db,
+                              blockIdx.x);
+  }
+}
 // stage 2: dWq += dQp^T I ; dbq += colsum(dQp) ; dI += dQp Wq
 __global__ __launch_bounds__(256) void k_mab0_post2(const Mab0PostJobs jobs) {
   const Mab0PostJob a = jobs.j[blockIdx.y];
@@ -530,6 +553,35 @@ __global__ __launch_bounds__(256) void k_mab0_post2(const Mab0PostJobs jobs) {
 }
 
 }  // namespace
+int terminal_launch(const BwdDefer& D, hipStream_t st) {
+  if (!D.has_cls && !D.has_sw) return mab0_post_launch(D.posts, st);
+  const Mab0PostJobs& J = D.posts;
+  int n1 = 0;
+  for (int i = 0; i < J.n; ++i) {
+    const int e1 = J.j[i].d * J.j[i].dk + J.j[i].m * J.j[i].d;
+    n1 = e1 > n1 ? e1 : n1;
+  }
+  int gx = (int)cdiv(n1, 256);
+  if (D.has_cls && D.cls.C > gx) gx = D.cls.C;
+  if (D.has_sw) {
+    const int gs = (int)cdiv(D.sw.M, D.sw.rows_per_wg);
+    gx = gs > gx ? gs : gx;
+  }
+  hipStream_t ts = terminal_stream(st);
+  hipLaunchKernelGGL(k_terminal1, dim3(gx, J.n + (D.has_cls ? 1 : 0) + (D.has_sw ? 1 : 0)),
+                     dim3(256), 0, ts, J, D.cls, D.has_cls, D.sw, D.has_sw);
+  PCA_TRY(check_launch("k_terminal1"));
+  if (J.n == 0) return PCA_OK;
+  int n2 = 0;
+  for (int i = 0; i < J.n; ++i) {
+    const Mab0PostJob& a = J.j[i];
+    const int e2 = a.d * a.dq + a.d + (a.dI ? a.m * a.dq : 0);
+    n2 = e2 > n2 ? e2 : n2;
+  }
+  hipLaunchKernelGGL(k_mab0_post2, dim3((unsigned)cdiv(n2, 256), J.n), dim3(256), 0, ts, J);
+  return check_launch("k_mab0_post2");
+}
+
 int mab0_post_launch(const Mab0PostJobs& J, hipStream_t st) {
   if (J.n == 0) return PCA_OK;
   int n1 = 0, n2 = 0;

@@ -102,8 +102,10 @@ struct WgradJobs {
 int wgrad128_launch(const WgradJobs& jobs, bool g_bf16, bool a_bf16, int rows_per_wg,
                     hipStream_t st);
 // dW[128 x dq] += G[M x 128]^T . X_h[M x dq] (dq <= 4; X_h = X + head(f)*x_head_stride), db += colsum
+struct BwdDefer;
 int wgrad_small_f32_launch(const float* G, const float* X, int64_t M, int dq,
-                           int64_t x_head_stride, float* dW, float* db, hipStream_t st);
+                           int64_t x_head_stride, float* dW, float* db, hipStream_t st,
+                           BwdDefer* defer = nullptr);
 // dH[q][c] (+)= dKp[q][:] . Wk[:][c] + dVp[q][:] . Wv[:][c]   per set (m = 16 rows, d = 128)
 int kv_dh_launch(const float* dKp, const float* dVp, const float* Wk, const float* Wv, float* dH,
                  int B, int m, int d, int accumulate, hipStream_t st);
@@ -241,6 +243,18 @@ int mab0_bf16_bwd(const pca_mab_shape& s, const float* I, const void* X,
                   const pca_mab_params& p, const void* saved, const float* dH, float* dI,
                   void* dX, int dk_accumulate, const pca_mab_grads& gr, void* ws,
                   hipStream_t st);
+struct ClsWgradArgs {
+  const float *dlogits, *P, *lossv, *corrv;
+  int B, d, C;
+  float *dWc, *dbc, *loss_out, *stats;
+};
+struct SmallWgradArgs {
+  const float *G, *X;
+  int64_t M;
+  int dq, rows_per_wg;
+  int64_t x_head_stride;
+  float *dW, *db;
+};
 // shared-query parameter gradients (dWk, dWq, dbq, dI) of up to 3 MABs: tiny, latency-bound
 // kernels, so callers may collect them and run ONE pair of launches at the end of a phase
 struct Mab0PostJob {
@@ -267,8 +281,14 @@ struct BwdDefer {
   Mab0PostJobs posts;
   WgradJobs wg_bf16;      // G, A bf16, M = B*N rows   (512 rows per workgroup)
   WgradJobs wg_f32;       // G, A fp32, M = B*m rows   (64 rows per workgroup)
+  // classifier weight gradient + loss counters, layer-1 fc_v gradient: they ride in the first
+  // post launch (k_terminal1) as extra job rows
+  ClsWgradArgs cls;
+  SmallWgradArgs sw;
+  int has_cls, has_sw;
 };
 int bwd_defer_flush(BwdDefer& D, hipStream_t st);
+int terminal_launch(const BwdDefer& D, hipStream_t st);    // post stages + riders
 // launch `jobs` now, or append them to the matching list of `defer`
 int wgrad128_defer(BwdDefer* defer, const WgradJobs& jobs, bool bf16, int rows_per_wg,
                    hipStream_t st);
@@ -310,6 +330,6 @@ int isab_bf16_bwd(const pca_mab_shape& s0, const pca_mab_shape& s1, const float*
 int cls_train_head(const float* P, const float* Wc, const float* bc, const int64_t* labels,
                    int B, int d, int C, float grad_scale, float* logits, float* dlogits,
                    float* dP, float* dWc, float* dbc, float* loss_out, float* stats, float* ws,
-                   hipStream_t st);
+                   hipStream_t st, BwdDefer* defer = nullptr);
 
 }  // namespace pca

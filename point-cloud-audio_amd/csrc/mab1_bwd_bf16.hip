@@ -14,6 +14,7 @@
 //   k_kv_grad    per (set, head): dKp = dS^T.Qp, dVp = P^T.dO (m x 32 outputs, N-long sums).
 // The tiny [B*m, d] projections of H (fc_k, fc_v) are differentiated with the fp32 GEMMs.
 #include "mab1_bf16.hpp"
+#include "terminal_bodies.hpp"
 
 #include <math.h>
 
@@ -689,41 +690,7 @@ __global__ __launch_bounds__(256) void k_wgrad_small(const GT* __restrict__ G,
                                                      int64_t x_head_stride,   // A = X + (f/32)*stride
                                                      float* __restrict__ dW,
                                                      float* __restrict__ db) {
-  constexpr int D = 128;
-  __shared__ float red[128][5];
-  const int f = threadIdx.x & 127, ph = threadIdx.x >> 7;
-  const float* __restrict__ Xh = X + (int64_t)(f >> 5) * x_head_stride;
-  const int64_t r0 = (int64_t)blockIdx.x * rows_per_wg;
-  const int64_t r1 = (r0 + rows_per_wg < M) ? r0 + rows_per_wg : M;
-  float acc[4] = {0.f, 0.f, 0.f, 0.f}, bs = 0.f;
-  // batches of 8 rows: 8 independent G loads (+ the broadcast X rows) in flight
-  for (int64_t row = r0 + ph; row < r1; row += 16) {
-    float gv[8], xv[8][4];
-#pragma unroll
-    for (int u = 0; u < 8; ++u) {
-      const int64_t rr = row + 2 * u;
-      const bool ok = rr < r1;
-      gv[u] = ok ? (float)G[rr * D + f] : 0.f;
-#pragma unroll
-      for (int c = 0; c < 4; ++c) xv[u][c] = (ok && c < dq) ? Xh[rr * dq + c] : 0.f;
-    }
-#pragma unroll
-    for (int u = 0; u < 8; ++u) {
-      bs += gv[u];
-#pragma unroll
-      for (int c = 0; c < 4; ++c) acc[c] = fmaf(gv[u], xv[u][c], acc[c]);
-    }
-  }
-  if (ph == 1) {
-#pragma unroll
-    for (int c = 0; c < 4; ++c) red[f][c] = acc[c];
-    red[f][4] = bs;
-  }
-  __syncthreads();
-  if (ph == 0) {
-    for (int c = 0; c < dq; ++c) atomicAdd(&dW[f * dq + c], acc[c] + red[f][c]);
-    if (db != nullptr) atomicAdd(&db[f], bs + red[f][4]);
-  }
+  wgrad_small_body<GT>(G, X, M, dq, rows_per_wg, x_head_stride, dW, db, blockIdx.x);
 }
 
 // per (set, head): dKp[b][key][32j + c] = sum_n dS[n][j*MI + key] Qp[n][32j + c]
@@ -915,13 +882,20 @@ int bwd_defer_flush(BwdDefer& D, hipStream_t st) {
     PCA_TRY(wgrad128_launch(D.wg_f32, false, false, 128, ts));   // 64: 18.7 us, 128: 14.2, 256: 15.3
     D.wg_f32.n = 0;
   }
-  PCA_TRY(mab0_post_launch(D.posts, st));
+  PCA_TRY(terminal_launch(D, st));
   D.posts.n = 0;
+  D.has_cls = D.has_sw = 0;
   return PCA_OK;
 }
 
 int wgrad_small_f32_launch(const float* G, const float* X, int64_t M, int dq,
-                           int64_t x_head_stride, float* dW, float* db, hipStream_t st) {
+                           int64_t x_head_stride, float* dW, float* db, hipStream_t st,
+                           BwdDefer* defer) {
+  if (defer != nullptr && !defer->has_sw) {
+    defer->sw = SmallWgradArgs{G, X, M, dq, 64, x_head_stride, dW, db};
+    defer->has_sw = 1;
+    return PCA_OK;
+  }
   hipLaunchKernelGGL((k_wgrad_small<float>), dim3((unsigned)cdiv(M, 64)), dim3(256), 0, st, G, X, M,
                      dq, 64, x_head_stride, dW, db);
   return check_launch("k_wgrad_small<float>");

@@ -302,7 +302,7 @@ int pca_st_train_fwd_bwd(const pca_st_config* c, const float* params, const floa
     // dec.1 (Linear) + mean cross-entropy, forward and backward, two launches
     PCA_TRY(pca::cls_train_head(w.P, p + L.wc, p + L.bc, labels, c->B, c->d, c->C, grad_scale,
                                 w.logits, w.dlogits, w.dP, g + L.wc, g + L.bc, loss_out, stats,
-                                w.clsws, st));
+                                w.clsws, st, &posts));
     // dec.0 (PMA)
     if (pca::mab_kind(s.pma) == 2)
       PCA_TRY(pca::mab0_bf16_bwd_ex(s.pma, p + L.S, w.Y[1], pca::params_at(p, L.pma),

@@ -2,6 +2,7 @@
 // nn.CrossEntropyLoss (mean) forward+gradient in one launch, and torch.optim.Adam with
 // coupled weight decay as one fused pass over a flat parameter vector.
 #include "mab1_bf16.hpp"
+#include "terminal_bodies.hpp"
 
 namespace pca {
 namespace {
@@ -146,60 +147,7 @@ __global__ __launch_bounds__(128) void k_cls_wgrad(
     const float* __restrict__ lossv, const float* __restrict__ corrv, int B, int d, int C,
     float* __restrict__ dWc, float* __restrict__ dbc, float* __restrict__ loss_out,
     float* __restrict__ stats) {
-  const int c = blockIdx.x, tid = threadIdx.x;
-  // this class's column of dlogits goes to LDS in one round trip (chunks of 1024 sets); the
-  // P loads are then the only global traffic of the reduction, 16 in flight
-  __shared__ float sg[1024];
-  for (int f0 = 0; f0 < d; f0 += 128) {
-    const int f = f0 + tid;
-    float acc = 0.f;
-    for (int b0 = 0; b0 < B; b0 += 1024) {
-      const int nb = (B - b0 < 1024) ? B - b0 : 1024;
-      __syncthreads();
-      for (int i = tid; i < nb; i += 128) sg[i] = dlogits[(int64_t)(b0 + i) * C + c];
-      __syncthreads();
-      if (f < d) {
-        int bb = 0;
-        for (; bb + 16 <= nb; bb += 16) {
-          float pv[16];
-#pragma unroll
-          for (int u = 0; u < 16; ++u) pv[u] = P[(int64_t)(b0 + bb + u) * d + f];
-#pragma unroll
-          for (int u = 0; u < 16; ++u) acc = fmaf(sg[bb + u], pv[u], acc);
-        }
-        for (; bb < nb; ++bb) acc = fmaf(sg[bb], P[(int64_t)(b0 + bb) * d + f], acc);
-      }
-    }
-    if (f < d) dWc[(int64_t)c * d + f] += acc;
-  }
-  __shared__ float red[128];
-  float part = 0.f;
-  for (int bb = tid; bb < B; bb += 128) part += dlogits[(int64_t)bb * C + c];
-  red[tid] = part;
-  __syncthreads();
-  if (tid == 0) {
-    float t = 0.f;
-    for (int i = 0; i < 128; ++i) t += red[i];
-    dbc[c] += t;
-  }
-  if (c == 0) {              // loss / accuracy counters, summed in a fixed order
-    __syncthreads();
-    float l = 0.f, k = 0.f;
-    for (int bb = tid; bb < B; bb += 128) { l += lossv[bb]; k += corrv[bb]; }
-    red[tid] = l;
-    __syncthreads();
-    float lt = 0.f;
-    if (tid == 0) for (int i = 0; i < 128; ++i) lt += red[i];
-    __syncthreads();
-    red[tid] = k;
-    __syncthreads();
-    if (tid == 0) {
-      float kt = 0.f;
-      for (int i = 0; i < 128; ++i) kt += red[i];
-      loss_out[0] = lt / (float)B;
-      if (stats != nullptr) { stats[0] += lt; stats[1] += kt; }
-    }
-  }
+  cls_wgrad_body(dlogits, P, lossv, corrv, B, d, C, dWc, dbc, loss_out, stats, blockIdx.x);
 }
 
 // step[0] = optimiser step count, step[1] = arrival ticket (zero between launches).  Every
@@ -249,12 +197,17 @@ __global__ __launch_bounds__(256) void k_adam(float* __restrict__ p, float* __re
 int cls_train_head(const float* P, const float* Wc, const float* bc, const int64_t* labels,
                    int B, int d, int C, float grad_scale, float* logits, float* dlogits,
                    float* dP, float* dWc, float* dbc, float* loss_out, float* stats, float* ws,
-                   hipStream_t st) {
+                   hipStream_t st, BwdDefer* defer) {
   float* lossv = ws;
   float* corrv = ws + B;
   hipLaunchKernelGGL(k_cls_fwd_bwd, dim3(B), dim3(128), (size_t)(d + C) * sizeof(float), st, P, Wc,
                      bc, labels, B, d, C, grad_scale, logits, dlogits, dP, lossv, corrv);
   PCA_TRY(check_launch("k_cls_fwd_bwd"));
+  if (defer != nullptr) {          // rides in the phase's terminal launch
+    defer->cls = ClsWgradArgs{dlogits, P, lossv, corrv, B, d, C, dWc, dbc, loss_out, stats};
+    defer->has_cls = 1;
+    return PCA_OK;
+  }
   hipLaunchKernelGGL(k_cls_wgrad, dim3(C), dim3(128), 0, terminal_stream(st), dlogits, P, lossv,
                      corrv, B, d, C, dWc, dbc, loss_out, stats);
   return check_launch("k_cls_wgrad");
