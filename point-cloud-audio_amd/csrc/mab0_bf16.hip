@@ -23,6 +23,7 @@
 //                 set shared by two workgroups
 //   k_mab0_epi    per set: O, Z, H (fp32 VALU; 2*m*d*(dk+d) MACs)
 #include "mab1_bf16.hpp"
+#include "pma_head_bodies.hpp"
 
 #include <math.h>
 
@@ -627,91 +628,7 @@ __global__ __launch_bounds__(256) void k_mab0_epi(const float* __restrict__ Tp, 
                                                   int dk, int h, float* __restrict__ H,
                                                   float* __restrict__ Osave,
                                                   float* __restrict__ Zsave) {
-  extern __shared__ float sm[];
-  float* sT = sm;                 // [h*m][dk]
-  float* sO = sT + h * m * dk;    // [m][d]
-  const int b = blockIdx.x, tid = threadIdx.x;
-  const int R = h * m, dh = d / h;
-  if (S == 0) {                 // T already merged (layer-1 path)
-    for (int i = tid; i < R * dk; i += 256) sT[i] = T[(int64_t)b * R * dk + i];
-  } else {
-    // merge the S point-range partials: T = sum_s f_s Tp_s / sum_s f_s Lp_s, f_s = 2^(M_s - M)
-    for (int i = tid; i < R * dk; i += 256) {
-      const int r = i / dk, c = i - r * dk;
-      float M = -INFINITY;
-      for (int s = 0; s < S; ++s) M = fmaxf(M, Mp[((int64_t)b * S + s) * R + r]);
-      float L = 0.f, t = 0.f;
-      for (int s = 0; s < S; ++s) {
-        const float ms = Mp[((int64_t)b * S + s) * R + r];
-        if (ms == -INFINITY) continue;
-        const float fs = exp2f(ms - M);
-        L += fs * Lp[((int64_t)b * S + s) * R + r];
-        t += fs * Tp[(((int64_t)b * S + s) * R + r) * dk + c];
-      }
-      const float v = t / L;
-      sT[i] = v;
-      T[(int64_t)b * R * dk + i] = v;
-      if (c == 0) LSE[(int64_t)b * R + r] = M + log2f(L);
-    }
-  }
-  __syncthreads();
-  const int f = tid % d, qh = tid / d;          // d == 128: two query halves
-  if (MQ == 1 && m == 1) {
-    // PMA (one seed): the second half of the workgroup would idle - it takes the second half
-    // of every contraction instead (these GEMVs are chains of dependent L2 round trips)
-    __shared__ float part[128];
-    const int j = f / dh;
-    float a1[1] = {qh == 0 ? Qp[f] + bv[f] : 0.f};
-    col_gemm<1>(sT + j * dk + qh * (dk / 2), dk, WvT + (int64_t)qh * (dk / 2) * d, d, dk / 2, f, a1);
-    if (qh == 1) part[f] = a1[0];
-    __syncthreads();
-    if (qh == 0) { a1[0] += part[f]; sO[f] = a1[0]; }
-    __syncthreads();
-    float z1[1] = {qh == 0 ? bo[f] : 0.f};
-    col_gemm<1>(sO + qh * (d / 2), d, WoT + (int64_t)qh * (d / 2) * d, d, d / 2, f, z1);
-    if (qh == 1) part[f] = z1[0];
-    __syncthreads();
-    if (qh == 0) {
-      z1[0] += part[f];
-      const float o1 = sO[f];
-      const int64_t o = (int64_t)b * d + f;
-      H[o] = o1 + fmaxf(z1[0], 0.f);
-      if (Osave != nullptr) {
-        Osave[o] = o1;
-        Zsave[o] = z1[0];
-      }
-    }
-    return;
-  }
-  const int q0 = qh * MQ;
-  const bool act = q0 < m;
-  float acc[MQ];
-  if (act) {
-    const int j = f / dh;
-#pragma unroll
-    for (int q = 0; q < MQ; ++q) acc[q] = (q0 + q < m) ? Qp[(q0 + q) * d + f] + bv[f] : 0.f;
-    col_gemm<MQ>(sT + (j * m + q0) * dk, dk, WvT, d, dk, f, acc);
-#pragma unroll
-    for (int q = 0; q < MQ; ++q)
-      if (q0 + q < m) sO[(q0 + q) * d + f] = acc[q];
-  }
-  __syncthreads();
-  if (act) {
-    float z[MQ];
-#pragma unroll
-    for (int q = 0; q < MQ; ++q) z[q] = bo[f];
-    col_gemm<MQ>(sO + q0 * d, d, WoT, d, d, f, z);
-#pragma unroll
-    for (int q = 0; q < MQ; ++q) {
-      if (q0 + q >= m) continue;
-      const int64_t o = (int64_t)b * m * d + (q0 + q) * d + f;
-      H[o] = acc[q] + fmaxf(z[q], 0.f);
-      if (Osave != nullptr) {
-        Osave[o] = acc[q];
-        Zsave[o] = z[q];
-      }
-    }
-  }
+  mab0_epi_body<MQ>(Tp, Mp, Lp, S, T, LSE, Qp, WvT, bv, WoT, bo, m, d, dk, h, H, Osave, Zsave, blockIdx.x);
 }
 
 }  // namespace

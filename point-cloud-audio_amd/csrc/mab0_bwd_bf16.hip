@@ -17,6 +17,7 @@
 //   identically zero (softmax shift invariance) and is left untouched.
 #include "mab1_bf16.hpp"
 #include "terminal_bodies.hpp"
+#include "pma_head_bodies.hpp"
 
 #include <math.h>
 
@@ -65,104 +66,8 @@ __global__ __launch_bounds__(256) void k_mab0_epi_bwd(
     __bf16* __restrict__ dTt,    // [B][dk][Rp] r-permuted
     float* __restrict__ Delta,   // [B][Rp]
     float* __restrict__ LSEp,    // [B][Rp] padded with +1e30
-    int B, float* __restrict__ zero_ptr, int zero_n) {   // optional: clears the DG accumulator
-  extern __shared__ float sm[];
-  if (zero_ptr != nullptr)
-    for (int i = blockIdx.x * 256 + threadIdx.x; i < zero_n; i += gridDim.x * 256)
-      zero_ptr[i] = 0.f;
-  float* sdZ = sm;               // [m][d]
-  float* sdO = sdZ + m * d;      // [m][d]
-  float* sDl = sdO + m * d;      // [Rp] partial Delta
-  const int b = blockIdx.x, tid = threadIdx.x;
-  const int R = h * m, dh = d / h;
-  for (int o = tid; o < m * d; o += 256) {
-    const float g = dH[(int64_t)b * m * d + o];
-    const float z = Z[(int64_t)b * m * d + o];
-    const float v = z > 0.f ? g : 0.f;
-    sdZ[o] = v;
-    dZ[(int64_t)b * m * d + o] = v;
-  }
-  for (int i = tid; i < Rp; i += 256) sDl[i] = 0.f;
-  __syncthreads();
-  const int c = tid % d;
-  // PMA (one seed): the second half of the workgroup takes the second half of the
-  // contraction over fc_o and the heads 2, 3 of the dT products instead of idling
-  const bool pma = MQ == 1 && m == 1 && (h % 2) == 0;
-  const int half = tid / d;
-  int q0 = half * MQ;
-  bool act = q0 < m;
-  if (pma) {
-    float* part = sDl + Rp;                 // [d] scratch behind the Delta slots
-    float a1[1] = {half == 0 ? dH[(int64_t)b * d + c] : 0.f};
-    col_gemm<1>(sdZ + half * (d / 2), d, Wo + (int64_t)half * (d / 2) * d, d, d / 2, c, a1);
-    if (half == 1) part[c] = a1[0];
-    __syncthreads();
-    if (half == 0) {
-      a1[0] += part[c];
-      sdO[c] = a1[0];
-      dO[(int64_t)b * d + c] = a1[0];
-    }
-    q0 = 0;
-    act = true;
-  } else if (act) {
-    float acc[MQ];
-#pragma unroll
-    for (int q = 0; q < MQ; ++q)
-      acc[q] = (q0 + q < m) ? dH[(int64_t)b * m * d + (q0 + q) * d + c] : 0.f;
-    col_gemm<MQ>(sdZ + q0 * d, d, Wo, d, d, c, acc);
-#pragma unroll
-    for (int q = 0; q < MQ; ++q)
-      if (q0 + q < m) {
-        sdO[(q0 + q) * d + c] = acc[q];
-        dO[(int64_t)b * m * d + (q0 + q) * d + c] = acc[q];
-      }
-  }
-  __syncthreads();
-  // dT[j m + q][cc] = sum_f dO[q][j dh + f] Wv[j dh + f][cc] ; thread owns column cc of dk
-  const int j_lo = pma ? half * (h / 2) : 0, j_hi = pma ? j_lo + h / 2 : h;
-  for (int cc = tid % d; cc < dk && act; cc += d) {
-    for (int j = j_lo; j < j_hi; ++j) {
-      float acc[MQ];
-#pragma unroll
-      for (int q = 0; q < MQ; ++q) acc[q] = 0.f;
-      col_gemm<MQ>(sdO + q0 * d + j * dh, d, Wv + (int64_t)j * dh * dk, dk, dh, cc, acc);
-#pragma unroll
-      for (int q = 0; q < MQ; ++q) {
-        if (q0 + q >= m) continue;
-        const int r = j * m + q0 + q;
-        const float tv = T[((int64_t)b * R + r) * dk + cc];
-        Th[((int64_t)j * B * m + (int64_t)b * m + q0 + q) * dk + cc] = tv;
-        atomicAdd(&sDl[r], acc[q] * tv);
-        if (dTf != nullptr) dTf[((int64_t)b * R + r) * dk + cc] = acc[q];
-        if (dTb != nullptr) {
-          dTb[((int64_t)b * Rp + r) * dk + cc] = (__bf16)acc[q];
-          const int rb32 = r & ~31, ro = r & 31;
-          int pos = 0;
-#pragma unroll
-          for (int p = 0; p < 32; ++p)
-            if (perm32(p) == ro) pos = p;
-          dTt[((int64_t)b * dk + cc) * Rp + rb32 + pos] = (__bf16)acc[q];
-        }
-      }
-    }
-  }
-  __syncthreads();
-  for (int r = tid; r < Rp; r += 256) {
-    Delta[(int64_t)b * Rp + r] = r < R ? sDl[r] : 0.f;
-    LSEp[(int64_t)b * Rp + r] = r < R ? LSE[(int64_t)b * R + r] : 1.0e30f;
-  }
-  if (dTb != nullptr) {          // zero the padding rows / columns of the bf16 images
-    for (int o = tid; o < (Rp - R) * dk; o += 256) {
-      const int r = R + o / dk, cc = o % dk;
-      dTb[((int64_t)b * Rp + r) * dk + cc] = (__bf16)0.f;
-      const int rb32 = r & ~31, ro = r & 31;
-      int pos = 0;
-#pragma unroll
-      for (int p = 0; p < 32; ++p)
-        if (perm32(p) == ro) pos = p;
-      dTt[((int64_t)b * dk + cc) * Rp + rb32 + pos] = (__bf16)0.f;
-    }
-  }
+    int B, float* __restrict__ zero_ptr, int zero_n) {
+  mab0_epi_bwd_body<MQ>(dH, Z, T, LSE, Wo, Wv, m, d, dk, h, Rp, dZ, dO, Th, dTf, dTb, dTt, Delta, LSEp, B, zero_ptr, zero_n, blockIdx.x);
 }
 
 // G'^T image shared by all sets: GtP[c][32 s + p] = G'[32 s + perm32(p)][c]  (zero padding)
@@ -553,6 +458,78 @@ __global__ __launch_bounds__(256) void k_mab0_post2(const Mab0PostJobs jobs) {
 }
 
 }  // namespace
+namespace {
+struct PmaHeadArgs {
+  // forward epilogue
+  const float *Tp, *Mp, *Lp;
+  int S;
+  float *T, *LSE;
+  const float *Qp, *WvT, *bv, *WoT, *bo;
+  int m, d, dk, h;
+  float *H, *Osave, *Zsave;
+  // classifier + loss
+  const float *Wc, *bc;
+  const int64_t* labels;
+  int B, C;
+  float grad_scale;
+  float *logits, *dlogits, *dP, *lossv, *corrv;
+  // backward epilogue
+  const float *Wo, *Wv;
+  int Rp;
+  float *dZ, *dO, *Th, *dTf;
+  __bf16 *dTb, *dTt;
+  float *Delta, *LSEp, *zero_ptr;
+  int zero_n;
+};
+// Everything a set needs between its attention forward and its attention backward.  The stages
+// hand over through global memory written by this very workgroup (H = pooled features, Z, T,
+// LSE, dP): a workgroup barrier makes those stores visible to the next stage.
+__global__ __launch_bounds__(256) void k_pma_head(const PmaHeadArgs a) {
+  const int b = blockIdx.x;
+  mab0_epi_body<1>(a.Tp, a.Mp, a.Lp, a.S, a.T, a.LSE, a.Qp, a.WvT, a.bv, a.WoT, a.bo, a.m, a.d,
+                   a.dk, a.h, a.H, a.Osave, a.Zsave, b);
+  __syncthreads();
+  cls_fwd_bwd_body(a.H, a.Wc, a.bc, a.labels, a.B, a.d, a.C, a.grad_scale, a.logits, a.dlogits,
+                   a.dP, a.lossv, a.corrv, b);
+  __syncthreads();
+  mab0_epi_bwd_body<1>(a.dP, a.Zsave, a.T, a.LSE, a.Wo, a.Wv, a.m, a.d, a.dk, a.h, a.Rp, a.dZ,
+                       a.dO, a.Th, a.dTf, a.dTb, a.dTt, a.Delta, a.LSEp, a.B, a.zero_ptr,
+                       a.zero_n, b);
+}
+}  // namespace
+
+int pma_head_launch(const pca_mab_shape& s, const pca_mab_params& p, void* saved, void* ws_bwd,
+                    float* P, const float* Wc, const float* bc, const int64_t* labels, int C,
+                    float grad_scale, float* logits, float* dlogits, float* dP, float* dWc,
+                    float* dbc, float* loss_out, float* stats, float* cls_ws, BwdDefer* defer,
+                    hipStream_t st) {
+  PCA_REQUIRE(s.nq == 1 && s.dk > 4 && defer != nullptr, "pma_head: needs the fused PMA (k = 1)");
+  Mab0Saved v;
+  mab0_carve_saved(s, &v, saved);
+  Mab0BwdWs w;
+  mab0_carve_bwd_ws(s, &w, ws_bwd);
+  const int d = s.d, m = s.nq, h = s.h, dk = s.dk, R = h * m, Rp = (int)cdiv(R, 32) * 32;
+  PmaHeadArgs a{};
+  a.Tp = v.Tp; a.Mp = v.Mp; a.Lp = v.Lp; a.S = mab0_splits(s); a.T = v.T; a.LSE = v.LSE;
+  a.Qp = v.Qp; a.WvT = v.WvT; a.bv = p.bv; a.WoT = v.WoT; a.bo = p.bo;
+  a.m = m; a.d = d; a.dk = dk; a.h = h; a.H = P; a.Osave = v.O; a.Zsave = v.Z;
+  a.Wc = Wc; a.bc = bc; a.labels = labels; a.B = s.B; a.C = C; a.grad_scale = grad_scale;
+  a.logits = logits; a.dlogits = dlogits; a.dP = dP; a.lossv = cls_ws; a.corrv = cls_ws + s.B;
+  a.Wo = p.wo; a.Wv = p.wv; a.Rp = Rp; a.dZ = w.dZ; a.dO = w.dO; a.Th = w.Th; a.dTf = nullptr;
+  a.dTb = w.dTb; a.dTt = w.dTt; a.Delta = w.Delta; a.LSEp = w.LSEp;
+  a.zero_ptr = w.DG; a.zero_n = Rp * dk;
+  size_t lds = ((size_t)R * dk + (size_t)m * d) * sizeof(float);
+  const size_t l2 = (size_t)(d + C) * sizeof(float);
+  const size_t l3 = (2 * (size_t)m * d + (size_t)Rp + (size_t)d) * sizeof(float);
+  lds = lds > l2 ? lds : l2;
+  lds = lds > l3 ? lds : l3;
+  hipLaunchKernelGGL(k_pma_head, dim3(s.B), dim3(256), lds, st, a);
+  PCA_TRY(check_launch("k_pma_head"));
+  defer->cls = ClsWgradArgs{dlogits, P, a.lossv, a.corrv, s.B, d, C, dWc, dbc, loss_out, stats};
+  defer->has_cls = 1;
+  return PCA_OK;
+}
+
 int terminal_launch(const BwdDefer& D, hipStream_t st) {
   if (!D.has_cls && !D.has_sw) return mab0_post_launch(D.posts, st);
   const Mab0PostJobs& J = D.posts;

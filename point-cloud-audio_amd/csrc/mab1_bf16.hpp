@@ -288,6 +288,15 @@ struct BwdDefer {
   int has_cls, has_sw;
 };
 int bwd_defer_flush(BwdDefer& D, hipStream_t st);
+// PMA epilogue + classifier + cross-entropy (forward and backward) + PMA backward epilogue of the
+// train step in ONE launch per set (after mab0_bf16_fwd_ex(..., PCA_F_SKIP_EPILOGUE); followed
+// by mab0_bf16_bwd_ex(..., PCA_F_SKIP_HEAD)).  P [B, d] receives the pooled features; the
+// classifier's weight gradient is queued in `defer`.  ws_bwd is the PMA's backward workspace.
+int pma_head_launch(const pca_mab_shape& s, const pca_mab_params& p, void* saved, void* ws_bwd,
+                    float* P, const float* Wc, const float* bc, const int64_t* labels, int C,
+                    float grad_scale, float* logits, float* dlogits, float* dP, float* dWc,
+                    float* dbc, float* loss_out, float* stats, float* cls_ws, BwdDefer* defer,
+                    hipStream_t st);
 int terminal_launch(const BwdDefer& D, hipStream_t st);    // post stages + riders
 // launch `jobs` now, or append them to the matching list of `defer`
 int wgrad128_defer(BwdDefer* defer, const WgradJobs& jobs, bool bf16, int rows_per_wg,

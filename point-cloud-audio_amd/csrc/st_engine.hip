@@ -222,8 +222,10 @@ int forward(const pca_st_config& c, const Layout& L, const Shapes& s, const floa
     in = w.Y[li];
   }
   if (training && mab_kind(s.pma) == 2)                                   // modules.py:63
+    // (its epilogue runs inside k_pma_head together with the classifier and the loss)
     PCA_TRY(mab0_bf16_fwd_ex(s.pma, p + L.S, w.Y[1], params_at(p, L.pma), w.P, w.saved[4],
-                             w.scratch, PCA_F_PREP_DONE, st));
+                             w.scratch, PCA_F_PREP_DONE | (c.k == 1 ? PCA_F_SKIP_EPILOGUE : 0),
+                             st));
   else
     PCA_TRY(mab_fwd_any(s.pma, p + L.S, w.Y[1], params_at(p, L.pma), w.P,
                         training ? w.saved[4] : nullptr, w.scratch, st));
@@ -299,19 +301,26 @@ int pca_st_train_fwd_bwd(const pca_st_config* c, const float* params, const floa
   pca::BwdDefer posts{};
   if (phase != 1) {
     PCA_TRY(pca::forward(*c, L, s, p, X, w, true, st));
-    // dec.1 (Linear) + mean cross-entropy, forward and backward, two launches
+    if (pca::mab_kind(s.pma) == 2) {
+      // dec.0 epilogue + dec.1 (Linear) + mean cross-entropy forward and backward + dec.0
+      // backward epilogue: one launch, one workgroup per set
+      PCA_TRY(pca::pma_head_launch(s.pma, pca::params_at(p, L.pma), w.saved[4], w.scratch, w.P,
+                                   p + L.wc, p + L.bc, labels, c->C, grad_scale, w.logits,
+                                   w.dlogits, w.dP, g + L.wc, g + L.bc, loss_out, stats,
+                                   w.clsws, &posts, st));
+      PCA_TRY(pca::mab0_bf16_bwd_ex(s.pma, p + L.S, w.Y[1], pca::params_at(p, L.pma),
+                                    w.saved[4], w.dP, g + L.S, w.dY2, 0,
+                                    pca::grads_at(g, L.pma), w.scratch, pca::PCA_F_SKIP_HEAD, st,
+                                    &posts));
+    } else {
+    // dec.1 (Linear) + mean cross-entropy, forward and backward
     PCA_TRY(pca::cls_train_head(w.P, p + L.wc, p + L.bc, labels, c->B, c->d, c->C, grad_scale,
                                 w.logits, w.dlogits, w.dP, g + L.wc, g + L.bc, loss_out, stats,
                                 w.clsws, st, &posts));
-    // dec.0 (PMA)
-    if (pca::mab_kind(s.pma) == 2)
-      PCA_TRY(pca::mab0_bf16_bwd_ex(s.pma, p + L.S, w.Y[1], pca::params_at(p, L.pma),
-                                    w.saved[4], w.dP, g + L.S, w.dY2, 0,
-                                    pca::grads_at(g, L.pma), w.scratch, 0, st, &posts));
-    else
     PCA_TRY(pca::mab_bwd_any(s.pma, p + L.S, w.Y[1], pca::params_at(p, L.pma), w.saved[4],
                              w.dP, g + L.S, w.dY2, 0, pca::grads_at(g, L.pma), w.scratch,
                              st));
+    }
     // enc.1: mab1(Y1, H2) then mab0(I2, Y1); Y1 feeds both, so dY1 accumulates
     if (w.fused[1]) {
       PCA_TRY(pca::isab_bf16_bwd(s.m0[1], s.m1[1], p + L.I[1], w.Y[0], w.H[1],

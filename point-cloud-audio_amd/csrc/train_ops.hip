@@ -3,6 +3,7 @@
 // coupled weight decay as one fused pass over a flat parameter vector.
 #include "mab1_bf16.hpp"
 #include "terminal_bodies.hpp"
+#include "pma_head_bodies.hpp"
 
 namespace pca {
 namespace {
@@ -66,80 +67,7 @@ __global__ __launch_bounds__(128) void k_cls_fwd_bwd(
     const int64_t* __restrict__ labels, int B, int d, int C, float grad_scale,
     float* __restrict__ logits, float* __restrict__ dlogits, float* __restrict__ dP,
     float* __restrict__ lossv, float* __restrict__ corrv) {
-  extern __shared__ float sm[];
-  float* sP = sm;            // [d]
-  float* sL = sP + d;        // [C] logits, then dlogits
-  __shared__ float red[2];
-  __shared__ int ramax;
-  const int b = blockIdx.x, tid = threadIdx.x;
-  for (int f = tid; f < d; f += 128) sP[f] = P[(int64_t)b * d + f];
-  __syncthreads();
-  for (int c = tid; c < C; c += 128) {
-    const float* w = Wc + (int64_t)c * d;
-    float acc = bc[c];
-    int f = 0;
-    for (; f + 32 <= d; f += 32) {          // 8 independent 16-byte loads in flight
-      float4 w4[8];
-#pragma unroll
-      for (int u = 0; u < 8; ++u) w4[u] = *reinterpret_cast<const float4*>(w + f + 4 * u);
-#pragma unroll
-      for (int u = 0; u < 8; ++u)
-        acc += sP[f + 4 * u] * w4[u].x + sP[f + 4 * u + 1] * w4[u].y + sP[f + 4 * u + 2] * w4[u].z +
-               sP[f + 4 * u + 3] * w4[u].w;
-    }
-    for (; f < d; f += 4) {
-      const float4 w4 = *reinterpret_cast<const float4*>(w + f);
-      acc += sP[f] * w4.x + sP[f + 1] * w4.y + sP[f + 2] * w4.z + sP[f + 3] * w4.w;
-    }
-    sL[c] = acc;
-    logits[(int64_t)b * C + c] = acc;
-  }
-  __syncthreads();
-  if (tid < 64) {            // one wave: max / argmax / sum over the C logits
-    float m = -INFINITY;
-    int am = 0x7fffffff;
-    for (int j = tid; j < C; j += 64)
-      if (sL[j] > m) { m = sL[j]; am = j; }
-#pragma unroll
-    for (int o = 32; o > 0; o >>= 1) {
-      const float om = __shfl_xor(m, o, 64);
-      const int oa = __shfl_xor(am, o, 64);
-      if (om > m || (om == m && oa < am)) { m = om; am = oa; }
-    }
-    float s = 0.f;
-    for (int j = tid; j < C; j += 64) s += expf(sL[j] - m);
-#pragma unroll
-    for (int o = 32; o > 0; o >>= 1) s += __shfl_xor(s, o, 64);
-    if (tid == 0) { red[0] = m; red[1] = s; ramax = am; }
-  }
-  __syncthreads();
-  const float m = red[0], s = red[1];
-  const int64_t y = labels[b];
-  const float gs = grad_scale / (float)B;
-  if (tid == 0) {
-    lossv[b] = m + logf(s) - sL[y];
-    corrv[b] = ramax == (int)y ? 1.f : 0.f;
-  }
-  __syncthreads();
-  for (int c = tid; c < C; c += 128) {
-    const float g = (expf(sL[c] - m) / s - (c == y ? 1.f : 0.f)) * gs;
-    sL[c] = g;
-    dlogits[(int64_t)b * C + c] = g;
-  }
-  __syncthreads();
-  for (int f = tid; f < d; f += 128) {
-    float acc = 0.f;
-    int c = 0;
-    for (; c + 10 <= C; c += 10) {          // 10 independent loads in flight
-      float wv[10];
-#pragma unroll
-      for (int u = 0; u < 10; ++u) wv[u] = Wc[(int64_t)(c + u) * d + f];
-#pragma unroll
-      for (int u = 0; u < 10; ++u) acc = fmaf(sL[c + u], wv[u], acc);
-    }
-    for (; c < C; ++c) acc += sL[c] * Wc[(int64_t)c * d + f];
-    dP[(int64_t)b * d + f] = acc;
-  }
+  cls_fwd_bwd_body(P, Wc, bc, labels, B, d, C, grad_scale, logits, dlogits, dP, lossv, corrv, blockIdx.x);
 }
 
 __global__ __launch_bounds__(128) void k_cls_wgrad(
