@@ -121,19 +121,35 @@ __global__ __launch_bounds__(256, 1) void k_mab0_bwd(const Mab0BwdArgs a) {
   int len = a.N;
   if (a.lengths != nullptr) len = a.lengths[b] < a.N ? a.lengths[b] : a.N;
 
-  for (int c = tid; c < RP * 16; c += 256) {
-    const int row = c >> 4, ch = c & 15;
-    *reinterpret_cast<uint4*>(sG + tr_off(row, ch)) =
-        *reinterpret_cast<const uint4*>(a.Gb + (int64_t)row * DK + ch * 8);
-    *reinterpret_cast<uint4*>(sdT + tr_off(row, ch)) =
-        *reinterpret_cast<const uint4*>(a.dTb + ((int64_t)b * RP + row) * DK + ch * 8);
-  }
-  for (int c = tid; c < DK * (RP / 8); c += 256) {
-    const int row = c / (RP / 8), ch = c % (RP / 8);
-    *reinterpret_cast<uint4*>(sGt + rp_off<RP>(row, ch)) =
-        *reinterpret_cast<const uint4*>(a.GtP + (int64_t)row * RP + ch * 8);
-    *reinterpret_cast<uint4*>(sdTt + rp_off<RP>(row, ch)) =
-        *reinterpret_cast<const uint4*>(a.dTt + ((int64_t)b * DK + row) * RP + ch * 8);
+  {
+    // all image chunks of this thread are fetched before the first LDS store: one round trip
+    // instead of one per loop iteration (the stores would order the loads behind them)
+    constexpr int NA = RP * 16 / 256, NB2 = DK * (RP / 8) / 256;
+    uint4 g1[NA], t1[NA], g2[NB2], t2[NB2];
+#pragma unroll
+    for (int e = 0; e < NA; ++e) {
+      const int c = tid + 256 * e, row = c >> 4, ch = c & 15;
+      g1[e] = *reinterpret_cast<const uint4*>(a.Gb + (int64_t)row * DK + ch * 8);
+      t1[e] = *reinterpret_cast<const uint4*>(a.dTb + ((int64_t)b * RP + row) * DK + ch * 8);
+    }
+#pragma unroll
+    for (int e = 0; e < NB2; ++e) {
+      const int c = tid + 256 * e, row = c / (RP / 8), ch = c % (RP / 8);
+      g2[e] = *reinterpret_cast<const uint4*>(a.GtP + (int64_t)row * RP + ch * 8);
+      t2[e] = *reinterpret_cast<const uint4*>(a.dTt + ((int64_t)b * DK + row) * RP + ch * 8);
+    }
+#pragma unroll
+    for (int e = 0; e < NA; ++e) {
+      const int c = tid + 256 * e, row = c >> 4, ch = c & 15;
+      *reinterpret_cast<uint4*>(sG + tr_off(row, ch)) = g1[e];
+      *reinterpret_cast<uint4*>(sdT + tr_off(row, ch)) = t1[e];
+    }
+#pragma unroll
+    for (int e = 0; e < NB2; ++e) {
+      const int c = tid + 256 * e, row = c / (RP / 8), ch = c % (RP / 8);
+      *reinterpret_cast<uint4*>(sGt + rp_off<RP>(row, ch)) = g2[e];
+      *reinterpret_cast<uint4*>(sdTt + rp_off<RP>(row, ch)) = t2[e];
+    }
   }
   for (int i = tid; i < RP; i += 256) {
     sLSE[i] = a.LSEp[(int64_t)b * RP + i];
