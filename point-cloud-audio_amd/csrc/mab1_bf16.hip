@@ -175,13 +175,23 @@ __global__ __launch_bounds__(64 * NW, NW == 8 ? 1 : 2) void k_mab1_fwd(const Mab
   const int r = lane & 15, g = lane >> 4;
 
   // ---- weights -> LDS once per workgroup (16-byte chunks, swizzled rows) ----
-  for (int c = tid; c < D * (D / 8); c += NT) {
-    const int row = c / (D / 8), c16 = c % (D / 8);
-    *reinterpret_cast<uint4*>(sWo + swz(row, c16, ROWB)) =
-        *reinterpret_cast<const uint4*>(a.WoP + (int64_t)row * D + c16 * 8);
-    if (!DIN_SMALL)
-      *reinterpret_cast<uint4*>(sWq + swz(row, c16, ROWB)) =
-          *reinterpret_cast<const uint4*>(a.WqB + (int64_t)row * D + c16 * 8);
+  {
+    // all chunks of this thread first, then the LDS stores: one round trip instead of one per
+    // iteration (a store between two loads orders them)
+    constexpr int NC = D * (D / 8) / NT;
+    uint4 wo[NC], wq[DIN_SMALL ? 1 : NC];
+#pragma unroll
+    for (int e = 0; e < NC; ++e) {
+      const int c = tid + NT * e, row = c / (D / 8), c16 = c % (D / 8);
+      wo[e] = *reinterpret_cast<const uint4*>(a.WoP + (int64_t)row * D + c16 * 8);
+      if (!DIN_SMALL) wq[e] = *reinterpret_cast<const uint4*>(a.WqB + (int64_t)row * D + c16 * 8);
+    }
+#pragma unroll
+    for (int e = 0; e < NC; ++e) {
+      const int c = tid + NT * e, row = c / (D / 8), c16 = c % (D / 8);
+      *reinterpret_cast<uint4*>(sWo + swz(row, c16, ROWB)) = wo[e];
+      if (!DIN_SMALL) *reinterpret_cast<uint4*>(sWq + swz(row, c16, ROWB)) = wq[e];
+    }
   }
 
   const int units_per_set = (a.tiles_per_set + SUBS - 1) / SUBS;   // SUBS tiles per workgroup pass

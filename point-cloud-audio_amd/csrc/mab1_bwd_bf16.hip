@@ -104,13 +104,22 @@ void k_mab1_bwd(const Mab1BwdArgs a) {
   int dbg_n = 0; (void)dbg_n;
   PCA_STAMP(0);
 
-  for (int c = tid; c < D * (D / 8); c += NT) {
-    const int row = c / (D / 8), c16 = c % (D / 8);
-    *reinterpret_cast<uint4*>(sWoT + swz(row, c16, ROWB)) =
-        *reinterpret_cast<const uint4*>(a.WoTP + (int64_t)row * D + c16 * 8);
-    if (WANT_DX)
-      *reinterpret_cast<uint4*>(sWqT + swz(row, c16, ROWB)) =
-          *reinterpret_cast<const uint4*>(a.WqTP + (int64_t)row * D + c16 * 8);
+  {
+    // all chunks of this thread first, then the LDS stores (one round trip, not one per chunk)
+    constexpr int NC = D * (D / 8) / NT;
+    uint4 wo[NC], wq[WANT_DX ? NC : 1];
+#pragma unroll
+    for (int e = 0; e < NC; ++e) {
+      const int c = tid + NT * e, row = c / (D / 8), c16 = c % (D / 8);
+      wo[e] = *reinterpret_cast<const uint4*>(a.WoTP + (int64_t)row * D + c16 * 8);
+      if (WANT_DX) wq[e] = *reinterpret_cast<const uint4*>(a.WqTP + (int64_t)row * D + c16 * 8);
+    }
+#pragma unroll
+    for (int e = 0; e < NC; ++e) {
+      const int c = tid + NT * e, row = c / (D / 8), c16 = c % (D / 8);
+      *reinterpret_cast<uint4*>(sWoT + swz(row, c16, ROWB)) = wo[e];
+      if (WANT_DX) *reinterpret_cast<uint4*>(sWqT + swz(row, c16, ROWB)) = wq[e];
+    }
   }
 
   const int total_tiles = a.B * a.tiles_per_set;
