@@ -319,6 +319,10 @@ typedef struct pca_gemm_desc {
 } pca_gemm_desc;
 int pca_gemm_f32(const pca_gemm_desc* g, const float* A, const float* B,
                  const float* bias, float* C, void* stream);
+/* same contract; A and B are rounded to bf16 on their way into the MFMA (fp32 accumulate):
+ * what PCA_MODE_BF16 runs for the blocks that have no fused kernel */
+int pca_gemm_bf16(const pca_gemm_desc* g, const float* A, const float* B,
+                  const float* bias, float* C, void* stream);
 
 /* rows of length n: X <- softmax(X * scale) in place */
 int pca_softmax_rows(float* X, int64_t rows, int n, float scale, void* stream);

@@ -3,11 +3,12 @@
 // configs[3], the shipped d = 64 / 8-head models).  Same descriptor, strides, batching, split-K
 // and epilogue as k_gemm_f32 (gemm_f32.hip); the inner product is v_mfma_f32_16x16x32_bf16.
 //
-// A 256-thread workgroup computes a 128x128 tile of C; wave w owns the 64x64 quadrant
-// (w >> 1, w & 1) as 4x4 MFMA tiles (16 MFMAs per 8 fragment reads).  fp32 operands are rounded
-// to bf16 while they are staged: As[m][k] and Bs[n][k] (k contiguous, 80-byte rows: 16-byte
-// fragment reads, rows spread over the LDS banks).  Staging is vectorised along whichever index
-// is contiguous in memory and the next K tile is prefetched into registers under the MFMAs.
+// A 256-thread workgroup computes one tile of C, its four waves 2 x 2; the tile shape follows the
+// problem (128x128 in general, 256x32 / 256x64 / 32x256 / 64x256 / 32x32 for the skinny
+// per-head products of the attention, see tile_variant()).  fp32 operands are rounded to bf16
+// while they are staged: As[m][k] and Bs[n][k] (k contiguous, 80-byte rows: 16-byte fragment
+// reads, rows spread over the LDS banks).  Staging is vectorised along whichever index is
+// contiguous in memory and the next K tile is prefetched into registers under the MFMAs.
 #include "pca_common.h"
 
 #include <stdint.h>
@@ -16,91 +17,140 @@
 namespace pca {
 
 namespace {
-constexpr int BM = 128, BN = 128, BK = 32, PITCH = 80;   // bytes per LDS row (32 bf16 + pad)
+constexpr int BK = 32, PITCH = 80;   // bytes per LDS row (32 bf16 + pad)
 
-// Stage a [128 rows][32 k] operand tile into LDS as bf16, rows = the non-contracted index.
+// Stage an [R rows][32 k] operand tile into LDS as bf16, rows = the non-contracted index.
 //   elem(i, k) = P[i * s_row + k * s_k]; rows >= n_rows and k >= k_left read as zero.
-// KVEC: s_k == 1   -> float4 along k, one 8-byte LDS store
-// RVEC: s_row == 1 -> float4 along the rows, 4x4 register transpose, 8-byte LDS stores
-// else scalar.  VEC needs 16-byte aligned addresses (checked by the host).
-template <int MODE>
-__device__ __forceinline__ void stage_load(const float* __restrict__ P, int64_t s_row, int64_t s_k,
-                                           int64_t n_rows, int64_t k_left, int tid,
-                                           float (&v)[16]) {
-  if (MODE == 0) {              // KVEC: 128 x 8 float4; thread -> 4 of them
+// KVEC (0): s_k == 1   -> float4 along k, one 8-byte LDS store
+// RVEC (1): s_row == 1 -> float4 along the rows; R >= 128: 4x4 register transpose and 8-byte
+//                         LDS stores, R < 128: R/32 float4 per thread, 2-byte stores
+// else (2) scalar.  VEC needs 16-byte aligned addresses (checked by the host).
+template <int MODE, int R>
+struct Stage {
+  // floats per thread
+  static constexpr int NV = R / 8;
+
+  static __device__ __forceinline__ void load(const float* __restrict__ P, int64_t s_row,
+                                              int64_t s_k, int64_t n_rows, int64_t k_left,
+                                              int tid, float (&v)[NV]) {
+    if constexpr (MODE == 0) {              // R x 8 float4; thread -> R/32 of them
 #pragma unroll
-    for (int e = 0; e < 4; ++e) {
-      const int idx = tid + e * 256;
-      const int i = idx >> 3, k4 = (idx & 7) * 4;
-      const float* src = P + i * s_row + k4;
-      if (i < n_rows && k4 + 3 < k_left) {
-        const float4 t = *reinterpret_cast<const float4*>(src);
-        v[4 * e] = t.x; v[4 * e + 1] = t.y; v[4 * e + 2] = t.z; v[4 * e + 3] = t.w;
-      } else {
+      for (int e = 0; e < R / 32; ++e) {
+        const int idx = tid + e * 256;
+        const int i = idx >> 3, k4 = (idx & 7) * 4;
+        const float* src = P + i * s_row + k4;
+        if (i < n_rows && k4 + 3 < k_left) {
+          const float4 t = *reinterpret_cast<const float4*>(src);
+          v[4 * e] = t.x; v[4 * e + 1] = t.y; v[4 * e + 2] = t.z; v[4 * e + 3] = t.w;
+        } else {
 #pragma unroll
-        for (int u = 0; u < 4; ++u) v[4 * e + u] = (i < n_rows && k4 + u < k_left) ? src[u] : 0.f;
+          for (int u = 0; u < 4; ++u)
+            v[4 * e + u] = (i < n_rows && k4 + u < k_left) ? src[u] : 0.f;
+        }
+      }
+    } else if constexpr (MODE == 1 && R >= 128) {   // 4 rows x 4 k blocks, float4 along the rows
+#pragma unroll
+      for (int e = 0; e < R / 128; ++e) {
+        const int bi = tid + e * 256;
+        const int i4 = (bi % (R / 4)) * 4, k4 = (bi / (R / 4)) * 4;
+#pragma unroll
+        for (int u = 0; u < 4; ++u) {
+          const float* src = P + i4 + (k4 + u) * s_k;
+          if (k4 + u < k_left && i4 + 3 < n_rows) {
+            const float4 t = *reinterpret_cast<const float4*>(src);
+            v[16 * e + 4 * u] = t.x; v[16 * e + 4 * u + 1] = t.y;
+            v[16 * e + 4 * u + 2] = t.z; v[16 * e + 4 * u + 3] = t.w;
+          } else {
+#pragma unroll
+            for (int rr = 0; rr < 4; ++rr)
+              v[16 * e + 4 * u + rr] = (k4 + u < k_left && i4 + rr < n_rows) ? src[rr] : 0.f;
+          }
+        }
+      }
+    } else if constexpr (MODE == 1) {       // R < 128: R/4 float4 along the rows x 32 k
+#pragma unroll
+      for (int e = 0; e < R / 32; ++e) {
+        const int idx = tid + e * 256;
+        const int i4 = (idx % (R / 4)) * 4, k = idx / (R / 4);
+        const float* src = P + i4 + k * s_k;
+        if (k < k_left && i4 + 3 < n_rows) {
+          const float4 t = *reinterpret_cast<const float4*>(src);
+          v[4 * e] = t.x; v[4 * e + 1] = t.y; v[4 * e + 2] = t.z; v[4 * e + 3] = t.w;
+        } else {
+#pragma unroll
+          for (int rr = 0; rr < 4; ++rr)
+            v[4 * e + rr] = (k < k_left && i4 + rr < n_rows) ? src[rr] : 0.f;
+        }
+      }
+    } else {
+#pragma unroll
+      for (int e = 0; e < R / 8; ++e) {
+        const int idx = tid + e * 256;
+        const int i = idx >> 5, k = idx & 31;
+        v[e] = (i < n_rows && k < k_left) ? P[i * s_row + k * s_k] : 0.f;
       }
     }
-  } else if (MODE == 1) {       // RVEC: one 4 rows x 4 k block per thread, float4 along the rows
-    const int i4 = (tid & 31) * 4, k4 = (tid >> 5) * 4;
+  }
+
+  static __device__ __forceinline__ void store(char* S, int tid, const float (&v)[NV]) {
+    if constexpr (MODE == 0) {
 #pragma unroll
-    for (int u = 0; u < 4; ++u) {
-      const float* src = P + i4 + (k4 + u) * s_k;
-      if (k4 + u < k_left && i4 + 3 < n_rows) {
-        const float4 t = *reinterpret_cast<const float4*>(src);
-        v[4 * u] = t.x; v[4 * u + 1] = t.y; v[4 * u + 2] = t.z; v[4 * u + 3] = t.w;
-      } else {
+      for (int e = 0; e < R / 32; ++e) {
+        const int idx = tid + e * 256;
+        const int i = idx >> 3, k4 = (idx & 7) * 4;
+        bf16x4 h;
+        h[0] = (__bf16)v[4 * e]; h[1] = (__bf16)v[4 * e + 1];
+        h[2] = (__bf16)v[4 * e + 2]; h[3] = (__bf16)v[4 * e + 3];
+        *reinterpret_cast<bf16x4*>(S + i * PITCH + k4 * 2) = h;
+      }
+    } else if constexpr (MODE == 1 && R >= 128) {   // transposed in registers, k contiguous
+#pragma unroll
+      for (int e = 0; e < R / 128; ++e) {
+        const int bi = tid + e * 256;
+        const int i4 = (bi % (R / 4)) * 4, k4 = (bi / (R / 4)) * 4;
+#pragma unroll
+        for (int rr = 0; rr < 4; ++rr) {
+          bf16x4 h;
+          h[0] = (__bf16)v[16 * e + rr]; h[1] = (__bf16)v[16 * e + 4 + rr];
+          h[2] = (__bf16)v[16 * e + 8 + rr]; h[3] = (__bf16)v[16 * e + 12 + rr];
+          *reinterpret_cast<bf16x4*>(S + (i4 + rr) * PITCH + k4 * 2) = h;
+        }
+      }
+    } else if constexpr (MODE == 1) {
+#pragma unroll
+      for (int e = 0; e < R / 32; ++e) {
+        const int idx = tid + e * 256;
+        const int i4 = (idx % (R / 4)) * 4, k = idx / (R / 4);
 #pragma unroll
         for (int rr = 0; rr < 4; ++rr)
-          v[4 * u + rr] = (k4 + u < k_left && i4 + rr < n_rows) ? src[rr] : 0.f;
+          *reinterpret_cast<__bf16*>(S + (i4 + rr) * PITCH + k * 2) = (__bf16)v[4 * e + rr];
+      }
+    } else {
+#pragma unroll
+      for (int e = 0; e < R / 8; ++e) {
+        const int idx = tid + e * 256;
+        const int i = idx >> 5, k = idx & 31;
+        *reinterpret_cast<__bf16*>(S + i * PITCH + k * 2) = (__bf16)v[e];
       }
     }
-  } else {
-#pragma unroll
-    for (int e = 0; e < 16; ++e) {
-      const int idx = tid + e * 256;
-      const int i = idx >> 5, k = idx & 31;
-      v[e] = (i < n_rows && k < k_left) ? P[i * s_row + k * s_k] : 0.f;
-    }
   }
-}
-template <int MODE>
-__device__ __forceinline__ void stage_store(char* S, int tid, const float (&v)[16]) {
-  if (MODE == 0) {
-#pragma unroll
-    for (int e = 0; e < 4; ++e) {
-      const int idx = tid + e * 256;
-      const int i = idx >> 3, k4 = (idx & 7) * 4;
-      bf16x4 h;
-      h[0] = (__bf16)v[4 * e]; h[1] = (__bf16)v[4 * e + 1];
-      h[2] = (__bf16)v[4 * e + 2]; h[3] = (__bf16)v[4 * e + 3];
-      *reinterpret_cast<bf16x4*>(S + i * PITCH + k4 * 2) = h;
-    }
-  } else if (MODE == 1) {       // transposed in registers: 8-byte stores, k contiguous
-    const int i4 = (tid & 31) * 4, k4 = (tid >> 5) * 4;
-#pragma unroll
-    for (int rr = 0; rr < 4; ++rr) {
-      bf16x4 h;
-      h[0] = (__bf16)v[rr]; h[1] = (__bf16)v[4 + rr];
-      h[2] = (__bf16)v[8 + rr]; h[3] = (__bf16)v[12 + rr];
-      *reinterpret_cast<bf16x4*>(S + (i4 + rr) * PITCH + k4 * 2) = h;
-    }
-  } else {
-#pragma unroll
-    for (int e = 0; e < 16; ++e) {
-      const int idx = tid + e * 256;
-      const int i = idx >> 5, k = idx & 31;
-      *reinterpret_cast<__bf16*>(S + i * PITCH + k * 2) = (__bf16)v[e];
-    }
-  }
-}
+};
 
-template <int MA, int MB>
+// Workgroup tile (32 WM) x (32 WN): the four waves sit 2 x 2, each owns WM x WN MFMA tiles.
+//   (4,4) 128x128 general | (8,1) 256x32 and (8,2) 256x64: few output columns (attention of the
+//   "many queries" block: N = m or dh) | (1,8), (2,8): few output rows | (1,1): both small,
+//   long K (the per-head products that reduce over the points)
+// The MFMA runs transposed (B fragment as the first operand), so a lane ends up with four
+// consecutive columns of one row of C: 16-byte stores when C allows them (vec_c).
+template <int MA, int MB, int WM, int WN>
 __global__ __launch_bounds__(256) void k_gemm_bf16(pca_gemm_desc g, const float* __restrict__ A,
                                                     const float* __restrict__ B,
                                                     const float* __restrict__ bias,
                                                     float* __restrict__ C, int split_k,
-                                                    int64_t kchunk) {
+                                                    int64_t kchunk, int vec_c) {
+  constexpr int BM = 32 * WM, BN = 32 * WN;
+  using SA = Stage<MA, BM>;
+  using SB = Stage<MB, BN>;
   __shared__ __attribute__((aligned(16))) char As[BM * PITCH];
   __shared__ __attribute__((aligned(16))) char Bs[BN * PITCH];
 
@@ -117,59 +167,77 @@ __global__ __launch_bounds__(256) void k_gemm_bf16(pca_gemm_desc g, const float*
   const int64_t n0 = (int64_t)blockIdx.y * BN;
   const int64_t k_begin = (int64_t)ks * kchunk;
   const int64_t k_end = (k_begin + kchunk < g.K) ? (k_begin + kchunk) : g.K;
-  const int wm = 64 * (wave >> 1), wn = 64 * (wave & 1);
+  const int wm = 16 * WM * (wave >> 1), wn = 16 * WN * (wave & 1);
   const float* Ab = A + m0 * g.sa_m;
   const float* Bb = B + n0 * g.sb_n;
 
-  f32x4 acc[4][4];
+  f32x4 acc[WM][WN];
 #pragma unroll
-  for (int i = 0; i < 4; ++i)
+  for (int i = 0; i < WM; ++i)
 #pragma unroll
-    for (int j = 0; j < 4; ++j) acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
+    for (int j = 0; j < WN; ++j) acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
 
-  float av[16], bv[16];
-  stage_load<MA>(Ab + k_begin * g.sa_k, g.sa_m, g.sa_k, g.M - m0, k_end - k_begin, tid, av);
-  stage_load<MB>(Bb + k_begin * g.sb_k, g.sb_n, g.sb_k, g.N - n0, k_end - k_begin, tid, bv);
+  float av[SA::NV], bv[SB::NV];
+  SA::load(Ab + k_begin * g.sa_k, g.sa_m, g.sa_k, g.M - m0, k_end - k_begin, tid, av);
+  SB::load(Bb + k_begin * g.sb_k, g.sb_n, g.sb_k, g.N - n0, k_end - k_begin, tid, bv);
   for (int64_t kt = k_begin; kt < k_end; kt += BK) {
     __syncthreads();                     // previous tile consumed
-    stage_store<MA>(As, tid, av);
-    stage_store<MB>(Bs, tid, bv);
+    SA::store(As, tid, av);
+    SB::store(Bs, tid, bv);
     __syncthreads();
     if (kt + BK < k_end) {               // next tile's loads fly under the MFMAs
-      stage_load<MA>(Ab + (kt + BK) * g.sa_k, g.sa_m, g.sa_k, g.M - m0, k_end - kt - BK, tid, av);
-      stage_load<MB>(Bb + (kt + BK) * g.sb_k, g.sb_n, g.sb_k, g.N - n0, k_end - kt - BK, tid, bv);
+      SA::load(Ab + (kt + BK) * g.sa_k, g.sa_m, g.sa_k, g.M - m0, k_end - kt - BK, tid, av);
+      SB::load(Bb + (kt + BK) * g.sb_k, g.sb_n, g.sb_k, g.N - n0, k_end - kt - BK, tid, bv);
     }
-    bf16x8 af[4];
+    bf16x8 af[WM];
 #pragma unroll
-    for (int i = 0; i < 4; ++i)
+    for (int i = 0; i < WM; ++i)
       af[i] = *reinterpret_cast<const bf16x8*>(As + (wm + 16 * i + r) * PITCH + 16 * gq);
 #pragma unroll
-    for (int j = 0; j < 4; ++j) {
+    for (int j = 0; j < WN; ++j) {
       const bf16x8 bf = *reinterpret_cast<const bf16x8*>(Bs + (wn + 16 * j + r) * PITCH + 16 * gq);
 #pragma unroll
-      for (int i = 0; i < 4; ++i) acc[i][j] = mfma32(af[i], bf, acc[i][j]);
+      for (int i = 0; i < WM; ++i) acc[i][j] = mfma32(bf, af[i], acc[i][j]);
     }
   }
 
-  // D[row = 4 gq + e][col = r] of tile (i, j)
+  // transposed product: acc[i][j][e] = C[row = 16 i + r][col = 16 j + 4 gq + e]
 #pragma unroll
-  for (int i = 0; i < 4; ++i)
+  for (int i = 0; i < WM; ++i) {
+    const int64_t row = m0 + wm + 16 * i + r;
+    if (row >= g.M) continue;
 #pragma unroll
-    for (int e = 0; e < 4; ++e) {
-      const int64_t row = m0 + wm + 16 * i + 4 * gq + e;
-      if (row >= g.M) continue;
+    for (int j = 0; j < WN; ++j) {
+      const int64_t col = n0 + wn + 16 * j + 4 * gq;
+      if (col >= g.N) continue;
+      float* dst = C + row * g.sc_m + col;
+      float v[4];
 #pragma unroll
-      for (int j = 0; j < 4; ++j) {
-        const int64_t col = n0 + wn + 16 * j + r;
-        if (col >= g.N) continue;
-        float v = g.alpha * acc[i][j][e];
-        if (bias != nullptr && ks == 0) v += bias[col];
-        float* dst = C + row * g.sc_m + col;
-        if (split_k > 1) atomicAdd(dst, v);
-        else if (g.accumulate) *dst += v;
-        else *dst = v;
+      for (int e = 0; e < 4; ++e) {
+        v[e] = g.alpha * acc[i][j][e];
+        if (bias != nullptr && ks == 0 && col + e < g.N) v[e] += bias[col + e];
+      }
+      if (split_k > 1) {
+#pragma unroll
+        for (int e = 0; e < 4; ++e)
+          if (col + e < g.N) atomicAdd(dst + e, v[e]);
+      } else if (vec_c && col + 3 < g.N) {
+        float4 o = float4{v[0], v[1], v[2], v[3]};
+        if (g.accumulate) {
+          const float4 c = *reinterpret_cast<const float4*>(dst);
+          o.x += c.x; o.y += c.y; o.z += c.z; o.w += c.w;
+        }
+        *reinterpret_cast<float4*>(dst) = o;
+      } else {
+#pragma unroll
+        for (int e = 0; e < 4; ++e)
+          if (col + e < g.N) {
+            if (g.accumulate) dst[e] += v[e];
+            else dst[e] = v[e];
+          }
       }
     }
+  }
 }
 
 // staging mode of an operand: 0 k-vectors, 1 row-vectors, 2 scalar
@@ -178,6 +246,29 @@ inline int stage_mode(const float* p, int64_t s_row, int64_t s_k, int64_t b1, in
   if (s_k == 1 && s_row % 4 == 0 && al) return 0;
   if (s_row == 1 && s_k % 4 == 0 && al) return 1;
   return 2;
+}
+
+// tile shape for an (M, N) problem: index into {(4,4), (8,1), (8,2), (1,8), (2,8), (1,1)}
+inline int tile_variant(int64_t M, int64_t N) {
+  if (M <= 32 && N <= 32) return 5;
+  if (N <= 32 && M >= 256) return 1;
+  if (N <= 64 && M >= 256) return 2;
+  if (M <= 32 && N >= 256) return 3;
+  if (M <= 64 && N >= 256) return 4;
+  return 0;
+}
+constexpr int kTileM[6] = {128, 256, 256, 32, 64, 32};
+constexpr int kTileN[6] = {128, 32, 64, 256, 256, 32};
+
+template <int WM, int WN>
+void launch_vec(int ma, int mb, dim3 grid, hipStream_t st, const pca_gemm_desc& g, const float* A,
+                const float* B, const float* bias, float* C, int split, int64_t kchunk, int vc) {
+#define PCA_GEMM_CASE(X, Y)                                                                   \
+  if (ma == X && mb == Y)                                                                     \
+    hipLaunchKernelGGL((k_gemm_bf16<X, Y, WM, WN>), grid, dim3(256), 0, st, g, A, B, bias, C, \
+                       split, kchunk, vc)
+  PCA_GEMM_CASE(0, 0); PCA_GEMM_CASE(0, 1); PCA_GEMM_CASE(1, 0); PCA_GEMM_CASE(1, 1);
+#undef PCA_GEMM_CASE
 }
 }  // namespace
 
@@ -189,7 +280,12 @@ int gemm_bf16(const pca_gemm_desc& gin, const float* A, const float* B, const fl
   if (g.nb1 <= 0) g.nb1 = 1;
   if (g.nb2 <= 0) g.nb2 = 1;
   if (g.M == 0 || g.N == 0) return PCA_OK;
-  const int64_t tiles_m = cdiv(g.M, BM), tiles_n = cdiv(g.N, BN);
+  // K chunks start at multiples of 32 floats, so the vector paths stay aligned
+  const int ma = stage_mode(A, g.sa_m, g.sa_k, g.sa_b1, g.sa_b2);
+  const int mb = stage_mode(B, g.sb_n, g.sb_k, g.sb_b1, g.sb_b2);
+  // the narrow tiles exist for the vectorised staging modes only
+  const int tv = (ma == 2 || mb == 2) ? 0 : tile_variant(g.M, g.N);
+  const int64_t tiles_m = cdiv(g.M, kTileM[tv]), tiles_n = cdiv(g.N, kTileN[tv]);
   const int64_t nbatch = (int64_t)g.nb1 * g.nb2;
   int split = g.split_k;
   if (split <= 0) {          // same policy as gemm_f32: only an initialised C can take atomics
@@ -210,17 +306,32 @@ int gemm_bf16(const pca_gemm_desc& gin, const float* A, const float* B, const fl
               "gemm_bf16: grid too large (N tiles %lld, batch*split %lld)",
               (long long)tiles_n, (long long)(nbatch * split));
   dim3 grid((unsigned)tiles_m, (unsigned)tiles_n, (unsigned)(nbatch * split));
-  // K chunks start at multiples of 32 floats, so the vector paths stay aligned
-  const int ma = stage_mode(A, g.sa_m, g.sa_k, g.sa_b1, g.sa_b2);
-  const int mb = stage_mode(B, g.sb_n, g.sb_k, g.sb_b1, g.sb_b2);
+  const int vc = (reinterpret_cast<uintptr_t>(C) & 15) == 0 && g.sc_m % 4 == 0 &&
+                 g.sc_b1 % 4 == 0 && g.sc_b2 % 4 == 0;
+  switch (tv) {
+    case 1: launch_vec<8, 1>(ma, mb, grid, st, g, A, B, bias, C, split, kchunk, vc); break;
+    case 2: launch_vec<8, 2>(ma, mb, grid, st, g, A, B, bias, C, split, kchunk, vc); break;
+    case 3: launch_vec<1, 8>(ma, mb, grid, st, g, A, B, bias, C, split, kchunk, vc); break;
+    case 4: launch_vec<2, 8>(ma, mb, grid, st, g, A, B, bias, C, split, kchunk, vc); break;
+    case 5: launch_vec<1, 1>(ma, mb, grid, st, g, A, B, bias, C, split, kchunk, vc); break;
+    default: {
 #define PCA_GEMM_CASE(X, Y)                                                                   \
   if (ma == X && mb == Y)                                                                     \
-    hipLaunchKernelGGL((k_gemm_bf16<X, Y>), grid, dim3(256), 0, st, g, A, B, bias, C, split, kchunk)
-  PCA_GEMM_CASE(0, 0); PCA_GEMM_CASE(0, 1); PCA_GEMM_CASE(0, 2);
-  PCA_GEMM_CASE(1, 0); PCA_GEMM_CASE(1, 1); PCA_GEMM_CASE(1, 2);
-  PCA_GEMM_CASE(2, 0); PCA_GEMM_CASE(2, 1); PCA_GEMM_CASE(2, 2);
+    hipLaunchKernelGGL((k_gemm_bf16<X, Y, 4, 4>), grid, dim3(256), 0, st, g, A, B, bias, C,   \
+                       split, kchunk, vc)
+      PCA_GEMM_CASE(0, 0); PCA_GEMM_CASE(0, 1); PCA_GEMM_CASE(0, 2);
+      PCA_GEMM_CASE(1, 0); PCA_GEMM_CASE(1, 1); PCA_GEMM_CASE(1, 2);
+      PCA_GEMM_CASE(2, 0); PCA_GEMM_CASE(2, 1); PCA_GEMM_CASE(2, 2);
 #undef PCA_GEMM_CASE
+    }
+  }
   return check_launch("k_gemm_bf16");
 }
 
 }  // namespace pca
+
+extern "C" int pca_gemm_bf16(const pca_gemm_desc* g, const float* A, const float* B,
+                             const float* bias, float* C, void* stream) {
+  PCA_REQUIRE(g != nullptr, "pca_gemm_bf16: null descriptor");
+  return pca::gemm_bf16(*g, A, B, bias, C, pca::as_stream(stream));
+}

@@ -106,6 +106,7 @@ SIGNATURES = {
     "pca_prof_stop": (C.c_int, [C.POINTER(C.c_double), C.POINTER(C.c_int64),
                                 C.POINTER(C.c_double), C.POINTER(C.c_double)]),
     "pca_gemm_f32": (C.c_int, [C.POINTER(GemmDesc), c_fp, c_fp, c_fp, c_fp, c_vp]),
+    "pca_gemm_bf16": (C.c_int, [C.POINTER(GemmDesc), c_fp, c_fp, c_fp, c_fp, c_vp]),
     "pca_softmax_rows": (C.c_int, [c_fp, C.c_int64, C.c_int, C.c_float, c_vp]),
     "pca_softmax_bwd_rows": (C.c_int, [c_fp, c_fp, C.c_int64, C.c_int, C.c_float, c_vp]),
     "pca_colsum": (C.c_int, [c_fp, C.c_int64, C.c_int, c_fp, C.c_int, c_vp]),

@@ -261,6 +261,87 @@ def test_mab0_bwd_bf16(dev, case):
     print(f"mab0 bwd {case}: " + " ".join(f"{k}={v:.1e}" for k, v in errs.items()))
 
 
+def _bf16_round(t):
+    return t.to(torch.bfloat16).to(torch.float64)
+
+
+@pytest.mark.parametrize("layout", ["nt", "nn", "tn", "tt", "scalar"])
+def test_gemm_bf16_tile_variants(dev, layout):
+    """pca_gemm_bf16 over every tile shape (128x128, 256x32, 256x64, 32x256, 64x256, 32x32) and
+    staging mode (k-vectors, row-vectors, scalar), with ragged edges, bias, alpha, accumulate,
+    batches with head-slice strides and split-K, against an fp64 product of the bf16-rounded
+    operands (so only the accumulation order differs)."""
+    import ctypes as C
+    from pca_hip import _lib
+    L = _lib.lib()
+    g = torch.Generator().manual_seed(11)
+    shapes = [(300, 32, 32), (517, 20, 64), (260, 64, 40), (32, 300, 32), (17, 1030, 96),
+              (64, 515, 32), (32, 32, 4096), (9, 30, 777), (130, 140, 70), (256, 256, 256),
+              (1, 1, 1)]
+    for (M, N, K) in shapes:
+        pad = 0 if layout != "scalar" else 1          # odd leading dimensions -> scalar staging
+        # A as [M, K] (k contiguous) or [K, M] (rows contiguous); same for B as [N, K] / [K, N]
+        a_t = layout[0] == "t"
+        b_t = layout[1] == "n" and layout != "scalar"
+        Ms, Ks, Ns = M + (-M) % 4, K + (-K) % 4, N + (-N) % 4      # 16-byte aligned rows
+        if a_t:
+            Abuf = torch.randn(K, Ms + pad, generator=g).to(dev); sa_m, sa_k = 1, Ms + pad
+            Aref = Abuf[:, :M].t()
+        else:
+            Abuf = torch.randn(M, Ks + pad, generator=g).to(dev); sa_m, sa_k = Ks + pad, 1
+            Aref = Abuf[:, :K]
+        if b_t:
+            Bbuf = torch.randn(K, Ns + pad, generator=g).to(dev); sb_n, sb_k = 1, Ns + pad
+            Bref = Bbuf[:, :N].t()
+        else:
+            Bbuf = torch.randn(N, Ks + pad, generator=g).to(dev); sb_n, sb_k = Ks + pad, 1
+            Bref = Bbuf[:, :K]
+        bias = torch.randn(N, generator=g).to(dev)
+        ldc = Ns + pad
+        C0 = torch.randn(M, ldc, generator=g).to(dev)
+        ref = 0.5 * (_bf16_round(Aref).cpu() @ _bf16_round(Bref).cpu().t()) + bias.double().cpu()
+        scale = float(ref.abs().max()) + 1e-6
+        for acc, split in ((0, 1), (1, 1), (1, 0), (1, 4)):
+            Cout = C0.clone()
+            d = _lib.GemmDesc(M, N, K, sa_m, sa_k, sb_k, sb_n, ldc, 1, 1, 0, 0, 0, 0, 0, 0,
+                              acc, split, 0.5)
+            _lib.check(L.pca_gemm_bf16(C.byref(d), Abuf.data_ptr(), Bbuf.data_ptr(),
+                                       bias.data_ptr(), Cout.data_ptr(), None))
+            want = ref + (C0[:, :N].double().cpu() if acc else 0)
+            err = float((Cout[:, :N].double().cpu() - want).abs().max()) / scale
+            assert err < 2e-5, f"{layout} {M}x{N}x{K} acc={acc} split={split}: {err:.2e}"
+            # nothing written outside the [M, N] block
+            assert torch.equal(Cout[:, N:], C0[:, N:]), f"{layout} {M}x{N}x{K}: wrote past N"
+    # batched head slices, as the attention of the exact chain issues them:
+    #   S[b, h] = Q[b, :, h*dh:(h+1)*dh] . K[b, :, h*dh:(h+1)*dh]^T   (many rows, few columns)
+    #   O[b, :, h*dh:(h+1)*dh] = S[b, h] . V[b, :, h*dh:(h+1)*dh]      (row-vector B operand)
+    Bn, h, nq, nk, dh = 3, 8, 300, 32, 32
+    dmodel = h * dh
+    Q = torch.randn(Bn, nq, dmodel, generator=g).to(dev)
+    Kx = torch.randn(Bn, nk, dmodel, generator=g).to(dev)
+    S = torch.zeros(Bn, h, nq, nk, device=dev)
+    d = _lib.GemmDesc(nq, nk, dh, dmodel, 1, 1, dmodel, nk, Bn, h, nq * dmodel, dh,
+                      nk * dmodel, dh, h * nq * nk, nq * nk, 0, 1, 1.0)
+    _lib.check(L.pca_gemm_bf16(C.byref(d), Q.data_ptr(), Kx.data_ptr(), None, S.data_ptr(), None))
+    Qh = _bf16_round(Q).cpu().view(Bn, nq, h, dh).permute(0, 2, 1, 3)
+    Kh = _bf16_round(Kx).cpu().view(Bn, nk, h, dh).permute(0, 2, 1, 3)
+    refS = Qh @ Kh.transpose(-1, -2)
+    assert float((S.double().cpu() - refS).abs().max()) < 2e-5 * float(refS.abs().max())
+    O = torch.zeros(Bn, nq, dmodel, device=dev)
+    d = _lib.GemmDesc(nq, dh, nk, nk, 1, dmodel, 1, dmodel, Bn, h, h * nq * nk, nq * nk,
+                      nk * dmodel, dh, nq * dmodel, dh, 0, 1, 1.0)
+    _lib.check(L.pca_gemm_bf16(C.byref(d), S.data_ptr(), Kx.data_ptr(), None, O.data_ptr(), None))
+    refO = (_bf16_round(S).cpu() @ Kh).permute(0, 2, 1, 3).reshape(Bn, nq, dmodel)
+    assert float((O.double().cpu() - refO).abs().max()) < 2e-5 * float(refO.abs().max())
+    # few rows, reduction over the points (32x32 tiles, batch of heads): dV[b,h] = S^T . dO_h
+    dV = torch.zeros(Bn, nk, dmodel, device=dev)
+    d = _lib.GemmDesc(nk, dh, nq, 1, nk, dmodel, 1, dmodel, Bn, h, h * nq * nk, nq * nk,
+                      nq * dmodel, dh, nk * dmodel, dh, 0, 1, 1.0)
+    _lib.check(L.pca_gemm_bf16(C.byref(d), S.data_ptr(), Q.data_ptr(), None, dV.data_ptr(), None))
+    refdV = (_bf16_round(S).cpu().transpose(-1, -2) @ Qh).permute(0, 2, 1, 3).reshape(Bn, nk, dmodel)
+    assert float((dV.double().cpu() - refdV).abs().max()) < 2e-5 * float(refdV.abs().max())
+
+
 @pytest.mark.parametrize("ci", [1, 3], ids=["st_shipped", "st_cfg4"])
 def test_engine_bf16_generic_gemm_path(dev, golden_st, ci):
     """mode = BF16 on architectures without fused kernels (shipped d=64 / 8 heads / 64 inducing
