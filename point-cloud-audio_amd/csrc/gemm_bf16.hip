@@ -51,8 +51,8 @@ struct Stage {
     } else if constexpr (MODE == 1 && R >= 128) {   // 4 rows x 4 k blocks, float4 along the rows
 #pragma unroll
       for (int e = 0; e < R / 128; ++e) {
-        const int bi = tid + e * 256;
-        const int i4 = (bi % (R / 4)) * 4, k4 = (bi / (R / 4)) * 4;
+        const int bi = tid + e * 256;      // 8 row groups x 8 k groups x R/32: LDS banks spread
+        const int i4 = ((bi >> 6) * 8 + (bi & 7)) * 4, k4 = ((bi >> 3) & 7) * 4;
 #pragma unroll
         for (int u = 0; u < 4; ++u) {
           const float* src = P + i4 + (k4 + u) * s_k;
@@ -106,8 +106,8 @@ struct Stage {
     } else if constexpr (MODE == 1 && R >= 128) {   // transposed in registers, k contiguous
 #pragma unroll
       for (int e = 0; e < R / 128; ++e) {
-        const int bi = tid + e * 256;
-        const int i4 = (bi % (R / 4)) * 4, k4 = (bi / (R / 4)) * 4;
+        const int bi = tid + e * 256;      // 8 row groups x 8 k groups x R/32: LDS banks spread
+        const int i4 = ((bi >> 6) * 8 + (bi & 7)) * 4, k4 = ((bi >> 3) & 7) * 4;
 #pragma unroll
         for (int rr = 0; rr < 4; ++rr) {
           bf16x4 h;
@@ -147,24 +147,46 @@ __global__ __launch_bounds__(256) void k_gemm_bf16(pca_gemm_desc g, const float*
                                                     const float* __restrict__ B,
                                                     const float* __restrict__ bias,
                                                     float* __restrict__ C, int split_k,
-                                                    int64_t kchunk, int vec_c) {
+                                                    int64_t kchunk, int vec_c, int remap,
+                                                    int tiles_m, int tiles_n, int nz) {
   constexpr int BM = 32 * WM, BN = 32 * WN;
   using SA = Stage<MA, BM>;
   using SB = Stage<MB, BN>;
-  __shared__ __attribute__((aligned(16))) char As[BM * PITCH];
-  __shared__ __attribute__((aligned(16))) char Bs[BN * PITCH];
+  __shared__ __attribute__((aligned(16))) char smem[(BM + BN) * PITCH];
+  char* const As = smem;
+  char* const Bs = smem + BM * PITCH;
 
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int r = lane & 15, gq = lane >> 4;
-  const int zb = blockIdx.z / split_k;
-  const int ks = blockIdx.z % split_k;
+  // Workgroup -> (m tile, n tile, batch/split z).  Workgroups go to the eight XCDs round-robin
+  // by their linear id, each XCD with an L2 of its own; the remapped orders put the tiles that
+  // read the same slab of the streamed operand eight ids apart, i.e. on one XCD back to back:
+  //   1: all n tiles of an m tile (tall A, few column tiles: the [B N, d] x [d, d] products)
+  //   2: all tiles of one K split (weight gradients: both operands streamed along K)
+  int bm = blockIdx.x, bn = blockIdx.y, bz = blockIdx.z;
+  if (remap == 1) {
+    const int grp = blockIdx.x / (8 * tiles_n), rem = blockIdx.x % (8 * tiles_n);
+    bn = rem >> 3;
+    bm = grp * 8 + (rem & 7);
+    if (bm >= tiles_m) return;
+  } else if (remap == 2) {
+    const int T = tiles_m * tiles_n;
+    const int grp = blockIdx.x / (8 * T), rem = blockIdx.x % (8 * T);
+    const int t = rem >> 3;
+    bz = grp * 8 + (rem & 7);
+    if (bz >= nz) return;
+    bm = t % tiles_m;
+    bn = t / tiles_m;
+  }
+  const int zb = bz / split_k;
+  const int ks = bz % split_k;
   const int z1 = zb / g.nb2, z2 = zb % g.nb2;
   A += z1 * g.sa_b1 + z2 * g.sa_b2;
   B += z1 * g.sb_b1 + z2 * g.sb_b2;
   C += z1 * g.sc_b1 + z2 * g.sc_b2;
 
-  const int64_t m0 = (int64_t)blockIdx.x * BM;
-  const int64_t n0 = (int64_t)blockIdx.y * BN;
+  const int64_t m0 = (int64_t)bm * BM;
+  const int64_t n0 = (int64_t)bn * BN;
   const int64_t k_begin = (int64_t)ks * kchunk;
   const int64_t k_end = (k_begin + kchunk < g.K) ? (k_begin + kchunk) : g.K;
   const int wm = 16 * WM * (wave >> 1), wn = 16 * WN * (wave & 1);
@@ -202,6 +224,61 @@ __global__ __launch_bounds__(256) void k_gemm_bf16(pca_gemm_desc g, const float*
   }
 
   // transposed product: acc[i][j][e] = C[row = 16 i + r][col = 16 j + 4 gq + e]
+  if constexpr (WM == 4 && WN == 4) {
+    // 128x128 tile: each wave turns its 16 x 64 strips through LDS (its own 16 x 68 floats of
+    // the staging buffers) so that one store instruction covers four rows of 256 contiguous
+    // bytes instead of sixteen rows of 64
+    constexpr int SP = 68;
+    __syncthreads();                     // every wave is done with As / Bs
+    float* scr = reinterpret_cast<float*>(smem) + wave * (16 * SP);
+    const int c4 = (lane & 15) * 4, rq = lane >> 4;
+    const int64_t col = n0 + wn + c4;
+    float bia[4] = {0.f, 0.f, 0.f, 0.f};
+    if (bias != nullptr && ks == 0) {
+#pragma unroll
+      for (int e = 0; e < 4; ++e)
+        if (col + e < g.N) bia[e] = bias[col + e];
+    }
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+      __builtin_amdgcn_wave_barrier();
+#pragma unroll
+      for (int j = 0; j < 4; ++j)
+        *reinterpret_cast<f32x4*>(scr + r * SP + 16 * j + 4 * gq) = acc[i][j];
+      __builtin_amdgcn_wave_barrier();
+#pragma unroll
+      for (int q = 0; q < 4; ++q) {
+        const int rl = rq + 4 * q;
+        const f32x4 t = *reinterpret_cast<const f32x4*>(scr + rl * SP + c4);
+        const int64_t row = m0 + wm + 16 * i + rl;
+        if (row >= g.M || col >= g.N) continue;
+        float* dst = C + row * g.sc_m + col;
+        float v[4];
+#pragma unroll
+        for (int e = 0; e < 4; ++e) v[e] = g.alpha * t[e] + bia[e];
+        if (split_k > 1) {
+#pragma unroll
+          for (int e = 0; e < 4; ++e)
+            if (col + e < g.N) atomicAdd(dst + e, v[e]);
+        } else if (vec_c && col + 3 < g.N) {
+          float4 o = float4{v[0], v[1], v[2], v[3]};
+          if (g.accumulate) {
+            const float4 c = *reinterpret_cast<const float4*>(dst);
+            o.x += c.x; o.y += c.y; o.z += c.z; o.w += c.w;
+          }
+          *reinterpret_cast<float4*>(dst) = o;
+        } else {
+#pragma unroll
+          for (int e = 0; e < 4; ++e)
+            if (col + e < g.N) {
+              if (g.accumulate) dst[e] += v[e];
+              else dst[e] = v[e];
+            }
+        }
+      }
+    }
+    return;
+  }
 #pragma unroll
   for (int i = 0; i < WM; ++i) {
     const int64_t row = m0 + wm + 16 * i + r;
@@ -262,11 +339,12 @@ constexpr int kTileN[6] = {128, 32, 64, 256, 256, 32};
 
 template <int WM, int WN>
 void launch_vec(int ma, int mb, dim3 grid, hipStream_t st, const pca_gemm_desc& g, const float* A,
-                const float* B, const float* bias, float* C, int split, int64_t kchunk, int vc) {
+                const float* B, const float* bias, float* C, int split, int64_t kchunk, int vc,
+                int remap, int tm, int tn, int nz) {
 #define PCA_GEMM_CASE(X, Y)                                                                   \
   if (ma == X && mb == Y)                                                                     \
     hipLaunchKernelGGL((k_gemm_bf16<X, Y, WM, WN>), grid, dim3(256), 0, st, g, A, B, bias, C, \
-                       split, kchunk, vc)
+                       split, kchunk, vc, remap, tm, tn, nz)
   PCA_GEMM_CASE(0, 0); PCA_GEMM_CASE(0, 1); PCA_GEMM_CASE(1, 0); PCA_GEMM_CASE(1, 1);
 #undef PCA_GEMM_CASE
 }
@@ -306,19 +384,30 @@ int gemm_bf16(const pca_gemm_desc& gin, const float* A, const float* B, const fl
               "gemm_bf16: grid too large (N tiles %lld, batch*split %lld)",
               (long long)tiles_n, (long long)(nbatch * split));
   dim3 grid((unsigned)tiles_m, (unsigned)tiles_n, (unsigned)(nbatch * split));
+  // XCD-aware orders (see the kernel): sharers of a streamed slab on one L2, back to back
+  const int64_t nz = nbatch * split, T = tiles_m * tiles_n;
+  int remap = 0;
+  if (tiles_n >= 2 && tiles_n <= 8 && tiles_m >= 64 && cdiv(tiles_m, 8) * 8 * tiles_n < (1ll << 31)) {
+    remap = 1;
+    grid = dim3((unsigned)(cdiv(tiles_m, 8) * 8 * tiles_n), 1, (unsigned)nz);
+  } else if (T >= 2 && T <= 8 && nz >= 16 && kchunk >= 1024) {
+    remap = 2;
+    grid = dim3((unsigned)(cdiv(nz, 8) * 8 * T), 1, 1);
+  }
+  const int tm = (int)tiles_m, tn = (int)tiles_n;
   const int vc = (reinterpret_cast<uintptr_t>(C) & 15) == 0 && g.sc_m % 4 == 0 &&
                  g.sc_b1 % 4 == 0 && g.sc_b2 % 4 == 0;
   switch (tv) {
-    case 1: launch_vec<8, 1>(ma, mb, grid, st, g, A, B, bias, C, split, kchunk, vc); break;
-    case 2: launch_vec<8, 2>(ma, mb, grid, st, g, A, B, bias, C, split, kchunk, vc); break;
-    case 3: launch_vec<1, 8>(ma, mb, grid, st, g, A, B, bias, C, split, kchunk, vc); break;
-    case 4: launch_vec<2, 8>(ma, mb, grid, st, g, A, B, bias, C, split, kchunk, vc); break;
-    case 5: launch_vec<1, 1>(ma, mb, grid, st, g, A, B, bias, C, split, kchunk, vc); break;
+    case 1: launch_vec<8, 1>(ma, mb, grid, st, g, A, B, bias, C, split, kchunk, vc, remap, tm, tn, (int)nz); break;
+    case 2: launch_vec<8, 2>(ma, mb, grid, st, g, A, B, bias, C, split, kchunk, vc, remap, tm, tn, (int)nz); break;
+    case 3: launch_vec<1, 8>(ma, mb, grid, st, g, A, B, bias, C, split, kchunk, vc, remap, tm, tn, (int)nz); break;
+    case 4: launch_vec<2, 8>(ma, mb, grid, st, g, A, B, bias, C, split, kchunk, vc, remap, tm, tn, (int)nz); break;
+    case 5: launch_vec<1, 1>(ma, mb, grid, st, g, A, B, bias, C, split, kchunk, vc, remap, tm, tn, (int)nz); break;
     default: {
 #define PCA_GEMM_CASE(X, Y)                                                                   \
   if (ma == X && mb == Y)                                                                     \
     hipLaunchKernelGGL((k_gemm_bf16<X, Y, 4, 4>), grid, dim3(256), 0, st, g, A, B, bias, C,   \
-                       split, kchunk, vc)
+                       split, kchunk, vc, remap, tm, tn, (int)nz)
       PCA_GEMM_CASE(0, 0); PCA_GEMM_CASE(0, 1); PCA_GEMM_CASE(0, 2);
       PCA_GEMM_CASE(1, 0); PCA_GEMM_CASE(1, 1); PCA_GEMM_CASE(1, 2);
       PCA_GEMM_CASE(2, 0); PCA_GEMM_CASE(2, 1); PCA_GEMM_CASE(2, 2);

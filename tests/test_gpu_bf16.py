@@ -278,6 +278,8 @@ def test_gemm_bf16_tile_variants(dev, layout):
     shapes = [(300, 32, 32), (517, 20, 64), (260, 64, 40), (32, 300, 32), (17, 1030, 96),
               (64, 515, 32), (32, 32, 4096), (9, 30, 777), (130, 140, 70), (256, 256, 256),
               (1, 1, 1)]
+    if layout in ("nt", "tn"):      # the XCD-aware workgroup orders: tall A; long split K
+        shapes += [(8203, 200, 40), (130, 140, 200000)]
     for (M, N, K) in shapes:
         pad = 0 if layout != "scalar" else 1          # odd leading dimensions -> scalar staging
         # A as [M, K] (k contiguous) or [K, M] (rows contiguous); same for B as [N, K] / [K, N]
