@@ -165,6 +165,123 @@ __global__ __launch_bounds__(256) void k_softmax_bwd_rows(const float* __restric
     for (int j = lane; j < n; j += G) da[j] = a[j] * (da[j] - dot) * scale;
 }
 
+// Rows of n floats with n % 4 == 0 and n <= 4 * G * NV: G lanes keep a whole row in registers
+// (NV float4 each), so the row crosses the memory pipeline once per direction.
+template <int G, int NV>
+__global__ __launch_bounds__(256) void k_softmax_rows_v4(float* __restrict__ X, int64_t rows,
+                                                          int n, float scale,
+                                                          const int32_t* __restrict__ lengths,
+                                                          int64_t rows_per_set) {
+  const int lane = threadIdx.x % G;
+  const int64_t row = ((int64_t)blockIdx.x * 256 + threadIdx.x) / G;
+  const bool live = row < rows;
+  float4* x = reinterpret_cast<float4*>(X + (live ? row : 0) * (int64_t)n);
+  int nv = n;
+  if (lengths != nullptr && live) {
+    nv = lengths[row / rows_per_set];
+    nv = nv < n ? nv : n;
+  }
+  const int n4 = n >> 2;
+  float v[NV][4];
+  float m = -INFINITY;
+#pragma unroll
+  for (int u = 0; u < NV; ++u) {
+    const int j4 = lane + u * G;
+    float4 t = make_float4(0.f, 0.f, 0.f, 0.f);
+    if (live && j4 < n4) t = x[j4];
+    v[u][0] = t.x; v[u][1] = t.y; v[u][2] = t.z; v[u][3] = t.w;
+#pragma unroll
+    for (int e = 0; e < 4; ++e) {
+      v[u][e] = (j4 < n4 && 4 * j4 + e < nv) ? v[u][e] * scale : -INFINITY;
+      m = fmaxf(m, v[u][e]);
+    }
+  }
+  m = group_max<G>(m);
+  if (m == -INFINITY) m = 0.f;              // no key at all: the row becomes zeros
+  float sum = 0.f;
+#pragma unroll
+  for (int u = 0; u < NV; ++u)
+#pragma unroll
+    for (int e = 0; e < 4; ++e) {
+      v[u][e] = expf(v[u][e] - m);          // masked entries: exp(-inf) = 0
+      sum += v[u][e];
+    }
+  sum = group_sum<G>(sum);
+  const float inv = sum > 0.f ? 1.f / sum : 0.f;
+#pragma unroll
+  for (int u = 0; u < NV; ++u) {
+    const int j4 = lane + u * G;
+    if (live && j4 < n4)
+      x[j4] = make_float4(v[u][0] * inv, v[u][1] * inv, v[u][2] * inv, v[u][3] * inv);
+  }
+}
+
+template <int G, int NV>
+__global__ __launch_bounds__(256) void k_softmax_bwd_rows_v4(const float* __restrict__ A,
+                                                              float* __restrict__ dA,
+                                                              int64_t rows, int n, float scale) {
+  const int lane = threadIdx.x % G;
+  const int64_t row = ((int64_t)blockIdx.x * 256 + threadIdx.x) / G;
+  const bool live = row < rows;
+  const float4* a = reinterpret_cast<const float4*>(A + (live ? row : 0) * (int64_t)n);
+  float4* da = reinterpret_cast<float4*>(dA + (live ? row : 0) * (int64_t)n);
+  const int n4 = n >> 2;
+  float4 av[NV], dv[NV];
+  float dot = 0.f;
+#pragma unroll
+  for (int u = 0; u < NV; ++u) {
+    const int j4 = lane + u * G;
+    av[u] = dv[u] = make_float4(0.f, 0.f, 0.f, 0.f);
+    if (live && j4 < n4) { av[u] = a[j4]; dv[u] = da[j4]; }
+    dot += av[u].x * dv[u].x + av[u].y * dv[u].y + av[u].z * dv[u].z + av[u].w * dv[u].w;
+  }
+  dot = group_sum<G>(dot);
+#pragma unroll
+  for (int u = 0; u < NV; ++u) {
+    const int j4 = lane + u * G;
+    if (live && j4 < n4)
+      da[j4] = make_float4(av[u].x * (dv[u].x - dot) * scale, av[u].y * (dv[u].y - dot) * scale,
+                           av[u].z * (dv[u].z - dot) * scale, av[u].w * (dv[u].w - dot) * scale);
+  }
+}
+
+// out[j..j+3] += sum_i X[i, j..j+3] for cols % 4 == 0: a wave reads 1 KB of a row per
+// instruction (64 lanes x float4), the four waves interleave rows, 8 rows in flight per wave
+__global__ __launch_bounds__(256) void k_colsum_v4(const float* __restrict__ X, int64_t rows,
+                                                    int cols, float* __restrict__ out, int rpb) {
+  __shared__ float4 red[4][64];
+  const int tx = threadIdx.x & 63, ty = threadIdx.x >> 6;
+  const int64_t r0 = (int64_t)blockIdx.x * rpb;
+  const int64_t r1 = (r0 + rpb < rows) ? r0 + rpb : rows;
+  const int j = (blockIdx.y * 64 + tx) * 4;
+  float4 s = make_float4(0.f, 0.f, 0.f, 0.f);
+  if (j < cols) {
+    int64_t i = r0 + ty;
+    for (; i + 28 < r1; i += 32) {
+      float4 t[8];
+#pragma unroll
+      for (int u = 0; u < 8; ++u)
+        t[u] = *reinterpret_cast<const float4*>(X + (i + 4 * u) * cols + j);
+#pragma unroll
+      for (int u = 0; u < 8; ++u) { s.x += t[u].x; s.y += t[u].y; s.z += t[u].z; s.w += t[u].w; }
+    }
+    for (; i < r1; i += 4) {
+      const float4 t = *reinterpret_cast<const float4*>(X + i * cols + j);
+      s.x += t.x; s.y += t.y; s.z += t.z; s.w += t.w;
+    }
+  }
+  red[ty][tx] = s;
+  __syncthreads();
+  if (ty == 0 && j < cols) {
+#pragma unroll
+    for (int w = 1; w < 4; ++w) {
+      s.x += red[w][tx].x; s.y += red[w][tx].y; s.z += red[w][tx].z; s.w += red[w][tx].w;
+    }
+    atomicAdd(&out[j], s.x); atomicAdd(&out[j + 1], s.y);
+    atomicAdd(&out[j + 2], s.z); atomicAdd(&out[j + 3], s.w);
+  }
+}
+
 // out[j] += sum_i X[i,j]; block = 64 column lanes x 4 row lanes; grid.x tiles the rows
 // (256 per block), grid.y tiles the columns (64 per block)
 __global__ __launch_bounds__(256) void k_colsum(const float* __restrict__ X, int64_t rows,
@@ -204,24 +321,55 @@ __global__ __launch_bounds__(256) void k_colsum_small(const float* __restrict__ 
   out[j] = s;
 }
 
+// (the elementwise kernels take float4 when n % 4 == 0 and every pointer is 16-byte aligned:
+//  vec != 0, decided by the host)
 __global__ void k_add_relu(const float* __restrict__ O, const float* __restrict__ Z,
-                           float* __restrict__ Y, int64_t n) {
+                           float* __restrict__ Y, int64_t n, int vec) {
   int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
   const int64_t stride = (int64_t)gridDim.x * blockDim.x;
+  if (vec) {
+    const float4* o4 = reinterpret_cast<const float4*>(O);
+    const float4* z4 = reinterpret_cast<const float4*>(Z);
+    float4* y4 = reinterpret_cast<float4*>(Y);
+    for (; i < (n >> 2); i += stride) {
+      const float4 o = o4[i], z = z4[i];
+      y4[i] = make_float4(o.x + fmaxf(z.x, 0.f), o.y + fmaxf(z.y, 0.f), o.z + fmaxf(z.z, 0.f),
+                          o.w + fmaxf(z.w, 0.f));
+    }
+    return;
+  }
   for (; i < n; i += stride) Y[i] = O[i] + fmaxf(Z[i], 0.f);
 }
 
 __global__ void k_relu_bwd(const float* __restrict__ dY, const float* __restrict__ Z,
-                           float* __restrict__ dZ, int64_t n) {
+                           float* __restrict__ dZ, int64_t n, int vec) {
   int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
   const int64_t stride = (int64_t)gridDim.x * blockDim.x;
+  if (vec) {
+    const float4* g4 = reinterpret_cast<const float4*>(dY);
+    const float4* z4 = reinterpret_cast<const float4*>(Z);
+    float4* o4 = reinterpret_cast<float4*>(dZ);
+    for (; i < (n >> 2); i += stride) {
+      const float4 g = g4[i], z = z4[i];
+      o4[i] = make_float4(z.x > 0.f ? g.x : 0.f, z.y > 0.f ? g.y : 0.f, z.z > 0.f ? g.z : 0.f,
+                          z.w > 0.f ? g.w : 0.f);
+    }
+    return;
+  }
   for (; i < n; i += stride) dZ[i] = Z[i] > 0.f ? dY[i] : 0.f;
 }
 
 __global__ void k_copy_rows(const float* __restrict__ src, int64_t src_elems,
-                            float* __restrict__ dst, int64_t n) {
+                            float* __restrict__ dst, int64_t n, int vec) {
   int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
   const int64_t stride = (int64_t)gridDim.x * blockDim.x;
+  if (vec) {                    // src_elems % 4 == 0 as well
+    const float4* s4 = reinterpret_cast<const float4*>(src);
+    float4* d4 = reinterpret_cast<float4*>(dst);
+    const int64_t se4 = src_elems >> 2;
+    for (; i < (n >> 2); i += stride) d4[i] = s4[i % se4];
+    return;
+  }
   for (; i < n; i += stride) dst[i] = src[i % src_elems];
 }
 
@@ -314,11 +462,24 @@ __global__ void k_fill_zero(float* __restrict__ dst, int64_t n) {
 }
 
 __global__ void k_add_inplace(float* __restrict__ dst, const float* __restrict__ src,
-                              int64_t n) {
+                              int64_t n, int vec) {
   int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
   const int64_t stride = (int64_t)gridDim.x * blockDim.x;
+  if (vec) {
+    float4* d4 = reinterpret_cast<float4*>(dst);
+    const float4* s4 = reinterpret_cast<const float4*>(src);
+    for (; i < (n >> 2); i += stride) {
+      float4 d = d4[i];
+      const float4 t = s4[i];
+      d.x += t.x; d.y += t.y; d.z += t.z; d.w += t.w;
+      d4[i] = d;
+    }
+    return;
+  }
   for (; i < n; i += stride) dst[i] += src[i];
 }
+
+inline bool al16(const void* p) { return (reinterpret_cast<uintptr_t>(p) & 15) == 0; }
 
 inline unsigned ew_blocks(int64_t n) {
   int64_t b = cdiv(n, 256);
@@ -337,11 +498,36 @@ inline unsigned ew_blocks(int64_t n) {
     else { CALL(8); }               \
   } while (0)
 
+// n % 4 == 0, n <= 4096: (lanes per row, float4 per lane) with 4 G NV >= n
+#define PCA_DISPATCH_V4(n, CALL)                 \
+  do {                                           \
+    const int n4_ = (n) / 4;                     \
+    if (n4_ <= 1) { CALL(1, 1); }                \
+    else if (n4_ <= 2) { CALL(2, 1); }           \
+    else if (n4_ <= 4) { CALL(4, 1); }           \
+    else if (n4_ <= 8) { CALL(8, 1); }           \
+    else if (n4_ <= 16) { CALL(16, 1); }         \
+    else if (n4_ <= 32) { CALL(32, 1); }         \
+    else if (n4_ <= 64) { CALL(64, 1); }         \
+    else if (n4_ <= 128) { CALL(64, 2); }        \
+    else if (n4_ <= 256) { CALL(64, 4); }        \
+    else if (n4_ <= 512) { CALL(64, 8); }        \
+    else { CALL(64, 16); }                       \
+  } while (0)
+
 int softmax_rows(float* X, int64_t rows, int n, float scale, hipStream_t st,
                  const int32_t* lengths, int64_t rows_per_set) {
   PCA_REQUIRE(X && n > 0 && rows >= 0, "softmax_rows: bad arguments");
   PCA_REQUIRE(lengths == nullptr || rows_per_set > 0, "softmax_rows: rows_per_set");
   if (rows == 0) return PCA_OK;
+  if (n % 4 == 0 && n <= 4096 && al16(X)) {        // whole row in registers
+#define CALLV(G, NV)                                                                          \
+  hipLaunchKernelGGL((k_softmax_rows_v4<G, NV>), dim3((unsigned)cdiv(rows * G, 256)), dim3(256), \
+                     0, st, X, rows, n, scale, lengths, rows_per_set)
+    PCA_DISPATCH_V4(n, CALLV);
+#undef CALLV
+    return check_launch("k_softmax_rows_v4");
+  }
 #define CALL(G)                                                                       \
   hipLaunchKernelGGL(k_softmax_rows<G>, dim3((unsigned)cdiv(rows * G, 256)), dim3(256), \
                      0, st, X, rows, n, scale, lengths, rows_per_set)
@@ -354,6 +540,14 @@ int softmax_bwd_rows(const float* A, float* dA, int64_t rows, int n, float scale
                      hipStream_t st) {
   PCA_REQUIRE(A && dA && n > 0 && rows >= 0, "softmax_bwd_rows: bad arguments");
   if (rows == 0) return PCA_OK;
+  if (n % 4 == 0 && n <= 4096 && al16(A) && al16(dA)) {
+#define CALLV(G, NV)                                                                       \
+  hipLaunchKernelGGL((k_softmax_bwd_rows_v4<G, NV>), dim3((unsigned)cdiv(rows * G, 256)),  \
+                     dim3(256), 0, st, A, dA, rows, n, scale)
+    PCA_DISPATCH_V4(n, CALLV);
+#undef CALLV
+    return check_launch("k_softmax_bwd_rows_v4");
+  }
 #define CALL(G)                                                                           \
   hipLaunchKernelGGL(k_softmax_bwd_rows<G>, dim3((unsigned)cdiv(rows * G, 256)), dim3(256), \
                      0, st, A, dA, rows, n, scale)
@@ -398,6 +592,12 @@ int colsum(const float* X, int64_t rows, int cols, float* out, int accumulate,
   }
   if (!accumulate) PCA_TRY(fill_zero(out, cols, st));
   if (rows == 0) return PCA_OK;
+  if (cols % 4 == 0 && al16(X) && rows >= 4096) {
+    const int rpb4 = 512;
+    hipLaunchKernelGGL(k_colsum_v4, dim3((unsigned)cdiv(rows, rpb4), (unsigned)cdiv(cols, 256)),
+                       dim3(256), 0, st, X, rows, cols, out, rpb4);
+    return check_launch("k_colsum_v4");
+  }
   const int rpb = rows * cdiv(cols, 64) < 256 * 512 ? 32 : 256;   // rows per block
   hipLaunchKernelGGL(k_colsum, dim3((unsigned)cdiv(rows, rpb), (unsigned)cdiv(cols, 64)),
                      dim3(256), 0, st, X, rows, cols, out, rpb);
@@ -406,13 +606,15 @@ int colsum(const float* X, int64_t rows, int cols, float* out, int accumulate,
 
 int add_relu(const float* O, const float* Z, float* Y, int64_t n, hipStream_t st) {
   if (n <= 0) return PCA_OK;
-  hipLaunchKernelGGL(k_add_relu, dim3(ew_blocks(n)), dim3(256), 0, st, O, Z, Y, n);
+  const int vec = n % 4 == 0 && al16(O) && al16(Z) && al16(Y);
+  hipLaunchKernelGGL(k_add_relu, dim3(ew_blocks(vec ? n / 4 : n)), dim3(256), 0, st, O, Z, Y, n, vec);
   return check_launch("k_add_relu");
 }
 
 int relu_bwd(const float* dY, const float* Z, float* dZ, int64_t n, hipStream_t st) {
   if (n <= 0) return PCA_OK;
-  hipLaunchKernelGGL(k_relu_bwd, dim3(ew_blocks(n)), dim3(256), 0, st, dY, Z, dZ, n);
+  const int vec = n % 4 == 0 && al16(dY) && al16(Z) && al16(dZ);
+  hipLaunchKernelGGL(k_relu_bwd, dim3(ew_blocks(vec ? n / 4 : n)), dim3(256), 0, st, dY, Z, dZ, n, vec);
   return check_launch("k_relu_bwd");
 }
 
@@ -420,14 +622,16 @@ int copy_rows(const float* src, int64_t src_rows, float* dst, int64_t rows, int6
               hipStream_t st) {
   const int64_t n = rows * cols;
   if (n <= 0) return PCA_OK;
-  hipLaunchKernelGGL(k_copy_rows, dim3(ew_blocks(n)), dim3(256), 0, st, src,
-                     src_rows * cols, dst, n);
+  const int vec = n % 4 == 0 && (src_rows * cols) % 4 == 0 && al16(src) && al16(dst);
+  hipLaunchKernelGGL(k_copy_rows, dim3(ew_blocks(vec ? n / 4 : n)), dim3(256), 0, st, src,
+                     src_rows * cols, dst, n, vec);
   return check_launch("k_copy_rows");
 }
 
 int add_inplace(float* dst, const float* src, int64_t n, hipStream_t st) {
   if (n <= 0) return PCA_OK;
-  hipLaunchKernelGGL(k_add_inplace, dim3(ew_blocks(n)), dim3(256), 0, st, dst, src, n);
+  const int vec = n % 4 == 0 && al16(dst) && al16(src);
+  hipLaunchKernelGGL(k_add_inplace, dim3(ew_blocks(vec ? n / 4 : n)), dim3(256), 0, st, dst, src, n, vec);
   return check_launch("k_add_inplace");
 }
 

@@ -65,7 +65,7 @@ def test_softmax_and_colsum(dev):
     from pca_hip import _lib
     L = _lib.lib()
     g = torch.Generator().manual_seed(5)
-    for n in (1, 7, 16, 33, 64, 513):
+    for n in (1, 7, 16, 33, 64, 513, 4, 8, 32, 100, 512, 1028, 4096, 4100):
         X = (torch.randn(37, n, generator=g) * 3).to(dev)
         A = X.clone()
         _lib.check(L.pca_softmax_rows(A.data_ptr(), 37, n, 0.25, None))
@@ -81,6 +81,12 @@ def test_softmax_and_colsum(dev):
     out = torch.ones(130, device=dev)
     _lib.check(L.pca_colsum(X.data_ptr(), 1000, 130, out.data_ptr(), 1, None))
     close(out, 1.0 + X.double().cpu().sum(0), 1e-5, "colsum")
+    for rows, cols in ((5000, 256), (4133, 132), (70000, 64)):      # float4 path
+        X = torch.randn(rows, cols, generator=g).to(dev)
+        for acc in (0, 1):
+            out = torch.full((cols,), 2.0, device=dev)
+            _lib.check(L.pca_colsum(X.data_ptr(), rows, cols, out.data_ptr(), acc, None))
+            close(out, 2.0 * acc + X.double().cpu().sum(0), 2e-5, f"colsum {rows}x{cols}")
 
 
 # ----------------------------------------------------------------------------- #
