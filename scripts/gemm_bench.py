@@ -38,6 +38,9 @@ G = _lib.GemmDesc
 big = 2 * R * d * 4
 run("linear fwd  [R,256]x[256,256]^T", G(R, d, d, d, 1, 1, d, d, 1, 1, 0, 0, 0, 0, 0, 0, 0, 1, 1.0), X, W, b, Y, big)
 run("linear dX   [R,256]x[256,256]", G(R, d, d, d, 1, d, 1, d, 1, 1, 0, 0, 0, 0, 0, 0, 0, 1, 1.0), X, W, None, Y, big)
+run("linear fwd again", G(R, d, d, d, 1, 1, d, d, 1, 1, 0, 0, 0, 0, 0, 0, 0, 1, 1.0), X, W, b, Y, big)
+run("linear dX accumulate", G(R, d, d, d, 1, d, 1, d, 1, 1, 0, 0, 0, 0, 0, 0, 1, 1, 1.0), X, W, None, Y, big * 1.5)
+run("linear fwd accumulate", G(R, d, d, d, 1, 1, d, d, 1, 1, 0, 0, 0, 0, 0, 0, 1, 1, 1.0), X, W, None, Y, big * 1.5)
 dW = torch.zeros(d, d, device=dev)
 run("linear dW   [256,R]x[R,256] acc", G(d, d, R, 1, d, d, 1, d, 1, 1, 0, 0, 0, 0, 0, 0, 1, 0, 1.0), X, Y, None, dW, big)
 X3 = torch.randn(R, 3, device=dev); W3 = torch.randn(d, 3, device=dev)
