@@ -32,14 +32,14 @@ struct Stage {
 
   static __device__ __forceinline__ void load(const float* __restrict__ P, int64_t s_row,
                                               int64_t s_k, int64_t n_rows, int64_t k_left,
-                                              int tid, float (&v)[NV]) {
+                                              int tid, bool vec, float (&v)[NV]) {
     if constexpr (MODE == 0) {              // R x 8 float4; thread -> R/32 of them
 #pragma unroll
       for (int e = 0; e < R / 32; ++e) {
         const int idx = tid + e * 256;
         const int i = idx >> 3, k4 = (idx & 7) * 4;
         const float* src = P + i * s_row + k4;
-        if (i < n_rows && k4 + 3 < k_left) {
+        if (vec && i < n_rows && k4 + 3 < k_left) {
           const float4 t = *reinterpret_cast<const float4*>(src);
           v[4 * e] = t.x; v[4 * e + 1] = t.y; v[4 * e + 2] = t.z; v[4 * e + 3] = t.w;
         } else {
@@ -56,7 +56,7 @@ struct Stage {
 #pragma unroll
         for (int u = 0; u < 4; ++u) {
           const float* src = P + i4 + (k4 + u) * s_k;
-          if (k4 + u < k_left && i4 + 3 < n_rows) {
+          if (vec && k4 + u < k_left && i4 + 3 < n_rows) {
             const float4 t = *reinterpret_cast<const float4*>(src);
             v[16 * e + 4 * u] = t.x; v[16 * e + 4 * u + 1] = t.y;
             v[16 * e + 4 * u + 2] = t.z; v[16 * e + 4 * u + 3] = t.w;
@@ -73,7 +73,7 @@ struct Stage {
         const int idx = tid + e * 256;
         const int i4 = (idx % (R / 4)) * 4, k = idx / (R / 4);
         const float* src = P + i4 + k * s_k;
-        if (k < k_left && i4 + 3 < n_rows) {
+        if (vec && k < k_left && i4 + 3 < n_rows) {
           const float4 t = *reinterpret_cast<const float4*>(src);
           v[4 * e] = t.x; v[4 * e + 1] = t.y; v[4 * e + 2] = t.z; v[4 * e + 3] = t.w;
         } else {
@@ -148,7 +148,8 @@ __global__ __launch_bounds__(256) void k_gemm_bf16(pca_gemm_desc g, const float*
                                                     const float* __restrict__ bias,
                                                     float* __restrict__ C, int split_k,
                                                     int64_t kchunk, int vec_c, int remap,
-                                                    int tiles_m, int tiles_n, int nz) {
+                                                    int tiles_m, int tiles_n, int nz,
+                                                    int vec_ab) {
   constexpr int BM = 32 * WM, BN = 32 * WN;
   using SA = Stage<MA, BM>;
   using SB = Stage<MB, BN>;
@@ -200,16 +201,17 @@ __global__ __launch_bounds__(256) void k_gemm_bf16(pca_gemm_desc g, const float*
     for (int j = 0; j < WN; ++j) acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
 
   float av[SA::NV], bv[SB::NV];
-  SA::load(Ab + k_begin * g.sa_k, g.sa_m, g.sa_k, g.M - m0, k_end - k_begin, tid, av);
-  SB::load(Bb + k_begin * g.sb_k, g.sb_n, g.sb_k, g.N - n0, k_end - k_begin, tid, bv);
+  const bool va = vec_ab & 1, vb = vec_ab & 2;     // 16-byte loads allowed (alignment)
+  SA::load(Ab + k_begin * g.sa_k, g.sa_m, g.sa_k, g.M - m0, k_end - k_begin, tid, va, av);
+  SB::load(Bb + k_begin * g.sb_k, g.sb_n, g.sb_k, g.N - n0, k_end - k_begin, tid, vb, bv);
   for (int64_t kt = k_begin; kt < k_end; kt += BK) {
     __syncthreads();                     // previous tile consumed
     SA::store(As, tid, av);
     SB::store(Bs, tid, bv);
     __syncthreads();
     if (kt + BK < k_end) {               // next tile's loads fly under the MFMAs
-      SA::load(Ab + (kt + BK) * g.sa_k, g.sa_m, g.sa_k, g.M - m0, k_end - kt - BK, tid, av);
-      SB::load(Bb + (kt + BK) * g.sb_k, g.sb_n, g.sb_k, g.N - n0, k_end - kt - BK, tid, bv);
+      SA::load(Ab + (kt + BK) * g.sa_k, g.sa_m, g.sa_k, g.M - m0, k_end - kt - BK, tid, va, av);
+      SB::load(Bb + (kt + BK) * g.sb_k, g.sb_n, g.sb_k, g.N - n0, k_end - kt - BK, tid, vb, bv);
     }
     bf16x8 af[WM];
 #pragma unroll
@@ -317,11 +319,14 @@ __global__ __launch_bounds__(256) void k_gemm_bf16(pca_gemm_desc g, const float*
   }
 }
 
-// staging mode of an operand: 0 k-vectors, 1 row-vectors, 2 scalar
-inline int stage_mode(const float* p, int64_t s_row, int64_t s_k, int64_t b1, int64_t b2) {
+// staging mode of an operand: 0 along k, 1 along the rows, 2 neither stride is 1;
+// *vec: the 16-byte loads of modes 0 / 1 are aligned
+inline int stage_mode(const float* p, int64_t s_row, int64_t s_k, int64_t b1, int64_t b2,
+                      bool* vec) {
   const bool al = (reinterpret_cast<uintptr_t>(p) & 15) == 0 && b1 % 4 == 0 && b2 % 4 == 0;
-  if (s_k == 1 && s_row % 4 == 0 && al) return 0;
-  if (s_row == 1 && s_k % 4 == 0 && al) return 1;
+  *vec = false;
+  if (s_k == 1) { *vec = al && s_row % 4 == 0; return 0; }
+  if (s_row == 1) { *vec = al && s_k % 4 == 0; return 1; }
   return 2;
 }
 
@@ -340,11 +345,11 @@ constexpr int kTileN[6] = {128, 32, 64, 256, 256, 32};
 template <int WM, int WN>
 void launch_vec(int ma, int mb, dim3 grid, hipStream_t st, const pca_gemm_desc& g, const float* A,
                 const float* B, const float* bias, float* C, int split, int64_t kchunk, int vc,
-                int remap, int tm, int tn, int nz) {
+                int remap, int tm, int tn, int nz, int vab) {
 #define PCA_GEMM_CASE(X, Y)                                                                   \
   if (ma == X && mb == Y)                                                                     \
     hipLaunchKernelGGL((k_gemm_bf16<X, Y, WM, WN>), grid, dim3(256), 0, st, g, A, B, bias, C, \
-                       split, kchunk, vc, remap, tm, tn, nz)
+                       split, kchunk, vc, remap, tm, tn, nz, vab)
   PCA_GEMM_CASE(0, 0); PCA_GEMM_CASE(0, 1); PCA_GEMM_CASE(1, 0); PCA_GEMM_CASE(1, 1);
 #undef PCA_GEMM_CASE
 }
@@ -359,9 +364,11 @@ int gemm_bf16(const pca_gemm_desc& gin, const float* A, const float* B, const fl
   if (g.nb2 <= 0) g.nb2 = 1;
   if (g.M == 0 || g.N == 0) return PCA_OK;
   // K chunks start at multiples of 32 floats, so the vector paths stay aligned
-  const int ma = stage_mode(A, g.sa_m, g.sa_k, g.sa_b1, g.sa_b2);
-  const int mb = stage_mode(B, g.sb_n, g.sb_k, g.sb_b1, g.sb_b2);
-  // the narrow tiles exist for the vectorised staging modes only
+  bool va = false, vb = false;
+  const int ma = stage_mode(A, g.sa_m, g.sa_k, g.sa_b1, g.sa_b2, &va);
+  const int mb = stage_mode(B, g.sb_n, g.sb_k, g.sb_b1, g.sb_b2, &vb);
+  const int vab = (va ? 1 : 0) | (vb ? 2 : 0);
+  // the narrow tiles exist for the staging modes 0 / 1 only
   const int tv = (ma == 2 || mb == 2) ? 0 : tile_variant(g.M, g.N);
   const int64_t tiles_m = cdiv(g.M, kTileM[tv]), tiles_n = cdiv(g.N, kTileN[tv]);
   const int64_t nbatch = (int64_t)g.nb1 * g.nb2;
@@ -398,16 +405,16 @@ int gemm_bf16(const pca_gemm_desc& gin, const float* A, const float* B, const fl
   const int vc = (reinterpret_cast<uintptr_t>(C) & 15) == 0 && g.sc_m % 4 == 0 &&
                  g.sc_b1 % 4 == 0 && g.sc_b2 % 4 == 0;
   switch (tv) {
-    case 1: launch_vec<8, 1>(ma, mb, grid, st, g, A, B, bias, C, split, kchunk, vc, remap, tm, tn, (int)nz); break;
-    case 2: launch_vec<8, 2>(ma, mb, grid, st, g, A, B, bias, C, split, kchunk, vc, remap, tm, tn, (int)nz); break;
-    case 3: launch_vec<1, 8>(ma, mb, grid, st, g, A, B, bias, C, split, kchunk, vc, remap, tm, tn, (int)nz); break;
-    case 4: launch_vec<2, 8>(ma, mb, grid, st, g, A, B, bias, C, split, kchunk, vc, remap, tm, tn, (int)nz); break;
-    case 5: launch_vec<1, 1>(ma, mb, grid, st, g, A, B, bias, C, split, kchunk, vc, remap, tm, tn, (int)nz); break;
+    case 1: launch_vec<8, 1>(ma, mb, grid, st, g, A, B, bias, C, split, kchunk, vc, remap, tm, tn, (int)nz, vab); break;
+    case 2: launch_vec<8, 2>(ma, mb, grid, st, g, A, B, bias, C, split, kchunk, vc, remap, tm, tn, (int)nz, vab); break;
+    case 3: launch_vec<1, 8>(ma, mb, grid, st, g, A, B, bias, C, split, kchunk, vc, remap, tm, tn, (int)nz, vab); break;
+    case 4: launch_vec<2, 8>(ma, mb, grid, st, g, A, B, bias, C, split, kchunk, vc, remap, tm, tn, (int)nz, vab); break;
+    case 5: launch_vec<1, 1>(ma, mb, grid, st, g, A, B, bias, C, split, kchunk, vc, remap, tm, tn, (int)nz, vab); break;
     default: {
 #define PCA_GEMM_CASE(X, Y)                                                                   \
   if (ma == X && mb == Y)                                                                     \
     hipLaunchKernelGGL((k_gemm_bf16<X, Y, 4, 4>), grid, dim3(256), 0, st, g, A, B, bias, C,   \
-                       split, kchunk, vc, remap, tm, tn, (int)nz)
+                       split, kchunk, vc, remap, tm, tn, (int)nz, vab)
       PCA_GEMM_CASE(0, 0); PCA_GEMM_CASE(0, 1); PCA_GEMM_CASE(0, 2);
       PCA_GEMM_CASE(1, 0); PCA_GEMM_CASE(1, 1); PCA_GEMM_CASE(1, 2);
       PCA_GEMM_CASE(2, 0); PCA_GEMM_CASE(2, 1); PCA_GEMM_CASE(2, 2);

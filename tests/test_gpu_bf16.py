@@ -265,7 +265,7 @@ def _bf16_round(t):
     return t.to(torch.bfloat16).to(torch.float64)
 
 
-@pytest.mark.parametrize("layout", ["nt", "nn", "tn", "tt", "scalar"])
+@pytest.mark.parametrize("layout", ["nt", "nn", "tn", "tt", "scalar", "scalar_tn", "strided"])
 def test_gemm_bf16_tile_variants(dev, layout):
     """pca_gemm_bf16 over every tile shape (128x128, 256x32, 256x64, 32x256, 64x256, 32x32) and
     staging mode (k-vectors, row-vectors, scalar), with ragged edges, bias, alpha, accumulate,
@@ -281,18 +281,26 @@ def test_gemm_bf16_tile_variants(dev, layout):
     if layout in ("nt", "tn"):      # the XCD-aware workgroup orders: tall A; long split K
         shapes += [(8203, 200, 40), (130, 140, 200000)]
     for (M, N, K) in shapes:
-        pad = 0 if layout != "scalar" else 1          # odd leading dimensions -> scalar staging
+        pad = 1 if layout.startswith("scalar") else 0   # odd leading dimensions -> 4-byte loads
         # A as [M, K] (k contiguous) or [K, M] (rows contiguous); same for B as [N, K] / [K, N]
-        a_t = layout[0] == "t"
-        b_t = layout[1] == "n" and layout != "scalar"
+        a_t = layout[0] == "t" or layout == "scalar_tn"
+        b_t = layout in ("nn", "tn", "scalar_tn")
         Ms, Ks, Ns = M + (-M) % 4, K + (-K) % 4, N + (-N) % 4      # 16-byte aligned rows
-        if a_t:
+        if layout == "strided":                      # neither stride is 1 (every other float)
+            if M * K > 4_000_000:
+                continue
+            Abuf = torch.randn(M, K, 2, generator=g).to(dev); sa_m, sa_k = 2 * K, 2
+            Aref = Abuf[:, :, 0]
+        elif a_t:
             Abuf = torch.randn(K, Ms + pad, generator=g).to(dev); sa_m, sa_k = 1, Ms + pad
             Aref = Abuf[:, :M].t()
         else:
             Abuf = torch.randn(M, Ks + pad, generator=g).to(dev); sa_m, sa_k = Ks + pad, 1
             Aref = Abuf[:, :K]
-        if b_t:
+        if layout == "strided":
+            Bbuf = torch.randn(N, K, 2, generator=g).to(dev); sb_n, sb_k = 2 * K, 2
+            Bref = Bbuf[:, :, 0]
+        elif b_t:
             Bbuf = torch.randn(K, Ns + pad, generator=g).to(dev); sb_n, sb_k = 1, Ns + pad
             Bref = Bbuf[:, :N].t()
         else:
