@@ -6,9 +6,9 @@ namespace pca {
 
 
 
-static int check_f32(const pca_mab_shape* s) {
+static int check_f32(const pca_mab_shape* s, bool inference) {
   // the exact path exchanges fp32 only; the fused kernels validate their own dtypes
-  PCA_REQUIRE(mab_kind(*s) != 0 || (s->q_dtype == PCA_F32 && s->k_dtype == PCA_F32 &&
+  PCA_REQUIRE(mab_kind(*s, inference) != 0 || (s->q_dtype == PCA_F32 && s->k_dtype == PCA_F32 &&
                                     s->y_dtype == PCA_F32),
               "mab: the exact fp32 path needs fp32 Q, K and Y");
   return PCA_OK;
@@ -17,11 +17,12 @@ static int check_f32(const pca_mab_shape* s) {
 // ---- mode resolution + dispatch, shared by the C entry points and the ST engine ----
 // kind: 0 = exact fp32 chain of GEMMs, 1 = fused bf16 mab1 (many queries, few keys),
 //       2 = fused bf16 mab0 (few shared queries, many keys)
-int mab_kind(const pca_mab_shape& s) {
+int mab_kind(const pca_mab_shape& s, bool inference) {
   // (a fused mab1 has the m inducing-point outputs as keys: always all of them; a caller that
   // masks keys of such a shape gets the exact path, whose softmax honours k_lengths)
   if (s.ln) return 0;          // LayerNorm variants: exact chain only
-  if (s.mode == PCA_MODE_BF16 && s.k_lengths == nullptr && mab1_bf16_supported(s)) return 1;
+  if (s.mode == PCA_MODE_BF16 && s.k_lengths == nullptr && mab1_bf16_supported(s, inference))
+    return 1;
   if (s.mode == PCA_MODE_BF16 && mab0_bf16_supported(s)) return 2;
   return 0;
 }
@@ -31,8 +32,14 @@ size_t mab_saved_bytes_any(const pca_mab_shape& s) {
                                                     : mab_f32_saved_bytes(s);
 }
 size_t mab_fwd_ws_bytes_any(const pca_mab_shape& s) {
-  // inference (saved == NULL) keeps the intermediates in the scratch block instead
-  const int k = mab_kind(s);
+  // inference (saved == NULL) keeps the intermediates in the scratch block instead; a training
+  // forward of the same shape never needs more (the exact chain's scratch is its saved block)
+  const int k = mab_kind(s, true);
+  if (k != mab_kind(s, false)) {
+    const size_t a = k == 1 ? mab1_bf16_fwd_ws_bytes(s) : mab0_bf16_fwd_ws_bytes(s);
+    const size_t b = mab_f32_saved_bytes(s);
+    return a > b ? a : b;
+  }
   return k == 1 ? mab1_bf16_fwd_ws_bytes(s) : k == 2 ? mab0_bf16_fwd_ws_bytes(s)
                                                      : mab_f32_saved_bytes(s);
 }
@@ -43,7 +50,7 @@ size_t mab_bwd_ws_bytes_any(const pca_mab_shape& s) {
 }
 int mab_fwd_any(const pca_mab_shape& s, const void* Q, const void* K, const pca_mab_params& p,
                 void* Y, void* saved, void* ws, hipStream_t st) {
-  const int k = mab_kind(s);
+  const int k = mab_kind(s, saved == nullptr);
   if (k == 1) return mab1_bf16_fwd(s, Q, (const float*)K, p, Y, saved, ws, st);
   if (k == 2) return mab0_bf16_fwd(s, (const float*)Q, K, p, (float*)Y, saved, ws, st);
   return mab_f32_fwd(s, (const float*)Q, (const float*)K, p, (float*)Y, saved ? saved : ws, st);
@@ -68,8 +75,8 @@ extern "C" {
 // An explicit PCA_MODE_BF16 request must be served by a fused kernel (no silent change of
 // arithmetic at this level); callers that want "bf16 where available" query
 // pca_mab_saved_bytes() first, which returns 0 for unsupported bf16 shapes.
-static int bf16_demand(const pca_mab_shape* s) {
-  if (s->mode == PCA_MODE_BF16 && pca::mab_kind(*s) == 0) {
+static int bf16_demand(const pca_mab_shape* s, bool inference = false) {
+  if (s->mode == PCA_MODE_BF16 && pca::mab_kind(*s, inference) == 0) {
     pca::set_error("mab: no bf16 kernel for B=%d nq=%d nk=%d dq=%d dk=%d d=%d h=%d q_shared=%d",
                    s->B, s->nq, s->nk, s->dq, s->dk, s->d, s->h, s->q_shared);
     return PCA_EUNSUPPORTED;
@@ -86,7 +93,7 @@ size_t pca_mab_saved_bytes(const pca_mab_shape* s) {
   return pca::mab_saved_bytes_any(*s);
 }
 size_t pca_mab_fwd_ws_bytes(const pca_mab_shape* s) {
-  if (pca::validate_shape(s) != PCA_OK || bf16_demand(s) != PCA_OK) return 0;
+  if (pca::validate_shape(s) != PCA_OK || bf16_demand(s, true) != PCA_OK) return 0;
   return pca::mab_fwd_ws_bytes_any(*s);
 }
 size_t pca_mab_bwd_ws_bytes(const pca_mab_shape* s) {
@@ -100,9 +107,9 @@ int pca_mab_fwd(const pca_mab_shape* s, const void* Q, const void* K,
   PCA_REQUIRE(Q && K && p && Y, "mab_fwd: null pointer");
   PCA_REQUIRE(p->wq && p->bq && p->wk && p->bk && p->wv && p->bv && p->wo && p->bo,
               "mab_fwd: null parameter");
-  PCA_TRY(bf16_demand(s));
-  PCA_TRY(pca::check_f32(s));
-  PCA_REQUIRE(ws != nullptr || (saved != nullptr && pca::mab_kind(*s) == 0),
+  PCA_TRY(bf16_demand(s, saved == nullptr));
+  PCA_TRY(pca::check_f32(s, saved == nullptr));
+  PCA_REQUIRE(ws != nullptr || (saved != nullptr && pca::mab_kind(*s, false) == 0),
               "mab_fwd: scratch block required");
   return pca::mab_fwd_any(*s, Q, K, *p, Y, saved, ws, pca::as_stream(stream));
 }
@@ -115,7 +122,7 @@ int pca_mab_bwd(const pca_mab_shape* s, const void* Q, const void* K,
   PCA_REQUIRE(g->wq && g->bq && g->wk && g->bk && g->wv && g->bv && g->wo && g->bo,
               "mab_bwd: null gradient buffer");
   PCA_TRY(bf16_demand(s));
-  PCA_TRY(pca::check_f32(s));
+  PCA_TRY(pca::check_f32(s, false));
   return pca::mab_bwd_any(*s, Q, K, *p, saved, dY, dQ, dK, dk_accumulate, *g, ws,
                           pca::as_stream(stream));
 }

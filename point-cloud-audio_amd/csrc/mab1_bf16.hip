@@ -92,7 +92,7 @@ __global__ void k_transpose_f32(const float* __restrict__ src, float* __restrict
 // with key(kp) = kp for m = 16 (16x16x16 MFMA, natural k) and perm32(kp) for m = 32.
 // ---------------------------------------------------------------------------------
 template <int MI>
-__global__ __launch_bounds__(256) void k_kv_proj(const float* __restrict__ H,
+__global__ __launch_bounds__(256) void k_kv_proj(const float* __restrict__ H,   // 64 or 256 threads
                                                  const float* __restrict__ WkT,   // [d][d] in x out
                                                  const float* __restrict__ bk,
                                                  const float* __restrict__ WvT,
@@ -103,10 +103,11 @@ __global__ __launch_bounds__(256) void k_kv_proj(const float* __restrict__ H,
                                                  __bf16* __restrict__ Vt) {
   extern __shared__ __attribute__((aligned(16))) float sH[];   // [MI][d]
   const int b = blockIdx.x;
-  for (int i = threadIdx.x; i < MI * d; i += 256) sH[i] = H[(int64_t)b * MI * d + i];
+  for (int i = threadIdx.x; i < MI * d; i += blockDim.x) sH[i] = H[(int64_t)b * MI * d + i];
   __syncthreads();
-  // thread = (output feature f, K or V); d == 128 -> 256 threads cover both
-  for (int o = threadIdx.x; o < 2 * d; o += 256) {
+  // thread = (output feature f, K or V); d == 128 -> 256 threads cover both; wider blocks are
+  // spread over blockIdx.y (a thread's MI * d MACs are the critical path)
+  for (int o = blockIdx.y * blockDim.x + threadIdx.x; o < 2 * d; o += blockDim.x * gridDim.y) {
     const int f = o % d, isv = o / d;
     float acc[MI];
     const float bias = isv ? bv[f] : bk[f];
@@ -157,18 +158,29 @@ struct Mab1FwdArgs {
 // LDS, so only one workgroup fits a CU; eight waves sharing those weights give each SIMD two
 // wavefronts to interleave (the chain is a long dependent sequence: ~0.3 instructions issued
 // per wave-cycle at one wavefront per SIMD).  Waves 4..7 take the next 128-point tile.
-template <int D, int MI, bool DIN_SMALL, bool ABF, int NW>
-__global__ __launch_bounds__(64 * NW, NW == 8 ? 1 : 2) void k_mab1_fwd(const Mab1FwdArgs a) {
+//
+// PHASE: d = 256 holds ONE 128 KiB weight image next to the K/V images of a set, so the d -> d
+// block runs as two launches that meet at O (bf16, in the scratch block):
+//   0  the whole chain (d = 128; d = 256 layer 1, which has no Wq image)
+//   1  Q phase: X -> Qp -> attention -> O     (Wq + K/V images; X fragments straight from global)
+//   2  O phase: Y = O + relu(O Wo^T + bo)     (Wo image)
+template <int D, int MI, bool DIN_SMALL, bool ABF, int NW, int PHASE>
+__global__ __launch_bounds__(64 * NW, (NW == 8 || D > 128) ? 1 : 2) void k_mab1_fwd(
+    const Mab1FwdArgs a) {
   constexpr int NT = 64 * NW, SUBS = NW / 4;
   constexpr int DT = D / 16;          // feature tiles
   constexpr int KS = D / 32;          // 32-wide K steps = heads (dh == 32)
   constexpr int ROWB = D * 2;         // bytes per row of a [.][D] bf16 image
+  constexpr bool HAS_WO = PHASE != 1, HAS_KV = PHASE != 2;
+  constexpr bool HAS_WQ = !DIN_SMALL && PHASE != 2;
+  static_assert(!(DIN_SMALL && PHASE != 0), "layer 1 runs the whole chain");
   extern __shared__ __attribute__((aligned(16))) char smem[];
   char* sWo = smem;                                   // D x D bf16, swizzled
-  char* sKp = sWo + D * ROWB;                         // MI x D
-  char* sVt = sKp + MI * ROWB;                        // D x MI
-  char* sWq = sVt + D * MI * 2;                       // D x D (absent when DIN_SMALL)
-  char* sX = sWq + (DIN_SMALL ? 0 : D * ROWB);        // TP x D (absent when DIN_SMALL)
+  char* sKp = sWo + (HAS_WO ? D * ROWB : 0);          // MI x D
+  char* sVt = sKp + (HAS_KV ? MI * ROWB : 0);         // D x MI
+  char* sWq = sVt + (HAS_KV ? D * MI * 2 : 0);        // D x D (absent when DIN_SMALL)
+  char* sX = sWq + (HAS_WQ ? D * ROWB : 0);           // TP x D (PHASE 0, d -> d only)
+  (void)sX;
 
   const int tid = threadIdx.x, lane = tid & 63, wave8 = tid >> 6;
   const int wave = wave8 & 3, sub = wave8 >> 2;
@@ -179,18 +191,18 @@ __global__ __launch_bounds__(64 * NW, NW == 8 ? 1 : 2) void k_mab1_fwd(const Mab
     // all chunks of this thread first, then the LDS stores: one round trip instead of one per
     // iteration (a store between two loads orders them)
     constexpr int NC = D * (D / 8) / NT;
-    uint4 wo[NC], wq[DIN_SMALL ? 1 : NC];
+    uint4 wo[HAS_WO ? NC : 1], wq[HAS_WQ ? NC : 1];
 #pragma unroll
     for (int e = 0; e < NC; ++e) {
       const int c = tid + NT * e, row = c / (D / 8), c16 = c % (D / 8);
-      wo[e] = *reinterpret_cast<const uint4*>(a.WoP + (int64_t)row * D + c16 * 8);
-      if (!DIN_SMALL) wq[e] = *reinterpret_cast<const uint4*>(a.WqB + (int64_t)row * D + c16 * 8);
+      if (HAS_WO) wo[e] = *reinterpret_cast<const uint4*>(a.WoP + (int64_t)row * D + c16 * 8);
+      if (HAS_WQ) wq[e] = *reinterpret_cast<const uint4*>(a.WqB + (int64_t)row * D + c16 * 8);
     }
 #pragma unroll
     for (int e = 0; e < NC; ++e) {
       const int c = tid + NT * e, row = c / (D / 8), c16 = c % (D / 8);
-      *reinterpret_cast<uint4*>(sWo + swz(row, c16, ROWB)) = wo[e];
-      if (!DIN_SMALL) *reinterpret_cast<uint4*>(sWq + swz(row, c16, ROWB)) = wq[e];
+      if (HAS_WO) *reinterpret_cast<uint4*>(sWo + swz(row, c16, ROWB)) = wo[e];
+      if (HAS_WQ) *reinterpret_cast<uint4*>(sWq + swz(row, c16, ROWB)) = wq[e];
     }
   }
 
@@ -199,7 +211,7 @@ __global__ __launch_bounds__(64 * NW, NW == 8 ? 1 : 2) void k_mab1_fwd(const Mab
   int cur_b = -1;
   for (int unit = blockIdx.x; unit < total_units; unit += gridDim.x) {
     const int b = unit / units_per_set, tile = (unit - b * units_per_set) * SUBS + sub;
-    if (b != cur_b) {                       // this set's Kp / Vp images
+    if (HAS_KV && b != cur_b) {             // this set's Kp / Vp images
       __syncthreads();
       for (int c = tid; c < MI * (D / 8); c += NT) {
         const int row = c / (D / 8), c16 = c % (D / 8);
@@ -217,7 +229,21 @@ __global__ __launch_bounds__(64 * NW, NW == 8 ? 1 : 2) void k_mab1_fwd(const Mab
     const int n_base = tile * TP + wave * 32;           // first point of this wave
     f32x4 acc[DT][NB];
 
-    if (DIN_SMALL) {
+    if (PHASE == 2) {
+      // O phase: the tile of O comes back from the scratch block (bf16, [point][feature])
+#pragma unroll
+      for (int nb = 0; nb < NB; ++nb) {
+        const int n = n_base + 16 * nb + r;
+#pragma unroll
+        for (int t = 0; t < DT; ++t) {
+          bf16x4 o4 = {(__bf16)0.f, (__bf16)0.f, (__bf16)0.f, (__bf16)0.f};
+          if (n < a.N)
+            o4 = *reinterpret_cast<const bf16x4*>(a.OS + ((int64_t)b * a.N + n) * D + 16 * t +
+                                                  4 * g);
+          acc[t][nb] = f32x4{(float)o4[0], (float)o4[1], (float)o4[2], (float)o4[3]};
+        }
+      }
+    } else if (DIN_SMALL) {
       // layer 1: Qp = x Wq^T + bq with dq in 1..4, exact fp32 on the vector ALU
       float xv[NB][4];
 #pragma unroll
@@ -242,6 +268,47 @@ __global__ __launch_bounds__(64 * NW, NW == 8 ? 1 : 2) void k_mab1_fwd(const Mab
           for (int nb = 0; nb < NB; ++nb)
             acc[t][nb][e] = bias + w[0] * xv[nb][0] + w[1] * xv[nb][1] + w[2] * xv[nb][2] +
                             w[3] * xv[nb][3];
+        }
+      }
+    } else if (PHASE == 1) {
+      // Q phase (d = 256): no room for an X tile in LDS; a lane's B fragment is 8 consecutive
+      // features of its point, i.e. 16 (bf16) or 32 (fp32) contiguous bytes of global memory
+#pragma unroll
+      for (int t = 0; t < DT; ++t) {
+        const float4 b4 = *reinterpret_cast<const float4*>(a.bq + 16 * t + 4 * g);
+#pragma unroll
+        for (int nb = 0; nb < NB; ++nb) acc[t][nb] = f32x4{b4.x, b4.y, b4.z, b4.w};
+      }
+      bf16x8 bxa[KS][NB];
+#pragma unroll
+      for (int s = 0; s < KS; ++s)
+#pragma unroll
+        for (int nb = 0; nb < NB; ++nb) {
+          const int n = n_base + 16 * nb + r;
+          const int64_t xo = ((int64_t)b * a.N + n) * D + 32 * s + 8 * g;
+          bf16x8 v;
+          if (n < a.N && ABF) {
+            v = *reinterpret_cast<const bf16x8*>(reinterpret_cast<const __bf16*>(a.X) + xo);
+          } else if (n < a.N) {
+            const float4* src =
+                reinterpret_cast<const float4*>(reinterpret_cast<const float*>(a.X) + xo);
+            const float4 lo = src[0], hi = src[1];
+            v[0] = (__bf16)lo.x; v[1] = (__bf16)lo.y; v[2] = (__bf16)lo.z; v[3] = (__bf16)lo.w;
+            v[4] = (__bf16)hi.x; v[5] = (__bf16)hi.y; v[6] = (__bf16)hi.z; v[7] = (__bf16)hi.w;
+          } else {
+#pragma unroll
+            for (int e = 0; e < 8; ++e) v[e] = (__bf16)0.f;
+          }
+          bxa[s][nb] = v;
+        }
+#pragma unroll
+      for (int s = 0; s < KS; ++s) {
+#pragma unroll
+        for (int t = 0; t < DT; ++t) {
+          const bf16x8 wa =
+              *reinterpret_cast<const bf16x8*>(sWq + swz(16 * t + r, 4 * s + g, ROWB));
+#pragma unroll
+          for (int nb = 0; nb < NB; ++nb) acc[t][nb] = mfma32(wa, bxa[s][nb], acc[t][nb]);
         }
       }
     } else {
@@ -290,6 +357,7 @@ __global__ __launch_bounds__(64 * NW, NW == 8 ? 1 : 2) void k_mab1_fwd(const Mab
       }
     }
 
+    if (PHASE != 2) {
     // ---- save Qp for the backward (bf16, [point][feature]) ----
     if (a.QpS != nullptr) {
 #pragma unroll
@@ -361,78 +429,99 @@ __global__ __launch_bounds__(64 * NW, NW == 8 ? 1 : 2) void k_mab1_fwd(const Mab
       }
     }
 
-    // ---- GEMM2: Z^T = Wo . O^T ; Y = O + relu(Z + bo) ----
-    f32x4 z[DT][NB];
-#pragma unroll
-    for (int t = 0; t < DT; ++t) {
-      const float4 b4 = *reinterpret_cast<const float4*>(a.bo + 16 * t + 4 * g);
-#pragma unroll
-      for (int nb = 0; nb < NB; ++nb) z[t][nb] = f32x4{b4.x, b4.y, b4.z, b4.w};
-    }
-#pragma unroll
-    for (int s = 0; s < KS; ++s) {
-      bf16x8 ob[NB];
-#pragma unroll
-      for (int nb = 0; nb < NB; ++nb) ob[nb] = pack8(acc[2 * s][nb], acc[2 * s + 1][nb]);
-#pragma unroll
-      for (int t = 0; t < DT; ++t) {
-        const bf16x8 wa =
-            *reinterpret_cast<const bf16x8*>(sWo + swz(16 * t + r, 4 * s + g, ROWB));
-#pragma unroll
-        for (int nb = 0; nb < NB; ++nb) z[t][nb] = mfma32(wa, ob[nb], z[t][nb]);
-      }
-    }
+    }   // PHASE != 2
+    if (PHASE == 1) continue;               // O is in the scratch block; the O phase finishes
 
+    // ---- GEMM2: Z^T = Wo . O^T ; Y = O + relu(Z + bo) ----
+    // (d = 256: the output features in two halves of 128, so that Z needs 64 registers)
+    constexpr int HT = D / 128, DTH = DT / HT;
+    bf16x8 oball[HT > 1 ? KS : 1][NB];      // packed once when it is used twice
+    if (HT > 1) {
 #pragma unroll
-    for (int nb = 0; nb < NB; ++nb) {
-      const int n = n_base + 16 * nb + r;
-      uint32_t bits[D / 128];
+      for (int s = 0; s < KS; ++s)
 #pragma unroll
-      for (int w = 0; w < D / 128; ++w) bits[w] = 0u;
+        for (int nb = 0; nb < NB; ++nb)
+          oball[HT > 1 ? s : 0][nb] = pack8(acc[2 * s][nb], acc[2 * s + 1][nb]);
+    }
 #pragma unroll
-      for (int t = 0; t < DT; ++t) {
-        f32x4 y;
+    for (int hf = 0; hf < HT; ++hf) {
+      f32x4 z[DTH][NB];
 #pragma unroll
-        for (int e = 0; e < 4; ++e) {
-          const float zz = z[t][nb][e];
-          y[e] = acc[t][nb][e] + fmaxf(zz, 0.f);
-          if (zz > 0.f) bits[t / 8] |= 1u << ((t & 7) * 4 + e);
-        }
-        if (n < a.N) {
-          const int64_t yo = ((int64_t)b * a.N + n) * D + 16 * t + 4 * g;
-          if (ABF) *reinterpret_cast<bf16x4*>(reinterpret_cast<__bf16*>(a.Y) + yo) = pack4(y);
-          else *reinterpret_cast<float4*>(reinterpret_cast<float*>(a.Y) + yo) =
-                   float4{y[0], y[1], y[2], y[3]};
+      for (int tt = 0; tt < DTH; ++tt) {
+        const float4 b4 = *reinterpret_cast<const float4*>(a.bo + 16 * (hf * DTH + tt) + 4 * g);
+#pragma unroll
+        for (int nb = 0; nb < NB; ++nb) z[tt][nb] = f32x4{b4.x, b4.y, b4.z, b4.w};
+      }
+#pragma unroll
+      for (int s = 0; s < KS; ++s) {
+        bf16x8 ob[NB];
+#pragma unroll
+        for (int nb = 0; nb < NB; ++nb)
+          ob[nb] = HT > 1 ? oball[HT > 1 ? s : 0][nb] : pack8(acc[2 * s][nb], acc[2 * s + 1][nb]);
+#pragma unroll
+        for (int tt = 0; tt < DTH; ++tt) {
+          const bf16x8 wa = *reinterpret_cast<const bf16x8*>(
+              sWo + swz(16 * (hf * DTH + tt) + r, 4 * s + g, ROWB));
+#pragma unroll
+          for (int nb = 0; nb < NB; ++nb) z[tt][nb] = mfma32(wa, ob[nb], z[tt][nb]);
         }
       }
-      if (a.mask != nullptr) {
 #pragma unroll
-        for (int w = 0; w < D / 128; ++w)
-          a.mask[mab1_mask_index<D>(b, a.tiles_per_set, tile, wave, nb, w, lane)] = bits[w];
+      for (int nb = 0; nb < NB; ++nb) {
+        const int n = n_base + 16 * nb + r;
+        uint32_t bits = 0u;                 // mask word hf covers feature tiles 8 hf .. 8 hf + 7
+#pragma unroll
+        for (int tt = 0; tt < DTH; ++tt) {
+          const int t = hf * DTH + tt;
+          f32x4 y;
+#pragma unroll
+          for (int e = 0; e < 4; ++e) {
+            const float zz = z[tt][nb][e];
+            y[e] = acc[t][nb][e] + fmaxf(zz, 0.f);
+            if (zz > 0.f) bits |= 1u << ((t & 7) * 4 + e);
+          }
+          if (n < a.N) {
+            const int64_t yo = ((int64_t)b * a.N + n) * D + 16 * t + 4 * g;
+            if (ABF) *reinterpret_cast<bf16x4*>(reinterpret_cast<__bf16*>(a.Y) + yo) = pack4(y);
+            else *reinterpret_cast<float4*>(reinterpret_cast<float*>(a.Y) + yo) =
+                     float4{y[0], y[1], y[2], y[3]};
+          }
+        }
+        if (a.mask != nullptr)
+          a.mask[mab1_mask_index<D>(b, a.tiles_per_set, tile, wave, nb, hf, lane)] = bits;
       }
     }
   }
 }
 
-template <int D, int MI, bool DS, bool ABF>
+template <int D, int MI, bool DS, bool ABF, int PHASE = 0>
 int launch_fwd(const Mab1FwdArgs& a, hipStream_t st) {
-  // layer 1 (40 KiB of LDS): 4 waves, two workgroups per CU; d -> d (104+ KiB): 8 waves
-  constexpr int NW = (DS || MI != 16) ? 4 : 8;
-  const size_t lds = (size_t)D * D * 2 + (size_t)MI * D * 2 + (size_t)D * MI * 2 +
-                     (DS ? 0 : (size_t)D * D * 2 + (size_t)NW * 32 * D * 2);
+  // layer 1 (40 KiB of LDS): 4 waves, two workgroups per CU; d -> d (104+ KiB): 8 waves;
+  // d = 256 (128 - 160 KiB): one workgroup per CU, 8 waves (layer 1: 4 waves, both the Qp and
+  // the Z tiles live in registers)
+  constexpr int NW = D > 128 ? (DS ? 4 : 8) : (DS || MI != 16) ? 4 : 8;
+  const size_t wimg = (size_t)D * D * 2, kv = (size_t)MI * D * 2 + (size_t)D * MI * 2;
+  const size_t lds = (PHASE != 1 ? wimg : 0) + (PHASE != 2 ? kv : 0) +
+                     ((!DS && PHASE != 2) ? wimg : 0) +
+                     ((!DS && PHASE == 0) ? (size_t)NW * 32 * D * 2 : 0);
   static std::once_flag once;
   std::call_once(once, [] {
-    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(k_mab1_fwd<D, MI, DS, ABF, NW>),
-                              hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+    (void)hipFuncSetAttribute(
+        reinterpret_cast<const void*>(k_mab1_fwd<D, MI, DS, ABF, NW, PHASE>),
+        hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
   });
   const int total = a.B * ((a.tiles_per_set + NW / 4 - 1) / (NW / 4));
-  const int cap = DS ? 512 : 256;
+  const int cap = (DS && D == 128) ? 512 : 256;
   const int grid = total < cap ? total : cap;
   const double pts = (double)a.B * a.N;
-  ProfScope ps(PCA_K_MAB1_FWD, st,
-               2.0 * pts * ((double)a.dq * D + (double)D * D + 2.0 * MI * D),
-               pts * ((ABF && !DS ? 2.0 : 4.0) * a.dq + (ABF ? 2.0 : 4.0) * D));
-  hipLaunchKernelGGL((k_mab1_fwd<D, MI, DS, ABF, NW>), dim3(grid), dim3(64 * NW), lds, st, a);
+  // PHASE 1 / 2 split the work of one block; the pair is one profiled unit
+  const double fl = 2.0 * pts * ((PHASE != 2 ? (double)a.dq * D + 2.0 * MI * D : 0.0) +
+                                 (PHASE != 1 ? (double)D * D : 0.0));
+  const double by = pts * ((PHASE != 2 ? (ABF && !DS ? 2.0 : 4.0) * a.dq : 0.0) +
+                           (PHASE != 1 ? (ABF ? 2.0 : 4.0) * D : 0.0));
+  ProfScope ps(PCA_K_MAB1_FWD, st, fl, by);
+  hipLaunchKernelGGL((k_mab1_fwd<D, MI, DS, ABF, NW, PHASE>), dim3(grid), dim3(64 * NW), lds, st,
+                     a);
   ps.end();
   return check_launch("k_mab1_fwd");
 }
@@ -462,11 +551,14 @@ int prep_weight(const float* src, __bf16* dst, int rows, int cols, int mode, hip
   return check_launch("k_prep_weight");
 }
 
-bool mab1_bf16_supported(const pca_mab_shape& s) {
+bool mab1_bf16_supported(const pca_mab_shape& s, bool inference) {
   // activations: fp32 everywhere, or bf16 for Y (and for X when it is a hidden tensor)
   const bool dt_ok = s.k_dtype == PCA_F32 &&
                      (s.dq <= 4 ? s.q_dtype == PCA_F32 : s.q_dtype == s.y_dtype);
-  return s.q_shared == 0 && s.d == 128 && s.h * 32 == s.d && (s.nk == 16 || s.nk == 32) &&
+  // d = 256 / m = 32 (BASELINE configs[3]): forward only so far, fp32 activations
+  const bool d_ok = s.d == 128 || (inference && s.d == 256 && s.nk == 32 &&
+                                   s.q_dtype == PCA_F32 && s.y_dtype == PCA_F32);
+  return s.q_shared == 0 && d_ok && s.h * 32 == s.d && (s.nk == 16 || s.nk == 32) &&
          s.dk == s.d && (s.dq == s.d || s.dq <= 4) && dt_ok;
 }
 
@@ -502,7 +594,7 @@ int mab1_bf16_fwd(const pca_mab_shape& s, const void* X, const float* H,
 int mab1_bf16_fwd_ex(const pca_mab_shape& s, const void* X, const float* H,
                      const pca_mab_params& p, void* Y, void* saved, void* ws, int flags,
                      hipStream_t st, const IsabImg* img) {
-  PCA_REQUIRE(mab1_bf16_supported(s), "mab1_bf16_fwd: unsupported shape");
+  PCA_REQUIRE(mab1_bf16_supported(s, saved == nullptr), "mab1_bf16_fwd: unsupported shape");
   PCA_REQUIRE(ws != nullptr, "mab1_bf16_fwd: scratch required");
   Carver cw(ws);
   __bf16* WqB = cw.take<__bf16>((size_t)s.d * s.d);
@@ -529,9 +621,12 @@ int mab1_bf16_fwd_ex(const pca_mab_shape& s, const void* X, const float* H,
   if (s.nk == 16)
     hipLaunchKernelGGL((k_kv_proj<16>), dim3(s.B), dim3(256), hl, st, H, WkT, p.bk, WvT, p.bv,
                        d, v.KpP, v.VpP, v.Kt, v.Vt);
-  else
+  else if (d <= 128)
     hipLaunchKernelGGL((k_kv_proj<32>), dim3(s.B), dim3(256), hl, st, H, WkT, p.bk, WvT, p.bv,
                        d, v.KpP, v.VpP, v.Kt, v.Vt);
+  else      // one wave per 64 outputs
+    hipLaunchKernelGGL((k_kv_proj<32>), dim3(s.B, 2 * d / 64), dim3(64), hl, st, H, WkT, p.bk,
+                       WvT, p.bv, d, v.KpP, v.VpP, v.Kt, v.Vt);
   PCA_TRY(check_launch("k_kv_proj"));
   }
 
@@ -553,6 +648,12 @@ int mab1_bf16_fwd_ex(const pca_mab_shape& s, const void* X, const float* H,
                  : launch_fwd<128, 16, false, false>(a, st);
   }
   PCA_REQUIRE(!abf, "mab1_bf16_fwd: bf16 activations need m = 16");
+  if (d == 256) {          // inference only (mab1_bf16_supported): O meets in the scratch block
+    if (small) return launch_fwd<256, 32, true, false>(a, st);
+    a.OS = v.OS;
+    PCA_TRY((launch_fwd<256, 32, false, false, 1>(a, st)));
+    return launch_fwd<256, 32, false, false, 2>(a, st);
+  }
   return small ? launch_fwd<128, 32, true, false>(a, st) : launch_fwd<128, 32, false, false>(a, st);
 }
 

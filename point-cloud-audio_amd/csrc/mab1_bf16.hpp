@@ -210,7 +210,7 @@ int linear_dx_acc_f32(const float* dY, const float* W, float* dX, int64_t M, int
                       int accumulate, hipStream_t st);
 // fused mab1 (many queries X, few keys H).  X / Y / dY / dX are fp32 or bf16 per the shape's
 // q_dtype / y_dtype; H and dH are fp32
-bool mab1_bf16_supported(const pca_mab_shape& s);
+bool mab1_bf16_supported(const pca_mab_shape& s, bool inference = false);
 size_t mab1_bf16_saved_bytes(const pca_mab_shape& s);
 size_t mab1_bf16_fwd_ws_bytes(const pca_mab_shape& s);
 size_t mab1_bf16_bwd_ws_bytes(const pca_mab_shape& s);
@@ -307,7 +307,7 @@ int mab0_bf16_bwd_ex(const pca_mab_shape& s, const float* I, const void* X,
                      void* dX, int dk_accumulate, const pca_mab_grads& gr, void* ws, int flags,
                      hipStream_t st, BwdDefer* defer = nullptr);
 // per-block dispatch (api_mab.hip): kind 0 exact fp32, 1 fused mab1, 2 fused mab0
-int mab_kind(const pca_mab_shape& s);
+int mab_kind(const pca_mab_shape& s, bool inference = false);
 size_t mab_saved_bytes_any(const pca_mab_shape& s);
 size_t mab_fwd_ws_bytes_any(const pca_mab_shape& s);
 size_t mab_bwd_ws_bytes_any(const pca_mab_shape& s);

@@ -74,13 +74,16 @@ def _lengths(key_lengths, B: int, like: torch.Tensor):
     return kl
 
 
-def _pick_mode(s: MabShape) -> MabShape:
+def _pick_mode(s: MabShape, inference: bool = False) -> MabShape:
     """Resolve the arithmetic mode of one block: 'bf16' demands the fused kernel, 'auto' takes
-    it where the library has one for this shape (pca_mab_saved_bytes() > 0) else exact fp32."""
+    it where the library has one for this shape (pca_mab_saved_bytes() > 0; forward-only calls
+    ask pca_mab_fwd_ws_bytes(), which also covers the kernels that have no backward yet) else
+    exact fp32."""
     if _MODE == "f32":
         return s
     s.mode = _lib.MODE_BF16
-    if _MODE == "auto" and lib().pca_mab_saved_bytes(C.byref(s)) == 0:
+    probe = lib().pca_mab_fwd_ws_bytes if inference else lib().pca_mab_saved_bytes
+    if _MODE == "auto" and probe(C.byref(s)) == 0:
         s.mode = _lib.MODE_F32
     return s
 
@@ -176,7 +179,8 @@ def mab_infer(Q, K, params, num_heads: int, q_shared: bool = False,
     nq, dq = Q.shape[-2], Q.shape[-1]
     d = params[0].shape[0]
     kl = _lengths(key_lengths, B, K)
-    s = _pick_mode(_shape(B, nq, nk, dq, dk, d, num_heads, q_shared, k_lengths=kl, ln=ln))
+    s = _pick_mode(_shape(B, nq, nk, dq, dk, d, num_heads, q_shared, k_lengths=kl, ln=ln),
+                   inference=True)
     L = lib()
     with torch.cuda.device(K.device):
         Y = torch.empty((B, nq, d), dtype=torch.float32, device=K.device)

@@ -43,7 +43,18 @@ MAB1_CASES = [      # B, N, m, dq, d, h
 ]
 
 
-@pytest.mark.parametrize("case", MAB1_CASES, ids=[str(c) for c in MAB1_CASES])
+# BASELINE configs[3] block (d = 256, 8 heads, m = 32): fused forward only so far (Q phase +
+# O phase for d -> d, one launch for layer 1); training of this shape runs the GEMM chain
+MAB1_D256_CASES = [
+    (2, 300, 32, 256, 256, 8),        # ragged N
+    (3, 128, 32, 256, 256, 8),
+    (2, 77, 32, 3, 256, 8),           # layer 1
+    (1, 1, 32, 256, 256, 8),          # a single point
+]
+
+
+@pytest.mark.parametrize("case", MAB1_CASES + MAB1_D256_CASES,
+                         ids=[str(c) for c in MAB1_CASES + MAB1_D256_CASES])
 def test_mab1_fwd_bf16(dev, case):
     import modules
     import pca_hip
