@@ -180,7 +180,10 @@ __global__ __launch_bounds__(64 * NW, (NW == 8 || D > 128) ? 1 : 2) void k_mab1_
   char* sVt = sKp + (HAS_KV ? MI * ROWB : 0);         // D x MI
   char* sWq = sVt + (HAS_KV ? D * MI * 2 : 0);        // D x D (absent when DIN_SMALL)
   char* sX = sWq + (HAS_WQ ? D * ROWB : 0);           // TP x D (PHASE 0, d -> d only)
-  (void)sX;
+  // layer 1, d = 128: fc_q's [D][dq <= 4] weights (padded to 4) and bias, fp32
+  constexpr bool WQ_LDS = DIN_SMALL && D == 128;
+  float* sWqF = reinterpret_cast<float*>(sX);         // [D][4]
+  float* sbq = sWqF + D * 4;                          // [D]
 
   const int tid = threadIdx.x, lane = tid & 63, wave8 = tid >> 6;
   const int wave = wave8 & 3, sub = wave8 >> 2;
@@ -203,6 +206,16 @@ __global__ __launch_bounds__(64 * NW, (NW == 8 || D > 128) ? 1 : 2) void k_mab1_
       const int c = tid + NT * e, row = c / (D / 8), c16 = c % (D / 8);
       if (HAS_WO) *reinterpret_cast<uint4*>(sWo + swz(row, c16, ROWB)) = wo[e];
       if (HAS_WQ) *reinterpret_cast<uint4*>(sWq + swz(row, c16, ROWB)) = wq[e];
+    }
+  }
+
+  if (WQ_LDS) {
+    for (int f = tid; f < D; f += NT) {
+      float w[4];
+#pragma unroll
+      for (int c = 0; c < 4; ++c) w[c] = c < a.dq ? a.WqF[f * a.dq + c] : 0.f;
+      *reinterpret_cast<float4*>(sWqF + 4 * f) = float4{w[0], w[1], w[2], w[3]};
+      sbq[f] = a.bq[f];
     }
   }
 
@@ -261,9 +274,16 @@ __global__ __launch_bounds__(64 * NW, (NW == 8 || D > 128) ? 1 : 2) void k_mab1_
         for (int e = 0; e < 4; ++e) {
           const int f = 16 * t + 4 * g + e;
           float w[4];
+          float bias;
+          if (WQ_LDS) {
+            const float4 w4 = *reinterpret_cast<const float4*>(sWqF + 4 * f);
+            w[0] = w4.x; w[1] = w4.y; w[2] = w4.z; w[3] = w4.w;
+            bias = sbq[f];
+          } else {
 #pragma unroll
-          for (int c = 0; c < 4; ++c) w[c] = c < a.dq ? a.WqF[f * a.dq + c] : 0.f;
-          const float bias = a.bq[f];
+            for (int c = 0; c < 4; ++c) w[c] = c < a.dq ? a.WqF[f * a.dq + c] : 0.f;
+            bias = a.bq[f];
+          }
 #pragma unroll
           for (int nb = 0; nb < NB; ++nb)
             acc[t][nb][e] = bias + w[0] * xv[nb][0] + w[1] * xv[nb][1] + w[2] * xv[nb][2] +
@@ -503,7 +523,8 @@ int launch_fwd(const Mab1FwdArgs& a, hipStream_t st) {
   const size_t wimg = (size_t)D * D * 2, kv = (size_t)MI * D * 2 + (size_t)D * MI * 2;
   const size_t lds = (PHASE != 1 ? wimg : 0) + (PHASE != 2 ? kv : 0) +
                      ((!DS && PHASE != 2) ? wimg : 0) +
-                     ((!DS && PHASE == 0) ? (size_t)NW * 32 * D * 2 : 0);
+                     ((!DS && PHASE == 0) ? (size_t)NW * 32 * D * 2 : 0) +
+                     ((DS && D == 128) ? (size_t)D * 5 * sizeof(float) : 0);
   static std::once_flag once;
   std::call_once(once, [] {
     (void)hipFuncSetAttribute(
