@@ -398,3 +398,33 @@ def test_engine_bf16_generic_gemm_path(dev, golden_st, ci):
     print(f"{name} bf16 generic path: logits err {err:.2e}, worst grad err {worst:.2e}")
     inf = trainer.STEngine(net, B, N, mode=_lib.MODE_BF16, training=False)
     close(inf.forward(X), ref, 3e-2, "logits(inference)")
+
+
+def test_engine_bf16_generic_path_large_rows(dev):
+    """The GEMM chain at a size where its large-problem branches run (XCD-aware workgroup order,
+    transposed-weight dX, float4 column sums): configs[3] architecture, 16 sets of 4096 points,
+    bf16 chain against the exact fp32 chain on the same weights and inputs."""
+    import inputs as gi
+    import models
+    from pca_hip import _lib, trainer
+    B, N, din, d, h, m, C = 16, 4096, 3, 256, 8, 32, 50
+    torch.manual_seed(5)
+    net = models.ST(dim_input=din, num_outputs=1, dim_output=C, num_inds=m, dim_hidden=d,
+                    num_heads=h).to(dev)
+    X = T(gi.pc_input(811, B, N, din), dev)
+    y = T(gi.labels(812, B, C), dev)
+    exact = trainer.STEngine(net, B, N, mode=_lib.MODE_F32, training=True)
+    exact.fwd_bwd(X, y, phase=-1)
+    eng = trainer.STEngine(net, B, N, mode=_lib.MODE_BF16, training=True)
+    eng.fwd_bwd(X, y, phase=-1)
+    err = close(eng.logits, exact.logits, 3e-2, "logits")
+    assert float((eng.logits - exact.logits).abs().max()) > 1e-6, "bf16 mode ran the fp32 GEMMs"
+    off, worst = 0, 0.0
+    for k, prm in net.named_parameters():
+        n = prm.numel()
+        worst = max(worst, close_robust(eng.grads[off:off + n], exact.grads[off:off + n], 5e-2, k,
+                                        outlier_frac=5e-3))
+        off += n
+    print(f"configs[3] architecture, B=16 N=4096: logits err {err:.2e}, worst grad err {worst:.2e}")
+    inf = trainer.STEngine(net, B, N, mode=_lib.MODE_BF16, training=False)    # fused mab1 forward
+    close(inf.forward(X), exact.logits, 3e-2, "logits(inference)")
