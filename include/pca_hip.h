@@ -42,7 +42,13 @@ enum {
 enum { PCA_F32 = 0, PCA_BF16 = 1 };
 
 /* arithmetic mode of a MAB: PCA_MODE_F32 = exact fp32 everywhere (parity mode);
- * PCA_MODE_BF16 = bf16 MFMA operands, fp32 accumulate / softmax / residuals.    */
+ * PCA_MODE_BF16 = bf16 MFMA operands, fp32 accumulate / softmax / residuals.
+ * pca_mab_* in PCA_MODE_BF16 demand a fused kernel for the shape (d = 128, head dim 32, m in
+ * {16, 32} inducing points; forward-only calls -- saved == NULL, sized by
+ * pca_mab_fwd_ws_bytes() -- also the many-queries block at d = 256, 8 heads, 32 keys) and
+ * return PCA_EUNSUPPORTED / 0 bytes otherwise: the caller falls back to PCA_MODE_F32
+ * explicitly.  The ST engine (pca_st_*) runs blocks without a fused kernel as the same chain
+ * of GEMMs with bf16 MFMA operands (pca_gemm_bf16). */
 enum { PCA_MODE_F32 = 0, PCA_MODE_BF16 = 1 };
 
 int pca_abi_version(void);
