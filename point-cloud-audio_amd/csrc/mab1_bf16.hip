@@ -132,6 +132,39 @@ __global__ __launch_bounds__(256) void k_kv_proj(const float* __restrict__ H,   
   }
 }
 
+// The four images of k_kv_proj from projections that already exist in fp32 (d = 256: the
+// projection itself is a [B m, d] x [d, d] product and goes through the GEMM kernel).
+template <int MI>
+__global__ __launch_bounds__(256) void k_kv_images(const float* __restrict__ Kf,   // [B][MI][d]
+                                                   const float* __restrict__ Vf, int d,
+                                                   __bf16* __restrict__ KpP,
+                                                   __bf16* __restrict__ VpP,
+                                                   __bf16* __restrict__ Kt,
+                                                   __bf16* __restrict__ Vt) {
+  const int b = blockIdx.x;
+  const int o = blockIdx.y * 256 + threadIdx.x;
+  if (o >= 2 * d) return;
+  const int f = o % d, isv = o / d;
+  const float* src = (isv ? Vf : Kf) + (int64_t)b * MI * d + f;
+  float acc[MI];
+#pragma unroll
+  for (int i = 0; i < MI; ++i) acc[i] = src[(int64_t)i * d];
+  const int jb = f & ~31, fo = f & 31;
+  int pos = 0;
+#pragma unroll
+  for (int p = 0; p < 32; ++p)
+    if (perm32(p) == fo) pos = p;
+  __bf16* PP = isv ? VpP : KpP;
+  __bf16* TT = isv ? Vt : Kt;
+#pragma unroll
+  for (int i = 0; i < MI; ++i) PP[((int64_t)b * MI + i) * d + jb + pos] = (__bf16)acc[i];
+#pragma unroll
+  for (int kp = 0; kp < MI; ++kp) {
+    const int key = (MI == 32) ? perm32(kp) : kp;
+    TT[((int64_t)b * d + f) * MI + kp] = (__bf16)acc[key];
+  }
+}
+
 // ---------------------------------------------------------------------------------
 // the fused forward kernel
 // ---------------------------------------------------------------------------------
@@ -576,9 +609,8 @@ bool mab1_bf16_supported(const pca_mab_shape& s, bool inference) {
   // activations: fp32 everywhere, or bf16 for Y (and for X when it is a hidden tensor)
   const bool dt_ok = s.k_dtype == PCA_F32 &&
                      (s.dq <= 4 ? s.q_dtype == PCA_F32 : s.q_dtype == s.y_dtype);
-  // d = 256 / m = 32 (BASELINE configs[3]): forward only so far, fp32 activations
-  const bool d_ok = s.d == 128 || (inference && s.d == 256 && s.nk == 32 &&
-                                   s.q_dtype == PCA_F32 && s.y_dtype == PCA_F32);
+  // d = 256 / m = 32 (BASELINE configs[3]): forward only so far
+  const bool d_ok = s.d == 128 || (inference && s.d == 256 && s.nk == 32);
   return s.q_shared == 0 && d_ok && s.h * 32 == s.d && (s.nk == 16 || s.nk == 32) &&
          s.dk == s.d && (s.dq == s.d || s.dq <= 4) && dt_ok;
 }
@@ -604,6 +636,7 @@ size_t mab1_bf16_saved_bytes(const pca_mab_shape& s) {
 }
 size_t mab1_bf16_fwd_ws_bytes(const pca_mab_shape& s) {
   return 2 * align256((size_t)s.d * s.d * 2) + 2 * align256((size_t)s.d * s.d * 4) +
+         (s.d > 128 ? 2 * align256((size_t)s.B * s.nk * s.d * 4) : 0) +      // fp32 Kp, Vp
          mab1_carve_saved(s, nullptr, nullptr);
 }
 
@@ -622,6 +655,8 @@ int mab1_bf16_fwd_ex(const pca_mab_shape& s, const void* X, const float* H,
   __bf16* WoP = cw.take<__bf16>((size_t)s.d * s.d);
   float* WkT = cw.take<float>((size_t)s.d * s.d);
   float* WvT = cw.take<float>((size_t)s.d * s.d);
+  float* Kf = s.d > 128 ? cw.take<float>((size_t)s.B * s.nk * s.d) : nullptr;
+  float* Vf = s.d > 128 ? cw.take<float>((size_t)s.B * s.nk * s.d) : nullptr;
   Mab1Saved v;
   const bool training = saved != nullptr;
   mab1_carve_saved(s, &v, training ? saved : (void*)(cw.base + cw.off));
@@ -635,19 +670,28 @@ int mab1_bf16_fwd_ex(const pca_mab_shape& s, const void* X, const float* H,
     if (!small) PCA_TRY(prep_weight(p.wq, WqB, d, d, 0, st));
     PCA_TRY(prep_weight(p.wo, WoP, d, d, 1, st));
   }
-  if (!(flags & PCA_F_KV_READY)) {
+  if (!(flags & PCA_F_KV_READY) && d > 128) {
+    // Kp = H Wk^T + bk, Vp = H Wv^T + bv as MFMA products (fp32 accumulation; the operand
+    // rounding is an order of magnitude below the bf16 rounding of the images), then the images
+    pca_gemm_desc g{};
+    g.M = (int64_t)s.B * s.nk; g.N = d; g.K = d;
+    g.sa_m = d; g.sa_k = 1; g.sb_k = 1; g.sb_n = d; g.sc_m = d;
+    g.nb1 = g.nb2 = 1; g.split_k = 1; g.alpha = 1.f;
+    PCA_TRY(gemm_bf16(g, H, p.wk, p.bk, Kf, st));
+    PCA_TRY(gemm_bf16(g, H, p.wv, p.bv, Vf, st));
+    hipLaunchKernelGGL((k_kv_images<32>), dim3(s.B, 2 * d / 256), dim3(256), 0, st, Kf, Vf, d,
+                       v.KpP, v.VpP, v.Kt, v.Vt);
+    PCA_TRY(check_launch("k_kv_images"));
+  } else if (!(flags & PCA_F_KV_READY)) {
   PCA_TRY(transpose_f32(p.wk, WkT, d, d, st));
   PCA_TRY(transpose_f32(p.wv, WvT, d, d, st));
   const size_t hl = (size_t)s.nk * d * sizeof(float);
   if (s.nk == 16)
     hipLaunchKernelGGL((k_kv_proj<16>), dim3(s.B), dim3(256), hl, st, H, WkT, p.bk, WvT, p.bv,
                        d, v.KpP, v.VpP, v.Kt, v.Vt);
-  else if (d <= 128)
+  else
     hipLaunchKernelGGL((k_kv_proj<32>), dim3(s.B), dim3(256), hl, st, H, WkT, p.bk, WvT, p.bv,
                        d, v.KpP, v.VpP, v.Kt, v.Vt);
-  else      // one wave per 64 outputs
-    hipLaunchKernelGGL((k_kv_proj<32>), dim3(s.B, 2 * d / 64), dim3(64), hl, st, H, WkT, p.bk,
-                       WvT, p.bv, d, v.KpP, v.VpP, v.Kt, v.Vt);
   PCA_TRY(check_launch("k_kv_proj"));
   }
 
@@ -668,13 +712,18 @@ int mab1_bf16_fwd_ex(const pca_mab_shape& s, const void* X, const float* H,
     return small ? launch_fwd<128, 16, true, false>(a, st)
                  : launch_fwd<128, 16, false, false>(a, st);
   }
-  PCA_REQUIRE(!abf, "mab1_bf16_fwd: bf16 activations need m = 16");
   if (d == 256) {          // inference only (mab1_bf16_supported): O meets in the scratch block
-    if (small) return launch_fwd<256, 32, true, false>(a, st);
+    if (small)
+      return abf ? launch_fwd<256, 32, true, true>(a, st) : launch_fwd<256, 32, true, false>(a, st);
     a.OS = v.OS;
+    if (abf) {
+      PCA_TRY((launch_fwd<256, 32, false, true, 1>(a, st)));
+      return launch_fwd<256, 32, false, true, 2>(a, st);
+    }
     PCA_TRY((launch_fwd<256, 32, false, false, 1>(a, st)));
     return launch_fwd<256, 32, false, false, 2>(a, st);
   }
+  PCA_REQUIRE(!abf, "mab1_bf16_fwd: bf16 activations need m = 16 (d = 128)");
   return small ? launch_fwd<128, 32, true, false>(a, st) : launch_fwd<128, 32, false, false>(a, st);
 }
 

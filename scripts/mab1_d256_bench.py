@@ -43,3 +43,19 @@ for B, N in ((128, 2048), (128, 4096)):
         print(f"mab1 fwd B={B} N={N} d={d} m={m} mode={mode:5s}: {us:9.1f} us  "
               f"{fl / us / 1e6:8.1f} TFLOP/s  ({100 * fl / us / 1e6 / 2500:.1f} % of 2.5 PF bf16 MFMA)")
     pca_hip.set_mode("f32")
+    # the same pair with bf16 activations crossing the ABI (what the fused training path passes
+    # between blocks at d = 128): C entry directly
+    import ctypes as C
+    from pca_hip import _lib
+    L = _lib.lib()
+    s = _lib.MabShape(B, N, m, d, d, d, h, 0, _lib.MODE_BF16, _lib.PCA_BF16, _lib.PCA_F32,
+                      _lib.PCA_BF16, None, 0)
+    Xb = X.to(torch.bfloat16)
+    Yb = torch.empty(B, N, d, dtype=torch.bfloat16, device=dev)
+    ws = torch.empty(L.pca_mab_fwd_ws_bytes(C.byref(s)), dtype=torch.uint8, device=dev)
+    pp = _lib.MabParams(*[t.data_ptr() for t in params], None, None, None, None)
+    us = timed(lambda: _lib.check(L.pca_mab_fwd(C.byref(s), Xb.data_ptr(), H.data_ptr(),
+                                                C.byref(pp), Yb.data_ptr(), None, ws.data_ptr(),
+                                                None)))
+    print(f"mab1 fwd B={B} N={N} d={d} m={m} bf16 in/out  : {us:9.1f} us  "
+          f"{fl / us / 1e6:8.1f} TFLOP/s  ({100 * fl / us / 1e6 / 2500:.1f} % of 2.5 PF bf16 MFMA)")

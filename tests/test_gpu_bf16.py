@@ -428,3 +428,43 @@ def test_engine_bf16_generic_path_large_rows(dev):
     print(f"configs[3] architecture, B=16 N=4096: logits err {err:.2e}, worst grad err {worst:.2e}")
     inf = trainer.STEngine(net, B, N, mode=_lib.MODE_BF16, training=False)    # fused mab1 forward
     close(inf.forward(X), exact.logits, 3e-2, "logits(inference)")
+
+
+@pytest.mark.parametrize("case", [(2, 300, 32, 256, 256, 8), (2, 77, 32, 3, 256, 8)],
+                         ids=["d256", "d256_layer1"])
+def test_mab1_fwd_d256_bf16_activations(dev, case):
+    """The d = 256 forward pair with bf16 activations crossing the ABI (q_dtype = y_dtype =
+    PCA_BF16; layer 1 takes its fp32 points and writes bf16), called through the C entry."""
+    import ctypes as C
+    from oracle import st_oracle as orc
+    from pca_hip import _lib
+    L = _lib.lib()
+    B, N, m, dq, d, h = case
+    p = _mab_params(dq, d, d, seed=sum(case) + 1)
+    g = torch.Generator().manual_seed(3 + sum(case))
+    X = torch.randn(B, N, dq, generator=g)
+    if dq <= 4:
+        X[..., -1] = X[..., -1] * 3 - 9
+    else:
+        X = X.to(torch.bfloat16).float()                 # what the bf16 tensor holds
+    H = torch.randn(B, m, d, generator=g)
+    ref = orc.mab_forward(X, H, p, h)
+    qdt = _lib.PCA_F32 if dq <= 4 else _lib.PCA_BF16
+    s = _lib.MabShape(B, N, m, dq, d, d, h, 0, _lib.MODE_BF16, qdt, _lib.PCA_F32, _lib.PCA_BF16,
+                      None, 0)
+    nws = L.pca_mab_fwd_ws_bytes(C.byref(s))
+    assert nws > 0, L.pca_last_error()
+    assert L.pca_mab_saved_bytes(C.byref(s)) == 0          # no backward for this shape yet
+    Xd = X.to(dev) if dq <= 4 else X.to(dev).to(torch.bfloat16)
+    Hd = H.to(dev)
+    prm = [p[k].to(dev).contiguous() for k in ("fc_q.weight", "fc_q.bias", "fc_k.weight",
+                                               "fc_k.bias", "fc_v.weight", "fc_v.bias",
+                                               "fc_o.weight", "fc_o.bias")]
+    pp = _lib.MabParams(*[t.data_ptr() for t in prm], None, None, None, None)
+    Y = torch.empty(B, N, d, dtype=torch.bfloat16, device=dev)
+    ws = torch.empty(nws, dtype=torch.uint8, device=dev)
+    _lib.check(L.pca_mab_fwd(C.byref(s), Xd.data_ptr(), Hd.data_ptr(), C.byref(pp), Y.data_ptr(),
+                             None, ws.data_ptr(), None))
+    torch.cuda.synchronize()
+    err = close(Y.float(), ref, FWD_TOL, f"mab1 fwd bf16 activations {case}")
+    print(f"mab1 fwd {case} bf16 in/out: max err {err:.3e}")
