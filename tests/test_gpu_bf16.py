@@ -468,3 +468,34 @@ def test_mab1_fwd_d256_bf16_activations(dev, case):
     torch.cuda.synchronize()
     err = close(Y.float(), ref, FWD_TOL, f"mab1 fwd bf16 activations {case}")
     print(f"mab1 fwd {case} bf16 in/out: max err {err:.3e}")
+
+
+def test_auto_mode_takes_forward_only_kernels(dev):
+    """'auto' under no_grad probes pca_mab_fwd_ws_bytes(): the d = 256 block runs its fused
+    forward; with autograd on it has no backward, so 'auto' resolves to the exact path and
+    'bf16' refuses."""
+    import modules
+    import pca_hip
+    B, N, m, d, h = 2, 130, 32, 256, 8
+    p = _mab_params(d, d, d, seed=77)
+    g = torch.Generator().manual_seed(78)
+    X, H = torch.randn(B, N, d, generator=g).to(dev), torch.randn(B, m, d, generator=g).to(dev)
+    mab = modules.MAB(d, d, d, h).to(dev)
+    mab.load_state_dict(p)
+    try:
+        pca_hip.set_mode("f32")
+        with torch.no_grad():
+            exact = mab(X, H)
+        pca_hip.set_mode("auto")
+        with torch.no_grad():
+            fused = mab(X, H)
+        diff = float((fused - exact).abs().max())
+        assert 1e-6 < diff < FWD_TOL * max(1.0, float(exact.abs().max())), diff
+        Y = mab(X.requires_grad_(True), H)                   # training: exact chain
+        assert float((Y.detach() - exact).abs().max()) < 1e-5
+        Y.sum().backward()
+        pca_hip.set_mode("bf16")
+        with pytest.raises(pca_hip.PcaHipError):
+            mab(X, H)
+    finally:
+        pca_hip.set_mode("f32")
