@@ -7,8 +7,8 @@
 
 A "step" is one pass of the hot path over one batch of synthetic input per GPU:
   gather B point sets from the HBM-resident log-magnitude spectrogram (pack kernel) ->
-  ST forward -> mean cross-entropy -> backward -> [all-reduce of the two gradient buckets
-  over RCCL, overlapped] -> fused Adam (coupled weight decay).
+  ST forward -> mean cross-entropy -> backward -> [all-reduce of the flat gradient vector
+  over RCCL] -> fused Adam (coupled weight decay).
 The spectrogram itself is produced once, before the timed region, by the STFT kernel from
 synthetic class-conditional clips (5 s @ 44.1 kHz) -- the reference also runs its STFT as
 a one-off pre-pass (Code/settransformer.py:43-53).  value = sets/s of all ranks divided by

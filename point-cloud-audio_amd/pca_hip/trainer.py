@@ -4,6 +4,10 @@ Replaces the training loop of Code/settransformer.py:96-112 (and settransformert
 ``DataLoader -> .to(device) -> nn.DataParallel(model)(imgs) -> CrossEntropyLoss -> backward ->
 Adam.step -> .item()`` becomes, per step and per GPU,
 
+    [pack batch] -> pca_st_train_fwd_bwd -> all-reduce(gradients) -> pca_adam_step
+
+or, with ``overlap`` (large models: the exchange hides under the rest of the backward),
+
     [pack batch] -> pca_st_train_fwd_bwd(phase 0) -> all-reduce(bucket enc.1+dec)
                  -> pca_st_train_fwd_bwd(phase 1) -> all-reduce(bucket enc.0) -> pca_adam_step
 
@@ -14,13 +18,15 @@ Adam.step -> .item()`` becomes, per step and per GPU,
   replayed, so no Python / autograd / allocator work sits between kernels;
 * nn.DataParallel (Code/settransformer.py:94: single process, per-step parameter broadcast,
   scatter and gather) is replaced by an RCCL all-reduce of gradients (torch.distributed
-  backend 'nccl' over xGMI) on a side stream, overlapped with the enc.0 backward;
+  backend 'nccl' over xGMI): one message between the backward and the optimiser, or two
+  buckets with the first on a side stream under the enc.0 backward (``overlap``);
 * loss / accuracy are accumulated on the device and read once per epoch instead of the
   two ``.item()`` host syncs per step of Code/settransformer.py:110-112.
 """
 from __future__ import annotations
 
 import ctypes as C
+import os
 from typing import Optional, Tuple
 
 import torch
@@ -198,7 +204,8 @@ class Trainer:
     def __init__(self, model, dataset, batch_size: int, lr: float = 1e-3,
                  weight_decay: float = 1e-3, betas=(0.9, 0.999), eps: float = 1e-8,
                  mode: int = _lib.MODE_F32, use_graph: bool = True, seed: int = 0,
-                 shuffle: bool = True, process_group=None, keep_grads: bool = False):
+                 shuffle: bool = True, process_group=None, keep_grads: bool = False,
+                 overlap: Optional[bool] = None):
         self.ds = dataset
         self.keep_grads = keep_grads    # True: gradients of the last step stay readable
         self.B = int(batch_size)
@@ -228,7 +235,21 @@ class Trainer:
             # batch (step_count - epoch_base), so a step is a bare graph replay
             self.epoch_base = torch.zeros(1, dtype=torch.int32, device=self.dev)
             self.seq = None
-            self.comm_stream = torch.cuda.Stream(self.dev) if self.world > 1 else None
+            # Several GPUs, two ways to exchange the gradients:
+            #   overlap=True : the step is split at the bucket boundary; bucket A (enc.1 + dec) is
+            #                  reduced on a side stream under enc.0's backward, bucket B after it
+            #   overlap=False: one all-reduce of the whole vector between backward and Adam
+            # The split costs three graph launches instead of one and ends the launch merging of
+            # the backward at the boundary: measured +82 us per step at cfg2 on one GPU
+            # (PCA_FORCE_SPLIT=1: 0.370 -> 0.452 ms), more than the all-reduce of 1.2 MB it can
+            # hide.  Default: overlap only from 16 MB of gradients on.
+            if overlap is None:
+                overlap = self.eng.flat.numel() * 4 >= (16 << 20)
+            self._split = (self.world > 1 and bool(overlap)) or \
+                os.environ.get("PCA_FORCE_SPLIT") == "1"
+            # (PCA_FORCE_SPLIT=2: the overlap=False step shape on one GPU, minus the all-reduce)
+            self._exchange = self.world > 1 or os.environ.get("PCA_FORCE_SPLIT") == "2"
+            self.comm_stream = torch.cuda.Stream(self.dev) if self._split else None
         self._cursor_mode = callable(getattr(dataset, "batch_seq", None))
         self._k = 0                       # optimiser steps issued so far (host copy)
         self.g0 = self.g1 = self.g2 = None
@@ -256,11 +277,11 @@ class Trainer:
             self.eng.grads.zero_()
         # one GPU: the whole backward in one call (the shared-query gradient kernels of all three
         # blocks then share one pair of launches); several GPUs: stop at the bucket boundary
-        self.eng.fwd_bwd(self.X, self.labels, phase=-1 if self.world == 1 else 0,
+        self.eng.fwd_bwd(self.X, self.labels, phase=0 if self._split else -1,
                          lengths=self.lengths)
 
     def _seg1(self):     # backward(enc.0)
-        if self.world > 1:
+        if self._split:
             self.eng.fwd_bwd(self.X, self.labels, phase=1, lengths=self.lengths)
 
     def _seg2(self):     # Adam over the flat vector
@@ -287,10 +308,16 @@ class Trainer:
         # thread-local capture mode: a HIP call from another thread (e.g. the RCCL watchdog of
         # torch.distributed) must not invalidate the capture
         mode = dict(capture_error_mode="thread_local")
-        if self.world == 1:
+        if not self._split and not self._exchange:
             self.g0 = torch.cuda.CUDAGraph()
             with torch.cuda.graph(self.g0, **mode):
                 self._seg0(); self._seg1(); self._seg2()
+        elif not self._split:           # [pack, forward, backward] | all-reduce | Adam
+            # (Adam is one kernel: a plain launch, not a one-node graph - every graph boundary
+            #  costs tens of microseconds of GPU idle time)
+            self.g0 = torch.cuda.CUDAGraph()
+            with torch.cuda.graph(self.g0, **mode):
+                self._seg0()
         else:
             self.g0, self.g1, self.g2 = (torch.cuda.CUDAGraph() for _ in range(3))
             with torch.cuda.graph(self.g0, **mode):
@@ -319,19 +346,27 @@ class Trainer:
         if self.use_graph and self.g0 is None:
             self._capture()
         main = torch.cuda.current_stream(self.dev)
-        if self.world == 1:
+        if not self._split and not self._exchange:
             if self.use_graph:
                 self.g0.replay()
             else:
                 self._seg0(); self._seg1(); self._seg2()
             return
         e = self.eng
+        if not self._split:
+            self.g0.replay() if self.use_graph else self._seg0()
+            if self.world > 1:
+                dist.all_reduce(e.grads, group=self.pg)
+            self._seg2()
+            return
         self.g0.replay() if self.use_graph else self._seg0()
         # bucket A (enc.1 + dec) is final: reduce it while enc.0's backward runs
         self.comm_stream.wait_stream(main)
-        second = allreduce_buckets(e.grads, e.split, self.pg, self.comm_stream)
+        if self.world > 1:
+            second = allreduce_buckets(e.grads, e.split, self.pg, self.comm_stream)
         self.g1.replay() if self.use_graph else self._seg1()
-        second()
+        if self.world > 1:
+            second()
         main.wait_stream(self.comm_stream)
         self.g2.replay() if self.use_graph else self._seg2()
 

@@ -25,11 +25,12 @@ def run(world_sim, rank_sim, batch, pg):
     net = models.ST(dim_input=2, dim_output=C, num_inds=16, dim_hidden=128, num_heads=4).to(dev)
     ds = dataset.ESC_pc(x, y, farr, device=dev)
     tr = trainer.Trainer(net, ds, batch, mode=mode, use_graph=use_graph, seed=11, shuffle=True,
-                         process_group=pg)
+                         process_group=pg, overlap=os.environ.get("PCA_OVERLAP", "1") == "1")
     if pg is None:                      # force a single-rank trainer inside the 2-rank job
         tr.world, tr.rank = 1, 0
         tr.indices = trainer.ShardedIndexStream(len(ds), batch, 0, 1, 11, True, dev)
         tr.comm_stream = None
+        tr._split = tr._exchange = False
     for _ in range(4):
         tr.step()
     torch.cuda.synchronize()

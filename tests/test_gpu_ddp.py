@@ -22,10 +22,15 @@ from util import close
 pytestmark = pytest.mark.gpu
 
 
-@pytest.mark.parametrize("mode,graph", [("f32", "1"), ("bf16", "1"), ("f32", "0")])
-def test_two_ranks_equal_one_rank_double_batch(tmp_path, mode, graph):
+@pytest.mark.parametrize("mode,graph,overlap", [("f32", "1", "1"), ("bf16", "1", "1"),
+                                                ("f32", "0", "1"), ("f32", "1", "0"),
+                                                ("bf16", "1", "0"), ("f32", "0", "0")])
+def test_two_ranks_equal_one_rank_double_batch(tmp_path, mode, graph, overlap):
+    """overlap = 1: split step, bucket A reduced under enc.0's backward; 0: one all-reduce of
+    the whole gradient vector between the backward graph and the Adam graph (the default for
+    models of this size)."""
     out = str(tmp_path / "flat.pt")
-    env = dict(os.environ, PCA_MODE=mode, PCA_GRAPH=graph, PCA_OUT=out,
+    env = dict(os.environ, PCA_MODE=mode, PCA_GRAPH=graph, PCA_OUT=out, PCA_OVERLAP=overlap,
                HSA_ENABLE_IPC_MODE_LEGACY="0")
     r = subprocess.run([sys.executable, "-m", "torch.distributed.run", "--nnodes=1",
                         "--nproc-per-node", "2", "--master-addr", "127.0.0.1",
