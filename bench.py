@@ -152,6 +152,74 @@ def cpu_baseline(cfg, N, budget_s=20.0):
                 pack_sets_per_s_1core=round(pack_rate, 1))
 
 
+def event_pair_overhead_us(dev, n=200):
+    """What two back-to-back event records on an idle stream measure (their own cost): the HIP
+    event clock of the roofline block includes it once per launch."""
+    evs = [(torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True))
+           for _ in range(n)]
+    torch.cuda.synchronize(dev)
+    for a, b in evs:
+        a.record()
+        b.record()
+    torch.cuda.synchronize(dev)
+    return float(np.median([a.elapsed_time(b) for a, b in evs])) * 1e3
+
+
+def committed_traffic(key):
+    """HBM bytes per launch of the dominant kernel from the newest committed PMC summary
+    (profiles/r*_hbm_traffic.json) - or None when that file predates the library it would
+    describe (a stale constant is worse than none)."""
+    import glob
+    if key is None:
+        return None
+    files = sorted(glob.glob(os.path.join(ROOT, "profiles", "r*_hbm_traffic.json")))
+    so = os.path.join(ROOT, "point-cloud-audio_amd", "pca_hip", "libpca_hip.so")
+    for path in reversed(files):
+        try:
+            d = json.load(open(path))
+        except Exception:
+            continue
+        if key not in d:
+            continue
+        import hashlib
+        cur = hashlib.sha256(open(so, "rb").read()).hexdigest()[:16]
+        return d[key] if d.get("library_sha16") == cur else None
+    return None
+
+
+def measure_kernel(L, _lib, tr, dev, kid, ksteps, peak):
+    """HIP-event time, algorithmic FLOPs and bytes of every launch of kernel family ``kid``
+    over ``ksteps`` eager steps -> roofline dictionary (None when it never ran)."""
+    _lib.check(L.pca_prof_start(kid, 4096 * ksteps), "prof_start")
+    for _ in range(ksteps):
+        tr.step()
+    torch.cuda.synchronize(dev)
+    ms, n, fl, by = C.c_double(), C.c_int64(), C.c_double(), C.c_double()
+    _lib.check(L.pca_prof_stop(C.byref(ms), C.byref(n), C.byref(fl), C.byref(by)), "prof_stop")
+    if n.value <= 0 or ms.value <= 0:
+        return None
+    tflops = fl.value / (ms.value * 1e-3) / 1e12
+    gbs = by.value / (ms.value * 1e-3) / 1e9
+    # roofline model: HBM-bound when the algorithmic intensity lies below the ridge
+    intensity = fl.value / max(by.value, 1.0)
+    hbm_bound = intensity < peak * 1e12 / (HBM_PEAK_GBS * 1e9)
+    return {
+        "kernel": "", "bound": "hbm" if hbm_bound else "mfma",
+        "achieved": round(gbs, 1) if hbm_bound else round(tflops, 3),
+        "peak": HBM_PEAK_GBS if hbm_bound else peak,
+        "unit": "GB/s" if hbm_bound else "TFLOP/s",
+        "frac": round(gbs / HBM_PEAK_GBS, 5) if hbm_bound else round(tflops / peak, 5),
+        "traffic": None,
+        "alg_intensity_flop_per_byte": round(intensity, 1),
+        "ridge_flop_per_byte": round(peak * 1e12 / (HBM_PEAK_GBS * 1e9), 1),
+        "achieved_tflops": round(tflops, 3), "frac_of_mfma_peak": round(tflops / peak, 5),
+        "achieved_gbs": round(gbs, 1), "frac_of_hbm_peak": round(gbs / HBM_PEAK_GBS, 5),
+        "launches": int(n.value), "avg_us": round(ms.value * 1e3 / n.value, 3),
+        "alg_flops_per_launch": round(fl.value / n.value),
+        "alg_bytes_per_launch": round(by.value / n.value),
+    }
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -166,6 +234,9 @@ def main():
     ap.add_argument("--no-graph", action="store_true")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-roofline", action="store_true")
+    ap.add_argument("--windows", type=int, default=50,
+                    help="extra timed windows of --steps steps each after the headline window "
+                         "(spread estimate: median / p10 / p90 in 'windows'; 0 = off)")
     args = ap.parse_args()
 
     world = int(os.environ.get("WORLD_SIZE", "1"))
@@ -190,7 +261,9 @@ def main():
     if args.batch:
         cfg["B"] = args.batch
     mode = _lib.MODE_F32 if args.mode == "f32" else _lib.MODE_BF16
-    ds, stft_s_per_clip = build_dataset(cfg, args.clips, dev, seed=rank)
+    # the same corpus on every rank: the index sharding of the Trainer (rank r takes elements
+    # r::world of ONE permutation) assumes identical datasets, as DistributedSampler does
+    ds, stft_s_per_clip = build_dataset(cfg, args.clips, dev, seed=0)
     N = ds.num_points
     torch.manual_seed(1)
     net = models.ST(dim_input=cfg["din"], num_outputs=1, dim_output=cfg["C"],
@@ -215,8 +288,23 @@ def main():
         t = torch.tensor([elapsed], dtype=torch.float64, device=dev)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         elapsed = float(t)
+    # spread: more windows of the same K steps, each bracketed like the headline window (bounded
+    # to ~10 s so that slow configurations still finish in minutes)
+    win_ms = []
+    n_win = args.windows if elapsed * args.windows <= 10.0 else max(0, int(10.0 / max(elapsed, 1e-9)))
+    for _ in range(n_win):
+        barrier()
+        w0 = time.perf_counter()
+        for _ in range(args.steps):
+            tr.step()
+        barrier()
+        win_ms.append((time.perf_counter() - w0) / args.steps * 1e3)
+    if world > 1 and win_ms:
+        t = torch.tensor(win_ms, dtype=torch.float64, device=dev)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        win_ms = t.cpu().tolist()
     loss_sum, correct = tr.read_stats()
-    n_seen = (args.warmup + args.steps) * cfg["B"] * world
+    n_seen = (args.warmup + args.steps * (1 + len(win_ms))) * cfg["B"] * world
     if not np.isfinite(loss_sum) or not bool(torch.isfinite(tr.eng.flat).all()):
         raise SystemExit(f"bench: non-finite training state (loss sum {loss_sum}): the timed "
                          "steps are invalid")
@@ -239,61 +327,60 @@ def main():
         "train_loss_mean": round(loss_sum / max(n_seen, 1), 4),
         "stft_ms_per_clip": round(stft_s_per_clip * 1e3, 3),
     }
+    if win_ms:
+        q = np.percentile(np.asarray(win_ms), [10, 50, 90])
+        out["windows"] = {"n": len(win_ms), "steps_each": args.steps,
+                          "ms_per_step_p10": round(float(q[0]), 4),
+                          "ms_per_step_median": round(float(q[1]), 4),
+                          "ms_per_step_p90": round(float(q[2]), 4),
+                          "value_median": round(cfg["B"] * world / (float(q[1]) * 1e-3)
+                                                / cfg["sets_per_clip"], 3)}
 
-    # ---- roofline of the dominant kernel: HIP events on its launch stream, live ------
+    # ---- roofline of the dominant kernel(s): HIP events on their launch stream, live ------
     if not args.no_roofline:
-        kid = _lib.K_GEMM_F32 if args.mode == "f32" else _lib.K_MAB1_BWD
-        ksteps = min(args.steps, 20)
         # un-captured steps of the same workload so that the events bracket real launches
         tr_use_graph = tr.use_graph
         tr.use_graph = False
         for _ in range(3):
             tr.step()
         torch.cuda.synchronize(dev)
-        _lib.check(L.pca_prof_start(kid, 4096 * ksteps), "prof_start")
-        for _ in range(ksteps):
-            tr.step()
-        torch.cuda.synchronize(dev)
-        ms, n, fl, by = C.c_double(), C.c_int64(), C.c_double(), C.c_double()
-        _lib.check(L.pca_prof_stop(C.byref(ms), C.byref(n), C.byref(fl), C.byref(by)),
-                   "prof_stop")
+        peak = FP32_VALU_PEAK_TFLOPS if args.mode == "f32" else MFMA_BF16_PEAK_TFLOPS
+        overhead_us = event_pair_overhead_us(dev)
+        if args.mode == "f32":
+            kernels = [(_lib.K_GEMM_F32, "k_gemm_f32", None,
+                        "exact-fp32 parity path: strided VALU GEMMs, priced against the fp32 "
+                        "vector/matrix peak (157.3 TFLOP/s)")]
+        else:
+            kernels = [
+                (_lib.K_MAB1_BWD, "k_mab1_bwd (fused ISAB mab1 backward chain, both layers)",
+                 "k_mab1_bwd_bytes_per_launch",
+                 "reference-formulation FLOPs 4*M*(dq*d + d^2 + 2*m*d) per launch (SURVEY 8d, "
+                 "backward = 2x forward); algorithmic bytes = dY in + X in + dX out, bf16 "
+                 "activations"),
+                (_lib.K_MAB0_BWD, "k_mab0_bwd (fused ISAB mab0 / PMA backward, few queries)",
+                 "k_mab0_bwd_bytes_per_launch",
+                 "reference-formulation FLOPs 4*M*(2*dk*d + 2*m*d) per launch; algorithmic bytes "
+                 "= X in + dX read-modify-write"),
+            ]
+        names = ["roofline", "roofline2"]
+        for (kid, label, tkey, note), key in zip(kernels, names):
+            r = measure_kernel(L, _lib, tr, dev, kid, min(args.steps, 20), peak)
+            if r is None:
+                continue
+            r["kernel"] = label
+            r["traffic"] = committed_traffic(tkey) if args.config == "cfg2" else None
+            r["clock"] = ("HIP events recorded by the library around every launch of this kernel on "
+                          "its launch stream (pca_prof_start/stop), eager steps of the same "
+                          "workload; an event pair around nothing measures "
+                          f"{overhead_us:.2f} us here, which is included in avg_us (the rocprofv3 "
+                          "kernel-trace average under profiles/ is the kernel alone)")
+            r["event_pair_overhead_us"] = round(overhead_us, 3)
+            r["note"] = note + ("; traffic = HBM bytes per launch from rocprofv3 PMC "
+                                "(profiles/, FETCH_SIZE doubled per MI355X_MICROARCH.md), null when "
+                                "no committed measurement matches the current library"
+                                if tkey else "")
+            out[key] = r
         tr.use_graph = tr_use_graph
-        if n.value > 0 and ms.value > 0:
-            tflops = fl.value / (ms.value * 1e-3) / 1e12
-            gbs = by.value / (ms.value * 1e-3) / 1e9
-            peak = FP32_VALU_PEAK_TFLOPS if args.mode == "f32" else MFMA_BF16_PEAK_TFLOPS
-            # roofline model: the kernel is HBM-bound when its algorithmic intensity lies
-            # below the ridge peak_flops / peak_bandwidth
-            intensity = fl.value / max(by.value, 1.0)
-            hbm_bound = intensity < peak * 1e12 / (HBM_PEAK_GBS * 1e9)
-            traffic = None
-            tpath = os.path.join(ROOT, "profiles", "r01_hbm_traffic.json")
-            if args.mode == "bf16" and args.config == "cfg2" and os.path.exists(tpath):
-                traffic = json.load(open(tpath)).get("k_mab1_bwd_bytes_per_launch")
-            out["roofline"] = {
-                "kernel": "k_gemm_f32" if args.mode == "f32" else "k_mab1_bwd (fused ISAB mab1 "
-                          "backward chain, both layers)",
-                "bound": "hbm" if hbm_bound else "mfma",
-                "achieved": round(gbs, 1) if hbm_bound else round(tflops, 3),
-                "peak": HBM_PEAK_GBS if hbm_bound else peak,
-                "unit": "GB/s" if hbm_bound else "TFLOP/s",
-                "frac": round(gbs / HBM_PEAK_GBS, 5) if hbm_bound else round(tflops / peak, 5),
-                "traffic": traffic,
-                "alg_intensity_flop_per_byte": round(intensity, 1),
-                "ridge_flop_per_byte": round(peak * 1e12 / (HBM_PEAK_GBS * 1e9), 1),
-                "achieved_tflops": round(tflops, 3), "frac_of_mfma_peak": round(tflops / peak, 5),
-                "achieved_gbs": round(gbs, 1), "frac_of_hbm_peak": round(gbs / HBM_PEAK_GBS, 5),
-                "launches": int(n.value), "avg_us": round(ms.value * 1e3 / n.value, 3),
-                "alg_flops_per_launch": round(fl.value / n.value),
-                "alg_bytes_per_launch": round(by.value / n.value),
-                "note": ("exact-fp32 parity path: strided VALU GEMMs, priced against the fp32 "
-                         "vector/matrix peak (157.3 TFLOP/s)" if args.mode == "f32" else
-                         "reference-formulation FLOPs 4*M*(dq*d + d^2 + 2*m*d) per launch "
-                         "(SURVEY 8d, backward = 2x forward); algorithmic bytes = dY in + X in + "
-                         "dX out, bf16 activations; traffic = HBM bytes per launch from "
-                         "rocprofv3 PMC (profiles/r01_hbm_traffic.json), FETCH_SIZE doubled per "
-                         "MI355X_MICROARCH.md"),
-            }
         fwd = st_fwd_macs(N, cfg["din"], cfg["d"], cfg["m"], 1, cfg["C"]) * 2
         out["model_tflops_ref_formulation"] = round(
             3 * fwd * cfg["B"] * world * args.steps / elapsed / 1e12, 3)

@@ -29,7 +29,7 @@
 extern "C" {
 #endif
 
-#define PCA_ABI_VERSION 1
+#define PCA_ABI_VERSION 2
 
 enum {
   PCA_OK = 0,
@@ -134,14 +134,18 @@ int pca_pack_points_3d_var(const float* spec, int64_t stride_f, int64_t stride_t
  *         order p = t*F + f (a stable argsort of the negated values; NaNs last).
  * mode 1: the first K entries of a uniformly random permutation of the points, drawn from
  *         the counter-based stream (seed, draw, batch slot b, set index); the reference uses the global
- *         numpy RNG, so only the distribution is reproducible.
+ *         numpy RNG, so only the distribution is reproducible.  The effective draw number is
+ *         draw + draw_dev[0] when draw_dev (device int32, nullable) is given: a step captured
+ *         into a hipGraph passes the optimiser's device step counter (pca_adam_step) so that
+ *         every replay draws a fresh selection (a by-value counter would be frozen in the graph).
  * out[B, K, 3] = (farr[f], tarr[t], value), or out[B, K, 2] = (farr[f], value) when tarr is
  * NULL.  sel (nullable) [B, K] int32 receives the selected point indices p. */
 int pca_subsample_points(const float* spec, int64_t stride_f, int64_t stride_t,
                          int64_t stride_s, const float* farr, const float* tarr,
                          const int64_t* idx, int B, int F, int Nt, int K, int mode,
-                         uint64_t seed, uint64_t draw, float* out, int32_t* sel,
-                         const int64_t* labels, int64_t* labels_out, void* stream);
+                         uint64_t seed, uint64_t draw, const int32_t* draw_dev, float* out,
+                         int32_t* sel, const int64_t* labels, int64_t* labels_out,
+                         void* stream);
 
 /* Importance-sampled point sets for a batch of frame chunks
  * replaces: Code/dataset.py:243-289  ESC_pc_temp_importancerandKSS.__getitem__
@@ -149,7 +153,7 @@ int pca_subsample_points(const float* spec, int64_t stride_f, int64_t stride_t,
  * caller passes kaiser(2) (x) kaiser(winF), beta 5.09, periodic, as the reference builds it),
  * zero 'same' padding, + 1e-6.  choice 1: the K flat heat indices i = f*Nt + t of largest
  * heat, descending (K <= N); choice 0: K draws with replacement from heat / sum(heat), stream
- * (seed, draw, batch slot, set).  As in the reference, index i then addresses ROW i of the
+ * (seed, draw + draw_dev[0], batch slot, set).  As in the reference, index i then addresses ROW i of the
  * time-major point table: out[b, q] = (farr[i % F], tarr[i / F], x[i % F, i / F]).
  * sel (nullable) [B, K] int32 = i; heat (nullable) [B, F, Nt] receives the heat maps.
  * Requires F >= 2, Nt >= 2, F*Nt <= 16384. */
@@ -157,8 +161,8 @@ int pca_importance_points(const float* spec, int64_t stride_f, int64_t stride_t,
                           int64_t stride_s, const float* farr, const float* tarr,
                           const int64_t* idx, int B, int F, int Nt, int K, int choice,
                           const float* kern, int winF, uint64_t seed, uint64_t draw,
-                          float* out, int32_t* sel, float* heat, const int64_t* labels,
-                          int64_t* labels_out, void* stream);
+                          const int32_t* draw_dev, float* out, int32_t* sel, float* heat,
+                          const int64_t* labels, int64_t* labels_out, void* stream);
 
 /* 2-D point sets from per-frame tables (the output of pc_maxK / pc_randK)
  * replaces: Code/dataset.py:76-80  ESC_pc_ss.__getitem__ (+ default_collate)

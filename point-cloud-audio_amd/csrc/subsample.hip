@@ -41,10 +41,12 @@ __global__ __launch_bounds__(1024) void k_subsample(
     const float* __restrict__ spec, int64_t stride_f, int64_t stride_t, int64_t stride_s,
     const float* __restrict__ farr, const float* __restrict__ tarr,     // tarr null: 2-D rows
     const int64_t* __restrict__ idx, int F, int Nt, int K, int mode, uint64_t seed,
-    uint64_t draw, int Np, float* __restrict__ out, int32_t* __restrict__ sel,
-    const int64_t* __restrict__ labels, int64_t* __restrict__ labels_out) {
+    uint64_t draw, const int32_t* __restrict__ draw_dev, int Np, float* __restrict__ out,
+    int32_t* __restrict__ sel, const int64_t* __restrict__ labels,
+    int64_t* __restrict__ labels_out) {
   extern __shared__ uint64_t keys[];                 // Np = power of two >= N
   const int b = blockIdx.x, tid = threadIdx.x;
+  if (draw_dev != nullptr) draw += (uint64_t)(uint32_t)draw_dev[0];   // device-side counter
   const int64_t set = idx[b];
   const int N = F * Nt;
   if (labels != nullptr && labels_out != nullptr && tid == 0) labels_out[b] = labels[set];
@@ -113,11 +115,13 @@ __global__ __launch_bounds__(1024) void k_importance(
     const float* __restrict__ spec, int64_t stride_f, int64_t stride_t, int64_t stride_s,
     const float* __restrict__ farr, const float* __restrict__ tarr,
     const int64_t* __restrict__ idx, int F, int Nt, int K, int choice,
-    const float* __restrict__ kern, int winF, uint64_t seed, uint64_t draw, int Np,
-    float* __restrict__ out, int32_t* __restrict__ sel, float* __restrict__ heat_out,
+    const float* __restrict__ kern, int winF, uint64_t seed, uint64_t draw,
+    const int32_t* __restrict__ draw_dev, int Np, float* __restrict__ out,
+    int32_t* __restrict__ sel, float* __restrict__ heat_out,
     const int64_t* __restrict__ labels, int64_t* __restrict__ labels_out) {
   extern __shared__ uint64_t lds64[];
   const int b = blockIdx.x, tid = threadIdx.x;
+  if (draw_dev != nullptr) draw += (uint64_t)(uint32_t)draw_dev[0];   // device-side counter
   const int64_t set = idx[b];
   const int N = F * Nt;
   float* sx = reinterpret_cast<float*>(lds64);        // xt [F][Nt], later the heat map
@@ -261,8 +265,9 @@ extern "C" {
 int pca_subsample_points(const float* spec, int64_t stride_f, int64_t stride_t,
                          int64_t stride_s, const float* farr, const float* tarr,
                          const int64_t* idx, int B, int F, int Nt, int K, int mode,
-                         uint64_t seed, uint64_t draw, float* out, int32_t* sel,
-                         const int64_t* labels, int64_t* labels_out, void* stream) {
+                         uint64_t seed, uint64_t draw, const int32_t* draw_dev, float* out,
+                         int32_t* sel, const int64_t* labels, int64_t* labels_out,
+                         void* stream) {
   PCA_REQUIRE(spec && farr && idx && out, "subsample_points: null pointer");
   PCA_REQUIRE(B > 0 && F > 0 && Nt > 0, "subsample_points: B=%d F=%d Nt=%d", B, F, Nt);
   PCA_REQUIRE(tarr != nullptr || Nt == 1, "subsample_points: Nt=%d needs tarr", Nt);
@@ -279,8 +284,8 @@ int pca_subsample_points(const float* spec, int64_t stride_f, int64_t stride_t,
   });
   hipLaunchKernelGGL(pca::k_subsample, dim3((unsigned)B), dim3(1024),
                      (size_t)Np * sizeof(uint64_t), pca::as_stream(stream), spec, stride_f,
-                     stride_t, stride_s, farr, tarr, idx, F, Nt, K, mode, seed, draw, Np, out,
-                     sel, labels, labels_out);
+                     stride_t, stride_s, farr, tarr, idx, F, Nt, K, mode, seed, draw, draw_dev,
+                     Np, out, sel, labels, labels_out);
   return pca::check_launch("k_subsample");
 }
 
@@ -288,8 +293,8 @@ int pca_importance_points(const float* spec, int64_t stride_f, int64_t stride_t,
                           int64_t stride_s, const float* farr, const float* tarr,
                           const int64_t* idx, int B, int F, int Nt, int K, int choice,
                           const float* kern, int winF, uint64_t seed, uint64_t draw,
-                          float* out, int32_t* sel, float* heat, const int64_t* labels,
-                          int64_t* labels_out, void* stream) {
+                          const int32_t* draw_dev, float* out, int32_t* sel, float* heat,
+                          const int64_t* labels, int64_t* labels_out, void* stream) {
   PCA_REQUIRE(spec && farr && tarr && idx && kern && out, "importance_points: null pointer");
   PCA_REQUIRE(B > 0 && F >= 2 && Nt >= 2, "importance_points: B=%d F=%d Nt=%d (torch.gradient "
               "needs two samples per axis)", B, F, Nt);
@@ -310,8 +315,8 @@ int pca_importance_points(const float* spec, int64_t stride_f, int64_t stride_t,
   if (lds < (size_t)N * 8) lds = (size_t)N * 8;
   hipLaunchKernelGGL(pca::k_importance, dim3((unsigned)B), dim3(1024), lds,
                      pca::as_stream(stream), spec, stride_f, stride_t, stride_s, farr, tarr, idx,
-                     F, Nt, K, choice, kern, winF, seed, draw, Np, out, sel, heat, labels,
-                     labels_out);
+                     F, Nt, K, choice, kern, winF, seed, draw, draw_dev, Np, out, sel, heat,
+                     labels, labels_out);
   return pca::check_launch("k_importance");
 }
 

@@ -18,13 +18,77 @@ from torch.utils.data import Dataset
 
 import pca_hip
 
-__all__ = ["ESC_pc", "ESC_pc_ss", "ESC_pc_temp", "ESC_pc_temp_maxKSS", "ESC_pc_temp_randKSS",
-           "ESC_pc_temp_importancerandKSS", "DeviceBatchLoader"]
+__all__ = ["ESC_baseline", "ESC_pc", "ESC_pc_ss", "ESC_baseline_temporal",
+           "ESC_baseline_temporal_maxK", "ESC_pc_temp", "ESC_pc_temp_maxKSS",
+           "ESC_pc_temp_randKSS", "ESC_pc_temp_importancerandKSS", "DeviceBatchLoader"]
 
 
 def _dev(device) -> torch.device:
     return torch.device("cuda", torch.cuda.current_device()) if device is None \
         else torch.device(device)
+
+
+# ---- datasets of the two comparison baselines (FB, CNN_temp) -------------------------------
+# Not point sets and not on the accelerated path: host
+# numpy, exactly the item contract of the reference, so that Code/baseline_eval.py and
+# Code/baseline_temp_eval.py keep importing them from here.  NOTE the return order: these
+# three yield (label, x); the point-cloud datasets yield (points, label).
+
+class ESC_baseline(Dataset):
+    """FB items (Code/dataset.py:10-27): x [N, T] spectral frames, y int[T].
+    Item idx -> (y[idx], tensor(x[:, idx]))."""
+
+    def __init__(self, x, y):
+        self.x = x
+        self.labels = y
+
+    def __len__(self):
+        return self.x.shape[1]
+
+    def __getitem__(self, idx):
+        return self.labels[idx], torch.tensor(self.x[:, idx])
+
+
+class ESC_baseline_temporal(Dataset):
+    """CNN_temp items (Code/dataset.py:82-99): x [N, Nt, T] chunked spectrograms, y int[T].
+    Item idx -> (tensor(y[idx]), tensor(x[:, :, idx]).T) i.e. [Nt, N]."""
+
+    def __init__(self, x, y):
+        self.x = x
+        self.labels = y
+
+    def __len__(self):
+        return self.x.shape[2]
+
+    def __getitem__(self, idx):
+        return torch.tensor(self.labels[idx]), torch.tensor(self.x[:, :, idx]).T
+
+
+class ESC_baseline_temporal_maxK(Dataset):
+    """CNN_temp items with all but K cells of the chunk zeroed (Code/dataset.py:101-135).
+    flag "max": keep the K largest values (``(-v).argsort()[:K]`` over the cells in
+    time-major order, as the reference enumerates them); "rand": keep K cells of
+    ``np.random.permutation`` (global numpy RNG, as the reference)."""
+
+    def __init__(self, x, y, K, flag="max"):
+        self.x = x
+        self.labels = y
+        self.K = K
+        self.flag = flag
+
+    def __len__(self):
+        return self.x.shape[2]
+
+    def __getitem__(self, idx):
+        xt = self.x[:, :, idx]                        # [N, Nt]
+        flat = xt.T.reshape(-1)                        # cell p = t*N + f
+        if self.flag == "rand":
+            keep = np.random.permutation(flat.shape[0])[:self.K]
+        else:
+            keep = (-flat).argsort()[:self.K]
+        out = np.zeros_like(flat)
+        out[keep] = flat[keep]
+        return torch.tensor(self.labels[idx]), torch.tensor(out.reshape(xt.shape[1], xt.shape[0]))
 
 
 class ESC_pc(Dataset):
@@ -237,12 +301,21 @@ class _TempSS(ESC_pc_temp):
 
     batch_seq = None        # selections are drawn per call: the Trainer uploads indices per step
 
-    def batch(self, idx: torch.Tensor, out=None, labels_out=None, want_sel: bool = False):
+    @property
+    def stochastic(self) -> bool:
+        """True when every call must draw a NEW selection (random-K, multinomial importance
+        sampling): a caller that captures ``batch`` into a hipGraph then has to pass
+        ``draw_dev`` - a device counter it advances per replay - because the host-side draw
+        number is a by-value kernel argument and would be frozen in the captured launch."""
+        return self._mode == pca_hip.RANDK
+
+    def batch(self, idx: torch.Tensor, out=None, labels_out=None, want_sel: bool = False,
+              draw_dev=None):
         spec, f32, t32, lab = self._resident()
         self._draw += 1
         return pca_hip.subsample_points(spec, f32, t32, idx, self.K, self._mode, self.seed,
                                         self._draw, lab, out=out, labels_out=labels_out,
-                                        want_sel=want_sel)
+                                        want_sel=want_sel, draw_dev=draw_dev)
 
     def __getitem__(self, idx):
         """float64 [K, 3] exactly as the reference builds it (float64 farr / tarr, the float32
@@ -289,8 +362,12 @@ class ESC_pc_temp_importancerandKSS(_TempSS):
         self.winF = int(winF)
         self._kern = None
 
+    @property
+    def stochastic(self) -> bool:
+        return self.choice == 0
+
     def batch(self, idx: torch.Tensor, out=None, labels_out=None, want_sel: bool = False,
-              want_heat: bool = False):
+              want_heat: bool = False, draw_dev=None):
         spec, f32, t32, lab = self._resident()
         if self._kern is None:
             self._kern = pca_hip.importance_kernel(self.winF).to(spec.device)
@@ -298,7 +375,7 @@ class ESC_pc_temp_importancerandKSS(_TempSS):
         return pca_hip.importance_points(spec, f32, t32, idx, self.K, self.choice, self._kern,
                                          self.seed, self._draw, lab, out=out,
                                          labels_out=labels_out, want_sel=want_sel,
-                                         want_heat=want_heat)
+                                         want_heat=want_heat, draw_dev=draw_dev)
 
 
 class DeviceBatchLoader:

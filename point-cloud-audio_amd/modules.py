@@ -56,7 +56,8 @@ class MAB(nn.Module):
         """Q [B,nq,dim_Q] (or the shared learned query [1,nq,dim_Q] with q_shared),
         K [B,nk,dim_K] -> [B,nq,dim_V].  key_lengths int[B]: valid keys per set."""
         if torch.is_grad_enabled() and (
-                Q.requires_grad or K.requires_grad or self.fc_q.weight.requires_grad):
+                Q.requires_grad or K.requires_grad
+                or any(p.requires_grad for p in self.parameters())):
             return pca_hip.mab(Q, K, *self._params(), self.num_heads, q_shared, key_lengths,
                                self._ln_params())
         return pca_hip.mab_infer(Q, K, self._params(), self.num_heads, q_shared, key_lengths,

@@ -87,11 +87,12 @@ SIGNATURES = {
     "pca_debug_poison_lds": (C.c_int, [c_vp]),
     "pca_subsample_points": (C.c_int, [c_fp, C.c_int64, C.c_int64, C.c_int64, c_fp, c_fp, c_vp,
                                        C.c_int, C.c_int, C.c_int, C.c_int, C.c_int,
-                                       C.c_uint64, C.c_uint64, c_fp, c_vp, c_vp, c_vp, c_vp]),
+                                       C.c_uint64, C.c_uint64, c_vp, c_fp, c_vp, c_vp, c_vp,
+                                       c_vp]),
     "pca_importance_points": (C.c_int, [c_fp, C.c_int64, C.c_int64, C.c_int64, c_fp, c_fp, c_vp,
                                         C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, c_fp,
-                                        C.c_int, C.c_uint64, C.c_uint64, c_fp, c_vp, c_fp, c_vp,
-                                        c_vp, c_vp]),
+                                        C.c_int, C.c_uint64, C.c_uint64, c_vp, c_fp, c_vp, c_fp,
+                                        c_vp, c_vp, c_vp]),
     "pca_pack_points_2d_ss": (C.c_int, [c_fp, c_fp, c_vp, C.c_int, C.c_int, c_fp, c_vp, c_vp,
                                         c_vp]),
     "pca_adam_step": (C.c_int, [c_fp, c_fp, c_fp, c_fp, C.c_int64, C.c_float, C.c_float,

@@ -348,12 +348,22 @@ def pack_points_3d(spec: torch.Tensor, farr: torch.Tensor, tarr: torch.Tensor,
 MAXK, RANDK = 0, 1
 
 
+def _draw_ptr(draw_dev):
+    if draw_dev is None:
+        return None
+    assert draw_dev.is_cuda and draw_dev.dtype == torch.int32 and draw_dev.numel() >= 1
+    return draw_dev.data_ptr()
+
+
 def subsample_points(spec: torch.Tensor, farr: torch.Tensor, tarr: Optional[torch.Tensor],
                      idx: torch.Tensor, K: int, mode: int = MAXK, seed: int = 0,
                      draw: int = 0, labels: Optional[torch.Tensor] = None,
                      out: Optional[torch.Tensor] = None,
-                     labels_out: Optional[torch.Tensor] = None, want_sel: bool = False):
+                     labels_out: Optional[torch.Tensor] = None, want_sel: bool = False,
+                     draw_dev: Optional[torch.Tensor] = None):
     """Batch of sub-sampled point sets selected on the device (pca_subsample_points).
+    ``draw_dev`` (device int32, optional): its first element is added to ``draw`` on the device,
+    so a launch captured into a hipGraph draws a fresh selection on every replay.
 
     spec indexed [f, t, s] through its strides ([F, T] with tarr=None for the framewise
     2-D case); idx int64[B].  mode MAXK: the K largest values per set, descending
@@ -382,8 +392,9 @@ def subsample_points(spec: torch.Tensor, farr: torch.Tensor, tarr: Optional[torc
         check(lib().pca_subsample_points(_ptr(spec), sf, st, ss, _ptr(farr), _ptr(tarr),
                                          _ptr(idx), B, F, Nt, int(K), int(mode),
                                          int(seed) & (2 ** 64 - 1), int(draw) & (2 ** 64 - 1),
-                                         _ptr(out), _ptr(sel), _ptr(labels), _ptr(labels_out),
-                                         _stream(spec)), "pca_subsample_points")
+                                         _draw_ptr(draw_dev), _ptr(out), _ptr(sel),
+                                         _ptr(labels), _ptr(labels_out), _stream(spec)),
+              "pca_subsample_points")
     return (out, labels_out, sel) if want_sel else (out, labels_out)
 
 
@@ -424,7 +435,7 @@ def importance_points(spec: torch.Tensor, farr: torch.Tensor, tarr: torch.Tensor
                       seed: int = 0, draw: int = 0, labels: Optional[torch.Tensor] = None,
                       out: Optional[torch.Tensor] = None,
                       labels_out: Optional[torch.Tensor] = None, want_sel: bool = False,
-                      want_heat: bool = False):
+                      want_heat: bool = False, draw_dev: Optional[torch.Tensor] = None):
     """Batch of ESC_pc_temp_importancerandKSS items (pca_importance_points): spec [F, Nt, S]
     through its strides, kern [2, winF] float32 on the device.  Returns
     (points [B, K, 3], labels[idx] or None[, sel int32 [B, K]][, heat [B, F, Nt]])."""
@@ -444,8 +455,8 @@ def importance_points(spec: torch.Tensor, farr: torch.Tensor, tarr: torch.Tensor
         check(lib().pca_importance_points(
             _ptr(spec), spec.stride(0), spec.stride(1), spec.stride(2), _ptr(farr), _ptr(tarr),
             _ptr(idx), B, F, Nt, int(K), int(choice), _ptr(kern), int(kern.shape[1]),
-            int(seed) & (2 ** 64 - 1), int(draw) & (2 ** 64 - 1), _ptr(out), _ptr(sel),
-            _ptr(heat), _ptr(labels), _ptr(labels_out), _stream(spec)), "pca_importance_points")
+            int(seed) & (2 ** 64 - 1), int(draw) & (2 ** 64 - 1), _draw_ptr(draw_dev), _ptr(out),
+            _ptr(sel), _ptr(heat), _ptr(labels), _ptr(labels_out), _stream(spec)), "pca_importance_points")
     res = [out, labels_out]
     if want_sel:
         res.append(sel)

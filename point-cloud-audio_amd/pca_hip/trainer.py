@@ -38,7 +38,9 @@ from .ops import _need_cuda
 
 
 def st_config(model, B: int, N: int, mode: int = _lib.MODE_F32) -> StConfig:
-    """Read the architecture off an ``models.ST`` instance."""
+    """Read the architecture off an ``models.ST`` instance (bare, or wrapped in
+    ``nn.DataParallel`` as ``runfiles.load_run`` / Code/pceval.py:46 hand it over)."""
+    model = getattr(model, "module", model)
     isab0 = model.enc[0]
     if getattr(isab0.mab0, "ln0", None) is not None:
         raise _lib.PcaHipError("the whole-model engine covers ST(ln=False) (45 tensors); a model "
@@ -53,6 +55,7 @@ def flatten_parameters(model) -> torch.Tensor:
     """Re-home every parameter of ``model`` as a view of ONE flat fp32 vector (state_dict
     order, the layout pca_st_* expects) and return that vector.  Idempotent: a model that
     is already flat keeps its vector (so several engines can share one model)."""
+    model = getattr(model, "module", model)
     params = list(model.parameters())
     names = [n for n, _ in model.named_parameters()]
     assert names == list(model.state_dict().keys()), "unexpected parameter order"
@@ -271,6 +274,11 @@ class Trainer:
         elif self.lengths is not None:
             self.ds.batch(self.idx, out=self.X, labels_out=self.labels,
                           lengths_out=self.lengths)
+        elif getattr(self.ds, "stochastic", False):
+            # random sub-sampling datasets: the draw number must advance per REPLAY of a captured
+            # step, so it is read on the device from the optimiser's step counter
+            self.ds.batch(self.idx, out=self.X, labels_out=self.labels,
+                          draw_dev=self.step_count)
         else:
             self.ds.batch(self.idx, out=self.X, labels_out=self.labels)
         if self.keep_grads:           # otherwise the Adam pass leaves them cleared

@@ -81,9 +81,11 @@ def save_run(model, config: Dict, directory: str, now: Optional[datetime] = None
     return stem + "_net.pth", stem + "_config.json"
 
 
-def load_run(json_path: str, pth_path: Optional[str] = None, device="cpu",
+def load_run(json_path: str, pth_path: Optional[str] = None, device=None,
              dim_output: Optional[int] = None):
-    """(DataParallel-wrapped ST, config) of a run.  ``pth_path`` defaults to the JSON's sibling.
+    """(DataParallel-wrapped ST, config) of a run.  ``pth_path`` defaults to the JSON's sibling;
+    ``device`` defaults to the current HIP device when there is one (the engine and
+    ``evalsweep.reframe_sweep`` take the wrapped model as it is), else the CPU.
 
     The evaluation scripts build the model with the default ``dim_output=10``; ``dim_output``
     overrides it, otherwise it is read off the classifier weight in the file."""
@@ -97,6 +99,8 @@ def load_run(json_path: str, pth_path: Optional[str] = None, device="cpu",
         sd = {"module." + k: v for k, v in sd.items()}
     if dim_output is None:
         dim_output = int(sd["module.dec.1.weight"].shape[0])
+    if device is None:
+        device = "cuda" if torch.cuda.is_available() else "cpu"
     model = ST(dim_input=3 if arch == "3ST" else 2, dim_output=dim_output,
                dim_hidden=config["dhidden"], num_heads=config["nheads"],
                num_inds=config["ninds"]).to(device)

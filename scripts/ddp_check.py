@@ -1,5 +1,7 @@
-"""Launched by tests/test_gpu_ddp.py under torch.distributed.run with 2 ranks on ONE GPU
-(backend gloo): the multi-rank step (phase-0 graph, bucket-A all-reduce on the side stream,
+"""Launched by tests/test_gpu_ddp.py under torch.distributed.run with 2 ranks: on ONE GPU with
+backend gloo (the rehearsal a one-GPU box allows), or with PCA_DIST_BACKEND=nccl (RCCL) - one
+rank per GPU when the box has two, both on GPU 0 otherwise (RCCL refuses that: the test records
+the refusal and skips).  The multi-rank step (phase-0 graph, bucket-A all-reduce on the side stream,
 phase-1 graph, bucket-B all-reduce, Adam) must reproduce a single-rank run on the union batch."""
 import os, sys
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
@@ -11,9 +13,22 @@ from pca_hip import _lib, trainer
 mode = _lib.MODE_BF16 if os.environ.get("PCA_MODE", "f32") == "bf16" else _lib.MODE_F32
 use_graph = os.environ.get("PCA_GRAPH", "1") == "1"
 rank, world = int(os.environ["RANK"]), int(os.environ["WORLD_SIZE"])
-dev = torch.device("cuda", 0)
-torch.cuda.set_device(0)
-dist.init_process_group("gloo")
+backend = os.environ.get("PCA_DIST_BACKEND", "gloo")
+local = int(os.environ.get("LOCAL_RANK", "0")) if (backend == "nccl" and torch.cuda.device_count() >= 2) else 0
+dev = torch.device("cuda", local)
+torch.cuda.set_device(local)
+try:
+    if backend == "nccl":
+        dist.init_process_group("nccl", device_id=dev)
+        probe = torch.ones(1, device=dev)
+        dist.all_reduce(probe)              # the first collective creates the communicator
+        torch.cuda.synchronize()
+        print(f"NCCL_RANKS {world} probe {float(probe)}", flush=True)
+    else:
+        dist.init_process_group("gloo")
+except Exception as e:                      # e.g. two ranks on one device
+    print("BACKEND_REFUSED", backend, repr(e)[:600], flush=True)
+    sys.exit(0)
 rng = np.random.Generator(np.random.PCG64(5))
 F, T, C, B = 256, 640, 10, 32
 x = rng.normal(-9, 3, size=(F, T)).astype(np.float32)
@@ -39,8 +54,9 @@ def run(world_sim, rank_sim, batch, pg):
 flat2, stats2 = run(world, rank, B, dist.group.WORLD)
 dist.barrier()
 # every rank holds identical parameters after the steps
-gathered = [torch.zeros_like(flat2) for _ in range(world)]
-dist.all_gather(gathered, flat2)
+mine = flat2.to(dev) if backend == "nccl" else flat2
+gathered = [torch.zeros_like(mine) for _ in range(world)]
+dist.all_gather(gathered, mine)
 same = all(torch.equal(gathered[0], g) for g in gathered)
 if rank == 0:
     print("RANKS_IDENTICAL", same)

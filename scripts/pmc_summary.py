@@ -39,17 +39,27 @@ write, _ = collect("WRITE_SIZE")
 per = {k: {"fetch_MB": round(2 * fetch[k] / 1e6, 2), "write_MB": round(write.get(k, 0) / 1e6, 2),
            "launches_sampled": nf[k]} for k in fetch}
 per = dict(sorted(per.items(), key=lambda kv: -(kv[1]["fetch_MB"] + kv[1]["write_MB"])))
-bwd = [k for k in per if k.startswith("k_mab1_bwd")]
-agg = sum((per[k]["fetch_MB"] + per[k]["write_MB"]) * per[k]["launches_sampled"] for k in bwd) / \
-    max(1, sum(per[k]["launches_sampled"] for k in bwd))
+
+
+def family(prefix):
+    ks = [k for k in per if k.startswith(prefix)]
+    return sum((per[k]["fetch_MB"] + per[k]["write_MB"]) * per[k]["launches_sampled"] for k in ks) / \
+        max(1, sum(per[k]["launches_sampled"] for k in ks))
+
+
+import hashlib
+so = "/root/repo/point-cloud-audio_amd/pca_hip/libpca_hip.so"
+agg = family("k_mab1_bwd")
 out = {
     "source": "rocprofv3 --kernel-trace --pmc FETCH_SIZE / --pmc WRITE_SIZE (separate passes), "
               "bench.py --mode bf16 --no-graph, cfg2 (scripts/pmc_traffic.sh)",
     "correction": "FETCH_SIZE (KiB) doubled per MI355X_MICROARCH.md (gfx950 reports 1/2 of wide "
                   "coalesced reads); WRITE_SIZE (KiB) as is",
+    "library_sha16": hashlib.sha256(open(so, "rb").read()).hexdigest()[:16],
     "k_mab1_bwd_bytes_per_launch": round(agg * 1e6),
+    "k_mab0_bwd_bytes_per_launch": round(family("k_mab0_bwd") * 1e6),
     "per_kernel_per_launch": per,
 }
-dst = sys.argv[1] if len(sys.argv) > 1 else "/root/repo/profiles/r01_hbm_traffic.json"
+dst = sys.argv[1] if len(sys.argv) > 1 else "/root/repo/profiles/r02_hbm_traffic.json"
 json.dump(out, open(dst, "w"), indent=1)
 print(json.dumps({k: per[k] for k in list(per)[:12]}, indent=1))

@@ -144,3 +144,46 @@ LN_MAB_CASES = [    # name, B, nq, nk, dq, dk, d, h
     ("ln_mab1", 2, 51, 4, 2, 64, 64, 8),
 ]
 LN_ST_CASE = ("ln_st", 3, 40, 2, 32, 4, 8, 10)     # name, B, N, din, d, h, m, C
+
+
+# ---- comparison baselines + metadata helpers (make_golden_base.py / test_boundary_names.py) ----
+BASE_FF_DIMS = [33, 17, 8]
+BASE_NCLASS = 5
+BASE_NT, BASE_NF = 4, 24
+BASE_CNN_DIMS = [20, 12, 6]       # Conv2d kernel (Nt, Nf + 1 - 20) = (4, 5)
+BASE_K = [1, 7, 40]
+
+
+def base_ff_input() -> np.ndarray:
+    return randn(4101, 6, BASE_FF_DIMS[0])
+
+
+def base_cnn_input() -> np.ndarray:
+    return randn(4102, 3, BASE_NT, BASE_NF)
+
+
+def base_dataset_inputs():
+    """x2 [N=9, T=5], y2 int[5]; x3 [N=8, Nt=5, T=4], y3 int[4] (x3 has repeated values so that
+    the top-K boundary meets ties)."""
+    x2 = randn(4103, 9, 5)
+    y2 = np.array([3, 1, 4, 1, 5], dtype=np.int64)
+    x3 = np.round(randn(4104, 8, 5, 4) * 4.0) / 4.0
+    y3 = np.array([2, 7, 1, 8], dtype=np.int64)
+    return x2, y2, x3.astype(np.float32), y3
+
+
+def base_csv_text() -> str:
+    """A synthetic esc50.csv: 6 categories (4 of them in ESC-10) x 7 files, shuffled rows."""
+    cats = ["dog", "rain", "sea_waves", "rooster", "cat", "door_knock"]
+    rows = []
+    for ci, c in enumerate(cats):
+        for k in range(7):
+            rows.append((f"{1 + k % 5}-{100000 + 37 * ci + k}-A-{ci}.wav", 1 + k % 5, ci, c,
+                         c in ("dog", "rain", "sea_waves", "rooster"), f"{100000 + 37 * ci + k}",
+                         "A"))
+    order = np.random.Generator(np.random.PCG64(4105)).permutation(len(rows))
+    lines = ["filename,fold,target,category,esc10,src_file,take"]
+    for i in order:
+        r = rows[i]
+        lines.append(f"{r[0]},{r[1]},{r[2]},{r[3]},{r[4]},{r[5]},{r[6]}")
+    return "\n".join(lines) + "\n"

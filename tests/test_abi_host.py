@@ -28,7 +28,7 @@ def test_library_exports_every_declared_symbol():
         assert hasattr(handle, s), f"{s} declared in pca_hip.h but not exported"
     assert sorted(_lib.SIGNATURES) == syms, "python binding and header disagree"
     L = pca_hip.lib()
-    assert L.pca_abi_version() == 1
+    assert L.pca_abi_version() == 2
     assert L.pca_stft_num_frames(220500, 512) == 431
     assert L.pca_stft_num_frames(220500, 1024) == 216
 

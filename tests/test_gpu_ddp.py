@@ -1,4 +1,6 @@
-"""Two ranks on the one GPU (gloo) through the real Trainer: phase graphs, side-stream
+"""Two ranks through the real Trainer - on the one GPU of the test box with gloo, and with
+nccl (RCCL) where the box allows it (two GPUs, or RCCL accepting two ranks on one device;
+otherwise the refusal is printed and the case skips): phase graphs, side-stream
 bucket all-reduce, fused Adam.  Checks (1) all ranks end with identical parameters and
 (2) they equal a single-rank run on the union batch (2B), fp32 mode, to 1e-4."""
 import os
@@ -22,22 +24,31 @@ from util import close
 pytestmark = pytest.mark.gpu
 
 
-@pytest.mark.parametrize("mode,graph,overlap", [("f32", "1", "1"), ("bf16", "1", "1"),
-                                                ("f32", "0", "1"), ("f32", "1", "0"),
-                                                ("bf16", "1", "0"), ("f32", "0", "0")])
-def test_two_ranks_equal_one_rank_double_batch(tmp_path, mode, graph, overlap):
+@pytest.mark.parametrize("mode,graph,overlap,backend", [
+    ("f32", "1", "1", "gloo"), ("bf16", "1", "1", "gloo"), ("f32", "0", "1", "gloo"),
+    ("f32", "1", "0", "gloo"), ("bf16", "1", "0", "gloo"), ("f32", "0", "0", "gloo"),
+    ("f32", "1", "0", "nccl"), ("bf16", "1", "1", "nccl")])
+def test_two_ranks_equal_one_rank_double_batch(tmp_path, mode, graph, overlap, backend):
     """overlap = 1: split step, bucket A reduced under enc.0's backward; 0: one all-reduce of
     the whole gradient vector between the backward graph and the Adam graph (the default for
     models of this size)."""
     out = str(tmp_path / "flat.pt")
     env = dict(os.environ, PCA_MODE=mode, PCA_GRAPH=graph, PCA_OUT=out, PCA_OVERLAP=overlap,
-               HSA_ENABLE_IPC_MODE_LEGACY="0")
+               HSA_ENABLE_IPC_MODE_LEGACY="0", PCA_DIST_BACKEND=backend)
     r = subprocess.run([sys.executable, "-m", "torch.distributed.run", "--nnodes=1",
                         "--nproc-per-node", "2", "--master-addr", "127.0.0.1",
                         "--master-port", str(_free_port()),
                         os.path.join(ROOT, "scripts", "ddp_check.py")],
                        env=env, capture_output=True, text=True, timeout=600)
     assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-3000:]
+    if "BACKEND_REFUSED" in r.stdout:
+        assert backend == "nccl", r.stdout
+        line = [ln for ln in r.stdout.splitlines() if "BACKEND_REFUSED" in ln][0]
+        print(line)
+        pytest.skip(f"RCCL refused two ranks on this box ({torch.cuda.device_count()} GPU): "
+                    + line[:300])
+    if backend == "nccl":
+        assert "NCCL_RANKS 2 probe 2.0" in r.stdout, r.stdout
     assert "RANKS_IDENTICAL True" in r.stdout, r.stdout
     flat2 = torch.load(out, weights_only=True)
 

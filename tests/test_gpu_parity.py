@@ -476,6 +476,20 @@ def test_reframe_sweep(dev, golden_ckpt, tmp_path):
     ds = dataset.ESC_pc(x[:, :full], y[:full], np.linspace(0, fs / 2, x.shape[0]) / fs, device=dev)
     acc, n = trainer.evaluate(net, ds, 8)
     assert n == full and abs(acc - out["data"][fs][2]) <= 1.0 / full + 1e-9
+    # the read side of Code/pceval.py:23-47 composes with the sweep: load_run hands over the
+    # nn.DataParallel-wrapped model on the device and the engine takes it as it is
+    import runfiles
+    import test_runfiles
+    stem = str(tmp_path / "FST(x)")
+    torch.save({k: T(v) for k, v in golden_ckpt.sub("fst/p/").items()}, stem + "_net.pth")
+    json.dump(test_runfiles.FST_SHIPPED, open(stem + "_config.json", "w"))
+    wrapped, _ = runfiles.load_run(stem + "_config.json")
+    assert isinstance(wrapped, torch.nn.DataParallel)
+    assert next(wrapped.parameters()).is_cuda
+    out2 = evalsweep.reframe_sweep(wrapped, clips, labels, fs, list_N[2:4])
+    assert out2["data"][fs] == out["data"][fs][2:4]
+    acc2, _ = trainer.evaluate(wrapped, ds, 8)
+    assert acc2 == acc
     # shorter window than n_fft: frame count and bin count follow librosa's framing
     d = evalsweep.framewise_dataset(clips, labels, fs, int(0.6 * Nfft))
     assert d.num_points == 1 + 2048 // 2

@@ -66,7 +66,7 @@ def test_round_trip(tmp_path, arch, din, wrap):
     back, cfg2 = runfiles.load_run(js)
     assert cfg2 == shipped and isinstance(back, torch.nn.DataParallel)
     for (k, a), (_, b) in zip(net.state_dict().items(), back.module.state_dict().items()):
-        assert torch.equal(a, b), k
+        assert torch.equal(a, b.cpu()), k
 
 
 def test_loads_the_reference_layout(tmp_path, golden_ckpt):
@@ -78,4 +78,4 @@ def test_loads_the_reference_layout(tmp_path, golden_ckpt):
     model, cfg = runfiles.load_run(stem + "_config.json")
     assert cfg["dhidden"] == 64 and model.module.dec[1].weight.shape == (10, 64)
     for k, v in sd.items():
-        assert torch.equal(model.state_dict()[k], v)
+        assert torch.equal(model.state_dict()[k].cpu(), v)

@@ -293,3 +293,36 @@ def test_importance_multinomial_distribution(dev):
     big = dataset.ESC_pc_temp_importancerandKSS(x, np.zeros(1, np.int64), farr, tarr, 500, 0,
                                                 winF, device=dev)
     assert tuple(big.batch(idx[:2])[0].shape) == (2, 500, 3)
+
+
+@pytest.mark.gpu
+def test_random_selection_advances_under_graph_replay(dev):
+    """A train step captured into a hipGraph must draw a NEW random-K subset on every replay:
+    the draw number reaches the kernel through a device counter (the optimiser's step count),
+    not as a by-value argument frozen at capture time."""
+    import dataset
+    import models
+    from pca_hip import _lib, trainer
+    F, Nt, S, K, B = 64, 4, 8, 37, 8
+    rng = np.random.Generator(np.random.PCG64(31))
+    x = rng.normal(-9, 3, size=(F, Nt, S)).astype(np.float32)
+    y = rng.integers(0, 5, size=S)
+    farr, tarr = np.linspace(0, 0.5, F), np.linspace(0, 0.1, Nt)
+    for cls, kw in ((dataset.ESC_pc_temp_randKSS, {}),
+                    (dataset.ESC_pc_temp_importancerandKSS, dict(choice=0, winF=5))):
+        ds = cls(x, y, farr, tarr, K, device=dev, seed=5, **kw)
+        assert ds.stochastic
+        torch.manual_seed(2)
+        net = models.ST(dim_input=3, num_outputs=1, dim_output=5, num_inds=4, dim_hidden=16,
+                        num_heads=4).to(dev)
+        tr = trainer.Trainer(net, ds, B, mode=_lib.MODE_F32, use_graph=True, shuffle=False)
+        seen = []
+        for _ in range(4):
+            tr.step()
+            torch.cuda.synchronize()
+            seen.append(tr.X.clone())
+        # same sets every step (shuffle off, S == B), different selections
+        for a in range(len(seen)):
+            for b in range(a + 1, len(seen)):
+                assert not torch.equal(seen[a], seen[b]), (cls.__name__, a, b)
+    assert not dataset.ESC_pc_temp_maxKSS(x, y, farr, tarr, K, device=dev).stochastic
