@@ -480,8 +480,12 @@ def mab1_forward_bf16emu(X: Tensor, H: Tensor, p: Params, num_heads: int) -> Ten
         Qp = X @ p["fc_q.weight"].t() + p["fc_q.bias"]
     else:
         Qp = rb(X) @ rb(p["fc_q.weight"]).t() + p["fc_q.bias"]
-    Kp = rb(_lin(H, p, "fc_k"))
-    Vp = rb(_lin(H, p, "fc_v"))
+    if d == 256:      # csrc/mab1_bf16.hip, d = 256: the K / V projections are MFMA products too
+        Kp = rb(rb(H) @ rb(p["fc_k.weight"]).t() + p["fc_k.bias"])
+        Vp = rb(rb(H) @ rb(p["fc_v.weight"]).t() + p["fc_v.bias"])
+    else:
+        Kp = rb(_lin(H, p, "fc_k"))
+        Vp = rb(_lin(H, p, "fc_v"))
     Qh = rb(Qp).view(B, nq, h, dh).permute(0, 2, 1, 3)
     Kh = Kp.view(B, nk, h, dh).permute(0, 2, 1, 3)
     Vh = Vp.view(B, nk, h, dh).permute(0, 2, 1, 3)

@@ -1,0 +1,1182 @@
+// Training kernels of the d = 256 / 8-head / m = 32 Set Transformer (BASELINE configs[3], the
+// north-star shape): the pieces of the MAB adjoint (set_transformer-master/
+// modules.py:19-33 backwards) that the d = 128 kernels hold in ONE launch do not fit a CU at
+// d = 256 (two 128 KiB weight images), so the backward of the many-queries block runs as
+//
+//   k_rowgemm<BWD_O>     dZ = dY.[Z>0] ; dO = dY + dZ Wo           (Wo^T image resident in LDS)
+//   k_attn1_bwd          per head: P recomputed, dA, dS, dQp = dO + dS Kp ; dKp, dVp of the set
+//                        (WAVE = HEAD: a wave owns the 32 features of one head of its 32-point
+//                        tiles - no weight image at all, 9 KiB of LDS per wave)
+//   k_rowgemm<BWD_Q>     dX (+)= dQp Wq                            (Wq^T image resident in LDS)
+//   k_wgrad256           dW[256 x 256] = G^T A over the B*N rows, deterministic two-stage sum
+//
+// and the few-queries block (ISAB mab0 at dk = 256) in the reference's own formulation
+// (modules.py:21: the N keys ARE projected) because the four 128 KiB operand images of the
+// reassociated backward exceed the register file + LDS of a CU:
+//
+//   k_rowgemm<PROJ>      Kp / Vp = X Wk^T + bk  (bf16, [B*N, 256])
+//   k_fq_attn_fwd        flash attention of the m shared queries of one head over the set's
+//                        keys (wave = head, head dim 32): online softmax, O partials per range
+//   k_fq_attn_bwd        dKp, dVp (bf16) and the set's dQp; both score orientations are
+//                        recomputed on the MFMA (one extra 16x16x32 each) instead of transposed
+//   k_rowgemm<BWD_Q> x2  dX (+)= dKp Wk + dVp Wv
+//
+// All activations cross these kernels in bf16 ([rows][256], row-major); accumulation, softmax
+// statistics, biases and residuals are fp32.  Layout conventions: mfma_common.hpp.
+#include "d256_bf16.hpp"
+
+#include <math.h>
+
+#include <mutex>
+
+namespace pca {
+
+namespace {
+
+constexpr int TP = M1_TP;      // 128 points per 4-wave tile (as the forward: the ReLU mask index)
+constexpr int NB = M1_NB;
+
+typedef __attribute__((address_space(3))) s16x4 lds_s16x4;
+
+// transposed fragment (k = the 32 points of a wave tile: slot (g, j) <-> point perm32(8g + j))
+// from a small row-major bf16 image with `rb` bytes per row, for the 16 columns from col0
+__device__ __forceinline__ bf16x8 tr_frag_small(const char* img, int rb, int col0, int lane) {
+  const int g = lane >> 4, i16 = lane & 15, q = i16 >> 2, p = i16 & 3;
+  const int a0 = (4 * g + q) * rb + (col0 + 4 * p) * 2;
+  const int a1 = (16 + 4 * g + q) * rb + (col0 + 4 * p) * 2;
+  const s16x4 lo = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_s16x4*)(img + a0));
+  const s16x4 hi = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_s16x4*)(img + a1));
+  const bf16x4 l4 = __builtin_bit_cast(bf16x4, lo), h4 = __builtin_bit_cast(bf16x4, hi);
+  bf16x8 r;
+#pragma unroll
+  for (int e = 0; e < 4; ++e) { r[e] = l4[e]; r[4 + e] = h4[e]; }
+  return r;
+}
+
+__device__ __forceinline__ bf16x8 cat8(bf16x4 lo, bf16x4 hi) {
+  bf16x8 r;
+#pragma unroll
+  for (int e = 0; e < 4; ++e) { r[e] = lo[e]; r[4 + e] = hi[e]; }
+  return r;
+}
+__device__ __forceinline__ f32x4 tof(bf16x4 v) {
+  return f32x4{(float)v[0], (float)v[1], (float)v[2], (float)v[3]};
+}
+__device__ __forceinline__ bf16x4 zero4b() {
+  return bf16x4{(__bf16)0.f, (__bf16)0.f, (__bf16)0.f, (__bf16)0.f};
+}
+
+// =====================================================================================
+// k_rowgemm: Out^T[f][pt] = sum_k W[f][k] In^T[k][pt]  with the [D][D] bf16 weight image resident
+// in LDS (K-permuted rows: the B operand comes from accumulator-layout registers, pack8) and one
+// 32-point tile per wave.  Same unit / wave -> point mapping as k_mab1_fwd (the ReLU mask index).
+// =====================================================================================
+enum { RG_PROJ = 0, RG_BWD_O = 1, RG_BWD_Q = 2 };
+
+struct RowGemmArgs {
+  const __bf16* In;       // [B*N][D]: PROJ X ; BWD_O dY ; BWD_Q dQp (or dKp / dVp)
+  const __bf16* W;        // [D][D] image (see the launcher for which)
+  const float* bias;      // PROJ
+  const uint32_t* mask;   // BWD_O: ReLU mask bits of the forward
+  __bf16* Out;            // PROJ Y ; BWD_O dO ; BWD_Q dX
+  __bf16* Out2;           // BWD_O: dZ
+  int B, N, tiles_per_set, accumulate;
+};
+
+template <int D, int MODE>
+__global__ __launch_bounds__(512, 2) void k_rowgemm(const RowGemmArgs a) {
+  constexpr int NW = 8, NT = 64 * NW, SUBS = 2;
+  constexpr int DT = D / 16, KS = D / 32, ROWB = D * 2;
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  char* sW = smem;
+  const int tid = threadIdx.x, lane = tid & 63, wave8 = tid >> 6;
+  const int wave = wave8 & 3, sub = wave8 >> 2;
+  const int r = lane & 15, g = lane >> 4;
+  {
+    constexpr int NC = D * (D / 8) / NT;
+    uint4 wv[NC];
+#pragma unroll
+    for (int e = 0; e < NC; ++e) {
+      const int c = tid + NT * e, row = c / (D / 8), c16 = c % (D / 8);
+      wv[e] = *reinterpret_cast<const uint4*>(a.W + (int64_t)row * D + c16 * 8);
+    }
+#pragma unroll
+    for (int e = 0; e < NC; ++e) {
+      const int c = tid + NT * e, row = c / (D / 8), c16 = c % (D / 8);
+      *reinterpret_cast<uint4*>(sW + swz(row, c16, ROWB)) = wv[e];
+    }
+  }
+  __syncthreads();
+  const int units_per_set = (a.tiles_per_set + SUBS - 1) / SUBS;
+  const int total_units = a.B * units_per_set;
+  for (int unit = blockIdx.x; unit < total_units; unit += gridDim.x) {
+    const int b = unit / units_per_set, tile = (unit - b * units_per_set) * SUBS + sub;
+    if (tile >= a.tiles_per_set) continue;                 // (no barrier inside the loop)
+    const int n_base = tile * TP + wave * 32;
+    bool live[NB];
+    int64_t row[NB];
+#pragma unroll
+    for (int nb = 0; nb < NB; ++nb) {
+      const int n = n_base + 16 * nb + r;
+      live[nb] = n < a.N;
+      row[nb] = (int64_t)b * a.N + (live[nb] ? n : 0);
+    }
+    f32x4 acc[DT][NB];
+    bf16x8 bop[KS][NB];
+#pragma unroll
+    for (int nb = 0; nb < NB; ++nb) {
+      uint32_t bits[D / 128];
+      if (MODE == RG_BWD_O) {
+#pragma unroll
+        for (int w = 0; w < D / 128; ++w)
+          bits[w] = a.mask[mab1_mask_index<D>(b, a.tiles_per_set, tile, wave, nb, w, lane)];
+      }
+      bf16x4 in4[DT];
+#pragma unroll
+      for (int t = 0; t < DT; ++t)
+        in4[t] = live[nb] ? *reinterpret_cast<const bf16x4*>(a.In + row[nb] * D + 16 * t + 4 * g)
+                          : zero4b();
+#pragma unroll
+      for (int t = 0; t < DT; ++t) {
+        if (MODE == RG_BWD_O) {
+          const f32x4 v = tof(in4[t]);
+          acc[t][nb] = v;                                   // dO starts as dY (residual path)
+          bf16x4 z4;
+#pragma unroll
+          for (int e = 0; e < 4; ++e)
+            z4[e] = ((bits[t / 8] >> ((t & 7) * 4 + e)) & 1u) ? in4[t][e] : (__bf16)0.f;
+          in4[t] = z4;
+          if (live[nb])
+            *reinterpret_cast<bf16x4*>(a.Out2 + row[nb] * D + 16 * t + 4 * g) = z4;
+        } else if (MODE == RG_PROJ) {
+          const float4 b4 = *reinterpret_cast<const float4*>(a.bias + 16 * t + 4 * g);
+          acc[t][nb] = f32x4{b4.x, b4.y, b4.z, b4.w};
+        } else {
+          acc[t][nb] = f32x4{0.f, 0.f, 0.f, 0.f};
+        }
+      }
+#pragma unroll
+      for (int s = 0; s < KS; ++s) bop[s][nb] = cat8(in4[2 * s], in4[2 * s + 1]);
+    }
+#pragma unroll
+    for (int s = 0; s < KS; ++s) {
+#pragma unroll
+      for (int t = 0; t < DT; ++t) {
+        const bf16x8 wa = *reinterpret_cast<const bf16x8*>(sW + swz(16 * t + r, 4 * s + g, ROWB));
+#pragma unroll
+        for (int nb = 0; nb < NB; ++nb) acc[t][nb] = mfma32(wa, bop[s][nb], acc[t][nb]);
+      }
+    }
+#pragma unroll
+    for (int nb = 0; nb < NB; ++nb)
+      if (live[nb]) {
+#pragma unroll
+        for (int t = 0; t < DT; ++t) {
+          bf16x4* pd = reinterpret_cast<bf16x4*>(a.Out + row[nb] * D + 16 * t + 4 * g);
+          f32x4 v = acc[t][nb];
+          if (MODE == RG_BWD_Q && a.accumulate) {
+            const f32x4 o = tof(*pd);
+            v[0] += o[0]; v[1] += o[1]; v[2] += o[2]; v[3] += o[3];
+          }
+          *pd = pack4(v);
+        }
+      }
+  }
+}
+
+template <int MODE>
+int launch_rowgemm(const RowGemmArgs& a, hipStream_t st) {
+  constexpr int D = 256;
+  static std::once_flag once;
+  std::call_once(once, [] {
+    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(k_rowgemm<D, MODE>),
+                              hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+  });
+  const int total = a.B * ((a.tiles_per_set + 1) / 2);
+  const int grid = total < 256 ? total : 256;
+  hipLaunchKernelGGL((k_rowgemm<D, MODE>), dim3(grid), dim3(512), (size_t)D * D * 2, st, a);
+  return check_launch("k_rowgemm");
+}
+
+// =====================================================================================
+// k_attn1_bwd: attention adjoint of the many-queries block, WAVE = HEAD
+// =====================================================================================
+struct Attn1BwdArgs {
+  const __bf16* dO;         // [B*N][D]
+  const __bf16* QpS;        // [B*N][D] projected queries saved by the forward
+  const __bf16 *KpP, *VpP;  // [B][MI][D] (K-permuted features inside each head)
+  const __bf16* Kt;         // [B][D][MI] (keys in perm32 order)
+  __bf16* dQp;              // [B*N][D]
+  float *dKpPart, *dVpPart; // [B][nparts][MI][D]
+  int B, N, nparts, pts_per_part;
+  float scale, scale_log2e;
+};
+
+template <int D>
+__global__ __launch_bounds__(64 * (D / 32), 2) void k_attn1_bwd(const Attn1BwdArgs a) {
+  constexpr int MI = 32, NW = D / 32;
+  constexpr int PQ = 72;                 // row pitch of the per-wave images: 64 B + 8 (banks)
+  constexpr int IMG = 32 * PQ;
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  const int tid = threadIdx.x, lane = tid & 63, j = tid >> 6;      // j = head of this wave
+  const int r = lane & 15, g = lane >> 4;
+  const int b = blockIdx.x / a.nparts, part = blockIdx.x - b * a.nparts;
+  char* myDS = smem + j * 4 * IMG;
+  char* myP = myDS + IMG;
+  char* myQ = myP + IMG;
+  char* myO = myQ + IMG;
+  (void)NW;
+
+  // the head's slices of the set's K / V images: MFMA A operands, resident in registers
+  bf16x8 kpa[2], vpa[2], kta[2];
+#pragma unroll
+  for (int kt = 0; kt < 2; ++kt) {
+    const int64_t o = ((int64_t)b * MI + 16 * kt + r) * D + 32 * j + 8 * g;
+    kpa[kt] = *reinterpret_cast<const bf16x8*>(a.KpP + o);
+    vpa[kt] = *reinterpret_cast<const bf16x8*>(a.VpP + o);
+    kta[kt] = *reinterpret_cast<const bf16x8*>(a.Kt + ((int64_t)b * D + 32 * j + 16 * kt + r) * MI +
+                                               8 * g);
+  }
+  f32x4 dkp[2][2], dvp[2][2];             // [key tile][feature tile]
+#pragma unroll
+  for (int kt = 0; kt < 2; ++kt)
+#pragma unroll
+    for (int tt = 0; tt < 2; ++tt) {
+      dkp[kt][tt] = f32x4{0.f, 0.f, 0.f, 0.f};
+      dvp[kt][tt] = f32x4{0.f, 0.f, 0.f, 0.f};
+    }
+  const int n_lo = part * a.pts_per_part;
+  const int n_hi = n_lo + a.pts_per_part < a.N ? n_lo + a.pts_per_part : a.N;
+  for (int n0 = n_lo; n0 < n_hi; n0 += 32) {
+#pragma unroll
+    for (int nb = 0; nb < NB; ++nb) {
+      const int n = n0 + 16 * nb + r;
+      const bool live = n < n_hi;
+      const int64_t row = (int64_t)b * a.N + (live ? n : 0);
+      bf16x4 qlo = zero4b(), qhi = zero4b(), o0 = zero4b(), o1 = zero4b();
+      if (live) {
+        qlo = *reinterpret_cast<const bf16x4*>(a.QpS + row * D + 32 * j + 4 * g);
+        qhi = *reinterpret_cast<const bf16x4*>(a.QpS + row * D + 32 * j + 16 + 4 * g);
+        o0 = *reinterpret_cast<const bf16x4*>(a.dO + row * D + 32 * j + 4 * g);
+        o1 = *reinterpret_cast<const bf16x4*>(a.dO + row * D + 32 * j + 16 + 4 * g);
+      }
+      const bf16x8 qb = cat8(qlo, qhi), dob = cat8(o0, o1);
+      f32x4 dq0 = tof(o0), dq1 = tof(o1);                 // dQp starts as dO (residual Q_)
+      f32x4 p0 = {0.f, 0.f, 0.f, 0.f}, p1 = p0, da0 = p0, da1 = p0;
+      p0 = mfma32(kpa[0], qb, p0);
+      p1 = mfma32(kpa[1], qb, p1);
+      da0 = mfma32(vpa[0], dob, da0);
+      da1 = mfma32(vpa[1], dob, da1);
+      float mx = fmaxf(fmaxf(fmaxf(p0[0], p0[1]), fmaxf(p0[2], p0[3])),
+                       fmaxf(fmaxf(p1[0], p1[1]), fmaxf(p1[2], p1[3])));
+      mx = wave16_max(mx);
+      float sum = 0.f;
+#pragma unroll
+      for (int e = 0; e < 4; ++e) {
+        p0[e] = exp2f((p0[e] - mx) * a.scale_log2e);
+        p1[e] = exp2f((p1[e] - mx) * a.scale_log2e);
+        sum += p0[e] + p1[e];
+      }
+      sum = wave16_sum(sum);
+      const float inv = 1.0f / sum;
+      float delta = 0.f;
+#pragma unroll
+      for (int e = 0; e < 4; ++e) {
+        p0[e] *= inv;
+        p1[e] *= inv;
+        delta += p0[e] * da0[e] + p1[e] * da1[e];
+      }
+      delta = wave16_sum(delta);
+      f32x4 ds0, ds1;
+#pragma unroll
+      for (int e = 0; e < 4; ++e) {
+        ds0[e] = p0[e] * (da0[e] - delta) * a.scale;
+        ds1[e] = p1[e] * (da1[e] - delta) * a.scale;
+      }
+      // wave-private [point][.] images for the sums over points (padding points: zeros)
+      const int pt = 16 * nb + r;
+      const f32x4 zero4 = {0.f, 0.f, 0.f, 0.f};
+      *reinterpret_cast<bf16x4*>(myDS + pt * PQ + 8 * g) = pack4(live ? ds0 : zero4);
+      *reinterpret_cast<bf16x4*>(myDS + pt * PQ + 32 + 8 * g) = pack4(live ? ds1 : zero4);
+      *reinterpret_cast<bf16x4*>(myP + pt * PQ + 8 * g) = pack4(live ? p0 : zero4);
+      *reinterpret_cast<bf16x4*>(myP + pt * PQ + 32 + 8 * g) = pack4(live ? p1 : zero4);
+      *reinterpret_cast<bf16x4*>(myQ + pt * PQ + 8 * g) = qlo;
+      *reinterpret_cast<bf16x4*>(myQ + pt * PQ + 32 + 8 * g) = qhi;
+      *reinterpret_cast<bf16x4*>(myO + pt * PQ + 8 * g) = o0;
+      *reinterpret_cast<bf16x4*>(myO + pt * PQ + 32 + 8 * g) = o1;
+      // dQp_h^T += Kp_h^T . dS^T   (k = the 32 keys, perm32 order on both operands)
+      const bf16x8 dsb = pack8(ds0, ds1);
+      dq0 = mfma32(kta[0], dsb, dq0);
+      dq1 = mfma32(kta[1], dsb, dq1);
+      if (live) {
+        *reinterpret_cast<bf16x4*>(a.dQp + row * D + 32 * j + 4 * g) = pack4(dq0);
+        *reinterpret_cast<bf16x4*>(a.dQp + row * D + 32 * j + 16 + 4 * g) = pack4(dq1);
+      }
+    }
+    // dKp_h[key][f] += sum_pt dS[pt][key] Qp[pt][f] ; dVp_h[key][f] += sum_pt P[pt][key] dO[pt][f]
+    bf16x8 qf[2], of[2];
+#pragma unroll
+    for (int tt = 0; tt < 2; ++tt) {
+      qf[tt] = tr_frag_small(myQ, PQ, 16 * tt, lane);
+      of[tt] = tr_frag_small(myO, PQ, 16 * tt, lane);
+    }
+#pragma unroll
+    for (int kt = 0; kt < 2; ++kt) {
+      const bf16x8 ads = tr_frag_small(myDS, PQ, 16 * kt, lane);
+      const bf16x8 ap = tr_frag_small(myP, PQ, 16 * kt, lane);
+#pragma unroll
+      for (int tt = 0; tt < 2; ++tt) {
+        dkp[kt][tt] = mfma32(ads, qf[tt], dkp[kt][tt]);
+        dvp[kt][tt] = mfma32(ap, of[tt], dvp[kt][tt]);
+      }
+    }
+  }
+  const int64_t pbase = ((int64_t)b * a.nparts + part) * MI * D;
+#pragma unroll
+  for (int kt = 0; kt < 2; ++kt)
+#pragma unroll
+    for (int tt = 0; tt < 2; ++tt)
+#pragma unroll
+      for (int e = 0; e < 4; ++e) {
+        const int64_t o = pbase + (int64_t)(16 * kt + 4 * g + e) * D + 32 * j + 16 * tt + r;
+        a.dKpPart[o] = dkp[kt][tt][e];
+        a.dVpPart[o] = dvp[kt][tt][e];
+      }
+}
+
+// dk[b][i] = sum_p kp[b][p][i] (same for v): the per-range partials of k_attn1_bwd
+__global__ void k_sum_parts256(const float* __restrict__ kp, const float* __restrict__ vp,
+                               float* __restrict__ dk, float* __restrict__ dv, int B, int nparts,
+                               int n) {
+  const int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x;
+  if (i >= (int64_t)B * n) return;
+  const int64_t b = i / n, o = i - b * n;
+  float x = 0.f, y = 0.f;
+  for (int p = 0; p < nparts; ++p) {
+    x += kp[(b * nparts + p) * n + o];
+    y += vp[(b * nparts + p) * n + o];
+  }
+  dk[i] = x;
+  dv[i] = y;
+}
+
+// =====================================================================================
+// k_wgrad256: dW[D x D] = G[M x D]^T A[M x D] (+ db = column sums of G), bf16 operands
+// =====================================================================================
+// [32 rows][256] bf16 tile as two [32][128] halves, each in the transposed-read layout (b) of
+// cdna_hip_programming.md T10 (conflict-free ds_read_tr16_b64)
+__device__ __forceinline__ int tr_off256(int row, int ch) {
+  return (ch >> 4) * (32 * 256) + 256 * row +
+         16 * ((ch & 15) ^ (((row & 3) << 2) | ((row >> 2) & 3)));
+}
+__device__ __forceinline__ bf16x8 tr_frag256(const char* img, int t, int lane) {
+  const int g = lane >> 4, i16 = lane & 15, q = i16 >> 2, p = i16 & 3;
+  const int a0 = tr_off256(4 * g + q, 2 * t + (p >> 1)) + 8 * (p & 1);
+  const int a1 = tr_off256(16 + 4 * g + q, 2 * t + (p >> 1)) + 8 * (p & 1);
+  const s16x4 lo = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_s16x4*)(img + a0));
+  const s16x4 hi = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_s16x4*)(img + a1));
+  const bf16x4 l4 = __builtin_bit_cast(bf16x4, lo), h4 = __builtin_bit_cast(bf16x4, hi);
+  bf16x8 r;
+#pragma unroll
+  for (int e = 0; e < 4; ++e) { r[e] = l4[e]; r[4 + e] = h4[e]; }
+  return r;
+}
+
+// One workgroup = one row range of one job; 8 waves, wave w owns the [64 x 128] output block
+// (G features 64 (w >> 1) .., A features 128 (w & 1) ..): 4 + 8 transposed fragments feed 32 MFMAs
+// per 32-row tile.  The fp32 block leaves as a slab ([nwg][D][D]); k_wgrad256_sum adds the slabs
+// of a job into dW in a fixed order (no atomics: the result is reproducible run to run).
+__global__ __launch_bounds__(512, 2) void k_wgrad256(const Wgrad256Jobs jobs, int rows_per_wg,
+                                                    float* __restrict__ slabs,
+                                                    float* __restrict__ bslabs) {
+  constexpr int D = 256, NT = 512, TB = 32 * D * 2;      // bytes of one 32-row tile
+  __shared__ __attribute__((aligned(16))) char lds[4 * TB];     // 2 buffers x (G, A)
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int r = lane & 15, g = lane >> 4;
+  const Wgrad256Job job = jobs.j[blockIdx.y];
+  const __bf16* __restrict__ G = job.G;
+  const __bf16* __restrict__ A = job.A;
+  const int64_t r0 = (int64_t)blockIdx.x * rows_per_wg;
+  const int64_t r1 = r0 + rows_per_wg < job.M ? r0 + rows_per_wg : job.M;
+  const int gt0 = 4 * (wave >> 1), at0 = 8 * (wave & 1);
+  f32x4 acc[4][8];
+#pragma unroll
+  for (int i = 0; i < 4; ++i)
+#pragma unroll
+    for (int t = 0; t < 8; ++t) acc[i][t] = f32x4{0.f, 0.f, 0.f, 0.f};
+  float bs[8] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+  bf16x8 vg[2], va[2];
+  auto fetch = [&](int64_t base) {
+#pragma unroll
+    for (int e = 0; e < 2; ++e) {
+      const int c = tid + e * NT, row = c >> 5, ch = c & 31;
+      if (base + row < r1) {
+        vg[e] = *reinterpret_cast<const bf16x8*>(G + (base + row) * D + ch * 8);
+        va[e] = *reinterpret_cast<const bf16x8*>(A + (base + row) * D + ch * 8);
+      } else {
+#pragma unroll
+        for (int k = 0; k < 8; ++k) { vg[e][k] = (__bf16)0.f; va[e][k] = (__bf16)0.f; }
+      }
+    }
+  };
+  if (r0 < r1) fetch(r0);
+  int buf = 0;
+  for (int64_t base = r0; base < r1; base += 32, buf ^= 1) {
+    char* sG = lds + buf * 2 * TB;
+    char* sA = sG + TB;
+#pragma unroll
+    for (int e = 0; e < 2; ++e) {
+      const int c = tid + e * NT, row = c >> 5, ch = c & 31;
+      *reinterpret_cast<bf16x8*>(sG + tr_off256(row, ch)) = vg[e];
+      *reinterpret_cast<bf16x8*>(sA + tr_off256(row, ch)) = va[e];
+      if (job.db != nullptr) {
+#pragma unroll
+        for (int k = 0; k < 8; ++k) bs[k] += (float)vg[e][k];
+      }
+    }
+    __syncthreads();
+    if (base + 32 < r1) fetch(base + 32);
+    bf16x8 ga[4];
+#pragma unroll
+    for (int i = 0; i < 4; ++i) ga[i] = tr_frag256(sG, gt0 + i, lane);
+#pragma unroll
+    for (int t = 0; t < 8; ++t) {
+      const bf16x8 ab = tr_frag256(sA, at0 + t, lane);
+#pragma unroll
+      for (int i = 0; i < 4; ++i) acc[i][t] = mfma32(ga[i], ab, acc[i][t]);
+    }
+  }
+  float* slab = slabs + ((int64_t)blockIdx.y * gridDim.x + blockIdx.x) * D * D;
+#pragma unroll
+  for (int i = 0; i < 4; ++i)
+#pragma unroll
+    for (int e = 0; e < 4; ++e) {
+      const int grow = 16 * (gt0 + i) + 4 * g + e;
+#pragma unroll
+      for (int t = 0; t < 8; ++t) slab[grow * D + 16 * (at0 + t) + r] = acc[i][t][e];
+    }
+  if (job.db != nullptr) {
+    // threads with equal (tid & 31) hold partial sums of the same 8 columns
+    __syncthreads();
+    float* red = reinterpret_cast<float*>(lds);             // [16][256]
+#pragma unroll
+    for (int k = 0; k < 8; ++k) red[(tid >> 5) * D + (tid & 31) * 8 + k] = bs[k];
+    __syncthreads();
+    if (tid < D) {
+      float t = 0.f;
+#pragma unroll
+      for (int q = 0; q < 16; ++q) t += red[q * D + tid];
+      bslabs[((int64_t)blockIdx.y * gridDim.x + blockIdx.x) * D + tid] = t;
+    }
+  }
+}
+
+__global__ __launch_bounds__(256) void k_wgrad256_sum(const Wgrad256Jobs jobs, int nwg,
+                                                     int rows_per_wg,
+                                                     const float* __restrict__ slabs,
+                                                     const float* __restrict__ bslabs) {
+  constexpr int D = 256;
+  const Wgrad256Job job = jobs.j[blockIdx.y];
+  const int used = (int)((job.M + rows_per_wg - 1) / rows_per_wg);      // slabs with rows
+  const int i = blockIdx.x * 256 + threadIdx.x;
+  if (i < D * D) {
+    const float* s = slabs + (int64_t)blockIdx.y * nwg * D * D + i;
+    float t = 0.f;
+    int w = 0;
+    for (; w + 8 <= used; w += 8) {
+      float v[8];
+#pragma unroll
+      for (int u = 0; u < 8; ++u) v[u] = s[(int64_t)(w + u) * D * D];
+#pragma unroll
+      for (int u = 0; u < 8; ++u) t += v[u];
+    }
+    for (; w < used; ++w) t += s[(int64_t)w * D * D];
+    job.dW[i] += t;
+  } else if (i < D * D + D && job.db != nullptr) {
+    const int c = i - D * D;
+    const float* s = bslabs + (int64_t)blockIdx.y * nwg * D + c;
+    float t = 0.f;
+    for (int w = 0; w < used; ++w) t += s[(int64_t)w * D];
+    job.db[c] += t;
+  }
+}
+
+// =====================================================================================
+// few-queries attention (ISAB mab0 at dk = 256) over projected keys: wave = head, head dim 32
+// =====================================================================================
+struct FqArgs {
+  const __bf16 *Kp, *Vp;     // [B*N][D]
+  const float* Qp;           // [m][D] shared projected query (fp32)
+  // forward
+  float *Op, *Mp, *Lp;       // [B][S][m][D] unnormalised sum_n 2^(s-M) Vp ; [B][S][H][MQ] M, L
+  // backward
+  const float* dOa;          // [B][m][D] gradient w.r.t. A Vp (= dO)
+  const float* LSE;          // [B][H][MQ] log2-domain
+  const float* Delta;        // [B][H][MQ]
+  __bf16 *dKp, *dVp;         // [B*N][D]
+  float* dQpPart;            // [B][S][m][D]
+  int B, N, m, S;
+  float scale_log2e, scale;  // log2(e)/sqrt(d) ; 1/sqrt(d)
+  const int32_t* lengths;
+};
+
+// shared query of head j as MFMA operands: element (q, f) = Qp[q][32 j + f] * mul
+// as B operand [k = f][col = q] / as A operand [row = q][k = f]: the same registers
+__device__ __forceinline__ bf16x8 q_frag(const float* Qp, int D, int m, int q, int j, int g,
+                                         float mul) {
+  bf16x8 v;
+  if (q < m) {
+    const float4 lo = *reinterpret_cast<const float4*>(Qp + (int64_t)q * D + 32 * j + 8 * g);
+    const float4 hi = *reinterpret_cast<const float4*>(Qp + (int64_t)q * D + 32 * j + 8 * g + 4);
+    v[0] = (__bf16)(lo.x * mul); v[1] = (__bf16)(lo.y * mul); v[2] = (__bf16)(lo.z * mul);
+    v[3] = (__bf16)(lo.w * mul); v[4] = (__bf16)(hi.x * mul); v[5] = (__bf16)(hi.y * mul);
+    v[6] = (__bf16)(hi.z * mul); v[7] = (__bf16)(hi.w * mul);
+  } else {
+#pragma unroll
+    for (int e = 0; e < 8; ++e) v[e] = (__bf16)0.f;
+  }
+  return v;
+}
+
+// forward: S^T[pt][q] = Kp_h[pt][:] . (sl2e Qp_h[q][:]) on the MFMA with the points on the
+// accumulator rows (a query's statistics: in-lane + 2 cross-lane steps), online softmax,
+// O^T[f][q] += Vp_h^T[f][pt] P^T[pt][q] with the probability tile as B operand straight from the
+// accumulators and Vp^T through a wave-private LDS tile + ds_read_tr16_b64.
+template <int D, int QT>          // QT = query tiles of 16 (m <= 16 QT)
+__global__ __launch_bounds__(64 * (D / 32)) void k_fq_attn_fwd(const FqArgs a) {
+  constexpr int PV = 72, H = D / 32, MQ = 16 * QT;
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  const int tid = threadIdx.x, lane = tid & 63, j = tid >> 6;
+  const int r = lane & 15, g = lane >> 4;
+  const int b = blockIdx.x, sp = blockIdx.y;
+  char* myV = smem + j * 32 * PV;
+  const int per = (int)(((int64_t)(a.N + 31) / 32 + a.S - 1) / a.S) * 32;
+  int len = a.N;
+  if (a.lengths != nullptr) len = a.lengths[b] < a.N ? a.lengths[b] : a.N;
+  const int n_lo = sp * per, n_hi = (n_lo + per < len) ? n_lo + per : len;
+  bf16x8 qf[QT];
+#pragma unroll
+  for (int qt = 0; qt < QT; ++qt) qf[qt] = q_frag(a.Qp, D, a.m, 16 * qt + r, j, g, a.scale_log2e);
+  float mrow[QT], lrow[QT];
+  f32x4 ot[2][QT];
+#pragma unroll
+  for (int qt = 0; qt < QT; ++qt) {
+    mrow[qt] = -INFINITY;
+    lrow[qt] = 0.f;
+    ot[0][qt] = f32x4{0.f, 0.f, 0.f, 0.f};
+    ot[1][qt] = f32x4{0.f, 0.f, 0.f, 0.f};
+  }
+  for (int n0 = n_lo; n0 < n_hi; n0 += 32) {
+    bf16x8 kr[2];
+#pragma unroll
+    for (int pb = 0; pb < 2; ++pb) {
+      const int n = n0 + 16 * pb + r;
+      bf16x8 vr;
+      if (n < n_hi) {
+        const int64_t o = ((int64_t)b * a.N + n) * D + 32 * j + 8 * g;
+        kr[pb] = *reinterpret_cast<const bf16x8*>(a.Kp + o);
+        vr = *reinterpret_cast<const bf16x8*>(a.Vp + o);
+      } else {
+#pragma unroll
+        for (int e = 0; e < 8; ++e) { kr[pb][e] = (__bf16)0.f; vr[e] = (__bf16)0.f; }
+      }
+      {   // (two 8-byte stores: the padded 72-byte pitch is not 16-byte aligned)
+        bf16x4 lo4, hi4;
+#pragma unroll
+        for (int e = 0; e < 4; ++e) { lo4[e] = vr[e]; hi4[e] = vr[4 + e]; }
+        *reinterpret_cast<bf16x4*>(myV + (16 * pb + r) * PV + 16 * g) = lo4;
+        *reinterpret_cast<bf16x4*>(myV + (16 * pb + r) * PV + 16 * g + 8) = hi4;
+      }
+    }
+    bf16x8 vt[2];
+#pragma unroll
+    for (int tt = 0; tt < 2; ++tt) vt[tt] = tr_frag_small(myV, PV, 16 * tt, lane);
+#pragma unroll
+    for (int qt = 0; qt < QT; ++qt) {
+      f32x4 s[2];
+      float mt = -INFINITY;
+#pragma unroll
+      for (int pb = 0; pb < 2; ++pb) {
+        s[pb] = mfma32(kr[pb], qf[qt], f32x4{0.f, 0.f, 0.f, 0.f});
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+          if (n0 + 16 * pb + 4 * g + e >= n_hi) s[pb][e] = -INFINITY;
+          mt = fmaxf(mt, s[pb][e]);
+        }
+      }
+      mt = wave16_max(mt);
+      const float mnew = fmaxf(mrow[qt], mt);           // finite: the tile has >= 1 live point
+      const float alpha = exp2f(mrow[qt] - mnew);
+      float ls = 0.f;
+#pragma unroll
+      for (int pb = 0; pb < 2; ++pb)
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+          s[pb][e] = exp2f(s[pb][e] - mnew);
+          ls += s[pb][e];
+        }
+      ls = wave16_sum(ls);
+      lrow[qt] = lrow[qt] * alpha + ls;
+      mrow[qt] = mnew;
+      const bf16x8 pb8 = pack8(s[0], s[1]);
+#pragma unroll
+      for (int tt = 0; tt < 2; ++tt) {
+#pragma unroll
+        for (int e = 0; e < 4; ++e) ot[tt][qt][e] *= alpha;     // column q = this lane's query
+        ot[tt][qt] = mfma32(vt[tt], pb8, ot[tt][qt]);
+      }
+    }
+  }
+  // partial (O^T, M, L) of this range: rows f = 16 tt + 4 g + e, column q = 16 qt + r
+  const int64_t pb0 = ((int64_t)b * a.S + sp);
+#pragma unroll
+  for (int qt = 0; qt < QT; ++qt) {
+    const int q = 16 * qt + r;
+    if (q < a.m) {
+#pragma unroll
+      for (int tt = 0; tt < 2; ++tt)
+        *reinterpret_cast<float4*>(a.Op + (pb0 * a.m + q) * D + 32 * j + 16 * tt + 4 * g) =
+            float4{ot[tt][qt][0], ot[tt][qt][1], ot[tt][qt][2], ot[tt][qt][3]};
+      if (g == 0) {
+        a.Mp[(pb0 * H + j) * MQ + q] = mrow[qt];
+        a.Lp[(pb0 * H + j) * MQ + q] = lrow[qt];
+      }
+    }
+  }
+}
+
+// backward.  Orientation A (points on accumulator rows, as the forward): P^T, dS^T -> the set's
+// dQp_h^T[f][q] += Kp_h^T[f][pt] dS^T[pt][q] (Kp^T through the LDS tile).  Orientation B
+// (queries on accumulator rows: S = Qp_h Kp_h^T recomputed with one more MFMA - the per-lane
+// Kp row registers serve as A operand of one and B operand of the other) -> dVp^T[f][pt] =
+// dO_h^T[f][q] P[q][pt], dKp^T[f][pt] = Qp_h^T[f][q] dS[q][pt] with P / dS as B operands straight
+// from the accumulators; both leave as 8-byte bf16 stores.
+template <int D, int QT>
+__global__ __launch_bounds__(64 * (D / 32)) void k_fq_attn_bwd(const FqArgs a) {
+  constexpr int PV = 72, H = D / 32, MQ = 16 * QT;
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  const int tid = threadIdx.x, lane = tid & 63, j = tid >> 6;
+  const int r = lane & 15, g = lane >> 4;
+  const int b = blockIdx.x, sp = blockIdx.y;
+  char* myK = smem + j * 32 * PV;
+  const int per = (int)(((int64_t)(a.N + 31) / 32 + a.S - 1) / a.S) * 32;
+  int len = a.N;
+  if (a.lengths != nullptr) len = a.lengths[b] < a.N ? a.lengths[b] : a.N;
+  const int n_lo = sp * per;
+  const int n_hi = (n_lo + per < a.N) ? n_lo + per : a.N;          // rows written (zeros past len)
+  // operands of head j.  qs = sl2e Qp (scores in the log2 domain), qn = Qp (for dKp), do = dO
+  bf16x8 qs[QT], dof[QT];
+  // A operands [row = f][k = q] of the products that sum over the queries:
+  //   m > 16: 16x16x32, k-slot 8 g + i <-> query perm32(8 g + i) (pack8 order of the B operand)
+  //   m <= 16: 16x16x16, k-slot 4 g + e <-> query 4 g + e
+  bf16x8 qnT[2], doT[2];
+  bf16x4 qn4[2], do4[2];
+  float lse_c[QT], del_c[QT];             // per column q = 16 qt + r        (orientation A)
+  float lse_r[QT][4], del_r[QT][4];       // per row q = 16 qt + 4 g + e      (orientation B)
+#pragma unroll
+  for (int qt = 0; qt < QT; ++qt) {
+    const int q = 16 * qt + r;
+    qs[qt] = q_frag(a.Qp, D, a.m, q, j, g, a.scale_log2e);
+    dof[qt] = q_frag(a.dOa + (int64_t)b * a.m * D, D, a.m, q, j, g, 1.0f);
+    lse_c[qt] = q < a.m ? a.LSE[((int64_t)b * H + j) * MQ + q] : 1.0e30f;
+    del_c[qt] = q < a.m ? a.Delta[((int64_t)b * H + j) * MQ + q] : 0.f;
+#pragma unroll
+    for (int e = 0; e < 4; ++e) {
+      const int qq = 16 * qt + 4 * g + e;
+      lse_r[qt][e] = qq < a.m ? a.LSE[((int64_t)b * H + j) * MQ + qq] : 1.0e30f;
+      del_r[qt][e] = qq < a.m ? a.Delta[((int64_t)b * H + j) * MQ + qq] : 0.f;
+    }
+  }
+#pragma unroll
+  for (int tt = 0; tt < 2; ++tt) {
+    const int f = 32 * j + 16 * tt + r;
+#pragma unroll
+    for (int i = 0; i < 8; ++i) {
+      const int kq = perm32(8 * g + i);
+      const bool ok = QT == 2 && kq < a.m;
+      qnT[tt][i] = (__bf16)(ok ? a.Qp[(int64_t)kq * D + f] : 0.f);
+      doT[tt][i] = (__bf16)(ok ? a.dOa[((int64_t)b * a.m + kq) * D + f] : 0.f);
+    }
+#pragma unroll
+    for (int e = 0; e < 4; ++e) {
+      const int kq = 4 * g + e;
+      const bool ok = QT == 1 && kq < a.m;
+      qn4[tt][e] = (__bf16)(ok ? a.Qp[(int64_t)kq * D + f] : 0.f);
+      do4[tt][e] = (__bf16)(ok ? a.dOa[((int64_t)b * a.m + kq) * D + f] : 0.f);
+    }
+  }
+  f32x4 dq[2][QT];
+#pragma unroll
+  for (int tt = 0; tt < 2; ++tt)
+#pragma unroll
+    for (int qt = 0; qt < QT; ++qt) dq[tt][qt] = f32x4{0.f, 0.f, 0.f, 0.f};
+
+  for (int n0 = n_lo; n0 < n_hi; n0 += 32) {
+    bf16x8 kr[2], vr[2];
+    bool key_c[2];                        // orientation B: column = point 16 pb + r
+#pragma unroll
+    for (int pb = 0; pb < 2; ++pb) {
+      const int n = n0 + 16 * pb + r;
+      key_c[pb] = n < len;
+      if (n < n_hi) {
+        const int64_t o = ((int64_t)b * a.N + n) * D + 32 * j + 8 * g;
+        kr[pb] = *reinterpret_cast<const bf16x8*>(a.Kp + o);
+        vr[pb] = *reinterpret_cast<const bf16x8*>(a.Vp + o);
+      } else {
+#pragma unroll
+        for (int e = 0; e < 8; ++e) { kr[pb][e] = (__bf16)0.f; vr[pb][e] = (__bf16)0.f; }
+      }
+      {
+        bf16x4 lo4, hi4;
+#pragma unroll
+        for (int e = 0; e < 4; ++e) { lo4[e] = kr[pb][e]; hi4[e] = kr[pb][4 + e]; }
+        *reinterpret_cast<bf16x4*>(myK + (16 * pb + r) * PV + 16 * g) = lo4;
+        *reinterpret_cast<bf16x4*>(myK + (16 * pb + r) * PV + 16 * g + 8) = hi4;
+      }
+    }
+    bf16x8 kt[2];
+#pragma unroll
+    for (int tt = 0; tt < 2; ++tt) kt[tt] = tr_frag_small(myK, PV, 16 * tt, lane);
+    // ---- orientation A: dQp ----
+#pragma unroll
+    for (int qt = 0; qt < QT; ++qt) {
+      f32x4 ds[2];
+#pragma unroll
+      for (int pb = 0; pb < 2; ++pb) {
+        const f32x4 z = {0.f, 0.f, 0.f, 0.f};
+        const f32x4 sv = mfma32(kr[pb], qs[qt], z);
+        const f32x4 da = mfma32(vr[pb], dof[qt], z);
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+          const bool key = n0 + 16 * pb + 4 * g + e < len;
+          const float p = key ? exp2f(sv[e] - lse_c[qt]) : 0.f;
+          ds[pb][e] = p * (da[e] - del_c[qt]) * a.scale;
+        }
+      }
+      const bf16x8 dsb = pack8(ds[0], ds[1]);
+#pragma unroll
+      for (int tt = 0; tt < 2; ++tt) dq[tt][qt] = mfma32(kt[tt], dsb, dq[tt][qt]);
+    }
+    // ---- orientation B: dKp, dVp ----
+#pragma unroll
+    for (int pb = 0; pb < 2; ++pb) {
+      f32x4 pq[QT], dsq[QT];
+#pragma unroll
+      for (int qt = 0; qt < QT; ++qt) {
+        const f32x4 z = {0.f, 0.f, 0.f, 0.f};
+        const f32x4 sv = mfma32(qs[qt], kr[pb], z);          // rows q, column pt
+        const f32x4 da = mfma32(dof[qt], vr[pb], z);
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+          const float p = key_c[pb] ? exp2f(sv[e] - lse_r[qt][e]) : 0.f;
+          pq[qt][e] = p;
+          dsq[qt][e] = p * (da[e] - del_r[qt][e]) * a.scale;
+        }
+      }
+      const int n = n0 + 16 * pb + r;
+      if (n < n_hi) {
+        const int64_t o = ((int64_t)b * a.N + n) * D + 32 * j;
+#pragma unroll
+        for (int tt = 0; tt < 2; ++tt) {
+          f32x4 dv = {0.f, 0.f, 0.f, 0.f}, dk = {0.f, 0.f, 0.f, 0.f};
+          if (QT == 2) {
+            dv = mfma32(doT[tt], pack8(pq[0], pq[QT - 1]), dv);
+            dk = mfma32(qnT[tt], pack8(dsq[0], dsq[QT - 1]), dk);
+          } else {
+            dv = mfma16(do4[tt], pack4(pq[0]), dv);
+            dk = mfma16(qn4[tt], pack4(dsq[0]), dk);
+          }
+          *reinterpret_cast<bf16x4*>(a.dVp + o + 16 * tt + 4 * g) = pack4(dv);
+          *reinterpret_cast<bf16x4*>(a.dKp + o + 16 * tt + 4 * g) = pack4(dk);
+        }
+      }
+    }
+  }
+  const int64_t pb0 = ((int64_t)b * a.S + sp);
+#pragma unroll
+  for (int qt = 0; qt < QT; ++qt) {
+    const int q = 16 * qt + r;
+    if (q < a.m) {
+#pragma unroll
+      for (int tt = 0; tt < 2; ++tt)
+        *reinterpret_cast<float4*>(a.dQpPart + (pb0 * a.m + q) * D + 32 * j + 16 * tt + 4 * g) =
+            float4{dq[tt][qt][0], dq[tt][qt][1], dq[tt][qt][2], dq[tt][qt][3]};
+    }
+  }
+}
+
+// merge of the forward partials + residual: O[b][q][f] = Qp[q][f] + sum_s w_s Op_s / sum_s w_s L_s,
+// LSE[b][h][q] = M + log2 L; Oa (= A Vp, for Delta) is O - Qp
+__global__ __launch_bounds__(256) void k_fq_merge(const float* __restrict__ Op,
+                                                  const float* __restrict__ Mp,
+                                                  const float* __restrict__ Lp,
+                                                  const float* __restrict__ Qp, int B, int S,
+                                                  int m, int D, int MQ, float* __restrict__ O,
+                                                  float* __restrict__ LSE) {
+  const int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x;
+  if (i >= (int64_t)B * m * D) return;
+  const int f = (int)(i % D);
+  const int q = (int)((i / D) % m);
+  const int64_t b = i / ((int64_t)D * m);
+  const int H = D / 32, j = f / 32;
+  float M = -INFINITY;
+  for (int s = 0; s < S; ++s) M = fmaxf(M, Mp[((b * S + s) * H + j) * MQ + q]);
+  float L = 0.f, t = 0.f;
+  for (int s = 0; s < S; ++s) {
+    const float ms = Mp[((b * S + s) * H + j) * MQ + q];
+    if (ms == -INFINITY) continue;
+    const float w = exp2f(ms - M);
+    L += w * Lp[((b * S + s) * H + j) * MQ + q];
+    t += w * Op[((b * S + s) * m + q) * D + f];
+  }
+  O[i] = Qp[(int64_t)q * D + f] + t / L;
+  if ((f & 31) == 0) LSE[(b * H + j) * MQ + q] = M + log2f(L);
+}
+
+// Delta[b][h][q] = sum_{f in head} dO[b][q][f] (O[b][q][f] - Qp[q][f])
+__global__ __launch_bounds__(256) void k_fq_delta(const float* __restrict__ dO,
+                                                  const float* __restrict__ O,
+                                                  const float* __restrict__ Qp, int B, int m,
+                                                  int D, int MQ, float* __restrict__ Delta) {
+  const int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x;
+  const int H = D / 32;
+  if (i >= (int64_t)B * H * m) return;
+  const int q = (int)(i % m);
+  const int j = (int)((i / m) % H);
+  const int64_t b = i / ((int64_t)m * H);
+  float t = 0.f;
+  for (int f = 0; f < 32; ++f) {
+    const int64_t o = (b * m + q) * D + 32 * j + f;
+    t += dO[o] * (O[o] - Qp[(int64_t)q * D + 32 * j + f]);
+  }
+  Delta[(b * H + j) * MQ + q] = t;
+}
+
+// dOt[b][q][f] = dO[b][q][f] + sum_s dQpPart[b][s][q][f]   (gradient w.r.t. Qp of set b)
+__global__ __launch_bounds__(256) void k_fq_dq_sum(const float* __restrict__ dO,
+                                                   const float* __restrict__ part, int B, int S,
+                                                   int md, float* __restrict__ out) {
+  const int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x;
+  if (i >= (int64_t)B * md) return;
+  const int64_t b = i / md, o = i - b * md;
+  float t = dO[i];
+  for (int s = 0; s < S; ++s) t += part[(b * S + s) * md + o];
+  out[i] = t;
+}
+
+__global__ __launch_bounds__(256) void k_cvt_f32_bf16(const float* __restrict__ s,
+                                                      __bf16* __restrict__ d, int64_t n4) {
+  const int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x;
+  if (i >= n4) return;
+  const float4 v = reinterpret_cast<const float4*>(s)[i];
+  reinterpret_cast<bf16x4*>(d)[i] = bf16x4{(__bf16)v.x, (__bf16)v.y, (__bf16)v.z, (__bf16)v.w};
+}
+__global__ __launch_bounds__(256) void k_cvt_bf16_f32(const __bf16* __restrict__ s,
+                                                      float* __restrict__ d, int64_t n4,
+                                                      int accumulate) {
+  const int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x;
+  if (i >= n4) return;
+  const bf16x4 v = reinterpret_cast<const bf16x4*>(s)[i];
+  float4 o = float4{(float)v[0], (float)v[1], (float)v[2], (float)v[3]};
+  if (accumulate) {
+    const float4 p = reinterpret_cast<const float4*>(d)[i];
+    o.x += p.x; o.y += p.y; o.z += p.z; o.w += p.w;
+  }
+  reinterpret_cast<float4*>(d)[i] = o;
+}
+
+// Kp / Vp of a layer whose input has dk <= 4 columns (layer 1): exact fp32 FMAs, bf16 out
+__global__ __launch_bounds__(256) void k_kv_proj_small(const float* __restrict__ X, int64_t M,
+                                                       int dk, const float* __restrict__ Wk,
+                                                       const float* __restrict__ bk,
+                                                       const float* __restrict__ Wv,
+                                                       const float* __restrict__ bv, int D,
+                                                       __bf16* __restrict__ Kp,
+                                                       __bf16* __restrict__ Vp) {
+  const int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x;      // one thread: 4 features of a row
+  const int per = D / 4;
+  if (i >= M * per) return;
+  const int64_t row = i / per;
+  const int f0 = (int)(i - row * per) * 4;
+  float x[4] = {0.f, 0.f, 0.f, 0.f};
+  for (int c = 0; c < dk; ++c) x[c] = X[row * dk + c];
+  bf16x4 k4, v4;
+#pragma unroll
+  for (int e = 0; e < 4; ++e) {
+    float ak = bk[f0 + e], av = bv[f0 + e];
+    for (int c = 0; c < dk; ++c) {
+      ak = fmaf(x[c], Wk[(f0 + e) * dk + c], ak);
+      av = fmaf(x[c], Wv[(f0 + e) * dk + c], av);
+    }
+    k4[e] = (__bf16)ak;
+    v4[e] = (__bf16)av;
+  }
+  *reinterpret_cast<bf16x4*>(Kp + row * D + f0) = k4;
+  *reinterpret_cast<bf16x4*>(Vp + row * D + f0) = v4;
+}
+
+
+// dW[256 x dq] += G[M x 256]^T X[M x dq] (dq <= 4, fp32 X), db += colsum(G): layer-1 fc_q / fc_k /
+// fc_v.  One thread per feature, a row range per workgroup, one atomic per element per workgroup.
+__global__ __launch_bounds__(256) void k_wgrad_small256(const __bf16* __restrict__ G,
+                                                        const float* __restrict__ X, int64_t M,
+                                                        int dq, int rows_per_wg,
+                                                        float* __restrict__ dW,
+                                                        float* __restrict__ db) {
+  constexpr int D = 256;
+  const int f = threadIdx.x;
+  const int64_t r0 = (int64_t)blockIdx.x * rows_per_wg;
+  const int64_t r1 = r0 + rows_per_wg < M ? r0 + rows_per_wg : M;
+  float acc[4] = {0.f, 0.f, 0.f, 0.f}, bs = 0.f;
+  for (int64_t row = r0; row < r1; row += 8) {
+    float gv[8], xv[8][4];
+#pragma unroll
+    for (int u = 0; u < 8; ++u) {
+      const int64_t rr = row + u;
+      const bool ok = rr < r1;
+      gv[u] = ok ? (float)G[rr * D + f] : 0.f;
+#pragma unroll
+      for (int c = 0; c < 4; ++c) xv[u][c] = (ok && c < dq) ? X[rr * dq + c] : 0.f;
+    }
+#pragma unroll
+    for (int u = 0; u < 8; ++u) {
+      bs += gv[u];
+#pragma unroll
+      for (int c = 0; c < 4; ++c) acc[c] = fmaf(gv[u], xv[u][c], acc[c]);
+    }
+  }
+  for (int c = 0; c < dq; ++c) atomicAdd(&dW[f * dq + c], acc[c]);
+  if (db != nullptr) atomicAdd(&db[f], bs);
+}
+
+// ---- per-set epilogue pieces of the few-queries block whose keys have dk <= 4 columns --------
+// O[b][q][f] = Qp[q][f] + bv[f] + sum_c T[b][j m + q][c] Wv[f][c]      (j = head of f)
+__global__ __launch_bounds__(256) void k_epi_small_fwd(const float* __restrict__ T,
+                                                       const float* __restrict__ Qp,
+                                                       const float* __restrict__ Wv,
+                                                       const float* __restrict__ bv, int B, int m,
+                                                       int D, int dk, float* __restrict__ O) {
+  const int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x;
+  if (i >= (int64_t)B * m * D) return;
+  const int f = (int)(i % D), q = (int)((i / D) % m);
+  const int64_t b = i / ((int64_t)D * m);
+  const int j = f / 32, R = (D / 32) * m;
+  float acc = Qp[(int64_t)q * D + f] + bv[f];
+  for (int c = 0; c < dk; ++c) acc = fmaf(T[(b * R + j * m + q) * dk + c], Wv[f * dk + c], acc);
+  O[i] = acc;
+}
+// dT[b][r][c] = sum_{f in head j} dO[b][q][f] Wv[f][c] ; Delta[b][r] = sum_c dT T   (r = j m + q)
+__global__ __launch_bounds__(256) void k_epi_small_bwd(const float* __restrict__ dO,
+                                                       const float* __restrict__ T,
+                                                       const float* __restrict__ Wv, int B, int m,
+                                                       int D, int dk, float* __restrict__ dT,
+                                                       float* __restrict__ Delta) {
+  const int R = (D / 32) * m;
+  const int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x;
+  if (i >= (int64_t)B * R) return;
+  const int rr = (int)(i % R), j = rr / m, q = rr - j * m;
+  const int64_t b = i / R;
+  float acc[4] = {0.f, 0.f, 0.f, 0.f};
+  for (int f = 32 * j; f < 32 * j + 32; ++f) {
+    const float g = dO[(b * m + q) * D + f];
+    for (int c = 0; c < dk; ++c) acc[c] = fmaf(g, Wv[f * dk + c], acc[c]);
+  }
+  float del = 0.f;
+  for (int c = 0; c < dk; ++c) {
+    dT[i * dk + c] = acc[c];
+    del = fmaf(acc[c], T[i * dk + c], del);
+  }
+  Delta[i] = del;
+}
+// dWv[f][c] += sum_{b,q} dO[b][q][f] T[b][j(f) m + q][c] ; dbv[f] += sum_{b,q} dO[b][q][f]
+__global__ __launch_bounds__(256) void k_epi_small_wv(const float* __restrict__ dO,
+                                                      const float* __restrict__ T, int B, int m,
+                                                      int dk, int rows_per_wg,
+                                                      float* __restrict__ dWv,
+                                                      float* __restrict__ dbv) {
+  constexpr int D = 256;
+  const int f = threadIdx.x, j = f / 32, R = (D / 32) * m;
+  const int64_t M = (int64_t)B * m;
+  const int64_t r0 = (int64_t)blockIdx.x * rows_per_wg;
+  const int64_t r1 = r0 + rows_per_wg < M ? r0 + rows_per_wg : M;
+  float acc[4] = {0.f, 0.f, 0.f, 0.f}, bs = 0.f;
+  for (int64_t row = r0; row < r1; ++row) {
+    const int64_t b = row / m;
+    const int q = (int)(row - b * m);
+    const float g = dO[row * D + f];
+    bs += g;
+    for (int c = 0; c < dk; ++c) acc[c] = fmaf(g, T[(b * R + j * m + q) * dk + c], acc[c]);
+  }
+  for (int c = 0; c < dk; ++c) atomicAdd(&dWv[f * dk + c], acc[c]);
+  atomicAdd(&dbv[f], bs);
+}
+
+}  // namespace
+
+// ---- launchers (declared in d256_bf16.hpp) ------------------------------------------------
+int rowgemm256_proj(const __bf16* X, const __bf16* WP, const float* bias, __bf16* Y, int B, int N,
+                    hipStream_t st) {
+  RowGemmArgs a{X, WP, bias, nullptr, Y, nullptr, B, N, (int)cdiv(N, TP), 0};
+  return launch_rowgemm<RG_PROJ>(a, st);
+}
+int rowgemm256_bwd_o(const __bf16* dY, const uint32_t* mask, const __bf16* WoTP, __bf16* dZ,
+                     __bf16* dO, int B, int N, hipStream_t st) {
+  RowGemmArgs a{dY, WoTP, nullptr, mask, dO, dZ, B, N, (int)cdiv(N, TP), 0};
+  return launch_rowgemm<RG_BWD_O>(a, st);
+}
+int rowgemm256_dx(const __bf16* G, const __bf16* WTP, __bf16* dX, int B, int N, int accumulate,
+                  hipStream_t st) {
+  RowGemmArgs a{G, WTP, nullptr, nullptr, dX, nullptr, B, N, (int)cdiv(N, TP), accumulate};
+  return launch_rowgemm<RG_BWD_Q>(a, st);
+}
+
+int attn1_bwd256_parts(int B, int N) {
+  // point ranges per set so that B * parts workgroups (2 per CU) cover the chip
+  int parts = 1;
+  const int tiles = (int)cdiv(N, 32);
+  while (parts * 2 <= tiles && B * parts < 512) parts *= 2;
+  return parts;
+}
+int attn1_bwd256(const __bf16* dO, const __bf16* QpS, const __bf16* KpP, const __bf16* VpP,
+                 const __bf16* Kt, __bf16* dQp, float* dKpPart, float* dVpPart, float* dKp,
+                 float* dVp, int B, int N, hipStream_t st) {
+  constexpr int D = 256;
+  const int parts = attn1_bwd256_parts(B, N);
+  const int ppp = (int)cdiv(cdiv(N, 32), parts) * 32;
+  Attn1BwdArgs a{dO, QpS, KpP, VpP, Kt, dQp, dKpPart, dVpPart, B, N, parts, ppp,
+                 1.0f / sqrtf((float)D), 1.4426950408889634f / sqrtf((float)D)};
+  static std::once_flag once;
+  std::call_once(once, [] {
+    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(k_attn1_bwd<D>),
+                              hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+  });
+  hipLaunchKernelGGL((k_attn1_bwd<D>), dim3(B * parts), dim3(64 * (D / 32)),
+                     (size_t)(D / 32) * 4 * 32 * 72, st, a);
+  PCA_TRY(check_launch("k_attn1_bwd"));
+  hipLaunchKernelGGL(k_sum_parts256, dim3((unsigned)cdiv((int64_t)B * 32 * D, 256)), dim3(256), 0,
+                     st, dKpPart, dVpPart, dKp, dVp, B, parts, 32 * D);
+  return check_launch("k_sum_parts256");
+}
+
+// workgroups per job: enough to stream from every CU, few enough that the slab pass (256 KiB per
+// workgroup written + read) stays small against the 1 KiB per row the job reads
+int wgrad256_nwg(int64_t maxM) {
+  int nwg = (int)cdiv(maxM, 1024);
+  if (nwg > 256) nwg = 256;
+  return nwg < 1 ? 1 : nwg;
+}
+size_t wgrad256_ws_bytes(int njobs, int64_t maxM) {
+  const size_t nwg = (size_t)wgrad256_nwg(maxM);
+  return align256((size_t)njobs * nwg * 256 * 256 * sizeof(float)) +
+         align256((size_t)njobs * nwg * 256 * sizeof(float));
+}
+int wgrad256_launch(const Wgrad256Jobs& jobs, void* ws, hipStream_t st) {
+  if (jobs.n == 0) return PCA_OK;
+  int64_t maxM = 0;
+  for (int i = 0; i < jobs.n; ++i) maxM = jobs.j[i].M > maxM ? jobs.j[i].M : maxM;
+  if (maxM == 0) return PCA_OK;
+  const int nwg = wgrad256_nwg(maxM);
+  int rpw = (int)cdiv(cdiv(maxM, nwg), 32) * 32;
+  Carver c(ws);
+  float* slabs = c.take<float>((size_t)jobs.n * nwg * 256 * 256);
+  float* bslabs = c.take<float>((size_t)jobs.n * nwg * 256);
+  double rows = 0;
+  for (int i = 0; i < jobs.n; ++i) rows += (double)jobs.j[i].M;
+  ProfScope ps(PCA_K_WGRAD, st, 2.0 * rows * 256 * 256, 4.0 * rows * 256);
+  hipLaunchKernelGGL(k_wgrad256, dim3(nwg, jobs.n), dim3(512), 0, st, jobs, rpw, slabs, bslabs);
+  ps.end();
+  PCA_TRY(check_launch("k_wgrad256"));
+  hipLaunchKernelGGL(k_wgrad256_sum, dim3((256 * 256 + 256 + 255) / 256, jobs.n), dim3(256), 0, st,
+                     jobs, nwg, rpw, slabs, bslabs);
+  return check_launch("k_wgrad256_sum");
+}
+
+int cvt_f32_bf16(const float* s, __bf16* d, int64_t n, hipStream_t st) {
+  hipLaunchKernelGGL(k_cvt_f32_bf16, dim3((unsigned)cdiv(n / 4, 256)), dim3(256), 0, st, s, d,
+                     n / 4);
+  return check_launch("k_cvt_f32_bf16");
+}
+int cvt_bf16_f32(const __bf16* s, float* d, int64_t n, int accumulate, hipStream_t st) {
+  hipLaunchKernelGGL(k_cvt_bf16_f32, dim3((unsigned)cdiv(n / 4, 256)), dim3(256), 0, st, s, d,
+                     n / 4, accumulate);
+  return check_launch("k_cvt_bf16_f32");
+}
+int kv_proj_small256(const float* X, int64_t M, int dk, const float* Wk, const float* bk,
+                     const float* Wv, const float* bv, __bf16* Kp, __bf16* Vp, hipStream_t st) {
+  hipLaunchKernelGGL(k_kv_proj_small, dim3((unsigned)cdiv(M * 64, 256)), dim3(256), 0, st, X, M, dk,
+                     Wk, bk, Wv, bv, 256, Kp, Vp);
+  return check_launch("k_kv_proj_small");
+}
+
+int fq_splits256(int B, int N) {
+  int S = 1;
+  const int tiles = (int)cdiv(N, 32);
+  while (S * 2 <= tiles && B * S < 1024 && S < 16) S *= 2;
+  return S;
+}
+int fq_attn_fwd256(const __bf16* Kp, const __bf16* Vp, const float* Qp, int B, int N, int m,
+                   const int32_t* lengths, float* Op, float* Mp, float* Lp, float* O, float* LSE,
+                   hipStream_t st) {
+  constexpr int D = 256;
+  const int S = fq_splits256(B, N), QT = m > 16 ? 2 : 1, MQ = 16 * QT;
+  FqArgs a{};
+  a.Kp = Kp; a.Vp = Vp; a.Qp = Qp; a.Op = Op; a.Mp = Mp; a.Lp = Lp;
+  a.B = B; a.N = N; a.m = m; a.S = S; a.lengths = lengths;
+  a.scale = 1.0f / sqrtf((float)D);
+  a.scale_log2e = 1.4426950408889634f * a.scale;
+  const size_t lds = (size_t)(D / 32) * 32 * 72;
+  if (QT == 2) hipLaunchKernelGGL((k_fq_attn_fwd<D, 2>), dim3(B, S), dim3(512), lds, st, a);
+  else hipLaunchKernelGGL((k_fq_attn_fwd<D, 1>), dim3(B, S), dim3(512), lds, st, a);
+  PCA_TRY(check_launch("k_fq_attn_fwd"));
+  hipLaunchKernelGGL(k_fq_merge, dim3((unsigned)cdiv((int64_t)B * m * D, 256)), dim3(256), 0, st,
+                     Op, Mp, Lp, Qp, B, S, m, D, MQ, O, LSE);
+  return check_launch("k_fq_merge");
+}
+int fq_attn_bwd256(const __bf16* Kp, const __bf16* Vp, const float* Qp, const float* dO,
+                   const float* O, const float* LSE, float* Delta, int B, int N, int m,
+                   const int32_t* lengths, __bf16* dKp, __bf16* dVp, float* dQpPart, float* dOt,
+                   hipStream_t st) {
+  constexpr int D = 256;
+  const int S = fq_splits256(B, N), QT = m > 16 ? 2 : 1, MQ = 16 * QT;
+  hipLaunchKernelGGL(k_fq_delta, dim3((unsigned)cdiv((int64_t)B * (D / 32) * m, 256)), dim3(256), 0,
+                     st, dO, O, Qp, B, m, D, MQ, Delta);
+  PCA_TRY(check_launch("k_fq_delta"));
+  FqArgs a{};
+  a.Kp = Kp; a.Vp = Vp; a.Qp = Qp; a.dOa = dO; a.LSE = LSE; a.Delta = Delta;
+  a.dKp = dKp; a.dVp = dVp; a.dQpPart = dQpPart;
+  a.B = B; a.N = N; a.m = m; a.S = S; a.lengths = lengths;
+  a.scale = 1.0f / sqrtf((float)D);
+  a.scale_log2e = 1.4426950408889634f * a.scale;
+  const size_t lds = (size_t)(D / 32) * 32 * 72;
+  if (QT == 2) hipLaunchKernelGGL((k_fq_attn_bwd<D, 2>), dim3(B, S), dim3(512), lds, st, a);
+  else hipLaunchKernelGGL((k_fq_attn_bwd<D, 1>), dim3(B, S), dim3(512), lds, st, a);
+  PCA_TRY(check_launch("k_fq_attn_bwd"));
+  hipLaunchKernelGGL(k_fq_dq_sum, dim3((unsigned)cdiv((int64_t)B * m * D, 256)), dim3(256), 0, st,
+                     dO, dQpPart, B, S, m * D, dOt);
+  return check_launch("k_fq_dq_sum");
+}
+
+int wgrad_small256(const __bf16* G, const float* X, int64_t M, int dq, float* dW, float* db,
+                   hipStream_t st) {
+  const int rpw = M >= 65536 ? 2048 : 256;
+  hipLaunchKernelGGL(k_wgrad_small256, dim3((unsigned)cdiv(M, rpw)), dim3(256), 0, st, G, X, M, dq,
+                     rpw, dW, db);
+  return check_launch("k_wgrad_small256");
+}
+int epi_small_fwd256(const float* T, const float* Qp, const float* Wv, const float* bv, int B, int m,
+                     int dk, float* O, hipStream_t st) {
+  hipLaunchKernelGGL(k_epi_small_fwd, dim3((unsigned)cdiv((int64_t)B * m * 256, 256)), dim3(256), 0,
+                     st, T, Qp, Wv, bv, B, m, 256, dk, O);
+  return check_launch("k_epi_small_fwd");
+}
+int epi_small_bwd256(const float* dO, const float* T, const float* Wv, int B, int m, int dk,
+                     float* dT, float* Delta, float* dWv, float* dbv, hipStream_t st) {
+  hipLaunchKernelGGL(k_epi_small_bwd, dim3((unsigned)cdiv((int64_t)B * 8 * m, 256)), dim3(256), 0,
+                     st, dO, T, Wv, B, m, 256, dk, dT, Delta);
+  PCA_TRY(check_launch("k_epi_small_bwd"));
+  hipLaunchKernelGGL(k_epi_small_wv, dim3((unsigned)cdiv((int64_t)B * m, 128)), dim3(256), 0, st, dO,
+                     T, B, m, dk, 128, dWv, dbv);
+  return check_launch("k_epi_small_wv");
+}
+
+}  // namespace pca

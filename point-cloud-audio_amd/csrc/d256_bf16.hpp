@@ -1,0 +1,64 @@
+// Launchers of the d = 256 training kernels (d256_bf16.hip); all activations bf16 [rows][256].
+#pragma once
+#include "mab1_bf16.hpp"
+
+namespace pca {
+
+// Y = X WP^T + bias   (WP: [256][256] K-permuted image of the nn.Linear weight, prep mode 1)
+int rowgemm256_proj(const __bf16* X, const __bf16* WP, const float* bias, __bf16* Y, int B, int N,
+                    hipStream_t st);
+// dZ = dY . [Z > 0] (mask bits of k_mab1_fwd) ; dO = dY + dZ Wo   (WoTP: prep mode 2 of Wo)
+int rowgemm256_bwd_o(const __bf16* dY, const uint32_t* mask, const __bf16* WoTP, __bf16* dZ,
+                     __bf16* dO, int B, int N, hipStream_t st);
+// dX (+)= G W   (WTP: prep mode 2 of W)
+int rowgemm256_dx(const __bf16* G, const __bf16* WTP, __bf16* dX, int B, int N, int accumulate,
+                  hipStream_t st);
+// attention adjoint of the many-queries block (m = 32 keys): dQp, and the set's dKp / dVp (fp32,
+// [B][32][256]; the per-range partials are summed into dKp / dVp)
+int attn1_bwd256_parts(int B, int N);
+int attn1_bwd256(const __bf16* dO, const __bf16* QpS, const __bf16* KpP, const __bf16* VpP,
+                 const __bf16* Kt, __bf16* dQp, float* dKpPart, float* dVpPart, float* dKp,
+                 float* dVp, int B, int N, hipStream_t st);
+
+// dW[256 x 256] += G^T A, db[256] += colsum(G) (nullable); G, A bf16 [M][256]
+struct Wgrad256Job {
+  const __bf16* G;
+  const __bf16* A;
+  float* dW;
+  float* db;
+  int64_t M;
+};
+struct Wgrad256Jobs {
+  Wgrad256Job j[8];
+  int n;
+};
+size_t wgrad256_ws_bytes(int njobs, int64_t maxM);
+int wgrad256_launch(const Wgrad256Jobs& jobs, void* ws, hipStream_t st);
+
+int cvt_f32_bf16(const float* s, __bf16* d, int64_t n, hipStream_t st);            // n % 4 == 0
+int cvt_bf16_f32(const __bf16* s, float* d, int64_t n, int accumulate, hipStream_t st);
+int kv_proj_small256(const float* X, int64_t M, int dk, const float* Wk, const float* bk,
+                     const float* Wv, const float* bv, __bf16* Kp, __bf16* Vp, hipStream_t st);
+
+// layer 1 (inputs of dq <= 4 columns)
+int wgrad_small256(const __bf16* G, const float* X, int64_t M, int dq, float* dW, float* db,
+                   hipStream_t st);
+int epi_small_fwd256(const float* T, const float* Qp, const float* Wv, const float* bv, int B, int m,
+                     int dk, float* O, hipStream_t st);
+int epi_small_bwd256(const float* dO, const float* T, const float* Wv, int B, int m, int dk,
+                     float* dT, float* Delta, float* dWv, float* dbv, hipStream_t st);
+
+// few shared queries (m <= 32) over projected keys, head dim 32
+int fq_splits256(int B, int N);
+// Op [B][S][m][256], Mp / Lp [B][S][8][MQ] scratch; O = Qp + A Vp [B][m][256]; LSE [B][8][MQ]
+int fq_attn_fwd256(const __bf16* Kp, const __bf16* Vp, const float* Qp, int B, int N, int m,
+                   const int32_t* lengths, float* Op, float* Mp, float* Lp, float* O, float* LSE,
+                   hipStream_t st);
+// dO [B][m][256] = gradient w.r.t. O; writes dKp, dVp (bf16 [B*N][256]) and
+// dOt = dO + (attention gradient w.r.t. Qp) per set [B][m][256]
+int fq_attn_bwd256(const __bf16* Kp, const __bf16* Vp, const float* Qp, const float* dO,
+                   const float* O, const float* LSE, float* Delta, int B, int N, int m,
+                   const int32_t* lengths, __bf16* dKp, __bf16* dVp, float* dQpPart, float* dOt,
+                   hipStream_t st);
+
+}  // namespace pca

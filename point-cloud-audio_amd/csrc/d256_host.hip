@@ -1,0 +1,316 @@
+// Host orchestration of the d = 256 / 8-head training blocks (kernels: d256_bf16.hip).
+//   mab1_d256_bwd     adjoint of ISAB's mab1(X, H) (modules.py:53 / 19-33): three row-GEMM /
+//                     attention launches + the 256-wide weight-gradient reduction
+//   mab0_d256_*       the few-shared-queries block (ISAB mab0, PMA; modules.py:52,63):
+//                       dk = 256 : keys projected (reference formulation), flash attention per head
+//                       dk <= 4  : reassociated layer-1 kernels (k_mab0_attn_small / _bwd_small)
+//                     with the per-set [B*m]-row epilogues on the GEMM kernel.
+// Activations cross the ABI in fp32 or bf16 (shape.*_dtype); inside, every [B*N, 256] tensor is
+// bf16 - fp32 callers pay one conversion pass per tensor.
+#include "d256_bf16.hpp"
+
+#include <math.h>
+
+namespace pca {
+
+namespace {
+constexpr int D = 256, H8 = 8;
+
+inline size_t nelem(const pca_mab_shape& s, bool keys) {
+  return (size_t)s.B * (keys ? s.nk : s.nq) * D;
+}
+}  // namespace
+
+// =====================================================================================
+// many-queries block, backward
+// =====================================================================================
+struct Mab1D256Ws {
+  __bf16 *WoTP, *WqTP;
+  __bf16 *dZ, *dO, *dQp;        // [B*N][D]
+  __bf16 *dYb, *Xb, *dXb;       // conversions of fp32 tensors at the ABI (null when bf16)
+  float *dKp, *dVp, *dKpPart, *dVpPart;
+  void* wg;
+};
+static size_t mab1_d256_carve(const pca_mab_shape& s, Mab1D256Ws* out, void* base) {
+  Carver c(base);
+  Mab1D256Ws w{};
+  const size_t M = (size_t)s.B * s.nq;
+  const bool abf = s.y_dtype == PCA_BF16;
+  w.WoTP = c.take<__bf16>((size_t)D * D);
+  w.WqTP = c.take<__bf16>((size_t)D * D);
+  w.dZ = c.take<__bf16>(M * D);
+  w.dO = c.take<__bf16>(M * D);
+  w.dQp = c.take<__bf16>(M * D);
+  if (!abf) {
+    w.dYb = c.take<__bf16>(M * D);
+    w.dXb = c.take<__bf16>(M * D);
+    if (s.dq == D) w.Xb = c.take<__bf16>(M * D);
+  }
+  const size_t parts = (size_t)attn1_bwd256_parts(s.B, s.nq);
+  w.dKp = c.take<float>((size_t)s.B * s.nk * D);
+  w.dVp = c.take<float>((size_t)s.B * s.nk * D);
+  w.dKpPart = c.take<float>((size_t)s.B * parts * s.nk * D);
+  w.dVpPart = c.take<float>((size_t)s.B * parts * s.nk * D);
+  w.wg = c.take<char>(wgrad256_ws_bytes(2, (int64_t)M));
+  if (out) *out = w;
+  return c.off;
+}
+size_t mab1_d256_bwd_ws_bytes(const pca_mab_shape& s) { return mab1_d256_carve(s, nullptr, nullptr); }
+
+int mab1_d256_bwd(const pca_mab_shape& s, const void* X, const float* Hk, const pca_mab_params& p,
+                  const void* saved, const void* dY, void* dX, float* dH, int dk_accumulate,
+                  const pca_mab_grads& gr, void* ws, hipStream_t st) {
+  PCA_REQUIRE(s.d == D && s.nk == 32 && s.h == H8, "mab1_d256_bwd: shape");
+  Mab1Saved v;
+  mab1_carve_saved(s, &v, const_cast<void*>(saved));
+  Mab1D256Ws w;
+  mab1_d256_carve(s, &w, ws);
+  const int64_t M = (int64_t)s.B * s.nq;
+  const bool small = s.dq <= 4, abf = s.y_dtype == PCA_BF16;
+  const bool want_dx = dX != nullptr;
+  if (want_dx && small) {
+    set_error("mab1_bf16_bwd: dQ for dq <= 4 is not built");
+    return PCA_EUNSUPPORTED;
+  }
+  PCA_TRY(prep_weight(p.wo, w.WoTP, D, D, 2, st));
+  if (want_dx) PCA_TRY(prep_weight(p.wq, w.WqTP, D, D, 2, st));
+  const __bf16* dYb = reinterpret_cast<const __bf16*>(dY);
+  const __bf16* Xb = small ? nullptr : reinterpret_cast<const __bf16*>(X);
+  if (!abf) {
+    PCA_TRY(cvt_f32_bf16(reinterpret_cast<const float*>(dY), w.dYb, M * D, st));
+    dYb = w.dYb;
+    if (!small) {
+      PCA_TRY(cvt_f32_bf16(reinterpret_cast<const float*>(X), w.Xb, M * D, st));
+      Xb = w.Xb;
+    }
+  }
+  // reference-formulation FLOPs / algorithmic bytes of the whole block's backward
+  const double flops = 4.0 * M * ((double)s.dq * D + (double)D * D + 2.0 * s.nk * D);
+  const double bytes = (double)M * (2.0 * D + (small ? 4.0 * s.dq : 2.0 * D) +
+                                    (want_dx ? 2.0 * D : 0.0));
+  ProfScope ps(PCA_K_MAB1_BWD, st, flops, bytes);
+  PCA_TRY(rowgemm256_bwd_o(dYb, v.mask, w.WoTP, w.dZ, w.dO, s.B, s.nq, st));
+  PCA_TRY(attn1_bwd256(w.dO, v.QpS, v.KpP, v.VpP, v.Kt, w.dQp, w.dKpPart, w.dVpPart, w.dKp, w.dVp,
+                       s.B, s.nq, st));
+  if (want_dx) {
+    __bf16* dXb = abf ? reinterpret_cast<__bf16*>(dX) : w.dXb;
+    PCA_TRY(rowgemm256_dx(w.dQp, w.WqTP, dXb, s.B, s.nq, 0, st));
+    if (!abf) PCA_TRY(cvt_bf16_f32(dXb, reinterpret_cast<float*>(dX), M * D, 0, st));
+  }
+  ps.end();
+  // weight gradients over the B*N rows
+  Wgrad256Jobs jobs{};
+  jobs.j[jobs.n++] = Wgrad256Job{w.dZ, v.OS, gr.wo, gr.bo, M};
+  if (!small) jobs.j[jobs.n++] = Wgrad256Job{w.dQp, Xb, gr.wq, gr.bq, M};
+  PCA_TRY(wgrad256_launch(jobs, w.wg, st));
+  if (small)
+    PCA_TRY(wgrad_small256(w.dQp, reinterpret_cast<const float*>(X), M, s.dq, gr.wq, gr.bq, st));
+  // fc_k / fc_v of the m inducing-point outputs ([B*m] rows) and dH
+  const int64_t Mk = (int64_t)s.B * s.nk;
+  PCA_TRY(linear_bwd_f32(Hk, p.wk, w.dKp, nullptr, gr.wk, gr.bk, Mk, D, D, st));
+  PCA_TRY(linear_bwd_f32(Hk, p.wv, w.dVp, nullptr, gr.wv, gr.bv, Mk, D, D, st));
+  if (dH != nullptr) {
+    PCA_TRY(linear_dx_acc_f32(w.dKp, p.wk, dH, Mk, D, D, dk_accumulate ? 1 : 0, st));
+    PCA_TRY(linear_dx_acc_f32(w.dVp, p.wv, dH, Mk, D, D, 1, st));
+  }
+  return PCA_OK;
+}
+
+// =====================================================================================
+// few-queries block
+// =====================================================================================
+bool mab0_d256_supported(const pca_mab_shape& s) {
+  const int R = s.h * s.nq;
+  const bool dt_ok = s.q_dtype == PCA_F32 && s.y_dtype == PCA_F32 &&
+                     (s.k_dtype == PCA_F32 || (s.k_dtype == PCA_BF16 && s.dk == D));
+  if (!(s.q_shared == 1 && s.d == D && s.h == H8 && s.dq == D && dt_ok)) return false;
+  if (s.dk == D) return s.nq >= 1 && s.nq <= 32;
+  return s.dk <= 4 && (R == 64 || R == 128 || R == 256);
+}
+
+struct Fq256Saved {
+  float *Qp, *O, *Z, *LSE;      // [m][D], [B][m][D] x2, [B][8][MQ] (dk <= 4: [B][R])
+  __bf16 *Kp, *Vp, *Xb;         // dk = 256: [B*N][D]; Xb only when the keys arrive in fp32
+  float *Gf, *T;                // dk <= 4: [R][dk], [B][R][dk]
+  float *Op, *Mp, *Lp;          // forward partials per point range
+};
+static size_t fq_carve_saved(const pca_mab_shape& s, Fq256Saved* out, void* base) {
+  Carver c(base);
+  Fq256Saved v{};
+  const int m = s.nq, R = s.h * m;
+  const size_t Bm = (size_t)s.B * m;
+  v.Qp = c.take<float>((size_t)m * D);
+  v.O = c.take<float>(Bm * D);
+  v.Z = c.take<float>(Bm * D);
+  if (s.dk == D) {
+    const int MQ = m > 16 ? 32 : 16, S = fq_splits256(s.B, s.nk);
+    v.LSE = c.take<float>((size_t)s.B * H8 * MQ);
+    v.Kp = c.take<__bf16>(nelem(s, true));
+    v.Vp = c.take<__bf16>(nelem(s, true));
+    if (s.k_dtype == PCA_F32) v.Xb = c.take<__bf16>(nelem(s, true));
+    v.Op = c.take<float>((size_t)s.B * S * m * D);
+    v.Mp = c.take<float>((size_t)s.B * S * H8 * MQ);
+    v.Lp = c.take<float>((size_t)s.B * S * H8 * MQ);
+  } else {
+    v.LSE = c.take<float>((size_t)s.B * R);
+    v.Gf = c.take<float>((size_t)R * s.dk);
+    v.T = c.take<float>((size_t)s.B * R * s.dk);
+  }
+  if (out) *out = v;
+  return c.off;
+}
+size_t mab0_d256_saved_bytes(const pca_mab_shape& s) { return fq_carve_saved(s, nullptr, nullptr); }
+size_t mab0_d256_fwd_ws_bytes(const pca_mab_shape& s) {
+  // two weight images + (inference) what the saved block would hold
+  return 2 * align256((size_t)D * D * 2) + fq_carve_saved(s, nullptr, nullptr);
+}
+
+int mab0_d256_fwd(const pca_mab_shape& s, const float* I, const void* X, const pca_mab_params& p,
+                  float* Hout, void* saved, void* ws, hipStream_t st) {
+  PCA_REQUIRE(mab0_d256_supported(s), "mab0_d256_fwd: unsupported shape");
+  PCA_REQUIRE(ws != nullptr, "mab0_d256_fwd: scratch required");
+  Carver cw(ws);
+  __bf16* WkP = cw.take<__bf16>((size_t)D * D);
+  __bf16* WvP = cw.take<__bf16>((size_t)D * D);
+  Fq256Saved v;
+  fq_carve_saved(s, &v, saved != nullptr ? saved : (void*)(cw.base + cw.off));
+  const int m = s.nq;
+  const int64_t Bm = (int64_t)s.B * m, M = (int64_t)s.B * s.nk;
+  {   // Qp = I Wq^T + bq (and, layer 1, G = sl2e Qp_h Wk_h): batch invariant
+    Mab0PrepJobs J{};
+    Mab0PrepJob a{};
+    a.I = I; a.Wq = p.wq; a.bq = p.bq; a.Wk = p.wk;
+    a.m = m; a.d = D; a.dq = s.dq; a.dk = s.dk; a.h = s.h; a.Rp = (int)cdiv(s.h * m, 32) * 32;
+    a.sl2e = 1.4426950408889634f / sqrtf((float)D);
+    a.Qp = v.Qp; a.Gf = s.dk == D ? nullptr : v.Gf;
+    J.j[J.n++] = a;
+    PCA_TRY(mab0_prep_launch(J, st));
+  }
+  if (s.dk == D) {
+    const __bf16* Xb = reinterpret_cast<const __bf16*>(X);
+    if (s.k_dtype == PCA_F32) {
+      PCA_TRY(cvt_f32_bf16(reinterpret_cast<const float*>(X), v.Xb, M * D, st));
+      Xb = v.Xb;
+    }
+    PCA_TRY(prep_weight(p.wk, WkP, D, D, 1, st));
+    PCA_TRY(prep_weight(p.wv, WvP, D, D, 1, st));
+    PCA_TRY(rowgemm256_proj(Xb, WkP, p.bk, v.Kp, s.B, s.nk, st));            // modules.py:21
+    PCA_TRY(rowgemm256_proj(Xb, WvP, p.bv, v.Vp, s.B, s.nk, st));
+    const double pts = (double)M;
+    ProfScope ps(PCA_K_MAB0_FWD, st, 2.0 * pts * 2.0 * m * D, pts * 4.0 * D);
+    PCA_TRY(fq_attn_fwd256(v.Kp, v.Vp, v.Qp, s.B, s.nk, m, s.k_lengths, v.Op, v.Mp, v.Lp, v.O,
+                           v.LSE, st));                                      // :28-29
+    ps.end();
+  } else {
+    PCA_TRY(mab0_attn_small_launch(reinterpret_cast<const float*>(X), v.Gf, s.B, s.nk, s.h * m,
+                                   s.dk, v.T, v.LSE, s.k_lengths, st));
+    PCA_TRY(epi_small_fwd256(v.T, v.Qp, p.wv, p.bv, s.B, m, s.dk, v.O, st));
+  }
+  PCA_TRY(linear_fwd_f32(v.O, p.wo, p.bo, v.Z, Bm, D, D, st));              // :31
+  return add_relu(v.O, v.Z, Hout, Bm * D, st);
+}
+
+struct Fq256BwdWs {
+  __bf16 *WkTP, *WvTP, *dKp, *dVp, *dXb;
+  float *dZ, *dO, *dOt, *Delta, *dQpPart, *dTf, *DG, *dQp;
+  void* wg;
+};
+static size_t fq_carve_bwd(const pca_mab_shape& s, Fq256BwdWs* out, void* base) {
+  Carver c(base);
+  Fq256BwdWs w{};
+  const int m = s.nq, R = s.h * m;
+  const size_t Bm = (size_t)s.B * m;
+  w.dZ = c.take<float>(Bm * D);
+  w.dO = c.take<float>(Bm * D);
+  w.dOt = c.take<float>(Bm * D);
+  w.dQp = c.take<float>((size_t)m * D);
+  if (s.dk == D) {
+    const int MQ = m > 16 ? 32 : 16, S = fq_splits256(s.B, s.nk);
+    w.WkTP = c.take<__bf16>((size_t)D * D);
+    w.WvTP = c.take<__bf16>((size_t)D * D);
+    w.dKp = c.take<__bf16>(nelem(s, true));
+    w.dVp = c.take<__bf16>(nelem(s, true));
+    if (s.k_dtype == PCA_F32) w.dXb = c.take<__bf16>(nelem(s, true));
+    w.Delta = c.take<float>((size_t)s.B * H8 * MQ);
+    w.dQpPart = c.take<float>((size_t)s.B * S * m * D);
+    w.wg = c.take<char>(wgrad256_ws_bytes(2, (int64_t)s.B * s.nk));
+  } else {
+    w.Delta = c.take<float>((size_t)s.B * R);
+    w.dTf = c.take<float>((size_t)s.B * R * s.dk);
+    w.DG = c.take<float>((size_t)R * s.dk);
+  }
+  if (out) *out = w;
+  return c.off;
+}
+size_t mab0_d256_bwd_ws_bytes(const pca_mab_shape& s) { return fq_carve_bwd(s, nullptr, nullptr); }
+
+// dQ -> dI [m, dq] (ACCUMULATED, may be null), dK -> dX [B, N, dk] (written or accumulated)
+int mab0_d256_bwd(const pca_mab_shape& s, const float* I, const void* X, const pca_mab_params& p,
+                  const void* saved, const float* dH, float* dI, void* dX, int dk_accumulate,
+                  const pca_mab_grads& gr, void* ws, hipStream_t st, BwdDefer* defer) {
+  Fq256Saved v;
+  fq_carve_saved(s, &v, const_cast<void*>(saved));
+  Fq256BwdWs w;
+  fq_carve_bwd(s, &w, ws);
+  const int m = s.nq, R = s.h * m;
+  const int64_t Bm = (int64_t)s.B * m, M = (int64_t)s.B * s.nk;
+  if (s.dk != D && dX != nullptr) {
+    set_error("mab0_bf16_bwd: dK for dk <= 4 is not built (the set is the model input)");
+    return PCA_EUNSUPPORTED;
+  }
+  // ---- epilogue adjoint: H = O + relu(O Wo^T + bo) ----
+  PCA_TRY(relu_bwd(dH, v.Z, w.dZ, Bm * D, st));
+  PCA_TRY(linear_bwd_f32(v.O, p.wo, w.dZ, nullptr, gr.wo, gr.bo, Bm, D, D, st));
+  PCA_TRY(copy_rows(dH, Bm, w.dO, Bm, D, st));
+  PCA_TRY(linear_dx_acc_f32(w.dZ, p.wo, w.dO, Bm, D, D, 1, st));
+  const float sl2e = 1.4426950408889634f / sqrtf((float)D);
+  Mab0PostJob pj{};
+  pj.Qp = v.Qp; pj.Wk = p.wk; pj.I = I; pj.Wq = p.wq;
+  pj.dWk = gr.wk; pj.dQp = w.dQp; pj.dWq = gr.wq; pj.dbq = gr.bq; pj.dI = dI;
+  pj.m = m; pj.d = D; pj.dk = s.dk; pj.dq = s.dq; pj.h = s.h; pj.sl2e = sl2e; pj.B = s.B;
+  if (s.dk == D) {
+    const __bf16* Xb = s.k_dtype == PCA_F32 ? v.Xb : reinterpret_cast<const __bf16*>(X);
+    const double pts = (double)M;
+    {
+      ProfScope ps(PCA_K_MAB0_BWD, st, 4.0 * pts * 2.0 * m * D, pts * 8.0 * D);
+      PCA_TRY(fq_attn_bwd256(v.Kp, v.Vp, v.Qp, w.dO, v.O, v.LSE, w.Delta, s.B, s.nk, m,
+                             s.k_lengths, w.dKp, w.dVp, w.dQpPart, w.dOt, st));
+      ps.end();
+    }
+    // fc_v bias: every row of A sums to one, so colsum(dVp) = sum over sets and queries of dO;
+    // fc_k bias: identically zero (softmax shift invariance), left untouched
+    PCA_TRY(colsum(w.dO, Bm, D, gr.bv, 1, st));
+    if (dX != nullptr) {
+      PCA_TRY(prep_weight(p.wk, w.WkTP, D, D, 2, st));
+      PCA_TRY(prep_weight(p.wv, w.WvTP, D, D, 2, st));
+      const bool f32 = s.k_dtype == PCA_F32;
+      __bf16* dXb = f32 ? w.dXb : reinterpret_cast<__bf16*>(dX);
+      PCA_TRY(rowgemm256_dx(w.dKp, w.WkTP, dXb, s.B, s.nk, (!f32 && dk_accumulate) ? 1 : 0, st));
+      PCA_TRY(rowgemm256_dx(w.dVp, w.WvTP, dXb, s.B, s.nk, 1, st));
+      if (f32)
+        PCA_TRY(cvt_bf16_f32(dXb, reinterpret_cast<float*>(dX), M * D, dk_accumulate ? 1 : 0, st));
+    }
+    Wgrad256Jobs jobs{};
+    jobs.j[jobs.n++] = Wgrad256Job{w.dKp, Xb, gr.wk, nullptr, M};
+    jobs.j[jobs.n++] = Wgrad256Job{w.dVp, Xb, gr.wv, nullptr, M};
+    PCA_TRY(wgrad256_launch(jobs, w.wg, st));
+    pj.DG = nullptr;
+    pj.dO = w.dOt;
+  } else {
+    PCA_TRY(fill_zero(w.DG, (int64_t)R * s.dk, st));
+    PCA_TRY(epi_small_bwd256(w.dO, v.T, p.wv, s.B, m, s.dk, w.dTf, w.Delta, gr.wv, gr.bv, st));
+    PCA_TRY(mab0_bwd_small_launch(reinterpret_cast<const float*>(X), v.Gf, w.dTf, v.LSE, w.Delta,
+                                  s.B, s.nk, R, R, s.dk, w.DG, s.k_lengths, st));
+    pj.DG = w.DG;
+    pj.dO = w.dO;
+  }
+  if (defer != nullptr && defer->posts.n < 3) {
+    defer->posts.j[defer->posts.n++] = pj;
+    return PCA_OK;
+  }
+  Mab0PostJobs one{};
+  one.j[one.n++] = pj;
+  return mab0_post_launch(one, st);
+}
+
+}  // namespace pca

@@ -162,6 +162,7 @@ __device__ __forceinline__ void mab0_prep_body(const Mab0PrepJob& a, float* sq, 
   }
   }
   __syncthreads();
+  if (a.Gf == nullptr) return;             // caller only wants Qp (keys are projected: d = 256)
   const int dh = d / h;
   for (int o = threadIdx.x; o < h * dk; o += 256) {
     const int j = o / dk, c = o - j * dk;
@@ -635,6 +636,7 @@ __global__ __launch_bounds__(256) void k_mab0_epi(const float* __restrict__ Tp, 
 
 // ---- host side --------------------------------------------------------------------
 bool mab0_bf16_supported(const pca_mab_shape& s) {
+  if (s.d == 256) return mab0_d256_supported(s);
   const int R = s.h * s.nq;
   if (!(s.nq == 16 || s.nq <= 2)) return false;      // epilogue: 8 or 1 queries per thread
   // the keys X may be bf16 when they are a hidden tensor (dk == d)
@@ -694,6 +696,15 @@ int mab0_prep_launch(const Mab0PrepJobs& J, hipStream_t st) {
   return check_launch("k_mab0_prep");
 }
 
+// layer-1 attention (dk <= 4) of R = h*m score rows, stand-alone (the d = 256 path calls it)
+int mab0_attn_small_launch(const float* X, const float* Gf, int B, int N, int R, int dk, float* T,
+                           float* LSE, const int32_t* lengths, hipStream_t st) {
+  PCA_REQUIRE(R == 64 || R == 128 || R == 256, "mab0_attn_small: %d score rows", R);
+  hipLaunchKernelGGL(k_mab0_attn_small, dim3(B, 2), dim3(256), 0, st, X, Gf, N, R, dk, T, LSE,
+                     lengths);
+  return check_launch("k_mab0_attn_small");
+}
+
 // point-range splits per set so that B*S workgroups cover the 256 CUs
 int mab0_splits(const pca_mab_shape& s) {
   if (s.dk <= 4) return 1;
@@ -730,9 +741,11 @@ size_t mab0_carve_saved(const pca_mab_shape& s, Mab0Saved* out, void* base) {
 }
 
 size_t mab0_bf16_saved_bytes(const pca_mab_shape& s) {
+  if (s.d == 256) return mab0_d256_saved_bytes(s);
   return mab0_carve_saved(s, nullptr, nullptr);
 }
 size_t mab0_bf16_fwd_ws_bytes(const pca_mab_shape& s) {
+  if (s.d == 256) return mab0_d256_fwd_ws_bytes(s);
   return mab0_carve_saved(s, nullptr, nullptr);
 }
 
@@ -743,6 +756,7 @@ int mab0_bf16_fwd(const pca_mab_shape& s, const float* I, const void* X,
 int mab0_bf16_fwd_ex(const pca_mab_shape& s, const float* I, const void* X,
                      const pca_mab_params& p, float* H, void* saved, void* ws, int flags,
                      hipStream_t st) {
+  if (s.d == 256) return mab0_d256_fwd(s, I, X, p, H, saved, ws, st);
   PCA_REQUIRE(mab0_bf16_supported(s), "mab0_bf16_fwd: unsupported shape");
   const bool training = saved != nullptr;
   PCA_REQUIRE(training || ws != nullptr, "mab0_bf16_fwd: scratch required");

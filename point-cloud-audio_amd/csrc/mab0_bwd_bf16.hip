@@ -408,6 +408,7 @@ __device__ __forceinline__ void post1_body(const Mab0PostJob& a, int blk) {
   const int dh = d / a.h;
   const int o = blk * 256 + threadIdx.x;
   if (o < d * dk) {
+    if (a.DG == nullptr) return;            // keys were projected: dWk comes from the GEMM path
     const int f = o / dk, c = o - f * dk, j = f / dh;
     a.dWk[o] += a.sl2e * dot_strided(a.Qp + f, d, a.DG + (int64_t)j * m * dk + c, dk, m);
   } else if (o < d * dk + m * d) {
@@ -429,8 +430,9 @@ __device__ __forceinline__ void post1_body(const Mab0PostJob& a, int blk) {
       }
       for (; bb < a.B; ++bb) qs += a.dO[bb * sb + oo];
     }
-    a.dQp[oo] = qs + a.sl2e * dot_strided(a.DG + (int64_t)(j * m + q) * dk, 1,
-                                                 a.Wk + (int64_t)f * dk, 1, dk);
+    a.dQp[oo] = a.DG == nullptr ? qs
+                                : qs + a.sl2e * dot_strided(a.DG + (int64_t)(j * m + q) * dk, 1,
+                                                            a.Wk + (int64_t)f * dk, 1, dk);
   }
 }
 // stage 1 + riders: rows [0, J.n) of blockIdx.y are the post-1 jobs, then (when present) the
@@ -591,6 +593,15 @@ int mab0_post_launch(const Mab0PostJobs& J, hipStream_t st) {
   return check_launch("k_mab0_post2");
 }
 
+int mab0_bwd_small_launch(const float* X, const float* Gf, const float* dTf, const float* LSE,
+                          const float* Delta, int B, int N, int R, int Rp, int dk, float* DG,
+                          const int32_t* lengths, hipStream_t st) {
+  PCA_REQUIRE(R == 64 || R == 128 || R == 256, "mab0_bwd_small: %d score rows", R);
+  hipLaunchKernelGGL(k_mab0_bwd_small, dim3(B, 2), dim3(256), 0, st, X, Gf, dTf, LSE, Delta, N, R,
+                     Rp, dk, DG, lengths);
+  return check_launch("k_mab0_bwd_small");
+}
+
 size_t mab0_carve_bwd_ws(const pca_mab_shape& s, Mab0BwdWs* out, void* base) {
   Carver c(base);
   Mab0BwdWs w;
@@ -613,6 +624,7 @@ size_t mab0_carve_bwd_ws(const pca_mab_shape& s, Mab0BwdWs* out, void* base) {
 }
 
 size_t mab0_bf16_bwd_ws_bytes(const pca_mab_shape& s) {
+  if (s.d == 256) return mab0_d256_bwd_ws_bytes(s);
   return mab0_carve_bwd_ws(s, nullptr, nullptr);
 }
 
@@ -627,6 +639,8 @@ int mab0_bf16_bwd_ex(const pca_mab_shape& s, const float* I, const void* X,
                      const pca_mab_params& p, const void* saved, const float* dH, float* dI,
                      void* dX, int dk_accumulate, const pca_mab_grads& gr, void* ws, int flags,
                      hipStream_t st, BwdDefer* defer) {
+  if (s.d == 256)
+    return mab0_d256_bwd(s, I, X, p, saved, dH, dI, dX, dk_accumulate, gr, ws, st, defer);
   Mab0Saved v;
   mab0_carve_saved(s, &v, const_cast<void*>(saved));
   Mab0BwdWs w;
@@ -683,7 +697,10 @@ int mab0_bf16_bwd_ex(const pca_mab_shape& s, const float* I, const void* X,
     });
     const double pts = (double)s.B * s.nk;
     const bool abf = s.k_dtype == PCA_BF16;
-    ProfScope ps(PCA_K_MAB0_BWD, st, 4.0 * pts * (2.0 * dk * d + 2.0 * m * d), pts * 8.0 * dk);
+    // algorithmic bytes: X in, dX out (read as well when it accumulates onto mab1's dQ)
+    const double eb0 = abf ? 2.0 : 4.0;
+    ProfScope ps(PCA_K_MAB0_BWD, st, 4.0 * pts * (2.0 * dk * d + 2.0 * m * d),
+                 pts * eb0 * dk * (1.0 + (dX != nullptr ? (dk_accumulate ? 2.0 : 1.0) : 0.0)));
     const dim3 grid(s.B, S);
     if (Rp == 32 && abf) hipLaunchKernelGGL((k_mab0_bwd<32, true>), grid, dim3(256), lds, st, a);
     else if (Rp == 32) hipLaunchKernelGGL((k_mab0_bwd<32, false>), grid, dim3(256), lds, st, a);

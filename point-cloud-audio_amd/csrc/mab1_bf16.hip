@@ -609,8 +609,9 @@ bool mab1_bf16_supported(const pca_mab_shape& s, bool inference) {
   // activations: fp32 everywhere, or bf16 for Y (and for X when it is a hidden tensor)
   const bool dt_ok = s.k_dtype == PCA_F32 &&
                      (s.dq <= 4 ? s.q_dtype == PCA_F32 : s.q_dtype == s.y_dtype);
-  // d = 256 / m = 32 (BASELINE configs[3]): forward only so far
-  const bool d_ok = s.d == 128 || (inference && s.d == 256 && s.nk == 32);
+  // d = 256 / m = 32 / 8 heads (BASELINE configs[3]): forward here, backward in d256_*.hip
+  (void)inference;
+  const bool d_ok = s.d == 128 || (s.d == 256 && s.nk == 32);
   return s.q_shared == 0 && d_ok && s.h * 32 == s.d && (s.nk == 16 || s.nk == 32) &&
          s.dk == s.d && (s.dq == s.d || s.dq <= 4) && dt_ok;
 }
@@ -712,7 +713,7 @@ int mab1_bf16_fwd_ex(const pca_mab_shape& s, const void* X, const float* H,
     return small ? launch_fwd<128, 16, true, false>(a, st)
                  : launch_fwd<128, 16, false, false>(a, st);
   }
-  if (d == 256) {          // inference only (mab1_bf16_supported): O meets in the scratch block
+  if (d == 256) {          // Q phase + O phase: O meets in the saved / scratch block
     if (small)
       return abf ? launch_fwd<256, 32, true, true>(a, st) : launch_fwd<256, 32, true, false>(a, st);
     a.OS = v.OS;

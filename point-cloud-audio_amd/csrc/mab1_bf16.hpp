@@ -306,6 +306,25 @@ int mab0_bf16_bwd_ex(const pca_mab_shape& s, const float* I, const void* X,
                      const pca_mab_params& p, const void* saved, const float* dH, float* dI,
                      void* dX, int dk_accumulate, const pca_mab_grads& gr, void* ws, int flags,
                      hipStream_t st, BwdDefer* defer = nullptr);
+// d = 256 / 8 heads (d256_host.hip): the many-queries backward and the few-queries block
+size_t mab1_d256_bwd_ws_bytes(const pca_mab_shape& s);
+int mab1_d256_bwd(const pca_mab_shape& s, const void* X, const float* H, const pca_mab_params& p,
+                  const void* saved, const void* dY, void* dX, float* dH, int dk_accumulate,
+                  const pca_mab_grads& gr, void* ws, hipStream_t st);
+bool mab0_d256_supported(const pca_mab_shape& s);
+size_t mab0_d256_saved_bytes(const pca_mab_shape& s);
+size_t mab0_d256_fwd_ws_bytes(const pca_mab_shape& s);
+size_t mab0_d256_bwd_ws_bytes(const pca_mab_shape& s);
+int mab0_d256_fwd(const pca_mab_shape& s, const float* I, const void* X, const pca_mab_params& p,
+                  float* H, void* saved, void* ws, hipStream_t st);
+int mab0_d256_bwd(const pca_mab_shape& s, const float* I, const void* X, const pca_mab_params& p,
+                  const void* saved, const float* dH, float* dI, void* dX, int dk_accumulate,
+                  const pca_mab_grads& gr, void* ws, hipStream_t st, BwdDefer* defer);
+int mab0_attn_small_launch(const float* X, const float* Gf, int B, int N, int R, int dk, float* T,
+                           float* LSE, const int32_t* lengths, hipStream_t st);
+int mab0_bwd_small_launch(const float* X, const float* Gf, const float* dTf, const float* LSE,
+                          const float* Delta, int B, int N, int R, int Rp, int dk, float* DG,
+                          const int32_t* lengths, hipStream_t st);
 // per-block dispatch (api_mab.hip): kind 0 exact fp32, 1 fused mab1, 2 fused mab0
 int mab_kind(const pca_mab_shape& s, bool inference = false);
 size_t mab_saved_bytes_any(const pca_mab_shape& s);

@@ -833,6 +833,7 @@ size_t mab1_carve_bwd_ws(const pca_mab_shape& s, Mab1BwdWs* out, void* base) {
 }
 
 size_t mab1_bf16_bwd_ws_bytes(const pca_mab_shape& s) {
+  if (s.d == 256) return mab1_d256_bwd_ws_bytes(s);
   return mab1_carve_bwd_ws(s, nullptr, nullptr);
 }
 
@@ -930,6 +931,8 @@ int mab1_bf16_bwd_ex(const pca_mab_shape& s, const void* X, const float* H,
                      float* dH, int dk_accumulate, const pca_mab_grads& gr, void* ws, int flags,
                      hipStream_t st, const IsabImg* img, float* zero_ptr, int zero_n,
                      int* nparts_out, BwdDefer* defer) {
+  if (s.d == 256)       // three launches + the 256-wide weight-gradient reduction (d256_host.hip)
+    return mab1_d256_bwd(s, X, H, p, saved, dY, dX, dH, dk_accumulate, gr, ws, st);
   Mab1Saved v;
   mab1_carve_saved(s, &v, const_cast<void*>(saved));
   Mab1BwdWs w;

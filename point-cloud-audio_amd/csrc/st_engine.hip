@@ -99,8 +99,12 @@ inline Shapes shapes(const pca_st_config& c, bool training, const int32_t* lengt
     t.m1[1].q_dtype = PCA_BF16;
     t.m1[1].y_dtype = PCA_BF16;
     t.pma.k_dtype = PCA_BF16;
-    if (isab_bf16_supported(t.m0[0], t.m1[0]) && isab_bf16_supported(t.m0[1], t.m1[1]) &&
-        mab_kind(t.pma) == 2) {
+    const bool isab128 = isab_bf16_supported(t.m0[0], t.m1[0]) &&
+                         isab_bf16_supported(t.m0[1], t.m1[1]);
+    // d = 256: every block has a fused kernel of its own (no ISAB-level fusion)
+    const bool blocks256 = c.d == 256 && mab_kind(t.m0[0]) == 2 && mab_kind(t.m1[0]) == 1 &&
+                           mab_kind(t.m0[1]) == 2 && mab_kind(t.m1[1]) == 1;
+    if ((isab128 || blocks256) && mab_kind(t.pma) == 2) {
       s = t;
       s.act_bf16 = true;
     }
@@ -109,6 +113,9 @@ inline Shapes shapes(const pca_st_config& c, bool training, const int32_t* lengt
   s.m0[0].k_lengths = s.m0[1].k_lengths = s.pma.k_lengths = lengths;
   return s;
 }
+
+// the PMA epilogue + classifier + loss launch (k_pma_head) exists for d = 128
+inline bool pma_head_ok(const Shapes& s) { return mab_kind(s.pma) == 2 && s.pma.d == 128; }
 
 struct Ws {
   void* saved[5];            // mab0[0], mab1[0], mab0[1], mab1[1], pma
@@ -198,7 +205,7 @@ int forward(const pca_st_config& c, const Layout& L, const Shapes& s, const floa
         mab0_carve_saved(s.m0[li], &v, w.saved[2 * li]);
         mab0_collect_prep(s.m0[li], p + L.I[li], params_at(p, L.mab0[li]), v, true, false, &MJ);
       }
-    if (mab_kind(s.pma) == 2) {
+    if (pma_head_ok(s)) {
       Mab0Saved v;
       mab0_carve_saved(s.pma, &v, w.saved[4]);
       mab0_collect_prep(s.pma, p + L.S, params_at(p, L.pma), v, true, true, &MJ);
@@ -221,7 +228,7 @@ int forward(const pca_st_config& c, const Layout& L, const Shapes& s, const floa
                         w.scratch, st));                            // modules.py:53
     in = w.Y[li];
   }
-  if (training && mab_kind(s.pma) == 2)                                   // modules.py:63
+  if (training && pma_head_ok(s))                                         // modules.py:63
     // (its epilogue runs inside k_pma_head together with the classifier and the loss)
     PCA_TRY(mab0_bf16_fwd_ex(s.pma, p + L.S, w.Y[1], params_at(p, L.pma), w.P, w.saved[4],
                              w.scratch, PCA_F_PREP_DONE | (c.k == 1 ? PCA_F_SKIP_EPILOGUE : 0),
@@ -301,7 +308,7 @@ int pca_st_train_fwd_bwd(const pca_st_config* c, const float* params, const floa
   pca::BwdDefer posts{};
   if (phase != 1) {
     PCA_TRY(pca::forward(*c, L, s, p, X, w, true, st));
-    if (pca::mab_kind(s.pma) == 2) {
+    if (pca::pma_head_ok(s)) {
       // dec.0 epilogue + dec.1 (Linear) + mean cross-entropy forward and backward + dec.0
       // backward epilogue: one launch, one workgroup per set
       PCA_TRY(pca::pma_head_launch(s.pma, pca::params_at(p, L.pma), w.saved[4], w.scratch, w.P,

@@ -43,8 +43,8 @@ MAB1_CASES = [      # B, N, m, dq, d, h
 ]
 
 
-# BASELINE configs[3] block (d = 256, 8 heads, m = 32): fused forward only so far (Q phase +
-# O phase for d -> d, one launch for layer 1); training of this shape runs the GEMM chain
+# BASELINE configs[3] block (d = 256, 8 heads, m = 32): Q phase + O phase for d -> d (one launch
+# for layer 1); the backward is three launches + the 256-wide weight-gradient reduction
 MAB1_D256_CASES = [
     (2, 300, 32, 256, 256, 8),        # ragged N
     (3, 128, 32, 256, 256, 8),
@@ -77,7 +77,8 @@ def test_mab1_fwd_bf16(dev, case):
     print(f"mab1 fwd {case}: max err {err:.3e} (max|ref| {float(ref.abs().max()):.2f})")
 
 
-@pytest.mark.parametrize("case", MAB1_CASES, ids=[str(c) for c in MAB1_CASES])
+@pytest.mark.parametrize("case", MAB1_CASES + MAB1_D256_CASES,
+                         ids=[str(c) for c in MAB1_CASES + MAB1_D256_CASES])
 def test_mab1_bwd_bf16(dev, case):
     """Fused backward chain + MFMA weight-gradient reductions.
 
@@ -112,7 +113,9 @@ def test_mab1_bwd_bf16(dev, case):
     Y = mab(Xd, Hd)
     (Y * G.to(dev)).sum().backward()
     pca_hip.set_mode("f32")
-    close(Y, Ye, 2e-3, "Y vs bf16 emulation")
+    # (d = 256: O crosses from the Q phase to the O phase in bf16, so the residual path of Y
+    #  carries one more rounding of relative size 2^-9 than the emulation)
+    close(Y, Ye, 2e-3 if d == 128 else 6e-3, "Y vs bf16 emulation")
     got = {"dK": Hd.grad}
     if dq > 4:
         got["dQ"] = Xd.grad
@@ -126,7 +129,8 @@ def test_mab1_bwd_bf16(dev, case):
             sc = max(1.0, float(emu["fc_k.weight"].abs().max()))
             assert float((v.cpu() - emu[k]).abs().max()) <= 1.5e-2 * sc
         else:
-            errs[k] = close_robust(v, emu[k], 1.5e-2, k)
+            # (d = 256: dO, dQp and dZ additionally cross HBM in bf16 between the three launches)
+            errs[k] = close_robust(v, emu[k], 1.5e-2, k, outlier_frac=2e-4 if d == 128 else 2e-3)
         sc = max(1.0, float(exact[k].abs().max()))
         if k == "fc_k.bias":
             sc = max(1.0, float(exact["fc_k.weight"].abs().max()))
@@ -170,6 +174,12 @@ MAB0_CASES = [      # B, N, m, dk, d, h   (query = learned [m, d], shared by all
     (3, 77, 16, 2, 128, 4),         # layer 1 (f, logmag): exact fp32
     (2, 33, 16, 3, 128, 4),
     (2, 1, 16, 128, 128, 4),        # a single key
+    # d = 256 / 8 heads (BASELINE configs[3]): keys projected, flash attention per head
+    (3, 200, 32, 256, 256, 8),      # ISAB mab0, ragged N
+    (4, 130, 1, 256, 256, 8),       # PMA: one seed (one query tile, 15 padding queries)
+    (2, 300, 16, 256, 256, 8),      # 16 queries: the 16x16x16 products of the backward
+    (2, 77, 32, 3, 256, 8),         # layer 1: reassociated fp32 kernels, 256 score rows
+    (2, 1, 32, 256, 256, 8),        # a single key
 ]
 
 
@@ -198,7 +208,9 @@ def test_mab0_fwd_bf16(dev, case):
 
 def mab0_forward_bf16emu(I, X, p, h):
     """Reassociated mab0 with the MFMA operands (G' = sl2e Qp_h Wk_h, X, P) rounded to bf16 as
-    csrc/mab0_bf16.hip does; epilogue fp32.  Returns H."""
+    csrc/mab0_bf16.hip does; epilogue fp32.  Returns H.
+    d = 256 with dk = 256 (csrc/d256_*.hip): the keys ARE projected - Kp, Vp, the scaled query
+    and P are the bf16 operands."""
     import math
     from oracle.st_oracle import rb
     B, N, dk = X.shape
@@ -207,6 +219,16 @@ def mab0_forward_bf16emu(I, X, p, h):
     dh = d // h
     sl2e = math.log2(math.e) / math.sqrt(d)
     Qp = I[0] @ p["fc_q.weight"].t() + p["fc_q.bias"]                  # [m, d]
+    if d == 256 and dk == 256:
+        Xb = rb(X)
+        Kp = rb(Xb @ rb(p["fc_k.weight"]).t() + p["fc_k.bias"]).view(B, N, h, dh)
+        Vp = rb(Xb @ rb(p["fc_v.weight"]).t() + p["fc_v.bias"]).view(B, N, h, dh)
+        S2 = torch.einsum("qjf,bnjf->bjqn", rb(Qp * sl2e).view(m, h, dh), Kp)
+        P = torch.softmax(S2 * math.log(2.0), dim=-1)
+        O = Qp.view(1, m, h, dh) + torch.einsum("bjqn,bnjf->bqjf", rb(P), Vp)
+        O = O.reshape(B, m, d)
+        Z = O @ p["fc_o.weight"].t() + p["fc_o.bias"]
+        return O + torch.relu(Z)
     Wk = p["fc_k.weight"].view(h, dh, dk)
     G = torch.einsum("qjf,jfc->jqc", Qp.view(m, h, dh), Wk) * sl2e      # [h, m, dk]
     small = dk <= 4
@@ -245,6 +267,8 @@ def test_mab0_bwd_bf16(dev, case):
     emu = {k: v.grad for k, v in leaves.items()}
     emu["dQ"], emu["dK"] = Ie.grad, Xe.grad
     emu["fc_k.bias"] = torch.zeros(d)
+    if N == 1:      # one key: P = 1 whatever the scores, so nothing flows into the key projection
+        emu["fc_k.weight"] = torch.zeros_like(emu["fc_k.weight"])
 
     mab = modules.MAB(d, dk, d, h).to(dev)
     mab.load_state_dict(p)
@@ -265,7 +289,10 @@ def test_mab0_bwd_bf16(dev, case):
         if k == "fc_k.bias":
             assert float(v.abs().max()) == 0.0           # exactly zero by construction
             continue
-        errs[k] = close_robust(v, emu[k], 1.5e-2, k)
+        # (d = 256: the online softmax feeds un-normalised probabilities to the MFMA, the emulation
+        #  normalised ones - a few more ReLU pre-activations of the 96 epilogue rows change sign)
+        errs[k] = close_robust(v, emu[k], 1.5e-2, k,
+                               outlier_frac=2e-4 if d == 128 else max(3e-3, 2.5 / v.numel()))
         sc = max(1.0, float(exact[k].abs().max()))
         rms = float((emu[k] - exact[k]).pow(2).mean().sqrt()) / sc
         assert rms < 3e-2, (k, rms)
@@ -454,7 +481,7 @@ def test_mab1_fwd_d256_bf16_activations(dev, case):
                       None, 0)
     nws = L.pca_mab_fwd_ws_bytes(C.byref(s))
     assert nws > 0, L.pca_last_error()
-    assert L.pca_mab_saved_bytes(C.byref(s)) == 0          # no backward for this shape yet
+    assert L.pca_mab_saved_bytes(C.byref(s)) > 0           # the shape trains on fused kernels
     Xd = X.to(dev) if dq <= 4 else X.to(dev).to(torch.bfloat16)
     Hd = H.to(dev)
     prm = [p[k].to(dev).contiguous() for k in ("fc_q.weight", "fc_q.bias", "fc_k.weight",
@@ -470,10 +497,10 @@ def test_mab1_fwd_d256_bf16_activations(dev, case):
     print(f"mab1 fwd {case} bf16 in/out: max err {err:.3e}")
 
 
-def test_auto_mode_takes_forward_only_kernels(dev):
-    """'auto' under no_grad probes pca_mab_fwd_ws_bytes(): the d = 256 block runs its fused
-    forward; with autograd on it has no backward, so 'auto' resolves to the exact path and
-    'bf16' refuses."""
+def test_auto_mode_at_d256(dev):
+    """'auto' probes the library per block: the d = 256 / 8-head / m = 32 block has fused forward
+    AND backward kernels, so it trains in bf16 mode; a shape without any (d = 256 with m = 20
+    inducing points) resolves to the exact path under 'auto' and refuses under 'bf16'."""
     import modules
     import pca_hip
     B, N, m, d, h = 2, 130, 32, 256, 8
@@ -491,11 +518,17 @@ def test_auto_mode_takes_forward_only_kernels(dev):
             fused = mab(X, H)
         diff = float((fused - exact).abs().max())
         assert 1e-6 < diff < FWD_TOL * max(1.0, float(exact.abs().max())), diff
-        Y = mab(X.requires_grad_(True), H)                   # training: exact chain
-        assert float((Y.detach() - exact).abs().max()) < 1e-5
+        Y = mab(X.clone().requires_grad_(True), H)           # training: fused as well
+        assert 1e-6 < float((Y.detach() - exact).abs().max()) < FWD_TOL * max(1.0, float(exact.abs().max()))
         Y.sum().backward()
-        pca_hip.set_mode("bf16")
-        with pytest.raises(pca_hip.PcaHipError):
-            mab(X, H)
+        H20 = H[:, :20].contiguous()                          # 20 keys: no fused kernel
+        with torch.no_grad():
+            pca_hip.set_mode("f32")
+            e20 = mab(X, H20)
+            pca_hip.set_mode("auto")
+            assert float((mab(X, H20) - e20).abs().max()) < 1e-5
+            pca_hip.set_mode("bf16")
+            with pytest.raises(pca_hip.PcaHipError):
+                mab(X, H20)
     finally:
         pca_hip.set_mode("f32")
