@@ -916,37 +916,66 @@ __global__ __launch_bounds__(256) void k_kv_proj_small(const float* __restrict__
 }
 
 
-// dW[256 x dq] += G[M x 256]^T X[M x dq] (dq <= 4, fp32 X), db += colsum(G): layer-1 fc_q / fc_k /
-// fc_v.  One thread per feature, a row range per workgroup, one atomic per element per workgroup.
+// dW[256 x dq] += G[M x 256]^T X[M x dq] (dq <= 4, fp32 X), db += colsum(G): layer-1 fc_q.
+// HBM-bound read of G: a thread owns 8 features (one 16-byte load per row) of every 8th row of
+// the workgroup's range, four rows in flight; the 8 row lanes meet in LDS, then one atomic per
+// element per workgroup.
 __global__ __launch_bounds__(256) void k_wgrad_small256(const __bf16* __restrict__ G,
                                                         const float* __restrict__ X, int64_t M,
                                                         int dq, int rows_per_wg,
                                                         float* __restrict__ dW,
                                                         float* __restrict__ db) {
   constexpr int D = 256;
-  const int f = threadIdx.x;
+  __shared__ float red[8][D][5];
+  const int fc = threadIdx.x & 31, rl = threadIdx.x >> 5;
   const int64_t r0 = (int64_t)blockIdx.x * rows_per_wg;
   const int64_t r1 = r0 + rows_per_wg < M ? r0 + rows_per_wg : M;
-  float acc[4] = {0.f, 0.f, 0.f, 0.f}, bs = 0.f;
-  for (int64_t row = r0; row < r1; row += 8) {
-    float gv[8], xv[8][4];
+  float acc[8][4], bs[8];
 #pragma unroll
-    for (int u = 0; u < 8; ++u) {
-      const int64_t rr = row + u;
+  for (int k = 0; k < 8; ++k) {
+    bs[k] = 0.f;
+#pragma unroll
+    for (int c = 0; c < 4; ++c) acc[k][c] = 0.f;
+  }
+  for (int64_t row = r0 + rl; row < r1; row += 32) {
+    bf16x8 gv[4];
+    float xv[4][4];
+#pragma unroll
+    for (int u = 0; u < 4; ++u) {
+      const int64_t rr = row + 8 * u;
       const bool ok = rr < r1;
-      gv[u] = ok ? (float)G[rr * D + f] : 0.f;
+      if (ok) gv[u] = *reinterpret_cast<const bf16x8*>(G + rr * D + 8 * fc);
+#pragma unroll
+      for (int k = 0; k < 8; ++k)
+        if (!ok) gv[u][k] = (__bf16)0.f;
 #pragma unroll
       for (int c = 0; c < 4; ++c) xv[u][c] = (ok && c < dq) ? X[rr * dq + c] : 0.f;
     }
 #pragma unroll
-    for (int u = 0; u < 8; ++u) {
-      bs += gv[u];
+    for (int u = 0; u < 4; ++u)
 #pragma unroll
-      for (int c = 0; c < 4; ++c) acc[c] = fmaf(gv[u], xv[u][c], acc[c]);
-    }
+      for (int k = 0; k < 8; ++k) {
+        const float g = (float)gv[u][k];
+        bs[k] += g;
+#pragma unroll
+        for (int c = 0; c < 4; ++c) acc[k][c] = fmaf(g, xv[u][c], acc[k][c]);
+      }
   }
-  for (int c = 0; c < dq; ++c) atomicAdd(&dW[f * dq + c], acc[c]);
-  if (db != nullptr) atomicAdd(&db[f], bs);
+#pragma unroll
+  for (int k = 0; k < 8; ++k) {
+#pragma unroll
+    for (int c = 0; c < 4; ++c) red[rl][8 * fc + k][c] = acc[k][c];
+    red[rl][8 * fc + k][4] = bs[k];
+  }
+  __syncthreads();
+  const int f = threadIdx.x;
+  float t[5] = {0.f, 0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+  for (int q = 0; q < 8; ++q)
+#pragma unroll
+    for (int c = 0; c < 5; ++c) t[c] += red[q][f][c];
+  for (int c = 0; c < dq; ++c) atomicAdd(&dW[f * dq + c], t[c]);
+  if (db != nullptr) atomicAdd(&db[f], t[4]);
 }
 
 // ---- per-set epilogue pieces of the few-queries block whose keys have dk <= 4 columns --------
@@ -1009,6 +1038,350 @@ __global__ __launch_bounds__(256) void k_epi_small_wv(const float* __restrict__ 
   }
   for (int c = 0; c < dk; ++c) atomicAdd(&dWv[f * dk + c], acc[c]);
   atomicAdd(&dbv[f], bs);
+}
+
+
+// =====================================================================================
+// PMA at dk = 256 (R = h*m <= 16 score rows): reassociated form of mab0_bf16.hip -
+//   G' = sl2e Qp_h Wk_h (batch invariant), S = G' X^T, A = softmax_N(S), T = A X -
+// so the N keys are never projected and X is read once.  One 16-row score tile; a wave streams
+// its own 32-point tiles of X through a private LDS tile (row fragments + transposed fragments).
+// =====================================================================================
+struct PmaArgs {
+  const __bf16* X;             // [B*N][256]
+  const __bf16* Gb;            // [>= 16][256] rows r (sl2e folded in; rows >= R zero)
+  float *Tp, *Mp, *Lp;         // forward partials [B][S][16][256], [B][S][16]
+  const __bf16* dTb;           // [B][16][256]
+  const __bf16* TG;            // [B][256][32]: k-slot 8 g + j = j < 4 ? dT[4g+j][c] : G'[4g+j-4][c]
+  const float *LSEp, *Delta;   // [B][16]
+  __bf16* dX;                  // [B*N][256] or null
+  float* DG;                   // [16][256], accumulated over sets
+  int B, N, R, S, accumulate_dx;
+  const int32_t* lengths;
+};
+
+__global__ __launch_bounds__(256, 1) void k_pma_fwd256(const PmaArgs a) {
+  constexpr int DK = 256, FT = DK / 16, KS = DK / 32, TB = 32 * DK * 2;
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  char* sX = smem;                                             // 4 waves x 16 KiB, later slabs
+  float* sAl = reinterpret_cast<float*>(smem + 4 * TB);        // 4 x 16
+  float* sM = sAl + 64;
+  float* sL = sM + 64;
+  float* sT = reinterpret_cast<float*>(sX);
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int r = lane & 15, g = lane >> 4;
+  const int b = blockIdx.x, sp = blockIdx.y;
+  const int per = (int)(((int64_t)(a.N + 127) / 128 + a.S - 1) / a.S) * 128;
+  int len = a.N;
+  if (a.lengths != nullptr) len = a.lengths[b] < a.N ? a.lengths[b] : a.N;
+  const int n_lo = sp * per, n_hi = (n_lo + per < len) ? n_lo + per : len;
+  bf16x8 gB[KS];
+#pragma unroll
+  for (int ks = 0; ks < KS; ++ks)
+    gB[ks] = *reinterpret_cast<const bf16x8*>(a.Gb + (int64_t)r * DK + 32 * ks + 8 * g);
+  char* myX = sX + wave * TB;
+  float* myAl = sAl + wave * 16;
+  float mrow = -INFINITY, lrow = 0.f;
+  f32x4 T[FT];
+#pragma unroll
+  for (int ft = 0; ft < FT; ++ft) T[ft] = f32x4{0.f, 0.f, 0.f, 0.f};
+  for (int n0 = n_lo + wave * 32; n0 < n_hi; n0 += 128) {
+#pragma unroll
+    for (int e = 0; e < 16; ++e) {
+      const int c = lane + 64 * e, row = c >> 5, ch = c & 31;
+      bf16x8 v;
+      if (n0 + row < n_hi) {
+        v = *reinterpret_cast<const bf16x8*>(a.X + ((int64_t)b * a.N + n0 + row) * DK + ch * 8);
+      } else {
+#pragma unroll
+        for (int k = 0; k < 8; ++k) v[k] = (__bf16)0.f;
+      }
+      *reinterpret_cast<bf16x8*>(myX + tr_off256(row, ch)) = v;
+    }
+    f32x4 s[2];
+    float mt = -INFINITY;
+#pragma unroll
+    for (int pb = 0; pb < 2; ++pb) {
+      s[pb] = f32x4{0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+      for (int ks = 0; ks < KS; ++ks)
+        s[pb] = mfma32(*reinterpret_cast<const bf16x8*>(myX + tr_off256(16 * pb + r, 4 * ks + g)),
+                       gB[ks], s[pb]);
+      // rows of s = points 16 pb + 4 g + e ; column = score row r
+#pragma unroll
+      for (int e = 0; e < 4; ++e) {
+        if (n0 + 16 * pb + 4 * g + e >= n_hi) s[pb][e] = -INFINITY;
+        mt = fmaxf(mt, s[pb][e]);
+      }
+    }
+    mt = wave16_max(mt);
+    const float mnew = fmaxf(mrow, mt);            // finite: the tile has >= 1 live point
+    const float alpha = exp2f(mrow - mnew);
+    float ls = 0.f;
+#pragma unroll
+    for (int pb = 0; pb < 2; ++pb)
+#pragma unroll
+      for (int e = 0; e < 4; ++e) {
+        s[pb][e] = exp2f(s[pb][e] - mnew);
+        ls += s[pb][e];
+      }
+    ls = wave16_sum(ls);
+    lrow = lrow * alpha + ls;
+    mrow = mnew;
+    // the T tiles hold score rows 4g+e on their accumulator rows: fetch their alphas
+    if (g == 0) myAl[r] = alpha;
+    const float4 a4 = *reinterpret_cast<const float4*>(&myAl[4 * g]);
+    const bf16x8 pa = pack8(s[0], s[1]);
+#pragma unroll
+    for (int ft = 0; ft < FT; ++ft) {
+      T[ft][0] *= a4.x; T[ft][1] *= a4.y; T[ft][2] *= a4.z; T[ft][3] *= a4.w;
+      T[ft] = mfma32(pa, tr_frag256(myX, ft, lane), T[ft]);
+    }
+  }
+  // ---- merge the four waves' partial (m, l, T): per-wave slabs over the dead X tiles ----
+  __syncthreads();
+  if (g == 0) {
+    sM[wave * 16 + r] = mrow;
+    sL[wave * 16 + r] = lrow;
+  }
+  __syncthreads();
+  float* mySlab = sT + wave * 16 * DK;
+  {
+    float f4[4];
+#pragma unroll
+    for (int e = 0; e < 4; ++e) {
+      const int rr = 4 * g + e;
+      const float M = fmaxf(fmaxf(sM[rr], sM[16 + rr]), fmaxf(sM[32 + rr], sM[48 + rr]));
+      const float mine = sM[wave * 16 + rr];
+      f4[e] = (mine == -INFINITY) ? 0.f : exp2f(mine - M);
+    }
+#pragma unroll
+    for (int ft = 0; ft < FT; ++ft)
+#pragma unroll
+      for (int e = 0; e < 4; ++e) mySlab[(4 * g + e) * DK + 16 * ft + r] = T[ft][e] * f4[e];
+  }
+  __syncthreads();
+  const int64_t pbase = ((int64_t)b * a.S + sp) * 16;
+  for (int i = tid; i < 16 * DK; i += 256) {
+    const int rr = i / DK;
+    a.Tp[pbase * DK + i] = sT[i] + sT[16 * DK + i] + sT[2 * 16 * DK + i] + sT[3 * 16 * DK + i];
+    if (i == rr * DK) {
+      float M = -INFINITY;
+#pragma unroll
+      for (int w = 0; w < 4; ++w) M = fmaxf(M, sM[w * 16 + rr]);
+      float L = 0.f;
+#pragma unroll
+      for (int w = 0; w < 4; ++w) {
+        const float mw = sM[w * 16 + rr];
+        if (mw != -INFINITY) L += sL[w * 16 + rr] * exp2f(mw - M);
+      }
+      a.Mp[pbase + rr] = M;
+      a.Lp[pbase + rr] = L;
+    }
+  }
+}
+
+// T[b][r][c] = sum_s w_s Tp / sum_s w_s Lp ; LSE[b][r] = M + log2 L   (r < R)
+__global__ __launch_bounds__(256) void k_pma_merge(const float* __restrict__ Tp,
+                                                   const float* __restrict__ Mp,
+                                                   const float* __restrict__ Lp, int B, int S,
+                                                   int R, float* __restrict__ T,
+                                                   float* __restrict__ LSE) {
+  constexpr int DK = 256;
+  const int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x;
+  if (i >= (int64_t)B * R * DK) return;
+  const int c = (int)(i % DK), rr = (int)((i / DK) % R);
+  const int64_t b = i / ((int64_t)DK * R);
+  float M = -INFINITY;
+  for (int s = 0; s < S; ++s) M = fmaxf(M, Mp[(b * S + s) * 16 + rr]);
+  float L = 0.f, t = 0.f;
+  for (int s = 0; s < S; ++s) {
+    const float ms = Mp[(b * S + s) * 16 + rr];
+    if (ms == -INFINITY) continue;
+    const float w = exp2f(ms - M);
+    L += w * Lp[(b * S + s) * 16 + rr];
+    t += w * Tp[((b * S + s) * 16 + rr) * DK + c];
+  }
+  T[i] = t / L;
+  if (c == 0) LSE[b * R + rr] = M + log2f(L);
+}
+
+// per set: dT[r][c] = sum_{f in head j} dO[q][f] Wv[f][c], Delta[r] = <dT[r], T[r]>, and the
+// operand images of k_pma_bwd256 (dTb natural rows, TG = [dT | G'] interleaved per column)
+__global__ __launch_bounds__(256) void k_pma_epi_bwd(const float* __restrict__ dO,
+                                                     const float* __restrict__ T,
+                                                     const float* __restrict__ LSE,
+                                                     const float* __restrict__ Wv,
+                                                     const float* __restrict__ Gf, int m, int R,
+                                                     __bf16* __restrict__ dTb,
+                                                     __bf16* __restrict__ TG,
+                                                     float* __restrict__ Delta,
+                                                     float* __restrict__ LSEp) {
+  constexpr int D = 256;
+  __shared__ float sdO[2 * D];            // m <= 2 query rows
+  __shared__ float sDel[16][4];
+  const int b = blockIdx.x, c = threadIdx.x;
+  for (int i = c; i < m * D; i += 256) sdO[i] = dO[(int64_t)b * m * D + i];
+  __syncthreads();
+  float dT[16];
+#pragma unroll
+  for (int rr = 0; rr < 16; ++rr) dT[rr] = 0.f;
+#pragma unroll
+  for (int rr = 0; rr < 16; ++rr) {
+    if (rr < R) {
+      const int j = rr / m, q = rr - j * m;
+      float acc = 0.f;
+      for (int f = 0; f < 32; ++f) acc = fmaf(sdO[q * D + 32 * j + f], Wv[(32 * j + f) * D + c], acc);
+      dT[rr] = acc;
+    }
+  }
+  // Delta: block reduction per row (wave shuffle, then 4 partials)
+#pragma unroll
+  for (int rr = 0; rr < 16; ++rr) {
+    float v = rr < R ? dT[rr] * T[((int64_t)b * R + rr) * D + c] : 0.f;
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);
+    if ((c & 63) == 0) sDel[rr][c >> 6] = v;
+  }
+  __syncthreads();
+  if (c < 16) {
+    Delta[(int64_t)b * 16 + c] = c < R ? sDel[c][0] + sDel[c][1] + sDel[c][2] + sDel[c][3] : 0.f;
+    LSEp[(int64_t)b * 16 + c] = c < R ? LSE[(int64_t)b * R + c] : 1.0e30f;
+  }
+#pragma unroll
+  for (int rr = 0; rr < 16; ++rr) dTb[((int64_t)b * 16 + rr) * D + c] = (__bf16)dT[rr];
+  bf16x8 row[4];
+#pragma unroll
+  for (int gq = 0; gq < 4; ++gq)
+#pragma unroll
+    for (int jj = 0; jj < 8; ++jj) {
+      const int rr = 4 * gq + (jj & 3);
+      row[gq][jj] = jj < 4 ? (__bf16)dT[rr] : (__bf16)(rr < R ? Gf[rr * D + c] : 0.f);
+    }
+#pragma unroll
+  for (int gq = 0; gq < 4; ++gq)
+    *reinterpret_cast<bf16x8*>(TG + ((int64_t)b * D + c) * 32 + 8 * gq) = row[gq];
+}
+
+// dWv[f][c] += sum_{b,q} dO[b][q][f] T[b][j(f) m + q][c]     (deterministic: one thread per (f, c))
+__global__ __launch_bounds__(256) void k_pma_dwv(const float* __restrict__ dO,
+                                                 const float* __restrict__ T, int B, int m, int R,
+                                                 float* __restrict__ dWv) {
+  constexpr int D = 256;
+  const int f = blockIdx.x, c = threadIdx.x, j = f / 32;
+  float acc = 0.f;
+  for (int b = 0; b < B; ++b)
+    for (int q = 0; q < m; ++q)
+      acc = fmaf(dO[((int64_t)b * m + q) * D + f], T[((int64_t)b * R + j * m + q) * D + c], acc);
+  dWv[f * D + c] += acc;
+}
+
+__global__ __launch_bounds__(256, 1) void k_pma_bwd256(const PmaArgs a) {
+  constexpr int DK = 256, FT = DK / 16, KS = DK / 32, TB = 32 * DK * 2, PD = 40;
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  char* sX = smem;                                 // 4 x 16 KiB ; later the dG slabs (4 x 16 KiB)
+  char* sTG = sX + 4 * TB;                         // [256][64 B]
+  char* sDS = sTG + DK * 64;                       // 4 x 32 x PD
+  float* sLSE = reinterpret_cast<float*>(sDS + 4 * 32 * PD);
+  float* sDel = sLSE + 16;
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int r = lane & 15, g = lane >> 4;
+  const int b = blockIdx.x, sp = blockIdx.y;
+  const int per = (int)(((int64_t)(a.N + 127) / 128 + a.S - 1) / a.S) * 128;
+  const int n_lo = sp * per, n_hi = (n_lo + per < a.N) ? n_lo + per : a.N;
+  int len = a.N;
+  if (a.lengths != nullptr) len = a.lengths[b] < a.N ? a.lengths[b] : a.N;
+  for (int i = tid; i < DK * 4; i += 256)
+    reinterpret_cast<uint4*>(sTG)[i] = reinterpret_cast<const uint4*>(a.TG + (int64_t)b * DK * 32)[i];
+  if (tid < 16) {
+    sLSE[tid] = a.LSEp[(int64_t)b * 16 + tid];
+    sDel[tid] = a.Delta[(int64_t)b * 16 + tid];
+  }
+  bf16x8 gA[KS], tA[KS];                   // rows r of G' / dT as A operands [row = r][k = c]
+#pragma unroll
+  for (int ks = 0; ks < KS; ++ks) {
+    gA[ks] = *reinterpret_cast<const bf16x8*>(a.Gb + (int64_t)r * DK + 32 * ks + 8 * g);
+    tA[ks] = *reinterpret_cast<const bf16x8*>(a.dTb + ((int64_t)b * 16 + r) * DK + 32 * ks + 8 * g);
+  }
+  __syncthreads();
+  const float4 l4 = *reinterpret_cast<const float4*>(&sLSE[4 * g]);
+  const float4 d4 = *reinterpret_cast<const float4*>(&sDel[4 * g]);
+  const float lse[4] = {l4.x, l4.y, l4.z, l4.w}, del[4] = {d4.x, d4.y, d4.z, d4.w};
+  char* myX = sX + wave * TB;
+  char* myDS = sDS + wave * 32 * PD;
+  f32x4 dG[FT];
+#pragma unroll
+  for (int ft = 0; ft < FT; ++ft) dG[ft] = f32x4{0.f, 0.f, 0.f, 0.f};
+  constexpr float LN2 = 0.6931471805599453f;
+  for (int n0 = n_lo + wave * 32; n0 < n_hi; n0 += 128) {
+#pragma unroll
+    for (int e = 0; e < 16; ++e) {
+      const int c = lane + 64 * e, row = c >> 5, ch = c & 31;
+      bf16x8 v;
+      if (n0 + row < n_hi) {
+        v = *reinterpret_cast<const bf16x8*>(a.X + ((int64_t)b * a.N + n0 + row) * DK + ch * 8);
+      } else {
+#pragma unroll
+        for (int k = 0; k < 8; ++k) v[k] = (__bf16)0.f;
+      }
+      *reinterpret_cast<bf16x8*>(myX + tr_off256(row, ch)) = v;
+    }
+    bf16x8 pds[2];                          // B operand [k = (P rows | dS rows)][col = point]
+#pragma unroll
+    for (int pb = 0; pb < 2; ++pb) {
+      f32x4 sv = {0.f, 0.f, 0.f, 0.f}, da = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+      for (int ks = 0; ks < KS; ++ks) {
+        const bf16x8 xr =
+            *reinterpret_cast<const bf16x8*>(myX + tr_off256(16 * pb + r, 4 * ks + g));
+        sv = mfma32(gA[ks], xr, sv);        // rows = score rows 4g+e, column = point 16 pb + r
+        da = mfma32(tA[ks], xr, da);
+      }
+      const bool key = n0 + 16 * pb + r < len;
+      f32x4 p, ds;
+#pragma unroll
+      for (int e = 0; e < 4; ++e) {
+        p[e] = key ? exp2f(sv[e] - lse[e]) : 0.f;
+        ds[e] = LN2 * p[e] * (da[e] - del[e]);
+      }
+      pds[pb] = pack8(p, ds);
+      *reinterpret_cast<bf16x4*>(myDS + (16 * pb + r) * PD + 8 * g) = pack4(ds);
+    }
+    if (a.dX != nullptr) {
+#pragma unroll
+      for (int ft = 0; ft < FT; ++ft) {
+        const bf16x8 tg = *reinterpret_cast<const bf16x8*>(sTG + (16 * ft + r) * 64 + 16 * g);
+#pragma unroll
+        for (int pb = 0; pb < 2; ++pb) {
+          const int n = n0 + 16 * pb + r;
+          f32x4 dx = mfma32(tg, pds[pb], f32x4{0.f, 0.f, 0.f, 0.f});
+          if (n < n_hi) {
+            bf16x4* pd = reinterpret_cast<bf16x4*>(a.dX + ((int64_t)b * a.N + n) * DK + 16 * ft +
+                                                   4 * g);
+            if (a.accumulate_dx) {
+              const f32x4 o = tof(*pd);
+              dx[0] += o[0]; dx[1] += o[1]; dx[2] += o[2]; dx[3] += o[3];
+            }
+            *pd = pack4(dx);
+          }
+        }
+      }
+    }
+    // dG[r][c] += sum_points dS[r][pt] X[pt][c]
+    const bf16x8 dsa = tr_frag_small(myDS, PD, 0, lane);
+#pragma unroll
+    for (int ft = 0; ft < FT; ++ft) dG[ft] = mfma32(dsa, tr_frag256(myX, ft, lane), dG[ft]);
+  }
+  __syncthreads();
+  float* slab = reinterpret_cast<float*>(sX) + wave * 16 * DK;
+#pragma unroll
+  for (int ft = 0; ft < FT; ++ft)
+#pragma unroll
+    for (int e = 0; e < 4; ++e) slab[(4 * g + e) * DK + 16 * ft + r] = dG[ft][e];
+  __syncthreads();
+  const float* s0 = reinterpret_cast<const float*>(sX);
+  for (int i = tid; i < a.R * DK; i += 256)
+    atomicAdd(&a.DG[i], s0[i] + s0[16 * DK + i] + s0[2 * 16 * DK + i] + s0[3 * 16 * DK + i]);
 }
 
 }  // namespace
@@ -1158,7 +1531,7 @@ int fq_attn_bwd256(const __bf16* Kp, const __bf16* Vp, const float* Qp, const fl
 
 int wgrad_small256(const __bf16* G, const float* X, int64_t M, int dq, float* dW, float* db,
                    hipStream_t st) {
-  const int rpw = M >= 65536 ? 2048 : 256;
+  const int rpw = M >= 65536 ? 512 : 128;
   hipLaunchKernelGGL(k_wgrad_small256, dim3((unsigned)cdiv(M, rpw)), dim3(256), 0, st, G, X, M, dq,
                      rpw, dW, db);
   return check_launch("k_wgrad_small256");
@@ -1177,6 +1550,59 @@ int epi_small_bwd256(const float* dO, const float* T, const float* Wv, int B, in
   hipLaunchKernelGGL(k_epi_small_wv, dim3((unsigned)cdiv((int64_t)B * m, 128)), dim3(256), 0, st, dO,
                      T, B, m, dk, 128, dWv, dbv);
   return check_launch("k_epi_small_wv");
+}
+
+int pma_splits256(int B, int N) {
+  int S = 1;
+  const int tiles = (int)cdiv(N, 128);
+  while (S * 2 <= tiles && B * S < 512 && S < 16) S *= 2;
+  return S;
+}
+int pma_attn_fwd256(const __bf16* X, const __bf16* Gb, int B, int N, int R, const int32_t* lengths,
+                    float* Tp, float* Mp, float* Lp, float* T, float* LSE, hipStream_t st) {
+  PmaArgs a{};
+  a.X = X; a.Gb = Gb; a.Tp = Tp; a.Mp = Mp; a.Lp = Lp;
+  a.B = B; a.N = N; a.R = R; a.S = pma_splits256(B, N); a.lengths = lengths;
+  static std::once_flag once;
+  std::call_once(once, [] {
+    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(k_pma_fwd256),
+                              hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+  });
+  hipLaunchKernelGGL(k_pma_fwd256, dim3(B, a.S), dim3(256), 4 * 32 * 256 * 2 + 3 * 64 * sizeof(float),
+                     st, a);
+  PCA_TRY(check_launch("k_pma_fwd256"));
+  hipLaunchKernelGGL(k_pma_merge, dim3((unsigned)cdiv((int64_t)B * R * 256, 256)), dim3(256), 0, st,
+                     Tp, Mp, Lp, B, a.S, R, T, LSE);
+  return check_launch("k_pma_merge");
+}
+int pma_epi_bwd256(const float* dO, const float* T, const float* LSE, const float* Wv,
+                   const float* Gf, int B, int m, int R, __bf16* dTb, __bf16* TG, float* Delta,
+                   float* LSEp, float* dWv, hipStream_t st) {
+  hipLaunchKernelGGL(k_pma_epi_bwd, dim3(B), dim3(256), 0, st, dO, T, LSE, Wv, Gf, m, R, dTb, TG,
+                     Delta, LSEp);
+  PCA_TRY(check_launch("k_pma_epi_bwd"));
+  hipLaunchKernelGGL(k_pma_dwv, dim3(256), dim3(256), 0, st, dO, T, B, m, R, dWv);
+  return check_launch("k_pma_dwv");
+}
+int pma_attn_bwd256(const __bf16* X, const __bf16* Gb, const __bf16* dTb, const __bf16* TG,
+                    const float* LSEp, const float* Delta, int B, int N, int R,
+                    const int32_t* lengths, __bf16* dX, int accumulate_dx, float* DG,
+                    hipStream_t st) {
+  PmaArgs a{};
+  a.X = X; a.Gb = Gb; a.dTb = dTb; a.TG = TG; a.LSEp = LSEp; a.Delta = Delta;
+  a.dX = dX; a.DG = DG; a.accumulate_dx = accumulate_dx;
+  a.B = B; a.N = N; a.R = R; a.lengths = lengths;
+  int S = pma_splits256(B, N);
+  while (S > 1 && B * S > 256) S /= 2;            // ~100 KiB of LDS: one workgroup per CU
+  a.S = S;
+  static std::once_flag once;
+  std::call_once(once, [] {
+    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(k_pma_bwd256),
+                              hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+  });
+  const size_t lds = 4 * 32 * 256 * 2 + 256 * 64 + 4 * 32 * 40 + 32 * sizeof(float);
+  hipLaunchKernelGGL(k_pma_bwd256, dim3(B, S), dim3(256), lds, st, a);
+  return check_launch("k_pma_bwd256");
 }
 
 }  // namespace pca

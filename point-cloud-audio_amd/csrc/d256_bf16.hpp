@@ -48,6 +48,23 @@ int epi_small_fwd256(const float* T, const float* Qp, const float* Wv, const flo
 int epi_small_bwd256(const float* dO, const float* T, const float* Wv, int B, int m, int dk,
                      float* dT, float* Delta, float* dWv, float* dbv, hipStream_t st);
 
+// PMA (R = h*m <= 16 score rows) at dk = 256, reassociated: X read once, keys never projected
+int pma_splits256(int B, int N);
+// Gb [>=16][256] bf16 (sl2e folded, rows >= R zero); Tp [B][S][16][256], Mp / Lp [B][S][16] scratch;
+// T [B][R][256] = A X, LSE [B][R] (log2 domain)
+int pma_attn_fwd256(const __bf16* X, const __bf16* Gb, int B, int N, int R, const int32_t* lengths,
+                    float* Tp, float* Mp, float* Lp, float* T, float* LSE, hipStream_t st);
+// per set: dT = dO_h Wv_h and its images (dTb [B][16][256], TG [B][256][32]), Delta, LSEp [B][16];
+// dWv += sum over sets of dO^T T
+int pma_epi_bwd256(const float* dO, const float* T, const float* LSE, const float* Wv,
+                   const float* Gf, int B, int m, int R, __bf16* dTb, __bf16* TG, float* Delta,
+                   float* LSEp, float* dWv, hipStream_t st);
+// dX (+)= P^T dT + dS^T G' ; DG [16][256] += dS X (ln2 units, as k_mab0_bwd; caller zeroes it)
+int pma_attn_bwd256(const __bf16* X, const __bf16* Gb, const __bf16* dTb, const __bf16* TG,
+                    const float* LSEp, const float* Delta, int B, int N, int R,
+                    const int32_t* lengths, __bf16* dX, int accumulate_dx, float* DG,
+                    hipStream_t st);
+
 // few shared queries (m <= 32) over projected keys, head dim 32
 int fq_splits256(int B, int N);
 // Op [B][S][m][256], Mp / Lp [B][S][8][MQ] scratch; O = Qp + A Vp [B][m][256]; LSE [B][8][MQ]

@@ -2,7 +2,9 @@
 //   mab1_d256_bwd     adjoint of ISAB's mab1(X, H) (modules.py:53 / 19-33): three row-GEMM /
 //                     attention launches + the 256-wide weight-gradient reduction
 //   mab0_d256_*       the few-shared-queries block (ISAB mab0, PMA; modules.py:52,63):
-//                       dk = 256 : keys projected (reference formulation), flash attention per head
+//                       dk = 256, R = h*m <= 16 (PMA): reassociated, X read once (k_pma_*256)
+//                       dk = 256, more queries: keys projected (reference formulation), flash
+//                                  attention per head
 //                       dk <= 4  : reassociated layer-1 kernels (k_mab0_attn_small / _bwd_small)
 //                     with the per-set [B*m]-row epilogues on the GEMM kernel.
 // Activations cross the ABI in fp32 or bf16 (shape.*_dtype); inside, every [B*N, 256] tensor is
@@ -61,6 +63,7 @@ int mab1_d256_bwd(const pca_mab_shape& s, const void* X, const float* Hk, const 
                   const void* saved, const void* dY, void* dX, float* dH, int dk_accumulate,
                   const pca_mab_grads& gr, void* ws, hipStream_t st) {
   PCA_REQUIRE(s.d == D && s.nk == 32 && s.h == H8, "mab1_d256_bwd: shape");
+  Bf16OperandScope ops(true);          // the [B*m]-row GEMMs of the K / V tail: MFMA
   Mab1Saved v;
   mab1_carve_saved(s, &v, const_cast<void*>(saved));
   Mab1D256Ws w;
@@ -128,10 +131,17 @@ bool mab0_d256_supported(const pca_mab_shape& s) {
   return s.dk <= 4 && (R == 64 || R == 128 || R == 256);
 }
 
+// which of the three few-queries paths serves a shape
+enum { FQ_SMALL = 0, FQ_PMA = 1, FQ_PROJ = 2 };
+static inline int fq_path(const pca_mab_shape& s) {
+  return s.dk != D ? FQ_SMALL : (s.h * s.nq <= 16 ? FQ_PMA : FQ_PROJ);
+}
+
 struct Fq256Saved {
-  float *Qp, *O, *Z, *LSE;      // [m][D], [B][m][D] x2, [B][8][MQ] (dk <= 4: [B][R])
-  __bf16 *Kp, *Vp, *Xb;         // dk = 256: [B*N][D]; Xb only when the keys arrive in fp32
-  float *Gf, *T;                // dk <= 4: [R][dk], [B][R][dk]
+  float *Qp, *O, *Z, *LSE;      // [m][D], [B][m][D] x2, [B][8][MQ] (reassociated paths: [B][R])
+  __bf16 *Kp, *Vp, *Xb;         // projected keys: [B*N][D]; Xb only when the keys arrive in fp32
+  float *Gf, *T;                // reassociated paths: [Rp][dk], [B][R][dk]
+  __bf16* Gb;                   // PMA: [32][D]
   float *Op, *Mp, *Lp;          // forward partials per point range
 };
 static size_t fq_carve_saved(const pca_mab_shape& s, Fq256Saved* out, void* base) {
@@ -142,7 +152,7 @@ static size_t fq_carve_saved(const pca_mab_shape& s, Fq256Saved* out, void* base
   v.Qp = c.take<float>((size_t)m * D);
   v.O = c.take<float>(Bm * D);
   v.Z = c.take<float>(Bm * D);
-  if (s.dk == D) {
+  if (fq_path(s) == FQ_PROJ) {
     const int MQ = m > 16 ? 32 : 16, S = fq_splits256(s.B, s.nk);
     v.LSE = c.take<float>((size_t)s.B * H8 * MQ);
     v.Kp = c.take<__bf16>(nelem(s, true));
@@ -151,6 +161,16 @@ static size_t fq_carve_saved(const pca_mab_shape& s, Fq256Saved* out, void* base
     v.Op = c.take<float>((size_t)s.B * S * m * D);
     v.Mp = c.take<float>((size_t)s.B * S * H8 * MQ);
     v.Lp = c.take<float>((size_t)s.B * S * H8 * MQ);
+  } else if (fq_path(s) == FQ_PMA) {
+    const int S = pma_splits256(s.B, s.nk);
+    v.LSE = c.take<float>((size_t)s.B * R);
+    v.Gf = c.take<float>((size_t)32 * D);
+    v.Gb = c.take<__bf16>((size_t)32 * D);
+    v.T = c.take<float>((size_t)s.B * R * D);
+    if (s.k_dtype == PCA_F32) v.Xb = c.take<__bf16>(nelem(s, true));
+    v.Op = c.take<float>((size_t)s.B * S * 16 * D);
+    v.Mp = c.take<float>((size_t)s.B * S * 16);
+    v.Lp = c.take<float>((size_t)s.B * S * 16);
   } else {
     v.LSE = c.take<float>((size_t)s.B * R);
     v.Gf = c.take<float>((size_t)R * s.dk);
@@ -182,11 +202,27 @@ int mab0_d256_fwd(const pca_mab_shape& s, const float* I, const void* X, const p
     a.I = I; a.Wq = p.wq; a.bq = p.bq; a.Wk = p.wk;
     a.m = m; a.d = D; a.dq = s.dq; a.dk = s.dk; a.h = s.h; a.Rp = (int)cdiv(s.h * m, 32) * 32;
     a.sl2e = 1.4426950408889634f / sqrtf((float)D);
-    a.Qp = v.Qp; a.Gf = s.dk == D ? nullptr : v.Gf;
+    a.Qp = v.Qp; a.Gf = fq_path(s) == FQ_PROJ ? nullptr : v.Gf;
+    a.Gb = fq_path(s) == FQ_PMA ? v.Gb : nullptr;
     J.j[J.n++] = a;
     PCA_TRY(mab0_prep_launch(J, st));
   }
-  if (s.dk == D) {
+  if (fq_path(s) == FQ_PMA) {
+    const __bf16* Xb = reinterpret_cast<const __bf16*>(X);
+    if (s.k_dtype == PCA_F32) {
+      PCA_TRY(cvt_f32_bf16(reinterpret_cast<const float*>(X), v.Xb, M * D, st));
+      Xb = v.Xb;
+    }
+    const double pts = (double)M;
+    {
+      // reference-formulation FLOPs (fc_k, fc_v over the keys + QK^T + AV); X read once
+      ProfScope ps(PCA_K_MAB0_FWD, st, 2.0 * pts * (2.0 * D * D + 2.0 * m * D), pts * 2.0 * D);
+      PCA_TRY(pma_attn_fwd256(Xb, v.Gb, s.B, s.nk, s.h * m, s.k_lengths, v.Op, v.Mp, v.Lp, v.T,
+                              v.LSE, st));
+      ps.end();
+    }
+    PCA_TRY(epi_small_fwd256(v.T, v.Qp, p.wv, p.bv, s.B, m, D, v.O, st));
+  } else if (fq_path(s) == FQ_PROJ) {
     const __bf16* Xb = reinterpret_cast<const __bf16*>(X);
     if (s.k_dtype == PCA_F32) {
       PCA_TRY(cvt_f32_bf16(reinterpret_cast<const float*>(X), v.Xb, M * D, st));
@@ -211,7 +247,8 @@ int mab0_d256_fwd(const pca_mab_shape& s, const float* I, const void* X, const p
 }
 
 struct Fq256BwdWs {
-  __bf16 *WkTP, *WvTP, *dKp, *dVp, *dXb;
+  __bf16 *WkTP, *WvTP, *dKp, *dVp, *dXb, *dTb, *TG;
+  float* LSEp;
   float *dZ, *dO, *dOt, *Delta, *dQpPart, *dTf, *DG, *dQp;
   void* wg;
 };
@@ -224,7 +261,14 @@ static size_t fq_carve_bwd(const pca_mab_shape& s, Fq256BwdWs* out, void* base) 
   w.dO = c.take<float>(Bm * D);
   w.dOt = c.take<float>(Bm * D);
   w.dQp = c.take<float>((size_t)m * D);
-  if (s.dk == D) {
+  if (fq_path(s) == FQ_PMA) {
+    if (s.k_dtype == PCA_F32) w.dXb = c.take<__bf16>(nelem(s, true));
+    w.Delta = c.take<float>((size_t)s.B * 16);
+    w.LSEp = c.take<float>((size_t)s.B * 16);
+    w.dTb = c.take<__bf16>((size_t)s.B * 16 * D);
+    w.TG = c.take<__bf16>((size_t)s.B * D * 32);
+    w.DG = c.take<float>((size_t)16 * D);
+  } else if (s.dk == D) {
     const int MQ = m > 16 ? 32 : 16, S = fq_splits256(s.B, s.nk);
     w.WkTP = c.take<__bf16>((size_t)D * D);
     w.WvTP = c.take<__bf16>((size_t)D * D);
@@ -268,7 +312,27 @@ int mab0_d256_bwd(const pca_mab_shape& s, const float* I, const void* X, const p
   pj.Qp = v.Qp; pj.Wk = p.wk; pj.I = I; pj.Wq = p.wq;
   pj.dWk = gr.wk; pj.dQp = w.dQp; pj.dWq = gr.wq; pj.dbq = gr.bq; pj.dI = dI;
   pj.m = m; pj.d = D; pj.dk = s.dk; pj.dq = s.dq; pj.h = s.h; pj.sl2e = sl2e; pj.B = s.B;
-  if (s.dk == D) {
+  if (fq_path(s) == FQ_PMA) {
+    const __bf16* Xb = s.k_dtype == PCA_F32 ? v.Xb : reinterpret_cast<const __bf16*>(X);
+    PCA_TRY(fill_zero(w.DG, (int64_t)16 * D, st));
+    PCA_TRY(pma_epi_bwd256(w.dO, v.T, v.LSE, p.wv, v.Gf, s.B, m, R, w.dTb, w.TG, w.Delta, w.LSEp,
+                           gr.wv, st));
+    PCA_TRY(colsum(w.dO, Bm, D, gr.bv, 1, st));
+    const bool f32 = s.k_dtype == PCA_F32;
+    __bf16* dXb = dX == nullptr ? nullptr : (f32 ? w.dXb : reinterpret_cast<__bf16*>(dX));
+    const double pts = (double)M;
+    {
+      ProfScope ps(PCA_K_MAB0_BWD, st, 4.0 * pts * (2.0 * D * D + 2.0 * m * D),
+                   pts * 2.0 * D * (1.0 + (dX != nullptr ? (dk_accumulate ? 2.0 : 1.0) : 0.0)));
+      PCA_TRY(pma_attn_bwd256(Xb, v.Gb, w.dTb, w.TG, w.LSEp, w.Delta, s.B, s.nk, R, s.k_lengths,
+                              dXb, (!f32 && dk_accumulate) ? 1 : 0, w.DG, st));
+      ps.end();
+    }
+    if (dX != nullptr && f32)
+      PCA_TRY(cvt_bf16_f32(dXb, reinterpret_cast<float*>(dX), M * D, dk_accumulate ? 1 : 0, st));
+    pj.DG = w.DG;
+    pj.dO = w.dO;
+  } else if (s.dk == D) {
     const __bf16* Xb = s.k_dtype == PCA_F32 ? v.Xb : reinterpret_cast<const __bf16*>(X);
     const double pts = (double)M;
     {

@@ -202,6 +202,13 @@ int mab_f32_bwd(const pca_mab_shape& s, const float* Q, const float* K,
                 const pca_mab_params& p, const void* saved, const float* dY, float* dQ,
                 float* dK, int dk_accumulate, const pca_mab_grads& g, void* ws,
                 hipStream_t st);
+// while alive: linear_fwd_f32 / linear_bwd_f32 / linear_dx_acc_f32 use k_gemm_bf16 (bf16 MFMA
+// operands, fp32 accumulation and I/O) instead of the exact fp32 GEMM
+struct Bf16OperandScope {
+  bool prev;
+  explicit Bf16OperandScope(bool on);
+  ~Bf16OperandScope();
+};
 int linear_fwd_f32(const float* X, const float* W, const float* b, float* Y, int64_t M,
                    int din, int dout, hipStream_t st);
 int linear_bwd_f32(const float* X, const float* W, const float* dY, float* dX, float* dW,

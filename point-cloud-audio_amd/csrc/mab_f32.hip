@@ -281,6 +281,11 @@ int mab_f32_bwd(const pca_mab_shape& s, const float* Q, const float* K,
   return PCA_OK;
 }
 
+// Scope guard for callers outside this file (the d = 256 blocks): the linear_* helpers below run
+// their GEMMs with bf16 MFMA operands while one is alive on the calling thread.
+Bf16OperandScope::Bf16OperandScope(bool on) : prev(t_bf16_operands) { t_bf16_operands = on; }
+Bf16OperandScope::~Bf16OperandScope() { t_bf16_operands = prev; }
+
 // ---- classifier head ----------------------------------------------------------
 int linear_fwd_f32(const float* X, const float* W, const float* b, float* Y, int64_t M,
                    int din, int dout, hipStream_t st) {

@@ -176,7 +176,8 @@ MAB0_CASES = [      # B, N, m, dk, d, h   (query = learned [m, d], shared by all
     (2, 1, 16, 128, 128, 4),        # a single key
     # d = 256 / 8 heads (BASELINE configs[3]): keys projected, flash attention per head
     (3, 200, 32, 256, 256, 8),      # ISAB mab0, ragged N
-    (4, 130, 1, 256, 256, 8),       # PMA: one seed (one query tile, 15 padding queries)
+    (4, 130, 1, 256, 256, 8),       # PMA: one seed, 8 score rows, reassociated (X read once)
+    (2, 515, 2, 256, 256, 8),       # two seeds: all 16 score rows live, ragged N
     (2, 300, 16, 256, 256, 8),      # 16 queries: the 16x16x16 products of the backward
     (2, 77, 32, 3, 256, 8),         # layer 1: reassociated fp32 kernels, 256 score rows
     (2, 1, 32, 256, 256, 8),        # a single key
@@ -219,7 +220,7 @@ def mab0_forward_bf16emu(I, X, p, h):
     dh = d // h
     sl2e = math.log2(math.e) / math.sqrt(d)
     Qp = I[0] @ p["fc_q.weight"].t() + p["fc_q.bias"]                  # [m, d]
-    if d == 256 and dk == 256:
+    if d == 256 and dk == 256 and h * m > 16:
         Xb = rb(X)
         Kp = rb(Xb @ rb(p["fc_k.weight"]).t() + p["fc_k.bias"]).view(B, N, h, dh)
         Vp = rb(Xb @ rb(p["fc_v.weight"]).t() + p["fc_v.bias"]).view(B, N, h, dh)
