@@ -68,30 +68,50 @@ __device__ __forceinline__ bf16x4 zero4b() {
 
 // =====================================================================================
 // k_rowgemm: Out^T[f][pt] = sum_k W[f][k] In^T[k][pt]  with the [D][D] bf16 weight image resident
-// in LDS (K-permuted rows: the B operand comes from accumulator-layout registers, pack8) and one
+// in LDS (K-permuted rows: the B operand comes from accumulator-layout registers, cat8) and one
 // 32-point tile per wave.  Same unit / wave -> point mapping as k_mab1_fwd (the ReLU mask index).
+//
+// Global traffic is full 128-byte lines: a wave moves its [32 rows][256] bf16 tile in four
+// 64-column chunks through a private 4 KiB LDS buffer - 16-byte coalesced loads / stores on the
+// memory side (8 lanes = one 128-byte row segment), 8-byte accumulator-layout accesses on the LDS
+// side.  (Accumulator-layout accesses straight to global memory touch 32 bytes of 16 different
+// rows per instruction; with 8 waves x 16 KiB of rows in flight the 32 KiB L1 re-fetched every
+// line up to four times: measured 209 -> see DESIGN.md.)
 // =====================================================================================
-enum { RG_PROJ = 0, RG_BWD_O = 1, RG_BWD_Q = 2 };
+enum { RG_PROJ = 0, RG_BWD_O = 1, RG_BWD_Q = 2, RG_FWD_O = 3 };
 
 struct RowGemmArgs {
-  const __bf16* In;       // [B*N][D]: PROJ X ; BWD_O dY ; BWD_Q dQp (or dKp / dVp)
+  const __bf16* In;       // [B*N][D]: PROJ X ; BWD_O dY ; BWD_Q dQp (or dKp / dVp) ; FWD_O O
   const __bf16* W;        // [D][D] image (see the launcher for which)
-  const float* bias;      // PROJ
+  const float* bias;      // PROJ, FWD_O
   const uint32_t* mask;   // BWD_O: ReLU mask bits of the forward
-  __bf16* Out;            // PROJ Y ; BWD_O dO ; BWD_Q dX
+  uint32_t* mask_out;     // FWD_O (nullable)
+  __bf16* Out;            // PROJ Y ; BWD_O dO ; BWD_Q dX ; FWD_O Y
   __bf16* Out2;           // BWD_O: dZ
   int B, N, tiles_per_set, accumulate;
 };
 
-template <int D, int MODE>
-__global__ __launch_bounds__(512, 2) void k_rowgemm(const RowGemmArgs a) {
-  constexpr int NW = 8, NT = 64 * NW, SUBS = 2;
-  constexpr int DT = D / 16, KS = D / 32, ROWB = D * 2;
+// byte offset of 16-byte piece c16 (0..7) of row `row` in a [32][64] bf16 chunk (128-byte rows);
+// the XOR spreads the 16 rows of an accumulator-layout access over all banks
+__device__ __forceinline__ int cko(int row, int c16) {
+  return row * 128 + ((c16 ^ ((row >> 1) & 7)) << 4);
+}
+
+// NB = 16-point blocks per wave: 2 (8 waves, 256 VGPRs) or 1 (16 waves of 128 VGPRs: four
+// wavefronts per SIMD to hide the memory latency, twice the LDS weight reads per MFMA)
+template <int D, int MODE, int NB>
+__global__ __launch_bounds__(1024 / NB, 4 / NB) void k_rowgemm(const RowGemmArgs a) {
+  constexpr int NW = 16 / NB, NT = 64 * NW, SUBS = 2;
+  constexpr int DT = D / 16, KS = D / 32, ROWB = D * 2, NCH = D / 64;
+  constexpr int CB = 16 * NB * 128;       // bytes of a wave's chunk buffer ([16 NB rows][64])
   extern __shared__ __attribute__((aligned(16))) char smem[];
   char* sW = smem;
-  const int tid = threadIdx.x, lane = tid & 63, wave8 = tid >> 6;
-  const int wave = wave8 & 3, sub = wave8 >> 2;
+  const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
+  // wave wv of the workgroup = 16-point blocks [wv * NB, wv * NB + NB) of a 256-point unit; in the
+  // forward's terms (mask index): tile `sub` of the unit, wave (0..3), block nb0 + nb of that wave
+  const int blk0 = wv * NB, sub = blk0 >> 3, wave = (blk0 & 7) >> 1, nb0 = blk0 & 1;
   const int r = lane & 15, g = lane >> 4;
+  char* myC = smem + D * ROWB + wv * CB;
   {
     constexpr int NC = D * (D / 8) / NT;
     uint4 wv[NC];
@@ -109,93 +129,188 @@ __global__ __launch_bounds__(512, 2) void k_rowgemm(const RowGemmArgs a) {
   __syncthreads();
   const int units_per_set = (a.tiles_per_set + SUBS - 1) / SUBS;
   const int total_units = a.B * units_per_set;
+  // coalesced side of the chunk moves: piece i of a lane = row (lane + 64 i) / 8, 16-byte column
+  // (lane + 64 i) % 8; accumulator side: row 16 nb + r, 8 bytes at columns 16 t' + 4 g
+  const int crow0 = lane >> 3, cc16 = lane & 7;
   for (int unit = blockIdx.x; unit < total_units; unit += gridDim.x) {
     const int b = unit / units_per_set, tile = (unit - b * units_per_set) * SUBS + sub;
     if (tile >= a.tiles_per_set) continue;                 // (no barrier inside the loop)
-    const int n_base = tile * TP + wave * 32;
-    bool live[NB];
-    int64_t row[NB];
-#pragma unroll
-    for (int nb = 0; nb < NB; ++nb) {
-      const int n = n_base + 16 * nb + r;
-      live[nb] = n < a.N;
-      row[nb] = (int64_t)b * a.N + (live[nb] ? n : 0);
-    }
-    f32x4 acc[DT][NB];
+    const int n_base = tile * TP + wave * 32 + nb0 * 16;
+    const int64_t rowbase = (int64_t)b * a.N + n_base;
+    const int nlive = a.N - n_base;                        // rows of this wave tile that exist
+    // FWD_O keeps O (the bf16 B operand) alive for the residual: its output features are
+    // computed in two halves of 128 so that the accumulators need 64 registers, not 128
+    constexpr int HT = 1, DTH = DT / HT;
+    f32x4 acc[DTH][NB];
     bf16x8 bop[KS][NB];
+    uint32_t bits[NB][D / 128];
+    if (MODE == RG_BWD_O) {
 #pragma unroll
-    for (int nb = 0; nb < NB; ++nb) {
-      uint32_t bits[D / 128];
-      if (MODE == RG_BWD_O) {
+      for (int nb = 0; nb < NB; ++nb)
 #pragma unroll
         for (int w = 0; w < D / 128; ++w)
-          bits[w] = a.mask[mab1_mask_index<D>(b, a.tiles_per_set, tile, wave, nb, w, lane)];
+          bits[nb][w] = a.mask[mab1_mask_index<D>(b, a.tiles_per_set, tile, wave, nb0 + nb, w, lane)];
+    }
+    constexpr int NI = 2 * NB;             // 16-byte pieces per lane and chunk
+    uint4 st[2][NI];
+    auto fetch = [&](int c, uint4 (&dst)[NI]) {
+#pragma unroll
+      for (int i = 0; i < NI; ++i) {
+        const int row = crow0 + 8 * i;
+        dst[i] = row < nlive
+                     ? *reinterpret_cast<const uint4*>(a.In + (rowbase + row) * D + 64 * c + 8 * cc16)
+                     : uint4{0u, 0u, 0u, 0u};
       }
-      bf16x4 in4[DT];
+    };
+    fetch(0, st[0]);
 #pragma unroll
-      for (int t = 0; t < DT; ++t)
-        in4[t] = live[nb] ? *reinterpret_cast<const bf16x4*>(a.In + row[nb] * D + 16 * t + 4 * g)
-                          : zero4b();
+    for (int c = 0; c < NCH; ++c) {
+      if (c + 1 < NCH) fetch(c + 1, st[(c + 1) & 1]);
 #pragma unroll
-      for (int t = 0; t < DT; ++t) {
-        if (MODE == RG_BWD_O) {
-          const f32x4 v = tof(in4[t]);
-          acc[t][nb] = v;                                   // dO starts as dY (residual path)
-          bf16x4 z4;
+      for (int i = 0; i < NI; ++i)
+        *reinterpret_cast<uint4*>(myC + cko(crow0 + 8 * i, cc16)) = st[c & 1][i];
+      bf16x4 in4[4][NB];
 #pragma unroll
-          for (int e = 0; e < 4; ++e)
-            z4[e] = ((bits[t / 8] >> ((t & 7) * 4 + e)) & 1u) ? in4[t][e] : (__bf16)0.f;
-          in4[t] = z4;
-          if (live[nb])
-            *reinterpret_cast<bf16x4*>(a.Out2 + row[nb] * D + 16 * t + 4 * g) = z4;
-        } else if (MODE == RG_PROJ) {
-          const float4 b4 = *reinterpret_cast<const float4*>(a.bias + 16 * t + 4 * g);
-          acc[t][nb] = f32x4{b4.x, b4.y, b4.z, b4.w};
-        } else {
-          acc[t][nb] = f32x4{0.f, 0.f, 0.f, 0.f};
+      for (int tq = 0; tq < 4; ++tq)
+#pragma unroll
+        for (int nb = 0; nb < NB; ++nb)
+          in4[tq][nb] = *reinterpret_cast<const bf16x4*>(myC + cko(16 * nb + r, 2 * tq + (g >> 1)) +
+                                                        8 * (g & 1));
+#pragma unroll
+      for (int tq = 0; tq < 4; ++tq) {
+        const int t = 4 * c + tq;
+#pragma unroll
+        for (int nb = 0; nb < NB; ++nb) {
+          if constexpr (MODE == RG_BWD_O) {
+            acc[t][nb] = tof(in4[tq][nb]);                  // dO starts as dY (residual path)
+            bf16x4 z4;
+#pragma unroll
+            for (int e = 0; e < 4; ++e)
+              z4[e] = ((bits[nb][t / 8] >> ((t & 7) * 4 + e)) & 1u) ? in4[tq][nb][e] : (__bf16)0.f;
+            in4[tq][nb] = z4;
+            // dZ goes back through the chunk buffer to leave in full lines
+            *reinterpret_cast<bf16x4*>(myC + cko(16 * nb + r, 2 * tq + (g >> 1)) + 8 * (g & 1)) = z4;
+          }
         }
       }
 #pragma unroll
-      for (int s = 0; s < KS; ++s) bop[s][nb] = cat8(in4[2 * s], in4[2 * s + 1]);
-    }
+      for (int nb = 0; nb < NB; ++nb) {
+        bop[2 * c][nb] = cat8(in4[0][nb], in4[1][nb]);
+        bop[2 * c + 1][nb] = cat8(in4[2][nb], in4[3][nb]);
+      }
+      if (MODE == RG_BWD_O) {
 #pragma unroll
-    for (int s = 0; s < KS; ++s) {
-#pragma unroll
-      for (int t = 0; t < DT; ++t) {
-        const bf16x8 wa = *reinterpret_cast<const bf16x8*>(sW + swz(16 * t + r, 4 * s + g, ROWB));
-#pragma unroll
-        for (int nb = 0; nb < NB; ++nb) acc[t][nb] = mfma32(wa, bop[s][nb], acc[t][nb]);
+        for (int i = 0; i < NI; ++i) {
+          const int row = crow0 + 8 * i;
+          const uint4 v = *reinterpret_cast<const uint4*>(myC + cko(row, cc16));
+          if (row < nlive)
+            *reinterpret_cast<uint4*>(a.Out2 + (rowbase + row) * D + 64 * c + 8 * cc16) = v;
+        }
       }
     }
+    // FWD_O: Y = O + relu(Z) - O is the bf16 B operand itself (feature 16 t + 4 g + e = element
+    // 4 (t & 1) + e of k-block t / 2); ReLU mask bits in the layout of k_mab1_fwd
+    uint32_t mb[NB][D / 128];
 #pragma unroll
     for (int nb = 0; nb < NB; ++nb)
-      if (live[nb]) {
 #pragma unroll
-        for (int t = 0; t < DT; ++t) {
-          bf16x4* pd = reinterpret_cast<bf16x4*>(a.Out + row[nb] * D + 16 * t + 4 * g);
-          f32x4 v = acc[t][nb];
-          if (MODE == RG_BWD_Q && a.accumulate) {
-            const f32x4 o = tof(*pd);
-            v[0] += o[0]; v[1] += o[1]; v[2] += o[2]; v[3] += o[3];
-          }
-          *pd = pack4(v);
+      for (int w = 0; w < D / 128; ++w) mb[nb][w] = 0u;
+#pragma unroll
+    for (int hf = 0; hf < HT; ++hf) {
+      if (MODE != RG_BWD_O) {
+#pragma unroll
+        for (int tt = 0; tt < DTH; ++tt) {
+          float4 b4 = float4{0.f, 0.f, 0.f, 0.f};
+          if (MODE == RG_PROJ || MODE == RG_FWD_O)
+            b4 = *reinterpret_cast<const float4*>(a.bias + 16 * (hf * DTH + tt) + 4 * g);
+#pragma unroll
+          for (int nb = 0; nb < NB; ++nb) acc[tt][nb] = f32x4{b4.x, b4.y, b4.z, b4.w};
         }
       }
+#pragma unroll
+      for (int s = 0; s < KS; ++s) {
+#pragma unroll
+        for (int tt = 0; tt < DTH; ++tt) {
+          const bf16x8 wa = *reinterpret_cast<const bf16x8*>(
+              sW + swz(16 * (hf * DTH + tt) + r, 4 * s + g, ROWB));
+#pragma unroll
+          for (int nb = 0; nb < NB; ++nb) acc[tt][nb] = mfma32(wa, bop[s][nb], acc[tt][nb]);
+        }
+      }
+#pragma unroll
+      for (int cc = 0; cc < NCH / HT; ++cc) {
+        const int c = hf * (NCH / HT) + cc;
+#pragma unroll
+        for (int tq = 0; tq < 4; ++tq) {
+          const int t = 4 * c + tq, tt = t - hf * DTH;
+#pragma unroll
+          for (int nb = 0; nb < NB; ++nb) {
+            f32x4 v = acc[tt][nb];
+            if (MODE == RG_FWD_O) {
+              const bf16x8 ob = bop[t / 2][nb];
+              const f32x4 of = tof((t & 1) ? __builtin_shufflevector(ob, ob, 4, 5, 6, 7)
+                                           : __builtin_shufflevector(ob, ob, 0, 1, 2, 3));
+#pragma unroll
+              for (int e = 0; e < 4; ++e) {
+                const float zz = v[e];
+                if (zz > 0.f) mb[nb][t / 8] |= 1u << ((t & 7) * 4 + e);
+                v[e] = of[e] + fmaxf(zz, 0.f);
+              }
+            }
+            if (MODE == RG_BWD_Q && a.accumulate) {
+              const int n = 16 * nb + r;
+              if (n < nlive) {
+                const f32x4 o = tof(*reinterpret_cast<const bf16x4*>(a.Out + (rowbase + n) * D +
+                                                                     16 * t + 4 * g));
+                v[0] += o[0]; v[1] += o[1]; v[2] += o[2]; v[3] += o[3];
+              }
+            }
+            *reinterpret_cast<bf16x4*>(myC + cko(16 * nb + r, 2 * tq + (g >> 1)) + 8 * (g & 1)) =
+                pack4(v);
+          }
+        }
+#pragma unroll
+        for (int i = 0; i < NI; ++i) {
+          const int row = crow0 + 8 * i;
+          const uint4 v = *reinterpret_cast<const uint4*>(myC + cko(row, cc16));
+          if (row < nlive)
+            *reinterpret_cast<uint4*>(a.Out + (rowbase + row) * D + 64 * c + 8 * cc16) = v;
+        }
+      }
+    }
+    if (MODE == RG_FWD_O && a.mask_out != nullptr) {
+#pragma unroll
+      for (int nb = 0; nb < NB; ++nb)
+#pragma unroll
+        for (int w = 0; w < D / 128; ++w)
+          a.mask_out[mab1_mask_index<D>(b, a.tiles_per_set, tile, wave, nb0 + nb, w, lane)] =
+              mb[nb][w];
+    }
   }
 }
 
-template <int MODE>
-int launch_rowgemm(const RowGemmArgs& a, hipStream_t st) {
+template <int MODE, int NBW>
+int launch_rowgemm_nb(const RowGemmArgs& a, hipStream_t st) {
   constexpr int D = 256;
   static std::once_flag once;
   std::call_once(once, [] {
-    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(k_rowgemm<D, MODE>),
+    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(k_rowgemm<D, MODE, NBW>),
                               hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
   });
   const int total = a.B * ((a.tiles_per_set + 1) / 2);
   const int grid = total < 256 ? total : 256;
-  hipLaunchKernelGGL((k_rowgemm<D, MODE>), dim3(grid), dim3(512), (size_t)D * D * 2, st, a);
+  hipLaunchKernelGGL((k_rowgemm<D, MODE, NBW>), dim3(grid), dim3(1024 / NBW),
+                     (size_t)D * D * 2 + 8 * 4096, st, a);
   return check_launch("k_rowgemm");
+}
+template <int MODE>
+int launch_rowgemm(const RowGemmArgs& a, hipStream_t st) {
+  // PCA_ROWGEMM_NB=2: the 8-wave variant (A/B measurements)
+  static const int nbw = [] {
+    const char* e = getenv("PCA_ROWGEMM_NB");
+    return (e != nullptr && e[0] == '2') ? 2 : 1;
+  }();
+  return nbw == 2 ? launch_rowgemm_nb<MODE, 2>(a, st) : launch_rowgemm_nb<MODE, 1>(a, st);
 }
 
 // =====================================================================================
@@ -386,6 +501,21 @@ __device__ __forceinline__ bf16x8 tr_frag256(const char* img, int t, int lane) {
 // (G features 64 (w >> 1) .., A features 128 (w & 1) ..): 4 + 8 transposed fragments feed 32 MFMAs
 // per 32-row tile.  The fp32 block leaves as a slab ([nwg][D][D]); k_wgrad256_sum adds the slabs
 // of a job into dW in a fixed order (no atomics: the result is reproducible run to run).
+__device__ __forceinline__ bf16x8 ld8(const __bf16* p) {
+  return *reinterpret_cast<const bf16x8*>(p);
+}
+__device__ __forceinline__ bf16x8 ld8(const float* p) {
+  const float4 lo = reinterpret_cast<const float4*>(p)[0], hi = reinterpret_cast<const float4*>(p)[1];
+  bf16x8 v;
+  v[0] = (__bf16)lo.x; v[1] = (__bf16)lo.y; v[2] = (__bf16)lo.z; v[3] = (__bf16)lo.w;
+  v[4] = (__bf16)hi.x; v[5] = (__bf16)hi.y; v[6] = (__bf16)hi.z; v[7] = (__bf16)hi.w;
+  return v;
+}
+
+// T: element type of G and A in memory (bf16, or fp32 rounded to bf16 while staged: the [B*m]-row
+// reductions of the per-set epilogues).  Two tiles are in flight per thread (registers) while a
+// third is consumed from LDS: one 32-row tile (32 KiB) ahead per CU was latency-bound at 2.6 TB/s.
+template <typename T>
 __global__ __launch_bounds__(512, 2) void k_wgrad256(const Wgrad256Jobs jobs, int rows_per_wg,
                                                     float* __restrict__ slabs,
                                                     float* __restrict__ bslabs) {
@@ -394,8 +524,8 @@ __global__ __launch_bounds__(512, 2) void k_wgrad256(const Wgrad256Jobs jobs, in
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int r = lane & 15, g = lane >> 4;
   const Wgrad256Job job = jobs.j[blockIdx.y];
-  const __bf16* __restrict__ G = job.G;
-  const __bf16* __restrict__ A = job.A;
+  const T* __restrict__ G = reinterpret_cast<const T*>(job.G);
+  const T* __restrict__ A = reinterpret_cast<const T*>(job.A);
   const int64_t r0 = (int64_t)blockIdx.x * rows_per_wg;
   const int64_t r1 = r0 + rows_per_wg < job.M ? r0 + rows_per_wg : job.M;
   const int gt0 = 4 * (wave >> 1), at0 = 8 * (wave & 1);
@@ -405,37 +535,35 @@ __global__ __launch_bounds__(512, 2) void k_wgrad256(const Wgrad256Jobs jobs, in
 #pragma unroll
     for (int t = 0; t < 8; ++t) acc[i][t] = f32x4{0.f, 0.f, 0.f, 0.f};
   float bs[8] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
-  bf16x8 vg[2], va[2];
-  auto fetch = [&](int64_t base) {
+  bf16x8 vg[2][2], va[2][2];               // [ring slot][piece]
+  auto fetch = [&](int64_t base, bf16x8 (&g2)[2], bf16x8 (&a2)[2]) {
 #pragma unroll
     for (int e = 0; e < 2; ++e) {
       const int c = tid + e * NT, row = c >> 5, ch = c & 31;
       if (base + row < r1) {
-        vg[e] = *reinterpret_cast<const bf16x8*>(G + (base + row) * D + ch * 8);
-        va[e] = *reinterpret_cast<const bf16x8*>(A + (base + row) * D + ch * 8);
+        g2[e] = ld8(G + (base + row) * D + ch * 8);
+        a2[e] = ld8(A + (base + row) * D + ch * 8);
       } else {
 #pragma unroll
-        for (int k = 0; k < 8; ++k) { vg[e][k] = (__bf16)0.f; va[e][k] = (__bf16)0.f; }
+        for (int k = 0; k < 8; ++k) { g2[e][k] = (__bf16)0.f; a2[e][k] = (__bf16)0.f; }
       }
     }
   };
-  if (r0 < r1) fetch(r0);
-  int buf = 0;
-  for (int64_t base = r0; base < r1; base += 32, buf ^= 1) {
+  auto consume = [&](int buf, bf16x8 (&g2)[2], bf16x8 (&a2)[2], int64_t refill) {
     char* sG = lds + buf * 2 * TB;
     char* sA = sG + TB;
 #pragma unroll
     for (int e = 0; e < 2; ++e) {
       const int c = tid + e * NT, row = c >> 5, ch = c & 31;
-      *reinterpret_cast<bf16x8*>(sG + tr_off256(row, ch)) = vg[e];
-      *reinterpret_cast<bf16x8*>(sA + tr_off256(row, ch)) = va[e];
+      *reinterpret_cast<bf16x8*>(sG + tr_off256(row, ch)) = g2[e];
+      *reinterpret_cast<bf16x8*>(sA + tr_off256(row, ch)) = a2[e];
       if (job.db != nullptr) {
 #pragma unroll
-        for (int k = 0; k < 8; ++k) bs[k] += (float)vg[e][k];
+        for (int k = 0; k < 8; ++k) bs[k] += (float)g2[e][k];
       }
     }
     __syncthreads();
-    if (base + 32 < r1) fetch(base + 32);
+    if (refill < r1) fetch(refill, g2, a2);
     bf16x8 ga[4];
 #pragma unroll
     for (int i = 0; i < 4; ++i) ga[i] = tr_frag256(sG, gt0 + i, lane);
@@ -445,6 +573,12 @@ __global__ __launch_bounds__(512, 2) void k_wgrad256(const Wgrad256Jobs jobs, in
 #pragma unroll
       for (int i = 0; i < 4; ++i) acc[i][t] = mfma32(ga[i], ab, acc[i][t]);
     }
+  };
+  if (r0 < r1) fetch(r0, vg[0], va[0]);
+  if (r0 + 32 < r1) fetch(r0 + 32, vg[1], va[1]);
+  for (int64_t base = r0; base < r1; base += 64) {
+    consume(0, vg[0], va[0], base + 64);
+    if (base + 32 < r1) consume(1, vg[1], va[1], base + 96);
   }
   float* slab = slabs + ((int64_t)blockIdx.y * gridDim.x + blockIdx.x) * D * D;
 #pragma unroll
@@ -1389,18 +1523,23 @@ __global__ __launch_bounds__(256, 1) void k_pma_bwd256(const PmaArgs a) {
 // ---- launchers (declared in d256_bf16.hpp) ------------------------------------------------
 int rowgemm256_proj(const __bf16* X, const __bf16* WP, const float* bias, __bf16* Y, int B, int N,
                     hipStream_t st) {
-  RowGemmArgs a{X, WP, bias, nullptr, Y, nullptr, B, N, (int)cdiv(N, TP), 0};
+  RowGemmArgs a{X, WP, bias, nullptr, nullptr, Y, nullptr, B, N, (int)cdiv(N, TP), 0};
   return launch_rowgemm<RG_PROJ>(a, st);
 }
 int rowgemm256_bwd_o(const __bf16* dY, const uint32_t* mask, const __bf16* WoTP, __bf16* dZ,
                      __bf16* dO, int B, int N, hipStream_t st) {
-  RowGemmArgs a{dY, WoTP, nullptr, mask, dO, dZ, B, N, (int)cdiv(N, TP), 0};
+  RowGemmArgs a{dY, WoTP, nullptr, mask, nullptr, dO, dZ, B, N, (int)cdiv(N, TP), 0};
   return launch_rowgemm<RG_BWD_O>(a, st);
 }
 int rowgemm256_dx(const __bf16* G, const __bf16* WTP, __bf16* dX, int B, int N, int accumulate,
                   hipStream_t st) {
-  RowGemmArgs a{G, WTP, nullptr, nullptr, dX, nullptr, B, N, (int)cdiv(N, TP), accumulate};
+  RowGemmArgs a{G, WTP, nullptr, nullptr, nullptr, dX, nullptr, B, N, (int)cdiv(N, TP), accumulate};
   return launch_rowgemm<RG_BWD_Q>(a, st);
+}
+int rowgemm256_fwd_o(const __bf16* O, const __bf16* WoP, const float* bo, __bf16* Y, uint32_t* mask,
+                     int B, int N, hipStream_t st) {
+  RowGemmArgs a{O, WoP, bo, nullptr, mask, Y, nullptr, B, N, (int)cdiv(N, TP), 0};
+  return launch_rowgemm<RG_FWD_O>(a, st);
 }
 
 int attn1_bwd256_parts(int B, int N) {
@@ -1434,7 +1573,8 @@ int attn1_bwd256(const __bf16* dO, const __bf16* QpS, const __bf16* KpP, const _
 // workgroups per job: enough to stream from every CU, few enough that the slab pass (256 KiB per
 // workgroup written + read) stays small against the 1 KiB per row the job reads
 int wgrad256_nwg(int64_t maxM) {
-  int nwg = (int)cdiv(maxM, 1024);
+  // long jobs: one workgroup per CU; short ones ([B*m] rows): 64 rows each
+  int nwg = (int)cdiv(maxM, maxM >= 65536 ? 1024 : 64);
   if (nwg > 256) nwg = 256;
   return nwg < 1 ? 1 : nwg;
 }
@@ -1444,19 +1584,27 @@ size_t wgrad256_ws_bytes(int njobs, int64_t maxM) {
          align256((size_t)njobs * nwg * 256 * sizeof(float));
 }
 int wgrad256_launch(const Wgrad256Jobs& jobs, void* ws, hipStream_t st) {
+  return wgrad256_launch_t(jobs, ws, false, st);
+}
+int wgrad256_launch_t(const Wgrad256Jobs& jobs, void* ws, bool f32_operands, hipStream_t st) {
   if (jobs.n == 0) return PCA_OK;
   int64_t maxM = 0;
   for (int i = 0; i < jobs.n; ++i) maxM = jobs.j[i].M > maxM ? jobs.j[i].M : maxM;
   if (maxM == 0) return PCA_OK;
   const int nwg = wgrad256_nwg(maxM);
-  int rpw = (int)cdiv(cdiv(maxM, nwg), 32) * 32;
+  int rpw = (int)cdiv(cdiv(maxM, nwg), 64) * 64;
   Carver c(ws);
   float* slabs = c.take<float>((size_t)jobs.n * nwg * 256 * 256);
   float* bslabs = c.take<float>((size_t)jobs.n * nwg * 256);
   double rows = 0;
   for (int i = 0; i < jobs.n; ++i) rows += (double)jobs.j[i].M;
   ProfScope ps(PCA_K_WGRAD, st, 2.0 * rows * 256 * 256, 4.0 * rows * 256);
-  hipLaunchKernelGGL(k_wgrad256, dim3(nwg, jobs.n), dim3(512), 0, st, jobs, rpw, slabs, bslabs);
+  if (f32_operands)
+    hipLaunchKernelGGL(k_wgrad256<float>, dim3(nwg, jobs.n), dim3(512), 0, st, jobs, rpw, slabs,
+                       bslabs);
+  else
+    hipLaunchKernelGGL(k_wgrad256<__bf16>, dim3(nwg, jobs.n), dim3(512), 0, st, jobs, rpw, slabs,
+                       bslabs);
   ps.end();
   PCA_TRY(check_launch("k_wgrad256"));
   hipLaunchKernelGGL(k_wgrad256_sum, dim3((256 * 256 + 256 + 255) / 256, jobs.n), dim3(256), 0, st,

@@ -7,6 +7,9 @@ namespace pca {
 // Y = X WP^T + bias   (WP: [256][256] K-permuted image of the nn.Linear weight, prep mode 1)
 int rowgemm256_proj(const __bf16* X, const __bf16* WP, const float* bias, __bf16* Y, int B, int N,
                     hipStream_t st);
+// Y = O + relu(O Wo^T + bo)  (WoP: prep mode 1 of Wo); mask (nullable): ReLU bits for the backward
+int rowgemm256_fwd_o(const __bf16* O, const __bf16* WoP, const float* bo, __bf16* Y, uint32_t* mask,
+                     int B, int N, hipStream_t st);
 // dZ = dY . [Z > 0] (mask bits of k_mab1_fwd) ; dO = dY + dZ Wo   (WoTP: prep mode 2 of Wo)
 int rowgemm256_bwd_o(const __bf16* dY, const uint32_t* mask, const __bf16* WoTP, __bf16* dZ,
                      __bf16* dO, int B, int N, hipStream_t st);
@@ -22,8 +25,8 @@ int attn1_bwd256(const __bf16* dO, const __bf16* QpS, const __bf16* KpP, const _
 
 // dW[256 x 256] += G^T A, db[256] += colsum(G) (nullable); G, A bf16 [M][256]
 struct Wgrad256Job {
-  const __bf16* G;
-  const __bf16* A;
+  const void* G;      // bf16, or fp32 with wgrad256_launch_t(..., f32_operands = true)
+  const void* A;
   float* dW;
   float* db;
   int64_t M;
@@ -34,6 +37,7 @@ struct Wgrad256Jobs {
 };
 size_t wgrad256_ws_bytes(int njobs, int64_t maxM);
 int wgrad256_launch(const Wgrad256Jobs& jobs, void* ws, hipStream_t st);
+int wgrad256_launch_t(const Wgrad256Jobs& jobs, void* ws, bool f32_operands, hipStream_t st);
 
 int cvt_f32_bf16(const float* s, __bf16* d, int64_t n, hipStream_t st);            // n % 4 == 0
 int cvt_bf16_f32(const __bf16* s, float* d, int64_t n, int accumulate, hipStream_t st);

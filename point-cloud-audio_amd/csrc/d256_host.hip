@@ -110,8 +110,12 @@ int mab1_d256_bwd(const pca_mab_shape& s, const void* X, const float* Hk, const 
     PCA_TRY(wgrad_small256(w.dQp, reinterpret_cast<const float*>(X), M, s.dq, gr.wq, gr.bq, st));
   // fc_k / fc_v of the m inducing-point outputs ([B*m] rows) and dH
   const int64_t Mk = (int64_t)s.B * s.nk;
-  PCA_TRY(linear_bwd_f32(Hk, p.wk, w.dKp, nullptr, gr.wk, gr.bk, Mk, D, D, st));
-  PCA_TRY(linear_bwd_f32(Hk, p.wv, w.dVp, nullptr, gr.wv, gr.bv, Mk, D, D, st));
+  {
+    Wgrad256Jobs kv{};
+    kv.j[kv.n++] = Wgrad256Job{w.dKp, Hk, gr.wk, gr.bk, Mk};
+    kv.j[kv.n++] = Wgrad256Job{w.dVp, Hk, gr.wv, gr.bv, Mk};
+    PCA_TRY(wgrad256_launch_t(kv, w.wg, true, st));
+  }
   if (dH != nullptr) {
     PCA_TRY(linear_dx_acc_f32(w.dKp, p.wk, dH, Mk, D, D, dk_accumulate ? 1 : 0, st));
     PCA_TRY(linear_dx_acc_f32(w.dVp, p.wv, dH, Mk, D, D, 1, st));
@@ -261,6 +265,7 @@ static size_t fq_carve_bwd(const pca_mab_shape& s, Fq256BwdWs* out, void* base) 
   w.dO = c.take<float>(Bm * D);
   w.dOt = c.take<float>(Bm * D);
   w.dQp = c.take<float>((size_t)m * D);
+  if (fq_path(s) != FQ_PROJ) w.wg = c.take<char>(wgrad256_ws_bytes(1, (int64_t)Bm));
   if (fq_path(s) == FQ_PMA) {
     if (s.k_dtype == PCA_F32) w.dXb = c.take<__bf16>(nelem(s, true));
     w.Delta = c.take<float>((size_t)s.B * 16);
@@ -304,7 +309,11 @@ int mab0_d256_bwd(const pca_mab_shape& s, const float* I, const void* X, const p
   }
   // ---- epilogue adjoint: H = O + relu(O Wo^T + bo) ----
   PCA_TRY(relu_bwd(dH, v.Z, w.dZ, Bm * D, st));
-  PCA_TRY(linear_bwd_f32(v.O, p.wo, w.dZ, nullptr, gr.wo, gr.bo, Bm, D, D, st));
+  {
+    Wgrad256Jobs ej{};
+    ej.j[ej.n++] = Wgrad256Job{w.dZ, v.O, gr.wo, gr.bo, Bm};
+    PCA_TRY(wgrad256_launch_t(ej, w.wg, true, st));
+  }
   PCA_TRY(copy_rows(dH, Bm, w.dO, Bm, D, st));
   PCA_TRY(linear_dx_acc_f32(w.dZ, p.wo, w.dO, Bm, D, D, 1, st));
   const float sl2e = 1.4426950408889634f / sqrtf((float)D);

@@ -12,6 +12,7 @@
 //
 // Roofline unit: per point 2*(2 d^2 + 2 m d) FLOP forward.
 #include "mab1_bf16.hpp"
+#include "d256_bf16.hpp"
 
 #include <math.h>
 
@@ -206,7 +207,7 @@ __global__ __launch_bounds__(64 * NW, (NW == 8 || D > 128) ? 1 : 2) void k_mab1_
   constexpr int ROWB = D * 2;         // bytes per row of a [.][D] bf16 image
   constexpr bool HAS_WO = PHASE != 1, HAS_KV = PHASE != 2;
   constexpr bool HAS_WQ = !DIN_SMALL && PHASE != 2;
-  static_assert(!(DIN_SMALL && PHASE != 0), "layer 1 runs the whole chain");
+  static_assert(!(DIN_SMALL && PHASE == 2), "layer 1 has no O phase of its own");
   extern __shared__ __attribute__((aligned(16))) char smem[];
   char* sWo = smem;                                   // D x D bf16, swizzled
   char* sKp = sWo + (HAS_WO ? D * ROWB : 0);          // MI x D
@@ -214,7 +215,7 @@ __global__ __launch_bounds__(64 * NW, (NW == 8 || D > 128) ? 1 : 2) void k_mab1_
   char* sWq = sVt + (HAS_KV ? D * MI * 2 : 0);        // D x D (absent when DIN_SMALL)
   char* sX = sWq + (HAS_WQ ? D * ROWB : 0);           // TP x D (PHASE 0, d -> d only)
   // layer 1, d = 128: fc_q's [D][dq <= 4] weights (padded to 4) and bias, fp32
-  constexpr bool WQ_LDS = DIN_SMALL && D == 128;
+  constexpr bool WQ_LDS = DIN_SMALL && (D == 128 || PHASE == 1);
   float* sWqF = reinterpret_cast<float*>(sX);         // [D][4]
   float* sbq = sWqF + D * 4;                          // [D]
 
@@ -552,12 +553,12 @@ int launch_fwd(const Mab1FwdArgs& a, hipStream_t st) {
   // layer 1 (40 KiB of LDS): 4 waves, two workgroups per CU; d -> d (104+ KiB): 8 waves;
   // d = 256 (128 - 160 KiB): one workgroup per CU, 8 waves (layer 1: 4 waves, both the Qp and
   // the Z tiles live in registers)
-  constexpr int NW = D > 128 ? (DS ? 4 : 8) : (DS || MI != 16) ? 4 : 8;
+  constexpr int NW = D > 128 ? ((DS && PHASE == 0) ? 4 : 8) : (DS || MI != 16) ? 4 : 8;
   const size_t wimg = (size_t)D * D * 2, kv = (size_t)MI * D * 2 + (size_t)D * MI * 2;
   const size_t lds = (PHASE != 1 ? wimg : 0) + (PHASE != 2 ? kv : 0) +
                      ((!DS && PHASE != 2) ? wimg : 0) +
                      ((!DS && PHASE == 0) ? (size_t)NW * 32 * D * 2 : 0) +
-                     ((DS && D == 128) ? (size_t)D * 5 * sizeof(float) : 0);
+                     ((DS && (D == 128 || PHASE == 1)) ? (size_t)D * 5 * sizeof(float) : 0);
   static std::once_flag once;
   std::call_once(once, [] {
     (void)hipFuncSetAttribute(
@@ -714,12 +715,19 @@ int mab1_bf16_fwd_ex(const pca_mab_shape& s, const void* X, const float* H,
                  : launch_fwd<128, 16, false, false>(a, st);
   }
   if (d == 256) {          // Q phase + O phase: O meets in the saved / scratch block
-    if (small)
-      return abf ? launch_fwd<256, 32, true, true>(a, st) : launch_fwd<256, 32, true, false>(a, st);
+    if (small && !abf) return launch_fwd<256, 32, true, false>(a, st);
     a.OS = v.OS;
     if (abf) {
-      PCA_TRY((launch_fwd<256, 32, false, true, 1>(a, st)));
-      return launch_fwd<256, 32, false, true, 2>(a, st);
+      // bf16 activations: the O phase is the row-GEMM kernel of d256_bf16.hip (full-line I/O);
+      // layer 1 runs its Q phase without any weight image (8 waves, 32 KiB of LDS)
+      if (small) PCA_TRY((launch_fwd<256, 32, true, true, 1>(a, st)));
+      else PCA_TRY((launch_fwd<256, 32, false, true, 1>(a, st)));
+      const double pts = (double)s.B * s.nq;
+      ProfScope ps(PCA_K_MAB1_FWD, st, 2.0 * pts * d * d, pts * 4.0 * d);
+      const int rc = rowgemm256_fwd_o(v.OS, WoP, p.bo, reinterpret_cast<__bf16*>(Y), a.mask, s.B,
+                                      s.nq, st);
+      ps.end();
+      return rc;
     }
     PCA_TRY((launch_fwd<256, 32, false, false, 1>(a, st)));
     return launch_fwd<256, 32, false, false, 2>(a, st);
