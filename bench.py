@@ -41,13 +41,18 @@ CONFIGS = {
                  desc="BASELINE configs[2]: 3-D temporal point sets N=2048, ST d=128 h=4 m=16"),
     "cfg4": dict(din=3, n_fft=1024, ntemp=8, d=256, h=8, m=32, C=50, B=128, sets_per_clip=53,
                  desc="BASELINE configs[3] shape: N=4096, ST d=256 h=8 m=32"),
+    "cfg5": dict(din=3, n_fft=1024, ntemp=8, d=256, h=8, m=32, C=10, B=128, sets_per_clip=26,
+                 varlen=True,
+                 desc="BASELINE configs[4] shape: UrbanSound8K-shaped clips of 1-4 s (padded "
+                      "variable-size sets, N <= 4096), ST d=256 h=8 m=32, 10 classes"),
     "fst": dict(din=2, n_fft=2048, ntemp=1, d=64, h=8, m=64, C=10, B=128, sets_per_clip=216,
                 desc="shipped FST shape: N=1025, ST d=64 h=8 m=64"),
     "3st": dict(din=3, n_fft=1024, ntemp=10, d=64, h=8, m=64, C=10, B=16, sets_per_clip=43,
                 desc="shipped 3ST shape: N=5120, ST d=64 h=8 m=64"),
 }
 FS = 44100
-MFMA_BF16_PEAK_TFLOPS = 2500.0     # MI355X_MICROARCH.md: ~2.5 PF dense bf16
+MFMA_BF16_PEAK_TFLOPS = 2500.0     # MI355X_MICROARCH.md: ~2.5 PF dense bf16 (non-scaled fp8 MFMA
+                                   # issues at the same rate: same peak for the fp8 mode here)
 FP32_VALU_PEAK_TFLOPS = 157.3
 HBM_PEAK_GBS = 8000.0
 
@@ -84,15 +89,27 @@ def build_dataset(cfg, n_clips, dev, seed):
     F = n_fft // 2 if drop else n_fft // 2 + 1
     specs, labels = [], []
     t_stft = 0.0
+    varlen = bool(cfg.get("varlen"))
+    nt_valid = []
     for i in range(n_clips):
         cls = (seed * 7919 + i) % C_
-        wave = torch.from_numpy(synth_clip(seed * 100000 + i, cls)).to(dev)
+        # UrbanSound8K-shaped: durations uniform in [1, 4] s
+        secs = 5.0 if not varlen else float(
+            np.random.Generator(np.random.PCG64(77 + i)).uniform(1.0, 4.0))
+        wave = torch.from_numpy(synth_clip(seed * 100000 + i, cls, seconds=secs)).to(dev)
         torch.cuda.synchronize(dev)
         t0 = time.perf_counter()
         s = pca_hip.stft_logmag(wave, n_fft, n_fft, hop, drop_nyquist=drop, frame_major=True)
         torch.cuda.synchronize(dev)
         t_stft += time.perf_counter() - t0
-        if ntemp > 1:
+        if ntemp > 1 and varlen:
+            # keep the short last chunk as a padded set with fewer valid frames
+            T_ = s.shape[0]
+            S = -(-T_ // ntemp)
+            pad = torch.zeros((S * ntemp - T_, F), dtype=s.dtype, device=dev)
+            s = torch.cat([s, pad]).reshape(S, ntemp, F)
+            nt_valid += [ntemp] * (S - 1) + [T_ - (S - 1) * ntemp]
+        elif ntemp > 1:
             S = s.shape[0] // ntemp
             s = s[:S * ntemp].reshape(S, ntemp, F)       # chunks of ntemp frames, tail dropped
         specs.append(s)
@@ -105,6 +122,8 @@ def build_dataset(cfg, n_clips, dev, seed):
     else:
         tarr = np.linspace(0, (hop / FS) * ntemp, ntemp)
         ds = dataset.ESC_pc_temp.from_device(spec, lab, farr, tarr)
+        if varlen:
+            ds.nt_valid = np.asarray(nt_valid, dtype=np.int32)
     return ds, t_stft / max(n_clips, 1)
 
 
@@ -227,9 +246,10 @@ def main():
     ap.add_argument("--warmup", type=int, default=20)
     ap.add_argument("--config", default="cfg2", choices=sorted(CONFIGS))
     ap.add_argument("--batch", type=int, default=0, help="sets per GPU per step (0 = config)")
-    ap.add_argument("--mode", default="bf16", choices=["f32", "bf16"],
-                    help="bf16 = fused MFMA kernels (bf16 operands, fp32 accumulate); f32 = exact "
-                         "parity path")
+    ap.add_argument("--mode", default="bf16", choices=["f32", "bf16", "fp8"],
+                    help="bf16 = fused MFMA kernels (bf16 operands, fp32 accumulate); fp8 = the "
+                         "same with fp8 e4m3 operands in the d x d projections of the forward; "
+                         "f32 = exact parity path")
     ap.add_argument("--clips", type=int, default=48, help="synthetic clips in the corpus")
     ap.add_argument("--no-graph", action="store_true")
     ap.add_argument("--no-cpu-baseline", action="store_true")
@@ -260,7 +280,7 @@ def main():
     cfg = dict(CONFIGS[args.config])
     if args.batch:
         cfg["B"] = args.batch
-    mode = _lib.MODE_F32 if args.mode == "f32" else _lib.MODE_BF16
+    mode = {"f32": _lib.MODE_F32, "bf16": _lib.MODE_BF16, "fp8": _lib.MODE_FP8}[args.mode]
     # the same corpus on every rank: the index sharding of the Trainer (rank r takes elements
     # r::world of ONE permutation) assumes identical datasets, as DistributedSampler does
     ds, stft_s_per_clip = build_dataset(cfg, args.clips, dev, seed=0)

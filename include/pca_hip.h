@@ -49,7 +49,12 @@ enum { PCA_F32 = 0, PCA_BF16 = 1 };
  * return PCA_EUNSUPPORTED / 0 bytes otherwise: the caller falls back to PCA_MODE_F32
  * explicitly.  The ST engine (pca_st_*) runs blocks without a fused kernel as the same chain
  * of GEMMs with bf16 MFMA operands (pca_gemm_bf16). */
-enum { PCA_MODE_F32 = 0, PCA_MODE_BF16 = 1 };
+/* PCA_MODE_FP8 (BASELINE configs[4]): as PCA_MODE_BF16, but the d x d projections of the forward
+ * (fc_q, fc_o of the many-queries block; fc_k, fc_v where the keys are projected, d = 256) take
+ * fp8 e4m3 (OCP) MFMA operands: weights scaled per tensor by a power of two, activations
+ * converted in registers; attention, softmax, residuals, the backward and the optimiser are those
+ * of PCA_MODE_BF16 (straight-through gradient of the operand rounding). */
+enum { PCA_MODE_F32 = 0, PCA_MODE_BF16 = 1, PCA_MODE_FP8 = 2 };
 
 int pca_abi_version(void);
 /* Test aid (no reference counterpart): overwrites the LDS of every CU with NaN bit patterns.

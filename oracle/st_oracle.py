@@ -494,3 +494,58 @@ def mab1_forward_bf16emu(X: Tensor, H: Tensor, p: Params, num_heads: int) -> Ten
     O = Oh.permute(0, 2, 1, 3).reshape(B, nq, d)
     Z = rb(O) @ rb(p["fc_o.weight"]).t() + p["fc_o.bias"]
     return O + torch.relu(Z)
+
+
+# --------------------------------------------------------------------------- #
+# fp8 (e4m3) operand emulation of PCA_MODE_FP8                                   #
+# --------------------------------------------------------------------------- #
+def rb8(x: Tensor) -> Tensor:
+    """x -> float(float8_e4m3fn(clamp(x, +-448))): the OCP e4m3 rounding of v_cvt_pk_fp8_f32."""
+    return x.clamp(-448.0, 448.0).to(torch.float8_e4m3fn).to(x.dtype)
+
+
+def f8_weight_scale(W: Tensor) -> float:
+    """The per-tensor power-of-two scale k_prep_weight_f8 applies: largest s = 2^k with
+    s * max|W| <= 448."""
+    m = float(W.abs().max())
+    return 2.0 ** math.floor(math.log2(448.0 / m)) if m > 0 else 1.0
+
+
+def _lin8(x: Tensor, W: Tensor, b: Tensor) -> Tensor:
+    s = f8_weight_scale(W)
+    return (rb8(x) @ rb8(W * s).t()) / s + b
+
+
+def mab1_forward_fp8emu(X: Tensor, H: Tensor, p: Params, num_heads: int,
+                        fp8_q: bool = False) -> Tensor:
+    """mab_forward(X, H) as csrc/mab1_bf16.hip computes it in PCA_MODE_FP8: fc_o (and fc_q with
+    fp8_q, the library's PCA_FP8_PROJ=qo) with fp8 e4m3 operands (weights scaled per tensor,
+    activations as they are), everything else as mab1_forward_bf16emu (bf16 K / V images, bf16
+    attention operands, fp32 accumulation)."""
+    B, nq, dq = X.shape
+    nk = H.shape[1]
+    d = p["fc_q.weight"].shape[0]
+    h = num_heads
+    dh = d // h
+    if dq <= 4:
+        Qp = X @ p["fc_q.weight"].t() + p["fc_q.bias"]
+    elif fp8_q:
+        Qp = _lin8(rb(X), p["fc_q.weight"], p["fc_q.bias"])
+    else:
+        Qp = rb(X) @ rb(p["fc_q.weight"]).t() + p["fc_q.bias"]
+    if d == 256:
+        Kp = rb(rb(H) @ rb(p["fc_k.weight"]).t() + p["fc_k.bias"])
+        Vp = rb(rb(H) @ rb(p["fc_v.weight"]).t() + p["fc_v.bias"])
+    else:
+        Kp = rb(_lin(H, p, "fc_k"))
+        Vp = rb(_lin(H, p, "fc_v"))
+    Qh = rb(Qp).view(B, nq, h, dh).permute(0, 2, 1, 3)
+    Kh = Kp.view(B, nk, h, dh).permute(0, 2, 1, 3)
+    Vh = Vp.view(B, nk, h, dh).permute(0, 2, 1, 3)
+    A = torch.softmax(Qh @ Kh.transpose(-1, -2) / math.sqrt(d), dim=-1)
+    Oh = Qp.view(B, nq, h, dh).permute(0, 2, 1, 3) + rb(A) @ Vh
+    O = Oh.permute(0, 2, 1, 3).reshape(B, nq, d)
+    if d == 256:
+        O = rb(O)         # crosses from the Q phase to the O phase in bf16
+    Z = _lin8(O, p["fc_o.weight"], p["fc_o.bias"])
+    return O + torch.relu(Z)

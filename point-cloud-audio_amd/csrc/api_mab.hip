@@ -21,9 +21,9 @@ int mab_kind(const pca_mab_shape& s, bool inference) {
   // (a fused mab1 has the m inducing-point outputs as keys: always all of them; a caller that
   // masks keys of such a shape gets the exact path, whose softmax honours k_lengths)
   if (s.ln) return 0;          // LayerNorm variants: exact chain only
-  if (s.mode == PCA_MODE_BF16 && s.k_lengths == nullptr && mab1_bf16_supported(s, inference))
-    return 1;
-  if (s.mode == PCA_MODE_BF16 && mab0_bf16_supported(s)) return 2;
+  const bool fused_mode = s.mode == PCA_MODE_BF16 || s.mode == PCA_MODE_FP8;
+  if (fused_mode && s.k_lengths == nullptr && mab1_bf16_supported(s, inference)) return 1;
+  if (fused_mode && mab0_bf16_supported(s)) return 2;
   return 0;
 }
 size_t mab_saved_bytes_any(const pca_mab_shape& s) {
@@ -76,12 +76,12 @@ extern "C" {
 // arithmetic at this level); callers that want "bf16 where available" query
 // pca_mab_saved_bytes() first, which returns 0 for unsupported bf16 shapes.
 static int bf16_demand(const pca_mab_shape* s, bool inference = false) {
-  if (s->mode == PCA_MODE_BF16 && pca::mab_kind(*s, inference) == 0) {
-    pca::set_error("mab: no bf16 kernel for B=%d nq=%d nk=%d dq=%d dk=%d d=%d h=%d q_shared=%d",
+  if ((s->mode == PCA_MODE_BF16 || s->mode == PCA_MODE_FP8) && pca::mab_kind(*s, inference) == 0) {
+    pca::set_error("mab: no bf16 / fp8 kernel for B=%d nq=%d nk=%d dq=%d dk=%d d=%d h=%d q_shared=%d",
                    s->B, s->nq, s->nk, s->dq, s->dk, s->d, s->h, s->q_shared);
     return PCA_EUNSUPPORTED;
   }
-  if (s->mode != PCA_MODE_BF16 && s->mode != PCA_MODE_F32) {
+  if (s->mode != PCA_MODE_BF16 && s->mode != PCA_MODE_F32 && s->mode != PCA_MODE_FP8) {
     pca::set_error("mab: unknown mode %d", s->mode);
     return PCA_EINVAL;
   }

@@ -84,6 +84,7 @@ struct RowGemmArgs {
   const __bf16* In;       // [B*N][D]: PROJ X ; BWD_O dY ; BWD_Q dQp (or dKp / dVp) ; FWD_O O
   const __bf16* W;        // [D][D] image (see the launcher for which)
   const float* bias;      // PROJ, FWD_O
+  const float* inv_scale; // F8: 1 / (per-tensor power-of-two scale of the fp8 weight image)
   const uint32_t* mask;   // BWD_O: ReLU mask bits of the forward
   uint32_t* mask_out;     // FWD_O (nullable)
   __bf16* Out;            // PROJ Y ; BWD_O dO ; BWD_Q dX ; FWD_O Y
@@ -99,10 +100,13 @@ __device__ __forceinline__ int cko(int row, int c16) {
 
 // NB = 16-point blocks per wave: 2 (8 waves, 256 VGPRs) or 1 (16 waves of 128 VGPRs: four
 // wavefronts per SIMD to hide the memory latency, twice the LDS weight reads per MFMA)
-template <int D, int MODE, int NB>
+// F8 (PROJ, FWD_O): W is an fp8 e4m3 image of s * W ([D][D] bytes), the activations are converted
+// to fp8 in registers; the accumulators are rescaled by 1 / s before the bias
+template <int D, int MODE, int NB, bool F8 = false>
 __global__ __launch_bounds__(1024 / NB, 4 / NB) void k_rowgemm(const RowGemmArgs a) {
   constexpr int NW = 16 / NB, NT = 64 * NW, SUBS = 2;
-  constexpr int DT = D / 16, KS = D / 32, ROWB = D * 2, NCH = D / 64;
+  constexpr int DT = D / 16, KS = D / 32, ROWB = F8 ? D : D * 2, NCH = D / 64;
+  static_assert(!F8 || MODE == RG_PROJ || MODE == RG_FWD_O, "fp8 operands: forward projections");
   constexpr int CB = 16 * NB * 128;       // bytes of a wave's chunk buffer ([16 NB rows][64])
   extern __shared__ __attribute__((aligned(16))) char smem[];
   char* sW = smem;
@@ -111,21 +115,30 @@ __global__ __launch_bounds__(1024 / NB, 4 / NB) void k_rowgemm(const RowGemmArgs
   // forward's terms (mask index): tile `sub` of the unit, wave (0..3), block nb0 + nb of that wave
   const int blk0 = wv * NB, sub = blk0 >> 3, wave = (blk0 & 7) >> 1, nb0 = blk0 & 1;
   const int r = lane & 15, g = lane >> 4;
-  char* myC = smem + D * ROWB + wv * CB;
+  char* myC = smem + D * ROWB + wv * CB;          // (behind the weight image)
   {
-    constexpr int NC = D * (D / 8) / NT;
+    constexpr int CPR = ROWB / 16;                 // 16-byte chunks per image row
+    constexpr int NC = D * CPR / NT;
     uint4 wv[NC];
+    const char* gW = reinterpret_cast<const char*>(a.W);
 #pragma unroll
     for (int e = 0; e < NC; ++e) {
-      const int c = tid + NT * e, row = c / (D / 8), c16 = c % (D / 8);
-      wv[e] = *reinterpret_cast<const uint4*>(a.W + (int64_t)row * D + c16 * 8);
+      const int c = tid + NT * e, row = c / CPR, c16 = c % CPR;
+      wv[e] = *reinterpret_cast<const uint4*>(gW + (int64_t)row * ROWB + c16 * 16);
     }
 #pragma unroll
     for (int e = 0; e < NC; ++e) {
-      const int c = tid + NT * e, row = c / (D / 8), c16 = c % (D / 8);
-      *reinterpret_cast<uint4*>(sW + swz(row, c16, ROWB)) = wv[e];
+      const int c = tid + NT * e, row = c / CPR, c16 = c % CPR;
+      if (F8) {
+        *reinterpret_cast<uint2*>(sW + f8off<D>(row, 2 * c16)) = uint2{wv[e].x, wv[e].y};
+        *reinterpret_cast<uint2*>(sW + f8off<D>(row, 2 * c16 + 1)) = uint2{wv[e].z, wv[e].w};
+      } else {
+        *reinterpret_cast<uint4*>(sW + swz(row, c16, ROWB)) = wv[e];
+      }
     }
   }
+  const float inv_s = F8 ? a.inv_scale[0] : 1.f;
+  (void)inv_s;
   __syncthreads();
   const int units_per_set = (a.tiles_per_set + SUBS - 1) / SUBS;
   const int total_units = a.B * units_per_set;
@@ -221,7 +234,7 @@ __global__ __launch_bounds__(1024 / NB, 4 / NB) void k_rowgemm(const RowGemmArgs
 #pragma unroll
         for (int tt = 0; tt < DTH; ++tt) {
           float4 b4 = float4{0.f, 0.f, 0.f, 0.f};
-          if (MODE == RG_PROJ || MODE == RG_FWD_O)
+          if (!F8 && (MODE == RG_PROJ || MODE == RG_FWD_O))
             b4 = *reinterpret_cast<const float4*>(a.bias + 16 * (hf * DTH + tt) + 4 * g);
 #pragma unroll
           for (int nb = 0; nb < NB; ++nb) acc[tt][nb] = f32x4{b4.x, b4.y, b4.z, b4.w};
@@ -229,12 +242,38 @@ __global__ __launch_bounds__(1024 / NB, 4 / NB) void k_rowgemm(const RowGemmArgs
       }
 #pragma unroll
       for (int s = 0; s < KS; ++s) {
+        if (F8) {
+          f8x8 b8[NB];
+#pragma unroll
+          for (int nb = 0; nb < NB; ++nb) b8[nb] = bf_to_f8(bop[s][nb]);
+#pragma unroll
+          for (int tt = 0; tt < DTH; ++tt) {
+            const f8x8 wa8 = *reinterpret_cast<const f8x8*>(
+                sW + f8off<D>(16 * (hf * DTH + tt) + r, 4 * s + g));
+#pragma unroll
+            for (int nb = 0; nb < NB; ++nb) acc[tt][nb] = mfma32_f8(wa8, b8[nb], acc[tt][nb]);
+          }
+        } else {
+#pragma unroll
+          for (int tt = 0; tt < DTH; ++tt) {
+            const bf16x8 wa = *reinterpret_cast<const bf16x8*>(
+                sW + swz(16 * (hf * DTH + tt) + r, 4 * s + g, ROWB));
+#pragma unroll
+            for (int nb = 0; nb < NB; ++nb) acc[tt][nb] = mfma32(wa, bop[s][nb], acc[tt][nb]);
+          }
+        }
+      }
+      if (F8) {
 #pragma unroll
         for (int tt = 0; tt < DTH; ++tt) {
-          const bf16x8 wa = *reinterpret_cast<const bf16x8*>(
-              sW + swz(16 * (hf * DTH + tt) + r, 4 * s + g, ROWB));
+          const float4 b4 = *reinterpret_cast<const float4*>(a.bias + 16 * (hf * DTH + tt) + 4 * g);
 #pragma unroll
-          for (int nb = 0; nb < NB; ++nb) acc[tt][nb] = mfma32(wa, bop[s][nb], acc[tt][nb]);
+          for (int nb = 0; nb < NB; ++nb) {
+            acc[tt][nb][0] = acc[tt][nb][0] * inv_s + b4.x;
+            acc[tt][nb][1] = acc[tt][nb][1] * inv_s + b4.y;
+            acc[tt][nb][2] = acc[tt][nb][2] * inv_s + b4.z;
+            acc[tt][nb][3] = acc[tt][nb][3] * inv_s + b4.w;
+          }
         }
       }
 #pragma unroll
@@ -289,28 +328,27 @@ __global__ __launch_bounds__(1024 / NB, 4 / NB) void k_rowgemm(const RowGemmArgs
   }
 }
 
-template <int MODE, int NBW>
+template <int MODE, int NBW, bool F8 = false>
 int launch_rowgemm_nb(const RowGemmArgs& a, hipStream_t st) {
   constexpr int D = 256;
   static std::once_flag once;
   std::call_once(once, [] {
-    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(k_rowgemm<D, MODE, NBW>),
+    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(k_rowgemm<D, MODE, NBW, F8>),
                               hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
   });
   const int total = a.B * ((a.tiles_per_set + 1) / 2);
   const int grid = total < 256 ? total : 256;
-  hipLaunchKernelGGL((k_rowgemm<D, MODE, NBW>), dim3(grid), dim3(1024 / NBW),
-                     (size_t)D * D * 2 + 8 * 4096, st, a);
+  hipLaunchKernelGGL((k_rowgemm<D, MODE, NBW, F8>), dim3(grid), dim3(1024 / NBW),
+                     (size_t)D * D * (F8 ? 1 : 2) + 8 * 4096, st, a);
   return check_launch("k_rowgemm");
 }
 template <int MODE>
 int launch_rowgemm(const RowGemmArgs& a, hipStream_t st) {
-  // PCA_ROWGEMM_NB=2: the 8-wave variant (A/B measurements)
-  static const int nbw = [] {
-    const char* e = getenv("PCA_ROWGEMM_NB");
-    return (e != nullptr && e[0] == '2') ? 2 : 1;
-  }();
-  return nbw == 2 ? launch_rowgemm_nb<MODE, 2>(a, st) : launch_rowgemm_nb<MODE, 1>(a, st);
+  // measured at configs[3] (B = 128, N = 4096): 8 waves x 2 blocks is the faster shape for PROJ /
+  // BWD_O / BWD_Q (126 / 147 / 172 us against 133 / 173 / 176), 16 waves x 1 block for FWD_O,
+  // whose 8-wave build spills (181 against 195 us)
+  if (MODE == RG_FWD_O) return launch_rowgemm_nb<MODE, 1>(a, st);
+  return launch_rowgemm_nb<MODE, 2>(a, st);
 }
 
 // =====================================================================================
@@ -1523,23 +1561,37 @@ __global__ __launch_bounds__(256, 1) void k_pma_bwd256(const PmaArgs a) {
 // ---- launchers (declared in d256_bf16.hpp) ------------------------------------------------
 int rowgemm256_proj(const __bf16* X, const __bf16* WP, const float* bias, __bf16* Y, int B, int N,
                     hipStream_t st) {
-  RowGemmArgs a{X, WP, bias, nullptr, nullptr, Y, nullptr, B, N, (int)cdiv(N, TP), 0};
+  RowGemmArgs a{X, WP, bias, nullptr, nullptr, nullptr, Y, nullptr, B, N, (int)cdiv(N, TP), 0};
   return launch_rowgemm<RG_PROJ>(a, st);
 }
 int rowgemm256_bwd_o(const __bf16* dY, const uint32_t* mask, const __bf16* WoTP, __bf16* dZ,
                      __bf16* dO, int B, int N, hipStream_t st) {
-  RowGemmArgs a{dY, WoTP, nullptr, mask, nullptr, dO, dZ, B, N, (int)cdiv(N, TP), 0};
+  RowGemmArgs a{dY, WoTP, nullptr, nullptr, mask, nullptr, dO, dZ, B, N, (int)cdiv(N, TP), 0};
   return launch_rowgemm<RG_BWD_O>(a, st);
 }
 int rowgemm256_dx(const __bf16* G, const __bf16* WTP, __bf16* dX, int B, int N, int accumulate,
                   hipStream_t st) {
-  RowGemmArgs a{G, WTP, nullptr, nullptr, nullptr, dX, nullptr, B, N, (int)cdiv(N, TP), accumulate};
+  RowGemmArgs a{G, WTP, nullptr, nullptr, nullptr, nullptr, dX, nullptr, B, N, (int)cdiv(N, TP),
+                accumulate};
   return launch_rowgemm<RG_BWD_Q>(a, st);
 }
 int rowgemm256_fwd_o(const __bf16* O, const __bf16* WoP, const float* bo, __bf16* Y, uint32_t* mask,
                      int B, int N, hipStream_t st) {
-  RowGemmArgs a{O, WoP, bo, nullptr, mask, Y, nullptr, B, N, (int)cdiv(N, TP), 0};
+  RowGemmArgs a{O, WoP, bo, nullptr, nullptr, mask, Y, nullptr, B, N, (int)cdiv(N, TP), 0};
   return launch_rowgemm<RG_FWD_O>(a, st);
+}
+// fp8 (e4m3) operands: W8 = image of s * W written by prep_weight_f8, inv_scale[0] = 1 / s
+int rowgemm256_proj_f8(const __bf16* X, const void* W8, const float* inv_scale, const float* bias,
+                       __bf16* Y, int B, int N, hipStream_t st) {
+  RowGemmArgs a{X, reinterpret_cast<const __bf16*>(W8), bias, inv_scale, nullptr, nullptr, Y,
+                nullptr, B, N, (int)cdiv(N, TP), 0};
+  return launch_rowgemm_nb<RG_PROJ, 2, true>(a, st);
+}
+int rowgemm256_fwd_o_f8(const __bf16* O, const void* W8, const float* inv_scale, const float* bo,
+                        __bf16* Y, uint32_t* mask, int B, int N, hipStream_t st) {
+  RowGemmArgs a{O, reinterpret_cast<const __bf16*>(W8), bo, inv_scale, nullptr, mask, Y, nullptr, B,
+                N, (int)cdiv(N, TP), 0};
+  return launch_rowgemm_nb<RG_FWD_O, 2, true>(a, st);
 }
 
 int attn1_bwd256_parts(int B, int N) {

@@ -10,6 +10,11 @@ int rowgemm256_proj(const __bf16* X, const __bf16* WP, const float* bias, __bf16
 // Y = O + relu(O Wo^T + bo)  (WoP: prep mode 1 of Wo); mask (nullable): ReLU bits for the backward
 int rowgemm256_fwd_o(const __bf16* O, const __bf16* WoP, const float* bo, __bf16* Y, uint32_t* mask,
                      int B, int N, hipStream_t st);
+// the same two with fp8 (e4m3) MFMA operands (PCA_MODE_FP8): W8 from prep_weight_f8 (mode 1)
+int rowgemm256_proj_f8(const __bf16* X, const void* W8, const float* inv_scale, const float* bias,
+                       __bf16* Y, int B, int N, hipStream_t st);
+int rowgemm256_fwd_o_f8(const __bf16* O, const void* W8, const float* inv_scale, const float* bo,
+                        __bf16* Y, uint32_t* mask, int B, int N, hipStream_t st);
 // dZ = dY . [Z > 0] (mask bits of k_mab1_fwd) ; dO = dY + dZ Wo   (WoTP: prep mode 2 of Wo)
 int rowgemm256_bwd_o(const __bf16* dY, const uint32_t* mask, const __bf16* WoTP, __bf16* dZ,
                      __bf16* dO, int B, int N, hipStream_t st);

@@ -185,8 +185,8 @@ static size_t fq_carve_saved(const pca_mab_shape& s, Fq256Saved* out, void* base
 }
 size_t mab0_d256_saved_bytes(const pca_mab_shape& s) { return fq_carve_saved(s, nullptr, nullptr); }
 size_t mab0_d256_fwd_ws_bytes(const pca_mab_shape& s) {
-  // two weight images + (inference) what the saved block would hold
-  return 2 * align256((size_t)D * D * 2) + fq_carve_saved(s, nullptr, nullptr);
+  // two weight images (+ fp8 scales) + (inference) what the saved block would hold
+  return 256 + 2 * align256((size_t)D * D * 2) + fq_carve_saved(s, nullptr, nullptr);
 }
 
 int mab0_d256_fwd(const pca_mab_shape& s, const float* I, const void* X, const pca_mab_params& p,
@@ -196,6 +196,7 @@ int mab0_d256_fwd(const pca_mab_shape& s, const float* I, const void* X, const p
   Carver cw(ws);
   __bf16* WkP = cw.take<__bf16>((size_t)D * D);
   __bf16* WvP = cw.take<__bf16>((size_t)D * D);
+  float* invs = cw.take<float>(2);
   Fq256Saved v;
   fq_carve_saved(s, &v, saved != nullptr ? saved : (void*)(cw.base + cw.off));
   const int m = s.nq;
@@ -232,10 +233,17 @@ int mab0_d256_fwd(const pca_mab_shape& s, const float* I, const void* X, const p
       PCA_TRY(cvt_f32_bf16(reinterpret_cast<const float*>(X), v.Xb, M * D, st));
       Xb = v.Xb;
     }
+    if (s.mode == PCA_MODE_FP8) {           // fc_k / fc_v with fp8 e4m3 operands
+      PCA_TRY(prep_weight_f8(p.wk, WkP, D, D, 1, invs, st));
+      PCA_TRY(prep_weight_f8(p.wv, WvP, D, D, 1, invs + 1, st));
+      PCA_TRY(rowgemm256_proj_f8(Xb, WkP, invs, p.bk, v.Kp, s.B, s.nk, st));
+      PCA_TRY(rowgemm256_proj_f8(Xb, WvP, invs + 1, p.bv, v.Vp, s.B, s.nk, st));
+    } else {
     PCA_TRY(prep_weight(p.wk, WkP, D, D, 1, st));
     PCA_TRY(prep_weight(p.wv, WvP, D, D, 1, st));
     PCA_TRY(rowgemm256_proj(Xb, WkP, p.bk, v.Kp, s.B, s.nk, st));            // modules.py:21
     PCA_TRY(rowgemm256_proj(Xb, WvP, p.bv, v.Vp, s.B, s.nk, st));
+    }
     const double pts = (double)M;
     ProfScope ps(PCA_K_MAB0_FWD, st, 2.0 * pts * 2.0 * m * D, pts * 4.0 * D);
     PCA_TRY(fq_attn_fwd256(v.Kp, v.Vp, v.Qp, s.B, s.nk, m, s.k_lengths, v.Op, v.Mp, v.Lp, v.O,

@@ -20,7 +20,7 @@ thread_local bool t_bf16_operands = false;
 struct OperandMode {
   bool prev;
   explicit OperandMode(const pca_mab_shape& s) : prev(t_bf16_operands) {
-    t_bf16_operands = s.mode == PCA_MODE_BF16;
+    t_bf16_operands = s.mode != PCA_MODE_F32;
   }
   ~OperandMode() { t_bf16_operands = prev; }
 };

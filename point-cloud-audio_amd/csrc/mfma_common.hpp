@@ -46,6 +46,34 @@ __device__ __forceinline__ bf16x4 pack4(f32x4 v) {
   return r;
 }
 
+// ---- fp8 (OCP e4m3) operands: same 16x16x32 shape and (g, j) k-slot structure as bf16, 8 values
+// per lane in two VGPRs (element j = byte j) --------------------------------------------------
+typedef long f8x8;
+__device__ __forceinline__ f32x4 mfma32_f8(f8x8 a, f8x8 b, f32x4 c) {
+  return __builtin_amdgcn_mfma_f32_16x16x32_fp8_fp8(a, b, c, 0, 0, 0);
+}
+__device__ __forceinline__ float clamp_f8(float x) { return fminf(fmaxf(x, -448.f), 448.f); }
+__device__ __forceinline__ uint32_t cvt4_f8(float a, float b, float c, float d) {
+  int p = __builtin_amdgcn_cvt_pk_fp8_f32(clamp_f8(a), clamp_f8(b), 0, false);
+  p = __builtin_amdgcn_cvt_pk_fp8_f32(clamp_f8(c), clamp_f8(d), p, true);
+  return (uint32_t)p;
+}
+__device__ __forceinline__ f8x8 pack8_f8(f32x4 lo, f32x4 hi) {
+  const uint64_t l = cvt4_f8(lo[0], lo[1], lo[2], lo[3]), h = cvt4_f8(hi[0], hi[1], hi[2], hi[3]);
+  return (f8x8)(l | (h << 32));
+}
+__device__ __forceinline__ f8x8 bf_to_f8(bf16x8 v) {
+  const uint64_t l = cvt4_f8((float)v[0], (float)v[1], (float)v[2], (float)v[3]);
+  const uint64_t h = cvt4_f8((float)v[4], (float)v[5], (float)v[6], (float)v[7]);
+  return (f8x8)(l | (h << 32));
+}
+// byte offset of 8-byte slot `slot` (8 fp8) of row `row` in a [.][D] fp8 LDS image: the XOR makes
+// the 32 (row, g) pairs of a half-wave's ds_read_b64 hit 32 different slots
+template <int D>
+__device__ __forceinline__ int f8off(int row, int slot) {
+  return row * D + ((slot ^ (D == 256 ? ((2 * row) & 31) : (row & 15))) << 3);
+}
+
 // byte offset of 16-byte chunk c16 of row `row` in a row-major bf16 LDS image with
 // `row_bytes` per row, XOR-swizzled so that 16 lanes reading the same chunk of 16 different
 // rows hit 16 different bank groups (cdna_hip_programming.md T2)

@@ -91,7 +91,7 @@ inline Shapes shapes(const pca_st_config& c, bool training, const int32_t* lengt
   }
   s.pma = shape(c, c.k, c.N, c.d, c.d, 1);
   s.act_bf16 = false;
-  if (training && c.mode == PCA_MODE_BF16) {
+  if (training && c.mode != PCA_MODE_F32) {
     // bf16 activations only when EVERY block runs on a fused kernel that understands them
     Shapes t = s;
     t.m1[0].y_dtype = PCA_BF16;
@@ -182,7 +182,8 @@ int validate(const pca_st_config* c) {
                   c->k > 0 && c->C > 0,
               "st: non-positive extent");
   PCA_REQUIRE(c->d % c->h == 0, "st: d=%d not divisible by h=%d", c->d, c->h);
-  PCA_REQUIRE(c->mode == PCA_MODE_F32 || c->mode == PCA_MODE_BF16, "st: unknown mode %d",
+  PCA_REQUIRE(c->mode == PCA_MODE_F32 || c->mode == PCA_MODE_BF16 || c->mode == PCA_MODE_FP8,
+              "st: unknown mode %d",
               c->mode);
   return PCA_OK;
 }

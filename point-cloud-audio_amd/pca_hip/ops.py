@@ -14,15 +14,16 @@ import torch
 from . import _lib
 from ._lib import MabGrads, MabParams, MabShape, check, lib
 
-_MODE = "f32"           # "f32" | "bf16" | "auto"
+_MODE = "f32"           # "f32" | "bf16" | "fp8" | "auto"
 
 
 def set_mode(mode: str) -> None:
     """Arithmetic mode of MAB blocks: 'f32' = exact fp32 kernels (parity mode),
     'bf16' = bf16 MFMA operands with fp32 accumulate/softmax (fails for shapes the fused
-    kernels do not cover), 'auto' = bf16 where covered, else f32."""
+    kernels do not cover), 'fp8' = as bf16 with fp8 (e4m3) operands in the d x d projections of
+    the forward, 'auto' = bf16 where covered, else f32."""
     global _MODE
-    if mode not in ("f32", "bf16", "auto"):
+    if mode not in ("f32", "bf16", "fp8", "auto"):
         raise ValueError(mode)
     _MODE = mode
 
@@ -81,7 +82,7 @@ def _pick_mode(s: MabShape, inference: bool = False) -> MabShape:
     exact fp32."""
     if _MODE == "f32":
         return s
-    s.mode = _lib.MODE_BF16
+    s.mode = _lib.MODE_FP8 if _MODE == "fp8" else _lib.MODE_BF16
     probe = lib().pca_mab_fwd_ws_bytes if inference else lib().pca_mab_saved_bytes
     if _MODE == "auto" and probe(C.byref(s)) == 0:
         s.mode = _lib.MODE_F32

@@ -533,3 +533,61 @@ def test_auto_mode_at_d256(dev):
                 mab(X, H20)
     finally:
         pca_hip.set_mode("f32")
+
+
+# ---- PCA_MODE_FP8: fp8 e4m3 operands in the d x d projections of the forward ---------------------
+FP8_CASES = [      # B, N, m, dq, d, h
+    (3, 200, 16, 128, 128, 4),
+    (2, 77, 16, 2, 128, 4),           # layer 1: only fc_o is a d x d projection
+    (2, 300, 32, 256, 256, 8),
+]
+
+
+@pytest.mark.parametrize("case", FP8_CASES, ids=[str(c) for c in FP8_CASES])
+def test_mab1_fwd_fp8(dev, case):
+    """Kernel vs the oracle-side fp8 emulation (same rounding points: e4m3 of s*W and of the
+    activations, fp32 accumulation) - tight; emulation vs the exact oracle - the precision
+    statement of the mode (e4m3 keeps 4 significant bits)."""
+    import ctypes as C
+    from oracle import st_oracle as orc
+    from pca_hip import _lib
+    L = _lib.lib()
+    B, N, m, dq, d, h = case
+    p = _mab_params(dq, d, d, seed=sum(case) + 5)
+    g = torch.Generator().manual_seed(9 + sum(case))
+    X = torch.randn(B, N, dq, generator=g)
+    if dq <= 4:
+        X[..., -1] = X[..., -1] * 3 - 9
+    H = torch.randn(B, m, d, generator=g)
+    abf = d == 256                              # d = 256: bf16 activations at the ABI
+    if abf and dq > 4:
+        X = X.to(torch.bfloat16).float()
+    emu = orc.mab1_forward_fp8emu(X, H, p, h)
+    exact = orc.mab_forward(X, H, p, h)
+    qdt = _lib.PCA_BF16 if (abf and dq > 4) else _lib.PCA_F32
+    ydt = _lib.PCA_BF16 if abf else _lib.PCA_F32
+    s = _lib.MabShape(B, N, m, dq, d, d, h, 0, _lib.MODE_FP8, qdt, _lib.PCA_F32, ydt, None, 0)
+    nws = L.pca_mab_fwd_ws_bytes(C.byref(s))
+    assert nws > 0, L.pca_last_error()
+    Xd = X.to(dev).to(torch.bfloat16) if qdt == _lib.PCA_BF16 else X.to(dev)
+    prm = [p[k].to(dev).contiguous() for k in ("fc_q.weight", "fc_q.bias", "fc_k.weight",
+                                               "fc_k.bias", "fc_v.weight", "fc_v.bias",
+                                               "fc_o.weight", "fc_o.bias")]
+    pp = _lib.MabParams(*[t.data_ptr() for t in prm], None, None, None, None)
+    Y = torch.empty(B, N, d, dtype=torch.bfloat16 if abf else torch.float32, device=dev)
+    ws = torch.empty(nws, dtype=torch.uint8, device=dev)
+    Hd = H.to(dev)
+    _lib.check(L.pca_mab_fwd(C.byref(s), Xd.data_ptr(), Hd.data_ptr(), C.byref(pp), Y.data_ptr(),
+                             None, ws.data_ptr(), None))
+    torch.cuda.synchronize()
+    e1 = close(Y.float(), emu, 1.5e-2, f"fp8 kernel vs fp8 emulation {case}")
+    sc = max(1.0, float(exact.abs().max()))
+    rms = float((emu - exact).pow(2).mean().sqrt()) / sc
+    print(f"mab1 fwd fp8 {case}: kernel vs emulation {e1:.2e}; emulation vs exact rms {rms:.2e}")
+    assert rms < 4e-2
+    # not the bf16 kernels under another name
+    s.mode = _lib.MODE_BF16
+    Yb = torch.empty_like(Y)
+    _lib.check(L.pca_mab_fwd(C.byref(s), Xd.data_ptr(), Hd.data_ptr(), C.byref(pp), Yb.data_ptr(),
+                             None, ws.data_ptr(), None))
+    assert float((Yb.float() - Y.float()).abs().max()) > 1e-3
