@@ -102,7 +102,7 @@ def test_trained_cfg1_weights_agreement_fp8(dev):
     assert frac >= 0.998
 
 
-RUNS = 6
+RUNS = int(os.environ.get("PCA_ACC_RUNS", "6"))
 
 
 @pytest.mark.parametrize("mode", ["f32", "bf16"])
