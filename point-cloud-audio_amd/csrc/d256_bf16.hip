@@ -169,10 +169,12 @@ __global__ __launch_bounds__(1024 / NB, 4 / NB) void k_rowgemm(const RowGemmArgs
     auto fetch = [&](int c, uint4 (&dst)[NI]) {
 #pragma unroll
       for (int i = 0; i < NI; ++i) {
-        const int row = crow0 + 8 * i;
-        dst[i] = row < nlive
-                     ? *reinterpret_cast<const uint4*>(a.In + (rowbase + row) * D + 64 * c + 8 * cc16)
-                     : uint4{0u, 0u, 0u, 0u};
+        // rows past the end of the set read its last row instead (never stored: a point only
+        // feeds its own output column) - a load under a divergent condition gets its own basic
+        // block and s_waitcnt vmcnt(0), which serialised the NI loads of a chunk
+        const int n = n_base + crow0 + 8 * i;
+        dst[i] = *reinterpret_cast<const uint4*>(
+            a.In + ((int64_t)b * a.N + (n < a.N ? n : a.N - 1)) * D + 64 * c + 8 * cc16);
       }
     };
     fetch(0, st[0]);
@@ -564,8 +566,11 @@ __global__ __launch_bounds__(512, 2) void k_wgrad256(const Wgrad256Jobs jobs, in
   const Wgrad256Job job = jobs.j[blockIdx.y];
   const T* __restrict__ G = reinterpret_cast<const T*>(job.G);
   const T* __restrict__ A = reinterpret_cast<const T*>(job.A);
-  const int64_t r0 = (int64_t)blockIdx.x * rows_per_wg;
-  const int64_t r1 = r0 + rows_per_wg < job.M ? r0 + rows_per_wg : job.M;
+  // 64-row blocks are dealt round-robin: the workgroups that run together read neighbouring
+  // addresses (one contiguous range per workgroup puts all of them 512 KiB apart, on the same few
+  // HBM channels at the same moment)
+  (void)rows_per_wg;
+  const int64_t r0 = (int64_t)blockIdx.x * 64, r1 = job.M, stride = (int64_t)gridDim.x * 64;
   const int gt0 = 4 * (wave >> 1), at0 = 8 * (wave & 1);
   f32x4 acc[4][8];
 #pragma unroll
@@ -578,10 +583,12 @@ __global__ __launch_bounds__(512, 2) void k_wgrad256(const Wgrad256Jobs jobs, in
 #pragma unroll
     for (int e = 0; e < 2; ++e) {
       const int c = tid + e * NT, row = c >> 5, ch = c & 31;
-      if (base + row < r1) {
-        g2[e] = ld8(G + (base + row) * D + ch * 8);
-        a2[e] = ld8(A + (base + row) * D + ch * 8);
-      } else {
+      // (unconditional loads, rows past the end zeroed afterwards: see k_wgrad_small256)
+      const bool ok = base + row < r1;
+      const int64_t rc = ok ? base + row : r1 - 1;
+      g2[e] = ld8(G + rc * D + ch * 8);
+      a2[e] = ld8(A + rc * D + ch * 8);
+      if (!ok) {
 #pragma unroll
         for (int k = 0; k < 8; ++k) { g2[e][k] = (__bf16)0.f; a2[e][k] = (__bf16)0.f; }
       }
@@ -614,18 +621,22 @@ __global__ __launch_bounds__(512, 2) void k_wgrad256(const Wgrad256Jobs jobs, in
   };
   if (r0 < r1) fetch(r0, vg[0], va[0]);
   if (r0 + 32 < r1) fetch(r0 + 32, vg[1], va[1]);
-  for (int64_t base = r0; base < r1; base += 64) {
-    consume(0, vg[0], va[0], base + 64);
-    if (base + 32 < r1) consume(1, vg[1], va[1], base + 96);
+  for (int64_t base = r0; base < r1; base += stride) {
+    consume(0, vg[0], va[0], base + stride);
+    if (base + 32 < r1) consume(1, vg[1], va[1], base + stride + 32);
   }
-  float* slab = slabs + ((int64_t)blockIdx.y * gridDim.x + blockIdx.x) * D * D;
+  // slab layout [job][output row][workgroup][256]: the partial sums of one output row lie next to
+  // each other, so the summing pass streams 1 KiB x nwg contiguous bytes per row (with one
+  // [256][256] block per workgroup it read 1 KiB out of every 256 KiB: 1.2 TB/s)
+  float* slab = slabs + (int64_t)blockIdx.y * D * gridDim.x * D + (int64_t)blockIdx.x * D;
 #pragma unroll
   for (int i = 0; i < 4; ++i)
 #pragma unroll
     for (int e = 0; e < 4; ++e) {
       const int grow = 16 * (gt0 + i) + 4 * g + e;
 #pragma unroll
-      for (int t = 0; t < 8; ++t) slab[grow * D + 16 * (at0 + t) + r] = acc[i][t][e];
+      for (int t = 0; t < 8; ++t)
+        slab[(int64_t)grow * gridDim.x * D + 16 * (at0 + t) + r] = acc[i][t][e];
     }
   if (job.db != nullptr) {
     // threads with equal (tid & 31) hold partial sums of the same 8 columns
@@ -649,27 +660,46 @@ __global__ __launch_bounds__(256) void k_wgrad256_sum(const Wgrad256Jobs jobs, i
                                                      const float* __restrict__ bslabs) {
   constexpr int D = 256;
   const Wgrad256Job job = jobs.j[blockIdx.y];
-  const int used = (int)((job.M + rows_per_wg - 1) / rows_per_wg);      // slabs with rows
-  const int i = blockIdx.x * 256 + threadIdx.x;
-  if (i < D * D) {
-    const float* s = slabs + (int64_t)blockIdx.y * nwg * D * D + i;
-    float t = 0.f;
-    int w = 0;
-    for (; w + 8 <= used; w += 8) {
-      float v[8];
+  (void)rows_per_wg;
+  const int64_t blocks = (job.M + 63) / 64;
+  const int used = (int)(blocks < nwg ? blocks : nwg);                  // slabs with rows
+  // blockIdx.x < 256: output row of dW; == 256: the bias sums (same walk over [nwg][256] partials -
+  // as a plain loop of one load per slab in one workgroup it was 256 dependent round trips, 90 us)
+  const bool bias_row = blockIdx.x == D;
+  if (bias_row && job.db == nullptr) return;
+  {
+    // 256 outputs per workgroup: lane group sg adds slabs sg, sg + 4, ... of four consecutive
+    // outputs (16-byte loads, eight in flight), then the four groups are added in a fixed order
+    __shared__ float4 red[4][64];
+    const int sg = threadIdx.x >> 6, c = threadIdx.x & 63;
+    const float* s = bias_row ? bslabs + (int64_t)blockIdx.y * nwg * D + 4 * c
+                              : slabs + ((int64_t)blockIdx.y * D + blockIdx.x) * nwg * D + 4 * c;
+    float* out = bias_row ? job.db + 4 * c : job.dW + blockIdx.x * 256 + 4 * c;
+    float4 t = {0.f, 0.f, 0.f, 0.f};
+    int w = sg;
+    for (; w + 28 < used; w += 32) {
+      float4 v[8];
 #pragma unroll
-      for (int u = 0; u < 8; ++u) v[u] = s[(int64_t)(w + u) * D * D];
+      for (int u = 0; u < 8; ++u)
+        v[u] = *reinterpret_cast<const float4*>(s + (int64_t)(w + 4 * u) * D);
 #pragma unroll
-      for (int u = 0; u < 8; ++u) t += v[u];
+      for (int u = 0; u < 8; ++u) { t.x += v[u].x; t.y += v[u].y; t.z += v[u].z; t.w += v[u].w; }
     }
-    for (; w < used; ++w) t += s[(int64_t)w * D * D];
-    job.dW[i] += t;
-  } else if (i < D * D + D && job.db != nullptr) {
-    const int c = i - D * D;
-    const float* s = bslabs + (int64_t)blockIdx.y * nwg * D + c;
-    float t = 0.f;
-    for (int w = 0; w < used; ++w) t += s[(int64_t)w * D];
-    job.db[c] += t;
+    for (; w < used; w += 4) {
+      const float4 v = *reinterpret_cast<const float4*>(s + (int64_t)w * D);
+      t.x += v.x; t.y += v.y; t.z += v.z; t.w += v.w;
+    }
+    red[sg][c] = t;
+    __syncthreads();
+    if (sg == 0) {
+      float4 o = *reinterpret_cast<float4*>(out);
+#pragma unroll
+      for (int q = 0; q < 4; ++q) {
+        const float4 v = red[q][c];
+        o.x += v.x; o.y += v.y; o.z += v.z; o.w += v.w;
+      }
+      *reinterpret_cast<float4*>(out) = o;
+    }
   }
 }
 
@@ -744,13 +774,15 @@ __global__ __launch_bounds__(64 * (D / 32)) void k_fq_attn_fwd(const FqArgs a) {
     for (int pb = 0; pb < 2; ++pb) {
       const int n = n0 + 16 * pb + r;
       bf16x8 vr;
-      if (n < n_hi) {
-        const int64_t o = ((int64_t)b * a.N + n) * D + 32 * j + 8 * g;
+      {   // unconditional loads (last row for points past the range), zeroed afterwards: a load
+          // under a divergent `if` is waited for with vmcnt(0) before the next one is issued
+        const int64_t o = ((int64_t)b * a.N + (n < n_hi ? n : n_hi - 1)) * D + 32 * j + 8 * g;
         kr[pb] = *reinterpret_cast<const bf16x8*>(a.Kp + o);
         vr = *reinterpret_cast<const bf16x8*>(a.Vp + o);
-      } else {
+        if (n >= n_hi) {
 #pragma unroll
-        for (int e = 0; e < 8; ++e) { kr[pb][e] = (__bf16)0.f; vr[e] = (__bf16)0.f; }
+          for (int e = 0; e < 8; ++e) { kr[pb][e] = (__bf16)0.f; vr[e] = (__bf16)0.f; }
+        }
       }
       {   // (two 8-byte stores: the padded 72-byte pitch is not 16-byte aligned)
         bf16x4 lo4, hi4;
@@ -890,13 +922,14 @@ __global__ __launch_bounds__(64 * (D / 32)) void k_fq_attn_bwd(const FqArgs a) {
     for (int pb = 0; pb < 2; ++pb) {
       const int n = n0 + 16 * pb + r;
       key_c[pb] = n < len;
-      if (n < n_hi) {
-        const int64_t o = ((int64_t)b * a.N + n) * D + 32 * j + 8 * g;
+      {
+        const int64_t o = ((int64_t)b * a.N + (n < n_hi ? n : n_hi - 1)) * D + 32 * j + 8 * g;
         kr[pb] = *reinterpret_cast<const bf16x8*>(a.Kp + o);
         vr[pb] = *reinterpret_cast<const bf16x8*>(a.Vp + o);
-      } else {
+        if (n >= n_hi) {
 #pragma unroll
-        for (int e = 0; e < 8; ++e) { kr[pb][e] = (__bf16)0.f; vr[pb][e] = (__bf16)0.f; }
+          for (int e = 0; e < 8; ++e) { kr[pb][e] = (__bf16)0.f; vr[pb][e] = (__bf16)0.f; }
+        }
       }
       {
         bf16x4 lo4, hi4;
@@ -1098,7 +1131,7 @@ __global__ __launch_bounds__(256) void k_wgrad_small256(const __bf16* __restrict
                                                         float* __restrict__ dW,
                                                         float* __restrict__ db) {
   constexpr int D = 256;
-  __shared__ float red[8][D][5];
+  __shared__ __attribute__((aligned(16))) float red[8][D][5];
   const int fc = threadIdx.x & 31, rl = threadIdx.x >> 5;
   const int64_t r0 = (int64_t)blockIdx.x * rows_per_wg;
   const int64_t r1 = r0 + rows_per_wg < M ? r0 + rows_per_wg : M;
@@ -1109,30 +1142,44 @@ __global__ __launch_bounds__(256) void k_wgrad_small256(const __bf16* __restrict
 #pragma unroll
     for (int c = 0; c < 4; ++c) acc[k][c] = 0.f;
   }
+  // the range's points, [row][4] (zero padded), staged once: fetched per row by every thread
+  // they were 12 four-byte loads per 4 rows next to the 4 sixteen-byte loads of G - the kernel
+  // was bound by load instructions, not bytes (2.2 TB/s)
+  float* sXs = &red[0][0][0];
+  for (int i = threadIdx.x; i < rows_per_wg * 4; i += 256) {
+    const int64_t rr = r0 + (i >> 2);
+    const int c = i & 3;
+    const float v = X[(rr < r1 ? rr : r1 - 1) * dq + (c < dq ? c : 0)];
+    sXs[i] = (rr < r1 && c < dq) ? v : 0.f;
+  }
+  __syncthreads();
+  // (rows past the end are fetched from the last row and weighted by zero: a load under a
+  //  divergent `if` gets its own basic block and its own s_waitcnt vmcnt(0) - four serialised
+  //  round trips per iteration instead of four loads in flight)
   for (int64_t row = r0 + rl; row < r1; row += 32) {
     bf16x8 gv[4];
-    float xv[4][4];
+    float xv[4][4], wv[4];
 #pragma unroll
     for (int u = 0; u < 4; ++u) {
       const int64_t rr = row + 8 * u;
-      const bool ok = rr < r1;
-      if (ok) gv[u] = *reinterpret_cast<const bf16x8*>(G + rr * D + 8 * fc);
-#pragma unroll
-      for (int k = 0; k < 8; ++k)
-        if (!ok) gv[u][k] = (__bf16)0.f;
-#pragma unroll
-      for (int c = 0; c < 4; ++c) xv[u][c] = (ok && c < dq) ? X[rr * dq + c] : 0.f;
+      const int64_t rc = rr < r1 ? rr : r1 - 1;
+      wv[u] = rr < r1 ? 1.f : 0.f;
+      gv[u] = *reinterpret_cast<const bf16x8*>(G + rc * D + 8 * fc);
+      const float4 x4 = *reinterpret_cast<const float4*>(sXs + (rc - r0) * 4);
+      xv[u][0] = x4.x * wv[u]; xv[u][1] = x4.y * wv[u];
+      xv[u][2] = x4.z * wv[u]; xv[u][3] = x4.w * wv[u];
     }
 #pragma unroll
     for (int u = 0; u < 4; ++u)
 #pragma unroll
       for (int k = 0; k < 8; ++k) {
         const float g = (float)gv[u][k];
-        bs[k] += g;
+        bs[k] = fmaf(g, wv[u], bs[k]);
 #pragma unroll
         for (int c = 0; c < 4; ++c) acc[k][c] = fmaf(g, xv[u][c], acc[k][c]);
       }
   }
+  __syncthreads();                       // the staged points share their LDS with `red`
 #pragma unroll
   for (int k = 0; k < 8; ++k) {
 #pragma unroll
@@ -1261,10 +1308,10 @@ __global__ __launch_bounds__(256, 1) void k_pma_fwd256(const PmaArgs a) {
 #pragma unroll
     for (int e = 0; e < 16; ++e) {
       const int c = lane + 64 * e, row = c >> 5, ch = c & 31;
-      bf16x8 v;
-      if (n0 + row < n_hi) {
-        v = *reinterpret_cast<const bf16x8*>(a.X + ((int64_t)b * a.N + n0 + row) * DK + ch * 8);
-      } else {
+      const int nr = n0 + row;
+      bf16x8 v = *reinterpret_cast<const bf16x8*>(
+          a.X + ((int64_t)b * a.N + (nr < n_hi ? nr : n_hi - 1)) * DK + ch * 8);
+      if (nr >= n_hi) {
 #pragma unroll
         for (int k = 0; k < 8; ++k) v[k] = (__bf16)0.f;
       }
@@ -1489,10 +1536,10 @@ __global__ __launch_bounds__(256, 1) void k_pma_bwd256(const PmaArgs a) {
 #pragma unroll
     for (int e = 0; e < 16; ++e) {
       const int c = lane + 64 * e, row = c >> 5, ch = c & 31;
-      bf16x8 v;
-      if (n0 + row < n_hi) {
-        v = *reinterpret_cast<const bf16x8*>(a.X + ((int64_t)b * a.N + n0 + row) * DK + ch * 8);
-      } else {
+      const int nr = n0 + row;
+      bf16x8 v = *reinterpret_cast<const bf16x8*>(
+          a.X + ((int64_t)b * a.N + (nr < n_hi ? nr : n_hi - 1)) * DK + ch * 8);
+      if (nr >= n_hi) {
 #pragma unroll
         for (int k = 0; k < 8; ++k) v[k] = (__bf16)0.f;
       }
@@ -1527,15 +1574,13 @@ __global__ __launch_bounds__(256, 1) void k_pma_bwd256(const PmaArgs a) {
         for (int pb = 0; pb < 2; ++pb) {
           const int n = n0 + 16 * pb + r;
           f32x4 dx = mfma32(tg, pds[pb], f32x4{0.f, 0.f, 0.f, 0.f});
-          if (n < n_hi) {
-            bf16x4* pd = reinterpret_cast<bf16x4*>(a.dX + ((int64_t)b * a.N + n) * DK + 16 * ft +
-                                                   4 * g);
-            if (a.accumulate_dx) {
-              const f32x4 o = tof(*pd);
-              dx[0] += o[0]; dx[1] += o[1]; dx[2] += o[2]; dx[3] += o[3];
-            }
-            *pd = pack4(dx);
+          bf16x4* pd = reinterpret_cast<bf16x4*>(
+              a.dX + ((int64_t)b * a.N + (n < n_hi ? n : n_hi - 1)) * DK + 16 * ft + 4 * g);
+          if (a.accumulate_dx) {            // (wave-uniform; the load itself is unconditional)
+            const f32x4 o = tof(*pd);
+            dx[0] += o[0]; dx[1] += o[1]; dx[2] += o[2]; dx[3] += o[3];
           }
+          if (n < n_hi) *pd = pack4(dx);
         }
       }
     }
@@ -1641,7 +1686,10 @@ int wgrad256_launch(const Wgrad256Jobs& jobs, void* ws, hipStream_t st) {
 int wgrad256_launch_t(const Wgrad256Jobs& jobs, void* ws, bool f32_operands, hipStream_t st) {
   if (jobs.n == 0) return PCA_OK;
   int64_t maxM = 0;
-  for (int i = 0; i < jobs.n; ++i) maxM = jobs.j[i].M > maxM ? jobs.j[i].M : maxM;
+  for (int i = 0; i < jobs.n; ++i) {
+    maxM = jobs.j[i].M > maxM ? jobs.j[i].M : maxM;
+    PCA_REQUIRE(((uintptr_t)jobs.j[i].dW & 15) == 0, "wgrad256: dW must be 16-byte aligned");
+  }
   if (maxM == 0) return PCA_OK;
   const int nwg = wgrad256_nwg(maxM);
   int rpw = (int)cdiv(cdiv(maxM, nwg), 64) * 64;

@@ -28,6 +28,14 @@ int attn1_bwd256(const __bf16* dO, const __bf16* QpS, const __bf16* KpP, const _
                  const __bf16* Kt, __bf16* dQp, float* dKpPart, float* dVpPart, float* dKp,
                  float* dVp, int B, int N, hipStream_t st);
 
+// the whole many-queries block in ONE launch (d256_fused.hip): wave = head, both weight slices in
+// registers.  WqB / WoB: natural bf16 images (prep mode 0); X bf16 [B*N][256] (or fp32 [B*N][dq],
+// dq <= 4, with WqF); QpS / OS / mask nullable (saved for the backward)
+int isab1_fwd256_fused(const void* X, int dq, const __bf16* WqB, const float* WqF, const float* bq,
+                       const __bf16* KpP, const __bf16* Vt, const __bf16* WoB, const float* bo,
+                       __bf16* Y, __bf16* QpS, __bf16* OS, uint32_t* mask, int B, int N,
+                       hipStream_t st);
+
 // dW[256 x 256] += G^T A, db[256] += colsum(G) (nullable); G, A bf16 [M][256]
 struct Wgrad256Job {
   const void* G;      // bf16, or fp32 with wgrad256_launch_t(..., f32_operands = true)

@@ -1,0 +1,390 @@
+// Single-launch forward of the many-queries block at d = 256 / 8 heads / m = 32 keys (ISAB's
+// mab1(X, H), set_transformer-master/modules.py:53 with :19-33 inside):
+//     Qp = fc_q(x) ; per head A = softmax(Qp_h Kp_h^T / sqrt d) ; O = Qp + A Vp ; Y = O + relu(fc_o(O))
+//
+// WAVE = HEAD, WEIGHTS IN REGISTERS.  The two 128 KiB weight images do not fit the 160 KiB of LDS
+// next to anything else - but the register file of a CU is 512 KiB.  The workgroup is 8 waves;
+// wave j owns head j, i.e. output features 32 j .. 32 j + 31 of BOTH projections, and keeps its
+// [32 x 256] slices of Wq and Wo as MFMA A operands in 128 VGPRs for the whole launch.  What
+// moves through LDS is only activations, in full tiles shared by the 8 waves:
+//     X tile [64 points][256] (LDS-DMA, double buffered)  --GEMM1-->  Qp_h (registers, fp32)
+//     --scores / softmax / A V, all inside the wave (its head's K / V slices: 16 VGPRs)-->  O_h
+//     --own 32-column slice written to the O tile--  barrier  --GEMM2 over the whole O tile-->
+//     Z_h ; Y_h = O_h + relu(Z_h + bo) --own slice of the Y tile-- barrier -- coalesced store.
+// So X is read once and Y written once (the two-phase split it replaces read / wrote O in
+// between: 2 extra passes over [B*N, 256]), no weight is ever re-read, and every global access is
+// a full 128-byte line.  Roofline unit: 2 (dq d + d^2 + 2 m d) FLOP per point,
+// 2 (dq + d) bytes per point.
+#include "d256_bf16.hpp"
+
+#include <math.h>
+
+#include <mutex>
+
+namespace pca {
+
+namespace {
+
+// 32-point tiles (2 blocks of 16): with 64 the kernel needs ~290 registers - over the 256 of two
+// waves per SIMD, and every scratch reload is a VMEM access that drains the LDS-DMA queue
+constexpr int D = 256, MI = 32, P = 32, NBK = P / 16;
+constexpr int ROWB = D * 2, TILEB = P * ROWB;               // 16 KiB per tile
+constexpr int DMA_PER_WAVE = TILEB / 1024 / 8;              // 1 KiB pieces per wave and tile
+
+struct FusedFwdArgs {
+  const void* X;          // [B*N][256] bf16, or fp32 [B*N][dq] for dq <= 4
+  const __bf16* Wq;       // [256][256] bf16, natural (nullptr for dq <= 4)
+  const float* WqF;       // dq <= 4: fp32 [256][dq]
+  const float* bq;
+  const __bf16* KpP;      // [B][32][256] (K-permuted features inside each head)
+  const __bf16* Vt;       // [B][256][32] (keys in perm32 order)
+  const __bf16* Wo;       // [256][256] bf16, natural
+  const float* bo;
+  __bf16* Y;              // [B*N][256]
+  __bf16 *QpS, *OS;       // saved for the backward (nullable)
+  uint32_t* mask;         // ReLU mask bits in the layout of mab1_mask_index<256> (nullable)
+  int B, N, dq, tiles_per_set, units_per_wg;
+  float scale_log2e;
+};
+
+// 16-byte chunk c16 of row `row` of a [64][256] bf16 tile (swizzled like the weight images)
+__device__ __forceinline__ int toff(int row, int c16) { return swz(row, c16, ROWB); }
+
+typedef __attribute__((address_space(1))) const void gptr_t;
+typedef __attribute__((address_space(3))) void lptr_t;
+
+template <bool SMALL>
+__global__ __launch_bounds__(512, 2) void k_isab1_fwd256(const FusedFwdArgs a) {
+  constexpr int KS = D / 32;
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  // every tile exists twice (iteration parity): the global stores of tile i are issued in
+  // iteration i + 1, so no wait of iteration i + 1 ever covers a store that was just issued
+  char* sXb = smem;                         // X tiles          [2][TILEB]
+  char* sOb = smem + 2 * TILEB;             // O tiles
+  char* sQb = smem + 4 * TILEB;             // Qp tiles (training: saved for the backward)
+  char* sYb = smem + 6 * TILEB;             // Y tiles
+  uint32_t* sMaskb = reinterpret_cast<uint32_t*>(smem + 8 * TILEB);   // [2][NBK blocks][2 words][64]
+  float* sBias = reinterpret_cast<float*>(sMaskb + 2 * NBK * 2 * 64); // bq [256], bo [256]
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int j = __builtin_amdgcn_readfirstlane(tid >> 6);              // head of this wave (scalar)
+  const int r = lane & 15, g = lane >> 4;
+
+  // ---- this head's weight slices: A operands [row = feature 32 j + 16 t + r][k = 32 s + 8 g ..] ----
+  bf16x8 wqa[SMALL ? 1 : KS][2], woa[KS][2];
+#pragma unroll
+  for (int s = 0; s < KS; ++s)
+#pragma unroll
+    for (int t = 0; t < 2; ++t) {
+      const int64_t o = (int64_t)(32 * j + 16 * t + r) * D + 32 * s + 8 * g;
+      woa[s][t] = *reinterpret_cast<const bf16x8*>(a.Wo + o);
+      if (!SMALL) wqa[s][t] = *reinterpret_cast<const bf16x8*>(a.Wq + o);
+    }
+  // layer 1: fc_q rows of the features this lane holds in the accumulator layout
+  float wqs[SMALL ? 2 : 1][4][4];
+  // (the biases live in LDS: 16 registers less in a kernel at the 256-register limit of two waves
+  //  per SIMD, and no ordinary global load inside the loop - hipcc drains the LDS-DMA queue with
+  //  vmcnt(0) at the first use of any such load)
+  if (tid < D) {
+    sBias[tid] = a.bq[tid];
+    sBias[D + tid] = a.bo[tid];
+  }
+  auto bias4 = [&](int which, int t) {
+    const float4 q4 = *reinterpret_cast<const float4*>(sBias + which * D + 32 * j + 16 * t + 4 * g);
+    return f32x4{q4.x, q4.y, q4.z, q4.w};
+  };
+  // workgroup barrier that orders LDS traffic only: __syncthreads() would also wait for every
+  // outstanding global store and LDS-DMA (vmcnt(0)), i.e. expose a full memory round trip three
+  // times per tile
+  auto lds_barrier = [] {
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+    __builtin_amdgcn_s_barrier();
+    asm volatile("" ::: "memory");
+  };
+#pragma unroll
+  for (int t = 0; t < 2; ++t) {
+    if (SMALL) {
+#pragma unroll
+      for (int e = 0; e < 4; ++e)
+#pragma unroll
+        for (int c = 0; c < 4; ++c)
+          wqs[SMALL ? t : 0][e][c] = c < a.dq ? a.WqF[(32 * j + 16 * t + 4 * g + e) * a.dq + c] : 0.f;
+    }
+  }
+
+  const int total_units = a.B * a.tiles_per_set;
+  const int u0 = blockIdx.x * a.units_per_wg;
+  const int u1 = (u0 + a.units_per_wg < total_units) ? u0 + a.units_per_wg : total_units;
+  // LDS-DMA of a unit's X tile: LDS is written linearly (wave base + 16 lane); piece p of the
+  // tile (row p / 32, slot p % 32) must hold chunk slot ^ (row & 15) of its row, so each lane
+  // fetches THAT chunk (the swizzle is an involution: source-side permutation, rule 21)
+  auto dma_x = [&](int unit, char* dst) {
+    const int b = unit / a.tiles_per_set, n0 = (unit - b * a.tiles_per_set) * P;
+#pragma unroll
+    for (int i = 0; i < DMA_PER_WAVE; ++i) {
+      const int p = (DMA_PER_WAVE * j + i) * 64 + lane;    // this wave: consecutive 1 KiB pieces
+      const int row = p >> 5, slot = p & 31;
+      const int ch = (slot & ~15) | ((slot ^ row) & 15);
+      const int n = n0 + row < a.N ? n0 + row : a.N - 1;   // padding rows: any valid line
+      const __bf16* src = reinterpret_cast<const __bf16*>(a.X) + ((int64_t)b * a.N + n) * D + ch * 8;
+      // The DMA is issued from inline asm on purpose: with the builtin, hipcc knows an LDS write is
+      // pending on the VM counter and puts s_waitcnt vmcnt(0) in front of every later ds_read that
+      // might alias it - i.e. the whole memory latency of the tile just requested would be waited
+      // for at once.  Hidden from the compiler, the transfer is ordered by the counted vmcnt in the
+      // loop (hidden VMEM operations can only make hipcc's own counted waits stricter: the counter
+      // retires in order).  M0 = wave-uniform LDS base, written in the statement that uses it.
+      const unsigned ldst = __builtin_amdgcn_readfirstlane(
+          (unsigned)(uintptr_t)(lptr_t*)(dst + (DMA_PER_WAVE * j + i) * 1024));
+      unsigned keep;
+      asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %2\n\ts_nop 0\n\t"
+                   "global_load_lds_dwordx4 %1, off\n\ts_mov_b32 m0, %0"
+                   : "=&s"(keep) : "v"(src), "s"(ldst) : "memory");
+    }
+  };
+  if (!SMALL && u0 < u1) dma_x(u0, sXb);
+
+  // Per-lane byte offsets into a tile, computed ONCE: the swizzle XORs the 16-byte chunk index with
+  // the row, so an address is not "base + constant" across k-steps - left to the compiler, every
+  // LDS access re-derived it (measured: 486 VALU instructions per wave and tile against 72 MFMAs).
+  //   oB[k]: B-operand row fragment, row r, chunk 4 (s & 3) + g  (+ 256 (s >> 2) + 8192 nb)
+  //   oD[t]: accumulator-layout 8 bytes, row r, features 32 j + 16 t + 4 g  (+ 8192 nb)
+  //   oC   : coalesced 16-byte piece of row tid / 32, chunk tid % 32   (+ 8192 i)
+  int oB[4], oD[2];
+#pragma unroll
+  for (int k = 0; k < 4; ++k) oB[k] = toff(r, 4 * k + g);
+#pragma unroll
+  for (int t = 0; t < 2; ++t) oD[t] = toff(r, 4 * j + 2 * t + (g >> 1)) + 8 * (g & 1);
+  const int oC = toff(tid >> 5, tid & 31);
+
+  // coalesced stores of a finished tile (Y; training: O, Qp, ReLU mask words) from its LDS tiles
+  auto store_tile = [&](int unit, int par) {
+    const int b = unit / a.tiles_per_set, tile = unit - b * a.tiles_per_set;
+    const int n0 = tile * P, nlive = a.N - n0;
+    const int64_t rowbase = (int64_t)b * a.N + n0;
+#pragma unroll
+    for (int i = 0; i < P / 16; ++i) {
+      const int c = tid + 512 * i, row = c >> 5, ch = c & 31;
+      if (row < nlive) {
+        *reinterpret_cast<uint4*>(a.Y + (rowbase + row) * D + ch * 8) =
+            *reinterpret_cast<const uint4*>(sYb + par * TILEB + oC + 8192 * i);
+        if (a.OS != nullptr)
+          *reinterpret_cast<uint4*>(a.OS + (rowbase + row) * D + ch * 8) =
+              *reinterpret_cast<const uint4*>(sOb + par * TILEB + oC + 8192 * i);
+        if (a.QpS != nullptr)
+          *reinterpret_cast<uint4*>(a.QpS + (rowbase + row) * D + ch * 8) =
+              *reinterpret_cast<const uint4*>(sQb + par * TILEB + oC + 8192 * i);
+      }
+    }
+    if (a.mask != nullptr && tid < NBK * 128) {
+      const int nb = tid >> 7, w = (tid >> 6) & 1;
+      const int tiles128 = (a.tiles_per_set * P + 127) / 128;
+      const int64_t blk = (int64_t)b * tiles128 * 8 + tile * NBK + nb;
+      a.mask[(blk * 2 + w) * 64 + lane] = sMaskb[par * NBK * 128 + (nb * 2 + w) * 64 + lane];
+    }
+  };
+
+  // (Tried: the two waves of each SIMD in antiphase - waves 0-3 one phase ahead of waves 4-7, half
+  //  steps between the barriers, so that one wave's softmax / epilogue VALU run meets the other's
+  //  MFMA run.  Same results, 6 % slower in training mode, equal in inference: the waves of a SIMD
+  //  already interleave inside a phase, and the split store passes cost more than the overlap won.)
+  int cur_b = -1;
+  bf16x8 kpa[2], vta[2];
+  for (int unit = u0; unit < u1; ++unit) {
+    const int par = (unit - u0) & 1;
+    char* sXc = sXb + par * TILEB;
+    char* sO = sOb + par * TILEB;
+    char* sQ = sQb + par * TILEB;
+    char* sY = sYb + par * TILEB;
+    uint32_t* sMask = sMaskb + par * NBK * 128;
+    const int b = unit / a.tiles_per_set, tile = unit - b * a.tiles_per_set;
+    const int n0 = tile * P, nlive = a.N - n0;
+    const int64_t rowbase = (int64_t)b * a.N + n0;
+    (void)tile;
+    // layer 1: this tile's points straight to registers (issued before the deferred stores, so
+    // that the counted wait for them does not cover the stores)
+    float xv[SMALL ? NBK : 1][4];
+    if (SMALL) {
+#pragma unroll
+      for (int nb = 0; nb < NBK; ++nb) {
+        const int n = 16 * nb + r;
+#pragma unroll
+        for (int c = 0; c < 4; ++c)
+          xv[SMALL ? nb : 0][c] = (n < nlive && c < a.dq)
+                      ? reinterpret_cast<const float*>(a.X)[(rowbase + n) * a.dq + c] : 0.f;
+      }
+    }
+    // The next tile starts to stream in now (the last readers of its buffer passed barrier B1 of
+    // the previous iteration); this tile's DMA was issued one iteration ago: everything older
+    // than the pieces just issued - it and the stores of two tiles back - must have landed.
+    if (!SMALL) {
+      if (unit + 1 < u1) {
+        dma_x(unit + 1, sXb + (par ^ 1) * TILEB);
+        static_assert(DMA_PER_WAVE == 2, "the counted wait below");
+        asm volatile("s_waitcnt vmcnt(2)" ::: "memory");
+      } else {
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+      }
+    }
+    lds_barrier();                       // B0: X tile (all waves' pieces); previous tile's Y / mask
+    if (unit > u0) store_tile(unit - 1, par ^ 1);
+    if (b != cur_b) {
+#pragma unroll
+      for (int kt = 0; kt < 2; ++kt) {
+        kpa[kt] = *reinterpret_cast<const bf16x8*>(a.KpP + ((int64_t)b * MI + 16 * kt + r) * D +
+                                                   32 * j + 8 * g);
+        vta[kt] = *reinterpret_cast<const bf16x8*>(a.Vt + ((int64_t)b * D + 32 * j + 16 * kt + r) * MI +
+                                                   8 * g);
+      }
+      cur_b = b;
+    }
+    // ---- GEMM1: Qp_h^T[f][pt] = Wq_h . X^T + bq ----
+    f32x4 acc[2][NBK];
+    if (SMALL) {
+      const f32x4 bqv[2] = {bias4(0, 0), bias4(0, 1)};
+#pragma unroll
+      for (int nb = 0; nb < NBK; ++nb)
+#pragma unroll
+        for (int t = 0; t < 2; ++t)
+#pragma unroll
+          for (int e = 0; e < 4; ++e)
+            acc[t][nb][e] = bqv[t][e] + wqs[SMALL ? t : 0][e][0] * xv[SMALL ? nb : 0][0] +
+                            wqs[SMALL ? t : 0][e][1] * xv[SMALL ? nb : 0][1] +
+                            wqs[SMALL ? t : 0][e][2] * xv[SMALL ? nb : 0][2] +
+                            wqs[SMALL ? t : 0][e][3] * xv[SMALL ? nb : 0][3];
+    } else {
+      const f32x4 bq0 = bias4(0, 0), bq1 = bias4(0, 1);
+#pragma unroll
+      for (int nb = 0; nb < NBK; ++nb) {
+        acc[0][nb] = bq0;
+        acc[1][nb] = bq1;
+      }
+#pragma unroll
+      for (int s = 0; s < KS; ++s)
+#pragma unroll
+        for (int nb = 0; nb < NBK; ++nb) {
+          const bf16x8 bx =
+              *reinterpret_cast<const bf16x8*>(sXc + oB[s & 3] + 256 * (s >> 2) + 8192 * nb);
+          acc[0][nb] = mfma32(wqa[SMALL ? 0 : s][0], bx, acc[0][nb]);
+          acc[1][nb] = mfma32(wqa[SMALL ? 0 : s][1], bx, acc[1][nb]);
+        }
+    }
+    if (a.QpS != nullptr) {              // own 32-column slice of the Qp tile
+#pragma unroll
+      for (int nb = 0; nb < NBK; ++nb)
+#pragma unroll
+        for (int t = 0; t < 2; ++t)
+          *reinterpret_cast<bf16x4*>(sQ + oD[t] + 8192 * nb) = pack4(acc[t][nb]);
+    }
+    // ---- attention over the 32 inducing keys, all inside the wave ----
+#pragma unroll
+    for (int nb = 0; nb < NBK; ++nb) {
+      const bf16x8 qb = pack8(acc[0][nb], acc[1][nb]);
+      const f32x4 z4 = {0.f, 0.f, 0.f, 0.f};
+      f32x4 s0 = mfma32(kpa[0], qb, z4), s1 = mfma32(kpa[1], qb, z4);
+      float mx = fmaxf(fmaxf(fmaxf(s0[0], s0[1]), fmaxf(s0[2], s0[3])),
+                       fmaxf(fmaxf(s1[0], s1[1]), fmaxf(s1[2], s1[3])));
+      mx = wave16_max(mx);
+      float sum = 0.f;
+#pragma unroll
+      for (int e = 0; e < 4; ++e) {
+        // raw v_exp_f32: the arguments are <= 0 and finite, so exp2f's range handling (compare,
+        // select, ldexp per element) buys nothing here
+        s0[e] = __builtin_amdgcn_exp2f((s0[e] - mx) * a.scale_log2e);
+        s1[e] = __builtin_amdgcn_exp2f((s1[e] - mx) * a.scale_log2e);
+        sum += s0[e] + s1[e];
+      }
+      sum = wave16_sum(sum);
+      const float inv = __builtin_amdgcn_rcpf(sum);
+#pragma unroll
+      for (int e = 0; e < 4; ++e) { s0[e] *= inv; s1[e] *= inv; }
+      const bf16x8 pb = pack8(s0, s1);
+      acc[0][nb] = mfma32(vta[0], pb, acc[0][nb]);
+      acc[1][nb] = mfma32(vta[1], pb, acc[1][nb]);
+    }
+    // ---- own slice of the O tile ----
+#pragma unroll
+    for (int nb = 0; nb < NBK; ++nb)
+#pragma unroll
+      for (int t = 0; t < 2; ++t)
+        *reinterpret_cast<bf16x4*>(sO + oD[t] + 8192 * nb) = pack4(acc[t][nb]);
+    lds_barrier();                       // B1: O (and Qp) tiles complete; X tile consumed
+    // ---- GEMM2: Z_h^T = Wo_h . O^T + bo ; Y_h = O_h + relu(Z_h) ----
+    // (the accumulators of O_h are re-used for Z_h: the residual O_h is read back from the
+    //  wave's own slice of the O tile - bf16, the rounding the two-launch form had as well)
+    {
+      const f32x4 bo0 = bias4(1, 0), bo1 = bias4(1, 1);
+#pragma unroll
+      for (int nb = 0; nb < NBK; ++nb) {
+        acc[0][nb] = bo0;
+        acc[1][nb] = bo1;
+      }
+    }
+#pragma unroll
+    for (int s = 0; s < KS; ++s)
+#pragma unroll
+      for (int nb = 0; nb < NBK; ++nb) {
+        const bf16x8 ob =
+            *reinterpret_cast<const bf16x8*>(sO + oB[s & 3] + 256 * (s >> 2) + 8192 * nb);
+        acc[0][nb] = mfma32(woa[s][0], ob, acc[0][nb]);
+        acc[1][nb] = mfma32(woa[s][1], ob, acc[1][nb]);
+      }
+#pragma unroll
+    for (int nb = 0; nb < NBK; ++nb) {
+      uint32_t bits = 0u;                // byte (j & 3) of mask word j >> 2: tiles 2 j, 2 j + 1
+#pragma unroll
+      for (int t = 0; t < 2; ++t) {
+        const bf16x4 o4 = *reinterpret_cast<const bf16x4*>(sO + oD[t] + 8192 * nb);
+        f32x4 y;
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+          const float zz = acc[t][nb][e];
+          y[e] = (float)o4[e] + fmaxf(zz, 0.f);
+          if (zz > 0.f) bits |= 1u << (4 * t + e);
+        }
+        *reinterpret_cast<bf16x4*>(sY + oD[t] + 8192 * nb) = pack4(y);
+      }
+      if (a.mask != nullptr)
+        reinterpret_cast<uint8_t*>(sMask)[((nb * 2 + (j >> 2)) * 64 + lane) * 4 + (j & 3)] =
+            (uint8_t)bits;
+    }
+    // (this tile's Y / O / Qp / mask leave in the next iteration, after its barrier B0)
+  }
+  if (u0 < u1) {
+    lds_barrier();
+    store_tile(u1 - 1, (u1 - 1 - u0) & 1);
+  }
+}
+
+}  // namespace
+
+int isab1_fwd256_fused(const void* X, int dq, const __bf16* WqB, const float* WqF, const float* bq,
+                       const __bf16* KpP, const __bf16* Vt, const __bf16* WoB, const float* bo,
+                       __bf16* Y, __bf16* QpS, __bf16* OS, uint32_t* mask, int B, int N,
+                       hipStream_t st) {
+  FusedFwdArgs a{};
+  a.X = X; a.Wq = WqB; a.WqF = WqF; a.bq = bq; a.KpP = KpP; a.Vt = Vt; a.Wo = WoB; a.bo = bo;
+  a.Y = Y; a.QpS = QpS; a.OS = OS; a.mask = mask;
+  a.B = B; a.N = N; a.dq = dq;
+  a.tiles_per_set = (int)cdiv(N, P);
+  a.scale_log2e = 1.4426950408889634f / sqrtf((float)D);
+  const int total = B * a.tiles_per_set;
+  int grid = total < 256 ? total : 256;
+  a.units_per_wg = (int)cdiv(total, grid);
+  grid = (int)cdiv(total, a.units_per_wg);
+  const size_t lds = 8 * (size_t)TILEB + 2 * NBK * 2 * 64 * sizeof(uint32_t) + 2 * D * sizeof(float);
+  static std::once_flag once;
+  std::call_once(once, [] {
+    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(k_isab1_fwd256<false>),
+                              hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(k_isab1_fwd256<true>),
+                              hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+  });
+  const double pts = (double)B * N;
+  ProfScope ps(PCA_K_MAB1_FWD, st, 2.0 * pts * ((double)dq * D + (double)D * D + 2.0 * MI * D),
+               pts * ((dq <= 4 ? 4.0 : 2.0) * dq + 2.0 * D));
+  if (dq <= 4) hipLaunchKernelGGL(k_isab1_fwd256<true>, dim3(grid), dim3(512), lds, st, a);
+  else hipLaunchKernelGGL(k_isab1_fwd256<false>, dim3(grid), dim3(512), lds, st, a);
+  ps.end();
+  return check_launch("k_isab1_fwd256");
+}
+
+}  // namespace pca

@@ -43,7 +43,11 @@ __global__ __launch_bounds__(256) void k_gemm_f32(pca_gemm_desc g, const float* 
 #pragma unroll
     for (int c = 0; c < 4; ++c) acc[r][c] = 0.f;
 
-  for (int64_t kt = k_begin; kt < k_end; kt += BK) {
+  // The next K-step's operands are fetched into registers while the current one is multiplied:
+  // with the loads issued only after the barrier, a [4096 x 256 x 256] product (16 K-steps, one
+  // workgroup per CU) spent 40 us waiting on 16 dependent memory round trips.
+  float ra[4], rb[4];
+  auto fetch = [&](int64_t kt) {
 #pragma unroll
     for (int e = 0; e < 4; ++e) {
       const int idx = tid + e * 256;
@@ -51,9 +55,7 @@ __global__ __launch_bounds__(256) void k_gemm_f32(pca_gemm_desc g, const float* 
       if (a_kcontig) { k = idx & (BK - 1); i = idx >> 4; }
       else           { i = idx & (BM - 1); k = idx >> 6; }
       const int64_t gi = m0 + i, gk = kt + k;
-      float v = 0.f;
-      if (gi < g.M && gk < k_end) v = A[gi * g.sa_m + gk * g.sa_k];
-      As[k][i] = v;
+      ra[e] = (gi < g.M && gk < k_end) ? A[gi * g.sa_m + gk * g.sa_k] : 0.f;
     }
 #pragma unroll
     for (int e = 0; e < 4; ++e) {
@@ -62,11 +64,29 @@ __global__ __launch_bounds__(256) void k_gemm_f32(pca_gemm_desc g, const float* 
       if (b_ncontig) { j = idx & (BN - 1); k = idx >> 6; }
       else           { k = idx & (BK - 1); j = idx >> 4; }
       const int64_t gj = n0 + j, gk = kt + k;
-      float v = 0.f;
-      if (gj < g.N && gk < k_end) v = B[gk * g.sb_k + gj * g.sb_n];
-      Bs[k][j] = v;
+      rb[e] = (gj < g.N && gk < k_end) ? B[gk * g.sb_k + gj * g.sb_n] : 0.f;
+    }
+  };
+  if (k_begin < k_end) fetch(k_begin);
+  for (int64_t kt = k_begin; kt < k_end; kt += BK) {
+#pragma unroll
+    for (int e = 0; e < 4; ++e) {
+      const int idx = tid + e * 256;
+      int i, k;
+      if (a_kcontig) { k = idx & (BK - 1); i = idx >> 4; }
+      else           { i = idx & (BM - 1); k = idx >> 6; }
+      As[k][i] = ra[e];
+    }
+#pragma unroll
+    for (int e = 0; e < 4; ++e) {
+      const int idx = tid + e * 256;
+      int j, k;
+      if (b_ncontig) { j = idx & (BN - 1); k = idx >> 6; }
+      else           { k = idx & (BK - 1); j = idx >> 4; }
+      Bs[k][j] = rb[e];
     }
     __syncthreads();
+    if (kt + BK < k_end) fetch(kt + BK);
 #pragma unroll
     for (int k = 0; k < BK; ++k) {
       const float4 a = *reinterpret_cast<const float4*>(&As[k][ty * 4]);

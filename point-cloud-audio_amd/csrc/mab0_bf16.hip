@@ -573,13 +573,15 @@ __global__ __launch_bounds__(256) void k_mab0_attn_small(const float* __restrict
         sv[u] = nn < cn ? gk[0] * x4.x + gk[1] * x4.y + gk[2] * x4.z + gk[3] * x4.w : -INFINITY;
       }
       const float mn = fmaxf(fmaxf(m, fmaxf(sv[0], sv[1])), fmaxf(sv[2], sv[3]));
-      const float al = exp2f(m - mn);
+      // (raw v_exp_f32: exp2f adds a range test and a rescale per call for results below 2^-126,
+      //  which are zero for every purpose here)
+      const float al = __builtin_amdgcn_exp2f(m - mn);
       l *= al;
 #pragma unroll
       for (int c = 0; c < 4; ++c) t[c] *= al;
 #pragma unroll
       for (int u = 0; u < 4; ++u) {
-        const float p = exp2f(sv[u] - mn);          // exp2(-inf) = 0 for padding
+        const float p = __builtin_amdgcn_exp2f(sv[u] - mn);          // exp2(-inf) = 0 for padding
         l += p;
 #pragma unroll
         for (int c = 0; c < 4; ++c) t[c] = fmaf(p, xv[u][c], t[c]);
@@ -697,11 +699,20 @@ int mab0_prep_launch(const Mab0PrepJobs& J, hipStream_t st) {
 }
 
 // layer-1 attention (dk <= 4) of R = h*m score rows, stand-alone (the d = 256 path calls it)
+// workgroups per set of the layer-1 kernels (each owns R / y >= 32 score rows and re-stages the
+// set's few-column points, which costs nothing): the work is vector-ALU arithmetic per (row,
+// point), so the launch should put four waves on every SIMD, not one
+int small_row_split(int B, int R) {
+  int y = 2;
+  while (y * 2 <= R / 32 && (int64_t)B * y < 1024) y *= 2;
+  return y;
+}
+
 int mab0_attn_small_launch(const float* X, const float* Gf, int B, int N, int R, int dk, float* T,
                            float* LSE, const int32_t* lengths, hipStream_t st) {
   PCA_REQUIRE(R == 64 || R == 128 || R == 256, "mab0_attn_small: %d score rows", R);
-  hipLaunchKernelGGL(k_mab0_attn_small, dim3(B, 2), dim3(256), 0, st, X, Gf, N, R, dk, T, LSE,
-                     lengths);
+  hipLaunchKernelGGL(k_mab0_attn_small, dim3(B, small_row_split(B, R)), dim3(256), 0, st, X, Gf, N,
+                     R, dk, T, LSE, lengths);
   return check_launch("k_mab0_attn_small");
 }
 

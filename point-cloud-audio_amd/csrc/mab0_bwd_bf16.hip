@@ -357,7 +357,7 @@ __global__ __launch_bounds__(256) void k_mab0_bwd_small(
         const float4 x4 = *reinterpret_cast<const float4*>(&sX[n * 4]);
         const float s = gk[0] * x4.x + gk[1] * x4.y + gk[2] * x4.z + gk[3] * x4.w;
         const float da = dt[0] * x4.x + dt[1] * x4.y + dt[2] * x4.z + dt[3] * x4.w;
-        const float ds = LN2 * exp2f(s - lse) * (da - del);
+        const float ds = LN2 * __builtin_amdgcn_exp2f(s - lse) * (da - del);
         acc[0] = fmaf(ds, x4.x, acc[0]); acc[1] = fmaf(ds, x4.y, acc[1]);
         acc[2] = fmaf(ds, x4.z, acc[2]); acc[3] = fmaf(ds, x4.w, acc[3]);
       }
@@ -597,8 +597,8 @@ int mab0_bwd_small_launch(const float* X, const float* Gf, const float* dTf, con
                           const float* Delta, int B, int N, int R, int Rp, int dk, float* DG,
                           const int32_t* lengths, hipStream_t st) {
   PCA_REQUIRE(R == 64 || R == 128 || R == 256, "mab0_bwd_small: %d score rows", R);
-  hipLaunchKernelGGL(k_mab0_bwd_small, dim3(B, 2), dim3(256), 0, st, X, Gf, dTf, LSE, Delta, N, R,
-                     Rp, dk, DG, lengths);
+  hipLaunchKernelGGL(k_mab0_bwd_small, dim3(B, small_row_split(B, R)), dim3(256), 0, st, X, Gf, dTf,
+                     LSE, Delta, N, R, Rp, dk, DG, lengths);
   return check_launch("k_mab0_bwd_small");
 }
 

@@ -880,6 +880,18 @@ int mab1_bf16_fwd_ex(const pca_mab_shape& s, const void* X, const float* H,
   if (d == 256) {          // Q phase + O phase: O meets in the saved / scratch block
     if (small && !abf) return launch_fwd<256, 32, true, false>(a, st);
     a.OS = v.OS;
+    // PCA_D256_FUSED=0: the two-launch form (Q phase + row-GEMM O phase) for A/B measurements
+    static const bool fused256 = [] {
+      const char* e = getenv("PCA_D256_FUSED");
+      return !(e != nullptr && e[0] == '0');
+    }();
+    if (abf && !f8 && fused256) {
+      // one launch: wave = head, both weight slices in registers (d256_fused.hip)
+      PCA_TRY(prep_weight(p.wo, WoP, d, d, 0, st));           // natural image for this kernel
+      return isab1_fwd256_fused(X, s.dq, WqB, p.wq, p.bq, v.KpP, v.Vt, WoP, p.bo,
+                                reinterpret_cast<__bf16*>(Y), a.QpS, training ? v.OS : nullptr,
+                                a.mask, s.B, s.nq, st);
+    }
     if (abf) {
       // bf16 activations: the O phase is the row-GEMM kernel of d256_bf16.hip (full-line I/O);
       // layer 1 runs its Q phase without any weight image (8 waves, 32 KiB of LDS)

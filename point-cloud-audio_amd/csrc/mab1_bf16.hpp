@@ -330,6 +330,7 @@ int mab0_d256_fwd(const pca_mab_shape& s, const float* I, const void* X, const p
 int mab0_d256_bwd(const pca_mab_shape& s, const float* I, const void* X, const pca_mab_params& p,
                   const void* saved, const float* dH, float* dI, void* dX, int dk_accumulate,
                   const pca_mab_grads& gr, void* ws, hipStream_t st, BwdDefer* defer);
+int small_row_split(int B, int R);
 int mab0_attn_small_launch(const float* X, const float* Gf, int B, int N, int R, int dk, float* T,
                            float* LSE, const int32_t* lengths, hipStream_t st);
 int mab0_bwd_small_launch(const float* X, const float* Gf, const float* dTf, const float* LSE,
