@@ -172,9 +172,16 @@ __global__ __launch_bounds__(1024 / NB, 4 / NB) void k_rowgemm(const RowGemmArgs
         // rows past the end of the set read its last row instead (never stored: a point only
         // feeds its own output column) - a load under a divergent condition gets its own basic
         // block and s_waitcnt vmcnt(0), which serialised the NI loads of a chunk
+        // (BWD_O keeps the guarded form: with the loads free to move, the scheduler hoists them
+        //  over the 128 accumulators it initialises from dY and spills 144 bytes per lane)
         const int n = n_base + crow0 + 8 * i;
-        dst[i] = *reinterpret_cast<const uint4*>(
-            a.In + ((int64_t)b * a.N + (n < a.N ? n : a.N - 1)) * D + 64 * c + 8 * cc16);
+        if (MODE == RG_BWD_O)
+          dst[i] = n < a.N ? *reinterpret_cast<const uint4*>(a.In + ((int64_t)b * a.N + n) * D +
+                                                             64 * c + 8 * cc16)
+                           : uint4{0u, 0u, 0u, 0u};
+        else
+          dst[i] = *reinterpret_cast<const uint4*>(
+              a.In + ((int64_t)b * a.N + (n < a.N ? n : a.N - 1)) * D + 64 * c + 8 * cc16);
       }
     };
     fetch(0, st[0]);
@@ -408,6 +415,7 @@ __global__ __launch_bounds__(64 * (D / 32), 2) void k_attn1_bwd(const Attn1BwdAr
       const int n = n0 + 16 * nb + r;
       const bool live = n < n_hi;
       const int64_t row = (int64_t)b * a.N + (live ? n : 0);
+      // (guarded loads on purpose: the unconditional form measured 8 % slower here)
       bf16x4 qlo = zero4b(), qhi = zero4b(), o0 = zero4b(), o1 = zero4b();
       if (live) {
         qlo = *reinterpret_cast<const bf16x4*>(a.QpS + row * D + 32 * j + 4 * g);
@@ -428,12 +436,12 @@ __global__ __launch_bounds__(64 * (D / 32), 2) void k_attn1_bwd(const Attn1BwdAr
       float sum = 0.f;
 #pragma unroll
       for (int e = 0; e < 4; ++e) {
-        p0[e] = exp2f((p0[e] - mx) * a.scale_log2e);
-        p1[e] = exp2f((p1[e] - mx) * a.scale_log2e);
+        p0[e] = __builtin_amdgcn_exp2f((p0[e] - mx) * a.scale_log2e);
+        p1[e] = __builtin_amdgcn_exp2f((p1[e] - mx) * a.scale_log2e);
         sum += p0[e] + p1[e];
       }
       sum = wave16_sum(sum);
-      const float inv = 1.0f / sum;
+      const float inv = __builtin_amdgcn_rcpf(sum);
       float delta = 0.f;
 #pragma unroll
       for (int e = 0; e < 4; ++e) {
@@ -484,6 +492,457 @@ __global__ __launch_bounds__(64 * (D / 32), 2) void k_attn1_bwd(const Attn1BwdAr
         dkp[kt][tt] = mfma32(ads, qf[tt], dkp[kt][tt]);
         dvp[kt][tt] = mfma32(ap, of[tt], dvp[kt][tt]);
       }
+    }
+  }
+  const int64_t pbase = ((int64_t)b * a.nparts + part) * MI * D;
+#pragma unroll
+  for (int kt = 0; kt < 2; ++kt)
+#pragma unroll
+    for (int tt = 0; tt < 2; ++tt)
+#pragma unroll
+      for (int e = 0; e < 4; ++e) {
+        const int64_t o = pbase + (int64_t)(16 * kt + 4 * g + e) * D + 32 * j + 16 * tt + r;
+        a.dKpPart[o] = dkp[kt][tt][e];
+        a.dVpPart[o] = dvp[kt][tt][e];
+      }
+}
+
+// k_attn1_bwd2: the same arithmetic with full-line global traffic.  In k_attn1_bwd every wave
+// fetches its head's 64-byte slice of each row straight from memory (16 rows x 32 bytes per load
+// instruction, 8-byte stores): 243 us at configs[3] for 0.8 GB, 3.3 TB/s.  Here the workgroup moves
+// whole [32 points][256] tiles: Qp and dO arrive by LDS-DMA (1 KiB per wave instruction, double
+// buffered, swizzled like the single-launch forward's tiles), each wave reads / writes its head's
+// slice of the tiles in LDS, and the dQp tile leaves in 16-byte pieces of full rows.
+typedef __attribute__((address_space(3))) void lds_void_t;
+template <int D>
+__global__ __launch_bounds__(64 * (D / 32), 2) void k_attn1_bwd2(const Attn1BwdArgs a) {
+  constexpr int MI = 32, ROWB = D * 2, TILEB = 32 * ROWB;
+  constexpr int PQ = 72, IMG = 32 * PQ;
+  static_assert(D == 256, "8 waves, 2 DMA pieces per wave and tensor");
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  char* sQb = smem;                       // [2][TILEB]
+  char* sOb = smem + 2 * TILEB;           // [2][TILEB]
+  char* sOut = smem + 4 * TILEB;          // dQp tile
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int j = __builtin_amdgcn_readfirstlane(tid >> 6);      // head of this wave
+  const int r = lane & 15, g = lane >> 4;
+  const int b = blockIdx.x / a.nparts, part = blockIdx.x - b * a.nparts;
+  char* myDS = smem + 5 * TILEB + j * 4 * IMG;
+  char* myP = myDS + IMG;
+  char* myQ = myP + IMG;
+  char* myO = myQ + IMG;
+
+  bf16x8 kpa[2], vpa[2], kta[2];
+#pragma unroll
+  for (int kt = 0; kt < 2; ++kt) {
+    const int64_t o = ((int64_t)b * MI + 16 * kt + r) * D + 32 * j + 8 * g;
+    kpa[kt] = *reinterpret_cast<const bf16x8*>(a.KpP + o);
+    vpa[kt] = *reinterpret_cast<const bf16x8*>(a.VpP + o);
+    kta[kt] = *reinterpret_cast<const bf16x8*>(a.Kt + ((int64_t)b * D + 32 * j + 16 * kt + r) * MI +
+                                               8 * g);
+  }
+  f32x4 dkp[2][2], dvp[2][2];
+#pragma unroll
+  for (int kt = 0; kt < 2; ++kt)
+#pragma unroll
+    for (int tt = 0; tt < 2; ++tt) {
+      dkp[kt][tt] = f32x4{0.f, 0.f, 0.f, 0.f};
+      dvp[kt][tt] = f32x4{0.f, 0.f, 0.f, 0.f};
+    }
+  const int n_lo = part * a.pts_per_part;
+  const int n_hi = n_lo + a.pts_per_part < a.N ? n_lo + a.pts_per_part : a.N;
+  const int T = n_lo < n_hi ? (n_hi - n_lo + 31) / 32 : 0;
+  // accumulator-layout 8 bytes of this lane in a tile (row = point r, features 32 j + 16 t + 4 g)
+  // and its coalesced 16-byte piece (row tid / 32, chunk tid % 32), as in k_isab1_fwd256
+  int oD[2];
+#pragma unroll
+  for (int t = 0; t < 2; ++t) oD[t] = swz(r, 4 * j + 2 * t + (g >> 1), ROWB) + 8 * (g & 1);
+  const int oC = swz(tid >> 5, tid & 31, ROWB);
+  auto lds_barrier = [] {
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+    __builtin_amdgcn_s_barrier();
+    asm volatile("" ::: "memory");
+  };
+  // LDS-DMA of tile k of both tensors (issued from inline asm: see k_isab1_fwd256)
+  auto dma = [&](int k) {
+    const int n0 = n_lo + 32 * k, par = k & 1;
+#pragma unroll
+    for (int w = 0; w < 2; ++w) {
+      const __bf16* base = w == 0 ? a.QpS : a.dO;
+      char* dst = (w == 0 ? sQb : sOb) + par * TILEB;
+#pragma unroll
+      for (int i = 0; i < 2; ++i) {
+        const int p = (2 * j + i) * 64 + lane;
+        const int row = p >> 5, slot = p & 31;
+        const int ch = (slot & ~15) | ((slot ^ row) & 15);
+        const int n = n0 + row < a.N ? n0 + row : a.N - 1;
+        const __bf16* src = base + ((int64_t)b * a.N + n) * D + ch * 8;
+        const unsigned ldst = __builtin_amdgcn_readfirstlane(
+            (unsigned)(uintptr_t)(lds_void_t*)(dst + (2 * j + i) * 1024));
+        unsigned keep;
+        asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %2\n\ts_nop 0\n\t"
+                     "global_load_lds_dwordx4 %1, off\n\ts_mov_b32 m0, %0"
+                     : "=&s"(keep) : "v"(src), "s"(ldst) : "memory");
+      }
+    }
+  };
+  if (T > 0) dma(0);
+  for (int k = 0; k < T; ++k) {
+    const int par = k & 1, n0 = n_lo + 32 * k, nlive = n_hi - n0;
+    const char* sQ = sQb + par * TILEB;
+    const char* sO = sOb + par * TILEB;
+    // tile k + 1 starts to stream in; everything older than it and the (two, for a full tile)
+    // dQp stores of tile k - 1 - i.e. this tile's DMA - must have landed
+    if (k + 1 < T) {
+      dma(k + 1);
+      if (k == 0) asm volatile("s_waitcnt vmcnt(4)" ::: "memory");
+      else asm volatile("s_waitcnt vmcnt(6)" ::: "memory");      // (tile k - 1 was full: not the last)
+    } else {
+      asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    }
+    lds_barrier();                       // B0: both tiles complete; the previous dQp tile is stored
+#pragma unroll
+    for (int nb = 0; nb < 2; ++nb) {
+      const bool live = 16 * nb + r < nlive;
+      const bf16x4 qlo = *reinterpret_cast<const bf16x4*>(sQ + oD[0] + 8192 * nb);
+      const bf16x4 qhi = *reinterpret_cast<const bf16x4*>(sQ + oD[1] + 8192 * nb);
+      const bf16x4 o0 = *reinterpret_cast<const bf16x4*>(sO + oD[0] + 8192 * nb);
+      const bf16x4 o1 = *reinterpret_cast<const bf16x4*>(sO + oD[1] + 8192 * nb);
+      const bf16x8 qb = cat8(qlo, qhi), dob = cat8(o0, o1);
+      f32x4 dq0 = tof(o0), dq1 = tof(o1);                 // dQp starts as dO (residual Q_)
+      f32x4 p0 = {0.f, 0.f, 0.f, 0.f}, p1 = p0, da0 = p0, da1 = p0;
+      p0 = mfma32(kpa[0], qb, p0);
+      p1 = mfma32(kpa[1], qb, p1);
+      da0 = mfma32(vpa[0], dob, da0);
+      da1 = mfma32(vpa[1], dob, da1);
+      float mx = fmaxf(fmaxf(fmaxf(p0[0], p0[1]), fmaxf(p0[2], p0[3])),
+                       fmaxf(fmaxf(p1[0], p1[1]), fmaxf(p1[2], p1[3])));
+      mx = wave16_max(mx);
+      float sum = 0.f;
+#pragma unroll
+      for (int e = 0; e < 4; ++e) {
+        p0[e] = __builtin_amdgcn_exp2f((p0[e] - mx) * a.scale_log2e);
+        p1[e] = __builtin_amdgcn_exp2f((p1[e] - mx) * a.scale_log2e);
+        sum += p0[e] + p1[e];
+      }
+      sum = wave16_sum(sum);
+      const float inv = __builtin_amdgcn_rcpf(sum);
+      float delta = 0.f;
+#pragma unroll
+      for (int e = 0; e < 4; ++e) {
+        p0[e] *= inv;
+        p1[e] *= inv;
+        delta += p0[e] * da0[e] + p1[e] * da1[e];
+      }
+      delta = wave16_sum(delta);
+      f32x4 ds0, ds1;
+#pragma unroll
+      for (int e = 0; e < 4; ++e) {
+        ds0[e] = p0[e] * (da0[e] - delta) * a.scale;
+        ds1[e] = p1[e] * (da1[e] - delta) * a.scale;
+      }
+      // wave-private [point][.] images for the sums over points (padding points: P = dS = 0, so
+      // the duplicated rows the DMA fetched for them do not count)
+      const int pt = 16 * nb + r;
+      const f32x4 zero4 = {0.f, 0.f, 0.f, 0.f};
+      *reinterpret_cast<bf16x4*>(myDS + pt * PQ + 8 * g) = pack4(live ? ds0 : zero4);
+      *reinterpret_cast<bf16x4*>(myDS + pt * PQ + 32 + 8 * g) = pack4(live ? ds1 : zero4);
+      *reinterpret_cast<bf16x4*>(myP + pt * PQ + 8 * g) = pack4(live ? p0 : zero4);
+      *reinterpret_cast<bf16x4*>(myP + pt * PQ + 32 + 8 * g) = pack4(live ? p1 : zero4);
+      *reinterpret_cast<bf16x4*>(myQ + pt * PQ + 8 * g) = qlo;
+      *reinterpret_cast<bf16x4*>(myQ + pt * PQ + 32 + 8 * g) = qhi;
+      *reinterpret_cast<bf16x4*>(myO + pt * PQ + 8 * g) = o0;
+      *reinterpret_cast<bf16x4*>(myO + pt * PQ + 32 + 8 * g) = o1;
+      const bf16x8 dsb = pack8(ds0, ds1);
+      dq0 = mfma32(kta[0], dsb, dq0);
+      dq1 = mfma32(kta[1], dsb, dq1);
+      *reinterpret_cast<bf16x4*>(sOut + oD[0] + 8192 * nb) = pack4(dq0);
+      *reinterpret_cast<bf16x4*>(sOut + oD[1] + 8192 * nb) = pack4(dq1);
+    }
+    bf16x8 qf[2], of[2];
+#pragma unroll
+    for (int tt = 0; tt < 2; ++tt) {
+      qf[tt] = tr_frag_small(myQ, PQ, 16 * tt, lane);
+      of[tt] = tr_frag_small(myO, PQ, 16 * tt, lane);
+    }
+#pragma unroll
+    for (int kt = 0; kt < 2; ++kt) {
+      const bf16x8 ads = tr_frag_small(myDS, PQ, 16 * kt, lane);
+      const bf16x8 ap = tr_frag_small(myP, PQ, 16 * kt, lane);
+#pragma unroll
+      for (int tt = 0; tt < 2; ++tt) {
+        dkp[kt][tt] = mfma32(ads, qf[tt], dkp[kt][tt]);
+        dvp[kt][tt] = mfma32(ap, of[tt], dvp[kt][tt]);
+      }
+    }
+    lds_barrier();                       // B1: the dQp tile is complete
+#pragma unroll
+    for (int i = 0; i < 2; ++i) {
+      const int c = tid + 512 * i, row = c >> 5, ch = c & 31;
+      if (row < nlive)
+        *reinterpret_cast<uint4*>(a.dQp + ((int64_t)b * a.N + n0 + row) * D + ch * 8) =
+            *reinterpret_cast<const uint4*>(sOut + oC + 8192 * i);
+    }
+  }
+  const int64_t pbase = ((int64_t)b * a.nparts + part) * MI * D;
+#pragma unroll
+  for (int kt = 0; kt < 2; ++kt)
+#pragma unroll
+    for (int tt = 0; tt < 2; ++tt)
+#pragma unroll
+      for (int e = 0; e < 4; ++e) {
+        const int64_t o = pbase + (int64_t)(16 * kt + 4 * g + e) * D + 32 * j + 16 * tt + r;
+        a.dKpPart[o] = dkp[kt][tt][e];
+        a.dVpPart[o] = dvp[kt][tt][e];
+      }
+}
+
+// k_attn1_bwd3: k_attn1_bwd2 with the fc_o adjoint in front of it (what k_rowgemm<BWD_O> did in
+// a launch of its own): dZ = dY . [Z > 0] ; dO = dY + dZ Wo, the head's 32 columns of dO computed
+// by the wave that consumes them - dO never goes to memory (one [B*N, 256] tensor less written
+// and read per block).  The wave keeps its [32 x 256] slice of Wo^T as MFMA A operands (64
+// registers); the dZ tile is assembled in LDS from the waves' own slices (mask bytes in the
+// forward's layout) and leaves for the weight-gradient pass in full rows.
+struct Attn1Bwd3Args {
+  Attn1BwdArgs base;
+  const __bf16* dY;         // [B*N][D]
+  const uint32_t* mask;     // ReLU mask words (mab1_mask_index<256>)
+  const __bf16* WoT;        // [256][256] bf16: row = column c of Wo, col = feature f (Wo[f][c])
+  __bf16* dZ;               // [B*N][D]
+  int tiles128;             // 128-point tiles per set (mask pitch)
+};
+template <int D>
+__global__ __launch_bounds__(64 * (D / 32), 2) void k_attn1_bwd3(const Attn1Bwd3Args aa) {
+  const Attn1BwdArgs& a = aa.base;
+  constexpr int MI = 32, ROWB = D * 2, TILEB = 32 * ROWB, KS = D / 32;
+  constexpr int PQ = 72, IMG = 32 * PQ;
+  static_assert(D == 256, "8 waves, 2 DMA pieces per wave and tensor");
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  char* sY = smem;                        // dY tile (single: refilled once phase A has read it)
+  char* sQb = smem + TILEB;               // [2][TILEB] Qp tiles
+  char* sZ = smem + 3 * TILEB;            // dZ tile
+  char* sOut = smem + 4 * TILEB;          // dQp tile
+  uint32_t* sMaskb = reinterpret_cast<uint32_t*>(smem + 5 * TILEB);      // [2][256 words]
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int j = __builtin_amdgcn_readfirstlane(tid >> 6);      // head of this wave
+  const int r = lane & 15, g = lane >> 4;
+  const int b = blockIdx.x / a.nparts, part = blockIdx.x - b * a.nparts;
+  char* myDS = smem + 5 * TILEB + 2048 + j * 4 * IMG;
+  char* myP = myDS + IMG;
+  char* myQ = myP + IMG;
+  char* myO = myQ + IMG;
+
+  bf16x8 woa[KS][2];
+#pragma unroll
+  for (int s = 0; s < KS; ++s)
+#pragma unroll
+    for (int t = 0; t < 2; ++t)
+      woa[s][t] = *reinterpret_cast<const bf16x8*>(aa.WoT + (int64_t)(32 * j + 16 * t + r) * D +
+                                                   32 * s + 8 * g);
+  bf16x8 kpa[2], vpa[2], kta[2];
+#pragma unroll
+  for (int kt = 0; kt < 2; ++kt) {
+    const int64_t o = ((int64_t)b * MI + 16 * kt + r) * D + 32 * j + 8 * g;
+    kpa[kt] = *reinterpret_cast<const bf16x8*>(a.KpP + o);
+    vpa[kt] = *reinterpret_cast<const bf16x8*>(a.VpP + o);
+    kta[kt] = *reinterpret_cast<const bf16x8*>(a.Kt + ((int64_t)b * D + 32 * j + 16 * kt + r) * MI +
+                                               8 * g);
+  }
+  f32x4 dkp[2][2], dvp[2][2];
+#pragma unroll
+  for (int kt = 0; kt < 2; ++kt)
+#pragma unroll
+    for (int tt = 0; tt < 2; ++tt) {
+      dkp[kt][tt] = f32x4{0.f, 0.f, 0.f, 0.f};
+      dvp[kt][tt] = f32x4{0.f, 0.f, 0.f, 0.f};
+    }
+  const int n_lo = part * a.pts_per_part;
+  const int n_hi = n_lo + a.pts_per_part < a.N ? n_lo + a.pts_per_part : a.N;
+  const int T = n_lo < n_hi ? (n_hi - n_lo + 31) / 32 : 0;
+  int oB[4], oD[2];
+#pragma unroll
+  for (int k = 0; k < 4; ++k) oB[k] = swz(r, 4 * k + g, ROWB);
+#pragma unroll
+  for (int t = 0; t < 2; ++t) oD[t] = swz(r, 4 * j + 2 * t + (g >> 1), ROWB) + 8 * (g & 1);
+  const int oC = swz(tid >> 5, tid & 31, ROWB);
+  auto lds_barrier = [] {
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+    __builtin_amdgcn_s_barrier();
+    asm volatile("" ::: "memory");
+  };
+  auto dma_piece = [&](const void* src, char* dst) {
+    const unsigned ldst = __builtin_amdgcn_readfirstlane((unsigned)(uintptr_t)(lds_void_t*)dst);
+    unsigned keep;
+    asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %2\n\ts_nop 0\n\t"
+                 "global_load_lds_dwordx4 %1, off\n\ts_mov_b32 m0, %0"
+                 : "=&s"(keep) : "v"(src), "s"(ldst) : "memory");
+  };
+  // tile k of a [B*N][256] tensor into `dst` (2 pieces of 1 KiB per wave, swizzled at the source)
+  auto dma_tile = [&](const __bf16* base, int k, char* dst) {
+    const int n0 = n_lo + 32 * k;
+#pragma unroll
+    for (int i = 0; i < 2; ++i) {
+      const int p = (2 * j + i) * 64 + lane;
+      const int row = p >> 5, slot = p & 31;
+      const int ch = (slot & ~15) | ((slot ^ row) & 15);
+      const int n = n0 + row < a.N ? n0 + row : a.N - 1;
+      dma_piece(base + ((int64_t)b * a.N + n) * D + ch * 8, dst + (2 * j + i) * 1024);
+    }
+  };
+  // Qp tile k and (wave 0) the tile's 256 mask words: 1 KiB contiguous in the forward's layout
+  auto dma_q = [&](int k) {
+    dma_tile(a.QpS, k, sQb + (k & 1) * TILEB);
+    if (j == 0) {
+      const int tile32 = (n_lo >> 5) + k;
+      const uint32_t* m = aa.mask + (((int64_t)b * aa.tiles128 * 8 + 2 * tile32) * 2) * 64;
+      dma_piece(m + 4 * lane, reinterpret_cast<char*>(sMaskb + (k & 1) * 256));
+    }
+  };
+  if (T > 0) {
+    dma_q(0);
+    dma_tile(aa.dY, 0, sY);
+  }
+  const int nq = j == 0 ? 3 : 2;          // DMA instructions of dma_q in this wave
+  for (int k = 0; k < T; ++k) {
+    const int par = k & 1, n0 = n_lo + 32 * k, nlive = n_hi - n0;
+    const char* sQ = sQb + par * TILEB;
+    const uint32_t* sMask = sMaskb + par * 256;
+    // Qp / mask of tile k + 1 start now (their buffers were last read in iteration k - 1); what must
+    // have landed is this tile's dY (issued after barrier B1 of iteration k - 1) and everything older:
+    // younger are only the 4 stores of tile k - 1 (always a full tile) and the DMA just issued
+    {
+      int younger = k > 0 ? 4 : 0;
+      if (k + 1 < T) {
+        dma_q(k + 1);
+        younger += nq;
+      }
+      switch (younger) {
+        case 0: asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); break;
+        case 2: asm volatile("s_waitcnt vmcnt(2)" ::: "memory"); break;
+        case 3: asm volatile("s_waitcnt vmcnt(3)" ::: "memory"); break;
+        case 4: asm volatile("s_waitcnt vmcnt(4)" ::: "memory"); break;
+        case 6: asm volatile("s_waitcnt vmcnt(6)" ::: "memory"); break;
+        default: asm volatile("s_waitcnt vmcnt(7)" ::: "memory"); break;
+      }
+    }
+    lds_barrier();                       // B0: dY, Qp, mask of tile k; tile k - 1 fully stored from LDS
+    // ---- phase A: own slice of dZ = dY . [Z > 0]; the dY slice stays as the residual ----
+    bf16x4 res[2][2];
+#pragma unroll
+    for (int nb = 0; nb < 2; ++nb) {
+      const uint32_t bits = (sMask[(nb * 2 + (j >> 2)) * 64 + lane] >> (8 * (j & 3))) & 0xffu;
+#pragma unroll
+      for (int t = 0; t < 2; ++t) {
+        const bf16x4 y4 = *reinterpret_cast<const bf16x4*>(sY + oD[t] + 8192 * nb);
+        res[t][nb] = y4;
+        bf16x4 z4;
+#pragma unroll
+        for (int e = 0; e < 4; ++e) z4[e] = ((bits >> (4 * t + e)) & 1u) ? y4[e] : (__bf16)0.f;
+        *reinterpret_cast<bf16x4*>(sZ + oD[t] + 8192 * nb) = z4;
+      }
+    }
+    lds_barrier();                       // B1: dZ tile complete; dY tile consumed
+    if (k + 1 < T) dma_tile(aa.dY, k + 1, sY);
+#pragma unroll
+    for (int i = 0; i < 2; ++i) {
+      const int c = tid + 512 * i, row = c >> 5, ch = c & 31;
+      if (row < nlive)
+        *reinterpret_cast<uint4*>(aa.dZ + ((int64_t)b * a.N + n0 + row) * D + ch * 8) =
+            *reinterpret_cast<const uint4*>(sZ + oC + 8192 * i);
+    }
+    // ---- phase B: dO_h = dY_h + (dZ Wo)_h, then the attention adjoint of this head ----
+    f32x4 acc[2][2];
+#pragma unroll
+    for (int t = 0; t < 2; ++t)
+#pragma unroll
+      for (int nb = 0; nb < 2; ++nb) acc[t][nb] = tof(res[t][nb]);
+#pragma unroll
+    for (int s = 0; s < KS; ++s)
+#pragma unroll
+      for (int nb = 0; nb < 2; ++nb) {
+        const bf16x8 zb =
+            *reinterpret_cast<const bf16x8*>(sZ + oB[s & 3] + 256 * (s >> 2) + 8192 * nb);
+        acc[0][nb] = mfma32(woa[s][0], zb, acc[0][nb]);
+        acc[1][nb] = mfma32(woa[s][1], zb, acc[1][nb]);
+      }
+#pragma unroll
+    for (int nb = 0; nb < 2; ++nb) {
+      const bool live = 16 * nb + r < nlive;
+      const bf16x4 qlo = *reinterpret_cast<const bf16x4*>(sQ + oD[0] + 8192 * nb);
+      const bf16x4 qhi = *reinterpret_cast<const bf16x4*>(sQ + oD[1] + 8192 * nb);
+      const bf16x4 o0 = pack4(acc[0][nb]), o1 = pack4(acc[1][nb]);     // dO, bf16 as before
+      const bf16x8 qb = cat8(qlo, qhi), dob = cat8(o0, o1);
+      f32x4 dq0 = tof(o0), dq1 = tof(o1);                 // dQp starts as dO (residual Q_)
+      f32x4 p0 = {0.f, 0.f, 0.f, 0.f}, p1 = p0, da0 = p0, da1 = p0;
+      p0 = mfma32(kpa[0], qb, p0);
+      p1 = mfma32(kpa[1], qb, p1);
+      da0 = mfma32(vpa[0], dob, da0);
+      da1 = mfma32(vpa[1], dob, da1);
+      float mx = fmaxf(fmaxf(fmaxf(p0[0], p0[1]), fmaxf(p0[2], p0[3])),
+                       fmaxf(fmaxf(p1[0], p1[1]), fmaxf(p1[2], p1[3])));
+      mx = wave16_max(mx);
+      float sum = 0.f;
+#pragma unroll
+      for (int e = 0; e < 4; ++e) {
+        p0[e] = __builtin_amdgcn_exp2f((p0[e] - mx) * a.scale_log2e);
+        p1[e] = __builtin_amdgcn_exp2f((p1[e] - mx) * a.scale_log2e);
+        sum += p0[e] + p1[e];
+      }
+      sum = wave16_sum(sum);
+      const float inv = __builtin_amdgcn_rcpf(sum);
+      float delta = 0.f;
+#pragma unroll
+      for (int e = 0; e < 4; ++e) {
+        p0[e] *= inv;
+        p1[e] *= inv;
+        delta += p0[e] * da0[e] + p1[e] * da1[e];
+      }
+      delta = wave16_sum(delta);
+      f32x4 ds0, ds1;
+#pragma unroll
+      for (int e = 0; e < 4; ++e) {
+        ds0[e] = p0[e] * (da0[e] - delta) * a.scale;
+        ds1[e] = p1[e] * (da1[e] - delta) * a.scale;
+      }
+      const int pt = 16 * nb + r;
+      const f32x4 zero4 = {0.f, 0.f, 0.f, 0.f};
+      *reinterpret_cast<bf16x4*>(myDS + pt * PQ + 8 * g) = pack4(live ? ds0 : zero4);
+      *reinterpret_cast<bf16x4*>(myDS + pt * PQ + 32 + 8 * g) = pack4(live ? ds1 : zero4);
+      *reinterpret_cast<bf16x4*>(myP + pt * PQ + 8 * g) = pack4(live ? p0 : zero4);
+      *reinterpret_cast<bf16x4*>(myP + pt * PQ + 32 + 8 * g) = pack4(live ? p1 : zero4);
+      *reinterpret_cast<bf16x4*>(myQ + pt * PQ + 8 * g) = qlo;
+      *reinterpret_cast<bf16x4*>(myQ + pt * PQ + 32 + 8 * g) = qhi;
+      *reinterpret_cast<bf16x4*>(myO + pt * PQ + 8 * g) = o0;
+      *reinterpret_cast<bf16x4*>(myO + pt * PQ + 32 + 8 * g) = o1;
+      const bf16x8 dsb = pack8(ds0, ds1);
+      dq0 = mfma32(kta[0], dsb, dq0);
+      dq1 = mfma32(kta[1], dsb, dq1);
+      *reinterpret_cast<bf16x4*>(sOut + oD[0] + 8192 * nb) = pack4(dq0);
+      *reinterpret_cast<bf16x4*>(sOut + oD[1] + 8192 * nb) = pack4(dq1);
+    }
+    bf16x8 qf[2], of[2];
+#pragma unroll
+    for (int tt = 0; tt < 2; ++tt) {
+      qf[tt] = tr_frag_small(myQ, PQ, 16 * tt, lane);
+      of[tt] = tr_frag_small(myO, PQ, 16 * tt, lane);
+    }
+#pragma unroll
+    for (int kt = 0; kt < 2; ++kt) {
+      const bf16x8 ads = tr_frag_small(myDS, PQ, 16 * kt, lane);
+      const bf16x8 ap = tr_frag_small(myP, PQ, 16 * kt, lane);
+#pragma unroll
+      for (int tt = 0; tt < 2; ++tt) {
+        dkp[kt][tt] = mfma32(ads, qf[tt], dkp[kt][tt]);
+        dvp[kt][tt] = mfma32(ap, of[tt], dvp[kt][tt]);
+      }
+    }
+    lds_barrier();                       // B2: the dQp tile is complete
+#pragma unroll
+    for (int i = 0; i < 2; ++i) {
+      const int c = tid + 512 * i, row = c >> 5, ch = c & 31;
+      if (row < nlive)
+        *reinterpret_cast<uint4*>(a.dQp + ((int64_t)b * a.N + n0 + row) * D + ch * 8) =
+            *reinterpret_cast<const uint4*>(sOut + oC + 8192 * i);
     }
   }
   const int64_t pbase = ((int64_t)b * a.nparts + part) * MI * D;
@@ -1128,8 +1587,7 @@ __global__ __launch_bounds__(256) void k_kv_proj_small(const float* __restrict__
 __global__ __launch_bounds__(256) void k_wgrad_small256(const __bf16* __restrict__ G,
                                                         const float* __restrict__ X, int64_t M,
                                                         int dq, int rows_per_wg,
-                                                        float* __restrict__ dW,
-                                                        float* __restrict__ db) {
+                                                        float* __restrict__ slabs) {
   constexpr int D = 256;
   __shared__ __attribute__((aligned(16))) float red[8][D][5];
   const int fc = threadIdx.x & 31, rl = threadIdx.x >> 5;
@@ -1193,8 +1651,44 @@ __global__ __launch_bounds__(256) void k_wgrad_small256(const __bf16* __restrict
   for (int q = 0; q < 8; ++q)
 #pragma unroll
     for (int c = 0; c < 5; ++c) t[c] += red[q][f][c];
-  for (int c = 0; c < dq; ++c) atomicAdd(&dW[f * dq + c], t[c]);
-  if (db != nullptr) atomicAdd(&db[f], t[4]);
+  // partial sums leave as a slab [workgroup][256][5]; k_wgrad_small256_sum adds the slabs in a
+  // fixed order (1026 workgroups x 1024 fp32 atomics onto the same 1024 addresses measured
+  // 30 us of this kernel's 117, and made the result depend on the arrival order)
+  float* slab = slabs + (int64_t)blockIdx.x * D * 5;
+#pragma unroll
+  for (int c = 0; c < 5; ++c) slab[f * 5 + c] = t[c];
+}
+
+// out[o] += sum over slabs, o = 5 f + c: c < dq -> dW[f][c], c == 4 -> db[f].  One workgroup per 64
+// outputs, 16 slab groups of 64 lanes, eight loads in flight each.
+__global__ __launch_bounds__(1024) void k_wgrad_small256_sum(const float* __restrict__ slabs,
+                                                            int nslabs, int dq,
+                                                            float* __restrict__ dW,
+                                                            float* __restrict__ db) {
+  constexpr int NO = 256 * 5;
+  __shared__ float red[16][64];
+  const int sg = threadIdx.x >> 6, c = threadIdx.x & 63, o = blockIdx.x * 64 + c;
+  const float* s = slabs + o;
+  float t = 0.f;
+  int w = sg;
+  for (; w + 112 < nslabs; w += 128) {
+    float v[8];
+#pragma unroll
+    for (int u = 0; u < 8; ++u) v[u] = s[(int64_t)(w + 16 * u) * NO];
+#pragma unroll
+    for (int u = 0; u < 8; ++u) t += v[u];
+  }
+  for (; w < nslabs; w += 16) t += s[(int64_t)w * NO];
+  red[sg][c] = t;
+  __syncthreads();
+  if (sg == 0) {
+    float v = 0.f;
+#pragma unroll
+    for (int q = 0; q < 16; ++q) v += red[q][c];
+    const int f = o / 5, k = o - 5 * f;
+    if (k < dq) dW[f * dq + k] += v;
+    else if (k == 4 && db != nullptr) db[f] += v;
+  }
 }
 
 // ---- per-set epilogue pieces of the few-queries block whose keys have dk <= 4 columns --------
@@ -1650,7 +2144,13 @@ int attn1_bwd256(const __bf16* dO, const __bf16* QpS, const __bf16* KpP, const _
                  const __bf16* Kt, __bf16* dQp, float* dKpPart, float* dVpPart, float* dKp,
                  float* dVp, int B, int N, hipStream_t st) {
   constexpr int D = 256;
-  const int parts = attn1_bwd256_parts(B, N);
+  int parts = attn1_bwd256_parts(B, N);
+  {
+    const char* e = getenv("PCA_ATTN1_V1");
+    // (k_attn1_bwd2 holds 152 KiB of LDS: one workgroup per CU, so half the ranges of the
+    //  two-per-CU form; the partial buffers are sized for the larger count)
+    if (!(e && e[0] == '1') && B * parts > 256 && parts > 1) parts /= 2;
+  }
   const int ppp = (int)cdiv(cdiv(N, 32), parts) * 32;
   Attn1BwdArgs a{dO, QpS, KpP, VpP, Kt, dQp, dKpPart, dVpPart, B, N, parts, ppp,
                  1.0f / sqrtf((float)D), 1.4426950408889634f / sqrtf((float)D)};
@@ -1658,10 +2158,46 @@ int attn1_bwd256(const __bf16* dO, const __bf16* QpS, const __bf16* KpP, const _
   std::call_once(once, [] {
     (void)hipFuncSetAttribute(reinterpret_cast<const void*>(k_attn1_bwd<D>),
                               hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(k_attn1_bwd2<D>),
+                              hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
   });
-  hipLaunchKernelGGL((k_attn1_bwd<D>), dim3(B * parts), dim3(64 * (D / 32)),
-                     (size_t)(D / 32) * 4 * 32 * 72, st, a);
+  // PCA_ATTN1_V1=1: the per-wave global-traffic form (A/B measurements)
+  static const bool v1 = [] { const char* e = getenv("PCA_ATTN1_V1"); return e && e[0] == '1'; }();
+  if (v1) {
+    hipLaunchKernelGGL((k_attn1_bwd<D>), dim3(B * parts), dim3(64 * (D / 32)),
+                       (size_t)(D / 32) * 4 * 32 * 72, st, a);
+  } else {
+    hipLaunchKernelGGL((k_attn1_bwd2<D>), dim3(B * parts), dim3(64 * (D / 32)),
+                       (size_t)5 * 32 * D * 2 + (size_t)(D / 32) * 4 * 32 * 72, st, a);
+  }
   PCA_TRY(check_launch("k_attn1_bwd"));
+  hipLaunchKernelGGL(k_sum_parts256, dim3((unsigned)cdiv((int64_t)B * 32 * D, 256)), dim3(256), 0,
+                     st, dKpPart, dVpPart, dKp, dVp, B, parts, 32 * D);
+  return check_launch("k_sum_parts256");
+}
+
+// fc_o adjoint + attention adjoint in one launch (k_attn1_bwd3); WoT: transposed natural image
+int attn1_bwd256_fused(const __bf16* dY, const uint32_t* mask, const __bf16* WoT, const __bf16* QpS,
+                       const __bf16* KpP, const __bf16* VpP, const __bf16* Kt, __bf16* dZ,
+                       __bf16* dQp, float* dKpPart, float* dVpPart, float* dKp, float* dVp, int B,
+                       int N, hipStream_t st) {
+  constexpr int D = 256;
+  int parts = attn1_bwd256_parts(B, N);
+  if (B * parts > 256 && parts > 1) parts /= 2;            // 155 KiB of LDS: one workgroup per CU
+  const int ppp = (int)cdiv(cdiv(N, 32), parts) * 32;
+  Attn1Bwd3Args a{};
+  a.base = Attn1BwdArgs{nullptr, QpS, KpP, VpP, Kt, dQp, dKpPart, dVpPart, B, N, parts, ppp,
+                        1.0f / sqrtf((float)D), 1.4426950408889634f / sqrtf((float)D)};
+  a.dY = dY; a.mask = mask; a.WoT = WoT; a.dZ = dZ;
+  a.tiles128 = (int)cdiv(N, 128);
+  static std::once_flag once;
+  std::call_once(once, [] {
+    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(k_attn1_bwd3<D>),
+                              hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+  });
+  hipLaunchKernelGGL((k_attn1_bwd3<D>), dim3(B * parts), dim3(512),
+                     (size_t)5 * 32 * D * 2 + 2048 + (size_t)8 * 4 * 32 * 72, st, a);
+  PCA_TRY(check_launch("k_attn1_bwd3"));
   hipLaunchKernelGGL(k_sum_parts256, dim3((unsigned)cdiv((int64_t)B * 32 * D, 256)), dim3(256), 0,
                      st, dKpPart, dVpPart, dKp, dVp, B, parts, 32 * D);
   return check_launch("k_sum_parts256");
@@ -1777,12 +2313,20 @@ int fq_attn_bwd256(const __bf16* Kp, const __bf16* Vp, const float* Qp, const fl
   return check_launch("k_fq_dq_sum");
 }
 
+size_t wgrad_small256_ws_bytes(int64_t M) {
+  return align256((size_t)cdiv(M, M >= 65536 ? 512 : 128) * 256 * 5 * sizeof(float));
+}
 int wgrad_small256(const __bf16* G, const float* X, int64_t M, int dq, float* dW, float* db,
-                   hipStream_t st) {
+                   void* ws, hipStream_t st) {
   const int rpw = M >= 65536 ? 512 : 128;
-  hipLaunchKernelGGL(k_wgrad_small256, dim3((unsigned)cdiv(M, rpw)), dim3(256), 0, st, G, X, M, dq,
-                     rpw, dW, db);
-  return check_launch("k_wgrad_small256");
+  const int nwg = (int)cdiv(M, rpw);
+  float* slabs = reinterpret_cast<float*>(ws);
+  hipLaunchKernelGGL(k_wgrad_small256, dim3((unsigned)nwg), dim3(256), 0, st, G, X, M, dq, rpw,
+                     slabs);
+  PCA_TRY(check_launch("k_wgrad_small256"));
+  hipLaunchKernelGGL(k_wgrad_small256_sum, dim3(256 * 5 / 64), dim3(1024), 0, st, slabs, nwg, dq, dW,
+                     db);
+  return check_launch("k_wgrad_small256_sum");
 }
 int epi_small_fwd256(const float* T, const float* Qp, const float* Wv, const float* bv, int B, int m,
                      int dk, float* O, hipStream_t st) {

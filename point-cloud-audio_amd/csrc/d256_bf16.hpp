@@ -58,8 +58,20 @@ int kv_proj_small256(const float* X, int64_t M, int dk, const float* Wk, const f
                      const float* Wv, const float* bv, __bf16* Kp, __bf16* Vp, hipStream_t st);
 
 // layer 1 (inputs of dq <= 4 columns)
+// d256_stream.hip: streaming row-GEMMs with the weights in registers
+int rowstream256_proj2(const __bf16* X, const __bf16* WkB, const __bf16* WvB, const float* bk,
+                       const float* bv, __bf16* Kp, __bf16* Vp, int B, int N, hipStream_t st);
+int rowstream256_dx2(const __bf16* dKp, const __bf16* dVp, const __bf16* WkT, const __bf16* WvT,
+                     __bf16* dX, int B, int N, int accumulate, hipStream_t st);
+int rowstream256_dx1(const __bf16* dQp, const __bf16* WqT, __bf16* dX, int B, int N,
+                     hipStream_t st);
+int attn1_bwd256_fused(const __bf16* dY, const uint32_t* mask, const __bf16* WoT, const __bf16* QpS,
+                       const __bf16* KpP, const __bf16* VpP, const __bf16* Kt, __bf16* dZ,
+                       __bf16* dQp, float* dKpPart, float* dVpPart, float* dKp, float* dVp, int B,
+                       int N, hipStream_t st);
+size_t wgrad_small256_ws_bytes(int64_t M);
 int wgrad_small256(const __bf16* G, const float* X, int64_t M, int dq, float* dW, float* db,
-                   hipStream_t st);
+                   void* ws, hipStream_t st);
 int epi_small_fwd256(const float* T, const float* Qp, const float* Wv, const float* bv, int B, int m,
                      int dk, float* O, hipStream_t st);
 int epi_small_bwd256(const float* dO, const float* T, const float* Wv, int B, int m, int dk,

@@ -33,6 +33,13 @@ struct Mab1D256Ws {
   float *dKp, *dVp, *dKpPart, *dVpPart;
   void* wg;
 };
+// PCA_ROWSTREAM=0: the LDS-resident-weight row-GEMMs (k_rowgemm) instead of the register-resident
+// streaming ones (d256_stream.hip), for A/B measurements
+static bool rowstream_on() {
+  static const bool on = [] { const char* e = getenv("PCA_ROWSTREAM"); return !(e && e[0] == '0'); }();
+  return on;
+}
+
 static size_t mab1_d256_carve(const pca_mab_shape& s, Mab1D256Ws* out, void* base) {
   Carver c(base);
   Mab1D256Ws w{};
@@ -53,7 +60,10 @@ static size_t mab1_d256_carve(const pca_mab_shape& s, Mab1D256Ws* out, void* bas
   w.dVp = c.take<float>((size_t)s.B * s.nk * D);
   w.dKpPart = c.take<float>((size_t)s.B * parts * s.nk * D);
   w.dVpPart = c.take<float>((size_t)s.B * parts * s.nk * D);
-  w.wg = c.take<char>(wgrad256_ws_bytes(2, (int64_t)M));
+  {
+    const size_t a = wgrad256_ws_bytes(2, (int64_t)M), b = wgrad_small256_ws_bytes((int64_t)M);
+    w.wg = c.take<char>(a > b ? a : b);      // (the two reductions run one after the other)
+  }
   if (out) *out = w;
   return c.off;
 }
@@ -75,8 +85,11 @@ int mab1_d256_bwd(const pca_mab_shape& s, const void* X, const float* Hk, const 
     set_error("mab1_bf16_bwd: dQ for dq <= 4 is not built");
     return PCA_EUNSUPPORTED;
   }
-  PCA_TRY(prep_weight(p.wo, w.WoTP, D, D, 2, st));
-  if (want_dx) PCA_TRY(prep_weight(p.wq, w.WqTP, D, D, 2, st));
+  // PCA_BWD_O_FUSED=0: fc_o adjoint as its own row-GEMM launch (A/B measurements)
+  static const bool fuse_o_env = [] { const char* e = getenv("PCA_BWD_O_FUSED"); return !(e && e[0] == '0'); }();
+  const bool fuse_o = fuse_o_env;
+  PCA_TRY(prep_weight(p.wo, w.WoTP, D, D, fuse_o ? 3 : 2, st));
+  if (want_dx) PCA_TRY(prep_weight(p.wq, w.WqTP, D, D, rowstream_on() ? 3 : 2, st));
   const __bf16* dYb = reinterpret_cast<const __bf16*>(dY);
   const __bf16* Xb = small ? nullptr : reinterpret_cast<const __bf16*>(X);
   if (!abf) {
@@ -92,12 +105,18 @@ int mab1_d256_bwd(const pca_mab_shape& s, const void* X, const float* Hk, const 
   const double bytes = (double)M * (2.0 * D + (small ? 4.0 * s.dq : 2.0 * D) +
                                     (want_dx ? 2.0 * D : 0.0));
   ProfScope ps(PCA_K_MAB1_BWD, st, flops, bytes);
-  PCA_TRY(rowgemm256_bwd_o(dYb, v.mask, w.WoTP, w.dZ, w.dO, s.B, s.nq, st));
-  PCA_TRY(attn1_bwd256(w.dO, v.QpS, v.KpP, v.VpP, v.Kt, w.dQp, w.dKpPart, w.dVpPart, w.dKp, w.dVp,
-                       s.B, s.nq, st));
+  if (fuse_o) {
+    PCA_TRY(attn1_bwd256_fused(dYb, v.mask, w.WoTP, v.QpS, v.KpP, v.VpP, v.Kt, w.dZ, w.dQp,
+                               w.dKpPart, w.dVpPart, w.dKp, w.dVp, s.B, s.nq, st));
+  } else {
+    PCA_TRY(rowgemm256_bwd_o(dYb, v.mask, w.WoTP, w.dZ, w.dO, s.B, s.nq, st));
+    PCA_TRY(attn1_bwd256(w.dO, v.QpS, v.KpP, v.VpP, v.Kt, w.dQp, w.dKpPart, w.dVpPart, w.dKp,
+                         w.dVp, s.B, s.nq, st));
+  }
   if (want_dx) {
     __bf16* dXb = abf ? reinterpret_cast<__bf16*>(dX) : w.dXb;
-    PCA_TRY(rowgemm256_dx(w.dQp, w.WqTP, dXb, s.B, s.nq, 0, st));
+    if (rowstream_on()) PCA_TRY(rowstream256_dx1(w.dQp, w.WqTP, dXb, s.B, s.nq, st));
+    else PCA_TRY(rowgemm256_dx(w.dQp, w.WqTP, dXb, s.B, s.nq, 0, st));
     if (!abf) PCA_TRY(cvt_bf16_f32(dXb, reinterpret_cast<float*>(dX), M * D, 0, st));
   }
   ps.end();
@@ -107,7 +126,7 @@ int mab1_d256_bwd(const pca_mab_shape& s, const void* X, const float* Hk, const 
   if (!small) jobs.j[jobs.n++] = Wgrad256Job{w.dQp, Xb, gr.wq, gr.bq, M};
   PCA_TRY(wgrad256_launch(jobs, w.wg, st));
   if (small)
-    PCA_TRY(wgrad_small256(w.dQp, reinterpret_cast<const float*>(X), M, s.dq, gr.wq, gr.bq, st));
+    PCA_TRY(wgrad_small256(w.dQp, reinterpret_cast<const float*>(X), M, s.dq, gr.wq, gr.bq, w.wg, st));
   // fc_k / fc_v of the m inducing-point outputs ([B*m] rows) and dH
   const int64_t Mk = (int64_t)s.B * s.nk;
   {
@@ -239,10 +258,16 @@ int mab0_d256_fwd(const pca_mab_shape& s, const float* I, const void* X, const p
       PCA_TRY(rowgemm256_proj_f8(Xb, WkP, invs, p.bk, v.Kp, s.B, s.nk, st));
       PCA_TRY(rowgemm256_proj_f8(Xb, WvP, invs + 1, p.bv, v.Vp, s.B, s.nk, st));
     } else {
-    PCA_TRY(prep_weight(p.wk, WkP, D, D, 1, st));
-    PCA_TRY(prep_weight(p.wv, WvP, D, D, 1, st));
-    PCA_TRY(rowgemm256_proj(Xb, WkP, p.bk, v.Kp, s.B, s.nk, st));            // modules.py:21
-    PCA_TRY(rowgemm256_proj(Xb, WvP, p.bv, v.Vp, s.B, s.nk, st));
+      if (rowstream_on()) {                  // one pass over X, weights in registers
+        PCA_TRY(prep_weight(p.wk, WkP, D, D, 0, st));
+        PCA_TRY(prep_weight(p.wv, WvP, D, D, 0, st));
+        PCA_TRY(rowstream256_proj2(Xb, WkP, WvP, p.bk, p.bv, v.Kp, v.Vp, s.B, s.nk, st));   // modules.py:21
+      } else {
+        PCA_TRY(prep_weight(p.wk, WkP, D, D, 1, st));
+        PCA_TRY(prep_weight(p.wv, WvP, D, D, 1, st));
+        PCA_TRY(rowgemm256_proj(Xb, WkP, p.bk, v.Kp, s.B, s.nk, st));
+        PCA_TRY(rowgemm256_proj(Xb, WvP, p.bv, v.Vp, s.B, s.nk, st));
+      }
     }
     const double pts = (double)M;
     ProfScope ps(PCA_K_MAB0_FWD, st, 2.0 * pts * 2.0 * m * D, pts * 4.0 * D);
@@ -362,12 +387,19 @@ int mab0_d256_bwd(const pca_mab_shape& s, const float* I, const void* X, const p
     // fc_k bias: identically zero (softmax shift invariance), left untouched
     PCA_TRY(colsum(w.dO, Bm, D, gr.bv, 1, st));
     if (dX != nullptr) {
-      PCA_TRY(prep_weight(p.wk, w.WkTP, D, D, 2, st));
-      PCA_TRY(prep_weight(p.wv, w.WvTP, D, D, 2, st));
       const bool f32 = s.k_dtype == PCA_F32;
       __bf16* dXb = f32 ? w.dXb : reinterpret_cast<__bf16*>(dX);
-      PCA_TRY(rowgemm256_dx(w.dKp, w.WkTP, dXb, s.B, s.nk, (!f32 && dk_accumulate) ? 1 : 0, st));
-      PCA_TRY(rowgemm256_dx(w.dVp, w.WvTP, dXb, s.B, s.nk, 1, st));
+      if (rowstream_on()) {                  // dKp Wk + dVp Wv in one pass, weights in registers
+        PCA_TRY(prep_weight(p.wk, w.WkTP, D, D, 3, st));
+        PCA_TRY(prep_weight(p.wv, w.WvTP, D, D, 3, st));
+        PCA_TRY(rowstream256_dx2(w.dKp, w.dVp, w.WkTP, w.WvTP, dXb, s.B, s.nk,
+                                 (!f32 && dk_accumulate) ? 1 : 0, st));
+      } else {
+        PCA_TRY(prep_weight(p.wk, w.WkTP, D, D, 2, st));
+        PCA_TRY(prep_weight(p.wv, w.WvTP, D, D, 2, st));
+        PCA_TRY(rowgemm256_dx(w.dKp, w.WkTP, dXb, s.B, s.nk, (!f32 && dk_accumulate) ? 1 : 0, st));
+        PCA_TRY(rowgemm256_dx(w.dVp, w.WvTP, dXb, s.B, s.nk, 1, st));
+      }
       if (f32)
         PCA_TRY(cvt_bf16_f32(dXb, reinterpret_cast<float*>(dX), M * D, dk_accumulate ? 1 : 0, st));
     }
