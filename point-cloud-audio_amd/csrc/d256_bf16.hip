@@ -1707,6 +1707,38 @@ __global__ __launch_bounds__(256) void k_epi_small_fwd(const float* __restrict__
   for (int c = 0; c < dk; ++c) acc = fmaf(T[(b * R + j * m + q) * dk + c], Wv[f * dk + c], acc);
   O[i] = acc;
 }
+// the same for dk = 256 (PMA): one wave per output, lanes over the contraction - a thread per
+// output walks Wv[f][:] with a 1 KiB stride between neighbouring lanes (46 us for 32 K outputs)
+__global__ __launch_bounds__(256) void k_epi_wide_fwd(const float* __restrict__ T,
+                                                      const float* __restrict__ Qp,
+                                                      const float* __restrict__ Wv,
+                                                      const float* __restrict__ bv, int B, int m,
+                                                      float* __restrict__ O) {
+  constexpr int D = 256, DKW = 256, PER = 8;             // outputs per wave
+  const int lane = threadIdx.x & 63;
+  const int64_t w = ((int64_t)blockIdx.x * 4 + (threadIdx.x >> 6)) * PER;
+  const int R = (D / 32) * m;
+  float4 tv[PER], wv[PER];
+#pragma unroll
+  for (int u = 0; u < PER; ++u) {
+    const int64_t i = w + u < (int64_t)B * m * D ? w + u : (int64_t)B * m * D - 1;
+    const int f = (int)(i % D), q = (int)((i / D) % m);
+    const int64_t b = i / ((int64_t)D * m);
+    tv[u] = *reinterpret_cast<const float4*>(T + (b * R + (f / 32) * m + q) * DKW + 4 * lane);
+    wv[u] = *reinterpret_cast<const float4*>(Wv + (int64_t)f * DKW + 4 * lane);
+  }
+#pragma unroll
+  for (int u = 0; u < PER; ++u) {
+    float acc = tv[u].x * wv[u].x + tv[u].y * wv[u].y + tv[u].z * wv[u].z + tv[u].w * wv[u].w;
+#pragma unroll
+    for (int sh = 1; sh < 64; sh <<= 1) acc += __shfl_xor(acc, sh);
+    const int64_t i = w + u;
+    if (lane == 0 && i < (int64_t)B * m * D) {
+      const int f = (int)(i % D), q = (int)((i / D) % m);
+      O[i] = acc + Qp[(int64_t)q * D + f] + bv[f];
+    }
+  }
+}
 // dT[b][r][c] = sum_{f in head j} dO[b][q][f] Wv[f][c] ; Delta[b][r] = sum_c dT T   (r = j m + q)
 __global__ __launch_bounds__(256) void k_epi_small_bwd(const float* __restrict__ dO,
                                                        const float* __restrict__ T,
@@ -1742,12 +1774,23 @@ __global__ __launch_bounds__(256) void k_epi_small_wv(const float* __restrict__ 
   const int64_t r0 = (int64_t)blockIdx.x * rows_per_wg;
   const int64_t r1 = r0 + rows_per_wg < M ? r0 + rows_per_wg : M;
   float acc[4] = {0.f, 0.f, 0.f, 0.f}, bs = 0.f;
-  for (int64_t row = r0; row < r1; ++row) {
-    const int64_t b = row / m;
-    const int q = (int)(row - b * m);
-    const float g = dO[row * D + f];
-    bs += g;
-    for (int c = 0; c < dk; ++c) acc[c] = fmaf(g, T[(b * R + j * m + q) * dk + c], acc[c]);
+  for (int64_t row0 = r0; row0 < r1; row0 += 8) {           // 8 rows in flight
+    float gv[8], tv[8][4];
+#pragma unroll
+    for (int u = 0; u < 8; ++u) {
+      const int64_t row = row0 + u < r1 ? row0 + u : r1 - 1;
+      const int64_t b = row / m;
+      const int q = (int)(row - b * m);
+      gv[u] = row0 + u < r1 ? dO[row * D + f] : 0.f;
+#pragma unroll
+      for (int c = 0; c < 4; ++c) tv[u][c] = c < dk ? T[(b * R + j * m + q) * dk + c] : 0.f;
+    }
+#pragma unroll
+    for (int u = 0; u < 8; ++u) {
+      bs += gv[u];
+#pragma unroll
+      for (int c = 0; c < 4; ++c) acc[c] = fmaf(gv[u], tv[u][c], acc[c]);
+    }
   }
   for (int c = 0; c < dk; ++c) atomicAdd(&dWv[f * dk + c], acc[c]);
   atomicAdd(&dbv[f], bs);
@@ -1982,10 +2025,26 @@ __global__ __launch_bounds__(256) void k_pma_dwv(const float* __restrict__ dO,
                                                  float* __restrict__ dWv) {
   constexpr int D = 256;
   const int f = blockIdx.x, c = threadIdx.x, j = f / 32;
+  // (fixed summation order; 8 terms fetched at a time - one by one the B*m dependent round trips
+  //  of this loop were 35 us at B = 128)
   float acc = 0.f;
-  for (int b = 0; b < B; ++b)
-    for (int q = 0; q < m; ++q)
-      acc = fmaf(dO[((int64_t)b * m + q) * D + f], T[((int64_t)b * R + j * m + q) * D + c], acc);
+  const int n = B * m;
+  int i = 0;
+  for (; i + 8 <= n; i += 8) {
+    float x[8], y[8];
+#pragma unroll
+    for (int u = 0; u < 8; ++u) {
+      const int b = (i + u) / m, q = (i + u) - b * m;
+      x[u] = dO[((int64_t)b * m + q) * D + f];
+      y[u] = T[((int64_t)b * R + j * m + q) * D + c];
+    }
+#pragma unroll
+    for (int u = 0; u < 8; ++u) acc = fmaf(x[u], y[u], acc);
+  }
+  for (; i < n; ++i) {
+    const int b = i / m, q = i - b * m;
+    acc = fmaf(dO[((int64_t)b * m + q) * D + f], T[((int64_t)b * R + j * m + q) * D + c], acc);
+  }
   dWv[f * D + c] += acc;
 }
 
@@ -2330,6 +2389,11 @@ int wgrad_small256(const __bf16* G, const float* X, int64_t M, int dq, float* dW
 }
 int epi_small_fwd256(const float* T, const float* Qp, const float* Wv, const float* bv, int B, int m,
                      int dk, float* O, hipStream_t st) {
+  if (dk == 256) {
+    hipLaunchKernelGGL(k_epi_wide_fwd, dim3((unsigned)cdiv((int64_t)B * m * 256, 32)), dim3(256), 0,
+                       st, T, Qp, Wv, bv, B, m, O);
+    return check_launch("k_epi_wide_fwd");
+  }
   hipLaunchKernelGGL(k_epi_small_fwd, dim3((unsigned)cdiv((int64_t)B * m * 256, 256)), dim3(256), 0,
                      st, T, Qp, Wv, bv, B, m, 256, dk, O);
   return check_launch("k_epi_small_fwd");
@@ -2339,8 +2403,8 @@ int epi_small_bwd256(const float* dO, const float* T, const float* Wv, int B, in
   hipLaunchKernelGGL(k_epi_small_bwd, dim3((unsigned)cdiv((int64_t)B * 8 * m, 256)), dim3(256), 0,
                      st, dO, T, Wv, B, m, 256, dk, dT, Delta);
   PCA_TRY(check_launch("k_epi_small_bwd"));
-  hipLaunchKernelGGL(k_epi_small_wv, dim3((unsigned)cdiv((int64_t)B * m, 128)), dim3(256), 0, st, dO,
-                     T, B, m, dk, 128, dWv, dbv);
+  hipLaunchKernelGGL(k_epi_small_wv, dim3((unsigned)cdiv((int64_t)B * m, 16)), dim3(256), 0, st, dO,
+                     T, B, m, dk, 16, dWv, dbv);
   return check_launch("k_epi_small_wv");
 }
 

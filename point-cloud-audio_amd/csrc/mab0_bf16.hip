@@ -89,7 +89,88 @@ __global__ __launch_bounds__(256) void k_prep_all(const PrepJobs W, const Mab0Pr
   jb.dst[idx] = (__bf16)v;
 }
 
+// d > 128: blockIdx.x = q * h + j - one workgroup per (query row, head).  A thread per output
+// feature walks Wq[f][:] with a 1 KiB stride between lanes in 16 dependent batches, then 8 more
+// for the rows of G: 45 us for PMA's single query row.  Here a wave owns 8 features of the head
+// (lanes over the contraction: coalesced, all 8 rows in flight), and the head's G row follows
+// from the 32 Qp values in LDS with coalesced reads of Wk.
+__device__ __forceinline__ void mab0_prep_head(const Mab0PrepJob& a, float* sq, int q, int j) {
+  const int m = a.m, d = a.d, dq = a.dq, dk = a.dk, dh = a.d / a.h;
+  const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
+  for (int f0 = wv * 8; f0 < dh; f0 += 32) {
+    float acc[8];
+#pragma unroll
+    for (int u = 0; u < 8; ++u) acc[u] = 0.f;
+    for (int c = lane; c < dq; c += 64) {
+      const float x = a.I[q * dq + c];
+#pragma unroll
+      for (int u = 0; u < 8; ++u)
+        if (f0 + u < dh) acc[u] = fmaf(x, a.Wq[(int64_t)(j * dh + f0 + u) * dq + c], acc[u]);
+    }
+#pragma unroll
+    for (int u = 0; u < 8; ++u) {
+#pragma unroll
+      for (int sh = 1; sh < 64; sh <<= 1) acc[u] += __shfl_xor(acc[u], sh);
+      if (lane == 0 && f0 + u < dh) {
+        const float v = acc[u] + a.bq[j * dh + f0 + u];
+        sq[f0 + u] = v;
+        a.Qp[q * d + j * dh + f0 + u] = v;
+      }
+    }
+  }
+  __syncthreads();
+  if (a.Gf != nullptr) {
+    const int r = j * m + q;
+    for (int c = threadIdx.x; c < dk; c += 256) {
+      float acc = 0.f;
+      for (int f = 0; f < dh; f += 16) {
+        float wv16[16];
+#pragma unroll
+        for (int u = 0; u < 16; ++u)
+          wv16[u] = (f + u < dh) ? a.Wk[(int64_t)(j * dh + f + u) * dk + c] : 0.f;
+#pragma unroll
+        for (int u = 0; u < 16; ++u)
+          if (f + u < dh) acc = fmaf(sq[f + u], wv16[u], acc);
+      }
+      acc *= a.sl2e;
+      a.Gf[r * dk + c] = acc;
+      if (a.Gb != nullptr) a.Gb[r * dk + c] = (__bf16)acc;
+      if (a.GtP != nullptr) {
+        const int rb32 = r & ~31, ro = r & 31;
+        int pos = 0;
+#pragma unroll
+        for (int p = 0; p < 32; ++p)
+          if (perm32(p) == ro) pos = p;
+        a.GtP[c * a.Rp + rb32 + pos] = (__bf16)acc;
+      }
+    }
+    if (q == 0 && j == 0 && a.Gb != nullptr) {         // zero the padding rows (PMA: R = h < 32)
+      const int R = a.h * m;
+      for (int o = threadIdx.x; o < (a.Rp - R) * dk; o += 256) {
+        const int rr = R + o / dk, c = o % dk;
+        a.Gb[rr * dk + c] = (__bf16)0.f;
+        if (a.GtP != nullptr) {
+          const int rb32 = rr & ~31, ro = rr & 31;
+          int pos = 0;
+#pragma unroll
+          for (int p = 0; p < 32; ++p)
+            if (perm32(p) == ro) pos = p;
+          a.GtP[c * a.Rp + rb32 + pos] = (__bf16)0.f;
+        }
+      }
+    }
+  }
+}
+
 __device__ __forceinline__ void mab0_prep_body(const Mab0PrepJob& a, float* sq, int q) {
+  if (a.d > 128) {
+    const int nx = a.m * a.h;
+    if (q < nx) {
+      mab0_prep_head(a, sq, q / a.h, q % a.h);
+      return;
+    }
+    q = q - nx + a.m;                        // spare workgroups: as below
+  }
   if (q >= a.m) {
     // spare workgroups: WvT[c][f] = Wv[f][c], WoT[c][f] = Wo[f][c]
     const int sp = q - a.m;
@@ -677,6 +758,8 @@ int prep_all_launch(const PrepJobs& W, const Mab0PrepJobs& Q, hipStream_t st) {
     const int e = W.j[i].rows * W.j[i].cols;
     maxe = e > maxe ? e : maxe;
   }
+  for (int i = 0; i < Q.n; ++i)              // d > 128: one workgroup per (query row, head)
+    if (Q.j[i].d > 128) maxm = Q.j[i].m * Q.j[i].h > maxm ? Q.j[i].m * Q.j[i].h : maxm;
   int gx = maxm + (spare ? PREP_SPARE : 0);
   const int gw = (int)cdiv(maxe, 256);
   gx = gx > gw ? gx : gw;
@@ -693,6 +776,8 @@ int mab0_prep_launch(const Mab0PrepJobs& J, hipStream_t st) {
   }
   bool spare = false;
   for (int i = 0; i < J.n; ++i) spare = spare || J.j[i].WvT != nullptr;
+  for (int i = 0; i < J.n; ++i)              // d > 128: one workgroup per (query row, head)
+    if (J.j[i].d > 128) maxm = J.j[i].m * J.j[i].h > maxm ? J.j[i].m * J.j[i].h : maxm;
   hipLaunchKernelGGL(k_mab0_prep, dim3(maxm + (spare ? PREP_SPARE : 0), J.n), dim3(256),
                      maxd * sizeof(float), st, J);
   return check_launch("k_mab0_prep");
