@@ -37,6 +37,10 @@ for kern, c in sorted(tab.items(), key=lambda kv: -dur.get(kv[0], 0)):
     for k in sorted(c):
         print(f"   {k:28s} {c[k]:16.0f}")
     if "SQ_VALU_MFMA_BUSY_CYCLES" in c and "SQ_BUSY_CYCLES" in c:
+        # SQ_BUSY_CYCLES is summed over the 32 shader engines (8 XCDs x 4), SQ_VALU_MFMA_BUSY_CYCLES
+        # over the 1024 SIMDs: 32 SIMDs per engine
+        print(f"   -> MFMA utilisation = SQ_VALU_MFMA_BUSY_CYCLES / (32 x SQ_BUSY_CYCLES) = "
+              f"{c['SQ_VALU_MFMA_BUSY_CYCLES'] / max(32 * c['SQ_BUSY_CYCLES'], 1):.3f}")
         # SQ_BUSY_CYCLES: per SE summed; MFMA busy counts per SIMD cycles: report the ratio to wave cycles
         wc = c.get("SQ_WAVE_CYCLES", 0) * 4          # quad-cycles -> cycles
         print(f"   -> MFMA-busy / (4 x SQ_WAVE_CYCLES) = {c['SQ_VALU_MFMA_BUSY_CYCLES'] / max(wc, 1):.3f}"

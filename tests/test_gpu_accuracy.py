@@ -102,7 +102,7 @@ def test_trained_cfg1_weights_agreement_fp8(dev):
     assert frac >= 0.998
 
 
-RUNS = int(os.environ.get("PCA_ACC_RUNS", "6"))
+RUNS = int(os.environ.get("PCA_ACC_RUNS", "20"))
 
 
 @pytest.mark.parametrize("mode", ["f32", "bf16"])
@@ -111,12 +111,18 @@ def test_train_from_scratch_accuracy(mode, dev):
 
     Adam at lr 1e-3 on this data is chaotic: the REFERENCE's own loss spikes above 10 late in
     training and its test accuracy drops from 0.89 to 0.49 and back between evaluations, and
-    two runs of the HIP path (whose atomic reductions are not bit-reproducible) differ by
-    several tenths of a percent in any late snapshot.  What is compared:
+    two runs of the HIP path differ by several tenths of a percent in any late snapshot.  So one
+    reference run is one draw from a distribution, and that distribution is what the HIP runs
+    are compared with: golden_acc_spread.npz holds 9 runs of the reference itself from the same
+    initial weights perturbed by 1e-6 (make_accuracy_spread.py) - converged accuracy 0.9929,
+    sigma 0.0013; the single run of golden_acc_train.npz (0.9948) is a +1.5 sigma draw of it.
+    What is compared:
       * the first 20 losses, step by step (tight: the trajectories have not separated yet);
       * the converged accuracy = mean of the three best of the ten evaluations (2200 test sets
-        each), averaged over RUNS repetitions, against the reference's single run; SURVEY.md
-        8d's +-0.2 % is applied to that mean with the measured standard error added."""
+        each), averaged over RUNS >= 20 repetitions, against the mean of the reference's runs:
+        SURVEY.md 8d's +-0.2 %, plus two standard errors of the difference of the two means
+        (about 0.15 % at 20 runs).  Measured over 24 runs each: fp32 0.9912 (sigma 0.0033),
+        bf16 0.9921 (sigma 0.0048) - bf16 is not below fp32."""
     import dataset
     import models
     from pca_hip import _lib, trainer
@@ -164,6 +170,12 @@ def test_train_from_scratch_accuracy(mode, dev):
     print(f"{mode}: reference evaluations {np.round(ref_accs, 4)} -> converged "
           f"{top3(ref_accs):.4f} (largest loss spike {ref_losses[50:].max():.1f}); HIP mean "
           f"{conv.mean():.4f}, run-to-run sigma {conv.std(ddof=1):.4f}")
+    spread = _npz("golden_acc_spread.npz")["eval_acc"]
+    ref_conv = np.asarray([top3(r) for r in spread])
+    ref_sem = ref_conv.std(ddof=1) / np.sqrt(len(ref_conv))
+    print(f"{mode}: reference distribution ({len(ref_conv)} runs) mean {ref_conv.mean():.4f}, sigma "
+          f"{ref_conv.std(ddof=1):.4f}; difference of means {conv.mean() - ref_conv.mean():+.4f}, "
+          f"standard error {np.hypot(sem, ref_sem):.4f}")
     tol_acc = float(os.environ.get("PCA_ACC_TOL", "0.002"))
-    assert abs(conv.mean() - top3(ref_accs)) <= tol_acc + 3 * sem
+    assert abs(conv.mean() - ref_conv.mean()) <= tol_acc + 2 * np.hypot(sem, ref_sem)
     assert np.median(medians) >= np.median(ref_accs) - 0.20     # coarse guard only: see above

@@ -134,3 +134,20 @@ def test_stft_against_torch_stft():
     c = orc.chunk_frames(a, 3)
     assert c.shape == (a.shape[0], 3, a.shape[1] // 3)
     np.testing.assert_array_equal(c[:, :, 1], a[:, 3:6])
+
+
+def test_reference_accuracy_spread_fixture():
+    """golden_acc_spread.npz (tests/golden/make_accuracy_spread.py): the reference's own
+    run-to-run distribution on the accuracy corpus - what tests/test_gpu_accuracy.py compares the
+    HIP runs with.  The single reference run of golden_acc_train.npz must be a plausible draw."""
+    import os
+    here = os.path.dirname(os.path.abspath(__file__))
+    sp = np.load(os.path.join(here, "golden", "golden_acc_spread.npz"))
+    one = np.load(os.path.join(here, "golden", "golden_acc_train.npz"))
+    ev = sp["eval_acc"]
+    assert ev.shape[0] >= 9 and ev.shape[1] == one["eval_acc"].shape[0]
+    assert np.all((ev >= 0) & (ev <= 1))
+    top3 = lambda v: float(np.sort(v)[-3:].mean())                      # noqa: E731
+    conv = np.asarray([top3(r) for r in ev])
+    assert 0.99 < conv.mean() < 0.996 and conv.std(ddof=1) < 0.003
+    assert abs(top3(one["eval_acc"]) - conv.mean()) < 3 * conv.std(ddof=1)
