@@ -1269,13 +1269,13 @@ __global__ __launch_bounds__(64 * (D / 32)) void k_fq_attn_fwd(const FqArgs a) {
       }
       mt = wave16_max(mt);
       const float mnew = fmaxf(mrow[qt], mt);           // finite: the tile has >= 1 live point
-      const float alpha = exp2f(mrow[qt] - mnew);
+      const float alpha = __builtin_amdgcn_exp2f(mrow[qt] - mnew);
       float ls = 0.f;
 #pragma unroll
       for (int pb = 0; pb < 2; ++pb)
 #pragma unroll
         for (int e = 0; e < 4; ++e) {
-          s[pb][e] = exp2f(s[pb][e] - mnew);
+          s[pb][e] = __builtin_amdgcn_exp2f(s[pb][e] - mnew);
           ls += s[pb][e];
         }
       ls = wave16_sum(ls);
@@ -1413,7 +1413,7 @@ __global__ __launch_bounds__(64 * (D / 32)) void k_fq_attn_bwd(const FqArgs a) {
 #pragma unroll
         for (int e = 0; e < 4; ++e) {
           const bool key = n0 + 16 * pb + 4 * g + e < len;
-          const float p = key ? exp2f(sv[e] - lse_c[qt]) : 0.f;
+          const float p = key ? __builtin_amdgcn_exp2f(sv[e] - lse_c[qt]) : 0.f;
           ds[pb][e] = p * (da[e] - del_c[qt]) * a.scale;
         }
       }
@@ -1432,7 +1432,7 @@ __global__ __launch_bounds__(64 * (D / 32)) void k_fq_attn_bwd(const FqArgs a) {
         const f32x4 da = mfma32(dof[qt], vr[pb], z);
 #pragma unroll
         for (int e = 0; e < 4; ++e) {
-          const float p = key_c[pb] ? exp2f(sv[e] - lse_r[qt][e]) : 0.f;
+          const float p = key_c[pb] ? __builtin_amdgcn_exp2f(sv[e] - lse_r[qt][e]) : 0.f;
           pq[qt][e] = p;
           dsq[qt][e] = p * (da[e] - del_r[qt][e]) * a.scale;
         }
@@ -1872,13 +1872,13 @@ __global__ __launch_bounds__(256, 1) void k_pma_fwd256(const PmaArgs a) {
     }
     mt = wave16_max(mt);
     const float mnew = fmaxf(mrow, mt);            // finite: the tile has >= 1 live point
-    const float alpha = exp2f(mrow - mnew);
+    const float alpha = __builtin_amdgcn_exp2f(mrow - mnew);
     float ls = 0.f;
 #pragma unroll
     for (int pb = 0; pb < 2; ++pb)
 #pragma unroll
       for (int e = 0; e < 4; ++e) {
-        s[pb][e] = exp2f(s[pb][e] - mnew);
+        s[pb][e] = __builtin_amdgcn_exp2f(s[pb][e] - mnew);
         ls += s[pb][e];
       }
     ls = wave16_sum(ls);
@@ -2113,7 +2113,7 @@ __global__ __launch_bounds__(256, 1) void k_pma_bwd256(const PmaArgs a) {
       f32x4 p, ds;
 #pragma unroll
       for (int e = 0; e < 4; ++e) {
-        p[e] = key ? exp2f(sv[e] - lse[e]) : 0.f;
+        p[e] = key ? __builtin_amdgcn_exp2f(sv[e] - lse[e]) : 0.f;
         ds[e] = LN2 * p[e] * (da[e] - del[e]);
       }
       pds[pb] = pack8(p, ds);

@@ -88,8 +88,10 @@ int mab1_d256_bwd(const pca_mab_shape& s, const void* X, const float* Hk, const 
   // PCA_BWD_O_FUSED=0: fc_o adjoint as its own row-GEMM launch (A/B measurements)
   static const bool fuse_o_env = [] { const char* e = getenv("PCA_BWD_O_FUSED"); return !(e && e[0] == '0'); }();
   const bool fuse_o = fuse_o_env;
-  PCA_TRY(prep_weight(p.wo, w.WoTP, D, D, fuse_o ? 3 : 2, st));
-  if (want_dx) PCA_TRY(prep_weight(p.wq, w.WqTP, D, D, rowstream_on() ? 3 : 2, st));
+  if (want_dx)
+    PCA_TRY(prep_weight2(p.wo, w.WoTP, fuse_o ? 3 : 2, p.wq, w.WqTP, rowstream_on() ? 3 : 2, D, D, st));
+  else
+    PCA_TRY(prep_weight(p.wo, w.WoTP, D, D, fuse_o ? 3 : 2, st));
   const __bf16* dYb = reinterpret_cast<const __bf16*>(dY);
   const __bf16* Xb = small ? nullptr : reinterpret_cast<const __bf16*>(X);
   if (!abf) {
@@ -259,8 +261,7 @@ int mab0_d256_fwd(const pca_mab_shape& s, const float* I, const void* X, const p
       PCA_TRY(rowgemm256_proj_f8(Xb, WvP, invs + 1, p.bv, v.Vp, s.B, s.nk, st));
     } else {
       if (rowstream_on()) {                  // one pass over X, weights in registers
-        PCA_TRY(prep_weight(p.wk, WkP, D, D, 0, st));
-        PCA_TRY(prep_weight(p.wv, WvP, D, D, 0, st));
+        PCA_TRY(prep_weight2(p.wk, WkP, 0, p.wv, WvP, 0, D, D, st));
         PCA_TRY(rowstream256_proj2(Xb, WkP, WvP, p.bk, p.bv, v.Kp, v.Vp, s.B, s.nk, st));   // modules.py:21
       } else {
         PCA_TRY(prep_weight(p.wk, WkP, D, D, 1, st));
@@ -390,8 +391,7 @@ int mab0_d256_bwd(const pca_mab_shape& s, const float* I, const void* X, const p
       const bool f32 = s.k_dtype == PCA_F32;
       __bf16* dXb = f32 ? w.dXb : reinterpret_cast<__bf16*>(dX);
       if (rowstream_on()) {                  // dKp Wk + dVp Wv in one pass, weights in registers
-        PCA_TRY(prep_weight(p.wk, w.WkTP, D, D, 3, st));
-        PCA_TRY(prep_weight(p.wv, w.WvTP, D, D, 3, st));
+        PCA_TRY(prep_weight2(p.wk, w.WkTP, 3, p.wv, w.WvTP, 3, D, D, st));
         PCA_TRY(rowstream256_dx2(w.dKp, w.dVp, w.WkTP, w.WvTP, dXb, s.B, s.nk,
                                  (!f32 && dk_accumulate) ? 1 : 0, st));
       } else {

@@ -735,10 +735,47 @@ int prep_weight_f8(const float* src, void* dst, int rows, int cols, int mode, fl
                      reinterpret_cast<uint8_t*>(dst), rows, cols, mode, inv_scale);
   return check_launch("k_prep_weight_f8");
 }
+// two images of equally shaped weights in one launch (blockIdx.y = image): every launch of a kernel
+// this small costs ~5 us of GPU time whatever it does
+__global__ void k_prep_weight2(const float* __restrict__ src0, __bf16* __restrict__ dst0, int mode0,
+                               const float* __restrict__ src1, __bf16* __restrict__ dst1, int mode1,
+                               int rows, int cols) {
+  const float* __restrict__ src = blockIdx.y == 0 ? src0 : src1;
+  __bf16* __restrict__ dst = blockIdx.y == 0 ? dst0 : dst1;
+  const int mode = blockIdx.y == 0 ? mode0 : mode1;
+  const int idx = blockIdx.x * blockDim.x + threadIdx.x;
+  if (idx >= rows * cols) return;
+  float v;
+  if (mode <= 1) {
+    const int n = idx / cols, k = idx - n * cols;
+    const int kk = mode == 1 ? (k & ~31) + perm32(k & 31) : k;
+    v = src[(int64_t)n * cols + kk];
+  } else {
+    const int n = idx / rows, k = idx - n * rows;
+    const int kk = mode == 2 ? (k & ~31) + perm32(k & 31) : k;
+    v = src[(int64_t)kk * cols + n];
+  }
+  dst[idx] = (__bf16)v;
+}
+int prep_weight2(const float* src0, __bf16* dst0, int mode0, const float* src1, __bf16* dst1,
+                 int mode1, int rows, int cols, hipStream_t st) {
+  hipLaunchKernelGGL(k_prep_weight2, dim3((unsigned)cdiv((int64_t)rows * cols, 256), 2), dim3(256),
+                     0, st, src0, dst0, mode0, src1, dst1, mode1, rows, cols);
+  return check_launch("k_prep_weight2");
+}
 int prep_weight(const float* src, __bf16* dst, int rows, int cols, int mode, hipStream_t st) {
   hipLaunchKernelGGL(k_prep_weight, dim3((unsigned)cdiv((int64_t)rows * cols, 256)), dim3(256), 0,
                      st, src, dst, rows, cols, mode);
   return check_launch("k_prep_weight");
+}
+
+// PCA_D256_FUSED=0: the two-launch form (Q phase + row-GEMM O phase) for A/B measurements
+static bool fused256_on() {
+  static const bool on = [] {
+    const char* e = getenv("PCA_D256_FUSED");
+    return !(e != nullptr && e[0] == '0');
+  }();
+  return on;
 }
 
 bool mab1_bf16_supported(const pca_mab_shape& s, bool inference) {
@@ -823,8 +860,10 @@ int mab1_bf16_fwd_ex(const pca_mab_shape& s, const void* X, const float* H,
     WqB = img->WqB;
     WoP = img->WoP;
   } else {
-    if (!small) PCA_TRY(prep_weight(p.wq, WqB, d, d, 0, st));
-    PCA_TRY(prep_weight(p.wo, WoP, d, d, 1, st));
+    // (d = 256 with bf16 activations runs k_isab1_fwd256, which takes Wo as a natural image too)
+    const int wo_mode = (d == 256 && s.y_dtype == PCA_BF16 && fused256_on()) ? 0 : 1;
+    if (!small) PCA_TRY(prep_weight2(p.wq, WqB, 0, p.wo, WoP, wo_mode, d, d, st));
+    else PCA_TRY(prep_weight(p.wo, WoP, d, d, wo_mode, st));
   }
   if (!(flags & PCA_F_KV_READY) && d > 128) {
     // Kp = H Wk^T + bk, Vp = H Wv^T + bv as MFMA products (fp32 accumulation; the operand
@@ -880,14 +919,10 @@ int mab1_bf16_fwd_ex(const pca_mab_shape& s, const void* X, const float* H,
   if (d == 256) {          // Q phase + O phase: O meets in the saved / scratch block
     if (small && !abf) return launch_fwd<256, 32, true, false>(a, st);
     a.OS = v.OS;
-    // PCA_D256_FUSED=0: the two-launch form (Q phase + row-GEMM O phase) for A/B measurements
-    static const bool fused256 = [] {
-      const char* e = getenv("PCA_D256_FUSED");
-      return !(e != nullptr && e[0] == '0');
-    }();
+    const bool fused256 = fused256_on();
     if (abf && !f8 && fused256) {
       // one launch: wave = head, both weight slices in registers (d256_fused.hip)
-      PCA_TRY(prep_weight(p.wo, WoP, d, d, 0, st));           // natural image for this kernel
+      if (img != nullptr) PCA_TRY(prep_weight(p.wo, WoP, d, d, 0, st));   // natural image for this kernel
       return isab1_fwd256_fused(X, s.dq, WqB, p.wq, p.bq, v.KpP, v.Vt, WoP, p.bo,
                                 reinterpret_cast<__bf16*>(Y), a.QpS, training ? v.OS : nullptr,
                                 a.mask, s.B, s.nq, st);

@@ -189,6 +189,8 @@ int mid_bwd_launch(const MidBwdLaunch& L, hipStream_t st);
 
 // fp32 weight [rows][cols] -> bf16 image; mode 0 natural, 1 K-permuted, 2 transposed +
 // K-permuted ([cols][rows]), 3 transposed natural
+int prep_weight2(const float* src0, __bf16* dst0, int mode0, const float* src1, __bf16* dst1,
+                 int mode1, int rows, int cols, hipStream_t st);
 int prep_weight(const float* src, __bf16* dst, int rows, int cols, int mode, hipStream_t st);
 // fp8 e4m3 image of s * W (mode 0 natural / 1 K-permuted), s a power of two; inv_scale[0] = 1 / s
 int prep_weight_f8(const float* src, void* dst, int rows, int cols, int mode, float* inv_scale,

@@ -99,4 +99,30 @@ __device__ __forceinline__ float wave16_sum(float v) {
   return __uint_as_float(b[0]) + __uint_as_float(b[1]);
 }
 
+// 8 consecutive features of row `n` of a [rows][DK] activation tensor as bf16 (ABF: stored bf16,
+// else fp32 rounded here); rows at or past `n_hi` read row n_hi - 1 and come back as zeros.
+// UNCONDITIONAL loads on purpose: a load under a divergent `if` gets its own basic block and an
+// s_waitcnt vmcnt(0) of its own, i.e. the 4-8 loads of a tile become as many serial round trips.
+template <bool ABF>
+__device__ __forceinline__ bf16x8 ld_x8_guard(const void* X, int64_t set_row0, int n, int n_hi,
+                                              int DK, int ch) {
+  const bool ok = n < n_hi;
+  const int64_t row = set_row0 + (ok ? n : n_hi - 1);
+  bf16x8 v;
+  if (ABF) {
+    v = *reinterpret_cast<const bf16x8*>(reinterpret_cast<const __bf16*>(X) + row * DK + ch * 8);
+  } else {
+    const float4* src =
+        reinterpret_cast<const float4*>(reinterpret_cast<const float*>(X) + row * DK + ch * 8);
+    const float4 lo = src[0], hi = src[1];
+    v[0] = (__bf16)lo.x; v[1] = (__bf16)lo.y; v[2] = (__bf16)lo.z; v[3] = (__bf16)lo.w;
+    v[4] = (__bf16)hi.x; v[5] = (__bf16)hi.y; v[6] = (__bf16)hi.z; v[7] = (__bf16)hi.w;
+  }
+  if (!ok) {
+#pragma unroll
+    for (int k = 0; k < 8; ++k) v[k] = (__bf16)0.f;
+  }
+  return v;
+}
+
 }  // namespace pca
