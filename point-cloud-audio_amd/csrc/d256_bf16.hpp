@@ -34,7 +34,7 @@ int attn1_bwd256(const __bf16* dO, const __bf16* QpS, const __bf16* KpP, const _
 int isab1_fwd256_fused(const void* X, int dq, const __bf16* WqB, const float* WqF, const float* bq,
                        const __bf16* KpP, const __bf16* Vt, const __bf16* WoB, const float* bo,
                        __bf16* Y, __bf16* QpS, __bf16* OS, uint32_t* mask, int B, int N,
-                       hipStream_t st);
+                       hipStream_t st, const float* inv_o = nullptr);
 
 // dW[256 x 256] += G^T A, db[256] += colsum(G) (nullable); G, A bf16 [M][256]
 struct Wgrad256Job {
@@ -61,6 +61,9 @@ int kv_proj_small256(const float* X, int64_t M, int dk, const float* Wk, const f
 // d256_stream.hip: streaming row-GEMMs with the weights in registers
 int rowstream256_proj2(const __bf16* X, const __bf16* WkB, const __bf16* WvB, const float* bk,
                        const float* bv, __bf16* Kp, __bf16* Vp, int B, int N, hipStream_t st);
+int rowstream256_proj2_f8(const __bf16* X, const void* Wk8, const void* Wv8, const float* inv_scale,
+                          const float* bk, const float* bv, __bf16* Kp, __bf16* Vp, int B, int N,
+                          hipStream_t st);
 int rowstream256_dx2(const __bf16* dKp, const __bf16* dVp, const __bf16* WkT, const __bf16* WvT,
                      __bf16* dX, int B, int N, int accumulate, hipStream_t st);
 int rowstream256_dx1(const __bf16* dQp, const __bf16* WqT, __bf16* dX, int B, int N,

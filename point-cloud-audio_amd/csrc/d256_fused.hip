@@ -38,7 +38,8 @@ struct FusedFwdArgs {
   const float* bq;
   const __bf16* KpP;      // [B][32][256] (K-permuted features inside each head)
   const __bf16* Vt;       // [B][256][32] (keys in perm32 order)
-  const __bf16* Wo;       // [256][256] bf16, natural
+  const __bf16* Wo;       // [256][256] bf16, natural (F8O: fp8 e4m3 bytes of s * Wo, natural)
+  const float* inv_o;     // F8O: 1 / s
   const float* bo;
   __bf16* Y;              // [B*N][256]
   __bf16 *QpS, *OS;       // saved for the backward (nullable)
@@ -53,7 +54,9 @@ __device__ __forceinline__ int toff(int row, int c16) { return swz(row, c16, ROW
 typedef __attribute__((address_space(1))) const void gptr_t;
 typedef __attribute__((address_space(3))) void lptr_t;
 
-template <bool SMALL>
+// F8O (PCA_MODE_FP8): fc_o with fp8 e4m3 operands - Wo slices as fp8 (32 registers instead of 64),
+// the O fragments converted in registers, Z rescaled by 1 / s before the bias
+template <bool SMALL, bool F8O = false>
 __global__ __launch_bounds__(512, 2) void k_isab1_fwd256(const FusedFwdArgs a) {
   constexpr int KS = D / 32;
   extern __shared__ __attribute__((aligned(16))) char smem[];
@@ -70,13 +73,19 @@ __global__ __launch_bounds__(512, 2) void k_isab1_fwd256(const FusedFwdArgs a) {
   const int r = lane & 15, g = lane >> 4;
 
   // ---- this head's weight slices: A operands [row = feature 32 j + 16 t + r][k = 32 s + 8 g ..] ----
-  bf16x8 wqa[SMALL ? 1 : KS][2], woa[KS][2];
+  bf16x8 wqa[SMALL ? 1 : KS][2], woa[F8O ? 1 : KS][2];
+  f8x8 woa8[F8O ? KS : 1][2];
+  const float inv_o = F8O ? a.inv_o[0] : 1.f;
 #pragma unroll
   for (int s = 0; s < KS; ++s)
 #pragma unroll
     for (int t = 0; t < 2; ++t) {
       const int64_t o = (int64_t)(32 * j + 16 * t + r) * D + 32 * s + 8 * g;
-      woa[s][t] = *reinterpret_cast<const bf16x8*>(a.Wo + o);
+      if (F8O)
+        woa8[F8O ? s : 0][t] =
+            *reinterpret_cast<const f8x8*>(reinterpret_cast<const uint8_t*>(a.Wo) + o);
+      else
+        woa[F8O ? 0 : s][t] = *reinterpret_cast<const bf16x8*>(a.Wo + o);
       if (!SMALL) wqa[s][t] = *reinterpret_cast<const bf16x8*>(a.Wq + o);
     }
   // layer 1: fc_q rows of the features this lane holds in the accumulator layout
@@ -311,7 +320,8 @@ __global__ __launch_bounds__(512, 2) void k_isab1_fwd256(const FusedFwdArgs a) {
     // (the accumulators of O_h are re-used for Z_h: the residual O_h is read back from the
     //  wave's own slice of the O tile - bf16, the rounding the two-launch form had as well)
     {
-      const f32x4 bo0 = bias4(1, 0), bo1 = bias4(1, 1);
+      const f32x4 z4 = {0.f, 0.f, 0.f, 0.f};
+      const f32x4 bo0 = F8O ? z4 : bias4(1, 0), bo1 = F8O ? z4 : bias4(1, 1);
 #pragma unroll
       for (int nb = 0; nb < NBK; ++nb) {
         acc[0][nb] = bo0;
@@ -324,8 +334,14 @@ __global__ __launch_bounds__(512, 2) void k_isab1_fwd256(const FusedFwdArgs a) {
       for (int nb = 0; nb < NBK; ++nb) {
         const bf16x8 ob =
             *reinterpret_cast<const bf16x8*>(sO + oB[s & 3] + 256 * (s >> 2) + 8192 * nb);
-        acc[0][nb] = mfma32(woa[s][0], ob, acc[0][nb]);
-        acc[1][nb] = mfma32(woa[s][1], ob, acc[1][nb]);
+        if (F8O) {
+          const f8x8 o8 = bf_to_f8(ob);
+          acc[0][nb] = mfma32_f8(woa8[F8O ? s : 0][0], o8, acc[0][nb]);
+          acc[1][nb] = mfma32_f8(woa8[F8O ? s : 0][1], o8, acc[1][nb]);
+        } else {
+          acc[0][nb] = mfma32(woa[F8O ? 0 : s][0], ob, acc[0][nb]);
+          acc[1][nb] = mfma32(woa[F8O ? 0 : s][1], ob, acc[1][nb]);
+        }
       }
 #pragma unroll
     for (int nb = 0; nb < NBK; ++nb) {
@@ -333,10 +349,11 @@ __global__ __launch_bounds__(512, 2) void k_isab1_fwd256(const FusedFwdArgs a) {
 #pragma unroll
       for (int t = 0; t < 2; ++t) {
         const bf16x4 o4 = *reinterpret_cast<const bf16x4*>(sO + oD[t] + 8192 * nb);
-        f32x4 y;
+        f32x4 y, bo4 = {0.f, 0.f, 0.f, 0.f};
+        if (F8O) bo4 = bias4(1, t);
 #pragma unroll
         for (int e = 0; e < 4; ++e) {
-          const float zz = acc[t][nb][e];
+          const float zz = F8O ? acc[t][nb][e] * inv_o + bo4[e] : acc[t][nb][e];
           y[e] = (float)o4[e] + fmaxf(zz, 0.f);
           if (zz > 0.f) bits |= 1u << (4 * t + e);
         }
@@ -359,8 +376,9 @@ __global__ __launch_bounds__(512, 2) void k_isab1_fwd256(const FusedFwdArgs a) {
 int isab1_fwd256_fused(const void* X, int dq, const __bf16* WqB, const float* WqF, const float* bq,
                        const __bf16* KpP, const __bf16* Vt, const __bf16* WoB, const float* bo,
                        __bf16* Y, __bf16* QpS, __bf16* OS, uint32_t* mask, int B, int N,
-                       hipStream_t st) {
+                       hipStream_t st, const float* inv_o) {
   FusedFwdArgs a{};
+  a.inv_o = inv_o;
   a.X = X; a.Wq = WqB; a.WqF = WqF; a.bq = bq; a.KpP = KpP; a.Vt = Vt; a.Wo = WoB; a.bo = bo;
   a.Y = Y; a.QpS = QpS; a.OS = OS; a.mask = mask;
   a.B = B; a.N = N; a.dq = dq;
@@ -373,16 +391,25 @@ int isab1_fwd256_fused(const void* X, int dq, const __bf16* WqB, const float* Wq
   const size_t lds = 8 * (size_t)TILEB + 2 * NBK * 2 * 64 * sizeof(uint32_t) + 2 * D * sizeof(float);
   static std::once_flag once;
   std::call_once(once, [] {
-    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(k_isab1_fwd256<false>),
+    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(k_isab1_fwd256<false, false>),
                               hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
-    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(k_isab1_fwd256<true>),
+    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(k_isab1_fwd256<true, false>),
+                              hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(k_isab1_fwd256<false, true>),
+                              hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(k_isab1_fwd256<true, true>),
                               hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
   });
   const double pts = (double)B * N;
   ProfScope ps(PCA_K_MAB1_FWD, st, 2.0 * pts * ((double)dq * D + (double)D * D + 2.0 * MI * D),
                pts * ((dq <= 4 ? 4.0 : 2.0) * dq + 2.0 * D));
-  if (dq <= 4) hipLaunchKernelGGL(k_isab1_fwd256<true>, dim3(grid), dim3(512), lds, st, a);
-  else hipLaunchKernelGGL(k_isab1_fwd256<false>, dim3(grid), dim3(512), lds, st, a);
+  if (inv_o != nullptr) {
+    if (dq <= 4) hipLaunchKernelGGL((k_isab1_fwd256<true, true>), dim3(grid), dim3(512), lds, st, a);
+    else hipLaunchKernelGGL((k_isab1_fwd256<false, true>), dim3(grid), dim3(512), lds, st, a);
+  } else {
+    if (dq <= 4) hipLaunchKernelGGL((k_isab1_fwd256<true, false>), dim3(grid), dim3(512), lds, st, a);
+    else hipLaunchKernelGGL((k_isab1_fwd256<false, false>), dim3(grid), dim3(512), lds, st, a);
+  }
   ps.end();
   return check_launch("k_isab1_fwd256");
 }

@@ -255,10 +255,16 @@ int mab0_d256_fwd(const pca_mab_shape& s, const float* I, const void* X, const p
       Xb = v.Xb;
     }
     if (s.mode == PCA_MODE_FP8) {           // fc_k / fc_v with fp8 e4m3 operands
-      PCA_TRY(prep_weight_f8(p.wk, WkP, D, D, 1, invs, st));
-      PCA_TRY(prep_weight_f8(p.wv, WvP, D, D, 1, invs + 1, st));
-      PCA_TRY(rowgemm256_proj_f8(Xb, WkP, invs, p.bk, v.Kp, s.B, s.nk, st));
-      PCA_TRY(rowgemm256_proj_f8(Xb, WvP, invs + 1, p.bv, v.Vp, s.B, s.nk, st));
+      if (rowstream_on()) {
+        PCA_TRY(prep_weight_f8(p.wk, WkP, D, D, 0, invs, st));
+        PCA_TRY(prep_weight_f8(p.wv, WvP, D, D, 0, invs + 1, st));
+        PCA_TRY(rowstream256_proj2_f8(Xb, WkP, WvP, invs, p.bk, p.bv, v.Kp, v.Vp, s.B, s.nk, st));
+      } else {
+        PCA_TRY(prep_weight_f8(p.wk, WkP, D, D, 1, invs, st));
+        PCA_TRY(prep_weight_f8(p.wv, WvP, D, D, 1, invs + 1, st));
+        PCA_TRY(rowgemm256_proj_f8(Xb, WkP, invs, p.bk, v.Kp, s.B, s.nk, st));
+        PCA_TRY(rowgemm256_proj_f8(Xb, WvP, invs + 1, p.bv, v.Vp, s.B, s.nk, st));
+      }
     } else {
       if (rowstream_on()) {                  // one pass over X, weights in registers
         PCA_TRY(prep_weight2(p.wk, WkP, 0, p.wv, WvP, 0, D, D, st));

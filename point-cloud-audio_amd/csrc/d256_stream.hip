@@ -30,6 +30,7 @@ struct RowStreamArgs {
   const __bf16* In[2];      // [B*N][256] input streams
   const __bf16* W[2];       // [256][256] bf16 A-operand images: row = output feature, col = k
   const float* bias[2];     // per output (nullable)
+  const float* inv_scale;   // F8: 1 / s of the two fp8 weight images (W holds fp8 bytes of s * W)
   __bf16* Out[2];           // [B*N][256]
   const __bf16* Acc;        // ACC: tensor added to output 0 (may alias Out[0])
   int B, N, tiles_per_set, units_per_wg;
@@ -58,7 +59,9 @@ __device__ __forceinline__ void wait_vm(int n) {
 // NIN input streams, NOUT outputs, NG = max(NIN, NOUT) weights: GEMM g multiplies input
 // (NIN == 2 ? g : 0) and lands in output (NOUT == 2 ? g : 0) - the two products of DX2 share one
 // accumulator.  ACC: output 0 also gets the tensor a.Acc (a third DMA stream).
-template <int NIN, int NOUT, bool ACC, int NBUF>
+// F8 (PROJ2): the weights are fp8 e4m3 images of s * W, the activation fragments are converted to
+// fp8 in registers, the accumulators are rescaled by 1 / s before the bias (PCA_MODE_FP8)
+template <int NIN, int NOUT, bool ACC, int NBUF, bool F8 = false>
 __global__ __launch_bounds__(512, 2) void k_rowstream(const RowStreamArgs a) {
   constexpr int NG = NIN > NOUT ? NIN : NOUT;
   constexpr int NS = NIN + (ACC ? 1 : 0);       // DMA streams
@@ -71,15 +74,24 @@ __global__ __launch_bounds__(512, 2) void k_rowstream(const RowStreamArgs a) {
   const int r = lane & 15, g = lane >> 4;
 
   // A operands: [row = feature 32 j + 16 t + r][k = 32 s + 8 g ..]
-  bf16x8 wa[NG][KS][2];
+  bf16x8 wa[F8 ? 1 : NG][KS][2];
+  f8x8 wa8[F8 ? NG : 1][KS][2];
+  float inv_s[NG];
 #pragma unroll
-  for (int q = 0; q < NG; ++q)
+  for (int q = 0; q < NG; ++q) {
+    inv_s[q] = F8 ? a.inv_scale[q] : 1.f;
 #pragma unroll
     for (int s = 0; s < KS; ++s)
 #pragma unroll
-      for (int t = 0; t < 2; ++t)
-        wa[q][s][t] = *reinterpret_cast<const bf16x8*>(
-            a.W[q] + (int64_t)(32 * j + 16 * t + r) * D + 32 * s + 8 * g);
+      for (int t = 0; t < 2; ++t) {
+        const int64_t o = (int64_t)(32 * j + 16 * t + r) * D + 32 * s + 8 * g;
+        if (F8)
+          wa8[F8 ? q : 0][s][t] =
+              *reinterpret_cast<const f8x8*>(reinterpret_cast<const uint8_t*>(a.W[q]) + o);
+        else
+          wa[F8 ? 0 : q][s][t] = *reinterpret_cast<const bf16x8*>(a.W[q] + o);
+      }
+  }
   f32x4 bz[NOUT][2];
 #pragma unroll
   for (int o = 0; o < NOUT; ++o)
@@ -165,7 +177,7 @@ __global__ __launch_bounds__(512, 2) void k_rowstream(const RowStreamArgs a) {
 #pragma unroll
       for (int t = 0; t < 2; ++t)
 #pragma unroll
-        for (int nb = 0; nb < 2; ++nb) acc[o][t][nb] = bz[o][t];
+        for (int nb = 0; nb < 2; ++nb) acc[o][t][nb] = F8 ? f32x4{0.f, 0.f, 0.f, 0.f} : bz[o][t];
 #pragma unroll
     for (int q = 0; q < NG; ++q) {
       const char* sX = sIn + ((NIN == 2 ? q : 0) * NBUF + k % NBUF) * TILEB;
@@ -178,8 +190,14 @@ __global__ __launch_bounds__(512, 2) void k_rowstream(const RowStreamArgs a) {
         for (int nb = 0; nb < 2; ++nb) {
           const bf16x8 bx =
               *reinterpret_cast<const bf16x8*>(sX + oB[s & 3] + 256 * (s >> 2) + 8192 * nb);
-          acc[o][0][nb] = mfma32(wa[q][s][0], bx, acc[o][0][nb]);
-          acc[o][1][nb] = mfma32(wa[q][s][1], bx, acc[o][1][nb]);
+          if (F8) {
+            const f8x8 b8 = bf_to_f8(bx);
+            acc[o][0][nb] = mfma32_f8(wa8[F8 ? q : 0][s][0], b8, acc[o][0][nb]);
+            acc[o][1][nb] = mfma32_f8(wa8[F8 ? q : 0][s][1], b8, acc[o][1][nb]);
+          } else {
+            acc[o][0][nb] = mfma32(wa[F8 ? 0 : q][s][0], bx, acc[o][0][nb]);
+            acc[o][1][nb] = mfma32(wa[F8 ? 0 : q][s][1], bx, acc[o][1][nb]);
+          }
         }
     }
 #pragma unroll
@@ -189,6 +207,10 @@ __global__ __launch_bounds__(512, 2) void k_rowstream(const RowStreamArgs a) {
 #pragma unroll
         for (int nb = 0; nb < 2; ++nb) {
           f32x4 v = acc[o][t][nb];
+          if (F8) {                      // (PROJ2 only: output o is GEMM o)
+#pragma unroll
+            for (int e = 0; e < 4; ++e) v[e] = v[e] * inv_s[o] + bz[o][t][e];
+          }
           if (ACC && o == 0) {
             const f32x4 old = tof(*reinterpret_cast<const bf16x4*>(
                 sIn + (NIN * NBUF + k % NBUF) * TILEB + oD[t] + 8192 * nb));
@@ -209,7 +231,7 @@ __global__ __launch_bounds__(512, 2) void k_rowstream(const RowStreamArgs a) {
   }
 }
 
-template <int NIN, int NOUT, bool ACC, int NBUF>
+template <int NIN, int NOUT, bool ACC, int NBUF, bool F8 = false>
 int launch_rowstream(RowStreamArgs a, hipStream_t st) {
   a.tiles_per_set = (int)cdiv(a.N, P);
   const int total = a.B * a.tiles_per_set;
@@ -221,10 +243,10 @@ int launch_rowstream(RowStreamArgs a, hipStream_t st) {
   static_assert((NS * NBUF + NOUT) * TILEB <= 160 * 1024, "LDS");
   static std::once_flag once;
   std::call_once(once, [] {
-    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(k_rowstream<NIN, NOUT, ACC, NBUF>),
+    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(k_rowstream<NIN, NOUT, ACC, NBUF, F8>),
                               hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
   });
-  hipLaunchKernelGGL((k_rowstream<NIN, NOUT, ACC, NBUF>), dim3(grid), dim3(512), lds, st, a);
+  hipLaunchKernelGGL((k_rowstream<NIN, NOUT, ACC, NBUF, F8>), dim3(grid), dim3(512), lds, st, a);
   return check_launch("k_rowstream");
 }
 
@@ -237,6 +259,17 @@ int rowstream256_proj2(const __bf16* X, const __bf16* WkB, const __bf16* WvB, co
   a.In[0] = X; a.W[0] = WkB; a.W[1] = WvB; a.bias[0] = bk; a.bias[1] = bv;
   a.Out[0] = Kp; a.Out[1] = Vp; a.B = B; a.N = N;
   return launch_rowstream<1, 2, false, 4>(a, st);
+}
+// the same with fp8 e4m3 operands: Wk8 / Wv8 = natural fp8 images of s * W (prep_weight_f8, mode 0),
+// inv_scale[0 / 1] = 1 / s
+int rowstream256_proj2_f8(const __bf16* X, const void* Wk8, const void* Wv8, const float* inv_scale,
+                          const float* bk, const float* bv, __bf16* Kp, __bf16* Vp, int B, int N,
+                          hipStream_t st) {
+  RowStreamArgs a{};
+  a.In[0] = X; a.W[0] = reinterpret_cast<const __bf16*>(Wk8);
+  a.W[1] = reinterpret_cast<const __bf16*>(Wv8); a.bias[0] = bk; a.bias[1] = bv;
+  a.inv_scale = inv_scale; a.Out[0] = Kp; a.Out[1] = Vp; a.B = B; a.N = N;
+  return launch_rowstream<1, 2, false, 4, true>(a, st);
 }
 // dX (+)= dKp Wk + dVp Wv ; WkT / WvT: transposed bf16 images ([in][out], prep mode 3)
 int rowstream256_dx2(const __bf16* dKp, const __bf16* dVp, const __bf16* WkT, const __bf16* WvT,

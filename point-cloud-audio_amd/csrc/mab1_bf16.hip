@@ -53,7 +53,9 @@ __global__ void k_prep_weight(const float* __restrict__ src, __bf16* __restrict_
 
 // fp8 (e4m3) image of an nn.Linear weight [rows][cols]: dst = fp8(s * W) (mode 0 natural, 1
 // K-permuted as k_prep_weight), s = the largest power of two with s * max|W| <= 448 (exact scaling);
-// inv_scale[0] = 1 / s.  One workgroup (the images are 64 K elements).
+// inv_scale[0] = 1 / s.  gridDim.x workgroups convert 4096 elements each; EVERY workgroup finds
+// the maximum of the whole tensor for itself (256 KiB of L2 reads, 16-byte loads, all in flight) -
+// the one-workgroup form walked the tensor twice with 64 dependent loads per thread: 20 us.
 __global__ __launch_bounds__(1024) void k_prep_weight_f8(const float* __restrict__ src,
                                                          uint8_t* __restrict__ dst, int rows,
                                                          int cols, int mode,
@@ -62,7 +64,21 @@ __global__ __launch_bounds__(1024) void k_prep_weight_f8(const float* __restrict
   __shared__ float s_scale;
   const int tid = threadIdx.x, n = rows * cols;
   float am = 0.f;
-  for (int i = tid; i < n; i += 1024) am = fmaxf(am, fabsf(src[i]));
+  if ((n & 3) == 0) {
+    for (int i0 = 4 * tid; i0 < n; i0 += 16 * 4096) {
+      float4 v[16];
+#pragma unroll
+      for (int u = 0; u < 16; ++u)
+        v[u] = i0 + u * 4096 < n ? *reinterpret_cast<const float4*>(src + i0 + u * 4096)
+                                 : float4{0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+      for (int u = 0; u < 16; ++u)
+        am = fmaxf(fmaxf(am, fmaxf(fabsf(v[u].x), fabsf(v[u].y))),
+                   fmaxf(fabsf(v[u].z), fabsf(v[u].w)));
+    }
+  } else {
+    for (int i = tid; i < n; i += 1024) am = fmaxf(am, fabsf(src[i]));
+  }
 #pragma unroll
   for (int o = 32; o > 0; o >>= 1) am = fmaxf(am, __shfl_xor(am, o, 64));
   if ((tid & 63) == 0) red[tid >> 6] = am;
@@ -72,17 +88,17 @@ __global__ __launch_bounds__(1024) void k_prep_weight_f8(const float* __restrict
     for (int i = 0; i < 16; ++i) m = fmaxf(m, red[i]);
     const float sc = m > 0.f ? exp2f(floorf(log2f(448.f / m))) : 1.f;
     s_scale = sc;
-    inv_scale[0] = 1.f / sc;
+    if (blockIdx.x == 0) inv_scale[0] = 1.f / sc;
   }
   __syncthreads();
   const float sc = s_scale;
-  for (int i0 = 4 * tid; i0 < n; i0 += 4096) {
+  for (int i0 = 4 * (blockIdx.x * 1024 + tid); i0 < n; i0 += 4096 * gridDim.x) {
     float v[4];
 #pragma unroll
     for (int u = 0; u < 4; ++u) {
       const int idx = i0 + u, r = idx / cols, k = idx - r * cols;
       const int kk = mode == 1 ? (k & ~31) + perm32(k & 31) : k;
-      v[u] = src[(int64_t)r * cols + kk] * sc;
+      v[u] = idx < n ? src[(int64_t)r * cols + kk] * sc : 0.f;
     }
     *reinterpret_cast<uint32_t*>(dst + i0) = cvt4_f8(v[0], v[1], v[2], v[3]);
   }
@@ -731,7 +747,7 @@ int prep_jobs_launch(const PrepJobs& jobs, hipStream_t st) {
 }
 int prep_weight_f8(const float* src, void* dst, int rows, int cols, int mode, float* inv_scale,
                    hipStream_t st) {
-  hipLaunchKernelGGL(k_prep_weight_f8, dim3(1), dim3(1024), 0, st, src,
+  hipLaunchKernelGGL(k_prep_weight_f8, dim3((unsigned)cdiv((int64_t)rows * cols, 4096)), dim3(1024), 0, st, src,
                      reinterpret_cast<uint8_t*>(dst), rows, cols, mode, inv_scale);
   return check_launch("k_prep_weight_f8");
 }
@@ -851,11 +867,14 @@ int mab1_bf16_fwd_ex(const pca_mab_shape& s, const void* X, const float* H,
     const char* e = getenv("PCA_FP8_PROJ");
     return e != nullptr && e[0] == 'q';
   }();
+  // d = 256, bf16 activations, fc_o in fp8 (the default split): the single-launch kernel
+  const bool f8_fused = f8 && !f8_q && d == 256 && s.y_dtype == PCA_BF16 && fused256_on();
   if (f8) {
-    // fp8 images of s * Wq (natural) and s * Wo (K-permuted); bf16 image of Wq when it stays bf16
+    // fp8 images of s * Wq (natural) and s * Wo (K-permuted; natural for the single-launch kernel);
+    // bf16 image of Wq when it stays bf16
     if (!small && f8_q) PCA_TRY(prep_weight_f8(p.wq, WqB, d, d, 0, invs, st));
     else if (!small) PCA_TRY(prep_weight(p.wq, WqB, d, d, 0, st));
-    PCA_TRY(prep_weight_f8(p.wo, WoP, d, d, 1, invs + 1, st));
+    PCA_TRY(prep_weight_f8(p.wo, WoP, d, d, f8_fused ? 0 : 1, invs + 1, st));
   } else if (img != nullptr) {
     WqB = img->WqB;
     WoP = img->WoP;
@@ -920,6 +939,10 @@ int mab1_bf16_fwd_ex(const pca_mab_shape& s, const void* X, const float* H,
     if (small && !abf) return launch_fwd<256, 32, true, false>(a, st);
     a.OS = v.OS;
     const bool fused256 = fused256_on();
+    if (f8_fused)
+      return isab1_fwd256_fused(X, s.dq, WqB, p.wq, p.bq, v.KpP, v.Vt, WoP, p.bo,
+                                reinterpret_cast<__bf16*>(Y), a.QpS, training ? v.OS : nullptr,
+                                a.mask, s.B, s.nq, st, invs + 1);
     if (abf && !f8 && fused256) {
       // one launch: wave = head, both weight slices in registers (d256_fused.hip)
       if (img != nullptr) PCA_TRY(prep_weight(p.wo, WoP, d, d, 0, st));   // natural image for this kernel

@@ -207,7 +207,7 @@ def test_mab0_fwd_bf16(dev, case):
     print(f"mab0 fwd {case}: max err {err:.3e} (max|ref| {float(ref.abs().max()):.2f})")
 
 
-def mab0_forward_bf16emu(I, X, p, h):
+def mab0_forward_bf16emu(I, X, p, h, fp8=False):
     """Reassociated mab0 with the MFMA operands (G' = sl2e Qp_h Wk_h, X, P) rounded to bf16 as
     csrc/mab0_bf16.hip does; epilogue fp32.  Returns H.
     d = 256 with dk = 256 (csrc/d256_*.hip): the keys ARE projected - Kp, Vp, the scaled query
@@ -222,8 +222,13 @@ def mab0_forward_bf16emu(I, X, p, h):
     Qp = I[0] @ p["fc_q.weight"].t() + p["fc_q.bias"]                  # [m, d]
     if d == 256 and dk == 256 and h * m > 16:
         Xb = rb(X)
-        Kp = rb(Xb @ rb(p["fc_k.weight"]).t() + p["fc_k.bias"]).view(B, N, h, dh)
-        Vp = rb(Xb @ rb(p["fc_v.weight"]).t() + p["fc_v.bias"]).view(B, N, h, dh)
+        if fp8:            # PCA_MODE_FP8: fc_k / fc_v with e4m3 operands (oracle/st_oracle.py:_lin8)
+            from oracle.st_oracle import _lin8
+            Kp = rb(_lin8(Xb, p["fc_k.weight"], p["fc_k.bias"])).view(B, N, h, dh)
+            Vp = rb(_lin8(Xb, p["fc_v.weight"], p["fc_v.bias"])).view(B, N, h, dh)
+        else:
+            Kp = rb(Xb @ rb(p["fc_k.weight"]).t() + p["fc_k.bias"]).view(B, N, h, dh)
+            Vp = rb(Xb @ rb(p["fc_v.weight"]).t() + p["fc_v.bias"]).view(B, N, h, dh)
         S2 = torch.einsum("qjf,bnjf->bjqn", rb(Qp * sl2e).view(m, h, dh), Kp)
         P = torch.softmax(S2 * math.log(2.0), dim=-1)
         O = Qp.view(1, m, h, dh) + torch.einsum("bjqn,bnjf->bqjf", rb(P), Vp)
@@ -536,10 +541,40 @@ def test_auto_mode_at_d256(dev):
 
 
 # ---- PCA_MODE_FP8: fp8 e4m3 operands in the d x d projections of the forward ---------------------
+def test_mab0_fwd_fp8_projected_keys(dev):
+    """Few-queries block at d = 256 in PCA_MODE_FP8: fc_k / fc_v over the N keys with fp8 e4m3
+    operands (k_rowstream PROJ2, F8).  Kernel vs the fp8-operand emulation (tight) and emulation vs
+    the bf16-operand emulation (the precision statement)."""
+    import modules
+    import pca_hip
+    B, N, m, dk, d, h = 3, 200, 32, 256, 256, 8
+    p = _mab_params(d, dk, d, seed=77)
+    g = torch.Generator().manual_seed(78)
+    I = torch.randn(1, m, d, generator=g) * 0.5
+    X = torch.randn(B, N, dk, generator=g)
+    e8 = mab0_forward_bf16emu(I, X, p, h, fp8=True)
+    eb = mab0_forward_bf16emu(I, X, p, h)
+    mab = modules.MAB(d, dk, d, h).to(dev)
+    mab.load_state_dict(p)
+    pca_hip.set_mode("fp8")
+    try:
+        with torch.no_grad():
+            H8 = mab(I.to(dev), X.to(dev), q_shared=True)
+    finally:
+        pca_hip.set_mode("f32")
+    e = close(H8, e8, 6e-3, "fp8 kernel vs fp8 emulation")
+    sc = max(1.0, float(eb.abs().max()))
+    rms = float((e8 - eb).pow(2).mean().sqrt()) / sc
+    print(f"mab0 fwd fp8: kernel vs emulation {e:.2e}; fp8 vs bf16 emulation rms {rms:.2e}")
+    assert 1e-5 < rms < 4e-2          # (and not the bf16 kernels under another name)
+
+
+
 FP8_CASES = [      # B, N, m, dq, d, h
     (3, 200, 16, 128, 128, 4),
     (2, 77, 16, 2, 128, 4),           # layer 1: only fc_o is a d x d projection
     (2, 300, 32, 256, 256, 8),
+    (2, 77, 32, 3, 256, 8),           # layer 1 at d = 256: single-launch kernel, fc_o in fp8
 ]
 
 
