@@ -72,6 +72,11 @@ int attn1_bwd256_fused(const __bf16* dY, const uint32_t* mask, const __bf16* WoT
                        const __bf16* KpP, const __bf16* VpP, const __bf16* Kt, __bf16* dZ,
                        __bf16* dQp, float* dKpPart, float* dVpPart, float* dKp, float* dVp, int B,
                        int N, hipStream_t st);
+// d128_fused.hip: the same single-launch forward at d = 128 / 4 heads / m = 16
+int isab1_fwd128_fused(const void* X, int dq, const __bf16* WqB, const float* WqF, const float* bq,
+                       const __bf16* KpP, const __bf16* Vt, const __bf16* WoP, const float* bo,
+                       __bf16* Y, __bf16* QpS, __bf16* OS, uint32_t* mask, int B, int N,
+                       hipStream_t st);
 size_t wgrad_small256_ws_bytes(int64_t M);
 int wgrad_small256(const __bf16* G, const float* X, int64_t M, int dq, float* dW, float* db,
                    void* ws, hipStream_t st);

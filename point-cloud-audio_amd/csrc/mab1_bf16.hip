@@ -930,6 +930,16 @@ int mab1_bf16_fwd_ex(const pca_mab_shape& s, const void* X, const float* H,
                : launch_fwd<128, 16, false, false, 0, 2>(a, st);
   }
   if (s.nk == 16) {
+    // PCA_D128_FUSED=0: the LDS-resident-weight kernel (k_mab1_fwd) instead of the wave = head one
+    static const bool fused128 = [] {
+      const char* e = getenv("PCA_D128_FUSED");
+      return !(e != nullptr && e[0] == '0');
+    }();
+    // (d -> d blocks only: at layer 1 - two or three input columns, no X tile to stream - the
+    //  wave = head kernel measured 17.6 us against 17.0)
+    if (abf && fused128 && !small)
+      return isab1_fwd128_fused(X, s.dq, WqB, p.wq, p.bq, v.KpP, v.Vt, WoP, p.bo,
+                                reinterpret_cast<__bf16*>(Y), a.QpS, a.OS, a.mask, s.B, s.nq, st);
     if (abf) return small ? launch_fwd<128, 16, true, true>(a, st)
                           : launch_fwd<128, 16, false, true>(a, st);
     return small ? launch_fwd<128, 16, true, false>(a, st)
