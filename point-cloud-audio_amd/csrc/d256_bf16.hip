@@ -710,8 +710,16 @@ struct Attn1Bwd3Args {
   const __bf16* WoT;        // [256][256] bf16: row = column c of Wo, col = feature f (Wo[f][c])
   __bf16* dZ;               // [B*N][D]
   int tiles128;             // 128-point tiles per set (mask pitch)
+  // SMALLQ (layer 1, dq <= 4): Qp is recomputed from the points - nothing was saved
+  const float* Xs;          // [B*N][dq] fp32
+  const float* WqF;         // [256][dq] fp32
+  const float* bq;
+  int dq;
 };
-template <int D>
+// SMALLQ: layer 1 (two or three input columns).  The projected queries are not read back (the
+// forward does not save them: one [B*N, 256] tensor less written and one less read) but recomputed
+// from the tile's points with the forward's own expression, so the bf16 values are the same.
+template <int D, bool SMALLQ>
 __global__ __launch_bounds__(64 * (D / 32), 2) void k_attn1_bwd3(const Attn1Bwd3Args aa) {
   const Attn1BwdArgs& a = aa.base;
   constexpr int MI = 32, ROWB = D * 2, TILEB = 32 * ROWB, KS = D / 32;
@@ -723,6 +731,9 @@ __global__ __launch_bounds__(64 * (D / 32), 2) void k_attn1_bwd3(const Attn1Bwd3
   char* sZ = smem + 3 * TILEB;            // dZ tile
   char* sOut = smem + 4 * TILEB;          // dQp tile
   uint32_t* sMaskb = reinterpret_cast<uint32_t*>(smem + 5 * TILEB);      // [2][256 words]
+  // SMALLQ: the tile's points [32][dq] fp32 arrive by LDS-DMA too (in the unused Qp tile buffers):
+  // ordinary global loads inside the loop make hipcc drain the DMA queue at their first use
+  float* sPts = reinterpret_cast<float*>(sQb);                           // [2][128 floats]
   const int tid = threadIdx.x, lane = tid & 63;
   const int j = __builtin_amdgcn_readfirstlane(tid >> 6);      // head of this wave
   const int r = lane & 15, g = lane >> 4;
@@ -747,6 +758,21 @@ __global__ __launch_bounds__(64 * (D / 32), 2) void k_attn1_bwd3(const Attn1Bwd3
     vpa[kt] = *reinterpret_cast<const bf16x8*>(a.VpP + o);
     kta[kt] = *reinterpret_cast<const bf16x8*>(a.Kt + ((int64_t)b * D + 32 * j + 16 * kt + r) * MI +
                                                8 * g);
+  }
+  float wqs[SMALLQ ? 2 : 1][4][4];
+  f32x4 bqv[2] = {f32x4{0.f, 0.f, 0.f, 0.f}, f32x4{0.f, 0.f, 0.f, 0.f}};
+  if (SMALLQ) {
+#pragma unroll
+    for (int t = 0; t < 2; ++t) {
+      const float4 b4 = *reinterpret_cast<const float4*>(aa.bq + 32 * j + 16 * t + 4 * g);
+      bqv[t] = f32x4{b4.x, b4.y, b4.z, b4.w};
+#pragma unroll
+      for (int e = 0; e < 4; ++e)
+#pragma unroll
+        for (int c = 0; c < 4; ++c)
+          wqs[SMALLQ ? t : 0][e][c] =
+              c < aa.dq ? aa.WqF[(32 * j + 16 * t + 4 * g + e) * aa.dq + c] : 0.f;
+    }
   }
   f32x4 dkp[2][2], dvp[2][2];
 #pragma unroll
@@ -791,7 +817,22 @@ __global__ __launch_bounds__(64 * (D / 32), 2) void k_attn1_bwd3(const Attn1Bwd3
   };
   // Qp tile k and (wave 0) the tile's 256 mask words: 1 KiB contiguous in the forward's layout
   auto dma_q = [&](int k) {
-    dma_tile(a.QpS, k, sQb + (k & 1) * TILEB);
+    if (!SMALLQ) dma_tile(a.QpS, k, sQb + (k & 1) * TILEB);
+    if (SMALLQ && (j == 1 || j == 2)) {
+      // floats [64 (j - 1), 64 j) of the tile's 32 * dq (<= 128) values; past the end of the tensor:
+      // its last element (such points are masked out below)
+      const int64_t first = ((int64_t)b * a.N + n_lo + 32 * k) * aa.dq;
+      const int64_t last = (int64_t)a.B * a.N * aa.dq - 1;
+      int64_t i = first + 64 * (j - 1) + lane;
+      i = i < last ? i : last;
+      const unsigned ldst = __builtin_amdgcn_readfirstlane(
+          (unsigned)(uintptr_t)(lds_void_t*)(sPts + (k & 1) * 128 + 64 * (j - 1)));
+      unsigned keep;
+      const float* src = aa.Xs + i;
+      asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %2\n\ts_nop 0\n\t"
+                   "global_load_lds_dword %1, off\n\ts_mov_b32 m0, %0"
+                   : "=&s"(keep) : "v"(src), "s"(ldst) : "memory");
+    }
     if (j == 0) {
       const int tile32 = (n_lo >> 5) + k;
       const uint32_t* m = aa.mask + (((int64_t)b * aa.tiles128 * 8 + 2 * tile32) * 2) * 64;
@@ -802,11 +843,13 @@ __global__ __launch_bounds__(64 * (D / 32), 2) void k_attn1_bwd3(const Attn1Bwd3
     dma_q(0);
     dma_tile(aa.dY, 0, sY);
   }
-  const int nq = j == 0 ? 3 : 2;          // DMA instructions of dma_q in this wave
+  // DMA instructions of dma_q in this wave
+  const int nq = (SMALLQ ? ((j == 1 || j == 2) ? 1 : 0) : 2) + (j == 0 ? 1 : 0);
   for (int k = 0; k < T; ++k) {
     const int par = k & 1, n0 = n_lo + 32 * k, nlive = n_hi - n0;
     const char* sQ = sQb + par * TILEB;
     const uint32_t* sMask = sMaskb + par * 256;
+    float xv[2][4];
     // Qp / mask of tile k + 1 start now (their buffers were last read in iteration k - 1); what must
     // have landed is this tile's dY (issued after barrier B1 of iteration k - 1) and everything older:
     // younger are only the 4 stores of tile k - 1 (always a full tile) and the DMA just issued
@@ -818,6 +861,8 @@ __global__ __launch_bounds__(64 * (D / 32), 2) void k_attn1_bwd3(const Attn1Bwd3
       }
       switch (younger) {
         case 0: asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); break;
+        case 1: asm volatile("s_waitcnt vmcnt(1)" ::: "memory"); break;
+        case 5: asm volatile("s_waitcnt vmcnt(5)" ::: "memory"); break;
         case 2: asm volatile("s_waitcnt vmcnt(2)" ::: "memory"); break;
         case 3: asm volatile("s_waitcnt vmcnt(3)" ::: "memory"); break;
         case 4: asm volatile("s_waitcnt vmcnt(4)" ::: "memory"); break;
@@ -826,6 +871,13 @@ __global__ __launch_bounds__(64 * (D / 32), 2) void k_attn1_bwd3(const Attn1Bwd3
       }
     }
     lds_barrier();                       // B0: dY, Qp, mask of tile k; tile k - 1 fully stored from LDS
+    if (SMALLQ) {                        // this lane's points (row r of block nb)
+#pragma unroll
+      for (int nb = 0; nb < 2; ++nb)
+#pragma unroll
+        for (int c = 0; c < 4; ++c)
+          xv[nb][c] = c < aa.dq ? sPts[par * 128 + (16 * nb + r) * aa.dq + (c < aa.dq ? c : 0)] : 0.f;
+    }
     // ---- phase A: own slice of dZ = dY . [Z > 0]; the dY slice stays as the residual ----
     bf16x4 res[2][2];
 #pragma unroll
@@ -868,8 +920,22 @@ __global__ __launch_bounds__(64 * (D / 32), 2) void k_attn1_bwd3(const Attn1Bwd3
 #pragma unroll
     for (int nb = 0; nb < 2; ++nb) {
       const bool live = 16 * nb + r < nlive;
-      const bf16x4 qlo = *reinterpret_cast<const bf16x4*>(sQ + oD[0] + 8192 * nb);
-      const bf16x4 qhi = *reinterpret_cast<const bf16x4*>(sQ + oD[1] + 8192 * nb);
+      bf16x4 qlo, qhi;
+      if (SMALLQ) {                        // the forward's expression (k_isab1_fwd256<true>)
+        f32x4 q[2];
+#pragma unroll
+        for (int t = 0; t < 2; ++t)
+#pragma unroll
+          for (int e = 0; e < 4; ++e)
+            q[t][e] = bqv[t][e] + wqs[SMALLQ ? t : 0][e][0] * xv[nb][0] +
+                      wqs[SMALLQ ? t : 0][e][1] * xv[nb][1] + wqs[SMALLQ ? t : 0][e][2] * xv[nb][2] +
+                      wqs[SMALLQ ? t : 0][e][3] * xv[nb][3];
+        qlo = pack4(q[0]);
+        qhi = pack4(q[1]);
+      } else {
+        qlo = *reinterpret_cast<const bf16x4*>(sQ + oD[0] + 8192 * nb);
+        qhi = *reinterpret_cast<const bf16x4*>(sQ + oD[1] + 8192 * nb);
+      }
       const bf16x4 o0 = pack4(acc[0][nb]), o1 = pack4(acc[1][nb]);     // dO, bf16 as before
       const bf16x8 qb = cat8(qlo, qhi), dob = cat8(o0, o1);
       f32x4 dq0 = tof(o0), dq1 = tof(o1);                 // dQp starts as dO (residual Q_)
@@ -2239,7 +2305,8 @@ int attn1_bwd256(const __bf16* dO, const __bf16* QpS, const __bf16* KpP, const _
 int attn1_bwd256_fused(const __bf16* dY, const uint32_t* mask, const __bf16* WoT, const __bf16* QpS,
                        const __bf16* KpP, const __bf16* VpP, const __bf16* Kt, __bf16* dZ,
                        __bf16* dQp, float* dKpPart, float* dVpPart, float* dKp, float* dVp, int B,
-                       int N, hipStream_t st) {
+                       int N, hipStream_t st, const float* Xs, const float* WqF, const float* bq,
+                       int dq) {
   constexpr int D = 256;
   int parts = attn1_bwd256_parts(B, N);
   if (B * parts > 256 && parts > 1) parts /= 2;            // 155 KiB of LDS: one workgroup per CU
@@ -2249,13 +2316,20 @@ int attn1_bwd256_fused(const __bf16* dY, const uint32_t* mask, const __bf16* WoT
                         1.0f / sqrtf((float)D), 1.4426950408889634f / sqrtf((float)D)};
   a.dY = dY; a.mask = mask; a.WoT = WoT; a.dZ = dZ;
   a.tiles128 = (int)cdiv(N, 128);
+  a.Xs = Xs; a.WqF = WqF; a.bq = bq; a.dq = dq;
+  const bool smallq = QpS == nullptr;
+  PCA_REQUIRE(!smallq || (Xs && WqF && bq && dq >= 1 && dq <= 4),
+              "attn1_bwd256_fused: no saved Qp and no points to recompute it from");
   static std::once_flag once;
   std::call_once(once, [] {
-    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(k_attn1_bwd3<D>),
+    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(k_attn1_bwd3<D, false>),
+                              hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(k_attn1_bwd3<D, true>),
                               hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
   });
-  hipLaunchKernelGGL((k_attn1_bwd3<D>), dim3(B * parts), dim3(512),
-                     (size_t)5 * 32 * D * 2 + 2048 + (size_t)8 * 4 * 32 * 72, st, a);
+  const size_t lds = (size_t)5 * 32 * D * 2 + 2048 + (size_t)8 * 4 * 32 * 72;
+  if (smallq) hipLaunchKernelGGL((k_attn1_bwd3<D, true>), dim3(B * parts), dim3(512), lds, st, a);
+  else hipLaunchKernelGGL((k_attn1_bwd3<D, false>), dim3(B * parts), dim3(512), lds, st, a);
   PCA_TRY(check_launch("k_attn1_bwd3"));
   hipLaunchKernelGGL(k_sum_parts256, dim3((unsigned)cdiv((int64_t)B * 32 * D, 256)), dim3(256), 0,
                      st, dKpPart, dVpPart, dKp, dVp, B, parts, 32 * D);

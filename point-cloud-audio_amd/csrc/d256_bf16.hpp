@@ -71,7 +71,8 @@ int rowstream256_dx1(const __bf16* dQp, const __bf16* WqT, __bf16* dX, int B, in
 int attn1_bwd256_fused(const __bf16* dY, const uint32_t* mask, const __bf16* WoT, const __bf16* QpS,
                        const __bf16* KpP, const __bf16* VpP, const __bf16* Kt, __bf16* dZ,
                        __bf16* dQp, float* dKpPart, float* dVpPart, float* dKp, float* dVp, int B,
-                       int N, hipStream_t st);
+                       int N, hipStream_t st, const float* Xs = nullptr,
+                       const float* WqF = nullptr, const float* bq = nullptr, int dq = 0);
 // d128_fused.hip: the same single-launch forward at d = 128 / 4 heads / m = 16
 int isab1_fwd128_fused(const void* X, int dq, const __bf16* WqB, const float* WqF, const float* bq,
                        const __bf16* KpP, const __bf16* Vt, const __bf16* WoP, const float* bo,

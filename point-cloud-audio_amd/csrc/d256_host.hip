@@ -108,8 +108,10 @@ int mab1_d256_bwd(const pca_mab_shape& s, const void* X, const float* Hk, const 
                                     (want_dx ? 2.0 * D : 0.0));
   ProfScope ps(PCA_K_MAB1_BWD, st, flops, bytes);
   if (fuse_o) {
-    PCA_TRY(attn1_bwd256_fused(dYb, v.mask, w.WoTP, v.QpS, v.KpP, v.VpP, v.Kt, w.dZ, w.dQp,
-                               w.dKpPart, w.dVpPart, w.dKp, w.dVp, s.B, s.nq, st));
+    // layer 1 (dq <= 4): Qp is recomputed from the points (mab1_saves_qp() == false: not saved)
+    PCA_TRY(attn1_bwd256_fused(dYb, v.mask, w.WoTP, mab1_saves_qp(s) ? v.QpS : nullptr, v.KpP,
+                               v.VpP, v.Kt, w.dZ, w.dQp, w.dKpPart, w.dVpPart, w.dKp, w.dVp, s.B,
+                               s.nq, st, reinterpret_cast<const float*>(X), p.wq, p.bq, s.dq));
   } else {
     PCA_TRY(rowgemm256_bwd_o(dYb, v.mask, w.WoTP, w.dZ, w.dO, s.B, s.nq, st));
     PCA_TRY(attn1_bwd256(w.dO, v.QpS, v.KpP, v.VpP, v.Kt, w.dQp, w.dKpPart, w.dVpPart, w.dKp,

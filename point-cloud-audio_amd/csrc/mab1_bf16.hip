@@ -794,6 +794,19 @@ static bool fused256_on() {
   return on;
 }
 
+// Does the training forward save the projected queries?  Not at layer 1 (two or three input
+// columns): there the backward recomputes them from the points - k_mab1_bwd<.., FUSE_WQ> at d = 128,
+// k_attn1_bwd3<256, SMALLQ> at d = 256 with bf16 activations (the fc_o-fused backward).
+bool mab1_saves_qp(const pca_mab_shape& s) {
+  if (s.dq > 4) return true;
+  if (s.nk == 16 && s.dq <= 3) return false;
+  static const bool fuse_o = [] { const char* e = getenv("PCA_BWD_O_FUSED"); return !(e && e[0] == '0'); }();
+  // PCA_L1_SAVE_QP=1: save them at d = 256 as well (A/B measurements)
+  static const bool save256 = [] { const char* e = getenv("PCA_L1_SAVE_QP"); return e && e[0] == '1'; }();
+  if (s.d == 256 && s.nk == 32 && fuse_o && !save256) return false;
+  return true;
+}
+
 bool mab1_bf16_supported(const pca_mab_shape& s, bool inference) {
   // activations: fp32 everywhere, or bf16 for Y (and for X when it is a hidden tensor)
   const bool dt_ok = s.k_dtype == PCA_F32 &&
@@ -914,7 +927,7 @@ int mab1_bf16_fwd_ex(const pca_mab_shape& s, const void* X, const float* H,
   a.bo = p.bo; a.Y = Y;
   a.inv_scale = f8 ? invs : nullptr;
   // layer 1 (dq <= 3, m = 16): the backward recomputes Qp from the points - nothing to save
-  a.QpS = (training && !(small && s.nk == 16 && s.dq <= 3)) ? v.QpS : nullptr;
+  a.QpS = (training && mab1_saves_qp(s)) ? v.QpS : nullptr;
   a.OS = training ? v.OS : nullptr;
   a.mask = training ? v.mask : nullptr;
   a.B = s.B; a.N = s.nq; a.dq = s.dq;

@@ -189,6 +189,7 @@ int mid_bwd_launch(const MidBwdLaunch& L, hipStream_t st);
 
 // fp32 weight [rows][cols] -> bf16 image; mode 0 natural, 1 K-permuted, 2 transposed +
 // K-permuted ([cols][rows]), 3 transposed natural
+bool mab1_saves_qp(const pca_mab_shape& s);
 int prep_weight2(const float* src0, __bf16* dst0, int mode0, const float* src1, __bf16* dst1,
                  int mode1, int rows, int cols, hipStream_t st);
 int prep_weight(const float* src, __bf16* dst, int rows, int cols, int mode, hipStream_t st);
