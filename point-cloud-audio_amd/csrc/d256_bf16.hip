@@ -1228,6 +1228,43 @@ __global__ __launch_bounds__(256) void k_wgrad256_sum(const Wgrad256Jobs jobs, i
   }
 }
 
+// out[i] (+)= sum_s slabs[s][i], i < n (n % 4 == 0, 16-byte aligned): the fixed-order replacement of
+// fp32 atomics wherever workgroups reduce into one small tensor (same walk as k_wgrad256_sum: four
+// lane groups take every fourth slab, eight 16-byte loads in flight, then a fixed-order merge)
+__global__ __launch_bounds__(256) void k_slab_sum(const float* __restrict__ slabs, int S, int n,
+                                                 float* __restrict__ out, int accumulate) {
+  __shared__ float4 red[4][64];
+  const int sg = threadIdx.x >> 6, c = threadIdx.x & 63;
+  const int i = blockIdx.x * 256 + 4 * c;
+  float4 t = {0.f, 0.f, 0.f, 0.f};
+  if (i < n) {
+    const float* s = slabs + i;
+    int w = sg;
+    for (; w + 28 < S; w += 32) {
+      float4 v[8];
+#pragma unroll
+      for (int u = 0; u < 8; ++u) v[u] = *reinterpret_cast<const float4*>(s + (int64_t)(w + 4 * u) * n);
+#pragma unroll
+      for (int u = 0; u < 8; ++u) { t.x += v[u].x; t.y += v[u].y; t.z += v[u].z; t.w += v[u].w; }
+    }
+    for (; w < S; w += 4) {
+      const float4 v = *reinterpret_cast<const float4*>(s + (int64_t)w * n);
+      t.x += v.x; t.y += v.y; t.z += v.z; t.w += v.w;
+    }
+  }
+  red[sg][c] = t;
+  __syncthreads();
+  if (sg == 0 && i < n) {
+    float4 o = accumulate ? *reinterpret_cast<float4*>(out + i) : float4{0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+    for (int q = 0; q < 4; ++q) {
+      const float4 v = red[q][c];
+      o.x += v.x; o.y += v.y; o.z += v.z; o.w += v.w;
+    }
+    *reinterpret_cast<float4*>(out + i) = o;
+  }
+}
+
 // =====================================================================================
 // few-queries attention (ISAB mab0 at dk = 256) over projected keys: wave = head, head dim 32
 // =====================================================================================
@@ -1832,8 +1869,7 @@ __global__ __launch_bounds__(256) void k_epi_small_bwd(const float* __restrict__
 __global__ __launch_bounds__(256) void k_epi_small_wv(const float* __restrict__ dO,
                                                       const float* __restrict__ T, int B, int m,
                                                       int dk, int rows_per_wg,
-                                                      float* __restrict__ dWv,
-                                                      float* __restrict__ dbv) {
+                                                      float* __restrict__ slabs) {
   constexpr int D = 256;
   const int f = threadIdx.x, j = f / 32, R = (D / 32) * m;
   const int64_t M = (int64_t)B * m;
@@ -1858,8 +1894,11 @@ __global__ __launch_bounds__(256) void k_epi_small_wv(const float* __restrict__ 
       for (int c = 0; c < 4; ++c) acc[c] = fmaf(gv[u], tv[u][c], acc[c]);
     }
   }
-  for (int c = 0; c < dk; ++c) atomicAdd(&dWv[f * dk + c], acc[c]);
-  atomicAdd(&dbv[f], bs);
+  // (no atomics: a slab [workgroup][256][5] in the format of k_wgrad_small256, summed in order)
+  float* slab = slabs + (int64_t)blockIdx.x * D * 5;
+#pragma unroll
+  for (int c = 0; c < 4; ++c) slab[f * 5 + c] = acc[c];
+  slab[f * 5 + 4] = bs;
 }
 
 
@@ -1877,7 +1916,7 @@ struct PmaArgs {
   const __bf16* TG;            // [B][256][32]: k-slot 8 g + j = j < 4 ? dT[4g+j][c] : G'[4g+j-4][c]
   const float *LSEp, *Delta;   // [B][16]
   __bf16* dX;                  // [B*N][256] or null
-  float* DG;                   // [16][256], accumulated over sets
+  float* DG;                   // backward: slabs [B][S][16][256] of per-workgroup sums
   int B, N, R, S, accumulate_dx;
   const int32_t* lengths;
 };
@@ -2216,8 +2255,10 @@ __global__ __launch_bounds__(256, 1) void k_pma_bwd256(const PmaArgs a) {
     for (int e = 0; e < 4; ++e) slab[(4 * g + e) * DK + 16 * ft + r] = dG[ft][e];
   __syncthreads();
   const float* s0 = reinterpret_cast<const float*>(sX);
-  for (int i = tid; i < a.R * DK; i += 256)
-    atomicAdd(&a.DG[i], s0[i] + s0[16 * DK + i] + s0[2 * 16 * DK + i] + s0[3 * 16 * DK + i]);
+  // (no atomics: one [16][256] slab per workgroup, k_slab_sum adds them in a fixed order)
+  float* out = a.DG + ((int64_t)b * a.S + sp) * 16 * DK;
+  for (int i = tid; i < 16 * DK; i += 256)
+    out[i] = s0[i] + s0[16 * DK + i] + s0[2 * 16 * DK + i] + s0[3 * 16 * DK + i];
 }
 
 }  // namespace
@@ -2472,16 +2513,33 @@ int epi_small_fwd256(const float* T, const float* Qp, const float* Wv, const flo
                      st, T, Qp, Wv, bv, B, m, 256, dk, O);
   return check_launch("k_epi_small_fwd");
 }
+size_t epi_small_bwd256_ws_bytes(int B, int m) {
+  return align256((size_t)cdiv((int64_t)B * m, 16) * 256 * 5 * sizeof(float));
+}
 int epi_small_bwd256(const float* dO, const float* T, const float* Wv, int B, int m, int dk,
-                     float* dT, float* Delta, float* dWv, float* dbv, hipStream_t st) {
+                     float* dT, float* Delta, float* dWv, float* dbv, void* ws, hipStream_t st) {
   hipLaunchKernelGGL(k_epi_small_bwd, dim3((unsigned)cdiv((int64_t)B * 8 * m, 256)), dim3(256), 0,
                      st, dO, T, Wv, B, m, 256, dk, dT, Delta);
   PCA_TRY(check_launch("k_epi_small_bwd"));
-  hipLaunchKernelGGL(k_epi_small_wv, dim3((unsigned)cdiv((int64_t)B * m, 16)), dim3(256), 0, st, dO,
-                     T, B, m, dk, 16, dWv, dbv);
-  return check_launch("k_epi_small_wv");
+  const int nwg = (int)cdiv((int64_t)B * m, 16);
+  float* slabs = reinterpret_cast<float*>(ws);
+  hipLaunchKernelGGL(k_epi_small_wv, dim3((unsigned)nwg), dim3(256), 0, st, dO, T, B, m, dk, 16, slabs);
+  PCA_TRY(check_launch("k_epi_small_wv"));
+  hipLaunchKernelGGL(k_wgrad_small256_sum, dim3(256 * 5 / 64), dim3(1024), 0, st, slabs, nwg, dk, dWv,
+                     dbv);
+  return check_launch("k_wgrad_small256_sum");
 }
 
+size_t pma_bwd256_slab_bytes(int B) {
+  return align256((size_t)(B > 256 ? B : 256) * 16 * 256 * sizeof(float));
+}
+int slab_sum(const float* slabs, int S, int n, float* out, int accumulate, hipStream_t st) {
+  PCA_REQUIRE(n % 4 == 0 && ((uintptr_t)out & 15) == 0 && ((uintptr_t)slabs & 15) == 0,
+              "slab_sum: alignment");
+  hipLaunchKernelGGL(k_slab_sum, dim3((unsigned)cdiv(n, 256)), dim3(256), 0, st, slabs, S, n, out,
+                     accumulate);
+  return check_launch("k_slab_sum");
+}
 int pma_splits256(int B, int N) {
   int S = 1;
   const int tiles = (int)cdiv(N, 128);
@@ -2517,10 +2575,10 @@ int pma_epi_bwd256(const float* dO, const float* T, const float* LSE, const floa
 int pma_attn_bwd256(const __bf16* X, const __bf16* Gb, const __bf16* dTb, const __bf16* TG,
                     const float* LSEp, const float* Delta, int B, int N, int R,
                     const int32_t* lengths, __bf16* dX, int accumulate_dx, float* DG,
-                    hipStream_t st) {
+                    float* DGslabs, hipStream_t st) {
   PmaArgs a{};
   a.X = X; a.Gb = Gb; a.dTb = dTb; a.TG = TG; a.LSEp = LSEp; a.Delta = Delta;
-  a.dX = dX; a.DG = DG; a.accumulate_dx = accumulate_dx;
+  a.dX = dX; a.DG = DGslabs; a.accumulate_dx = accumulate_dx;
   a.B = B; a.N = N; a.R = R; a.lengths = lengths;
   int S = pma_splits256(B, N);
   while (S > 1 && B * S > 256) S /= 2;            // ~100 KiB of LDS: one workgroup per CU
@@ -2532,7 +2590,9 @@ int pma_attn_bwd256(const __bf16* X, const __bf16* Gb, const __bf16* dTb, const 
   });
   const size_t lds = 4 * 32 * 256 * 2 + 256 * 64 + 4 * 32 * 40 + 32 * sizeof(float);
   hipLaunchKernelGGL(k_pma_bwd256, dim3(B, S), dim3(256), lds, st, a);
-  return check_launch("k_pma_bwd256");
+  PCA_TRY(check_launch("k_pma_bwd256"));
+  hipLaunchKernelGGL(k_slab_sum, dim3(16), dim3(256), 0, st, DGslabs, B * S, 16 * 256, DG, 0);
+  return check_launch("k_slab_sum");
 }
 
 }  // namespace pca

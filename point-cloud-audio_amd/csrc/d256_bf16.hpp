@@ -83,8 +83,9 @@ int wgrad_small256(const __bf16* G, const float* X, int64_t M, int dq, float* dW
                    void* ws, hipStream_t st);
 int epi_small_fwd256(const float* T, const float* Qp, const float* Wv, const float* bv, int B, int m,
                      int dk, float* O, hipStream_t st);
+size_t epi_small_bwd256_ws_bytes(int B, int m);
 int epi_small_bwd256(const float* dO, const float* T, const float* Wv, int B, int m, int dk,
-                     float* dT, float* Delta, float* dWv, float* dbv, hipStream_t st);
+                     float* dT, float* Delta, float* dWv, float* dbv, void* ws, hipStream_t st);
 
 // PMA (R = h*m <= 16 score rows) at dk = 256, reassociated: X read once, keys never projected
 int pma_splits256(int B, int N);
@@ -100,8 +101,10 @@ int pma_epi_bwd256(const float* dO, const float* T, const float* LSE, const floa
 // dX (+)= P^T dT + dS^T G' ; DG [16][256] += dS X (ln2 units, as k_mab0_bwd; caller zeroes it)
 int pma_attn_bwd256(const __bf16* X, const __bf16* Gb, const __bf16* dTb, const __bf16* TG,
                     const float* LSEp, const float* Delta, int B, int N, int R,
-                    const int32_t* lengths, __bf16* dX, int accumulate_dx, float* DG,
+                    const int32_t* lengths, __bf16* dX, int accumulate_dx, float* DG, float* DGslabs,
                     hipStream_t st);
+size_t pma_bwd256_slab_bytes(int B);
+int slab_sum(const float* slabs, int S, int n, float* out, int accumulate, hipStream_t st);
 
 // few shared queries (m <= 32) over projected keys, head dim 32
 int fq_splits256(int B, int N);

@@ -296,6 +296,7 @@ struct Fq256BwdWs {
   __bf16 *WkTP, *WvTP, *dKp, *dVp, *dXb, *dTb, *TG;
   float* LSEp;
   float *dZ, *dO, *dOt, *Delta, *dQpPart, *dTf, *DG, *dQp;
+  float* slabs;      // per-workgroup partial sums of the reductions that used fp32 atomics
   void* wg;
 };
 static size_t fq_carve_bwd(const pca_mab_shape& s, Fq256BwdWs* out, void* base) {
@@ -315,6 +316,7 @@ static size_t fq_carve_bwd(const pca_mab_shape& s, Fq256BwdWs* out, void* base) 
     w.dTb = c.take<__bf16>((size_t)s.B * 16 * D);
     w.TG = c.take<__bf16>((size_t)s.B * D * 32);
     w.DG = c.take<float>((size_t)16 * D);
+    w.slabs = reinterpret_cast<float*>(c.take<char>(pma_bwd256_slab_bytes(s.B)));
   } else if (s.dk == D) {
     const int MQ = m > 16 ? 32 : 16, S = fq_splits256(s.B, s.nk);
     w.WkTP = c.take<__bf16>((size_t)D * D);
@@ -325,10 +327,13 @@ static size_t fq_carve_bwd(const pca_mab_shape& s, Fq256BwdWs* out, void* base) 
     w.Delta = c.take<float>((size_t)s.B * H8 * MQ);
     w.dQpPart = c.take<float>((size_t)s.B * S * m * D);
     w.wg = c.take<char>(wgrad256_ws_bytes(2, (int64_t)s.B * s.nk));
+    w.slabs = c.take<float>((size_t)cdiv((int64_t)Bm, 512) * D);          // column-sum partials
   } else {
     w.Delta = c.take<float>((size_t)s.B * R);
     w.dTf = c.take<float>((size_t)s.B * R * s.dk);
     w.DG = c.take<float>((size_t)R * s.dk);
+    const size_t a = epi_small_bwd256_ws_bytes(s.B, m), b = (size_t)s.B * R * s.dk * sizeof(float);
+    w.slabs = reinterpret_cast<float*>(c.take<char>(a > b ? a : b));     // (used one after the other)
   }
   if (out) *out = w;
   return c.off;
@@ -365,7 +370,6 @@ int mab0_d256_bwd(const pca_mab_shape& s, const float* I, const void* X, const p
   pj.m = m; pj.d = D; pj.dk = s.dk; pj.dq = s.dq; pj.h = s.h; pj.sl2e = sl2e; pj.B = s.B;
   if (fq_path(s) == FQ_PMA) {
     const __bf16* Xb = s.k_dtype == PCA_F32 ? v.Xb : reinterpret_cast<const __bf16*>(X);
-    PCA_TRY(fill_zero(w.DG, (int64_t)16 * D, st));
     PCA_TRY(pma_epi_bwd256(w.dO, v.T, v.LSE, p.wv, v.Gf, s.B, m, R, w.dTb, w.TG, w.Delta, w.LSEp,
                            gr.wv, st));
     PCA_TRY(colsum(w.dO, Bm, D, gr.bv, 1, st));
@@ -376,7 +380,7 @@ int mab0_d256_bwd(const pca_mab_shape& s, const float* I, const void* X, const p
       ProfScope ps(PCA_K_MAB0_BWD, st, 4.0 * pts * (2.0 * D * D + 2.0 * m * D),
                    pts * 2.0 * D * (1.0 + (dX != nullptr ? (dk_accumulate ? 2.0 : 1.0) : 0.0)));
       PCA_TRY(pma_attn_bwd256(Xb, v.Gb, w.dTb, w.TG, w.LSEp, w.Delta, s.B, s.nk, R, s.k_lengths,
-                              dXb, (!f32 && dk_accumulate) ? 1 : 0, w.DG, st));
+                              dXb, (!f32 && dk_accumulate) ? 1 : 0, w.DG, w.slabs, st));
       ps.end();
     }
     if (dX != nullptr && f32)
@@ -394,7 +398,14 @@ int mab0_d256_bwd(const pca_mab_shape& s, const float* I, const void* X, const p
     }
     // fc_v bias: every row of A sums to one, so colsum(dVp) = sum over sets and queries of dO;
     // fc_k bias: identically zero (softmax shift invariance), left untouched
-    PCA_TRY(colsum(w.dO, Bm, D, gr.bv, 1, st));
+    if (Bm > 256) {                         // (per-block partials + ordered sum, no atomics; <= 256
+                                            //  rows: colsum's one-launch form has none either)
+      int np = 0;
+      PCA_TRY(colsum_parts(w.dO, Bm, D, w.slabs, &np, st));
+      PCA_TRY(slab_sum(w.slabs, np, D, gr.bv, 1, st));
+    } else {
+      PCA_TRY(colsum(w.dO, Bm, D, gr.bv, 1, st));
+    }
     if (dX != nullptr) {
       const bool f32 = s.k_dtype == PCA_F32;
       __bf16* dXb = f32 ? w.dXb : reinterpret_cast<__bf16*>(dX);
@@ -418,10 +429,19 @@ int mab0_d256_bwd(const pca_mab_shape& s, const float* I, const void* X, const p
     pj.DG = nullptr;
     pj.dO = w.dOt;
   } else {
-    PCA_TRY(fill_zero(w.DG, (int64_t)R * s.dk, st));
-    PCA_TRY(epi_small_bwd256(w.dO, v.T, p.wv, s.B, m, s.dk, w.dTf, w.Delta, gr.wv, gr.bv, st));
-    PCA_TRY(mab0_bwd_small_launch(reinterpret_cast<const float*>(X), v.Gf, w.dTf, v.LSE, w.Delta,
-                                  s.B, s.nk, R, R, s.dk, w.DG, s.k_lengths, st));
+    // (both reductions through per-workgroup / per-set partials in w.slabs and a fixed-order sum:
+    //  no fp32 atomics anywhere in the d = 256 step, so it is bit-reproducible run to run)
+    PCA_TRY(epi_small_bwd256(w.dO, v.T, p.wv, s.B, m, s.dk, w.dTf, w.Delta, gr.wv, gr.bv, w.slabs,
+                             st));
+    if ((R * s.dk) % 4 == 0) {
+      PCA_TRY(mab0_bwd_small_launch(reinterpret_cast<const float*>(X), v.Gf, w.dTf, v.LSE, w.Delta,
+                                    s.B, s.nk, R, R, s.dk, w.DG, s.k_lengths, st, w.slabs));
+      PCA_TRY(slab_sum(w.slabs, s.B, R * s.dk, w.DG, 0, st));
+    } else {
+      PCA_TRY(fill_zero(w.DG, (int64_t)R * s.dk, st));
+      PCA_TRY(mab0_bwd_small_launch(reinterpret_cast<const float*>(X), v.Gf, w.dTf, v.LSE, w.Delta,
+                                    s.B, s.nk, R, R, s.dk, w.DG, s.k_lengths, st));
+    }
     pj.DG = w.DG;
     pj.dO = w.dO;
   }

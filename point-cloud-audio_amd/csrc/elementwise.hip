@@ -247,8 +247,11 @@ __global__ __launch_bounds__(256) void k_softmax_bwd_rows_v4(const float* __rest
 
 // out[j..j+3] += sum_i X[i, j..j+3] for cols % 4 == 0: a wave reads 1 KB of a row per
 // instruction (64 lanes x float4), the four waves interleave rows, 8 rows in flight per wave
+// part != nullptr: the row block's sums go to part[blockIdx.x][cols] instead of atomics (the
+// caller adds the blocks in a fixed order)
 __global__ __launch_bounds__(256) void k_colsum_v4(const float* __restrict__ X, int64_t rows,
-                                                    int cols, float* __restrict__ out, int rpb) {
+                                                    int cols, float* __restrict__ out, int rpb,
+                                                    float* __restrict__ part) {
   __shared__ float4 red[4][64];
   const int tx = threadIdx.x & 63, ty = threadIdx.x >> 6;
   const int64_t r0 = (int64_t)blockIdx.x * rpb;
@@ -277,8 +280,12 @@ __global__ __launch_bounds__(256) void k_colsum_v4(const float* __restrict__ X, 
     for (int w = 1; w < 4; ++w) {
       s.x += red[w][tx].x; s.y += red[w][tx].y; s.z += red[w][tx].z; s.w += red[w][tx].w;
     }
-    atomicAdd(&out[j], s.x); atomicAdd(&out[j + 1], s.y);
-    atomicAdd(&out[j + 2], s.z); atomicAdd(&out[j + 3], s.w);
+    if (part != nullptr) {
+      *reinterpret_cast<float4*>(part + (int64_t)blockIdx.x * cols + j) = s;
+    } else {
+      atomicAdd(&out[j], s.x); atomicAdd(&out[j + 1], s.y);
+      atomicAdd(&out[j + 2], s.z); atomicAdd(&out[j + 3], s.w);
+    }
   }
 }
 
@@ -603,13 +610,26 @@ int colsum(const float* X, int64_t rows, int cols, float* out, int accumulate,
   if (cols % 4 == 0 && al16(X) && rows >= 4096) {
     const int rpb4 = 512;
     hipLaunchKernelGGL(k_colsum_v4, dim3((unsigned)cdiv(rows, rpb4), (unsigned)cdiv(cols, 256)),
-                       dim3(256), 0, st, X, rows, cols, out, rpb4);
+                       dim3(256), 0, st, X, rows, cols, out, rpb4, nullptr);
     return check_launch("k_colsum_v4");
   }
   const int rpb = rows * cdiv(cols, 64) < 256 * 512 ? 32 : 256;   // rows per block
   hipLaunchKernelGGL(k_colsum, dim3((unsigned)cdiv(rows, rpb), (unsigned)cdiv(cols, 64)),
                      dim3(256), 0, st, X, rows, cols, out, rpb);
   return check_launch("k_colsum");
+}
+
+// Deterministic column sums of a tall fp32 matrix (cols % 4 == 0, 16-byte aligned rows): per-block
+// partials [cdiv(rows, 512)][cols] into `part`; the caller reduces them (slab_sum, d256_bf16.hip).
+// Returns the number of partials through *nparts.
+int colsum_parts(const float* X, int64_t rows, int cols, float* part, int* nparts, hipStream_t st) {
+  PCA_REQUIRE(X && part && nparts && cols % 4 == 0 && al16(X) && al16(part) && rows > 0,
+              "colsum_parts: bad arguments");
+  const int rpb4 = 512;
+  *nparts = (int)cdiv(rows, rpb4);
+  hipLaunchKernelGGL(k_colsum_v4, dim3((unsigned)*nparts, (unsigned)cdiv(cols, 256)), dim3(256), 0,
+                     st, X, rows, cols, nullptr, rpb4, part);
+  return check_launch("k_colsum_v4");
 }
 
 int add_relu(const float* O, const float* Z, float* Y, int64_t n, hipStream_t st) {

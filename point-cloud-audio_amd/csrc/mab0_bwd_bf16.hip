@@ -310,7 +310,7 @@ __global__ __launch_bounds__(256, 1) void k_mab0_bwd(const Mab0BwdArgs a) {
 __global__ __launch_bounds__(256) void k_mab0_bwd_small(
     const float* __restrict__ X, const float* __restrict__ Gf, const float* __restrict__ dTf,
     const float* __restrict__ LSE, const float* __restrict__ Delta, int N, int R, int Rp, int dk,
-    float* __restrict__ DG, const int32_t* __restrict__ lengths) {
+    float* __restrict__ DG, const int32_t* __restrict__ lengths, float* __restrict__ slabs) {
   constexpr int CH = 2048;
   __shared__ float sD[256][4];
   __shared__ __attribute__((aligned(16))) float sX[CH * 4];
@@ -357,7 +357,9 @@ __global__ __launch_bounds__(256) void k_mab0_bwd_small(
     for (int c = 0; c < dk; ++c) {
       float v = 0.f;
       for (int p = 0; p < parts; ++p) v += sD[p * Rb + tid][c];
-      atomicAdd(&DG[(row0 + tid) * dk + c], v);
+      // slabs != nullptr: per-set partial [b][R][dk] (summed in a fixed order by the caller)
+      if (slabs != nullptr) slabs[((int64_t)b * R + row0 + tid) * dk + c] = v;
+      else atomicAdd(&DG[(row0 + tid) * dk + c], v);
     }
   }
 }
@@ -582,10 +584,10 @@ int mab0_post_launch(const Mab0PostJobs& J, hipStream_t st) {
 
 int mab0_bwd_small_launch(const float* X, const float* Gf, const float* dTf, const float* LSE,
                           const float* Delta, int B, int N, int R, int Rp, int dk, float* DG,
-                          const int32_t* lengths, hipStream_t st) {
+                          const int32_t* lengths, hipStream_t st, float* slabs) {
   PCA_REQUIRE(R == 64 || R == 128 || R == 256, "mab0_bwd_small: %d score rows", R);
   hipLaunchKernelGGL(k_mab0_bwd_small, dim3(B, small_row_split(B, R)), dim3(256), 0, st, X, Gf, dTf,
-                     LSE, Delta, N, R, Rp, dk, DG, lengths);
+                     LSE, Delta, N, R, Rp, dk, DG, lengths, slabs);
   return check_launch("k_mab0_bwd_small");
 }
 
@@ -661,7 +663,7 @@ int mab0_bf16_bwd_ex(const pca_mab_shape& s, const float* I, const void* X,
   if (small) {
     hipLaunchKernelGGL(k_mab0_bwd_small, dim3(s.B, (R % 64 == 0 && R <= 512) ? 2 : 1), dim3(256), 0, st,
                        reinterpret_cast<const float*>(X), v.Gf, w.dTf, v.LSE,
-                       w.Delta, s.nk, R, Rp, dk, w.DG, s.k_lengths);
+                       w.Delta, s.nk, R, Rp, dk, w.DG, s.k_lengths, nullptr);
     PCA_TRY(check_launch("k_mab0_bwd_small"));
   } else {
     int S = mab0_splits(s);

@@ -338,7 +338,7 @@ int mab0_attn_small_launch(const float* X, const float* Gf, int B, int N, int R,
                            float* LSE, const int32_t* lengths, hipStream_t st);
 int mab0_bwd_small_launch(const float* X, const float* Gf, const float* dTf, const float* LSE,
                           const float* Delta, int B, int N, int R, int Rp, int dk, float* DG,
-                          const int32_t* lengths, hipStream_t st);
+                          const int32_t* lengths, hipStream_t st, float* slabs = nullptr);
 // per-block dispatch (api_mab.hip): kind 0 exact fp32, 1 fused mab1, 2 fused mab0
 int mab_kind(const pca_mab_shape& s, bool inference = false);
 size_t mab_saved_bytes_any(const pca_mab_shape& s);

@@ -89,6 +89,7 @@ int layernorm_bwd(const float* dY, const float* X, const float* mean, const floa
                   hipStream_t st);
 int softmax_bwd_rows(const float* A, float* dA, int64_t rows, int n, float scale,
                      hipStream_t st);
+int colsum_parts(const float* X, int64_t rows, int cols, float* part, int* nparts, hipStream_t st);
 int colsum(const float* X, int64_t rows, int cols, float* out, int accumulate,
            hipStream_t st);
 // Y = O + relu(Z)

@@ -88,3 +88,29 @@ def test_cfg4_architecture_large_rows_vs_oracle(dev, mode):
     the large-problem branches of whichever kernels serve this shape, against the ORACLE (not
     against another mode of this library)."""
     _check(dev, 3, 4096, 3, 256, 8, 32, 50, mode, seed=9300)
+
+
+def test_d256_step_is_bit_reproducible(dev):
+    """The d = 256 / 8 heads / m = 32 training step uses no fp32 atomics (weight-gradient slabs,
+    per-workgroup partials + fixed-order sums everywhere): two forward + backward passes over the
+    same batch give bit-identical gradients and loss.  (The d = 128 path still reduces with atomics
+    in k_wgrad128 / k_mab0_bwd: DESIGN.md section 7.)"""
+    import models
+    from pca_hip import _lib, trainer
+    B, N, din, d, h, m, C = 16, 1000, 3, 256, 8, 32, 50
+    torch.manual_seed(4)
+    net = models.ST(dim_input=din, num_outputs=1, dim_output=C, num_inds=m, dim_hidden=d,
+                    num_heads=h).to(dev)
+    X = T(gi.pc_input(5, B, N, din), dev)
+    y = T(gi.labels(6, B, C), dev)
+    eng = trainer.STEngine(net, B, N, _lib.MODE_BF16, training=True)
+    runs = []
+    for _ in range(3):
+        eng.grads.zero_()
+        eng.fwd_bwd(X, y, phase=-1)
+        torch.cuda.synchronize()
+        runs.append((eng.grads.clone(), float(eng.loss)))
+    assert torch.isfinite(runs[0][0]).all()
+    for g, loss in runs[1:]:
+        assert torch.equal(g, runs[0][0])
+        assert loss == runs[0][1]
