@@ -1572,6 +1572,203 @@ __global__ __launch_bounds__(64 * (D / 32)) void k_fq_attn_bwd(const FqArgs a) {
   }
 }
 
+// k_fq_attn_bwd2 (m = 32, d = 256): the same arithmetic with full-line global traffic, as
+// k_attn1_bwd2 is to k_attn1_bwd.  The workgroup streams whole [32 keys][256] tiles of Kp and Vp in
+// by LDS-DMA (double buffered), each wave (= head) reads its 64-byte slices from LDS, writes its
+// slices of the dKp / dVp tiles to LDS, and the two tiles leave in 16-byte pieces of full rows -
+// the per-wave form reads 16 rows x 64 bytes per load instruction and writes 8-byte pieces.
+__global__ __launch_bounds__(512, 2) void k_fq_attn_bwd2(const FqArgs a) {
+  constexpr int D = 256, QT = 2, PV = 72, H = D / 32, MQ = 16 * QT;
+  constexpr int ROWB = D * 2, TILEB = 32 * ROWB;
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  char* sKb = smem;                        // [2][TILEB]
+  char* sVb = smem + 2 * TILEB;            // [2][TILEB]
+  char* sDK = smem + 4 * TILEB;            // dKp tile
+  char* sDV = smem + 5 * TILEB;            // dVp tile
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int j = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int r = lane & 15, g = lane >> 4;
+  const int b = blockIdx.x, sp = blockIdx.y;
+  char* myK = smem + 6 * TILEB + j * 32 * PV;
+  const int per = (int)(((int64_t)(a.N + 31) / 32 + a.S - 1) / a.S) * 32;
+  int len = a.N;
+  if (a.lengths != nullptr) len = a.lengths[b] < a.N ? a.lengths[b] : a.N;
+  const int n_lo = sp * per;
+  const int n_hi = (n_lo + per < a.N) ? n_lo + per : a.N;
+  const int T = n_lo < n_hi ? (n_hi - n_lo + 31) / 32 : 0;
+  bf16x8 qs[QT], dof[QT], qnT[2], doT[2];
+  float lse_c[QT], del_c[QT], lse_r[QT][4], del_r[QT][4];
+#pragma unroll
+  for (int qt = 0; qt < QT; ++qt) {
+    const int q = 16 * qt + r;
+    qs[qt] = q_frag(a.Qp, D, a.m, q, j, g, a.scale_log2e);
+    dof[qt] = q_frag(a.dOa + (int64_t)b * a.m * D, D, a.m, q, j, g, 1.0f);
+    lse_c[qt] = q < a.m ? a.LSE[((int64_t)b * H + j) * MQ + q] : 1.0e30f;
+    del_c[qt] = q < a.m ? a.Delta[((int64_t)b * H + j) * MQ + q] : 0.f;
+#pragma unroll
+    for (int e = 0; e < 4; ++e) {
+      const int qq = 16 * qt + 4 * g + e;
+      lse_r[qt][e] = qq < a.m ? a.LSE[((int64_t)b * H + j) * MQ + qq] : 1.0e30f;
+      del_r[qt][e] = qq < a.m ? a.Delta[((int64_t)b * H + j) * MQ + qq] : 0.f;
+    }
+  }
+#pragma unroll
+  for (int tt = 0; tt < 2; ++tt) {
+    const int f = 32 * j + 16 * tt + r;
+#pragma unroll
+    for (int i = 0; i < 8; ++i) {
+      const int kq = perm32(8 * g + i);
+      const bool ok = kq < a.m;
+      qnT[tt][i] = (__bf16)(ok ? a.Qp[(int64_t)kq * D + f] : 0.f);
+      doT[tt][i] = (__bf16)(ok ? a.dOa[((int64_t)b * a.m + kq) * D + f] : 0.f);
+    }
+  }
+  f32x4 dq[2][QT];
+#pragma unroll
+  for (int tt = 0; tt < 2; ++tt)
+#pragma unroll
+    for (int qt = 0; qt < QT; ++qt) dq[tt][qt] = f32x4{0.f, 0.f, 0.f, 0.f};
+
+  // this lane's pieces of a tile: the head's 16 bytes of row r (natural chunk 4 j + g), its
+  // accumulator-layout 8 bytes (features 32 j + 16 t + 4 g), the coalesced 16-byte piece
+  int oK, oD[2];
+  oK = swz(r, 4 * j + g, ROWB);
+#pragma unroll
+  for (int t = 0; t < 2; ++t) oD[t] = swz(r, 4 * j + 2 * t + (g >> 1), ROWB) + 8 * (g & 1);
+  const int oC = swz(tid >> 5, tid & 31, ROWB);
+  auto lds_barrier = [] {
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+    __builtin_amdgcn_s_barrier();
+    asm volatile("" ::: "memory");
+  };
+  auto dma = [&](int k) {                 // tile k of Kp and Vp (issued from inline asm: k_isab1_fwd256)
+    const int n0 = n_lo + 32 * k, par = k & 1;
+#pragma unroll
+    for (int w = 0; w < 2; ++w) {
+      const __bf16* base = w == 0 ? a.Kp : a.Vp;
+      char* dst = (w == 0 ? sKb : sVb) + par * TILEB;
+#pragma unroll
+      for (int i = 0; i < 2; ++i) {
+        const int p = (2 * j + i) * 64 + lane;
+        const int row = p >> 5, slot = p & 31;
+        const int ch = (slot & ~15) | ((slot ^ row) & 15);
+        const int n = n0 + row < a.N ? n0 + row : a.N - 1;
+        const __bf16* src = base + ((int64_t)b * a.N + n) * D + ch * 8;
+        const unsigned ldst = __builtin_amdgcn_readfirstlane(
+            (unsigned)(uintptr_t)(lds_void_t*)(dst + (2 * j + i) * 1024));
+        unsigned keep;
+        asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %2\n\ts_nop 0\n\t"
+                     "global_load_lds_dwordx4 %1, off\n\ts_mov_b32 m0, %0"
+                     : "=&s"(keep) : "v"(src), "s"(ldst) : "memory");
+      }
+    }
+  };
+  if (T > 0) dma(0);
+  for (int k = 0; k < T; ++k) {
+    const int par = k & 1, n0 = n_lo + 32 * k, nlive = n_hi - n0;
+    const char* sK = sKb + par * TILEB;
+    const char* sV = sVb + par * TILEB;
+    // tile k + 1 starts to stream in; this tile's DMA (one iteration old) must have landed: younger
+    // are the 4 pieces just issued and the 4 stores of tile k - 1 (always a full tile)
+    if (k + 1 < T) {
+      dma(k + 1);
+      if (k == 0) asm volatile("s_waitcnt vmcnt(4)" ::: "memory");
+      else asm volatile("s_waitcnt vmcnt(8)" ::: "memory");
+    } else {
+      asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    }
+    lds_barrier();                       // B0: Kp / Vp tiles complete; previous output tiles stored
+    bf16x8 kr[2], vr[2];
+    bool key_c[2];
+#pragma unroll
+    for (int pb = 0; pb < 2; ++pb) {
+      const int n = n0 + 16 * pb + r;
+      key_c[pb] = n < len;
+      kr[pb] = *reinterpret_cast<const bf16x8*>(sK + oK + 8192 * pb);
+      vr[pb] = *reinterpret_cast<const bf16x8*>(sV + oK + 8192 * pb);
+      if (n >= n_hi) {                     // rows past the range: the DMA fetched a duplicate
+#pragma unroll
+        for (int e = 0; e < 8; ++e) { kr[pb][e] = (__bf16)0.f; vr[pb][e] = (__bf16)0.f; }
+      }
+      bf16x4 lo4, hi4;
+#pragma unroll
+      for (int e = 0; e < 4; ++e) { lo4[e] = kr[pb][e]; hi4[e] = kr[pb][4 + e]; }
+      *reinterpret_cast<bf16x4*>(myK + (16 * pb + r) * PV + 16 * g) = lo4;
+      *reinterpret_cast<bf16x4*>(myK + (16 * pb + r) * PV + 16 * g + 8) = hi4;
+    }
+    bf16x8 kt[2];
+#pragma unroll
+    for (int tt = 0; tt < 2; ++tt) kt[tt] = tr_frag_small(myK, PV, 16 * tt, lane);
+    // ---- orientation A: dQp ----
+#pragma unroll
+    for (int qt = 0; qt < QT; ++qt) {
+      f32x4 ds[2];
+#pragma unroll
+      for (int pb = 0; pb < 2; ++pb) {
+        const f32x4 z = {0.f, 0.f, 0.f, 0.f};
+        const f32x4 sv = mfma32(kr[pb], qs[qt], z);
+        const f32x4 da = mfma32(vr[pb], dof[qt], z);
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+          const bool key = n0 + 16 * pb + 4 * g + e < len;
+          const float p = key ? __builtin_amdgcn_exp2f(sv[e] - lse_c[qt]) : 0.f;
+          ds[pb][e] = p * (da[e] - del_c[qt]) * a.scale;
+        }
+      }
+      const bf16x8 dsb = pack8(ds[0], ds[1]);
+#pragma unroll
+      for (int tt = 0; tt < 2; ++tt) dq[tt][qt] = mfma32(kt[tt], dsb, dq[tt][qt]);
+    }
+    // ---- orientation B: dKp, dVp -> own slices of the output tiles ----
+#pragma unroll
+    for (int pb = 0; pb < 2; ++pb) {
+      f32x4 pq[QT], dsq[QT];
+#pragma unroll
+      for (int qt = 0; qt < QT; ++qt) {
+        const f32x4 z = {0.f, 0.f, 0.f, 0.f};
+        const f32x4 sv = mfma32(qs[qt], kr[pb], z);          // rows q, column pt
+        const f32x4 da = mfma32(dof[qt], vr[pb], z);
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+          const float p = key_c[pb] ? __builtin_amdgcn_exp2f(sv[e] - lse_r[qt][e]) : 0.f;
+          pq[qt][e] = p;
+          dsq[qt][e] = p * (da[e] - del_r[qt][e]) * a.scale;
+        }
+      }
+      const bf16x8 pb8 = pack8(pq[0], pq[1]), ds8 = pack8(dsq[0], dsq[1]);
+#pragma unroll
+      for (int tt = 0; tt < 2; ++tt) {
+        const f32x4 z = {0.f, 0.f, 0.f, 0.f};
+        const f32x4 dv = mfma32(doT[tt], pb8, z);
+        const f32x4 dk = mfma32(qnT[tt], ds8, z);
+        *reinterpret_cast<bf16x4*>(sDV + oD[tt] + 8192 * pb) = pack4(dv);
+        *reinterpret_cast<bf16x4*>(sDK + oD[tt] + 8192 * pb) = pack4(dk);
+      }
+    }
+    lds_barrier();                       // B1: dKp / dVp tiles complete
+#pragma unroll
+    for (int i = 0; i < 2; ++i) {
+      const int c = tid + 512 * i, row = c >> 5, ch = c & 31;
+      if (row < nlive) {
+        const int64_t o = ((int64_t)b * a.N + n0 + row) * D + ch * 8;
+        *reinterpret_cast<uint4*>(a.dKp + o) = *reinterpret_cast<const uint4*>(sDK + oC + 8192 * i);
+        *reinterpret_cast<uint4*>(a.dVp + o) = *reinterpret_cast<const uint4*>(sDV + oC + 8192 * i);
+      }
+    }
+  }
+  const int64_t pb0 = ((int64_t)b * a.S + sp);
+#pragma unroll
+  for (int qt = 0; qt < QT; ++qt) {
+    const int q = 16 * qt + r;
+    if (q < a.m) {
+#pragma unroll
+      for (int tt = 0; tt < 2; ++tt)
+        *reinterpret_cast<float4*>(a.dQpPart + (pb0 * a.m + q) * D + 32 * j + 16 * tt + 4 * g) =
+            float4{dq[tt][qt][0], dq[tt][qt][1], dq[tt][qt][2], dq[tt][qt][3]};
+    }
+  }
+}
+
 // merge of the forward partials + residual: O[b][q][f] = Qp[q][f] + sum_s w_s Op_s / sum_s w_s L_s,
 // LSE[b][h][q] = M + log2 L; Oa (= A Vp, for Delta) is O - Qp
 __global__ __launch_bounds__(256) void k_fq_merge(const float* __restrict__ Op,
@@ -2479,11 +2676,28 @@ int fq_attn_bwd256(const __bf16* Kp, const __bf16* Vp, const float* Qp, const fl
   a.scale = 1.0f / sqrtf((float)D);
   a.scale_log2e = 1.4426950408889634f * a.scale;
   const size_t lds = (size_t)(D / 32) * 32 * 72;
-  if (QT == 2) hipLaunchKernelGGL((k_fq_attn_bwd<D, 2>), dim3(B, S), dim3(512), lds, st, a);
-  else hipLaunchKernelGGL((k_fq_attn_bwd<D, 1>), dim3(B, S), dim3(512), lds, st, a);
+  // PCA_FQ_BWD_V1=1: the per-wave global-traffic form (A/B measurements)
+  static const bool v1 = [] { const char* e = getenv("PCA_FQ_BWD_V1"); return e && e[0] == '1'; }();
+  int S2 = S;
+  if (QT == 2 && !v1) {
+    // full-line traffic through LDS tiles: 114 KiB per workgroup, one per CU - fewer point ranges
+    // (the partial buffers are sized for S)
+    while (S2 > 1 && B * S2 > 256) S2 /= 2;
+    a.S = S2;
+    static std::once_flag once;
+    std::call_once(once, [] {
+      (void)hipFuncSetAttribute(reinterpret_cast<const void*>(k_fq_attn_bwd2),
+                                hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+    });
+    hipLaunchKernelGGL(k_fq_attn_bwd2, dim3(B, S2), dim3(512), (size_t)6 * 32 * D * 2 + lds, st, a);
+  } else if (QT == 2) {
+    hipLaunchKernelGGL((k_fq_attn_bwd<D, 2>), dim3(B, S), dim3(512), lds, st, a);
+  } else {
+    hipLaunchKernelGGL((k_fq_attn_bwd<D, 1>), dim3(B, S), dim3(512), lds, st, a);
+  }
   PCA_TRY(check_launch("k_fq_attn_bwd"));
   hipLaunchKernelGGL(k_fq_dq_sum, dim3((unsigned)cdiv((int64_t)B * m * D, 256)), dim3(256), 0, st,
-                     dO, dQpPart, B, S, m * D, dOt);
+                     dO, dQpPart, B, S2, m * D, dOt);
   return check_launch("k_fq_dq_sum");
 }
 
