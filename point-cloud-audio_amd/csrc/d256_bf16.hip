@@ -1411,6 +1411,149 @@ __global__ __launch_bounds__(64 * (D / 32)) void k_fq_attn_fwd(const FqArgs a) {
   }
 }
 
+// k_fq_attn_fwd2 (m = 32, d = 256): the forward with full-line reads - the workgroup streams whole
+// [32 keys][256] tiles of Kp and Vp in by LDS-DMA (double buffered) and every wave (= head) takes its
+// 64-byte slices from LDS, where k_fq_attn_fwd reads 16 rows x 64 bytes per load instruction.
+__global__ __launch_bounds__(512, 2) void k_fq_attn_fwd2(const FqArgs a) {
+  constexpr int D = 256, QT = 2, PV = 72, H = D / 32, MQ = 16 * QT;
+  constexpr int ROWB = D * 2, TILEB = 32 * ROWB;
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  char* sKb = smem;                        // [2][TILEB]
+  char* sVb = smem + 2 * TILEB;            // [2][TILEB]
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int j = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int r = lane & 15, g = lane >> 4;
+  const int b = blockIdx.x, sp = blockIdx.y;
+  char* myV = smem + 4 * TILEB + j * 32 * PV;
+  const int per = (int)(((int64_t)(a.N + 31) / 32 + a.S - 1) / a.S) * 32;
+  int len = a.N;
+  if (a.lengths != nullptr) len = a.lengths[b] < a.N ? a.lengths[b] : a.N;
+  const int n_lo = sp * per, n_hi = (n_lo + per < len) ? n_lo + per : len;
+  const int T = n_lo < n_hi ? (n_hi - n_lo + 31) / 32 : 0;
+  bf16x8 qf[QT];
+#pragma unroll
+  for (int qt = 0; qt < QT; ++qt) qf[qt] = q_frag(a.Qp, D, a.m, 16 * qt + r, j, g, a.scale_log2e);
+  float mrow[QT], lrow[QT];
+  f32x4 ot[2][QT];
+#pragma unroll
+  for (int qt = 0; qt < QT; ++qt) {
+    mrow[qt] = -INFINITY;
+    lrow[qt] = 0.f;
+    ot[0][qt] = f32x4{0.f, 0.f, 0.f, 0.f};
+    ot[1][qt] = f32x4{0.f, 0.f, 0.f, 0.f};
+  }
+  const int oK = swz(r, 4 * j + g, ROWB);
+  auto lds_barrier = [] {
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+    __builtin_amdgcn_s_barrier();
+    asm volatile("" ::: "memory");
+  };
+  auto dma = [&](int k) {
+    const int n0 = n_lo + 32 * k, par = k & 1;
+#pragma unroll
+    for (int w = 0; w < 2; ++w) {
+      const __bf16* base = w == 0 ? a.Kp : a.Vp;
+      char* dst = (w == 0 ? sKb : sVb) + par * TILEB;
+#pragma unroll
+      for (int i = 0; i < 2; ++i) {
+        const int p = (2 * j + i) * 64 + lane;
+        const int row = p >> 5, slot = p & 31;
+        const int ch = (slot & ~15) | ((slot ^ row) & 15);
+        const int n = n0 + row < a.N ? n0 + row : a.N - 1;
+        const __bf16* src = base + ((int64_t)b * a.N + n) * D + ch * 8;
+        const unsigned ldst = __builtin_amdgcn_readfirstlane(
+            (unsigned)(uintptr_t)(lds_void_t*)(dst + (2 * j + i) * 1024));
+        unsigned keep;
+        asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %2\n\ts_nop 0\n\t"
+                     "global_load_lds_dwordx4 %1, off\n\ts_mov_b32 m0, %0"
+                     : "=&s"(keep) : "v"(src), "s"(ldst) : "memory");
+      }
+    }
+  };
+  if (T > 0) dma(0);
+  for (int k = 0; k < T; ++k) {
+    const int par = k & 1, n0 = n_lo + 32 * k;
+    const char* sK = sKb + par * TILEB;
+    const char* sV = sVb + par * TILEB;
+    if (k + 1 < T) {
+      dma(k + 1);
+      asm volatile("s_waitcnt vmcnt(4)" ::: "memory");      // everything but the 4 pieces just issued
+    } else {
+      asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    }
+    lds_barrier();                       // tiles of iteration k complete (and k - 1 consumed by all)
+    bf16x8 kr[2];
+#pragma unroll
+    for (int pb = 0; pb < 2; ++pb) {
+      const int n = n0 + 16 * pb + r;
+      kr[pb] = *reinterpret_cast<const bf16x8*>(sK + oK + 8192 * pb);
+      bf16x8 vr = *reinterpret_cast<const bf16x8*>(sV + oK + 8192 * pb);
+      if (n >= n_hi) {                     // rows past the range: the DMA fetched other rows
+#pragma unroll
+        for (int e = 0; e < 8; ++e) { kr[pb][e] = (__bf16)0.f; vr[e] = (__bf16)0.f; }
+      }
+      bf16x4 lo4, hi4;
+#pragma unroll
+      for (int e = 0; e < 4; ++e) { lo4[e] = vr[e]; hi4[e] = vr[4 + e]; }
+      *reinterpret_cast<bf16x4*>(myV + (16 * pb + r) * PV + 16 * g) = lo4;
+      *reinterpret_cast<bf16x4*>(myV + (16 * pb + r) * PV + 16 * g + 8) = hi4;
+    }
+    bf16x8 vt[2];
+#pragma unroll
+    for (int tt = 0; tt < 2; ++tt) vt[tt] = tr_frag_small(myV, PV, 16 * tt, lane);
+#pragma unroll
+    for (int qt = 0; qt < QT; ++qt) {
+      f32x4 s[2];
+      float mt = -INFINITY;
+#pragma unroll
+      for (int pb = 0; pb < 2; ++pb) {
+        s[pb] = mfma32(kr[pb], qf[qt], f32x4{0.f, 0.f, 0.f, 0.f});
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+          if (n0 + 16 * pb + 4 * g + e >= n_hi) s[pb][e] = -INFINITY;
+          mt = fmaxf(mt, s[pb][e]);
+        }
+      }
+      mt = wave16_max(mt);
+      const float mnew = fmaxf(mrow[qt], mt);           // finite: the tile has >= 1 live point
+      const float alpha = __builtin_amdgcn_exp2f(mrow[qt] - mnew);
+      float ls = 0.f;
+#pragma unroll
+      for (int pb = 0; pb < 2; ++pb)
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+          s[pb][e] = __builtin_amdgcn_exp2f(s[pb][e] - mnew);
+          ls += s[pb][e];
+        }
+      ls = wave16_sum(ls);
+      lrow[qt] = lrow[qt] * alpha + ls;
+      mrow[qt] = mnew;
+      const bf16x8 pb8 = pack8(s[0], s[1]);
+#pragma unroll
+      for (int tt = 0; tt < 2; ++tt) {
+#pragma unroll
+        for (int e = 0; e < 4; ++e) ot[tt][qt][e] *= alpha;
+        ot[tt][qt] = mfma32(vt[tt], pb8, ot[tt][qt]);
+      }
+    }
+  }
+  const int64_t pb0 = ((int64_t)b * a.S + sp);
+#pragma unroll
+  for (int qt = 0; qt < QT; ++qt) {
+    const int q = 16 * qt + r;
+    if (q < a.m) {
+#pragma unroll
+      for (int tt = 0; tt < 2; ++tt)
+        *reinterpret_cast<float4*>(a.Op + (pb0 * a.m + q) * D + 32 * j + 16 * tt + 4 * g) =
+            float4{ot[tt][qt][0], ot[tt][qt][1], ot[tt][qt][2], ot[tt][qt][3]};
+      if (g == 0) {
+        a.Mp[(pb0 * H + j) * MQ + q] = mrow[qt];
+        a.Lp[(pb0 * H + j) * MQ + q] = lrow[qt];
+      }
+    }
+  }
+}
+
 // backward.  Orientation A (points on accumulator rows, as the forward): P^T, dS^T -> the set's
 // dQp_h^T[f][q] += Kp_h^T[f][pt] dS^T[pt][q] (Kp^T through the LDS tile).  Orientation B
 // (queries on accumulator rows: S = Qp_h Kp_h^T recomputed with one more MFMA - the per-lane
@@ -2653,11 +2796,26 @@ int fq_attn_fwd256(const __bf16* Kp, const __bf16* Vp, const float* Qp, int B, i
   a.scale = 1.0f / sqrtf((float)D);
   a.scale_log2e = 1.4426950408889634f * a.scale;
   const size_t lds = (size_t)(D / 32) * 32 * 72;
-  if (QT == 2) hipLaunchKernelGGL((k_fq_attn_fwd<D, 2>), dim3(B, S), dim3(512), lds, st, a);
-  else hipLaunchKernelGGL((k_fq_attn_fwd<D, 1>), dim3(B, S), dim3(512), lds, st, a);
+  // PCA_FQ_FWD_V1=1: the per-wave global-traffic form (A/B measurements)
+  static const bool v1 = [] { const char* e = getenv("PCA_FQ_FWD_V1"); return e && e[0] == '1'; }();
+  int S2 = S;
+  if (QT == 2 && !v1) {
+    while (S2 > 1 && B * S2 > 256) S2 /= 2;       // 82 KiB of LDS: one workgroup per CU
+    a.S = S2;
+    static std::once_flag once;
+    std::call_once(once, [] {
+      (void)hipFuncSetAttribute(reinterpret_cast<const void*>(k_fq_attn_fwd2),
+                                hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+    });
+    hipLaunchKernelGGL(k_fq_attn_fwd2, dim3(B, S2), dim3(512), (size_t)4 * 32 * D * 2 + lds, st, a);
+  } else if (QT == 2) {
+    hipLaunchKernelGGL((k_fq_attn_fwd<D, 2>), dim3(B, S), dim3(512), lds, st, a);
+  } else {
+    hipLaunchKernelGGL((k_fq_attn_fwd<D, 1>), dim3(B, S), dim3(512), lds, st, a);
+  }
   PCA_TRY(check_launch("k_fq_attn_fwd"));
   hipLaunchKernelGGL(k_fq_merge, dim3((unsigned)cdiv((int64_t)B * m * D, 256)), dim3(256), 0, st,
-                     Op, Mp, Lp, Qp, B, S, m, D, MQ, O, LSE);
+                     Op, Mp, Lp, Qp, B, S2, m, D, MQ, O, LSE);
   return check_launch("k_fq_merge");
 }
 int fq_attn_bwd256(const __bf16* Kp, const __bf16* Vp, const float* Qp, const float* dO,
