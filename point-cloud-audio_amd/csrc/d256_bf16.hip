@@ -2286,19 +2286,31 @@ __global__ __launch_bounds__(256, 1) void k_pma_fwd256(const PmaArgs a) {
   f32x4 T[FT];
 #pragma unroll
   for (int ft = 0; ft < FT; ++ft) T[ft] = f32x4{0.f, 0.f, 0.f, 0.f};
-  for (int n0 = n_lo + wave * 32; n0 < n_hi; n0 += 128) {
+  // The wave's next tile is fetched into registers (64 VGPRs - the kernel runs one wave per SIMD,
+  // there are 512) while the current one is worked on: without it every tile starts with an
+  // exposed round trip to memory.
+  bf16x8 nx[16];
+  auto fetch_tile = [&](int n0) {
 #pragma unroll
     for (int e = 0; e < 16; ++e) {
       const int c = lane + 64 * e, row = c >> 5, ch = c & 31;
       const int nr = n0 + row;
-      bf16x8 v = *reinterpret_cast<const bf16x8*>(
+      nx[e] = *reinterpret_cast<const bf16x8*>(
           a.X + ((int64_t)b * a.N + (nr < n_hi ? nr : n_hi - 1)) * DK + ch * 8);
       if (nr >= n_hi) {
 #pragma unroll
-        for (int k = 0; k < 8; ++k) v[k] = (__bf16)0.f;
+        for (int k = 0; k < 8; ++k) nx[e][k] = (__bf16)0.f;
       }
-      *reinterpret_cast<bf16x8*>(myX + tr_off256(row, ch)) = v;
     }
+  };
+  if (n_lo + wave * 32 < n_hi) fetch_tile(n_lo + wave * 32);
+  for (int n0 = n_lo + wave * 32; n0 < n_hi; n0 += 128) {
+#pragma unroll
+    for (int e = 0; e < 16; ++e) {
+      const int c = lane + 64 * e, row = c >> 5, ch = c & 31;
+      *reinterpret_cast<bf16x8*>(myX + tr_off256(row, ch)) = nx[e];
+    }
+    if (n0 + 128 < n_hi) fetch_tile(n0 + 128);
     f32x4 s[2];
     float mt = -INFINITY;
 #pragma unroll
@@ -2530,19 +2542,31 @@ __global__ __launch_bounds__(256, 1) void k_pma_bwd256(const PmaArgs a) {
 #pragma unroll
   for (int ft = 0; ft < FT; ++ft) dG[ft] = f32x4{0.f, 0.f, 0.f, 0.f};
   constexpr float LN2 = 0.6931471805599453f;
-  for (int n0 = n_lo + wave * 32; n0 < n_hi; n0 += 128) {
+  // The wave's next tile is fetched into registers (64 VGPRs - the kernel runs one wave per SIMD,
+  // there are 512) while the current one is worked on: without it every tile starts with an
+  // exposed round trip to memory.
+  bf16x8 nx[16];
+  auto fetch_tile = [&](int n0) {
 #pragma unroll
     for (int e = 0; e < 16; ++e) {
       const int c = lane + 64 * e, row = c >> 5, ch = c & 31;
       const int nr = n0 + row;
-      bf16x8 v = *reinterpret_cast<const bf16x8*>(
+      nx[e] = *reinterpret_cast<const bf16x8*>(
           a.X + ((int64_t)b * a.N + (nr < n_hi ? nr : n_hi - 1)) * DK + ch * 8);
       if (nr >= n_hi) {
 #pragma unroll
-        for (int k = 0; k < 8; ++k) v[k] = (__bf16)0.f;
+        for (int k = 0; k < 8; ++k) nx[e][k] = (__bf16)0.f;
       }
-      *reinterpret_cast<bf16x8*>(myX + tr_off256(row, ch)) = v;
     }
+  };
+  if (n_lo + wave * 32 < n_hi) fetch_tile(n_lo + wave * 32);
+  for (int n0 = n_lo + wave * 32; n0 < n_hi; n0 += 128) {
+#pragma unroll
+    for (int e = 0; e < 16; ++e) {
+      const int c = lane + 64 * e, row = c >> 5, ch = c & 31;
+      *reinterpret_cast<bf16x8*>(myX + tr_off256(row, ch)) = nx[e];
+    }
+    if (n0 + 128 < n_hi) fetch_tile(n0 + 128);
     bf16x8 pds[2];                          // B operand [k = (P rows | dS rows)][col = point]
 #pragma unroll
     for (int pb = 0; pb < 2; ++pb) {
@@ -2564,28 +2588,38 @@ __global__ __launch_bounds__(256, 1) void k_pma_bwd256(const PmaArgs a) {
       pds[pb] = pack8(p, ds);
       *reinterpret_cast<bf16x4*>(myDS + (16 * pb + r) * PD + 8 * g) = pack4(ds);
     }
+    // dG[r][c] += sum_points dS[r][pt] X[pt][c]   (before the X tile is re-used for dX)
+    const bf16x8 dsa = tr_frag_small(myDS, PD, 0, lane);
+#pragma unroll
+    for (int ft = 0; ft < FT; ++ft) dG[ft] = mfma32(dsa, tr_frag256(myX, ft, lane), dG[ft]);
     if (a.dX != nullptr) {
+      // dX tile [32 points][256] assembled in the wave's own LDS tile (its X is no longer needed)
+      // and stored / accumulated in 16-byte pieces of full rows - straight from the accumulator
+      // layout it was 32 store instructions of 8 bytes per lane, 16 rows x 32 bytes each
 #pragma unroll
       for (int ft = 0; ft < FT; ++ft) {
         const bf16x8 tg = *reinterpret_cast<const bf16x8*>(sTG + (16 * ft + r) * 64 + 16 * g);
 #pragma unroll
         for (int pb = 0; pb < 2; ++pb) {
-          const int n = n0 + 16 * pb + r;
-          f32x4 dx = mfma32(tg, pds[pb], f32x4{0.f, 0.f, 0.f, 0.f});
-          bf16x4* pd = reinterpret_cast<bf16x4*>(
-              a.dX + ((int64_t)b * a.N + (n < n_hi ? n : n_hi - 1)) * DK + 16 * ft + 4 * g);
-          if (a.accumulate_dx) {            // (wave-uniform; the load itself is unconditional)
-            const f32x4 o = tof(*pd);
-            dx[0] += o[0]; dx[1] += o[1]; dx[2] += o[2]; dx[3] += o[3];
-          }
-          if (n < n_hi) *pd = pack4(dx);
+          const f32x4 dx = mfma32(tg, pds[pb], f32x4{0.f, 0.f, 0.f, 0.f});
+          *reinterpret_cast<bf16x4*>(myX + swz(16 * pb + r, 2 * ft + (g >> 1), 2 * DK) + 8 * (g & 1)) =
+              pack4(dx);
         }
       }
-    }
-    // dG[r][c] += sum_points dS[r][pt] X[pt][c]
-    const bf16x8 dsa = tr_frag_small(myDS, PD, 0, lane);
 #pragma unroll
-    for (int ft = 0; ft < FT; ++ft) dG[ft] = mfma32(dsa, tr_frag256(myX, ft, lane), dG[ft]);
+      for (int e = 0; e < 16; ++e) {
+        const int c = lane + 64 * e, row = c >> 5, ch = c & 31;
+        const int n = n0 + row;
+        bf16x8 v = *reinterpret_cast<const bf16x8*>(myX + swz(row, ch, 2 * DK));
+        __bf16* pd = a.dX + ((int64_t)b * a.N + (n < n_hi ? n : n_hi - 1)) * DK + ch * 8;
+        if (a.accumulate_dx) {              // (wave-uniform; the load itself is unconditional)
+          const bf16x8 o = *reinterpret_cast<const bf16x8*>(pd);
+#pragma unroll
+          for (int k = 0; k < 8; ++k) v[k] = (__bf16)((float)v[k] + (float)o[k]);
+        }
+        if (n < n_hi) *reinterpret_cast<bf16x8*>(pd) = v;
+      }
+    }
   }
   __syncthreads();
   float* slab = reinterpret_cast<float*>(sX) + wave * 16 * DK;
