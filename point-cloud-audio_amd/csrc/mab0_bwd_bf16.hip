@@ -166,14 +166,25 @@ __global__ __launch_bounds__(256, 1) void k_mab0_bwd(const Mab0BwdArgs a) {
     for (int ft = 0; ft < FT; ++ft) dG[rb][ft] = f32x4{0.f, 0.f, 0.f, 0.f};
   constexpr float LN2 = 0.6931471805599453f;
 
+  // the wave's next X tile is fetched into registers while the current one is worked on (the kernel
+  // runs one wave per SIMD: registers are free, and every tile used to start with an exposed round trip)
+  bf16x8 nx[8];
+  auto fetch_tile = [&](int n0) {
+#pragma unroll
+    for (int e = 0; e < 8; ++e) {
+      const int c = lane + 64 * e;
+      nx[e] = ld_x8_guard<ABF>(a.X, (int64_t)b * a.N, n0 + (c >> 4), n_hi, DK, c & 15);
+    }
+  };
+  if (n_lo + wave * 32 < n_hi) fetch_tile(n_lo + wave * 32);
   for (int n0 = n_lo + wave * 32; n0 < n_hi; n0 += 128) {
 #pragma unroll
     for (int e = 0; e < 8; ++e) {
       const int c = lane + 64 * e;
       const int row = c >> 4, ch = c & 15;
-      const bf16x8 v = ld_x8_guard<ABF>(a.X, (int64_t)b * a.N, n0 + row, n_hi, DK, ch);
-      *reinterpret_cast<bf16x8*>(myX + tr_off(row, ch)) = v;
+      *reinterpret_cast<bf16x8*>(myX + tr_off(row, ch)) = nx[e];
     }
+    if (n0 + 128 < n_hi) fetch_tile(n0 + 128);
     bf16x8 xrow[2][KS];
 #pragma unroll
     for (int pb = 0; pb < 2; ++pb)
@@ -256,7 +267,32 @@ __global__ __launch_bounds__(256, 1) void k_mab0_bwd(const Mab0BwdArgs a) {
       for (int ft = 0; ft < FT; ++ft) dG[rb][ft] = mfma32(da, xtr[ft], dG[rb][ft]);
     }
 
-    if (a.dX != nullptr) {
+    if (a.dX != nullptr && ABF) {
+      // bf16 dX: the [32 points][128] tile is assembled in the wave's own LDS tile (X is no longer
+      // needed) and stored / accumulated in 16-byte pieces of full rows, the loads unconditional -
+      // from the accumulator layout it was 16 guarded read-modify-writes of 8 bytes per lane, each
+      // waited for on its own
+#pragma unroll
+      for (int pb = 0; pb < 2; ++pb)
+#pragma unroll
+        for (int ft = 0; ft < FT; ++ft)
+          *reinterpret_cast<bf16x4*>(myX + swz(16 * pb + r, 2 * ft + (g >> 1), 2 * DK) + 8 * (g & 1)) =
+              pack4(dx[ft][pb]);
+#pragma unroll
+      for (int e = 0; e < 8; ++e) {
+        const int c = lane + 64 * e, row = c >> 4, ch = c & 15;
+        const int n = n0 + row;
+        bf16x8 v = *reinterpret_cast<const bf16x8*>(myX + swz(row, ch, 2 * DK));
+        __bf16* pd = reinterpret_cast<__bf16*>(a.dX) +
+                     ((int64_t)b * a.N + (n < n_hi ? n : n_hi - 1)) * DK + ch * 8;
+        if (a.accumulate_dx) {
+          const bf16x8 o = *reinterpret_cast<const bf16x8*>(pd);
+#pragma unroll
+          for (int k = 0; k < 8; ++k) v[k] = (__bf16)((float)v[k] + (float)o[k]);
+        }
+        if (n < n_hi) *reinterpret_cast<bf16x8*>(pd) = v;
+      }
+    } else if (a.dX != nullptr) {
 #pragma unroll
       for (int pb = 0; pb < 2; ++pb)
         if (live[pb]) {
