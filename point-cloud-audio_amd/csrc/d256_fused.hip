@@ -54,6 +54,28 @@ __device__ __forceinline__ int toff(int row, int c16) { return swz(row, c16, ROW
 typedef __attribute__((address_space(1))) const void gptr_t;
 typedef __attribute__((address_space(3))) void lptr_t;
 
+#define PCA_WAIT_VM_CASE(n) case n: asm volatile("s_waitcnt vmcnt(" #n ")" ::: "memory"); break;
+__device__ __forceinline__ void wait_vm(int n) {
+  switch (n) {
+    PCA_WAIT_VM_CASE(2) PCA_WAIT_VM_CASE(3) PCA_WAIT_VM_CASE(4) PCA_WAIT_VM_CASE(5)
+    PCA_WAIT_VM_CASE(6) PCA_WAIT_VM_CASE(7) PCA_WAIT_VM_CASE(8) PCA_WAIT_VM_CASE(9)
+    default: asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+  }
+}
+
+#ifdef PCA_FWD_STAMPS
+// (measurement build only, -DPCA_FWD_STAMPS: cycle stamps of workgroup 0, every wave, the first 64
+//  tiles.  The stamps are global stores: they perturb every vmcnt wait of the stamped workgroup.)
+__device__ long long g_fwd_stamps[8 * 64 * 16];
+#define FWD_STAMP(i)                                                                          \
+  do {                                                                                        \
+    if (blockIdx.x == 0 && lane == 0 && unit - u0 < 64)                                       \
+      g_fwd_stamps[(j * 64 + (unit - u0)) * 16 + (i)] = (long long)__builtin_readcyclecounter(); \
+  } while (0)
+#else
+#define FWD_STAMP(i)
+#endif
+
 // F8O (PCA_MODE_FP8): fc_o with fp8 e4m3 operands - Wo slices as fp8 (32 registers instead of 64),
 // the O fragments converted in registers, Z rescaled by 1 / s before the bias
 template <bool SMALL, bool F8O = false>
@@ -126,8 +148,10 @@ __global__ __launch_bounds__(512, 2) void k_isab1_fwd256(const FusedFwdArgs a) {
   // LDS-DMA of a unit's X tile: LDS is written linearly (wave base + 16 lane); piece p of the
   // tile (row p / 32, slot p % 32) must hold chunk slot ^ (row & 15) of its row, so each lane
   // fetches THAT chunk (the swizzle is an involution: source-side permutation, rule 21)
-  auto dma_x = [&](int unit, char* dst) {
-    const int b = unit / a.tiles_per_set, n0 = (unit - b * a.tiles_per_set) * P;
+  // ((set, tile) of the previous / current / next unit are carried through the loop: an integer
+  //  division by a run-time value costs ~40 instructions, and there were three per tile and wave)
+  auto dma_x = [&](int b, int tile, char* dst) {
+    const int n0 = tile * P;
 #pragma unroll
     for (int i = 0; i < DMA_PER_WAVE; ++i) {
       const int p = (DMA_PER_WAVE * j + i) * 64 + lane;    // this wave: consecutive 1 KiB pieces
@@ -149,7 +173,9 @@ __global__ __launch_bounds__(512, 2) void k_isab1_fwd256(const FusedFwdArgs a) {
                    : "=&s"(keep) : "v"(src), "s"(ldst) : "memory");
     }
   };
-  if (!SMALL && u0 < u1) dma_x(u0, sXb);
+  int cb = u0 / a.tiles_per_set, ct = u0 - cb * a.tiles_per_set;      // current unit
+  int pb_ = cb, pt_ = ct;                                             // previous unit
+  if (!SMALL && u0 < u1) dma_x(cb, ct, sXb);
 
   // Per-lane byte offsets into a tile, computed ONCE: the swizzle XORs the 16-byte chunk index with
   // the row, so an address is not "base + constant" across k-steps - left to the compiler, every
@@ -165,8 +191,8 @@ __global__ __launch_bounds__(512, 2) void k_isab1_fwd256(const FusedFwdArgs a) {
   const int oC = toff(tid >> 5, tid & 31);
 
   // coalesced stores of a finished tile (Y; training: O, Qp, ReLU mask words) from its LDS tiles
-  auto store_tile = [&](int unit, int par) {
-    const int b = unit / a.tiles_per_set, tile = unit - b * a.tiles_per_set;
+  const int tiles128 = (a.tiles_per_set * P + 127) / 128;
+  auto store_tile = [&](int b, int tile, int par) {
     const int n0 = tile * P, nlive = a.N - n0;
     const int64_t rowbase = (int64_t)b * a.N + n0;
 #pragma unroll
@@ -185,7 +211,6 @@ __global__ __launch_bounds__(512, 2) void k_isab1_fwd256(const FusedFwdArgs a) {
     }
     if (a.mask != nullptr && tid < NBK * 128) {
       const int nb = tid >> 7, w = (tid >> 6) & 1;
-      const int tiles128 = (a.tiles_per_set * P + 127) / 128;
       const int64_t blk = (int64_t)b * tiles128 * 8 + tile * NBK + nb;
       a.mask[(blk * 2 + w) * 64 + lane] = sMaskb[par * NBK * 128 + (nb * 2 + w) * 64 + lane];
     }
@@ -195,6 +220,13 @@ __global__ __launch_bounds__(512, 2) void k_isab1_fwd256(const FusedFwdArgs a) {
   //  steps between the barriers, so that one wave's softmax / epilogue VALU run meets the other's
   //  MFMA run.  Same results, 6 % slower in training mode, equal in inference: the waves of a SIMD
   //  already interleave inside a phase, and the split store passes cost more than the overlap won.)
+  // VM instructions per thread of store_tile for a full tile (the last tile of a set is ragged when
+  // 32 does not divide N: its pass issues fewer, so the wait that would count it drains instead)
+  const int n_store = (P / 16) * (1 + (a.OS != nullptr ? 1 : 0) + (a.QpS != nullptr ? 1 : 0)) +
+                      ((a.mask != nullptr && j < NBK * 2) ? 1 : 0);
+  const bool ragged = a.N % P != 0;
+  auto full_tile = [&](int b, int tile) { (void)b; return !ragged || tile != a.tiles_per_set - 1; };
+  int n_last = 0;          // store instructions of the store_tile pass issued in the previous iteration
   int cur_b = -1;
   bf16x8 kpa[2], vta[2];
   for (int unit = u0; unit < u1; ++unit) {
@@ -204,10 +236,13 @@ __global__ __launch_bounds__(512, 2) void k_isab1_fwd256(const FusedFwdArgs a) {
     char* sQ = sQb + par * TILEB;
     char* sY = sYb + par * TILEB;
     uint32_t* sMask = sMaskb + par * NBK * 128;
-    const int b = unit / a.tiles_per_set, tile = unit - b * a.tiles_per_set;
+    const int b = cb, tile = ct;
+    int nb_ = cb, nt_ = ct + 1;                                       // next unit
+    if (nt_ == a.tiles_per_set) { nt_ = 0; ++nb_; }
     const int n0 = tile * P, nlive = a.N - n0;
     const int64_t rowbase = (int64_t)b * a.N + n0;
     (void)tile;
+    FWD_STAMP(0);
     // layer 1: this tile's points straight to registers (issued before the deferred stores, so
     // that the counted wait for them does not cover the stores)
     float xv[SMALL ? NBK : 1][4];
@@ -226,15 +261,29 @@ __global__ __launch_bounds__(512, 2) void k_isab1_fwd256(const FusedFwdArgs a) {
     // than the pieces just issued - it and the stores of two tiles back - must have landed.
     if (!SMALL) {
       if (unit + 1 < u1) {
-        dma_x(unit + 1, sXb + (par ^ 1) * TILEB);
+        dma_x(nb_, nt_, sXb + (par ^ 1) * TILEB);
         static_assert(DMA_PER_WAVE == 2, "the counted wait below");
-        asm volatile("s_waitcnt vmcnt(2)" ::: "memory");
+        // Younger than this tile's DMA are the 2 pieces just issued and the stores of tile unit - 2
+        // (issued one iteration ago, after its barrier B0): counted, so that they may stay in flight.
+        // (Measured: no difference to draining them - they are acknowledged within an iteration.  The
+        //  12 % "stall" the cycle stamps of scripts/experiments/fwd_stamps.py showed here was the
+        //  stamps' own global stores being waited for.)
+        wait_vm(DMA_PER_WAVE + n_last);
       } else {
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
       }
     }
+    FWD_STAMP(1);
     lds_barrier();                       // B0: X tile (all waves' pieces); previous tile's Y / mask
-    if (unit > u0) store_tile(unit - 1, par ^ 1);
+    FWD_STAMP(2);
+    n_last = 0;
+    if (unit > u0) {
+      store_tile(pb_, pt_, par ^ 1);
+      n_last = full_tile(pb_, pt_) ? n_store : 0;          // (ragged: count unknown -> drained next time)
+    }
+    pb_ = cb; pt_ = ct;
+    cb = nb_; ct = nt_;
+    FWD_STAMP(3);
     if (b != cur_b) {
 #pragma unroll
       for (int kt = 0; kt < 2; ++kt) {
@@ -276,6 +325,7 @@ __global__ __launch_bounds__(512, 2) void k_isab1_fwd256(const FusedFwdArgs a) {
           acc[1][nb] = mfma32(wqa[SMALL ? 0 : s][1], bx, acc[1][nb]);
         }
     }
+    FWD_STAMP(4);
     if (a.QpS != nullptr) {              // own 32-column slice of the Qp tile
 #pragma unroll
       for (int nb = 0; nb < NBK; ++nb)
@@ -315,7 +365,9 @@ __global__ __launch_bounds__(512, 2) void k_isab1_fwd256(const FusedFwdArgs a) {
 #pragma unroll
       for (int t = 0; t < 2; ++t)
         *reinterpret_cast<bf16x4*>(sO + oD[t] + 8192 * nb) = pack4(acc[t][nb]);
+    FWD_STAMP(5);
     lds_barrier();                       // B1: O (and Qp) tiles complete; X tile consumed
+    FWD_STAMP(6);
     // ---- GEMM2: Z_h^T = Wo_h . O^T + bo ; Y_h = O_h + relu(Z_h) ----
     // (the accumulators of O_h are re-used for Z_h: the residual O_h is read back from the
     //  wave's own slice of the O tile - bf16, the rounding the two-launch form had as well)
@@ -343,6 +395,7 @@ __global__ __launch_bounds__(512, 2) void k_isab1_fwd256(const FusedFwdArgs a) {
           acc[1][nb] = mfma32(woa[F8O ? 0 : s][1], ob, acc[1][nb]);
         }
       }
+    FWD_STAMP(7);
 #pragma unroll
     for (int nb = 0; nb < NBK; ++nb) {
       uint32_t bits = 0u;                // byte (j & 3) of mask word j >> 2: tiles 2 j, 2 j + 1
@@ -363,11 +416,12 @@ __global__ __launch_bounds__(512, 2) void k_isab1_fwd256(const FusedFwdArgs a) {
         reinterpret_cast<uint8_t*>(sMask)[((nb * 2 + (j >> 2)) * 64 + lane) * 4 + (j & 3)] =
             (uint8_t)bits;
     }
+    FWD_STAMP(8);
     // (this tile's Y / O / Qp / mask leave in the next iteration, after its barrier B0)
   }
   if (u0 < u1) {
     lds_barrier();
-    store_tile(u1 - 1, (u1 - 1 - u0) & 1);
+    store_tile(pb_, pt_, (u1 - 1 - u0) & 1);
   }
 }
 
@@ -413,5 +467,11 @@ int isab1_fwd256_fused(const void* X, int dq, const __bf16* WqB, const float* Wq
   ps.end();
   return check_launch("k_isab1_fwd256");
 }
+
+#ifdef PCA_FWD_STAMPS
+extern "C" int pca_debug_fwd_stamps(long long* out) {
+  return (int)hipMemcpyFromSymbol(out, HIP_SYMBOL(g_fwd_stamps), sizeof(g_fwd_stamps));
+}
+#endif
 
 }  // namespace pca
