@@ -48,6 +48,9 @@ struct Wgrad256Jobs {
   Wgrad256Job j[8];
   int n;
 };
+void wgrad256_handoff_arm(bool on);
+bool wgrad256_handoff_pending();
+int wgrad256_handoff_flush(void* ws, hipStream_t st);
 size_t wgrad256_ws_bytes(int njobs, int64_t maxM);
 int wgrad256_launch(const Wgrad256Jobs& jobs, void* ws, hipStream_t st);
 int wgrad256_launch_t(const Wgrad256Jobs& jobs, void* ws, bool f32_operands, hipStream_t st);

@@ -33,6 +33,23 @@ struct Mab1D256Ws {
   float *dKp, *dVp, *dKpPart, *dVpPart;
   void* wg;
 };
+// Hand-over of mab1's fc_q weight-gradient job ({dQp, X}) to the few-queries block of the same ISAB,
+// whose two jobs ({dKp, X}, {dVp, X}) read the same X: launched together, the three share each X tile
+// through the XCD's L2 (k_wgrad256's shared-operand order).  Armed by the engine only, around the
+// pair of calls, with separate workspaces for the two blocks (dQp must outlive mab1's call).
+namespace {
+struct WgHandoff {
+  bool armed = false, has = false;
+  Wgrad256Job job{};
+};
+thread_local WgHandoff g_handoff;
+}  // namespace
+void wgrad256_handoff_arm(bool on) {
+  g_handoff.armed = on;
+  if (!on) g_handoff.has = false;
+}
+bool wgrad256_handoff_pending() { return g_handoff.has; }
+
 // PCA_ROWSTREAM=0: the LDS-resident-weight row-GEMMs (k_rowgemm) instead of the register-resident
 // streaming ones (d256_stream.hip), for A/B measurements
 static bool rowstream_on() {
@@ -67,6 +84,15 @@ static size_t mab1_d256_carve(const pca_mab_shape& s, Mab1D256Ws* out, void* bas
   if (out) *out = w;
   return c.off;
 }
+// a handed-over job nobody took (the following block was not the projected-keys few-queries one)
+int wgrad256_handoff_flush(void* ws, hipStream_t st) {
+  if (!g_handoff.has) return PCA_OK;
+  Wgrad256Jobs jobs{};
+  jobs.j[jobs.n++] = g_handoff.job;
+  g_handoff.has = false;
+  return wgrad256_launch(jobs, ws, st);
+}
+
 size_t mab1_d256_bwd_ws_bytes(const pca_mab_shape& s) { return mab1_d256_carve(s, nullptr, nullptr); }
 
 int mab1_d256_bwd(const pca_mab_shape& s, const void* X, const float* Hk, const pca_mab_params& p,
@@ -127,7 +153,15 @@ int mab1_d256_bwd(const pca_mab_shape& s, const void* X, const float* Hk, const 
   // weight gradients over the B*N rows
   Wgrad256Jobs jobs{};
   jobs.j[jobs.n++] = Wgrad256Job{w.dZ, v.OS, gr.wo, gr.bo, M};
-  if (!small) jobs.j[jobs.n++] = Wgrad256Job{w.dQp, Xb, gr.wq, gr.bq, M};
+  if (!small) {
+    const Wgrad256Job jq{w.dQp, Xb, gr.wq, gr.bq, M};
+    if (g_handoff.armed && abf) {          // launched by the few-queries block with its own two jobs
+      g_handoff.job = jq;
+      g_handoff.has = true;
+    } else {
+      jobs.j[jobs.n++] = jq;
+    }
+  }
   PCA_TRY(wgrad256_launch(jobs, w.wg, st));
   if (small)
     PCA_TRY(wgrad_small256(w.dQp, reinterpret_cast<const float*>(X), M, s.dq, gr.wq, gr.bq, w.wg, st));
@@ -326,7 +360,7 @@ static size_t fq_carve_bwd(const pca_mab_shape& s, Fq256BwdWs* out, void* base) 
     if (s.k_dtype == PCA_F32) w.dXb = c.take<__bf16>(nelem(s, true));
     w.Delta = c.take<float>((size_t)s.B * H8 * MQ);
     w.dQpPart = c.take<float>((size_t)s.B * S * m * D);
-    w.wg = c.take<char>(wgrad256_ws_bytes(2, (int64_t)s.B * s.nk));
+    w.wg = c.take<char>(wgrad256_ws_bytes(3, (int64_t)s.B * s.nk));         // (+ mab1's handed-over job)
     w.slabs = c.take<float>((size_t)cdiv((int64_t)Bm, 512) * D);          // column-sum partials
   } else {
     w.Delta = c.take<float>((size_t)s.B * R);
@@ -425,6 +459,10 @@ int mab0_d256_bwd(const pca_mab_shape& s, const float* I, const void* X, const p
     Wgrad256Jobs jobs{};
     jobs.j[jobs.n++] = Wgrad256Job{w.dKp, Xb, gr.wk, nullptr, M};
     jobs.j[jobs.n++] = Wgrad256Job{w.dVp, Xb, gr.wv, nullptr, M};
+    if (g_handoff.has && g_handoff.job.A == Xb && g_handoff.job.M == M) {     // mab1's {dQp, X}
+      jobs.j[jobs.n++] = g_handoff.job;
+      g_handoff.has = false;
+    }
     PCA_TRY(wgrad256_launch(jobs, w.wg, st));
     pj.DG = nullptr;
     pj.dO = w.dOt;

@@ -4,6 +4,7 @@
 // in state_dict order.  No Python, autograd or allocator sits between the kernels, so the
 // caller can capture the call in a hipGraph.
 #include "mab1_bf16.hpp"
+#include "d256_bf16.hpp"
 
 namespace pca {
 
@@ -337,12 +338,23 @@ int pca_st_train_fwd_bwd(const pca_st_config* c, const float* params, const floa
                                  pca::grads_at(g, L.mab0[1]), pca::grads_at(g, L.mab1[1]),
                                  w.scratch_bw[1], w.img[1], st, &posts));
     } else {
+    // d = 256: mab1's fc_q weight-gradient job is handed to the few-queries block, whose two jobs
+    // read the same Y1 (wgrad256_handoff, d256_host.hip); the two blocks then need separate
+    // workspaces - mab0 takes the forward / PMA scratch, which is free by now
+    const bool hand = s.m1[1].d == 256 && pca::mab_kind(s.m1[1]) == 1 && pca::mab_kind(s.m0[1]) == 2;
+    struct HandGuard {
+      bool on;
+      explicit HandGuard(bool o) : on(o) { if (on) pca::wgrad256_handoff_arm(true); }
+      ~HandGuard() { if (on) pca::wgrad256_handoff_arm(false); }
+    } hand_guard(hand);
     PCA_TRY(pca::mab_bwd_any(s.m1[1], w.Y[0], w.H[1], pca::params_at(p, L.mab1[1]),
                              w.saved[3], w.dY2, w.dY1, w.dH, 0, pca::grads_at(g, L.mab1[1]),
                              w.scratch_bw[1], st));
     PCA_TRY(pca::mab_bwd_any(s.m0[1], p + L.I[1], w.Y[0], pca::params_at(p, L.mab0[1]),
                              w.saved[2], w.dH, g + L.I[1], w.dY1, 1,
-                             pca::grads_at(g, L.mab0[1]), w.scratch_bw[1], st));
+                             pca::grads_at(g, L.mab0[1]), hand ? w.scratch : w.scratch_bw[1], st));
+    if (hand && pca::wgrad256_handoff_pending())        // (nobody took it: run it on its own)
+      PCA_TRY(pca::wgrad256_handoff_flush(w.scratch, st));
     }
   }
   if (phase != 0) {
