@@ -239,17 +239,18 @@ void k_mab1_bwd(const Mab1BwdArgs a) {
       f32x4 dz[DT];
 #pragma unroll
       for (int t = 0; t < DT; ++t) {
-        float4 v = float4{0.f, 0.f, 0.f, 0.f};
-        if (live[nb]) {
-          if (ABF) {
-            const bf16x4 h4 = *reinterpret_cast<const bf16x4*>(
-                reinterpret_cast<const __bf16*>(a.dY) + row[nb] * D + 16 * t + 4 * g);
-            v = float4{(float)h4[0], (float)h4[1], (float)h4[2], (float)h4[3]};
-          } else {
-            v = *reinterpret_cast<const float4*>(reinterpret_cast<const float*>(a.dY) +
-                                                 row[nb] * D + 16 * t + 4 * g);
-          }
+        // (unconditional - row[] is clamped for padding points - and zeroed afterwards: under the
+        //  divergent `if (live)` each of the DT loads was waited for before the next was issued)
+        float4 v;
+        if (ABF) {
+          const bf16x4 h4 = *reinterpret_cast<const bf16x4*>(
+              reinterpret_cast<const __bf16*>(a.dY) + row[nb] * D + 16 * t + 4 * g);
+          v = float4{(float)h4[0], (float)h4[1], (float)h4[2], (float)h4[3]};
+        } else {
+          v = *reinterpret_cast<const float4*>(reinterpret_cast<const float*>(a.dY) +
+                                               row[nb] * D + 16 * t + 4 * g);
         }
+        if (!live[nb]) v = float4{0.f, 0.f, 0.f, 0.f};
         dO[t][nb] = f32x4{v.x, v.y, v.z, v.w};
 #pragma unroll
         for (int e = 0; e < 4; ++e)
