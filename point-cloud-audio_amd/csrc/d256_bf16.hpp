@@ -50,6 +50,11 @@ struct Wgrad256Jobs {
 };
 void wgrad256_handoff_arm(bool on);
 bool wgrad256_handoff_pending();
+struct DxHandoff {            // mab1's dX = dQp Wq, deferred into the few-queries block's DX launch
+  const __bf16 *dQp, *WqT;
+  __bf16* dX;
+  int B, N;
+};
 int wgrad256_handoff_flush(void* ws, hipStream_t st);
 size_t wgrad256_ws_bytes(int njobs, int64_t maxM);
 int wgrad256_launch(const Wgrad256Jobs& jobs, void* ws, hipStream_t st);
@@ -69,6 +74,8 @@ int rowstream256_proj2_f8(const __bf16* X, const void* Wk8, const void* Wv8, con
                           hipStream_t st);
 int rowstream256_dx2(const __bf16* dKp, const __bf16* dVp, const __bf16* WkT, const __bf16* WvT,
                      __bf16* dX, int B, int N, int accumulate, hipStream_t st);
+int rowstream256_dx3(const __bf16* dQp, const __bf16* dKp, const __bf16* dVp, const __bf16* WqT,
+                     const __bf16* WkT, const __bf16* WvT, __bf16* dX, int B, int N, hipStream_t st);
 int rowstream256_dx1(const __bf16* dQp, const __bf16* WqT, __bf16* dX, int B, int N,
                      hipStream_t st);
 int attn1_bwd256_fused(const __bf16* dY, const uint32_t* mask, const __bf16* WoT, const __bf16* QpS,

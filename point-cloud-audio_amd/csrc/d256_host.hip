@@ -39,16 +39,17 @@ struct Mab1D256Ws {
 // pair of calls, with separate workspaces for the two blocks (dQp must outlive mab1's call).
 namespace {
 struct WgHandoff {
-  bool armed = false, has = false;
+  bool armed = false, has = false, has_dx = false;
   Wgrad256Job job{};
+  DxHandoff dx{};
 };
 thread_local WgHandoff g_handoff;
 }  // namespace
 void wgrad256_handoff_arm(bool on) {
   g_handoff.armed = on;
-  if (!on) g_handoff.has = false;
+  if (!on) { g_handoff.has = false; g_handoff.has_dx = false; }
 }
-bool wgrad256_handoff_pending() { return g_handoff.has; }
+bool wgrad256_handoff_pending() { return g_handoff.has || g_handoff.has_dx; }
 
 // PCA_ROWSTREAM=0: the LDS-resident-weight row-GEMMs (k_rowgemm) instead of the register-resident
 // streaming ones (d256_stream.hip), for A/B measurements
@@ -86,6 +87,11 @@ static size_t mab1_d256_carve(const pca_mab_shape& s, Mab1D256Ws* out, void* bas
 }
 // a handed-over job nobody took (the following block was not the projected-keys few-queries one)
 int wgrad256_handoff_flush(void* ws, hipStream_t st) {
+  if (g_handoff.has_dx) {
+    g_handoff.has_dx = false;
+    PCA_TRY(rowstream256_dx1(g_handoff.dx.dQp, g_handoff.dx.WqT, g_handoff.dx.dX, g_handoff.dx.B,
+                             g_handoff.dx.N, st));
+  }
   if (!g_handoff.has) return PCA_OK;
   Wgrad256Jobs jobs{};
   jobs.j[jobs.n++] = g_handoff.job;
@@ -145,8 +151,15 @@ int mab1_d256_bwd(const pca_mab_shape& s, const void* X, const float* Hk, const 
   }
   if (want_dx) {
     __bf16* dXb = abf ? reinterpret_cast<__bf16*>(dX) : w.dXb;
-    if (rowstream_on()) PCA_TRY(rowstream256_dx1(w.dQp, w.WqTP, dXb, s.B, s.nq, st));
-    else PCA_TRY(rowgemm256_dx(w.dQp, w.WqTP, dXb, s.B, s.nq, 0, st));
+    if (rowstream_on() && g_handoff.armed && abf) {
+      // deferred: the few-queries block of this ISAB adds its dKp Wk + dVp Wv in the same pass (DX3)
+      g_handoff.dx = DxHandoff{w.dQp, w.WqTP, dXb, s.B, s.nq};
+      g_handoff.has_dx = true;
+    } else if (rowstream_on()) {
+      PCA_TRY(rowstream256_dx1(w.dQp, w.WqTP, dXb, s.B, s.nq, st));
+    } else {
+      PCA_TRY(rowgemm256_dx(w.dQp, w.WqTP, dXb, s.B, s.nq, 0, st));
+    }
     if (!abf) PCA_TRY(cvt_bf16_f32(dXb, reinterpret_cast<float*>(dX), M * D, 0, st));
   }
   ps.end();
@@ -445,6 +458,13 @@ int mab0_d256_bwd(const pca_mab_shape& s, const float* I, const void* X, const p
       __bf16* dXb = f32 ? w.dXb : reinterpret_cast<__bf16*>(dX);
       if (rowstream_on()) {                  // dKp Wk + dVp Wv in one pass, weights in registers
         PCA_TRY(prep_weight2(p.wk, w.WkTP, 3, p.wv, w.WvTP, 3, D, D, st));
+        if (g_handoff.has_dx && !f32 && dk_accumulate && g_handoff.dx.dX == dXb &&
+            g_handoff.dx.B == s.B && g_handoff.dx.N == s.nk) {
+          // ... and mab1's dQp Wq (it would have written dX first; nothing to accumulate onto)
+          g_handoff.has_dx = false;
+          PCA_TRY(rowstream256_dx3(g_handoff.dx.dQp, w.dKp, w.dVp, g_handoff.dx.WqT, w.WkTP, w.WvTP,
+                                   dXb, s.B, s.nk, st));
+        } else
         PCA_TRY(rowstream256_dx2(w.dKp, w.dVp, w.WkTP, w.WvTP, dXb, s.B, s.nk,
                                  (!f32 && dk_accumulate) ? 1 : 0, st));
       } else {

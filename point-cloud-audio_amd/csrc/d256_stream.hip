@@ -4,6 +4,7 @@
 //                                                          the N keys, modules.py:21; one pass over X)
 //     DX2     dX (+)= dKp Wk + dVp Wv                     (their adjoint w.r.t. the keys; one pass)
 //     DX1     dX = dQp Wq                                 (adjoint of fc_q, modules.py:20)
+//     DX3     dX = dQp Wq + dKp Wk + dVp Wv               (both of the above for one ISAB input)
 // k_rowgemm (d256_bf16.hip) keeps the 128 KiB weight image in LDS, which leaves 32 KiB for
 // activations: 32 KiB in flight per CU is 4 TB/s by Little's law, and that is what it measured
 // (3.3 TB/s; PROJ and the dKp / dVp adjoint also ran as two launches each, reading X / re-reading
@@ -27,8 +28,8 @@ constexpr int D = 256, P = 32, KS = D / 32;
 constexpr int ROWB = D * 2, TILEB = P * ROWB;               // 16 KiB per tile
 
 struct RowStreamArgs {
-  const __bf16* In[2];      // [B*N][256] input streams
-  const __bf16* W[2];       // [256][256] bf16 A-operand images: row = output feature, col = k
+  const __bf16* In[3];      // [B*N][256] input streams
+  const __bf16* W[3];       // [256][256] bf16 A-operand images: row = output feature, col = k
   const float* bias[2];     // per output (nullable)
   const float* inv_scale;   // F8: 1 / s of the two fp8 weight images (W holds fp8 bytes of s * W)
   __bf16* Out[2];           // [B*N][256]
@@ -180,7 +181,7 @@ __global__ __launch_bounds__(512, 2) void k_rowstream(const RowStreamArgs a) {
         for (int nb = 0; nb < 2; ++nb) acc[o][t][nb] = F8 ? f32x4{0.f, 0.f, 0.f, 0.f} : bz[o][t];
 #pragma unroll
     for (int q = 0; q < NG; ++q) {
-      const char* sX = sIn + ((NIN == 2 ? q : 0) * NBUF + k % NBUF) * TILEB;
+      const char* sX = sIn + ((NIN >= 2 ? q : 0) * NBUF + k % NBUF) * TILEB;
       constexpr int dummy = 0;
       (void)dummy;
       const int o = NOUT == 2 ? q : 0;
@@ -279,6 +280,15 @@ int rowstream256_dx2(const __bf16* dKp, const __bf16* dVp, const __bf16* WkT, co
   a.Out[0] = dX; a.Acc = dX; a.B = B; a.N = N;
   if (accumulate) return launch_rowstream<2, 1, true, 2>(a, st);
   return launch_rowstream<2, 1, false, 3>(a, st);
+}
+// dX = dQp Wq + dKp Wk + dVp Wv in one pass (the ISAB input's whole gradient: mab1's fc_q adjoint
+// and the few-queries block's key / value adjoints; three weights = 192 registers)
+int rowstream256_dx3(const __bf16* dQp, const __bf16* dKp, const __bf16* dVp, const __bf16* WqT,
+                     const __bf16* WkT, const __bf16* WvT, __bf16* dX, int B, int N, hipStream_t st) {
+  RowStreamArgs a{};
+  a.In[0] = dQp; a.In[1] = dKp; a.In[2] = dVp; a.W[0] = WqT; a.W[1] = WkT; a.W[2] = WvT;
+  a.Out[0] = dX; a.B = B; a.N = N;
+  return launch_rowstream<3, 1, false, 2>(a, st);
 }
 // dX = dQp Wq ; WqT: transposed bf16 image
 int rowstream256_dx1(const __bf16* dQp, const __bf16* WqT, __bf16* dX, int B, int N,
