@@ -1568,6 +1568,236 @@ __global__ __launch_bounds__(512, 2) void k_fq_attn_fwd2(const FqArgs a) {
   }
 }
 
+// k_fq_proj_fwd (m = 32, d = 256): fc_k / fc_v of the N keys AND the few-queries attention over
+// them in one pass over X.  Per 32-point tile the workgroup computes the Kp / Vp tiles as
+// k_rowstream<1,2> does (wave j: output features 32 j .. 32 j + 31 of both, the two [32 x 256]
+// weight slices in 128 registers, X tiles by LDS-DMA three deep), every wave writes its slices to
+// the Kp / Vp tiles in LDS - and head j's attention needs exactly the slices wave j just wrote, so
+// it reads them back without a barrier and runs k_fq_attn_fwd2's body on them; after one barrier
+// the two tiles leave for the backward in full rows.  Against PROJ2 + k_fq_attn_fwd2 the Kp / Vp
+// tensors are written but never read back: two [B*N, 256] passes less.
+struct FqProjArgs {
+  FqArgs f;
+  const __bf16* X;               // [B*N][256]
+  const __bf16 *WkB, *WvB;       // natural bf16 images [256][256]
+  const float *bk, *bv;
+  __bf16 *KpO, *VpO;             // [B*N][256] outputs (saved for the backward)
+};
+__global__ __launch_bounds__(512, 2) void k_fq_proj_fwd(const FqProjArgs aa) {
+  const FqArgs& a = aa.f;
+  constexpr int D = 256, QT = 2, PV = 72, H = D / 32, MQ = 16 * QT, KS = D / 32;
+  constexpr int ROWB = D * 2, TILEB = 32 * ROWB, NBUF = 3, PD = NBUF - 1;
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  char* sXb = smem;                        // [NBUF][TILEB]
+  char* sK = smem + NBUF * TILEB;          // Kp tile
+  char* sV = sK + TILEB;                   // Vp tile
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int j = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int r = lane & 15, g = lane >> 4;
+  const int b = blockIdx.x, sp = blockIdx.y;
+  char* myV = sV + TILEB + j * 32 * PV;
+  const int per = (int)(((int64_t)(a.N + 31) / 32 + a.S - 1) / a.S) * 32;
+  int len = a.N;
+  if (a.lengths != nullptr) len = a.lengths[b] < a.N ? a.lengths[b] : a.N;
+  // the projections cover every row of the range (the backward reads padded rows too); the
+  // attention only the keys: rows below min(range end, len)
+  const int n_lo = sp * per;
+  const int n_end = (n_lo + per < a.N) ? n_lo + per : a.N;
+  const int n_hi = n_end < len ? n_end : len;
+  const int T = n_lo < n_end ? (n_end - n_lo + 31) / 32 : 0;
+  bf16x8 wk[KS][2], wv[KS][2];
+#pragma unroll
+  for (int s = 0; s < KS; ++s)
+#pragma unroll
+    for (int t = 0; t < 2; ++t) {
+      const int64_t o = (int64_t)(32 * j + 16 * t + r) * D + 32 * s + 8 * g;
+      wk[s][t] = *reinterpret_cast<const bf16x8*>(aa.WkB + o);
+      wv[s][t] = *reinterpret_cast<const bf16x8*>(aa.WvB + o);
+    }
+  f32x4 bkz[2], bvz[2];
+#pragma unroll
+  for (int t = 0; t < 2; ++t) {
+    const float4 k4 = *reinterpret_cast<const float4*>(aa.bk + 32 * j + 16 * t + 4 * g);
+    const float4 v4 = *reinterpret_cast<const float4*>(aa.bv + 32 * j + 16 * t + 4 * g);
+    bkz[t] = f32x4{k4.x, k4.y, k4.z, k4.w};
+    bvz[t] = f32x4{v4.x, v4.y, v4.z, v4.w};
+  }
+  bf16x8 qf[QT];
+#pragma unroll
+  for (int qt = 0; qt < QT; ++qt) qf[qt] = q_frag(a.Qp, D, a.m, 16 * qt + r, j, g, a.scale_log2e);
+  float mrow[QT], lrow[QT];
+  f32x4 ot[2][QT];
+#pragma unroll
+  for (int qt = 0; qt < QT; ++qt) {
+    mrow[qt] = -INFINITY;
+    lrow[qt] = 0.f;
+    ot[0][qt] = f32x4{0.f, 0.f, 0.f, 0.f};
+    ot[1][qt] = f32x4{0.f, 0.f, 0.f, 0.f};
+  }
+  int oB[4], oD[2];
+#pragma unroll
+  for (int k = 0; k < 4; ++k) oB[k] = swz(r, 4 * k + g, ROWB);
+#pragma unroll
+  for (int t = 0; t < 2; ++t) oD[t] = swz(r, 4 * j + 2 * t + (g >> 1), ROWB) + 8 * (g & 1);
+  const int oK = swz(r, 4 * j + g, ROWB);
+  const int oC = swz(tid >> 5, tid & 31, ROWB);
+  auto lds_barrier = [] {
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+    __builtin_amdgcn_s_barrier();
+    asm volatile("" ::: "memory");
+  };
+  auto dma = [&](int k) {
+    const int n0 = n_lo + 32 * k;
+    char* dst = sXb + (k % NBUF) * TILEB;
+#pragma unroll
+    for (int i = 0; i < 2; ++i) {
+      const int p = (2 * j + i) * 64 + lane;
+      const int row = p >> 5, slot = p & 31;
+      const int ch = (slot & ~15) | ((slot ^ row) & 15);
+      const int n = n0 + row < a.N ? n0 + row : a.N - 1;
+      const __bf16* src = aa.X + ((int64_t)b * a.N + n) * D + ch * 8;
+      const unsigned ldst = __builtin_amdgcn_readfirstlane(
+          (unsigned)(uintptr_t)(lds_void_t*)(dst + (2 * j + i) * 1024));
+      unsigned keep;
+      asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %2\n\ts_nop 0\n\t"
+                   "global_load_lds_dwordx4 %1, off\n\ts_mov_b32 m0, %0"
+                   : "=&s"(keep) : "v"(src), "s"(ldst) : "memory");
+    }
+  };
+#pragma unroll 1
+  for (int k = 0; k < PD && k < T; ++k) dma(k);
+#pragma unroll 1
+  for (int k = 0; k < T; ++k) {
+    const int n0 = n_lo + 32 * k, nlive = a.N - n0;
+    const char* sX = sXb + (k % NBUF) * TILEB;
+    // tile k + PD streams in; tile k must have landed: younger are the DMAs of the tiles ahead (2
+    // pieces each) and the 4 stores of each of the last PD tiles (all full: not the last of a range)
+    if (k + PD < T) dma(k + PD);
+    {
+      const int ahead = (T - 1 - k) < PD ? (T - 1 - k) : PD;
+      const int behind = k < PD ? k : PD;
+      switch (2 * ahead + 4 * behind) {
+        case 12: asm volatile("s_waitcnt vmcnt(12)" ::: "memory"); break;
+        case 10: asm volatile("s_waitcnt vmcnt(10)" ::: "memory"); break;
+        case 8: asm volatile("s_waitcnt vmcnt(8)" ::: "memory"); break;
+        case 6: asm volatile("s_waitcnt vmcnt(6)" ::: "memory"); break;
+        case 4: asm volatile("s_waitcnt vmcnt(4)" ::: "memory"); break;
+        case 2: asm volatile("s_waitcnt vmcnt(2)" ::: "memory"); break;
+        default: asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); break;
+      }
+    }
+    lds_barrier();                       // B0: X tile k; the previous Kp / Vp tiles are stored
+    // ---- Kp_h^T, Vp_h^T = W_h . X^T + b: own slices of the two tiles ----
+    {
+      f32x4 ak[2][2], av[2][2];
+#pragma unroll
+      for (int t = 0; t < 2; ++t)
+#pragma unroll
+        for (int nb = 0; nb < 2; ++nb) { ak[t][nb] = bkz[t]; av[t][nb] = bvz[t]; }
+#pragma unroll
+      for (int s = 0; s < KS; ++s)
+#pragma unroll
+        for (int nb = 0; nb < 2; ++nb) {
+          const bf16x8 bx =
+              *reinterpret_cast<const bf16x8*>(sX + oB[s & 3] + 256 * (s >> 2) + 8192 * nb);
+          ak[0][nb] = mfma32(wk[s][0], bx, ak[0][nb]);
+          ak[1][nb] = mfma32(wk[s][1], bx, ak[1][nb]);
+          av[0][nb] = mfma32(wv[s][0], bx, av[0][nb]);
+          av[1][nb] = mfma32(wv[s][1], bx, av[1][nb]);
+        }
+#pragma unroll
+      for (int t = 0; t < 2; ++t)
+#pragma unroll
+        for (int nb = 0; nb < 2; ++nb) {
+          *reinterpret_cast<bf16x4*>(sK + oD[t] + 8192 * nb) = pack4(ak[t][nb]);
+          *reinterpret_cast<bf16x4*>(sV + oD[t] + 8192 * nb) = pack4(av[t][nb]);
+        }
+    }
+    // ---- head j's attention on the slices this wave just wrote (k_fq_attn_fwd2's body) ----
+    if (n0 < n_hi) {
+      bf16x8 kr[2];
+#pragma unroll
+      for (int pb = 0; pb < 2; ++pb) {
+        const int n = n0 + 16 * pb + r;
+        kr[pb] = *reinterpret_cast<const bf16x8*>(sK + oK + 8192 * pb);
+        bf16x8 vr = *reinterpret_cast<const bf16x8*>(sV + oK + 8192 * pb);
+        if (n >= n_hi) {
+#pragma unroll
+          for (int e = 0; e < 8; ++e) { kr[pb][e] = (__bf16)0.f; vr[e] = (__bf16)0.f; }
+        }
+        bf16x4 lo4, hi4;
+#pragma unroll
+        for (int e = 0; e < 4; ++e) { lo4[e] = vr[e]; hi4[e] = vr[4 + e]; }
+        *reinterpret_cast<bf16x4*>(myV + (16 * pb + r) * PV + 16 * g) = lo4;
+        *reinterpret_cast<bf16x4*>(myV + (16 * pb + r) * PV + 16 * g + 8) = hi4;
+      }
+      bf16x8 vt[2];
+#pragma unroll
+      for (int tt = 0; tt < 2; ++tt) vt[tt] = tr_frag_small(myV, PV, 16 * tt, lane);
+#pragma unroll
+      for (int qt = 0; qt < QT; ++qt) {
+        f32x4 s[2];
+        float mt = -INFINITY;
+#pragma unroll
+        for (int pb = 0; pb < 2; ++pb) {
+          s[pb] = mfma32(kr[pb], qf[qt], f32x4{0.f, 0.f, 0.f, 0.f});
+#pragma unroll
+          for (int e = 0; e < 4; ++e) {
+            if (n0 + 16 * pb + 4 * g + e >= n_hi) s[pb][e] = -INFINITY;
+            mt = fmaxf(mt, s[pb][e]);
+          }
+        }
+        mt = wave16_max(mt);
+        const float mnew = fmaxf(mrow[qt], mt);
+        const float alpha = __builtin_amdgcn_exp2f(mrow[qt] - mnew);
+        float ls = 0.f;
+#pragma unroll
+        for (int pb = 0; pb < 2; ++pb)
+#pragma unroll
+          for (int e = 0; e < 4; ++e) {
+            s[pb][e] = __builtin_amdgcn_exp2f(s[pb][e] - mnew);
+            ls += s[pb][e];
+          }
+        ls = wave16_sum(ls);
+        lrow[qt] = lrow[qt] * alpha + ls;
+        mrow[qt] = mnew;
+        const bf16x8 pb8 = pack8(s[0], s[1]);
+#pragma unroll
+        for (int tt = 0; tt < 2; ++tt) {
+#pragma unroll
+          for (int e = 0; e < 4; ++e) ot[tt][qt][e] *= alpha;
+          ot[tt][qt] = mfma32(vt[tt], pb8, ot[tt][qt]);
+        }
+      }
+    }
+    lds_barrier();                       // B1: Kp / Vp tiles complete (X tile k consumed)
+#pragma unroll
+    for (int i = 0; i < 2; ++i) {
+      const int c = tid + 512 * i, row = c >> 5, ch = c & 31;
+      if (row < nlive) {
+        const int64_t o = ((int64_t)b * a.N + n0 + row) * D + ch * 8;
+        *reinterpret_cast<uint4*>(aa.KpO + o) = *reinterpret_cast<const uint4*>(sK + oC + 8192 * i);
+        *reinterpret_cast<uint4*>(aa.VpO + o) = *reinterpret_cast<const uint4*>(sV + oC + 8192 * i);
+      }
+    }
+  }
+  const int64_t pb0 = ((int64_t)b * a.S + sp);
+#pragma unroll
+  for (int qt = 0; qt < QT; ++qt) {
+    const int q = 16 * qt + r;
+    if (q < a.m) {
+#pragma unroll
+      for (int tt = 0; tt < 2; ++tt)
+        *reinterpret_cast<float4*>(a.Op + (pb0 * a.m + q) * D + 32 * j + 16 * tt + 4 * g) =
+            float4{ot[tt][qt][0], ot[tt][qt][1], ot[tt][qt][2], ot[tt][qt][3]};
+      if (g == 0) {
+        a.Mp[(pb0 * H + j) * MQ + q] = mrow[qt];
+        a.Lp[(pb0 * H + j) * MQ + q] = lrow[qt];
+      }
+    }
+  }
+}
+
 // backward.  Orientation A (points on accumulator rows, as the forward): P^T, dS^T -> the set's
 // dQp_h^T[f][q] += Kp_h^T[f][pt] dS^T[pt][q] (Kp^T through the LDS tile).  Orientation B
 // (queries on accumulator rows: S = Qp_h Kp_h^T recomputed with one more MFMA - the per-lane
@@ -2867,6 +3097,33 @@ int fq_attn_fwd256(const __bf16* Kp, const __bf16* Vp, const float* Qp, int B, i
   PCA_TRY(check_launch("k_fq_attn_fwd"));
   hipLaunchKernelGGL(k_fq_merge, dim3((unsigned)cdiv((int64_t)B * m * D, 256)), dim3(256), 0, st,
                      Op, Mp, Lp, Qp, B, S2, m, D, MQ, O, LSE);
+  return check_launch("k_fq_merge");
+}
+// fc_k / fc_v over the keys + the attention in one launch (k_fq_proj_fwd), then the merge; m = 32
+int fq_proj_attn_fwd256(const __bf16* X, const __bf16* WkB, const __bf16* WvB, const float* bk,
+                        const float* bv, const float* Qp, int B, int N, int m,
+                        const int32_t* lengths, __bf16* Kp, __bf16* Vp, float* Op, float* Mp,
+                        float* Lp, float* O, float* LSE, hipStream_t st) {
+  constexpr int D = 256;
+  PCA_REQUIRE(m > 16 && m <= 32, "fq_proj_attn_fwd256: m = %d", m);
+  int S2 = fq_splits256(B, N);
+  while (S2 > 1 && B * S2 > 256) S2 /= 2;         // 98 KiB of LDS: one workgroup per CU
+  FqProjArgs a{};
+  a.f.Qp = Qp; a.f.Op = Op; a.f.Mp = Mp; a.f.Lp = Lp;
+  a.f.B = B; a.f.N = N; a.f.m = m; a.f.S = S2; a.f.lengths = lengths;
+  a.f.scale = 1.0f / sqrtf((float)D);
+  a.f.scale_log2e = 1.4426950408889634f * a.f.scale;
+  a.X = X; a.WkB = WkB; a.WvB = WvB; a.bk = bk; a.bv = bv; a.KpO = Kp; a.VpO = Vp;
+  static std::once_flag once;
+  std::call_once(once, [] {
+    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(k_fq_proj_fwd),
+                              hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+  });
+  const size_t lds = (size_t)5 * 32 * D * 2 + (size_t)(D / 32) * 32 * 72;
+  hipLaunchKernelGGL(k_fq_proj_fwd, dim3(B, S2), dim3(512), lds, st, a);
+  PCA_TRY(check_launch("k_fq_proj_fwd"));
+  hipLaunchKernelGGL(k_fq_merge, dim3((unsigned)cdiv((int64_t)B * m * D, 256)), dim3(256), 0, st,
+                     Op, Mp, Lp, Qp, B, S2, m, D, 32, O, LSE);
   return check_launch("k_fq_merge");
 }
 int fq_attn_bwd256(const __bf16* Kp, const __bf16* Vp, const float* Qp, const float* dO,
