@@ -36,6 +36,9 @@ CASES = [  # name, din, d, h, m, C, N, lengths
     ("shipped_f32", 3, 64, 8, 64, 10, 60, [60, 33, 1]),
     ("cfg1", 2, 128, 4, 16, 50, 300, [300, 129, 128, 1, 257, 64]),
     ("cfg3", 3, 128, 4, 16, 50, 640, [640, 500, 131, 17]),
+    # configs[4] architecture (d = 256, 8 heads, 32 inducing points): the fused d = 256 kernels with
+    # lengths - range splits, ragged last tiles, a set shorter than one tile, a single point
+    ("cfg5", 3, 256, 8, 32, 10, 300, [300, 129, 31, 1, 257]),
 ]
 
 
@@ -45,7 +48,7 @@ def test_mask_equals_truncation_engine(dev, case, mode):
     import models
     from pca_hip import _lib, trainer
     name, din, d, h, m, C, N, lengths = case
-    if mode == "bf16" and d != 128:
+    if mode == "bf16" and d not in (128, 256):
         pytest.skip("no fused bf16 kernels for this architecture (runs the fp32 path)")
     B = len(lengths)
     torch.manual_seed(5)
