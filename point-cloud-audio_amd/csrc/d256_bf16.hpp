@@ -48,6 +48,9 @@ struct Wgrad256Jobs {
   Wgrad256Job j[8];
   int n;
 };
+int mab0_d256_prep_all(int n, const pca_mab_shape* const* shapes, const float* const* I,
+                       const pca_mab_params* params, void* const* saved, hipStream_t st);
+void mab0_d256_prep_done(bool on);
 void wgrad256_handoff_arm(bool on);
 bool wgrad256_handoff_pending();
 struct DxHandoff {            // mab1's dX = dQp Wq, deferred into the few-queries block's DX launch

@@ -259,6 +259,33 @@ size_t mab0_d256_fwd_ws_bytes(const pca_mab_shape& s) {
   return 256 + 2 * align256((size_t)D * D * 2) + fq_carve_saved(s, nullptr, nullptr);
 }
 
+static Mab0PrepJob fq_prep_job(const pca_mab_shape& s, const float* I, const pca_mab_params& p,
+                               const Fq256Saved& v) {
+  Mab0PrepJob a{};
+  const int m = s.nq;
+  a.I = I; a.Wq = p.wq; a.bq = p.bq; a.Wk = p.wk;
+  a.m = m; a.d = D; a.dq = s.dq; a.dk = s.dk; a.h = s.h; a.Rp = (int)cdiv(s.h * m, 32) * 32;
+  a.sl2e = 1.4426950408889634f / sqrtf((float)D);
+  a.Qp = v.Qp; a.Gf = fq_path(s) == FQ_PROJ ? nullptr : v.Gf;
+  a.Gb = fq_path(s) == FQ_PMA ? v.Gb : nullptr;
+  return a;
+}
+// The query side of every few-queries block of a training step (Qp, G: parameters only) in ONE
+// launch at the start of the forward instead of one ~20 us dependent chain per block; the blocks'
+// own forward calls then skip it (engine only: the saved blocks must exist, i.e. training).
+static thread_local bool g_prep256_done = false;
+int mab0_d256_prep_all(int n, const pca_mab_shape* const* shapes, const float* const* I,
+                       const pca_mab_params* params, void* const* saved, hipStream_t st) {
+  Mab0PrepJobs J{};
+  for (int i = 0; i < n; ++i) {
+    Fq256Saved v;
+    fq_carve_saved(*shapes[i], &v, saved[i]);
+    J.j[J.n++] = fq_prep_job(*shapes[i], I[i], params[i], v);
+  }
+  return mab0_prep_launch(J, st);
+}
+void mab0_d256_prep_done(bool on) { g_prep256_done = on; }
+
 int mab0_d256_fwd(const pca_mab_shape& s, const float* I, const void* X, const pca_mab_params& p,
                   float* Hout, void* saved, void* ws, hipStream_t st) {
   PCA_REQUIRE(mab0_d256_supported(s), "mab0_d256_fwd: unsupported shape");
@@ -271,15 +298,9 @@ int mab0_d256_fwd(const pca_mab_shape& s, const float* I, const void* X, const p
   fq_carve_saved(s, &v, saved != nullptr ? saved : (void*)(cw.base + cw.off));
   const int m = s.nq;
   const int64_t Bm = (int64_t)s.B * m, M = (int64_t)s.B * s.nk;
-  {   // Qp = I Wq^T + bq (and, layer 1, G = sl2e Qp_h Wk_h): batch invariant
+  if (!g_prep256_done) {   // Qp = I Wq^T + bq (and, layer 1, G = sl2e Qp_h Wk_h): batch invariant
     Mab0PrepJobs J{};
-    Mab0PrepJob a{};
-    a.I = I; a.Wq = p.wq; a.bq = p.bq; a.Wk = p.wk;
-    a.m = m; a.d = D; a.dq = s.dq; a.dk = s.dk; a.h = s.h; a.Rp = (int)cdiv(s.h * m, 32) * 32;
-    a.sl2e = 1.4426950408889634f / sqrtf((float)D);
-    a.Qp = v.Qp; a.Gf = fq_path(s) == FQ_PROJ ? nullptr : v.Gf;
-    a.Gb = fq_path(s) == FQ_PMA ? v.Gb : nullptr;
-    J.j[J.n++] = a;
+    J.j[J.n++] = fq_prep_job(s, I, p, v);
     PCA_TRY(mab0_prep_launch(J, st));
   }
   if (fq_path(s) == FQ_PMA) {

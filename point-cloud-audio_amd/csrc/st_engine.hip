@@ -214,6 +214,23 @@ int forward(const pca_st_config& c, const Layout& L, const Shapes& s, const floa
     }
     PCA_TRY(prep_all_launch(J, MJ, st));
   }
+  // d = 256: the query side of all three few-queries blocks in one launch (mab0_d256_prep_all)
+  const bool prep256 = training && s.m0[0].d == 256 && mab_kind(s.m0[0]) == 2 &&
+                       mab_kind(s.m0[1]) == 2 && mab_kind(s.pma) == 2 && !pma_head_ok(s);
+  struct PrepGuard {
+    bool on;
+    explicit PrepGuard(bool o) : on(o) {}
+    ~PrepGuard() { if (on) mab0_d256_prep_done(false); }
+  } prep_guard(prep256);
+  if (prep256) {
+    const pca_mab_shape* sh[3] = {&s.m0[0], &s.m0[1], &s.pma};
+    const float* Iq[3] = {p + L.I[0], p + L.I[1], p + L.S};
+    const pca_mab_params pr[3] = {params_at(p, L.mab0[0]), params_at(p, L.mab0[1]),
+                                  params_at(p, L.pma)};
+    void* sv[3] = {w.saved[0], w.saved[2], w.saved[4]};
+    PCA_TRY(mab0_d256_prep_all(3, sh, Iq, pr, sv, st));
+    mab0_d256_prep_done(true);
+  }
   for (int li = 0; li < 2; ++li) {
     void* sv0 = training ? w.saved[2 * li] : nullptr;
     void* sv1 = training ? w.saved[2 * li + 1] : nullptr;
