@@ -20,6 +20,7 @@
 #include "pma_head_bodies.hpp"
 
 #include <math.h>
+#include <stdlib.h>
 
 #include <mutex>
 
@@ -96,6 +97,7 @@ struct Mab0BwdArgs {
   int B, N, accumulate_dx, S;
   const int32_t* lengths;   // [B] valid points per set, or null
   int R;                    // real score rows (<= RP): only these rows of dG are non-zero
+  float* slabs;             // [B*S][R][128]: per-workgroup dG (summed in a fixed order afterwards)
 };
 
 template <int RP, bool ABF>
@@ -185,6 +187,18 @@ __global__ __launch_bounds__(256, 1) void k_mab0_bwd(const Mab0BwdArgs a) {
       *reinterpret_cast<bf16x8*>(myX + tr_off(row, ch)) = nx[e];
     }
     if (n0 + 128 < n_hi) fetch_tile(n0 + 128);
+    // the rows this tile's dX is added onto (mab1's dQ part) are fetched now, a whole tile of work
+    // ahead of their use: read at the end they were an exposed round trip per tile (5 of 37 us)
+    bf16x8 od[8];
+    if (ABF && a.dX != nullptr && a.accumulate_dx) {
+#pragma unroll
+      for (int e = 0; e < 8; ++e) {
+        const int c = lane + 64 * e, n = n0 + (c >> 4);
+        od[e] = *reinterpret_cast<const bf16x8*>(
+            reinterpret_cast<const __bf16*>(a.dX) +
+            ((int64_t)b * a.N + (n < n_hi ? n : n_hi - 1)) * DK + (c & 15) * 8);
+      }
+    }
     bf16x8 xrow[2][KS];
 #pragma unroll
     for (int pb = 0; pb < 2; ++pb)
@@ -286,9 +300,8 @@ __global__ __launch_bounds__(256, 1) void k_mab0_bwd(const Mab0BwdArgs a) {
         __bf16* pd = reinterpret_cast<__bf16*>(a.dX) +
                      ((int64_t)b * a.N + (n < n_hi ? n : n_hi - 1)) * DK + ch * 8;
         if (a.accumulate_dx) {
-          const bf16x8 o = *reinterpret_cast<const bf16x8*>(pd);
 #pragma unroll
-          for (int k = 0; k < 8; ++k) v[k] = (__bf16)((float)v[k] + (float)o[k]);
+          for (int k = 0; k < 8; ++k) v[k] = (__bf16)((float)v[k] + (float)od[e][k]);
         }
         if (n < n_hi) *reinterpret_cast<bf16x8*>(pd) = v;
       }
@@ -336,9 +349,12 @@ __global__ __launch_bounds__(256, 1) void k_mab0_bwd(const Mab0BwdArgs a) {
         slab[(16 * rb + 4 * g + e) * DK + 16 * ft + r] = dG[rb][ft][e];
   __syncthreads();
   const float* s0 = reinterpret_cast<const float*>(smem);
-  // (PMA: 4 of the 32 padded rows are real - 8x fewer atomics)
+  // (PMA: 4 of the 32 padded rows are real.)  One slab per workgroup, plain stores: 256 workgroups
+  // adding into one [R][128] block cost 11 of this kernel's 37 us at B = 128 - the adds to one
+  // address serialise at ~25 ns each - and made the result depend on their order
+  float* out = a.slabs + ((int64_t)b * a.S + sp) * a.R * DK;
   for (int i = tid; i < a.R * DK; i += 256)
-    atomicAdd(&a.DG[i], s0[i] + s0[RP * DK + i] + s0[2 * RP * DK + i] + s0[3 * RP * DK + i]);
+    out[i] = s0[i] + s0[RP * DK + i] + s0[2 * RP * DK + i] + s0[3 * RP * DK + i];
 }
 
 // layer 1 (dk <= 4): thread = (query row r, point partition); accumulates DG only.  The
@@ -627,6 +643,12 @@ int mab0_bwd_small_launch(const float* X, const float* Gf, const float* dTf, con
   return check_launch("k_mab0_bwd_small");
 }
 
+// point ranges per set of k_mab0_bwd (96+ KiB of LDS: one workgroup per CU)
+int mab0_bwd_splits(const pca_mab_shape& s) {
+  int S = mab0_splits(s);
+  while (S > 1 && s.B * S > 256) S /= 2;
+  return S;
+}
 size_t mab0_carve_bwd_ws(const pca_mab_shape& s, Mab0BwdWs* out, void* base) {
   Carver c(base);
   Mab0BwdWs w;
@@ -644,6 +666,7 @@ size_t mab0_carve_bwd_ws(const pca_mab_shape& s, Mab0BwdWs* out, void* base) {
   w.dTb = c.take<__bf16>((size_t)s.B * Rp * s.dk);
   w.dTt = c.take<__bf16>((size_t)s.B * Rp * s.dk);
   w.GtP = c.take<__bf16>((size_t)Rp * s.dk);
+  w.slabs = s.dk <= 4 ? nullptr : c.take<float>((size_t)s.B * mab0_bwd_splits(s) * R * s.dk);
   if (out) *out = w;
   return c.off;
 }
@@ -702,10 +725,9 @@ int mab0_bf16_bwd_ex(const pca_mab_shape& s, const float* I, const void* X,
                        w.Delta, s.nk, R, Rp, dk, w.DG, s.k_lengths, nullptr);
     PCA_TRY(check_launch("k_mab0_bwd_small"));
   } else {
-    int S = mab0_splits(s);
-    while (S > 1 && s.B * S > 256) S /= 2;     // 96+ KiB of LDS: one workgroup per CU
+    const int S = mab0_bwd_splits(s);
     Mab0BwdArgs a{X, v.Gb, v.GtP, w.dTb, w.dTt, w.LSEp, w.Delta, dX, w.DG, s.B, s.nk,
-                  dk_accumulate ? 1 : 0, S, s.k_lengths, R};
+                  dk_accumulate ? 1 : 0, S, s.k_lengths, R, w.slabs};
     size_t lds = 2 * (size_t)Rp * 256 + 2 * (size_t)128 * Rp * 2 + 2 * 4 * 32 * 256 +
                  2 * Rp * sizeof(float);
     if (lds < (size_t)4 * Rp * 128 * 4) lds = (size_t)4 * Rp * 128 * 4;     // merge slabs
@@ -733,6 +755,17 @@ int mab0_bf16_bwd_ex(const pca_mab_shape& s, const float* I, const void* X,
     else hipLaunchKernelGGL((k_mab0_bwd<64, false>), grid, dim3(256), lds, st, a);
     ps.end();
     PCA_TRY(check_launch("k_mab0_bwd"));
+    // dG = the workgroups' slabs added in a fixed order: with the other sums of the step when
+    // the caller defers them, else right away
+    const SlabSumJob sj{w.slabs, w.DG, s.B * S, R * dk, 0};
+    if (defer != nullptr) {
+      PCA_REQUIRE(defer->sums.n < 24, "mab0_bf16_bwd: slab-sum table full");
+      defer->sums.j[defer->sums.n++] = sj;
+    } else {
+      SlabSumJobs one{};
+      one.j[one.n++] = sj;
+      PCA_TRY(slab_sum_jobs(one, st));
+    }
   }
 
   // ---- parameter gradients of the epilogue: [B*m]-row reductions, ONE MFMA launch ----

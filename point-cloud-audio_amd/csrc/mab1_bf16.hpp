@@ -142,7 +142,9 @@ size_t mab1_carve_bwd_ws(const pca_mab_shape& s, Mab1BwdWs* out, void* base);
 struct Mab0BwdWs {
   float *dZ, *dO, *Th, *dTf, *Delta, *LSEp, *DG, *dQs, *dQp;
   __bf16 *dTb, *dTt, *GtP;
+  float* slabs;           // [workgroups][R][dk] partial dG of k_mab0_bwd
 };
+int mab0_bwd_splits(const pca_mab_shape& s);
 size_t mab0_carve_bwd_ws(const pca_mab_shape& s, Mab0BwdWs* out, void* base);
 
 // flags of the *_ex host entry points used by the fused ISAB path
@@ -290,7 +292,19 @@ int mab0_post_launch(const Mab0PostJobs& J, hipStream_t st);
 // phase - one bf16 and one fp32 weight-gradient launch (job tables) and one pair of post
 // launches instead of one set per block.  Their operands live in per-block workspaces that
 // stay untouched until then.
+// fixed-order sums of per-workgroup partial tensors ([S][n] fp32 -> out[n]), several per launch
+struct SlabSumJob {
+  const float* slabs;
+  float* out;
+  int S, n, accumulate;
+};
+struct SlabSumJobs {
+  SlabSumJob j[24];
+  int n;
+};
+int slab_sum_jobs(const SlabSumJobs& J, hipStream_t st);
 struct BwdDefer {
+  SlabSumJobs sums;       // partial sums the post stages / the optimizer read: run first
   Mab0PostJobs posts;
   WgradJobs wg_bf16;      // G, A bf16, M = B*N rows   (512 rows per workgroup)
   WgradJobs wg_f32;       // G, A fp32, M = B*m rows   (64 rows per workgroup)

@@ -17,6 +17,7 @@
 #include "terminal_bodies.hpp"
 
 #include <math.h>
+#include <stdlib.h>
 
 #include <mutex>
 
@@ -50,6 +51,7 @@ struct Mab1BwdArgs {
   int B, N, tiles_per_set;
   int tpw;                  // consecutive tiles of ONE set per workgroup (fused mode)
   float scale, scale_log2e;
+  int dbg_wg;               // PCA_DEBUG_CLOCKS builds: the workgroup whose phase stamps are kept
 };
 
 typedef __attribute__((address_space(3))) s16x4 lds_s16x4;
@@ -70,7 +72,9 @@ __device__ __forceinline__ bf16x8 tr_frag_small(const char* img, int rb, int col
 }
 
 #ifdef PCA_DEBUG_CLOCKS
-#define PCA_STAMP(i) do { if (a.dbg && blockIdx.x == 0 && threadIdx.x == 0) a.dbg[dbg_n++] = ((long long)(i) << 48) | (wall_clock64() & 0xffffffffffffLL); } while (0)
+// (kept in scalar registers and written once at the end: a store per stamp would sit in vmcnt and be
+//  waited for by the next phase's loads)
+#define PCA_STAMP(i) do { stamp_[i] = wall_clock64(); } while (0)
 #else
 #define PCA_STAMP(i) do {} while (0)
 #endif
@@ -101,7 +105,9 @@ void k_mab1_bwd(const Mab1BwdArgs a) {
   const int tid = threadIdx.x, lane = tid & 63, wave8 = tid >> 6;
   const int wave = wave8 & 3, sub = wave8 >> 2;
   const int r = lane & 15, g = lane >> 4;
-  int dbg_n = 0; (void)dbg_n;
+#ifdef PCA_DEBUG_CLOCKS
+  long long stamp_[10] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0};
+#endif
   PCA_STAMP(0);
 
   {
@@ -122,6 +128,7 @@ void k_mab1_bwd(const Mab1BwdArgs a) {
     }
   }
 
+  PCA_STAMP(8);
   const int total_tiles = a.B * a.tiles_per_set;
   int cur_b = -1;
   if (a.zero_ptr != nullptr)
@@ -510,6 +517,14 @@ void k_mab1_bwd(const Mab1BwdArgs a) {
     }
   }
   PCA_STAMP(7);
+#ifdef PCA_DEBUG_CLOCKS
+  if (a.dbg && (int)blockIdx.x == a.dbg_wg && threadIdx.x == 0)
+    for (int i = 0; i < 10; ++i) a.dbg[i] = ((long long)i << 48) | (stamp_[i] & 0xffffffffffffLL);
+  if (a.dbg && threadIdx.x == 0 && blockIdx.x < 1024) {
+    a.dbg[64 + 2 * blockIdx.x] = stamp_[0];
+    a.dbg[65 + 2 * blockIdx.x] = stamp_[7];
+  }
+#endif
 }
 
 // ---------------------------------------------------------------------------------
@@ -777,14 +792,20 @@ __global__ void k_sum_parts(const float* __restrict__ kp, const float* __restric
 long long* debug_clock_buffer(int which) {
   static long long* buf[2] = {nullptr, nullptr};
   if (buf[which] == nullptr) {
-    (void)hipHostMalloc(reinterpret_cast<void**>(&buf[which]), 64 * sizeof(long long), 0);
-    for (int i = 0; i < 64; ++i) buf[which][i] = 0;
+    (void)hipHostMalloc(reinterpret_cast<void**>(&buf[which]), (64 + 2048) * sizeof(long long), 0);
+    for (int i = 0; i < 64 + 2048; ++i) buf[which][i] = 0;
     static int reg[2] = {0, 1};
     struct P { static void dump(int w) {
       long long* b = buf[w]; long long t0 = b[0] & 0xffffffffffffLL;
       fprintf(stderr, "k_mab1_bwd[%d] stamps (phase:us):", w);
       for (int i = 0; i < 64 && (i == 0 || b[i]); ++i)
         fprintf(stderr, " %lld:%.2f", b[i] >> 48, ((b[i] & 0xffffffffffffLL) - t0) / 100.0);
+      fprintf(stderr, "\n");
+      long long s0 = 0; int n = 0;
+      for (int i = 0; i < 1024; ++i) if (b[64 + 2 * i]) { if (!n || b[64 + 2 * i] < s0) s0 = b[64 + 2 * i]; ++n; }
+      fprintf(stderr, "k_mab1_bwd[%d] per-workgroup start/end us (%d wgs):", w, n);
+      for (int i = 0; i < n; i += (n > 64 ? n / 32 : 1))
+        fprintf(stderr, " %d:%.1f/%.1f", i, (b[64 + 2 * i] - s0) / 100.0, (b[65 + 2 * i] - s0) / 100.0);
       fprintf(stderr, "\n"); } };
     if (which == 0) atexit([] { P::dump(0); }); else atexit([] { P::dump(1); });
     (void)reg;
@@ -893,6 +914,8 @@ int bwd_defer_flush(BwdDefer& D, hipStream_t st) {
     PCA_TRY(wgrad128_launch(D.wg_f32, false, false, 128, ts));   // 64: 18.7 us, 128: 14.2, 256: 15.3
     D.wg_f32.n = 0;
   }
+  PCA_TRY(slab_sum_jobs(D.sums, ts));
+  D.sums.n = 0;
   PCA_TRY(terminal_launch(D, st));
   D.posts.n = 0;
   D.has_cls = D.has_sw = 0;
@@ -964,6 +987,7 @@ int mab1_bf16_bwd_ex(const pca_mab_shape& s, const void* X, const float* H,
   a.B = s.B; a.N = s.nq; a.tiles_per_set = (int)cdiv(s.nq, TP);
   a.scale = 1.0f / sqrtf((float)d);
   a.scale_log2e = 1.4426950408889634f * a.scale;
+  a.dbg_wg = getenv("PCA_DBG_WG") ? atoi(getenv("PCA_DBG_WG")) : 0;
   // reference-formulation backward FLOPs of the block: 2x forward
   const double flops = 4.0 * M * ((double)s.dq * d + (double)d * d + 2.0 * MI * d);
   // algorithmic HBM bytes (each operand once): dY in, X in, dX out
