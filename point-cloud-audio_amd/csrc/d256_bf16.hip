@@ -24,6 +24,7 @@
 // All activations cross these kernels in bf16 ([rows][256], row-major); accumulation, softmax
 // statistics, biases and residuals are fp32.  Layout conventions: mfma_common.hpp.
 #include "d256_bf16.hpp"
+#include "slab_sum_body.hpp"
 
 #include <math.h>
 
@@ -3223,47 +3224,15 @@ int slab_sum(const float* slabs, int S, int n, float* out, int accumulate, hipSt
 namespace {
 // several slab sums in one launch (blockIdx.y = job); same walk and summation order as k_slab_sum
 __global__ __launch_bounds__(256) void k_slab_sum_jobs(const SlabSumJobs jobs) {
-  const SlabSumJob j = jobs.j[blockIdx.y];
-  __shared__ float4 red[4][64];
-  const int sg = threadIdx.x >> 6, c = threadIdx.x & 63;
-  const int i = blockIdx.x * 256 + 4 * c;
-  if (blockIdx.x * 256 >= j.n) return;
-  float4 t = {0.f, 0.f, 0.f, 0.f};
-  if (i < j.n) {
-    const float* s = j.slabs + i;
-    int w = sg;
-    for (; w + 28 < j.S; w += 32) {
-      float4 v[8];
-#pragma unroll
-      for (int u = 0; u < 8; ++u)
-        v[u] = *reinterpret_cast<const float4*>(s + (int64_t)(w + 4 * u) * j.n);
-#pragma unroll
-      for (int u = 0; u < 8; ++u) { t.x += v[u].x; t.y += v[u].y; t.z += v[u].z; t.w += v[u].w; }
-    }
-    for (; w < j.S; w += 4) {
-      const float4 v = *reinterpret_cast<const float4*>(s + (int64_t)w * j.n);
-      t.x += v.x; t.y += v.y; t.z += v.z; t.w += v.w;
-    }
-  }
-  red[sg][c] = t;
-  __syncthreads();
-  if (sg == 0 && i < j.n) {
-    float4 o = j.accumulate ? *reinterpret_cast<float4*>(j.out + i) : float4{0.f, 0.f, 0.f, 0.f};
-#pragma unroll
-    for (int q = 0; q < 4; ++q) {
-      const float4 v = red[q][c];
-      o.x += v.x; o.y += v.y; o.z += v.z; o.w += v.w;
-    }
-    *reinterpret_cast<float4*>(j.out + i) = o;
-  }
+  __shared__ float4 red[4 * 64];
+  slab_sum_body(jobs.j[blockIdx.y], blockIdx.x, threadIdx.x, red);
 }
 }  // namespace
 int slab_sum_jobs(const SlabSumJobs& J, hipStream_t st) {
   if (J.n == 0) return PCA_OK;
   int nmax = 0;
   for (int i = 0; i < J.n; ++i) {
-    PCA_REQUIRE(J.j[i].n % 4 == 0 && ((uintptr_t)J.j[i].out & 15) == 0 &&
-                    ((uintptr_t)J.j[i].slabs & 15) == 0, "slab_sum_jobs: alignment");
+    PCA_REQUIRE(slab_sum_job_ok(J.j[i]), "slab_sum_jobs: alignment");
     nmax = J.j[i].n > nmax ? J.j[i].n : nmax;
   }
   hipLaunchKernelGGL(k_slab_sum_jobs, dim3((unsigned)cdiv(nmax, 256), (unsigned)J.n), dim3(256), 0,

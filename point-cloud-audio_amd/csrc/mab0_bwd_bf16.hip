@@ -18,6 +18,7 @@
 #include "mab1_bf16.hpp"
 #include "terminal_bodies.hpp"
 #include "pma_head_bodies.hpp"
+#include "slab_sum_body.hpp"
 
 #include <math.h>
 #include <stdlib.h>
@@ -481,7 +482,7 @@ __device__ __forceinline__ void post1_body(const Mab0PostJob& a, int blk) {
 __device__ __forceinline__ void post1_body(const Mab0PostJob& a, int blk);
 __global__ __launch_bounds__(256) void k_terminal1(const Mab0PostJobs jobs, const ClsWgradArgs c,
                                                    int has_cls, const SmallWgradArgs w,
-                                                   int has_sw) {
+                                                   int has_sw, const SlabSumJobs late) {
   const int y = blockIdx.y;
   if (y < jobs.n) {
     post1_body(jobs.j[y], blockIdx.x);
@@ -489,10 +490,14 @@ __global__ __launch_bounds__(256) void k_terminal1(const Mab0PostJobs jobs, cons
     if ((int)blockIdx.x < c.C)
       cls_wgrad_body(c.dlogits, c.P, c.lossv, c.corrv, c.B, c.d, c.C, c.dWc, c.dbc, c.loss_out,
                      c.stats, blockIdx.x);
-  } else if (has_sw) {
+  } else if (has_sw && y == jobs.n + has_cls) {
     if ((int64_t)blockIdx.x * w.rows_per_wg < w.M)
       wgrad_small_body<float>(w.G, w.X, w.M, w.dq, w.rows_per_wg, w.x_head_stride, w.dW, w.db,
                               blockIdx.x);
+  } else {
+    // rider rows: the weight-gradient slabs of this step, added in a fixed order
+    __shared__ float4 red[4 * 64];
+    slab_sum_body(late.j[y - jobs.n - has_cls - has_sw], blockIdx.x, threadIdx.x, red);
   }
 }
 // stage 2: dWq += dQp^T I ; dbq += colsum(dQp) ; dI += dQp Wq
@@ -589,8 +594,10 @@ int pma_head_launch(const pca_mab_shape& s, const pca_mab_params& p, void* saved
   return PCA_OK;
 }
 
-int terminal_launch(const BwdDefer& D, hipStream_t st) {
-  if (!D.has_cls && !D.has_sw) return mab0_post_launch(D.posts, st);
+int terminal_launch(const BwdDefer& D, hipStream_t st, const SlabSumJobs* late_in) {
+  SlabSumJobs late{};
+  if (late_in != nullptr) late = *late_in;
+  if (!D.has_cls && !D.has_sw && late.n == 0) return mab0_post_launch(D.posts, st);
   const Mab0PostJobs& J = D.posts;
   int n1 = 0;
   for (int i = 0; i < J.n; ++i) {
@@ -603,9 +610,15 @@ int terminal_launch(const BwdDefer& D, hipStream_t st) {
     const int gs = (int)cdiv(D.sw.M, D.sw.rows_per_wg);
     gx = gs > gx ? gs : gx;
   }
+  for (int i = 0; i < late.n; ++i) {
+    PCA_REQUIRE(slab_sum_job_ok(late.j[i]), "terminal: rider alignment");
+    const int need = (int)cdiv(late.j[i].n, 256);
+    gx = need > gx ? need : gx;
+  }
   hipStream_t ts = terminal_stream(st);
-  hipLaunchKernelGGL(k_terminal1, dim3(gx, J.n + (D.has_cls ? 1 : 0) + (D.has_sw ? 1 : 0)),
-                     dim3(256), 0, ts, J, D.cls, D.has_cls, D.sw, D.has_sw);
+  hipLaunchKernelGGL(k_terminal1,
+                     dim3(gx, J.n + (D.has_cls ? 1 : 0) + (D.has_sw ? 1 : 0) + late.n),
+                     dim3(256), 0, ts, J, D.cls, D.has_cls ? 1 : 0, D.sw, D.has_sw ? 1 : 0, late);
   PCA_TRY(check_launch("k_terminal1"));
   if (J.n == 0) return PCA_OK;
   int n2 = 0;

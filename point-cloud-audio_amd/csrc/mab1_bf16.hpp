@@ -93,14 +93,24 @@ struct WgradJob {
   float* db;
   int64_t M;
   int g_lo, g_hi;
+  float* slab;            // set by the launcher: [workgroups][(g_hi - g_lo) * 128 (+ 128 with db)]
+                          // partials, summed in a fixed order afterwards (null: fp32 atomics)
 };
 struct WgradJobs {
   WgradJob j[16];
   int n;
 };
 // g_bf16 / a_bf16: element type of every job's G / A (bf16 or fp32)
+struct SlabSumJobs;
+struct WgradSlabs {          // optional slab mode of wgrad128_launch
+  float* ws;                 // partials go here (cap bytes) ...
+  size_t cap;
+  SlabSumJobs* sums_out;     // ... and their sum jobs are appended here (run them afterwards)
+  const SlabSumJobs* riders; // sums that are due now: extra workgroup rows of this launch
+  size_t used;               // out: bytes of ws taken
+};
 int wgrad128_launch(const WgradJobs& jobs, bool g_bf16, bool a_bf16, int rows_per_wg,
-                    hipStream_t st);
+                    hipStream_t st, WgradSlabs* slabs = nullptr);
 // dW[128 x dq] += G[M x 128]^T . X_h[M x dq] (dq <= 4; X_h = X + head(f)*x_head_stride), db += colsum
 struct BwdDefer;
 int wgrad_small_f32_launch(const float* G, const float* X, int64_t M, int dq,
@@ -297,14 +307,21 @@ struct SlabSumJob {
   const float* slabs;
   float* out;
   int S, n, accumulate;
+  int stride;             // floats between consecutive slabs (0: n)
 };
 struct SlabSumJobs {
-  SlabSumJob j[24];
+  SlabSumJob j[40];
   int n;
 };
+inline bool slab_sum_job_ok(const SlabSumJob& j) {      // 16-byte accesses throughout
+  return j.n % 4 == 0 && j.stride % 4 == 0 && ((uintptr_t)j.out & 15) == 0 &&
+         ((uintptr_t)j.slabs & 15) == 0;
+}
 int slab_sum_jobs(const SlabSumJobs& J, hipStream_t st);
 struct BwdDefer {
-  SlabSumJobs sums;       // partial sums the post stages / the optimizer read: run first
+  SlabSumJobs sums;       // partial sums the post stages read: run before them
+  float* slab_ws;         // room for the weight-gradient partials of the two deferred lists
+  size_t slab_cap;        // (bytes; null / 0: those reductions use fp32 atomics)
   Mab0PostJobs posts;
   WgradJobs wg_bf16;      // G, A bf16, M = B*N rows   (512 rows per workgroup)
   WgradJobs wg_f32;       // G, A fp32, M = B*m rows   (64 rows per workgroup)
@@ -315,6 +332,7 @@ struct BwdDefer {
   int has_cls, has_sw;
 };
 int bwd_defer_flush(BwdDefer& D, hipStream_t st);
+bool wgrad_slabs_on();       // PCA_WGRAD_SLABS=1: weight gradients of the fused d = 128 path without atomics
 // PMA epilogue + classifier + cross-entropy (forward and backward) + PMA backward epilogue of the
 // train step in ONE launch per set (after mab0_bf16_fwd_ex(..., PCA_F_SKIP_EPILOGUE); followed
 // by mab0_bf16_bwd_ex(..., PCA_F_SKIP_HEAD)).  P [B, d] receives the pooled features; the
@@ -324,7 +342,8 @@ int pma_head_launch(const pca_mab_shape& s, const pca_mab_params& p, void* saved
                     float grad_scale, float* logits, float* dlogits, float* dP, float* dWc,
                     float* dbc, float* loss_out, float* stats, float* cls_ws, BwdDefer* defer,
                     hipStream_t st);
-int terminal_launch(const BwdDefer& D, hipStream_t st);    // post stages + riders
+// post stages + riders (`late`: sums nobody reads before the optimizer, e.g. weight gradients)
+int terminal_launch(const BwdDefer& D, hipStream_t st, const SlabSumJobs* late = nullptr);
 // launch `jobs` now, or append them to the matching list of `defer`
 int wgrad128_defer(BwdDefer* defer, const WgradJobs& jobs, bool bf16, int rows_per_wg,
                    hipStream_t st);

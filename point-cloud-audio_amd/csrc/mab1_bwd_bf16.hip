@@ -15,6 +15,7 @@
 // The tiny [B*m, d] projections of H (fc_k, fc_v) are differentiated with the fp32 GEMMs.
 #include "mab1_bf16.hpp"
 #include "terminal_bodies.hpp"
+#include "slab_sum_body.hpp"
 
 #include <math.h>
 #include <stdlib.h>
@@ -569,10 +570,16 @@ __device__ __forceinline__ bf16x8 load8(const float* p) {
 // per CU; the kernel runs on at most half the CUs because every workgroup costs 16384 atomics):
 // group q takes the 32-row tiles q, q + NG, ...; the groups' [128][128] blocks are summed in LDS.
 template <typename GT, typename AT, int NG>
-__global__ __launch_bounds__(256 * NG) void k_wgrad128(const WgradJobs jobs, int rows_per_wg) {
+__global__ __launch_bounds__(256 * NG) void k_wgrad128(const WgradJobs jobs, int rows_per_wg,
+                                                       const SlabSumJobs riders) {
   constexpr int D = 128, NT = 256 * NG;
   // 64 KiB: 2 x 2 staging tiles per group during the loop, the fp32 [128][128] result afterwards
   __shared__ __attribute__((aligned(16))) char lds[4 * 32 * 256 * 2];
+  if ((int)blockIdx.y >= jobs.n) {          // rider rows: partial sums that are due now
+    slab_sum_body(riders.j[blockIdx.y - jobs.n], blockIdx.x, threadIdx.x,
+                  reinterpret_cast<float4*>(lds));
+    return;
+  }
   const int tid = threadIdx.x, lane = tid & 63, wave = (tid >> 6) & 3, grp = tid >> 8;
   const int gtid = tid & 255;
   char (*sG)[32 * 256] = reinterpret_cast<char (*)[32 * 256]>(lds + grp * (4 * 32 * 256));
@@ -660,7 +667,15 @@ __global__ __launch_bounds__(256 * NG) void k_wgrad128(const WgradJobs jobs, int
     }
     __syncthreads();
   }
-  for (int i = job.g_lo * D + tid; i < job.g_hi * D; i += NT) atomicAdd(&job.dW[i], res[i]);
+  // slab mode: this workgroup's [rows][128] block (+ its 128 bias sums) as plain stores
+  const int n1 = (job.g_hi - job.g_lo) * D;
+  float* slab = job.slab == nullptr
+                    ? nullptr
+                    : job.slab + (int64_t)blockIdx.x * (n1 + (job.db != nullptr ? D : 0));
+  if (slab != nullptr)
+    for (int i = tid; i < n1; i += NT) slab[i] = res[job.g_lo * D + i];
+  else
+    for (int i = job.g_lo * D + tid; i < job.g_hi * D; i += NT) atomicAdd(&job.dW[i], res[i]);
   if (job.db != nullptr) {
     // threads with equal (tid & 15) hold partial sums of the same 8 columns
     __syncthreads();
@@ -672,7 +687,8 @@ __global__ __launch_bounds__(256 * NG) void k_wgrad128(const WgradJobs jobs, int
       float t = 0.f;
 #pragma unroll
       for (int q = 0; q < 16 * NG; ++q) t += red[q * D + tid];
-      atomicAdd(&job.db[tid], t);
+      if (slab != nullptr) slab[n1 + tid] = t;
+      else atomicAdd(&job.db[tid], t);
     }
   }
 }
@@ -859,23 +875,57 @@ size_t mab1_bf16_bwd_ws_bytes(const pca_mab_shape& s) {
   return mab1_carve_bwd_ws(s, nullptr, nullptr);
 }
 
-int wgrad128_launch(const WgradJobs& jobs, bool g_bf16, bool a_bf16, int rows_per_wg,
-                    hipStream_t st) {
+int wgrad128_launch(const WgradJobs& jobs_in, bool g_bf16, bool a_bf16, int rows_per_wg,
+                    hipStream_t st, WgradSlabs* sl) {
+  WgradJobs jobs = jobs_in;
   int64_t maxM = 0;
   for (int i = 0; i < jobs.n; ++i) maxM = jobs.j[i].M > maxM ? jobs.j[i].M : maxM;
-  if (maxM == 0 || jobs.n == 0) return PCA_OK;
-  const dim3 grid((unsigned)cdiv(maxM, rows_per_wg), (unsigned)jobs.n);
+  SlabSumJobs riders{};
+  if (sl != nullptr && sl->riders != nullptr) riders = *sl->riders;
+  if (maxM == 0 || jobs.n == 0) return slab_sum_jobs(riders, st);
+  if (sl != nullptr && sl->ws != nullptr) {
+    // one slab per workgroup and job; more rows per workgroup until they fit
+    for (;;) {
+      size_t need = 0;
+      for (int i = 0; i < jobs.n; ++i) {
+        const WgradJob& j = jobs.j[i];
+        need += (size_t)cdiv(j.M, rows_per_wg) * ((j.g_hi - j.g_lo) * 128 + (j.db ? 128 : 0)) * 4;
+      }
+      if (need <= sl->cap) break;
+      rows_per_wg *= 2;
+    }
+    float* at = sl->ws;
+    for (int i = 0; i < jobs.n; ++i) {
+      WgradJob& j = jobs.j[i];
+      if (j.M <= 0) continue;
+      const int nwg = (int)cdiv(j.M, rows_per_wg), n1 = (j.g_hi - j.g_lo) * 128;
+      const int stride = n1 + (j.db ? 128 : 0);
+      j.slab = at;
+      PCA_REQUIRE(sl->sums_out->n + 2 <= 40, "wgrad128: slab-sum table full");
+      sl->sums_out->j[sl->sums_out->n++] = SlabSumJob{at, j.dW + (int64_t)j.g_lo * 128, nwg, n1, 1, stride};
+      if (j.db) sl->sums_out->j[sl->sums_out->n++] = SlabSumJob{at + n1, j.db, nwg, 128, 1, stride};
+      at += (size_t)nwg * stride;
+    }
+    sl->used = (size_t)(at - sl->ws) * sizeof(float);
+  }
+  unsigned gx = (unsigned)cdiv(maxM, rows_per_wg);
+  for (int i = 0; i < riders.n; ++i) {
+    PCA_REQUIRE(slab_sum_job_ok(riders.j[i]), "wgrad128: rider alignment");
+    const unsigned need = (unsigned)cdiv(riders.j[i].n, 256);
+    gx = need > gx ? need : gx;
+  }
+  const dim3 grid(gx, (unsigned)(jobs.n + riders.n));
   // two row groups per workgroup when every workgroup has at least four tiles to share
   const bool two = rows_per_wg >= 128;
   if (g_bf16 && a_bf16) {
-    if (two) hipLaunchKernelGGL((k_wgrad128<__bf16, __bf16, 2>), grid, dim3(512), 0, st, jobs, rows_per_wg);
-    else hipLaunchKernelGGL((k_wgrad128<__bf16, __bf16, 1>), grid, dim3(256), 0, st, jobs, rows_per_wg);
+    if (two) hipLaunchKernelGGL((k_wgrad128<__bf16, __bf16, 2>), grid, dim3(512), 0, st, jobs, rows_per_wg, riders);
+    else hipLaunchKernelGGL((k_wgrad128<__bf16, __bf16, 1>), grid, dim3(256), 0, st, jobs, rows_per_wg, riders);
   } else if (g_bf16) {
-    if (two) hipLaunchKernelGGL((k_wgrad128<__bf16, float, 2>), grid, dim3(512), 0, st, jobs, rows_per_wg);
-    else hipLaunchKernelGGL((k_wgrad128<__bf16, float, 1>), grid, dim3(256), 0, st, jobs, rows_per_wg);
+    if (two) hipLaunchKernelGGL((k_wgrad128<__bf16, float, 2>), grid, dim3(512), 0, st, jobs, rows_per_wg, riders);
+    else hipLaunchKernelGGL((k_wgrad128<__bf16, float, 1>), grid, dim3(256), 0, st, jobs, rows_per_wg, riders);
   } else if (!a_bf16) {
-    if (two) hipLaunchKernelGGL((k_wgrad128<float, float, 2>), grid, dim3(512), 0, st, jobs, rows_per_wg);
-    else hipLaunchKernelGGL((k_wgrad128<float, float, 1>), grid, dim3(256), 0, st, jobs, rows_per_wg);
+    if (two) hipLaunchKernelGGL((k_wgrad128<float, float, 2>), grid, dim3(512), 0, st, jobs, rows_per_wg, riders);
+    else hipLaunchKernelGGL((k_wgrad128<float, float, 1>), grid, dim3(256), 0, st, jobs, rows_per_wg, riders);
   } else {
     set_error("wgrad128: fp32 G with bf16 A is not instantiated");
     return PCA_EUNSUPPORTED;
@@ -895,28 +945,54 @@ int wgrad128_defer(BwdDefer* defer, const WgradJobs& jobs, bool bf16, int rows_p
   return PCA_OK;
 }
 
+bool wgrad_slabs_on() {
+  static const bool on = [] {
+    const char* e = getenv("PCA_WGRAD_SLABS");
+    return e != nullptr && e[0] == '1';
+  }();
+  return on;
+}
 int bwd_defer_flush(BwdDefer& D, hipStream_t st) {
   hipStream_t ts = terminal_stream(st);
+  // The sums the post stages read (D.sums: dG of the few-queries blocks) ride in the first
+  // weight-gradient launch as extra workgroup rows.  Slab mode (PCA_WGRAD_SLABS=1, the caller lent
+  // room): the weight gradients themselves use no fp32 atomics either - per-workgroup partials,
+  // summed in a fixed order by rider rows of k_terminal1 (`late`: only the optimizer reads them).
+  // Off by default: at configs[1] it measured 0.343 ... 0.361 ms/step against a steady 0.348 with
+  // the atomics, depending on where the 35 MB of partials happen to lie (six same-box A/B runs).
+  const bool slab_mode = wgrad_slabs_on() && D.slab_ws != nullptr && D.slab_cap > 0;
+  SlabSumJobs late{};
+  size_t used = 0;          // the two lists' slabs lie back to back
   if (D.wg_bf16.n > 0) {
     double rows = 0;
     for (int i = 0; i < D.wg_bf16.n; ++i) rows += (double)D.wg_bf16.j[i].M;
     ProfScope ps(PCA_K_WGRAD, ts, 2.0 * rows * 128 * 128, 4.0 * rows * 128);
-    // every workgroup costs 16384 atomics and the atomic rate is the floor of this kernel: aim at
-    // ~200 workgroups over all jobs (512 rows for one B*N-row job, 1024 for three, ...)
+    // every workgroup costs a 64 KiB slab (16384 atomics without the slabs): aim at ~200
+    // workgroups over all jobs (512 rows for one B*N-row job, 1024 for three, ...)
     // (measured at 3 x 65536 rows: 512 -> 41 us, 768 -> 41, 1024 -> 31, 1536 -> 31, 2048 -> 39)
     int rpw = 512 * (int)((rows + 98303.0) / 98304.0);
     rpw = rpw < 512 ? 512 : (rpw > 1024 ? 1024 : rpw);
-    PCA_TRY(wgrad128_launch(D.wg_bf16, true, true, rpw, ts));
+    static const int rpw_env = getenv("PCA_WGRAD_RPW") ? atoi(getenv("PCA_WGRAD_RPW")) : 0;
+    if (rpw_env > 0) rpw = rpw_env;
+    WgradSlabs sl{slab_mode ? D.slab_ws : nullptr, D.slab_cap * 3 / 4, &late, &D.sums, 0};
+    PCA_TRY(wgrad128_launch(D.wg_bf16, true, true, rpw, ts, &sl));
+    used = (sl.used + 255) & ~(size_t)255;
     ps.end();
     D.wg_bf16.n = 0;
+    D.sums.n = 0;
   }
   if (D.wg_f32.n > 0) {
-    PCA_TRY(wgrad128_launch(D.wg_f32, false, false, 128, ts));   // 64: 18.7 us, 128: 14.2, 256: 15.3
+    // 64: 18.7 us, 128: 14.2, 256: 15.3
+    WgradSlabs sl{slab_mode ? D.slab_ws + used / sizeof(float) : nullptr, D.slab_cap - used, &late,
+                  &D.sums, 0};
+    static const int rpw32_env = getenv("PCA_WGRAD_RPW_F32") ? atoi(getenv("PCA_WGRAD_RPW_F32")) : 0;
+    PCA_TRY(wgrad128_launch(D.wg_f32, false, false, rpw32_env > 0 ? rpw32_env : 128, ts, &sl));
     D.wg_f32.n = 0;
+    D.sums.n = 0;
   }
-  PCA_TRY(slab_sum_jobs(D.sums, ts));
+  PCA_TRY(slab_sum_jobs(D.sums, ts));        // (nobody carried them)
   D.sums.n = 0;
-  PCA_TRY(terminal_launch(D, st));
+  PCA_TRY(terminal_launch(D, st, &late));
   D.posts.n = 0;
   D.has_cls = D.has_sw = 0;
   return PCA_OK;

@@ -3,6 +3,7 @@
 // forward -> cross-entropy -> backward against flat parameter / gradient vectors laid out
 // in state_dict order.  No Python, autograd or allocator sits between the kernels, so the
 // caller can capture the call in a hipGraph.
+#include <stdlib.h>
 #include "mab1_bf16.hpp"
 #include "d256_bf16.hpp"
 
@@ -127,6 +128,8 @@ struct Ws {
                              // reductions run on the helper stream while the main stream moves on
   IsabImg img[2];            // weight images of the two ISABs (fused bf16 path)
   bool fused[2];
+  float* wg_slabs;           // weight-gradient partials of the deferred reductions (fused d = 128)
+  size_t wg_slab_bytes;
 };
 
 inline size_t carve(const pca_st_config& c, int training, Ws* out, void* base) {
@@ -173,6 +176,13 @@ inline size_t carve(const pca_st_config& c, int training, Ws* out, void* base) {
   w.scratch = cv.take<char>(max_scratch);
   for (int li = 0; li < 2; ++li)
     w.scratch_bw[li] = training ? (void*)cv.take<char>(max_scratch) : w.scratch;
+  if ((w.fused[0] || w.fused[1]) && wgrad_slabs_on()) {
+    // two lists (B*N-row and B*m-row jobs) of up to ~600 [128 x 128 (+128)] fp32 slabs each;
+    // bwd_defer_flush gives a workgroup more rows when a list would not fit
+    static const int slab_mb = getenv("PCA_WGRAD_SLAB_MB") ? atoi(getenv("PCA_WGRAD_SLAB_MB")) : 40;
+    w.wg_slab_bytes = 2 * (size_t)slab_mb * 1024 * 1024;
+    w.wg_slabs = cv.take<float>(w.wg_slab_bytes / sizeof(float));
+  }
   if (out) *out = w;
   return cv.off;
 }
@@ -325,6 +335,8 @@ int pca_st_train_fwd_bwd(const pca_st_config* c, const float* params, const floa
   // shared-query gradients of the fused blocks of this call: one pair of launches at the end
   // (their inputs live in per-block workspaces, which stay untouched until then)
   pca::BwdDefer posts{};
+  posts.slab_ws = w.wg_slabs;
+  posts.slab_cap = w.wg_slab_bytes;
   if (phase != 1) {
     PCA_TRY(pca::forward(*c, L, s, p, X, w, true, st));
     if (pca::pma_head_ok(s)) {
