@@ -560,6 +560,237 @@ __global__ __launch_bounds__(256) void k_pma_head(const PmaHeadArgs a) {
                        a.dO, a.Th, a.dTf, a.dTb, a.dTt, a.Delta, a.LSEp, a.B, a.zero_ptr,
                        a.zero_n, b);
 }
+
+// The same chain for the shape the engine actually runs it on (one seed, d = dk = 128, four heads,
+// C <= 64): every weight element a thread will need - 64 + 64 + 32 + 32 + 64 + 64 floats over the
+// six GEMV stages - is requested before the first stage, and the stages hand over through LDS
+// instead of through the global arrays they also write.  The generic bodies above spend the
+// launch in ~25 dependent L2 round trips (16 loads in flight each, one batch after the other,
+// plus the re-reads of H / Z / T / dP between stages): 25 us for ~2 us of arithmetic.  Same
+// products in the same order; Delta is reduced by shuffles instead of LDS float atomics.
+__global__ __launch_bounds__(256) void k_pma_head1(const PmaHeadArgs a) {
+  constexpr int D = 128, DK = 128, DH = 32, R = 4;        // (four heads)
+  __shared__ float sT[R * DK], sO[D], sP[D], sZ[D], sL[64], sdZ[D], sdO[D], sdP[D], part[D];
+  __shared__ float sLSE[R], sDl[2 * R], red[2];
+  __shared__ int ramax;
+  const int b = blockIdx.x, tid = threadIdx.x, f = tid & 127, half = tid >> 7;
+  const int S = a.S, C = a.C;
+
+  // ---- stage 0 loads first (they are needed first), then all the weights ----
+  float mp[2][8], lp[2][8], tp[2][8];
+  const int SS = S < 8 ? S : 8;
+#pragma unroll
+  for (int e = 0; e < 2; ++e) {
+    const int i = tid + 256 * e, r = i >> 7, c = i & 127;
+#pragma unroll
+    for (int q = 0; q < 8; ++q) {
+      const bool on = q < SS;
+      const int64_t o = ((int64_t)b * S + (on ? q : 0)) * R + r;
+      mp[e][q] = on ? a.Mp[o] : -INFINITY;
+      lp[e][q] = on ? a.Lp[o] : 0.f;
+      tp[e][q] = on ? a.Tp[o * DK + c] : 0.f;
+    }
+  }
+  const float qb = a.Qp[f] + a.bv[f], bo_f = a.bo[f];
+  float w1[64], w2[64], w5[64], w6[2][DH], w4[32];
+  float4 w3[8];
+#pragma unroll
+  for (int c = 0; c < 64; ++c) w1[c] = a.WvT[(int64_t)(half * 64 + c) * D + f];
+#pragma unroll
+  for (int c = 0; c < 64; ++c) w2[c] = a.WoT[(int64_t)(half * 64 + c) * D + f];
+  const int c3 = tid >> 2, part3 = tid & 3;
+#pragma unroll
+  for (int u = 0; u < 8; ++u)
+    w3[u] = *reinterpret_cast<const float4*>(a.Wc + (int64_t)(c3 < C ? c3 : 0) * D + part3 * 32 + 4 * u);
+  const float bc3 = a.bc[c3 < C ? c3 : 0];
+  const int c0 = half * (C / 2), c1 = half ? C : C / 2;
+#pragma unroll
+  for (int u = 0; u < 32; ++u) w4[u] = a.Wc[(int64_t)(c0 + u < c1 ? c0 + u : c0) * D + f];
+#pragma unroll
+  for (int k = 0; k < 64; ++k) w5[k] = a.Wo[(int64_t)(half * 64 + k) * D + f];
+#pragma unroll
+  for (int jj = 0; jj < 2; ++jj)
+#pragma unroll
+    for (int k = 0; k < DH; ++k)
+      w6[jj][k] = a.Wv[(int64_t)((2 * half + jj) * DH + k) * DK + f];
+  const int64_t y = a.labels[b];
+  if (a.zero_ptr != nullptr)
+    for (int i = b * 256 + tid; i < a.zero_n; i += gridDim.x * 256) a.zero_ptr[i] = 0.f;
+
+  // ---- forward epilogue: merge the S point-range partials (mab0_epi_body) ----
+#pragma unroll
+  for (int e = 0; e < 2; ++e) {
+    const int i = tid + 256 * e, r = i >> 7, c = i & 127;
+    float M = -INFINITY;
+#pragma unroll
+    for (int q = 0; q < 8; ++q) M = fmaxf(M, mp[e][q]);
+    float L = 0.f, t = 0.f;
+#pragma unroll
+    for (int q = 0; q < 8; ++q) {
+      if (q >= SS || mp[e][q] == -INFINITY) continue;
+      const float fs = exp2f(mp[e][q] - M);
+      L += fs * lp[e][q];
+      t += fs * tp[e][q];
+    }
+    const float v = t / L;
+    sT[i] = v;
+    a.T[(int64_t)b * R * DK + i] = v;
+    if (c == 0) {
+      const float lse = M + log2f(L);
+      a.LSE[(int64_t)b * R + r] = lse;
+      sLSE[r] = lse;
+    }
+  }
+  __syncthreads();
+  // O = Qp + T_h Wv_h^T + bv ; each half of the workgroup takes half of the contraction
+  {
+    const int j = f / DH;
+    float a1 = half == 0 ? qb : 0.f;
+#pragma unroll
+    for (int c = 0; c < 64; ++c) a1 = fmaf(sT[j * DK + half * 64 + c], w1[c], a1);
+    if (half == 1) part[f] = a1;
+    __syncthreads();
+    if (half == 0) sO[f] = a1 + part[f];
+    __syncthreads();
+  }
+  {
+    float z1 = half == 0 ? bo_f : 0.f;
+#pragma unroll
+    for (int c = 0; c < 64; ++c) z1 = fmaf(sO[half * 64 + c], w2[c], z1);
+    if (half == 1) part[f] = z1;
+    __syncthreads();
+    if (half == 0) {
+      z1 += part[f];
+      const float o1 = sO[f], hv = o1 + fmaxf(z1, 0.f);
+      const int64_t o = (int64_t)b * D + f;
+      a.H[o] = hv;
+      a.Osave[o] = o1;
+      a.Zsave[o] = z1;
+      sP[f] = hv;
+      sZ[f] = z1;
+    }
+    __syncthreads();
+  }
+  // ---- classifier + cross-entropy, forward and backward (cls_fwd_bwd_body) ----
+  {
+    float acc = 0.f;
+    if (c3 < C) {
+      const float* x = sP + part3 * 32;
+#pragma unroll
+      for (int u = 0; u < 8; ++u)
+        acc += x[4 * u] * w3[u].x + x[4 * u + 1] * w3[u].y + x[4 * u + 2] * w3[u].z +
+               x[4 * u + 3] * w3[u].w;
+    }
+    acc += __shfl_xor(acc, 1, 64);
+    acc += __shfl_xor(acc, 2, 64);
+    if (c3 < C && part3 == 0) {
+      acc += bc3;
+      sL[c3] = acc;
+      a.logits[(int64_t)b * C + c3] = acc;
+    }
+  }
+  __syncthreads();
+  if (tid < 64) {
+    float m = -INFINITY;
+    int am = 0x7fffffff;
+    for (int j = tid; j < C; j += 64)
+      if (sL[j] > m) { m = sL[j]; am = j; }
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) {
+      const float om = __shfl_xor(m, o, 64);
+      const int oa = __shfl_xor(am, o, 64);
+      if (om > m || (om == m && oa < am)) { m = om; am = oa; }
+    }
+    float sm = 0.f;
+    for (int j = tid; j < C; j += 64) sm += expf(sL[j] - m);
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) sm += __shfl_xor(sm, o, 64);
+    if (tid == 0) { red[0] = m; red[1] = sm; ramax = am; }
+  }
+  __syncthreads();
+  {
+    const float m = red[0], sm = red[1];
+    const float gs = a.grad_scale / (float)a.B;
+    if (tid == 0) {
+      a.lossv[b] = m + logf(sm) - sL[y];
+      a.corrv[b] = ramax == (int)y ? 1.f : 0.f;
+    }
+    __syncthreads();
+    for (int c = tid; c < C; c += 256) {
+      const float g = (expf(sL[c] - m) / sm - (c == y ? 1.f : 0.f)) * gs;
+      sL[c] = g;
+      a.dlogits[(int64_t)b * C + c] = g;
+    }
+    __syncthreads();
+    float acc = 0.f;
+#pragma unroll
+    for (int u = 0; u < 32; ++u)
+      if (c0 + u < c1) acc = fmaf(sL[c0 + u], w4[u], acc);
+    if (half == 1) part[f] = acc;
+    __syncthreads();
+    if (half == 0) {
+      const float dp = acc + part[f];
+      a.dP[(int64_t)b * D + f] = dp;
+      sdP[f] = dp;
+    }
+    __syncthreads();
+  }
+  // ---- backward epilogue (mab0_epi_bwd_body): dZ, dO = dP + dZ Wo, dT_h = dO_h Wv_h, Delta ----
+  if (tid < D) {
+    const float v = sZ[tid] > 0.f ? sdP[tid] : 0.f;
+    sdZ[tid] = v;
+    a.dZ[(int64_t)b * D + tid] = v;
+  }
+  __syncthreads();
+  {
+    float a5 = half == 0 ? sdP[f] : 0.f;
+#pragma unroll
+    for (int k = 0; k < 64; ++k) a5 = fmaf(sdZ[half * 64 + k], w5[k], a5);
+    if (half == 1) part[f] = a5;
+    __syncthreads();
+    if (half == 0) {
+      a5 += part[f];
+      sdO[f] = a5;
+      a.dO[(int64_t)b * D + f] = a5;
+    }
+    __syncthreads();
+  }
+#pragma unroll
+  for (int jj = 0; jj < 2; ++jj) {
+    const int j = 2 * half + jj;                  // head = score row r (one seed)
+    float acc = 0.f;
+#pragma unroll
+    for (int k = 0; k < DH; ++k) acc = fmaf(sdO[j * DH + k], w6[jj][k], acc);
+    const float tv = sT[j * DK + f];
+    a.Th[((int64_t)j * a.B + b) * DK + f] = tv;
+    a.dTb[((int64_t)b * a.Rp + j) * DK + f] = (__bf16)acc;
+    int pos = 0;
+#pragma unroll
+    for (int p = 0; p < 32; ++p)
+      if (perm32(p) == j) pos = p;
+    a.dTt[((int64_t)b * DK + f) * a.Rp + pos] = (__bf16)acc;
+    // Delta[r] = sum over the 128 columns: the wave's 64 by shuffles, the two waves through LDS
+    float dl = acc * tv;
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) dl += __shfl_xor(dl, o, 64);
+    if ((tid & 63) == 0) sDl[2 * j + ((tid >> 6) & 1)] = dl;
+  }
+  __syncthreads();
+  for (int r = tid; r < a.Rp; r += 256) {
+    a.Delta[(int64_t)b * a.Rp + r] = r < R ? sDl[2 * r] + sDl[2 * r + 1] : 0.f;
+    a.LSEp[(int64_t)b * a.Rp + r] = r < R ? sLSE[r] : 1.0e30f;
+  }
+  for (int o = tid; o < (a.Rp - R) * DK; o += 256) {       // padding rows / columns of the images
+    const int r = R + o / DK, cc = o % DK;
+    a.dTb[((int64_t)b * a.Rp + r) * DK + cc] = (__bf16)0.f;
+    const int rb32 = r & ~31, ro = r & 31;
+    int pos = 0;
+#pragma unroll
+    for (int p = 0; p < 32; ++p)
+      if (perm32(p) == ro) pos = p;
+    a.dTt[((int64_t)b * DK + cc) * a.Rp + rb32 + pos] = (__bf16)0.f;
+  }
+}
 }  // namespace
 
 int pma_head_launch(const pca_mab_shape& s, const pca_mab_params& p, void* saved, void* ws_bwd,
@@ -587,7 +818,11 @@ int pma_head_launch(const pca_mab_shape& s, const pca_mab_params& p, void* saved
   const size_t l3 = (2 * (size_t)m * d + (size_t)Rp + (size_t)d) * sizeof(float);
   lds = lds > l2 ? lds : l2;
   lds = lds > l3 ? lds : l3;
-  hipLaunchKernelGGL(k_pma_head, dim3(s.B), dim3(256), lds, st, a);
+  static const bool v1 = getenv("PCA_PMA_HEAD_V1") != nullptr && getenv("PCA_PMA_HEAD_V1")[0] == '1';
+  if (!v1 && d == 128 && dk == 128 && h == 4 && m == 1 && C <= 64 && a.S >= 1 && a.S <= 8)
+    hipLaunchKernelGGL(k_pma_head1, dim3(s.B), dim3(256), 0, st, a);
+  else
+    hipLaunchKernelGGL(k_pma_head, dim3(s.B), dim3(256), lds, st, a);
   PCA_TRY(check_launch("k_pma_head"));
   defer->cls = ClsWgradArgs{dlogits, P, a.lossv, a.corrv, s.B, d, C, dWc, dbc, loss_out, stats};
   defer->has_cls = 1;
