@@ -424,11 +424,20 @@ __global__ __launch_bounds__(256) void k_mab0_bwd_small(
 //   dQp[q][f]   = dQs[q][f] + sum_c dG_raw[j m + q][c] Wk[f][c]
 //   dWq += dQp^T I ; dbq += colsum(dQp) ; dI += dQp Wq
 // ---------------------------------------------------------------------------------
-// dot of two strided sequences with 16 independent loads in flight
+// dot of two strided sequences with NF independent load pairs in flight (the post kernels are a
+// few dependent L2 round trips long and nothing else: a 128-term dot is 2 trips at NF = 64, 8 at 16)
+template <int NF = 64>
 __device__ __forceinline__ float dot_strided(const float* __restrict__ a, int64_t sa,
                                              const float* __restrict__ b, int64_t sb, int n) {
   float acc = 0.f;
   int i = 0;
+  for (; i + NF <= n; i += NF) {
+    float x[NF], y[NF];
+#pragma unroll
+    for (int u = 0; u < NF; ++u) { x[u] = a[(i + u) * sa]; y[u] = b[(i + u) * sb]; }
+#pragma unroll
+    for (int u = 0; u < NF; ++u) acc = fmaf(x[u], y[u], acc);
+  }
   for (; i + 16 <= n; i += 16) {
     float x[16], y[16];
 #pragma unroll
@@ -463,6 +472,13 @@ __device__ __forceinline__ void post1_body(const Mab0PostJob& a, int blk) {
       qs = 0.f;
       const int64_t sb = (int64_t)m * d;
       int bb = 0;
+      for (; bb + 64 <= a.B; bb += 64) {
+        float v[64];
+#pragma unroll
+        for (int u = 0; u < 64; ++u) v[u] = a.dO[(bb + u) * sb + oo];
+#pragma unroll
+        for (int u = 0; u < 64; ++u) qs += v[u];
+      }
       for (; bb + 16 <= a.B; bb += 16) {
         float v[16];
 #pragma unroll

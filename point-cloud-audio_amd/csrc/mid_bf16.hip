@@ -84,21 +84,42 @@ __global__ __launch_bounds__(256) void k_mid_fwd(const MidFwdArgs a) {
   if (SMALL) {
     for (int i = tid; i < 64 * dk; i += 256) sTf[(i / dk) * 4 + (i % dk)] = a.T[(int64_t)b * 64 * dk + i];
   } else {
-    for (int i = tid; i < 64 * 16; i += 256) {         // (row, 8-element chunk)
+#pragma unroll
+    for (int it = 0; it < 4; ++it) {                   // (row, 8-element chunk)
+      const int i = tid + 256 * it;
       const int row = i >> 4, ch = i & 15;
+      // the partials of up to four point ranges at a time, all loads issued together (clamped
+      // slot, zero weight): one round trip per group instead of three dependent ones per range
       float M = -INFINITY;
-      for (int s = 0; s < a.S; ++s) M = fmaxf(M, a.Mp[((int64_t)b * a.S + s) * 64 + row]);
       float L = 0.f, t[8] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
-      for (int s = 0; s < a.S; ++s) {
-        const float ms = a.Mp[((int64_t)b * a.S + s) * 64 + row];
-        if (ms == -INFINITY) continue;
-        const float fs = exp2f(ms - M);
-        L += fs * a.Lp[((int64_t)b * a.S + s) * 64 + row];
-        const float4* tp = reinterpret_cast<const float4*>(
-            a.Tp + (((int64_t)b * a.S + s) * 64 + row) * D + ch * 8);
-        const float4 lo = tp[0], hi = tp[1];
-        t[0] += fs * lo.x; t[1] += fs * lo.y; t[2] += fs * lo.z; t[3] += fs * lo.w;
-        t[4] += fs * hi.x; t[5] += fs * hi.y; t[6] += fs * hi.z; t[7] += fs * hi.w;
+      float msv[8];
+#pragma unroll
+      for (int s = 0; s < 8; ++s) {
+        msv[s] = a.Mp[((int64_t)b * a.S + (s < a.S ? s : 0)) * 64 + row];
+        if (s < a.S) M = fmaxf(M, msv[s]);
+      }
+#pragma unroll
+      for (int s0 = 0; s0 < 8; s0 += 4) {
+        if (s0 >= a.S) break;
+        float lpv[4];
+        float4 lo[4], hi[4];
+#pragma unroll
+        for (int u = 0; u < 4; ++u) {
+          const int64_t o = ((int64_t)b * a.S + (s0 + u < a.S ? s0 + u : 0)) * 64 + row;
+          lpv[u] = a.Lp[o];
+          const float4* tp = reinterpret_cast<const float4*>(a.Tp + o * D + ch * 8);
+          lo[u] = tp[0];
+          hi[u] = tp[1];
+        }
+#pragma unroll
+        for (int u = 0; u < 4; ++u) {
+          const float ms = msv[s0 + u];
+          if (s0 + u >= a.S || ms == -INFINITY) continue;
+          const float fs = exp2f(ms - M);
+          L += fs * lpv[u];
+          t[0] += fs * lo[u].x; t[1] += fs * lo[u].y; t[2] += fs * lo[u].z; t[3] += fs * lo[u].w;
+          t[4] += fs * hi[u].x; t[5] += fs * hi[u].y; t[6] += fs * hi[u].z; t[7] += fs * hi[u].w;
+        }
       }
       const float inv = 1.f / L;
       bf16x8 v;
@@ -278,15 +299,26 @@ __global__ __launch_bounds__(256) void k_mid_bwd(const MidBwdArgs a) {
   for (int i = tid; i < 16 * 16; i += 256) {
     const int row = i >> 4, ch = i & 15;
     float k[8] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f}, v[8] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
-    for (int pp = 0; pp < a.nparts; ++pp) {
-      const int64_t off = (((int64_t)b * a.nparts + pp) * MQ + row) * D + ch * 8;
-      const float4* pk = reinterpret_cast<const float4*>(a.dKpPart + off);
-      const float4* pv = reinterpret_cast<const float4*>(a.dVpPart + off);
-      const float4 k0 = pk[0], k1 = pk[1], v0 = pv[0], v1 = pv[1];
-      k[0] += k0.x; k[1] += k0.y; k[2] += k0.z; k[3] += k0.w;
-      k[4] += k1.x; k[5] += k1.y; k[6] += k1.z; k[7] += k1.w;
-      v[0] += v0.x; v[1] += v0.y; v[2] += v0.z; v[3] += v0.w;
-      v[4] += v1.x; v[5] += v1.y; v[6] += v1.z; v[7] += v1.w;
+    // four partials at a time, their loads issued together (one round trip per group, not per
+    // partial); same summation order
+    for (int p0 = 0; p0 < a.nparts; p0 += 4) {
+      float4 k0[4], k1[4], v0[4], v1[4];
+#pragma unroll
+      for (int u = 0; u < 4; ++u) {
+        const int pp = p0 + u < a.nparts ? p0 + u : p0;
+        const int64_t off = (((int64_t)b * a.nparts + pp) * MQ + row) * D + ch * 8;
+        const float4* pk = reinterpret_cast<const float4*>(a.dKpPart + off);
+        const float4* pv = reinterpret_cast<const float4*>(a.dVpPart + off);
+        k0[u] = pk[0]; k1[u] = pk[1]; v0[u] = pv[0]; v1[u] = pv[1];
+      }
+#pragma unroll
+      for (int u = 0; u < 4; ++u) {
+        if (p0 + u >= a.nparts) continue;
+        k[0] += k0[u].x; k[1] += k0[u].y; k[2] += k0[u].z; k[3] += k0[u].w;
+        k[4] += k1[u].x; k[5] += k1[u].y; k[6] += k1[u].z; k[7] += k1[u].w;
+        v[0] += v0[u].x; v[1] += v0[u].y; v[2] += v0[u].z; v[3] += v0[u].w;
+        v[4] += v1[u].x; v[5] += v1[u].y; v[6] += v1[u].z; v[7] += v1[u].w;
+      }
     }
     const int64_t so = ((int64_t)b * MQ + row) * D + ch * 8;
     reinterpret_cast<float4*>(a.dKp + so)[0] = float4{k[0], k[1], k[2], k[3]};

@@ -28,6 +28,13 @@ __device__ __forceinline__ void cls_wgrad_body(
       __syncthreads();
       if (f < d) {
         int bb = 0;
+        for (; bb + 64 <= nb; bb += 64) {        // (a few dependent L2 round trips and nothing else)
+          float pv[64];
+#pragma unroll
+          for (int u = 0; u < 64; ++u) pv[u] = P[(int64_t)(b0 + bb + u) * d + f];
+#pragma unroll
+          for (int u = 0; u < 64; ++u) acc = fmaf(sg[bb + u], pv[u], acc);
+        }
         for (; bb + 16 <= nb; bb += 16) {
           float pv[16];
 #pragma unroll
@@ -84,19 +91,22 @@ __device__ __forceinline__ void wgrad_small_body(const GT* __restrict__ G,
   const int64_t r0 = (int64_t)blk * rows_per_wg;
   const int64_t r1 = (r0 + rows_per_wg < M) ? r0 + rows_per_wg : M;
   float acc[4] = {0.f, 0.f, 0.f, 0.f}, bs = 0.f;
-  // batches of 8 rows: 8 independent G loads (+ the broadcast X rows) in flight
-  for (int64_t row = r0 + ph; row < r1; row += 16) {
-    float gv[8], xv[8][4];
+  // batches of 16 rows: 16 independent G loads (+ the broadcast X rows) in flight; rows beyond the
+  // range are read from the last valid row (unconditional loads) and zeroed
+  for (int64_t row = r0 + ph; row < r1; row += 32) {
+    float gv[16], xv[16][4];
 #pragma unroll
-    for (int u = 0; u < 8; ++u) {
+    for (int u = 0; u < 16; ++u) {
       const int64_t rr = row + 2 * u;
       const bool ok = rr < r1;
-      gv[u] = ok ? (float)G[rr * D + f] : 0.f;
+      const int64_t rc = ok ? rr : r1 - 1;
+      const float gq = (float)G[rc * D + f];
+      gv[u] = ok ? gq : 0.f;
 #pragma unroll
-      for (int c = 0; c < 4; ++c) xv[u][c] = (ok && c < dq) ? Xh[rr * dq + c] : 0.f;
+      for (int c = 0; c < 4; ++c) xv[u][c] = c < dq ? Xh[rc * dq + c] : 0.f;
     }
 #pragma unroll
-    for (int u = 0; u < 8; ++u) {
+    for (int u = 0; u < 16; ++u) {
       bs += gv[u];
 #pragma unroll
       for (int c = 0; c < 4; ++c) acc[c] = fmaf(gv[u], xv[u][c], acc[c]);
