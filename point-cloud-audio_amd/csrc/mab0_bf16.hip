@@ -203,7 +203,48 @@ __device__ __forceinline__ void mab0_prep_body(const Mab0PrepJob& a, float* sq, 
   }
   const int m = a.m, d = a.d, dq = a.dq, dk = a.dk, h = a.h;
   const int R = h * m;
-  if (d <= 128 && dq % 32 == 0) {
+  // The Wk values of the G stage do not depend on the Qp stage: request them now (head dim 32, at
+  // most two outputs per thread), so that the launch is two L2 round trips deep instead of six
+  const int dh_ = d / h;
+  const bool pre = a.Gf != nullptr && dh_ == 32 && h * dk <= 512;
+  float wk_pre[2][32];
+  if (pre) {
+#pragma unroll
+    for (int it = 0; it < 2; ++it) {
+      int o = threadIdx.x + 256 * it;
+      o = o < h * dk ? o : h * dk - 1;
+      const int j = o / dk, c = o - j * dk;
+#pragma unroll
+      for (int u = 0; u < 32; ++u) wk_pre[it][u] = a.Wk[(j * 32 + u) * dk + c];
+    }
+  }
+  if (d <= 128 && dq == 128) {
+    // as below, the thread's 64 weights and the 64 inputs of its half in one batch
+    __shared__ float part[128];
+    const int f = threadIdx.x & 127, kh = threadIdx.x >> 7;
+    const int fc = f < d ? f : d - 1;
+    float4 w4[16], x4[16];
+#pragma unroll
+    for (int u = 0; u < 16; ++u) {
+      w4[u] = *reinterpret_cast<const float4*>(a.Wq + fc * dq + kh * 64 + 4 * u);
+      x4[u] = *reinterpret_cast<const float4*>(a.I + q * dq + kh * 64 + 4 * u);
+    }
+    float acc = 0.f;
+#pragma unroll
+    for (int u = 0; u < 16; ++u) {
+      acc = fmaf(x4[u].x, w4[u].x, acc);
+      acc = fmaf(x4[u].y, w4[u].y, acc);
+      acc = fmaf(x4[u].z, w4[u].z, acc);
+      acc = fmaf(x4[u].w, w4[u].w, acc);
+    }
+    if (kh == 1 && f < d) part[f] = acc;
+    __syncthreads();
+    if (kh == 0 && f < d) {
+      acc += part[f] + a.bq[f];
+      sq[f] = acc;
+      a.Qp[q * d + f] = acc;
+    }
+  } else if (d <= 128 && dq % 32 == 0) {
     // both halves of the workgroup work on the d outputs: half kh takes half of the
     // contraction (the dot products are chains of dependent L2 round trips)
     __shared__ float part[128];
@@ -245,9 +286,16 @@ __device__ __forceinline__ void mab0_prep_body(const Mab0PrepJob& a, float* sq, 
   __syncthreads();
   if (a.Gf == nullptr) return;             // caller only wants Qp (keys are projected: d = 256)
   const int dh = d / h;
-  for (int o = threadIdx.x; o < h * dk; o += 256) {
+#pragma unroll 2
+  for (int it = 0; it * 256 < h * dk; ++it) {
+    const int o = threadIdx.x + 256 * it;
+    if (o >= h * dk) break;
     const int j = o / dk, c = o - j * dk;
     float acc = 0.f;
+    if (pre) {
+#pragma unroll
+      for (int u = 0; u < 32; ++u) acc = fmaf(sq[j * 32 + u], wk_pre[it & 1][u], acc);
+    } else {
     for (int f = 0; f < dh; f += 16) {
       float wv[16];
 #pragma unroll
@@ -255,6 +303,7 @@ __device__ __forceinline__ void mab0_prep_body(const Mab0PrepJob& a, float* sq, 
 #pragma unroll
       for (int u = 0; u < 16; ++u)
         if (f + u < dh) acc = fmaf(sq[j * dh + f + u], wv[u], acc);
+    }
     }
     acc *= a.sl2e;
     const int r = j * m + q;

@@ -87,10 +87,9 @@ __global__ __launch_bounds__(256) void k_adam(float* __restrict__ p, float* __re
                                               int64_t n, float lr, float b1, float b2,
                                               float eps, float wd, float gscale,
                                               int32_t* __restrict__ step, int zero_grad) {
-  __shared__ int s_t;
-  if (threadIdx.x == 0) s_t = step[0] + 1;
-  __syncthreads();
-  const int ti = s_t;
+  // (every thread reads the count itself, in the same round trip as its first parameters: through
+  //  thread 0, LDS and a barrier the launch was one dependent L2 round trip longer)
+  const int ti = *reinterpret_cast<volatile const int32_t*>(step) + 1;
   const float t = (float)ti;
   const float bc1 = 1.f - powf(b1, t);
   const float bc2 = 1.f - powf(b2, t);
@@ -110,6 +109,7 @@ __global__ __launch_bounds__(256) void k_adam(float* __restrict__ p, float* __re
     p[i] = w - step_size * (mi / denom);
     if (zero_grad) g[i] = 0.f;
   }
+  __syncthreads();          // every thread of the workgroup has used its copy of the count
   if (threadIdx.x == 0) {
     const int ticket = atomicAdd(&step[1], 1);
     if (ticket == (int)gridDim.x - 1) {
