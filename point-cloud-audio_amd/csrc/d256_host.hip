@@ -286,10 +286,20 @@ int mab0_d256_prep_all(int n, const pca_mab_shape* const* shapes, const float* c
 }
 void mab0_d256_prep_done(bool on) { g_prep256_done = on; }
 
+static bool fq_epi_bf16() {
+  static const bool on = [] {
+    const char* e = getenv("PCA_FQ_EPI_F32");
+    return !(e != nullptr && e[0] == '1');
+  }();
+  return on;
+}
 int mab0_d256_fwd(const pca_mab_shape& s, const float* I, const void* X, const pca_mab_params& p,
                   float* Hout, void* saved, void* ws, hipStream_t st) {
   PCA_REQUIRE(mab0_d256_supported(s), "mab0_d256_fwd: unsupported shape");
   PCA_REQUIRE(ws != nullptr, "mab0_d256_fwd: scratch required");
+  // fc_o on the [B*m] query rows with bf16 MFMA operands (fp32 accumulation and I/O), as the
+  // d = 128 path's k_mid_fwd does: the exact fp32 GEMM was 22 us per call for 0.5 GFLOP
+  Bf16OperandScope ops(fq_epi_bf16());
   Carver cw(ws);
   __bf16* WkP = cw.take<__bf16>((size_t)D * D);
   __bf16* WvP = cw.take<__bf16>((size_t)D * D);
@@ -428,6 +438,7 @@ int mab0_d256_bwd(const pca_mab_shape& s, const float* I, const void* X, const p
   fq_carve_saved(s, &v, const_cast<void*>(saved));
   Fq256BwdWs w;
   fq_carve_bwd(s, &w, ws);
+  Bf16OperandScope ops(fq_epi_bf16());       // dO = dH + dZ Wo on the MFMA (see mab0_d256_fwd)
   const int m = s.nq, R = s.h * m;
   const int64_t Bm = (int64_t)s.B * m, M = (int64_t)s.B * s.nk;
   if (s.dk != D && dX != nullptr) {

@@ -165,8 +165,8 @@ int pca_adam_step(float* param, float* grad, float* exp_avg, float* exp_avg_sq, 
   PCA_REQUIRE(n >= 0, "adam_step: n=%lld", (long long)n);
   hipStream_t st = pca::as_stream(stream);
   // few, longer workgroups: the arrival tickets are serialised atomics on one address
-  int64_t blocks = pca::cdiv(n, 256 * 8);
-  if (blocks > 1024) blocks = 1024;
+  int64_t blocks = pca::cdiv(n, 256 * 4);       // one batch of four elements per thread
+  if (blocks > 2048) blocks = 2048;
   if (blocks < 1) blocks = 1;                      // n == 0 still advances the step count
   hipLaunchKernelGGL(pca::k_adam, dim3((unsigned)blocks), dim3(256), 0, st, param, grad,
                      exp_avg, exp_avg_sq, n, lr, beta1, beta2, eps, weight_decay, grad_scale,

@@ -203,13 +203,34 @@ def test_mab0_fwd_bf16(dev, case):
     with torch.no_grad():
         Y = mab(I.to(dev), X.to(dev), q_shared=True)
     pca_hip.set_mode("f32")
-    err = close(Y, ref, FWD_TOL if dk > 4 else 2e-4, f"mab0 fwd {case}")
+    # (layer 1, dk <= 4: scores, softmax and fc_v are exact fp32 arithmetic on the points; at
+    #  d = 256 the block's fc_o runs on the MFMA with bf16 operands like every other block's)
+    err = close(Y, ref, FWD_TOL if dk > 4 or d == 256 else 2e-4, f"mab0 fwd {case}")
     print(f"mab0 fwd {case}: max err {err:.3e} (max|ref| {float(ref.abs().max()):.2f})")
+
+
+class _LinearBf16Operands(torch.autograd.Function):
+    """y = rb(x) rb(W)^T + b the way csrc/d256_host.hip runs fc_o of the few-queries block: both
+    GEMM operands rounded to bf16 in the forward AND in the backward (dx = rb(g) rb(W),
+    dW = rb(g)^T rb(x)), accumulation in fp32."""
+
+    @staticmethod
+    def forward(ctx, x, W, b):
+        r = lambda t: t.to(torch.bfloat16).to(torch.float32)
+        ctx.save_for_backward(x, W)
+        return r(x) @ r(W).t() + b
+
+    @staticmethod
+    def backward(ctx, g):
+        r = lambda t: t.to(torch.bfloat16).to(torch.float32)
+        x, W = ctx.saved_tensors
+        g2, x2 = g.reshape(-1, g.shape[-1]), x.reshape(-1, x.shape[-1])
+        return r(g) @ r(W), r(g2).t() @ r(x2), g2.sum(0)
 
 
 def mab0_forward_bf16emu(I, X, p, h, fp8=False):
     """Reassociated mab0 with the MFMA operands (G' = sl2e Qp_h Wk_h, X, P) rounded to bf16 as
-    csrc/mab0_bf16.hip does; epilogue fp32.  Returns H.
+    csrc/mab0_bf16.hip does; epilogue fp32 (d = 256: fc_o with bf16 operands).  Returns H.
     d = 256 with dk = 256 (csrc/d256_*.hip): the keys ARE projected - Kp, Vp, the scaled query
     and P are the bf16 operands."""
     import math
@@ -233,7 +254,7 @@ def mab0_forward_bf16emu(I, X, p, h, fp8=False):
         P = torch.softmax(S2 * math.log(2.0), dim=-1)
         O = Qp.view(1, m, h, dh) + torch.einsum("bjqn,bnjf->bqjf", rb(P), Vp)
         O = O.reshape(B, m, d)
-        Z = O @ p["fc_o.weight"].t() + p["fc_o.bias"]
+        Z = _LinearBf16Operands.apply(O, p["fc_o.weight"], p["fc_o.bias"])   # d = 256: on the MFMA
         return O + torch.relu(Z)
     Wk = p["fc_k.weight"].view(h, dh, dk)
     G = torch.einsum("qjf,jfc->jqc", Qp.view(m, h, dh), Wk) * sl2e      # [h, m, dk]
@@ -245,7 +266,10 @@ def mab0_forward_bf16emu(I, X, p, h, fp8=False):
     Wv = p["fc_v.weight"].view(h, dh, dk)
     O = Qp.view(1, m, h, dh) + torch.einsum("bjqc,jfc->bqjf", T, Wv) + p["fc_v.bias"].view(1, 1, h, dh)
     O = O.reshape(B, m, d)
-    Z = O @ p["fc_o.weight"].t() + p["fc_o.bias"]
+    if d == 256:       # csrc/d256_host.hip: fc_o with bf16 MFMA operands (fp32 accumulation)
+        Z = _LinearBf16Operands.apply(O, p["fc_o.weight"], p["fc_o.bias"])
+    else:
+        Z = O @ p["fc_o.weight"].t() + p["fc_o.bias"]
     return O + torch.relu(Z)
 
 
@@ -297,8 +321,15 @@ def test_mab0_bwd_bf16(dev, case):
             continue
         # (d = 256: the online softmax feeds un-normalised probabilities to the MFMA, the emulation
         #  normalised ones - a few more ReLU pre-activations of the 96 epilogue rows change sign)
-        errs[k] = close_robust(v, emu[k], 1.5e-2, k,
-                               outlier_frac=2e-4 if d == 128 else max(3e-3, 2.5 / v.numel()))
+        # dQ at d = 256: every flipped pre-activation moves a whole 256-wide row of the [m, d] query
+        # gradient by ~|dH| |Wo| - held to the gradient tolerance of the module docstring instead
+        # fc_o at d = 256: a flipped pre-activation (b, q, f) moves row f of d/d(Wo) by dH.O - up to
+        # four such rows / bias elements of the 256 may differ from the emulation's
+        frac = 2e-4 if d == 128 else max(3e-3, 2.5 / v.numel())
+        if d == 256 and k.startswith("fc_o."):
+            frac = 4.0 / 256
+        errs[k] = close_robust(v, emu[k], BWD_TOL if (d == 256 and k == "dQ") else 1.5e-2, k,
+                               outlier_frac=frac)
         sc = max(1.0, float(exact[k].abs().max()))
         rms = float((emu[k] - exact[k]).pow(2).mean().sqrt()) / sc
         assert rms < 3e-2, (k, rms)
