@@ -87,9 +87,10 @@ __global__ __launch_bounds__(256) void k_adam(float* __restrict__ p, float* __re
                                               int64_t n, float lr, float b1, float b2,
                                               float eps, float wd, float gscale,
                                               int32_t* __restrict__ step, int zero_grad) {
-  // (every thread reads the count itself, in the same round trip as its first parameters: through
-  //  thread 0, LDS and a barrier the launch was one dependent L2 round trip longer)
-  const int ti = *reinterpret_cast<volatile const int32_t*>(step) + 1;
+  __shared__ int s_t;
+  if (threadIdx.x == 0) s_t = step[0] + 1;
+  __syncthreads();
+  const int ti = s_t;
   const float t = (float)ti;
   const float bc1 = 1.f - powf(b1, t);
   const float bc2 = 1.f - powf(b2, t);
@@ -109,7 +110,6 @@ __global__ __launch_bounds__(256) void k_adam(float* __restrict__ p, float* __re
     p[i] = w - step_size * (mi / denom);
     if (zero_grad) g[i] = 0.f;
   }
-  __syncthreads();          // every thread of the workgroup has used its copy of the count
   if (threadIdx.x == 0) {
     const int ticket = atomicAdd(&step[1], 1);
     if (ticket == (int)gridDim.x - 1) {
@@ -165,8 +165,8 @@ int pca_adam_step(float* param, float* grad, float* exp_avg, float* exp_avg_sq, 
   PCA_REQUIRE(n >= 0, "adam_step: n=%lld", (long long)n);
   hipStream_t st = pca::as_stream(stream);
   // few, longer workgroups: the arrival tickets are serialised atomics on one address
-  int64_t blocks = pca::cdiv(n, 256 * 4);       // one batch of four elements per thread
-  if (blocks > 2048) blocks = 2048;
+  int64_t blocks = pca::cdiv(n, 256 * 8);
+  if (blocks > 1024) blocks = 1024;
   if (blocks < 1) blocks = 1;                      // n == 0 still advances the step count
   hipLaunchKernelGGL(pca::k_adam, dim3((unsigned)blocks), dim3(256), 0, st, param, grad,
                      exp_avg, exp_avg_sq, n, lr, beta1, beta2, eps, weight_decay, grad_scale,
