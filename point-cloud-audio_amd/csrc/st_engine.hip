@@ -126,6 +126,8 @@ struct Ws {
   void* scratch;             // forward + PMA backward
   void* scratch_bw[2];       // backward of enc.0 / enc.1: separate, because their terminal
                              // reductions run on the helper stream while the main stream moves on
+  void* scratch_pma;         // d = 256: the PMA's backward workspace, kept until the deferred post
+                             // stages of all three few-queries blocks have run (else = scratch)
   IsabImg img[2];            // weight images of the two ISABs (fused bf16 path)
   bool fused[2];
   float* wg_slabs;           // weight-gradient partials of the deferred reductions (fused d = 128)
@@ -176,6 +178,9 @@ inline size_t carve(const pca_st_config& c, int training, Ws* out, void* base) {
   w.scratch = cv.take<char>(max_scratch);
   for (int li = 0; li < 2; ++li)
     w.scratch_bw[li] = training ? (void*)cv.take<char>(max_scratch) : w.scratch;
+  w.scratch_pma = w.scratch;
+  if (training && s.pma.d == 256 && mab_kind(s.pma) == 2)
+    w.scratch_pma = cv.take<char>(mab_bwd_ws_bytes_any(s.pma));
   if ((w.fused[0] || w.fused[1]) && wgrad_slabs_on()) {
     // two lists (B*N-row and B*m-row jobs) of up to ~600 [128 x 128 (+128)] fp32 slabs each;
     // bwd_defer_flush gives a workgroup more rows when a list would not fit
@@ -185,6 +190,15 @@ inline size_t carve(const pca_st_config& c, int training, Ws* out, void* base) {
   }
   if (out) *out = w;
   return cv.off;
+}
+
+// PCA_D256_DEFER_POSTS=0: the d = 256 few-queries blocks run their post stages per block
+inline bool defer256_on() {
+  static const bool on = [] {
+    const char* e = getenv("PCA_D256_DEFER_POSTS");
+    return !(e != nullptr && e[0] == '0');
+  }();
+  return on;
 }
 
 int validate(const pca_st_config* c) {
@@ -355,6 +369,11 @@ int pca_st_train_fwd_bwd(const pca_st_config* c, const float* params, const floa
     PCA_TRY(pca::cls_train_head(w.P, p + L.wc, p + L.bc, labels, c->B, c->d, c->C, grad_scale,
                                 w.logits, w.dlogits, w.dP, g + L.wc, g + L.bc, loss_out, stats,
                                 w.clsws, st, &posts));
+    if (s.pma.d == 256 && pca::mab_kind(s.pma) == 2 && pca::defer256_on())   // post stages deferred
+      PCA_TRY(pca::mab0_bf16_bwd_ex(s.pma, p + L.S, w.Y[1], pca::params_at(p, L.pma), w.saved[4],
+                                    w.dP, g + L.S, w.dY2, 0, pca::grads_at(g, L.pma),
+                                    w.scratch_pma, 0, st, &posts));
+    else
     PCA_TRY(pca::mab_bwd_any(s.pma, p + L.S, w.Y[1], pca::params_at(p, L.pma), w.saved[4],
                              w.dP, g + L.S, w.dY2, 0, pca::grads_at(g, L.pma), w.scratch,
                              st));
@@ -379,6 +398,11 @@ int pca_st_train_fwd_bwd(const pca_st_config* c, const float* params, const floa
     PCA_TRY(pca::mab_bwd_any(s.m1[1], w.Y[0], w.H[1], pca::params_at(p, L.mab1[1]),
                              w.saved[3], w.dY2, w.dY1, w.dH, 0, pca::grads_at(g, L.mab1[1]),
                              w.scratch_bw[1], st));
+    if (hand && pca::defer256_on())   // (its post stage waits for the flush: w.scratch stays untouched)
+      PCA_TRY(pca::mab0_bf16_bwd_ex(s.m0[1], p + L.I[1], w.Y[0], pca::params_at(p, L.mab0[1]),
+                                    w.saved[2], w.dH, g + L.I[1], w.dY1, 1,
+                                    pca::grads_at(g, L.mab0[1]), w.scratch, 0, st, &posts));
+    else
     PCA_TRY(pca::mab_bwd_any(s.m0[1], p + L.I[1], w.Y[0], pca::params_at(p, L.mab0[1]),
                              w.saved[2], w.dH, g + L.I[1], w.dY1, 1,
                              pca::grads_at(g, L.mab0[1]), hand ? w.scratch : w.scratch_bw[1], st));
@@ -398,6 +422,11 @@ int pca_st_train_fwd_bwd(const pca_st_config* c, const float* params, const floa
     PCA_TRY(pca::mab_bwd_any(s.m1[0], X, w.H[0], pca::params_at(p, L.mab1[0]), w.saved[1],
                              w.dY1, nullptr, w.dH, 0, pca::grads_at(g, L.mab1[0]),
                              w.scratch_bw[0], st));
+    if (s.m0[0].d == 256 && pca::mab_kind(s.m0[0]) == 2 && pca::defer256_on())
+      PCA_TRY(pca::mab0_bf16_bwd_ex(s.m0[0], p + L.I[0], X, pca::params_at(p, L.mab0[0]),
+                                    w.saved[0], w.dH, g + L.I[0], nullptr, 0,
+                                    pca::grads_at(g, L.mab0[0]), w.scratch_bw[0], 0, st, &posts));
+    else
     PCA_TRY(pca::mab_bwd_any(s.m0[0], p + L.I[0], X, pca::params_at(p, L.mab0[0]),
                              w.saved[0], w.dH, g + L.I[0], nullptr, 0,
                              pca::grads_at(g, L.mab0[0]), w.scratch_bw[0], st));
