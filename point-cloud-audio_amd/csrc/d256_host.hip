@@ -446,13 +446,12 @@ int mab0_d256_bwd(const pca_mab_shape& s, const float* I, const void* X, const p
     return PCA_EUNSUPPORTED;
   }
   // ---- epilogue adjoint: H = O + relu(O Wo^T + bo) ----
-  PCA_TRY(relu_bwd(dH, v.Z, w.dZ, Bm * D, st));
+  PCA_TRY(relu_bwd_copy(dH, v.Z, w.dZ, w.dO, Bm * D, st));       // dZ, and dO = dH
   {
     Wgrad256Jobs ej{};
     ej.j[ej.n++] = Wgrad256Job{w.dZ, v.O, gr.wo, gr.bo, Bm};
     PCA_TRY(wgrad256_launch_t(ej, w.wg, true, st));
   }
-  PCA_TRY(copy_rows(dH, Bm, w.dO, Bm, D, st));
   PCA_TRY(linear_dx_acc_f32(w.dZ, p.wo, w.dO, Bm, D, D, 1, st));
   const float sl2e = 1.4426950408889634f / sqrtf((float)D);
   Mab0PostJob pj{};

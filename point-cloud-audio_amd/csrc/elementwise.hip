@@ -366,6 +366,22 @@ __global__ void k_relu_bwd(const float* __restrict__ dY, const float* __restrict
   for (; i < n; i += stride) dZ[i] = Z[i] > 0.f ? dY[i] : 0.f;
 }
 
+// dZ = dY.[Z > 0] and dO = dY in one pass (the adjoint of H = O + relu(Z) starts with both)
+__global__ void k_relu_bwd_copy(const float* __restrict__ dY, const float* __restrict__ Z,
+                                float* __restrict__ dZ, float* __restrict__ dO, int64_t n4) {
+  int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  const int64_t stride = (int64_t)gridDim.x * blockDim.x;
+  const float4* g4 = reinterpret_cast<const float4*>(dY);
+  const float4* z4 = reinterpret_cast<const float4*>(Z);
+  for (; i < n4; i += stride) {
+    const float4 g = g4[i], z = z4[i];
+    reinterpret_cast<float4*>(dZ)[i] =
+        make_float4(z.x > 0.f ? g.x : 0.f, z.y > 0.f ? g.y : 0.f, z.z > 0.f ? g.z : 0.f,
+                    z.w > 0.f ? g.w : 0.f);
+    reinterpret_cast<float4*>(dO)[i] = g;
+  }
+}
+
 __global__ void k_copy_rows(const float* __restrict__ src, int64_t src_elems,
                             float* __restrict__ dst, int64_t n, int vec) {
   int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
@@ -644,6 +660,16 @@ int relu_bwd(const float* dY, const float* Z, float* dZ, int64_t n, hipStream_t 
   const int vec = n % 4 == 0 && al16(dY) && al16(Z) && al16(dZ);
   hipLaunchKernelGGL(k_relu_bwd, dim3(vec ? ew_blocks_v4(n / 4) : ew_blocks(n)), dim3(256), 0, st, dY, Z, dZ, n, vec);
   return check_launch("k_relu_bwd");
+}
+
+int relu_bwd_copy(const float* dY, const float* Z, float* dZ, float* dO, int64_t n, hipStream_t st) {
+  if (n <= 0) return PCA_OK;
+  if (!(n % 4 == 0 && al16(dY) && al16(Z) && al16(dZ) && al16(dO))) {
+    PCA_TRY(relu_bwd(dY, Z, dZ, n, st));
+    return copy_rows(dY, 1, dO, 1, n, st);
+  }
+  hipLaunchKernelGGL(k_relu_bwd_copy, dim3(ew_blocks_v4(n / 4)), dim3(256), 0, st, dY, Z, dZ, dO, n / 4);
+  return check_launch("k_relu_bwd_copy");
 }
 
 int copy_rows(const float* src, int64_t src_rows, float* dst, int64_t rows, int64_t cols,

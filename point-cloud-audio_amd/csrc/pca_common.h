@@ -96,6 +96,7 @@ int colsum(const float* X, int64_t rows, int cols, float* out, int accumulate,
 int add_relu(const float* O, const float* Z, float* Y, int64_t n, hipStream_t st);
 // dZ = dY * [Z > 0]
 int relu_bwd(const float* dY, const float* Z, float* dZ, int64_t n, hipStream_t st);
+int relu_bwd_copy(const float* dY, const float* Z, float* dZ, float* dO, int64_t n, hipStream_t st);
 // dst[r, :] = src[(r % src_rows), :]   (broadcast copy when src_rows < rows)
 int copy_rows(const float* src, int64_t src_rows, float* dst, int64_t rows, int64_t cols,
               hipStream_t st);
