@@ -509,7 +509,7 @@ __global__ __launch_bounds__(256) void k_terminal1(const Mab0PostJobs jobs, cons
   } else if (has_sw && y == jobs.n + has_cls) {
     if ((int64_t)blockIdx.x * w.rows_per_wg < w.M)
       wgrad_small_body<float>(w.G, w.X, w.M, w.dq, w.rows_per_wg, w.x_head_stride, w.dW, w.db,
-                              blockIdx.x);
+                              blockIdx.x, w.slab);
   } else {
     // rider rows: the weight-gradient slabs of this step, added in a fixed order
     __shared__ float4 red[4 * 64];
@@ -517,7 +517,12 @@ __global__ __launch_bounds__(256) void k_terminal1(const Mab0PostJobs jobs, cons
   }
 }
 // stage 2: dWq += dQp^T I ; dbq += colsum(dQp) ; dI += dQp Wq
-__global__ __launch_bounds__(256) void k_mab0_post2(const Mab0PostJobs jobs) {
+__global__ __launch_bounds__(256) void k_mab0_post2(const Mab0PostJobs jobs, const SlabSumJobs late) {
+  if ((int)blockIdx.y >= jobs.n) {       // rider rows (partials written by k_terminal1 itself)
+    __shared__ float4 red[4 * 64];
+    slab_sum_body(late.j[blockIdx.y - jobs.n], blockIdx.x, threadIdx.x, red);
+    return;
+  }
   const Mab0PostJob a = jobs.j[blockIdx.y];
   const int m = a.m, d = a.d, dq = a.dq;
   const int o = blockIdx.x * 256 + threadIdx.x;
@@ -871,14 +876,23 @@ int terminal_launch(const BwdDefer& D, hipStream_t st, const SlabSumJobs* late_i
                      dim3(gx, J.n + (D.has_cls ? 1 : 0) + (D.has_sw ? 1 : 0) + late.n),
                      dim3(256), 0, ts, J, D.cls, D.has_cls ? 1 : 0, D.sw, D.has_sw ? 1 : 0, late);
   PCA_TRY(check_launch("k_terminal1"));
-  if (J.n == 0) return PCA_OK;
+  // the layer-1 fc_v partials k_terminal1 wrote (slab mode) are summed by rider rows of post 2
+  SlabSumJobs late2{};
+  if (D.has_sw && D.sw.slab != nullptr) {
+    const int nwg = (int)cdiv(D.sw.M, D.sw.rows_per_wg), n1 = 128 * D.sw.dq, stride = n1 + 128;
+    late2.j[late2.n++] = SlabSumJob{D.sw.slab, D.sw.dW, nwg, n1, 1, stride};
+    if (D.sw.db != nullptr) late2.j[late2.n++] = SlabSumJob{D.sw.slab + n1, D.sw.db, nwg, 128, 1, stride};
+  }
+  if (J.n == 0) return slab_sum_jobs(late2, ts);
   int n2 = 0;
   for (int i = 0; i < J.n; ++i) {
     const Mab0PostJob& a = J.j[i];
     const int e2 = a.d * a.dq + a.d + (a.dI ? a.m * a.dq : 0);
     n2 = e2 > n2 ? e2 : n2;
   }
-  hipLaunchKernelGGL(k_mab0_post2, dim3((unsigned)cdiv(n2, 256), J.n), dim3(256), 0, ts, J);
+  for (int i = 0; i < late2.n; ++i) n2 = late2.j[i].n > n2 ? late2.j[i].n : n2;
+  hipLaunchKernelGGL(k_mab0_post2, dim3((unsigned)cdiv(n2, 256), J.n + late2.n), dim3(256), 0, ts, J,
+                     late2);
   return check_launch("k_mab0_post2");
 }
 
@@ -894,7 +908,8 @@ int mab0_post_launch(const Mab0PostJobs& J, hipStream_t st) {
   hipStream_t ts = terminal_stream(st);     // off the critical path
   hipLaunchKernelGGL(k_mab0_post1, dim3((unsigned)cdiv(n1, 256), J.n), dim3(256), 0, ts, J);
   PCA_TRY(check_launch("k_mab0_post1"));
-  hipLaunchKernelGGL(k_mab0_post2, dim3((unsigned)cdiv(n2, 256), J.n), dim3(256), 0, ts, J);
+  hipLaunchKernelGGL(k_mab0_post2, dim3((unsigned)cdiv(n2, 256), J.n), dim3(256), 0, ts, J,
+                     SlabSumJobs{});
   return check_launch("k_mab0_post2");
 }
 
@@ -930,7 +945,8 @@ size_t mab0_carve_bwd_ws(const pca_mab_shape& s, Mab0BwdWs* out, void* base) {
   w.dTb = c.take<__bf16>((size_t)s.B * Rp * s.dk);
   w.dTt = c.take<__bf16>((size_t)s.B * Rp * s.dk);
   w.GtP = c.take<__bf16>((size_t)Rp * s.dk);
-  w.slabs = s.dk <= 4 ? nullptr : c.take<float>((size_t)s.B * mab0_bwd_splits(s) * R * s.dk);
+  w.slabs = c.take<float>(s.dk <= 4 ? (size_t)s.B * R * s.dk
+                                     : (size_t)s.B * mab0_bwd_splits(s) * R * s.dk);
   if (out) *out = w;
   return c.off;
 }
@@ -984,10 +1000,24 @@ int mab0_bf16_bwd_ex(const pca_mab_shape& s, const float* I, const void* X,
   // (with head_done the caller's k_mid_bwd has cleared DG)
 
   if (small) {
+    // slab mode: per-set partials [B][R][dk] instead of atomics, summed in a fixed order
+    float* sl = (wgrad_slabs_on() && (R * dk) % 4 == 0) ? w.slabs : nullptr;
     hipLaunchKernelGGL(k_mab0_bwd_small, dim3(s.B, (R % 64 == 0 && R <= 512) ? 2 : 1), dim3(256), 0, st,
                        reinterpret_cast<const float*>(X), v.Gf, w.dTf, v.LSE,
-                       w.Delta, s.nk, R, Rp, dk, w.DG, s.k_lengths, nullptr);
+                       w.Delta, s.nk, R, Rp, dk, w.DG, s.k_lengths, sl);
     PCA_TRY(check_launch("k_mab0_bwd_small"));
+    if (sl != nullptr) {
+      // (only the first R * dk floats of the [Rp][dk] block are read by the post stage)
+      const SlabSumJob sj{sl, w.DG, s.B, R * dk, 0, 0};
+      if (defer != nullptr) {
+        PCA_REQUIRE(defer->sums.n < 40, "mab0_bf16_bwd: slab-sum table full");
+        defer->sums.j[defer->sums.n++] = sj;
+      } else {
+        SlabSumJobs one{};
+        one.j[one.n++] = sj;
+        PCA_TRY(slab_sum_jobs(one, st));
+      }
+    }
   } else {
     const int S = mab0_bwd_splits(s);
     Mab0BwdArgs a{X, v.Gb, v.GtP, w.dTb, w.dTt, w.LSEp, w.Delta, dX, w.DG, s.B, s.nk,
@@ -1023,7 +1053,7 @@ int mab0_bf16_bwd_ex(const pca_mab_shape& s, const float* I, const void* X,
     // the caller defers them, else right away
     const SlabSumJob sj{w.slabs, w.DG, s.B * S, R * dk, 0};
     if (defer != nullptr) {
-      PCA_REQUIRE(defer->sums.n < 24, "mab0_bf16_bwd: slab-sum table full");
+      PCA_REQUIRE(defer->sums.n < 40, "mab0_bf16_bwd: slab-sum table full");
       defer->sums.j[defer->sums.n++] = sj;
     } else {
       SlabSumJobs one{};

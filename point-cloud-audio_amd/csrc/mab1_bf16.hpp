@@ -279,6 +279,7 @@ struct SmallWgradArgs {
   int dq, rows_per_wg;
   int64_t x_head_stride;
   float *dW, *db;
+  float* slab;            // per-workgroup partials [wg][128*dq + 128] instead of atomics (null: atomics)
 };
 // shared-query parameter gradients (dWk, dWq, dbq, dI) of up to 3 MABs: tiny, latency-bound
 // kernels, so callers may collect them and run ONE pair of launches at the end of a phase
@@ -320,6 +321,7 @@ inline bool slab_sum_job_ok(const SlabSumJob& j) {      // 16-byte accesses thro
 int slab_sum_jobs(const SlabSumJobs& J, hipStream_t st);
 struct BwdDefer {
   SlabSumJobs sums;       // partial sums the post stages read: run before them
+  SlabSumJobs late;       // partial sums only the optimizer reads (ride in the last launches)
   float* slab_ws;         // room for the weight-gradient partials of the two deferred lists
   size_t slab_cap;        // (bytes; null / 0: those reductions use fp32 atomics)
   Mab0PostJobs posts;

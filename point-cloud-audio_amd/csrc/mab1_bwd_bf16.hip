@@ -43,6 +43,7 @@ struct Mab1BwdArgs {
   float *dKpG, *dVpG;       // [B][nparts][MI][D] fp32 partial K/V gradients (fused mode)
   const float* Xs;          // layer 1 (dq <= 3): the fp32 points [B, N, dq] ...
   float *dWqS, *dbqS;       // ... and fc_q gradients accumulated here (fused reduction)
+  float* wq_slab;           // ... or, when set, per-workgroup partials [wg][D*dq + D] (fixed-order sum later)
   const float *WqF, *bqF;   // ... and fc_q itself: Qp is recomputed (2..3 FMAs per element)
                             //     instead of being saved by the forward and read back
   int dq;
@@ -485,7 +486,11 @@ void k_mab1_bwd(const Mab1BwdArgs a) {
 #pragma unroll
       for (int w = 0; w < NW; ++w) v += red[w * D * 4 + i];
       const int f = i >> 2, c = i & 3;
-      if (c < a.dq) atomicAdd(&a.dWqS[f * a.dq + c], v);
+      if (a.wq_slab != nullptr) {
+        float* slab = a.wq_slab + (int64_t)blockIdx.x * (D * a.dq + D);
+        if (c < a.dq) slab[f * a.dq + c] = v;
+        else if (c == 3) slab[D * a.dq + f] = v;
+      } else if (c < a.dq) atomicAdd(&a.dWqS[f * a.dq + c], v);
       else if (c == 3) atomicAdd(&a.dbqS[f], v);
     }
     __syncthreads();
@@ -945,12 +950,9 @@ int wgrad128_defer(BwdDefer* defer, const WgradJobs& jobs, bool bf16, int rows_p
   return PCA_OK;
 }
 
-bool wgrad_slabs_on() {
-  static const bool on = [] {
-    const char* e = getenv("PCA_WGRAD_SLABS");
-    return e != nullptr && e[0] == '1';
-  }();
-  return on;
+bool wgrad_slabs_on() {          // (read per call: a test switches it between two engines)
+  const char* e = getenv("PCA_WGRAD_SLABS");
+  return e != nullptr && e[0] == '1';
 }
 int bwd_defer_flush(BwdDefer& D, hipStream_t st) {
   hipStream_t ts = terminal_stream(st);
@@ -987,11 +989,22 @@ int bwd_defer_flush(BwdDefer& D, hipStream_t st) {
                   &D.sums, 0};
     static const int rpw32_env = getenv("PCA_WGRAD_RPW_F32") ? atoi(getenv("PCA_WGRAD_RPW_F32")) : 0;
     PCA_TRY(wgrad128_launch(D.wg_f32, false, false, rpw32_env > 0 ? rpw32_env : 128, ts, &sl));
+    used += (sl.used + 255) & ~(size_t)255;
     D.wg_f32.n = 0;
     D.sums.n = 0;
   }
   PCA_TRY(slab_sum_jobs(D.sums, ts));        // (nobody carried them)
   D.sums.n = 0;
+  for (int i = 0; i < D.late.n; ++i) {
+    PCA_REQUIRE(late.n < 40, "bwd_defer_flush: slab-sum table full");
+    late.j[late.n++] = D.late.j[i];
+  }
+  D.late.n = 0;
+  if (slab_mode && D.has_sw) {     // layer-1 fc_v gradient (rider of k_terminal1): slabs as well
+    const int nwg = (int)cdiv(D.sw.M, D.sw.rows_per_wg), stride = 128 * D.sw.dq + 128;
+    if ((128 * D.sw.dq) % 4 == 0 && used + (size_t)nwg * stride * 4 <= D.slab_cap)
+      D.sw.slab = D.slab_ws + used / sizeof(float);
+  }
   PCA_TRY(terminal_launch(D, st, &late));
   D.posts.n = 0;
   D.has_cls = D.has_sw = 0;
@@ -1002,7 +1015,7 @@ int wgrad_small_f32_launch(const float* G, const float* X, int64_t M, int dq,
                            int64_t x_head_stride, float* dW, float* db, hipStream_t st,
                            BwdDefer* defer) {
   if (defer != nullptr && !defer->has_sw) {
-    defer->sw = SmallWgradArgs{G, X, M, dq, 64, x_head_stride, dW, db};
+    defer->sw = SmallWgradArgs{G, X, M, dq, 64, x_head_stride, dW, db, nullptr};
     defer->has_sw = 1;
     return PCA_OK;
   }
@@ -1091,6 +1104,10 @@ int mab1_bf16_bwd_ex(const pca_mab_shape& s, const void* X, const float* H,
     const bool fwq = small && s.dq <= 3;
     a.Xs = reinterpret_cast<const float*>(X); a.dWqS = gr.wq; a.dbqS = gr.bq; a.dq = s.dq;
     a.WqF = p.wq; a.bqF = p.bq;
+    // slab mode: the (unused in this mode) dS block of the workspace holds the fc_q partials
+    if (fwq && wgrad_slabs_on() && (128 * s.dq) % 4 == 0 &&
+        (size_t)a.B * a.tiles_per_set / tpw * (128 * s.dq + 128) * 4 <= (size_t)M * s.h * s.nk * 2)
+      a.wq_slab = reinterpret_cast<float*>(w.dS);
     if (abf)
       rc = want_dx ? launch_bwd<128, 16, true, true, false, true>(a, st, flops, bytes)
            : fwq   ? launch_bwd<128, 16, false, true, true, true>(a, st, flops, bytes)
@@ -1105,6 +1122,19 @@ int mab1_bf16_bwd_ex(const pca_mab_shape& s, const void* X, const float* H,
                  : launch_bwd<128, 32, false, false, false, false>(a, st, flops, bytes);
   }
   PCA_TRY(rc);
+  if (a.wq_slab != nullptr) {        // fc_q of layer 1: the workgroups' partials, summed in a fixed order
+    const int nwg = a.B * a.tiles_per_set / a.tpw, n1 = 128 * s.dq, stride = n1 + 128;
+    SlabSumJobs two{};
+    two.j[two.n++] = SlabSumJob{a.wq_slab, gr.wq, nwg, n1, 1, stride};
+    two.j[two.n++] = SlabSumJob{a.wq_slab + n1, gr.bq, nwg, 128, 1, stride};
+    if (defer != nullptr) {
+      PCA_REQUIRE(defer->late.n + 2 <= 40, "mab1_bf16_bwd: slab-sum table full");
+      defer->late.j[defer->late.n++] = two.j[0];
+      defer->late.j[defer->late.n++] = two.j[1];
+    } else {
+      PCA_TRY(slab_sum_jobs(two, st));
+    }
+  }
   if (nparts_out != nullptr) *nparts_out = fuse ? a.tiles_per_set / a.tpw : 0;
   // ---- reductions over points (one launch for dWo / dWq when both operands are bf16) ----
   // 512 rows per workgroup: the fp32 atomics of the [128 x 128] result cost ~1 lane-op per

@@ -83,7 +83,7 @@ __device__ __forceinline__ void wgrad_small_body(const GT* __restrict__ G,
                                                  const float* __restrict__ X, int64_t M, int dq,
                                                  int rows_per_wg, int64_t x_head_stride,
                                                  float* __restrict__ dW, float* __restrict__ db,
-                                                 int blk) {
+                                                 int blk, float* __restrict__ slab = nullptr) {
   constexpr int D = 128;
   __shared__ float red[128][5];
   const int f = threadIdx.x & 127, ph = threadIdx.x >> 7;
@@ -118,7 +118,11 @@ __device__ __forceinline__ void wgrad_small_body(const GT* __restrict__ G,
     red[f][4] = bs;
   }
   __syncthreads();
-  if (ph == 0) {
+  if (ph == 0 && slab != nullptr) {       // this workgroup's partial (summed by rider rows later)
+    float* out = slab + (int64_t)blk * (D * dq + D);
+    for (int c = 0; c < dq; ++c) out[f * dq + c] = acc[c] + red[f][c];
+    out[D * dq + f] = bs + red[f][4];
+  } else if (ph == 0) {
     for (int c = 0; c < dq; ++c) atomicAdd(&dW[f * dq + c], acc[c] + red[f][c]);
     if (db != nullptr) atomicAdd(&db[f], bs + red[f][4]);
   }

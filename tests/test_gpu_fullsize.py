@@ -93,8 +93,8 @@ def test_cfg4_architecture_large_rows_vs_oracle(dev, mode):
 def test_d256_step_is_bit_reproducible(dev):
     """The d = 256 / 8 heads / m = 32 training step uses no fp32 atomics (weight-gradient slabs,
     per-workgroup partials + fixed-order sums everywhere): two forward + backward passes over the
-    same batch give bit-identical gradients and loss.  (The d = 128 path still reduces with atomics
-    in k_wgrad128 / k_mab0_bwd: DESIGN.md section 7.)"""
+    same batch give bit-identical gradients and loss.  (The d = 128 path does the same in its slab
+    mode, PCA_WGRAD_SLABS=1: next test.)"""
     import models
     from pca_hip import _lib, trainer
     B, N, din, d, h, m, C = 16, 1000, 3, 256, 8, 32, 50
@@ -114,3 +114,41 @@ def test_d256_step_is_bit_reproducible(dev):
     for g, loss in runs[1:]:
         assert torch.equal(g, runs[0][0])
         assert loss == runs[0][1]
+
+
+@pytest.mark.parametrize("din", [2, 3])
+def test_d128_step_is_bit_reproducible_in_slab_mode(dev, din, monkeypatch):
+    """PCA_WGRAD_SLABS=1: the d = 128 training step (BASELINE configs[0..2] architecture) reduces
+    without fp32 atomics as well - per-workgroup partials of k_wgrad128, k_mab0_bwd, the layer-1
+    fc_q / fc_v gradients and dG, all added in a fixed order by rider rows of later launches - so
+    three passes over the same batch give bit-identical gradients and loss, and the result agrees
+    with the default (atomic) mode to reduction-order rounding."""
+    import models
+    from pca_hip import _lib, trainer
+    B, N, d, h, m, C = 32, 501, 128, 4, 16, 50
+    torch.manual_seed(7)
+    net = models.ST(dim_input=din, num_outputs=1, dim_output=C, num_inds=m, dim_hidden=d,
+                    num_heads=h).to(dev)
+    X = T(gi.pc_input(8, B, N, din), dev)
+    y = T(gi.labels(9, B, C), dev)
+
+    def passes(n):
+        eng = trainer.STEngine(net, B, N, _lib.MODE_BF16, training=True)
+        out = []
+        for _ in range(n):
+            eng.grads.zero_()
+            eng.fwd_bwd(X, y, phase=-1)
+            torch.cuda.synchronize()
+            out.append((eng.grads.clone(), float(eng.loss)))
+        return out
+
+    ref = passes(1)[0]
+    monkeypatch.setenv("PCA_WGRAD_SLABS", "1")
+    runs = passes(3)
+    assert torch.isfinite(runs[0][0]).all()
+    for g, loss in runs[1:]:
+        assert torch.equal(g, runs[0][0])
+        assert loss == runs[0][1]
+    sc = max(1.0, float(ref[0].abs().max()))
+    assert float((runs[0][0] - ref[0]).abs().max()) <= 2e-5 * sc
+    assert abs(runs[0][1] - ref[1]) <= 1e-6 * max(1.0, abs(ref[1]))
