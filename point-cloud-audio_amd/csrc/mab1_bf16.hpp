@@ -334,7 +334,8 @@ struct BwdDefer {
   int has_cls, has_sw;
 };
 int bwd_defer_flush(BwdDefer& D, hipStream_t st);
-bool wgrad_slabs_on();       // PCA_WGRAD_SLABS=1: weight gradients of the fused d = 128 path without atomics
+bool wgrad_slabs_on();       // reductions of the fused d = 128 path as slabs + fixed-order sums
+                             // (PCA_WGRAD_SLABS=0: fp32 atomics)
 // PMA epilogue + classifier + cross-entropy (forward and backward) + PMA backward epilogue of the
 // train step in ONE launch per set (after mab0_bf16_fwd_ex(..., PCA_F_SKIP_EPILOGUE); followed
 // by mab0_bf16_bwd_ex(..., PCA_F_SKIP_HEAD)).  P [B, d] receives the pooled features; the

@@ -952,16 +952,18 @@ int wgrad128_defer(BwdDefer* defer, const WgradJobs& jobs, bool bf16, int rows_p
 
 bool wgrad_slabs_on() {          // (read per call: a test switches it between two engines)
   const char* e = getenv("PCA_WGRAD_SLABS");
-  return e != nullptr && e[0] == '1';
+  return !(e != nullptr && e[0] == '0');
 }
 int bwd_defer_flush(BwdDefer& D, hipStream_t st) {
   hipStream_t ts = terminal_stream(st);
   // The sums the post stages read (D.sums: dG of the few-queries blocks) ride in the first
-  // weight-gradient launch as extra workgroup rows.  Slab mode (PCA_WGRAD_SLABS=1, the caller lent
-  // room): the weight gradients themselves use no fp32 atomics either - per-workgroup partials,
-  // summed in a fixed order by rider rows of k_terminal1 (`late`: only the optimizer reads them).
-  // Off by default: at configs[1] it measured 0.343 ... 0.361 ms/step against a steady 0.348 with
-  // the atomics, depending on where the 35 MB of partials happen to lie (six same-box A/B runs).
+  // weight-gradient launch as extra workgroup rows.  Slab mode (the default when the caller lent
+  // room; PCA_WGRAD_SLABS=0 switches back to fp32 atomics): the weight gradients themselves use no
+  // atomics either - per-workgroup partials, summed in a fixed order by rider rows of k_terminal1
+  // (`late`: only the optimizer reads them).  With EVERY reduction of the step in this form
+  // configs[1] measured 0.324 ms/step against 0.335 with the atomics (three same-box pairs), and the
+  // step is bit-reproducible.  (With only k_wgrad128 converted it was 0.343 ... 0.361 against 0.348,
+  // depending on where the partials happened to lie.)
   const bool slab_mode = wgrad_slabs_on() && D.slab_ws != nullptr && D.slab_cap > 0;
   SlabSumJobs late{};
   size_t used = 0;          // the two lists' slabs lie back to back

@@ -93,8 +93,7 @@ def test_cfg4_architecture_large_rows_vs_oracle(dev, mode):
 def test_d256_step_is_bit_reproducible(dev):
     """The d = 256 / 8 heads / m = 32 training step uses no fp32 atomics (weight-gradient slabs,
     per-workgroup partials + fixed-order sums everywhere): two forward + backward passes over the
-    same batch give bit-identical gradients and loss.  (The d = 128 path does the same in its slab
-    mode, PCA_WGRAD_SLABS=1: next test.)"""
+    same batch give bit-identical gradients and loss.  (So does the d = 128 path: next test.)"""
     import models
     from pca_hip import _lib, trainer
     B, N, din, d, h, m, C = 16, 1000, 3, 256, 8, 32, 50
@@ -117,12 +116,12 @@ def test_d256_step_is_bit_reproducible(dev):
 
 
 @pytest.mark.parametrize("din", [2, 3])
-def test_d128_step_is_bit_reproducible_in_slab_mode(dev, din, monkeypatch):
-    """PCA_WGRAD_SLABS=1: the d = 128 training step (BASELINE configs[0..2] architecture) reduces
-    without fp32 atomics as well - per-workgroup partials of k_wgrad128, k_mab0_bwd, the layer-1
-    fc_q / fc_v gradients and dG, all added in a fixed order by rider rows of later launches - so
-    three passes over the same batch give bit-identical gradients and loss, and the result agrees
-    with the default (atomic) mode to reduction-order rounding."""
+def test_d128_step_is_bit_reproducible(dev, din, monkeypatch):
+    """The d = 128 training step (BASELINE configs[0..2] architecture) reduces without fp32 atomics
+    as well - per-workgroup partials of k_wgrad128, k_mab0_bwd, the layer-1 fc_q / fc_v gradients
+    and dG, all added in a fixed order by rider rows of later launches - so three passes over the
+    same batch give bit-identical gradients and loss, and the result agrees with the atomic mode
+    (PCA_WGRAD_SLABS=0) to reduction-order rounding."""
     import models
     from pca_hip import _lib, trainer
     B, N, d, h, m, C = 32, 501, 128, 4, 16, 50
@@ -142,8 +141,9 @@ def test_d128_step_is_bit_reproducible_in_slab_mode(dev, din, monkeypatch):
             out.append((eng.grads.clone(), float(eng.loss)))
         return out
 
+    monkeypatch.setenv("PCA_WGRAD_SLABS", "0")
     ref = passes(1)[0]
-    monkeypatch.setenv("PCA_WGRAD_SLABS", "1")
+    monkeypatch.delenv("PCA_WGRAD_SLABS")
     runs = passes(3)
     assert torch.isfinite(runs[0][0]).all()
     for g, loss in runs[1:]:
