@@ -403,6 +403,34 @@ def test_trainer_trajectory_golden(dev, golden_train, use_graph):
     assert n == steps * B and 0.0 <= acc <= 1.0
 
 
+def test_trainer_bf16_graph_equals_eager_bitwise(dev):
+    """BASELINE cfg2 size in the bench's mode (bf16): no reduction of the step uses fp32 atomics
+    (per-workgroup partials + fixed-order sums), so 12 optimiser steps by hipGraph replay, 12 by
+    eager launches and a second graph run give bit-identical parameters and gradients."""
+    import bench
+    import models
+    from pca_hip import _lib, trainer
+    cfg = dict(bench.CONFIGS["cfg2"])
+    ds, _ = bench.build_dataset(cfg, 4, dev, seed=0)
+
+    def run(graph):
+        torch.manual_seed(1)
+        net = models.ST(dim_input=2, dim_output=50, num_inds=16, dim_hidden=128,
+                        num_heads=4).to(dev)
+        tr = trainer.Trainer(net, ds, 128, mode=_lib.MODE_BF16, use_graph=graph, seed=1,
+                             keep_grads=True)
+        for _ in range(12):
+            tr.step()
+        torch.cuda.synchronize()
+        return tr.eng.flat.clone(), tr.eng.grads.clone()
+
+    g1, e1, g2 = run(True), run(False), run(True)
+    assert torch.isfinite(g1[0]).all() and float(g1[1].abs().max()) > 0
+    for other in (e1, g2):
+        assert torch.equal(g1[0], other[0])
+        assert torch.equal(g1[1], other[1])
+
+
 def test_trainer_full_size_graph_vs_eager_vs_oracle(dev):
     """BASELINE cfg2 size (B=128, N=512, d=128, h=4, m=16, C=50) on STFT-derived synthetic
     clips: (1) hipGraph replay and eager launches give the same parameters after 12 steps
