@@ -655,7 +655,7 @@ __global__ __launch_bounds__(256) void k_mab0_attn_small(const float* __restrict
                                                          int R, int dk, float* __restrict__ T,
                                                          float* __restrict__ LSE,
                                                          const int32_t* __restrict__ lengths) {
-  constexpr int CH = 2048;                    // points staged per chunk (<= 32 KiB of LDS)
+  constexpr int CH = PCA_POINT_CHUNK;         // points staged per chunk (16 KiB of LDS)
   __shared__ float sM[256], sL[256], sT[256][4];
   __shared__ __attribute__((aligned(16))) float sX[CH * 4];
   const int b = blockIdx.x, tid = threadIdx.x;
@@ -669,45 +669,58 @@ __global__ __launch_bounds__(256) void k_mab0_attn_small(const float* __restrict
 #pragma unroll
   for (int c = 0; c < 4; ++c) gk[c] = c < dk ? Gf[r * dk + c] : 0.f;
   float m = -INFINITY, l = 0.f, t[4] = {0.f, 0.f, 0.f, 0.f};
+  f32x2 l2 = {0.f, 0.f}, t2[4] = {{0.f, 0.f}, {0.f, 0.f}, {0.f, 0.f}, {0.f, 0.f}};
   int len = N;
   if (lengths != nullptr) len = lengths[b] < N ? lengths[b] : N;
+  float xr[16];
+  if (len > 0) fetch_points(X + (int64_t)b * N * dk, len < CH ? len : CH, dk, xr);
   for (int n0 = 0; n0 < len; n0 += CH) {
     const int cn = (len - n0 < CH) ? len - n0 : CH;
-    __syncthreads();
-    // coalesced copy of cn*dk floats, re-laid out as [point][4]
-    for (int i = tid; i < cn * 4; i += 256) {       // unused components must be zero, not stale LDS
-      const int pt = i >> 2, c = i & 3;
-      sX[i] = c < dk ? X[((int64_t)b * N + n0 + pt) * dk + c] : 0.f;
-    }
-    __syncthreads();
-    // online softmax over this thread's points of the chunk, 4 at a time (one rescale per 4)
-    for (int n = part; n < cn; n += 4 * parts) {
-      float sv[4], xv[4][4];
+    // the chunk as [pair of points][component][2]: the loop below works on two points per
+    // packed-fp32 instruction (v_pk_fma_f32 / v_pk_mul_f32 run two fp32 lanes per issue slot), whose
+    // operands are the register PAIRS {x_a[c], x_b[c]} this layout delivers; the next chunk's loads
+    // are in flight while this one is worked on
+    const int npairs = (cn + 1) >> 1;
+    commit_points(xr, cn, dk, sX);
+    if (n0 + CH < len)
+      fetch_points(X + ((int64_t)b * N + n0 + CH) * dk, (len - n0 - CH < CH) ? len - n0 - CH : CH, dk, xr);
+    // online softmax over this thread's pairs of the chunk, four pairs at a time (one rescale per 8 points)
+    for (int q = part; q < npairs; q += 4 * parts) {
+      f32x2 sv[4], xv[4][4];
 #pragma unroll
       for (int u = 0; u < 4; ++u) {
-        const int nn = n + u * parts;
-        const float4 x4 = nn < cn ? *reinterpret_cast<const float4*>(&sX[nn * 4])
-                                  : float4{0.f, 0.f, 0.f, 0.f};
-        xv[u][0] = x4.x; xv[u][1] = x4.y; xv[u][2] = x4.z; xv[u][3] = x4.w;
-        sv[u] = nn < cn ? gk[0] * x4.x + gk[1] * x4.y + gk[2] * x4.z + gk[3] * x4.w : -INFINITY;
+        const int pq = q + u * parts;
+        const bool ok = pq < npairs;
+        const float4 lo = ok ? *reinterpret_cast<const float4*>(&sX[pq * 8]) : float4{0.f, 0.f, 0.f, 0.f};
+        const float4 hi = ok ? *reinterpret_cast<const float4*>(&sX[pq * 8 + 4]) : float4{0.f, 0.f, 0.f, 0.f};
+        xv[u][0] = f32x2{lo.x, lo.y}; xv[u][1] = f32x2{lo.z, lo.w};
+        xv[u][2] = f32x2{hi.x, hi.y}; xv[u][3] = f32x2{hi.z, hi.w};
+        sv[u] = gk[0] * xv[u][0] + gk[1] * xv[u][1] + gk[2] * xv[u][2] + gk[3] * xv[u][3];
+        if (!ok) sv[u] = f32x2{-INFINITY, -INFINITY};
+        else if (2 * pq + 1 >= cn) sv[u][1] = -INFINITY;           // the odd point of the chunk
       }
-      const float mn = fmaxf(fmaxf(m, fmaxf(sv[0], sv[1])), fmaxf(sv[2], sv[3]));
+      const float mn = fmaxf(fmaxf(fmaxf(m, fmaxf(sv[0][0], sv[0][1])), fmaxf(sv[1][0], sv[1][1])),
+                             fmaxf(fmaxf(sv[2][0], sv[2][1]), fmaxf(sv[3][0], sv[3][1])));
       // (raw v_exp_f32: exp2f adds a range test and a rescale per call for results below 2^-126,
       //  which are zero for every purpose here)
       const float al = __builtin_amdgcn_exp2f(m - mn);
-      l *= al;
+      l2 *= al;
 #pragma unroll
-      for (int c = 0; c < 4; ++c) t[c] *= al;
+      for (int c = 0; c < 4; ++c) t2[c] *= al;
 #pragma unroll
       for (int u = 0; u < 4; ++u) {
-        const float p = __builtin_amdgcn_exp2f(sv[u] - mn);          // exp2(-inf) = 0 for padding
-        l += p;
+        const f32x2 p = {__builtin_amdgcn_exp2f(sv[u][0] - mn),          // exp2(-inf) = 0 for padding
+                         __builtin_amdgcn_exp2f(sv[u][1] - mn)};
+        l2 += p;
 #pragma unroll
-        for (int c = 0; c < 4; ++c) t[c] = fmaf(p, xv[u][c], t[c]);
+        for (int c = 0; c < 4; ++c) t2[c] += p * xv[u][c];
       }
       m = mn;
     }
   }
+  l = l2[0] + l2[1];
+#pragma unroll
+  for (int c = 0; c < 4; ++c) t[c] = t2[c][0] + t2[c][1];
   if (part >= parts) { m = -INFINITY; l = 0.f; }
   sM[tid] = m; sL[tid] = l;
 #pragma unroll

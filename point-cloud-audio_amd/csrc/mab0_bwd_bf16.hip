@@ -364,7 +364,7 @@ __global__ __launch_bounds__(256) void k_mab0_bwd_small(
     const float* __restrict__ X, const float* __restrict__ Gf, const float* __restrict__ dTf,
     const float* __restrict__ LSE, const float* __restrict__ Delta, int N, int R, int Rp, int dk,
     float* __restrict__ DG, const int32_t* __restrict__ lengths, float* __restrict__ slabs) {
-  constexpr int CH = 2048;
+  constexpr int CH = PCA_POINT_CHUNK;
   __shared__ float sD[256][4];
   __shared__ __attribute__((aligned(16))) float sX[CH * 4];
   const int b = blockIdx.x, tid = threadIdx.x;
@@ -374,7 +374,8 @@ __global__ __launch_bounds__(256) void k_mab0_bwd_small(
   const int rl = tid % Rb, part = tid / Rb;
   const int r = row0 + rl;
   constexpr float LN2 = 0.6931471805599453f;
-  float gk[4], dt[4], acc[4] = {0.f, 0.f, 0.f, 0.f};
+  float gk[4], dt[4], acc[4];
+  f32x2 acc2[4] = {{0.f, 0.f}, {0.f, 0.f}, {0.f, 0.f}, {0.f, 0.f}};
 #pragma unroll
   for (int c = 0; c < 4; ++c) {
     gk[c] = c < dk ? Gf[r * dk + c] : 0.f;
@@ -383,26 +384,33 @@ __global__ __launch_bounds__(256) void k_mab0_bwd_small(
   const float lse = LSE[(int64_t)b * R + r], del = Delta[(int64_t)b * Rp + r];
   int len = N;
   if (lengths != nullptr) len = lengths[b] < N ? lengths[b] : N;
+  float xr[16];
+  if (len > 0) fetch_points(X + (int64_t)b * N * dk, len < CH ? len : CH, dk, xr);
   for (int n0 = 0; n0 < len; n0 += CH) {
     const int cn = (len - n0 < CH) ? len - n0 : CH;
-    __syncthreads();
-    for (int i = tid; i < cn * 4; i += 256) {       // unused components must be zero, not stale LDS
-      const int pt = i >> 2, c = i & 3;
-      sX[i] = c < dk ? X[((int64_t)b * N + n0 + pt) * dk + c] : 0.f;
-    }
-    __syncthreads();
+    // [pair of points][component][2] (as k_mab0_attn_small): two points per packed-fp32 instruction;
+    // unused components and the odd point of the chunk are zero (x = 0 contributes dS.x = 0); the
+    // next chunk's loads are in flight while this one is worked on
+    const int npairs = (cn + 1) >> 1;
+    commit_points(xr, cn, dk, sX);
+    if (n0 + CH < len)
+      fetch_points(X + ((int64_t)b * N + n0 + CH) * dk, (len - n0 - CH < CH) ? len - n0 - CH : CH, dk, xr);
     if (part < parts) {
 #pragma unroll 4
-      for (int n = part; n < cn; n += parts) {
-        const float4 x4 = *reinterpret_cast<const float4*>(&sX[n * 4]);
-        const float s = gk[0] * x4.x + gk[1] * x4.y + gk[2] * x4.z + gk[3] * x4.w;
-        const float da = dt[0] * x4.x + dt[1] * x4.y + dt[2] * x4.z + dt[3] * x4.w;
-        const float ds = LN2 * __builtin_amdgcn_exp2f(s - lse) * (da - del);
-        acc[0] = fmaf(ds, x4.x, acc[0]); acc[1] = fmaf(ds, x4.y, acc[1]);
-        acc[2] = fmaf(ds, x4.z, acc[2]); acc[3] = fmaf(ds, x4.w, acc[3]);
+      for (int q = part; q < npairs; q += parts) {
+        const float4 lo = *reinterpret_cast<const float4*>(&sX[q * 8]);
+        const float4 hi = *reinterpret_cast<const float4*>(&sX[q * 8 + 4]);
+        const f32x2 x0 = {lo.x, lo.y}, x1 = {lo.z, lo.w}, x2 = {hi.x, hi.y}, x3 = {hi.z, hi.w};
+        const f32x2 sc = gk[0] * x0 + gk[1] * x1 + gk[2] * x2 + gk[3] * x3;
+        const f32x2 da = dt[0] * x0 + dt[1] * x1 + dt[2] * x2 + dt[3] * x3;
+        const f32x2 pe = {__builtin_amdgcn_exp2f(sc[0] - lse), __builtin_amdgcn_exp2f(sc[1] - lse)};
+        const f32x2 ds = (LN2 * pe) * (da - del);
+        acc2[0] += ds * x0; acc2[1] += ds * x1; acc2[2] += ds * x2; acc2[3] += ds * x3;
       }
     }
   }
+#pragma unroll
+  for (int c = 0; c < 4; ++c) acc[c] = acc2[c][0] + acc2[c][1];
 #pragma unroll
   for (int c = 0; c < 4; ++c) sD[tid][c] = acc[c];
   __syncthreads();

@@ -18,6 +18,7 @@ typedef __attribute__((ext_vector_type(8))) __bf16 bf16x8;
 typedef __attribute__((ext_vector_type(4))) __bf16 bf16x4;
 typedef __attribute__((ext_vector_type(4))) short s16x4;
 typedef __attribute__((ext_vector_type(4))) float f32x4;
+typedef float f32x2 __attribute__((ext_vector_type(2)));   // packed-fp32 operand pair (v_pk_*_f32)
 
 // position p = 8g + j inside a 32-wide K block -> index of the element that k-slot (g, j)
 // carries when the B operand is built from two accumulator tiles
@@ -123,6 +124,43 @@ __device__ __forceinline__ bf16x8 ld_x8_guard(const void* X, int64_t set_row0, i
     for (int k = 0; k < 8; ++k) v[k] = (__bf16)0.f;
   }
   return v;
+}
+
+// A chunk of cn <= 1024 points with dk (<= 4) fp32 components each, contiguous in memory, into LDS as
+// [pair of points][component][2] (the operand pairs of the packed-fp32 loops of k_mab0_attn_small /
+// k_mab0_bwd_small), unused components and the odd point zero - in two halves, so that the loads of
+// the NEXT chunk are in flight while the current one is worked on:
+//   fetch_points   the raw cn*dk floats into 16 registers per thread (coalesced dwords, all issued
+//                  together: one float per loop trip, each waited for on its own, had made the
+//                  staging - not the arithmetic - the cost of those kernels)
+//   commit_points  registers -> LDS.  Every thread of the 256-thread workgroup must call it (two
+//                  barriers inside: the first also ends the previous chunk's reads of sX)
+constexpr int PCA_POINT_CHUNK = 1024;
+__device__ __forceinline__ void fetch_points(const float* __restrict__ X, int cn, int dk,
+                                             float (&v)[16]) {
+  const int n = cn * dk;
+#pragma unroll
+  for (int u = 0; u < 16; ++u) {
+    const int e = threadIdx.x + 256 * u;
+    v[u] = X[e < n ? e : n - 1];
+  }
+}
+__device__ __forceinline__ void commit_points(const float (&v)[16], int cn, int dk, float* sX) {
+  const int tid = threadIdx.x;
+  const int npairs = (cn + 1) >> 1, n = cn * dk;
+  __syncthreads();
+  if (dk < 4 || (cn & 1))
+    for (int i = tid; i < npairs * 8; i += 256) sX[i] = 0.f;
+  __syncthreads();
+#pragma unroll
+  for (int u = 0; u < 16; ++u) {
+    const int e = tid + 256 * u;
+    if (e < n) {
+      const int pt = e / dk, c = e - pt * dk;
+      sX[(pt >> 1) * 8 + c * 2 + (pt & 1)] = v[u];
+    }
+  }
+  __syncthreads();
 }
 
 }  // namespace pca
