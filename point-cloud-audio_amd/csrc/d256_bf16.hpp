@@ -51,6 +51,11 @@ struct Wgrad256Jobs {
 int mab0_d256_prep_all(int n, const pca_mab_shape* const* shapes, const float* const* I,
                        const pca_mab_params* params, void* const* saved, hipStream_t st);
 void mab0_d256_prep_done(bool on);
+// image modes the d = 256 backward asks for (fc_o / fc_q of the many-queries block, fc_k / fc_v of
+// the few-queries block): they follow the A/B switches of d256_host.hip
+int d256_bwd_wo_mode();
+int d256_bwd_wq_mode();
+int d256_bwd_kv_mode();
 void wgrad256_handoff_arm(bool on);
 bool wgrad256_handoff_pending();
 struct DxHandoff {            // mab1's dX = dQp Wq, deferred into the few-queries block's DX launch

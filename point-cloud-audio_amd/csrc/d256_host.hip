@@ -101,6 +101,15 @@ int wgrad256_handoff_flush(void* ws, hipStream_t st) {
 
 size_t mab1_d256_bwd_ws_bytes(const pca_mab_shape& s) { return mab1_d256_carve(s, nullptr, nullptr); }
 
+// PCA_BWD_O_FUSED=0: fc_o adjoint as its own row-GEMM launch (A/B measurements)
+static bool fuse_o_on() {
+  static const bool on = [] { const char* e = getenv("PCA_BWD_O_FUSED"); return !(e && e[0] == '0'); }();
+  return on;
+}
+int d256_bwd_wo_mode() { return fuse_o_on() ? 3 : 2; }
+int d256_bwd_wq_mode() { return rowstream_on() ? 3 : 2; }
+int d256_bwd_kv_mode() { return rowstream_on() ? 3 : 2; }
+
 int mab1_d256_bwd(const pca_mab_shape& s, const void* X, const float* Hk, const pca_mab_params& p,
                   const void* saved, const void* dY, void* dX, float* dH, int dk_accumulate,
                   const pca_mab_grads& gr, void* ws, hipStream_t st) {
@@ -118,12 +127,11 @@ int mab1_d256_bwd(const pca_mab_shape& s, const void* X, const float* Hk, const 
     return PCA_EUNSUPPORTED;
   }
   // PCA_BWD_O_FUSED=0: fc_o adjoint as its own row-GEMM launch (A/B measurements)
-  static const bool fuse_o_env = [] { const char* e = getenv("PCA_BWD_O_FUSED"); return !(e && e[0] == '0'); }();
-  const bool fuse_o = fuse_o_env;
+  const bool fuse_o = fuse_o_on();
   if (want_dx)
-    PCA_TRY(prep_weight2(p.wo, w.WoTP, fuse_o ? 3 : 2, p.wq, w.WqTP, rowstream_on() ? 3 : 2, D, D, st));
+    PCA_TRY(weight_image2(p.wo, &w.WoTP, d256_bwd_wo_mode(), p.wq, &w.WqTP, d256_bwd_wq_mode(), D, D, st));
   else
-    PCA_TRY(prep_weight(p.wo, w.WoTP, D, D, fuse_o ? 3 : 2, st));
+    PCA_TRY(weight_image1(p.wo, &w.WoTP, D, D, d256_bwd_wo_mode(), st));
   const __bf16* dYb = reinterpret_cast<const __bf16*>(dY);
   const __bf16* Xb = small ? nullptr : reinterpret_cast<const __bf16*>(X);
   if (!abf) {
@@ -338,7 +346,7 @@ int mab0_d256_fwd(const pca_mab_shape& s, const float* I, const void* X, const p
     static const bool fq_fused = [] { const char* e = getenv("PCA_FQ_FUSED_FWD"); return !(e && e[0] == '0'); }();
     if (s.mode != PCA_MODE_FP8 && rowstream_on() && fq_fused && m > 16) {
       // fc_k / fc_v over the keys and the attention in one pass over X (k_fq_proj_fwd)
-      PCA_TRY(prep_weight2(p.wk, WkP, 0, p.wv, WvP, 0, D, D, st));
+      PCA_TRY(weight_image2(p.wk, &WkP, 0, p.wv, &WvP, 0, D, D, st));
       const double pts = (double)M;
       ProfScope ps(PCA_K_MAB0_FWD, st, 2.0 * pts * (2.0 * D * D + 2.0 * m * D), pts * 2.0 * D);
       PCA_TRY(fq_proj_attn_fwd256(Xb, WkP, WvP, p.bk, p.bv, v.Qp, s.B, s.nk, m, s.k_lengths, v.Kp,
@@ -358,7 +366,7 @@ int mab0_d256_fwd(const pca_mab_shape& s, const float* I, const void* X, const p
       }
     } else {
       if (rowstream_on()) {                  // one pass over X, weights in registers
-        PCA_TRY(prep_weight2(p.wk, WkP, 0, p.wv, WvP, 0, D, D, st));
+        PCA_TRY(weight_image2(p.wk, &WkP, 0, p.wv, &WvP, 0, D, D, st));
         PCA_TRY(rowstream256_proj2(Xb, WkP, WvP, p.bk, p.bv, v.Kp, v.Vp, s.B, s.nk, st));   // modules.py:21
       } else {
         PCA_TRY(prep_weight(p.wk, WkP, D, D, 1, st));
@@ -500,7 +508,7 @@ int mab0_d256_bwd(const pca_mab_shape& s, const float* I, const void* X, const p
       const bool f32 = s.k_dtype == PCA_F32;
       __bf16* dXb = f32 ? w.dXb : reinterpret_cast<__bf16*>(dX);
       if (rowstream_on()) {                  // dKp Wk + dVp Wv in one pass, weights in registers
-        PCA_TRY(prep_weight2(p.wk, w.WkTP, 3, p.wv, w.WvTP, 3, D, D, st));
+        PCA_TRY(weight_image2(p.wk, &w.WkTP, 3, p.wv, &w.WvTP, 3, D, D, st));
         if (g_handoff.has_dx && !f32 && dk_accumulate && g_handoff.dx.dX == dXb &&
             g_handoff.dx.B == s.B && g_handoff.dx.N == s.nk) {
           // ... and mab1's dQp Wq (it would have written dX first; nothing to accumulate onto)

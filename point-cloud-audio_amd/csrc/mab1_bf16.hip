@@ -785,6 +785,31 @@ int prep_weight(const float* src, __bf16* dst, int rows, int cols, int mode, hip
   return check_launch("k_prep_weight");
 }
 
+static thread_local const WeightImages* t_images = nullptr;
+void weight_images_use(const WeightImages* t) { t_images = t; }
+static __bf16* image_of(const float* src, int mode, int rows, int cols) {
+  if (t_images == nullptr) return nullptr;
+  for (int i = 0; i < t_images->n; ++i) {
+    const WeightImages::E& e = t_images->e[i];
+    if (e.src == src && e.mode == mode && e.rows == rows && e.cols == cols) return e.img;
+  }
+  return nullptr;
+}
+int weight_image1(const float* src, __bf16** dst, int rows, int cols, int mode, hipStream_t st) {
+  if (__bf16* im = image_of(src, mode, rows, cols)) { *dst = im; return PCA_OK; }
+  return prep_weight(src, *dst, rows, cols, mode, st);
+}
+int weight_image2(const float* src0, __bf16** dst0, int mode0, const float* src1, __bf16** dst1,
+                  int mode1, int rows, int cols, hipStream_t st) {
+  __bf16* i0 = image_of(src0, mode0, rows, cols);
+  __bf16* i1 = image_of(src1, mode1, rows, cols);
+  if (i0 == nullptr && i1 == nullptr)
+    return prep_weight2(src0, *dst0, mode0, src1, *dst1, mode1, rows, cols, st);
+  if (i0 != nullptr) *dst0 = i0; else PCA_TRY(prep_weight(src0, *dst0, rows, cols, mode0, st));
+  if (i1 != nullptr) *dst1 = i1; else PCA_TRY(prep_weight(src1, *dst1, rows, cols, mode1, st));
+  return PCA_OK;
+}
+
 // PCA_D256_FUSED=0: the two-launch form (Q phase + row-GEMM O phase) for A/B measurements
 static bool fused256_on() {
   static const bool on = [] {
@@ -805,6 +830,10 @@ bool mab1_saves_qp(const pca_mab_shape& s) {
   static const bool save256 = [] { const char* e = getenv("PCA_L1_SAVE_QP"); return e && e[0] == '1'; }();
   if (s.d == 256 && s.nk == 32 && fuse_o && !save256) return false;
   return true;
+}
+
+int mab1_fwd_wo_mode(const pca_mab_shape& s) {
+  return (s.d == 256 && s.y_dtype == PCA_BF16 && fused256_on()) ? 0 : 1;
 }
 
 bool mab1_bf16_supported(const pca_mab_shape& s, bool inference) {
@@ -893,9 +922,9 @@ int mab1_bf16_fwd_ex(const pca_mab_shape& s, const void* X, const float* H,
     WoP = img->WoP;
   } else {
     // (d = 256 with bf16 activations runs k_isab1_fwd256, which takes Wo as a natural image too)
-    const int wo_mode = (d == 256 && s.y_dtype == PCA_BF16 && fused256_on()) ? 0 : 1;
-    if (!small) PCA_TRY(prep_weight2(p.wq, WqB, 0, p.wo, WoP, wo_mode, d, d, st));
-    else PCA_TRY(prep_weight(p.wo, WoP, d, d, wo_mode, st));
+    const int wo_mode = mab1_fwd_wo_mode(s);
+    if (!small) PCA_TRY(weight_image2(p.wq, &WqB, 0, p.wo, &WoP, wo_mode, d, d, st));
+    else PCA_TRY(weight_image1(p.wo, &WoP, d, d, wo_mode, st));
   }
   if (!(flags & PCA_F_KV_READY) && d > 128) {
     // Kp = H Wk^T + bk, Vp = H Wv^T + bv as MFMA products (fp32 accumulation; the operand

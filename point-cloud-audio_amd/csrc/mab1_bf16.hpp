@@ -138,6 +138,20 @@ struct PrepJobs {
   int n;
 };
 int prep_jobs_launch(const PrepJobs& jobs, hipStream_t st);
+// Weight images prepared ahead by the caller (the ST engine: every bf16 image the d = 256 blocks of a
+// training step will ask for, in ONE launch at the start of the step instead of one ~5 us launch per
+// block and direction).  While a table is in use on the calling thread, weight_image1 / 2 redirect
+// *dst to a registered image of (src, mode, rows, cols) instead of converting into *dst; anything
+// not registered is converted as before, so a table can only save launches, never change results.
+struct WeightImages {
+  struct E { const float* src; int mode, rows, cols; __bf16* img; } e[24];
+  int n;
+};
+void weight_images_use(const WeightImages* t);       // thread-local; nullptr ends the scope
+int weight_image1(const float* src, __bf16** dst, int rows, int cols, int mode, hipStream_t st);
+int weight_image2(const float* src0, __bf16** dst0, int mode0, const float* src1, __bf16** dst1,
+                  int mode1, int rows, int cols, hipStream_t st);
+int mab1_fwd_wo_mode(const pca_mab_shape& s);        // image mode of fc_o the mab1 forward asks for
 // the weight images AND the query-side tensors of a step in ONE launch (both depend on the
 // parameters only; blockIdx.y selects the job, the two kinds share the grid)
 int prep_all_launch(const PrepJobs& W, const Mab0PrepJobs& Q, hipStream_t st);

@@ -132,6 +132,7 @@ struct Ws {
   bool fused[2];
   float* wg_slabs;           // weight-gradient partials of the deferred reductions (fused d = 128)
   size_t wg_slab_bytes;
+  __bf16* img256;            // d = 256: 24 weight images [256][256] prepared in one launch per step
 };
 
 inline size_t carve(const pca_st_config& c, int training, Ws* out, void* base) {
@@ -188,8 +189,44 @@ inline size_t carve(const pca_st_config& c, int training, Ws* out, void* base) {
     w.wg_slab_bytes = 2 * (size_t)slab_mb * 1024 * 1024;
     w.wg_slabs = cv.take<float>(w.wg_slab_bytes / sizeof(float));
   }
+  if (training && c.d == 256 && c.mode == PCA_MODE_BF16)
+    w.img256 = cv.take<__bf16>((size_t)24 * 256 * 256);
   if (out) *out = w;
   return cv.off;
+}
+
+// Every bf16 weight image the d = 256 blocks of a training step ask for (weight_image1 / 2 in
+// mab1_bf16.hip, d256_host.hip), registered in `tab`; launch != 0 also converts them, all in one
+// launch.  A request this list does not foresee is converted on the spot by the block itself.
+inline int images256_prepare(const pca_st_config& c, const Layout& L, const Shapes& s, const float* p,
+                             const Ws& w, WeightImages* tab, bool launch, hipStream_t st) {
+  tab->n = 0;
+  static const bool off = [] { const char* e = getenv("PCA_D256_IMAGES"); return e && e[0] == '0'; }();
+  if (w.img256 == nullptr || off) return PCA_OK;       // (PCA_D256_IMAGES=0: per-block conversions)
+  PrepJobs J{};
+  auto add = [&](const float* src, int mode) {
+    if (tab->n >= 24) return;
+    __bf16* img = w.img256 + (size_t)tab->n * 256 * 256;
+    tab->e[tab->n++] = WeightImages::E{src, mode, 256, 256, img};
+    J.j[J.n++] = PrepJob{src, img, 256, 256, mode};
+  };
+  for (int li = 0; li < 2; ++li) {
+    if (mab_kind(s.m1[li]) == 1 && s.m1[li].d == 256 && s.m1[li].nk == 32) {
+      const pca_mab_params pm = params_at(p, L.mab1[li]);
+      const bool small = s.m1[li].dq <= 4;
+      add(pm.wo, mab1_fwd_wo_mode(s.m1[li]));                 // forward: fc_o (and fc_q of a d -> d block)
+      if (!small) add(pm.wq, 0);
+      add(pm.wo, d256_bwd_wo_mode());                        // backward
+      if (!small) add(pm.wq, d256_bwd_wq_mode());
+    }
+    if (mab_kind(s.m0[li]) == 2 && s.m0[li].d == 256 && s.m0[li].dk == 256) {
+      const pca_mab_params pk = params_at(p, L.mab0[li]);
+      add(pk.wk, 0); add(pk.wv, 0);                          // forward: fc_k / fc_v over the keys
+      add(pk.wk, d256_bwd_kv_mode()); add(pk.wv, d256_bwd_kv_mode());
+    }
+  }
+  (void)c;
+  return launch ? prep_jobs_launch(J, st) : PCA_OK;
 }
 
 // PCA_D256_DEFER_POSTS=0: the d = 256 few-queries blocks run their post stages per block
@@ -351,6 +388,15 @@ int pca_st_train_fwd_bwd(const pca_st_config* c, const float* params, const floa
   pca::BwdDefer posts{};
   posts.slab_ws = w.wg_slabs;
   posts.slab_cap = w.wg_slab_bytes;
+  // d = 256: all weight images of the step in one launch (phase 1 of a split step finds the images
+  // of phase 0 still in place: the parameters do not change in between)
+  pca::WeightImages images{};
+  struct ImagesGuard {
+    explicit ImagesGuard(const pca::WeightImages* t) { pca::weight_images_use(t); }
+    ~ImagesGuard() { pca::weight_images_use(nullptr); }
+  };
+  PCA_TRY(pca::images256_prepare(*c, L, s, p, w, &images, phase != 1, st));
+  ImagesGuard images_guard(images.n > 0 ? &images : nullptr);
   if (phase != 1) {
     PCA_TRY(pca::forward(*c, L, s, p, X, w, true, st));
     if (pca::pma_head_ok(s)) {
