@@ -101,6 +101,26 @@ int wgrad256_handoff_flush(void* ws, hipStream_t st) {
 
 size_t mab1_d256_bwd_ws_bytes(const pca_mab_shape& s) { return mab1_d256_carve(s, nullptr, nullptr); }
 
+// [B*m]-row jobs (fp32 operands): queued in `defer` when the caller collects them (one launch for
+// all blocks at the end of the backward: bwd_defer_flush), else launched now
+static int wgrad256_short(const Wgrad256Jobs& jobs, void* ws, BwdDefer* defer, hipStream_t st) {
+  if (defer != nullptr && defer->wg256_ws != nullptr && defer->wg256_n + jobs.n <= 8) {
+    for (int i = 0; i < jobs.n; ++i) {
+      const Wgrad256Job& j = jobs.j[i];
+      defer->wg256[defer->wg256_n++] = BwdDefer::Wg256{j.G, j.A, j.dW, j.db, j.M};
+    }
+    return PCA_OK;
+  }
+  return wgrad256_launch_t(jobs, ws, true, st);
+}
+int wgrad256_flush_deferred(BwdDefer& D, hipStream_t st) {
+  Wgrad256Jobs J{};
+  for (int i = 0; i < D.wg256_n; ++i)
+    J.j[J.n++] = Wgrad256Job{D.wg256[i].G, D.wg256[i].A, D.wg256[i].dW, D.wg256[i].db, D.wg256[i].M};
+  D.wg256_n = 0;
+  return wgrad256_launch_t(J, D.wg256_ws, true, st);
+}
+
 // PCA_BWD_O_FUSED=0: fc_o adjoint as its own row-GEMM launch (A/B measurements)
 static bool fuse_o_on() {
   static const bool on = [] { const char* e = getenv("PCA_BWD_O_FUSED"); return !(e && e[0] == '0'); }();
@@ -112,7 +132,7 @@ int d256_bwd_kv_mode() { return rowstream_on() ? 3 : 2; }
 
 int mab1_d256_bwd(const pca_mab_shape& s, const void* X, const float* Hk, const pca_mab_params& p,
                   const void* saved, const void* dY, void* dX, float* dH, int dk_accumulate,
-                  const pca_mab_grads& gr, void* ws, hipStream_t st) {
+                  const pca_mab_grads& gr, void* ws, hipStream_t st, BwdDefer* defer) {
   PCA_REQUIRE(s.d == D && s.nk == 32 && s.h == H8, "mab1_d256_bwd: shape");
   Bf16OperandScope ops(true);          // the [B*m]-row GEMMs of the K / V tail: MFMA
   Mab1Saved v;
@@ -192,7 +212,7 @@ int mab1_d256_bwd(const pca_mab_shape& s, const void* X, const float* Hk, const 
     Wgrad256Jobs kv{};
     kv.j[kv.n++] = Wgrad256Job{w.dKp, Hk, gr.wk, gr.bk, Mk};
     kv.j[kv.n++] = Wgrad256Job{w.dVp, Hk, gr.wv, gr.bv, Mk};
-    PCA_TRY(wgrad256_launch_t(kv, w.wg, true, st));
+    PCA_TRY(wgrad256_short(kv, w.wg, defer, st));
   }
   if (dH != nullptr) {
     PCA_TRY(linear_dx_acc_f32(w.dKp, p.wk, dH, Mk, D, D, dk_accumulate ? 1 : 0, st));
@@ -458,7 +478,7 @@ int mab0_d256_bwd(const pca_mab_shape& s, const float* I, const void* X, const p
   {
     Wgrad256Jobs ej{};
     ej.j[ej.n++] = Wgrad256Job{w.dZ, v.O, gr.wo, gr.bo, Bm};
-    PCA_TRY(wgrad256_launch_t(ej, w.wg, true, st));
+    PCA_TRY(wgrad256_short(ej, w.wg, defer, st));
   }
   PCA_TRY(linear_dx_acc_f32(w.dZ, p.wo, w.dO, Bm, D, D, 1, st));
   const float sl2e = 1.4426950408889634f / sqrtf((float)D);

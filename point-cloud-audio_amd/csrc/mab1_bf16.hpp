@@ -336,6 +336,12 @@ int slab_sum_jobs(const SlabSumJobs& J, hipStream_t st);
 struct BwdDefer {
   SlabSumJobs sums;       // partial sums the post stages read: run before them
   SlabSumJobs late;       // partial sums only the optimizer reads (ride in the last launches)
+  // d = 256: the [B*m]-row weight-gradient jobs of all blocks (fp32 operands, k_wgrad256<float>):
+  // one launch + one sum at the end instead of one pair per block.  Collected only when wg256_ws is
+  // set (room for wgrad256_ws_bytes(8, rows)); the operands stay in the blocks' workspaces
+  struct Wg256 { const void *G, *A; float *dW, *db; int64_t M; } wg256[8];
+  int wg256_n;
+  void* wg256_ws;
   float* slab_ws;         // room for the weight-gradient partials of the two deferred lists
   size_t slab_cap;        // (bytes; null / 0: those reductions use fp32 atomics)
   Mab0PostJobs posts;
@@ -348,6 +354,7 @@ struct BwdDefer {
   int has_cls, has_sw;
 };
 int bwd_defer_flush(BwdDefer& D, hipStream_t st);
+int wgrad256_flush_deferred(BwdDefer& D, hipStream_t st);       // d256_host.hip
 bool wgrad_slabs_on();       // reductions of the fused d = 128 path as slabs + fixed-order sums
                              // (PCA_WGRAD_SLABS=0: fp32 atomics)
 // PMA epilogue + classifier + cross-entropy (forward and backward) + PMA backward epilogue of the
@@ -373,7 +380,7 @@ int mab0_bf16_bwd_ex(const pca_mab_shape& s, const float* I, const void* X,
 size_t mab1_d256_bwd_ws_bytes(const pca_mab_shape& s);
 int mab1_d256_bwd(const pca_mab_shape& s, const void* X, const float* H, const pca_mab_params& p,
                   const void* saved, const void* dY, void* dX, float* dH, int dk_accumulate,
-                  const pca_mab_grads& gr, void* ws, hipStream_t st);
+                  const pca_mab_grads& gr, void* ws, hipStream_t st, BwdDefer* defer = nullptr);
 bool mab0_d256_supported(const pca_mab_shape& s);
 size_t mab0_d256_saved_bytes(const pca_mab_shape& s);
 size_t mab0_d256_fwd_ws_bytes(const pca_mab_shape& s);

@@ -995,6 +995,7 @@ int bwd_defer_flush(BwdDefer& D, hipStream_t st) {
     D.wg_f32.n = 0;
     D.sums.n = 0;
   }
+  if (D.wg256_n > 0) PCA_TRY(wgrad256_flush_deferred(D, ts));
   PCA_TRY(slab_sum_jobs(D.sums, ts));        // (nobody carried them)
   D.sums.n = 0;
   for (int i = 0; i < D.late.n; ++i) {
@@ -1047,7 +1048,7 @@ int mab1_bf16_bwd_ex(const pca_mab_shape& s, const void* X, const float* H,
                      hipStream_t st, const IsabImg* img, float* zero_ptr, int zero_n,
                      int* nparts_out, BwdDefer* defer) {
   if (s.d == 256)       // three launches + the 256-wide weight-gradient reduction (d256_host.hip)
-    return mab1_d256_bwd(s, X, H, p, saved, dY, dX, dH, dk_accumulate, gr, ws, st);
+    return mab1_d256_bwd(s, X, H, p, saved, dY, dX, dH, dk_accumulate, gr, ws, st, defer);
   Mab1Saved v;
   mab1_carve_saved(s, &v, const_cast<void*>(saved));
   Mab1BwdWs w;

@@ -133,6 +133,9 @@ struct Ws {
   float* wg_slabs;           // weight-gradient partials of the deferred reductions (fused d = 128)
   size_t wg_slab_bytes;
   __bf16* img256;            // d = 256: 24 weight images [256][256] prepared in one launch per step
+  void* wg256_def;           // d = 256: slabs of the deferred [B*m]-row weight-gradient launch
+  void* scratch_m0;          // d = 256: enc.0's few-queries backward (its ISAB partner's [B*m]-row
+                             // operands in scratch_bw[0] stay in place until that launch)
 };
 
 inline size_t carve(const pca_st_config& c, int training, Ws* out, void* base) {
@@ -191,6 +194,11 @@ inline size_t carve(const pca_st_config& c, int training, Ws* out, void* base) {
   }
   if (training && c.d == 256 && c.mode == PCA_MODE_BF16)
     w.img256 = cv.take<__bf16>((size_t)24 * 256 * 256);
+  w.scratch_m0 = w.scratch_bw[0];
+  if (training && c.d == 256 && mab_kind(s.m0[0]) == 2 && mab_kind(s.m1[0]) == 1) {
+    w.wg256_def = cv.take<char>(wgrad256_ws_bytes(8, (int64_t)c.B * c.m));
+    w.scratch_m0 = cv.take<char>(mab_bwd_ws_bytes_any(s.m0[0]));
+  }
   if (out) *out = w;
   return cv.off;
 }
@@ -397,6 +405,14 @@ int pca_st_train_fwd_bwd(const pca_st_config* c, const float* params, const floa
   };
   PCA_TRY(pca::images256_prepare(*c, L, s, p, w, &images, phase != 1, st));
   ImagesGuard images_guard(images.n > 0 ? &images : nullptr);
+  // d = 256: the [B*m]-row weight-gradient jobs of all five blocks in one launch at the flush -
+  // needs every block's operands in place until then: the hand-over form of enc.1 (its few-queries
+  // block works in w.scratch) and a workspace of its own for enc.0's few-queries block
+  const bool hand1 = s.m1[1].d == 256 && pca::mab_kind(s.m1[1]) == 1 && pca::mab_kind(s.m0[1]) == 2;
+  static const bool wg_off = [] { const char* e = getenv("PCA_D256_DEFER_WGRAD"); return e && e[0] == '0'; }();
+  const bool defer_wg = !wg_off && w.wg256_def != nullptr && hand1 && pca::defer256_on() &&
+                        pca::mab_kind(s.pma) == 2 && s.pma.d == 256;
+  if (defer_wg) posts.wg256_ws = w.wg256_def;
   if (phase != 1) {
     PCA_TRY(pca::forward(*c, L, s, p, X, w, true, st));
     if (pca::pma_head_ok(s)) {
@@ -441,6 +457,11 @@ int pca_st_train_fwd_bwd(const pca_st_config* c, const float* params, const floa
       explicit HandGuard(bool o) : on(o) { if (on) pca::wgrad256_handoff_arm(true); }
       ~HandGuard() { if (on) pca::wgrad256_handoff_arm(false); }
     } hand_guard(hand);
+    if (defer_wg)
+      PCA_TRY(pca::mab1_bf16_bwd_ex(s.m1[1], w.Y[0], w.H[1], pca::params_at(p, L.mab1[1]),
+                                    w.saved[3], w.dY2, w.dY1, w.dH, 0, pca::grads_at(g, L.mab1[1]),
+                                    w.scratch_bw[1], 0, st, nullptr, nullptr, 0, nullptr, &posts));
+    else
     PCA_TRY(pca::mab_bwd_any(s.m1[1], w.Y[0], w.H[1], pca::params_at(p, L.mab1[1]),
                              w.saved[3], w.dY2, w.dY1, w.dH, 0, pca::grads_at(g, L.mab1[1]),
                              w.scratch_bw[1], st));
@@ -465,13 +486,19 @@ int pca_st_train_fwd_bwd(const pca_st_config* c, const float* params, const floa
                                  pca::grads_at(g, L.mab0[0]), pca::grads_at(g, L.mab1[0]),
                                  w.scratch_bw[0], w.img[0], st, &posts));
     } else {
+    if (defer_wg)
+      PCA_TRY(pca::mab1_bf16_bwd_ex(s.m1[0], X, w.H[0], pca::params_at(p, L.mab1[0]), w.saved[1],
+                                    w.dY1, nullptr, w.dH, 0, pca::grads_at(g, L.mab1[0]),
+                                    w.scratch_bw[0], 0, st, nullptr, nullptr, 0, nullptr, &posts));
+    else
     PCA_TRY(pca::mab_bwd_any(s.m1[0], X, w.H[0], pca::params_at(p, L.mab1[0]), w.saved[1],
                              w.dY1, nullptr, w.dH, 0, pca::grads_at(g, L.mab1[0]),
                              w.scratch_bw[0], st));
     if (s.m0[0].d == 256 && pca::mab_kind(s.m0[0]) == 2 && pca::defer256_on())
       PCA_TRY(pca::mab0_bf16_bwd_ex(s.m0[0], p + L.I[0], X, pca::params_at(p, L.mab0[0]),
                                     w.saved[0], w.dH, g + L.I[0], nullptr, 0,
-                                    pca::grads_at(g, L.mab0[0]), w.scratch_bw[0], 0, st, &posts));
+                                    pca::grads_at(g, L.mab0[0]),
+                                    defer_wg ? w.scratch_m0 : w.scratch_bw[0], 0, st, &posts));
     else
     PCA_TRY(pca::mab_bwd_any(s.m0[0], p + L.I[0], X, pca::params_at(p, L.mab0[0]),
                              w.saved[0], w.dH, g + L.I[0], nullptr, 0,
