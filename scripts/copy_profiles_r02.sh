@@ -12,6 +12,8 @@ cp $O/stats_cfg4/*/*kernel_stats.csv profiles/r02_bf16_cfg4_kernel_stats.csv
 python3 scripts/pmc_summary.py profiles/r02_hbm_traffic.json > /dev/null
 (echo "# SQ counters of the cfg4 step (bench.py --config cfg4 --no-graph, 3 steps), one rocprofv3 --pmc pass per counter group; kernel time from the --kernel-trace --stats pass of the same config (profiles/r02_bf16_cfg4_kernel_stats.csv)"
  python3 scripts/sq_summary.py $O/sqcfg4) > profiles/r02_sq_cfg4.txt
+(echo "# SQ counters of the cfg2 step (bench.py --no-graph, 6 steps), one rocprofv3 --pmc pass per counter group; kernel time from a --kernel-trace --stats pass of the same (un-captured) workload"
+ python3 scripts/sq_summary.py $O/sqcfg2) > profiles/r02_sq_cfg2.txt
 for v in fused pair; do
   (echo "# d=256 many-queries block forward, B=128 sets, bf16 in/out, inference ($v): whole-call times (HIP events), rocprofv3 kernel-trace averages per N, SQ counters (N=2048)"
    grep "whole call" $O/fwd256_$v/bench.log
