@@ -268,9 +268,17 @@ def main():
     local_rank = int(os.environ.get("PCA_FORCE_DEVICE", local_rank))
     torch.cuda.set_device(local_rank)
     dev = torch.device("cuda", local_rank)
+    backend, rccl_ranks = None, None
     if world > 1:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        dist.init_process_group(os.environ.get("PCA_DIST_BACKEND", "nccl"), device_id=dev)
+        backend = os.environ.get("PCA_DIST_BACKEND", "nccl")
+        dist.init_process_group(backend, device_id=dev)
+        # self-check of the exchange the step relies on: a sum of ones over the ranks, on the
+        # device, through the same backend (nccl = RCCL over xGMI) - reported in the JSON line
+        ones = torch.ones(1, dtype=torch.float32, device=dev)
+        dist.all_reduce(ones)
+        rccl_ranks = int(round(float(ones)))
+        assert rccl_ranks == world, f"all-reduce of ones over {world} ranks gave {rccl_ranks}"
 
     import models
     import pca_hip
@@ -346,6 +354,8 @@ def main():
         "sets_per_s": round(sets_per_s, 1),
         "train_loss_mean": round(loss_sum / max(n_seen, 1), 4),
         "stft_ms_per_clip": round(stft_s_per_clip * 1e3, 3),
+        "dist_backend": backend, "rccl_ranks": rccl_ranks,
+        "grad_allreduce_bytes": int(tr.eng.grads.numel()) * 4 if world > 1 else 0,
     }
     if win_ms:
         q = np.percentile(np.asarray(win_ms), [10, 50, 90])
@@ -370,13 +380,30 @@ def main():
             kernels = [(_lib.K_GEMM_F32, "k_gemm_f32", None,
                         "exact-fp32 parity path: strided VALU GEMMs, priced against the fp32 "
                         "vector/matrix peak (157.3 TFLOP/s)")]
+        elif cfg["d"] == 256:
+            # configs[3] / [4]: the dominant kernel is the weight-gradient reduction k_wgrad256
+            # (17 % of the step, profiles/r0*_bf16_cfg4_kernel_stats.csv), then k_attn1_bwd3
+            kernels = [
+                (_lib.K_WGRAD, "k_wgrad256 (dW = G^T A over the B*N rows, all jobs of the step; "
+                               "the [B*m]-row fp32 jobs of the deferred launch included)",
+                 None,
+                 "2*rows*256*256 FLOPs per job; algorithmic bytes = both operands of every job "
+                 "once (an operand shared by the jobs of one launch once)"),
+                (_lib.K_MAB1_BWD, "k_attn1_bwd3 (+ k_sum_parts256): fc_o adjoint + attention "
+                                  "adjoint of the many-queries block, both layers",
+                 None,
+                 "reference-formulation FLOPs of the launches inside the scope only: "
+                 "M*(2*d^2 + 8*m*d) (dX runs in k_rowstream, the weight gradients in k_wgrad256); "
+                 "algorithmic bytes = dY + Qp in (layer 1: the points), dZ + dQp out"),
+            ]
         else:
             kernels = [
                 (_lib.K_MAB1_BWD, "k_mab1_bwd (fused ISAB mab1 backward chain, both layers)",
                  "k_mab1_bwd_bytes_per_launch",
-                 "reference-formulation FLOPs 4*M*(dq*d + d^2 + 2*m*d) per launch (SURVEY 8d, "
-                 "backward = 2x forward); algorithmic bytes = dY in + X in + dX out, bf16 "
-                 "activations"),
+                 "reference-formulation FLOPs of what the launch computes: M*(2*d^2 + 8*m*d "
+                 "+ 2*dq*d [dX, or layer 1's in-kernel dWq]) (dWo / dWq of the d -> d layer run in "
+                 "k_wgrad128 and are not charged here); algorithmic bytes = dY in + X in + dX out, "
+                 "bf16 activations"),
                 (_lib.K_MAB0_BWD, "k_mab0_bwd (fused ISAB mab0 / PMA backward, few queries)",
                  "k_mab0_bwd_bytes_per_launch",
                  "reference-formulation FLOPs 4*M*(2*dk*d + 2*m*d) per launch; algorithmic bytes "

@@ -3004,8 +3004,13 @@ int wgrad256_nwg(int64_t maxM) {
   if (nwg > 256) nwg = 256;
   return nwg < 1 ? 1 : nwg;
 }
+// Room for `njobs` jobs of AT MOST maxM rows each.  wgrad256_nwg() is not monotonic in the row
+// count (64 rows per workgroup below 65 536 rows, 1024 above), and one workspace serves the long
+// [B N]-row jobs as well as the short [B m]-row ones of the same block: size for the largest
+// workgroup count any job of up to maxM rows can get.
 size_t wgrad256_ws_bytes(int njobs, int64_t maxM) {
-  const size_t nwg = (size_t)wgrad256_nwg(maxM);
+  size_t nwg = (size_t)cdiv(maxM < 1 ? 1 : maxM, 64);
+  if (nwg > 256) nwg = 256;
   return align256((size_t)njobs * nwg * 256 * 256 * sizeof(float)) +
          align256((size_t)njobs * nwg * 256 * sizeof(float));
 }
@@ -3027,9 +3032,12 @@ int wgrad256_launch_t(const Wgrad256Jobs& jobs, void* ws, bool f32_operands, hip
   float* bslabs = c.take<float>((size_t)jobs.n * nwg * 256);
   double rows = 0;
   for (int i = 0; i < jobs.n; ++i) rows += (double)jobs.j[i].M;
-  ProfScope ps(PCA_K_WGRAD, st, 2.0 * rows * 256 * 256, 4.0 * rows * 256);
   bool shared = jobs.n > 1;
   for (int i = 1; i < jobs.n; ++i) shared = shared && jobs.j[i].A == jobs.j[0].A;
+  // algorithmic bytes: both operands of every job once (a shared A operand once for all jobs)
+  const double eb = f32_operands ? 4.0 : 2.0;
+  const double opbytes = shared ? eb * 256 * (rows + (double)jobs.j[0].M) : 2.0 * eb * 256 * rows;
+  ProfScope ps(PCA_K_WGRAD, st, 2.0 * rows * 256 * 256, opbytes);
   if (shared) rpw = -rpw;
   if (f32_operands)
     hipLaunchKernelGGL(k_wgrad256<float>, dim3(nwg * jobs.n), dim3(512), 0, st, jobs, rpw, slabs,

@@ -79,19 +79,24 @@ static size_t mab1_d256_carve(const pca_mab_shape& s, Mab1D256Ws* out, void* bas
   w.dKpPart = c.take<float>((size_t)s.B * parts * s.nk * D);
   w.dVpPart = c.take<float>((size_t)s.B * parts * s.nk * D);
   {
-    const size_t a = wgrad256_ws_bytes(2, (int64_t)M), b = wgrad_small256_ws_bytes((int64_t)M);
+    // serves the long {dZ, O} / {dQp, X} jobs ([B nq] rows) AND the short fc_k / fc_v ones ([B nk])
+    const int64_t Mk = (int64_t)s.B * s.nk, Mw = (int64_t)M > Mk ? (int64_t)M : Mk;
+    const size_t a = wgrad256_ws_bytes(2, Mw), b = wgrad_small256_ws_bytes((int64_t)M);
     w.wg = c.take<char>(a > b ? a : b);      // (the two reductions run one after the other)
   }
   if (out) *out = w;
   return c.off;
 }
+// mab1's deferred dX = dQp Wq, written (not accumulated) now
+static int wgrad256_handoff_flush_dx(hipStream_t st) {
+  if (!g_handoff.has_dx) return PCA_OK;
+  g_handoff.has_dx = false;
+  return rowstream256_dx1(g_handoff.dx.dQp, g_handoff.dx.WqT, g_handoff.dx.dX, g_handoff.dx.B,
+                          g_handoff.dx.N, st);
+}
 // a handed-over job nobody took (the following block was not the projected-keys few-queries one)
 int wgrad256_handoff_flush(void* ws, hipStream_t st) {
-  if (g_handoff.has_dx) {
-    g_handoff.has_dx = false;
-    PCA_TRY(rowstream256_dx1(g_handoff.dx.dQp, g_handoff.dx.WqT, g_handoff.dx.dX, g_handoff.dx.B,
-                             g_handoff.dx.N, st));
-  }
+  PCA_TRY(wgrad256_handoff_flush_dx(st));
   if (!g_handoff.has) return PCA_OK;
   Wgrad256Jobs jobs{};
   jobs.j[jobs.n++] = g_handoff.job;
@@ -134,7 +139,7 @@ int mab1_d256_bwd(const pca_mab_shape& s, const void* X, const float* Hk, const 
                   const void* saved, const void* dY, void* dX, float* dH, int dk_accumulate,
                   const pca_mab_grads& gr, void* ws, hipStream_t st, BwdDefer* defer) {
   PCA_REQUIRE(s.d == D && s.nk == 32 && s.h == H8, "mab1_d256_bwd: shape");
-  Bf16OperandScope ops(true);          // the [B*m]-row GEMMs of the K / V tail: MFMA
+  Bf16OperandScope ops(1);             // the [B*m]-row GEMMs of the K / V tail: MFMA
   Mab1Saved v;
   mab1_carve_saved(s, &v, const_cast<void*>(saved));
   Mab1D256Ws w;
@@ -162,10 +167,12 @@ int mab1_d256_bwd(const pca_mab_shape& s, const void* X, const float* Hk, const 
       Xb = w.Xb;
     }
   }
-  // reference-formulation FLOPs / algorithmic bytes of the whole block's backward
-  const double flops = 4.0 * M * ((double)s.dq * D + (double)D * D + 2.0 * s.nk * D);
-  const double bytes = (double)M * (2.0 * D + (small ? 4.0 * s.dq : 2.0 * D) +
-                                    (want_dx ? 2.0 * D : 0.0));
+  // reference-formulation FLOPs / algorithmic bytes of the launches inside the scope (round 3: the
+  // scope closes after the fc_o + attention adjoint - dX runs in k_rowstream, every weight gradient
+  // in k_wgrad256, each with a scope of its own or none): dO = dY + dZ Wo (2 M d^2) and the
+  // attention adjoint (8 M m d); dY and Qp (layer 1: the points) in, dZ and dQp out
+  const double flops = (double)M * (2.0 * D * D + 8.0 * s.nk * D);
+  const double bytes = (double)M * (2.0 * D + (small ? 4.0 * s.dq : 2.0 * D) + 4.0 * D);
   ProfScope ps(PCA_K_MAB1_BWD, st, flops, bytes);
   if (fuse_o) {
     // layer 1 (dq <= 4): Qp is recomputed from the points (mab1_saves_qp() == false: not saved)
@@ -177,6 +184,7 @@ int mab1_d256_bwd(const pca_mab_shape& s, const void* X, const float* Hk, const 
     PCA_TRY(attn1_bwd256(w.dO, v.QpS, v.KpP, v.VpP, v.Kt, w.dQp, w.dKpPart, w.dVpPart, w.dKp,
                          w.dVp, s.B, s.nq, st));
   }
+  ps.end();
   if (want_dx) {
     __bf16* dXb = abf ? reinterpret_cast<__bf16*>(dX) : w.dXb;
     if (rowstream_on() && g_handoff.armed && abf) {
@@ -190,7 +198,6 @@ int mab1_d256_bwd(const pca_mab_shape& s, const void* X, const float* Hk, const 
     }
     if (!abf) PCA_TRY(cvt_bf16_f32(dXb, reinterpret_cast<float*>(dX), M * D, 0, st));
   }
-  ps.end();
   // weight gradients over the B*N rows
   Wgrad256Jobs jobs{};
   jobs.j[jobs.n++] = Wgrad256Job{w.dZ, v.OS, gr.wo, gr.bo, M};
@@ -314,12 +321,18 @@ int mab0_d256_prep_all(int n, const pca_mab_shape* const* shapes, const float* c
 }
 void mab0_d256_prep_done(bool on) { g_prep256_done = on; }
 
-static bool fq_epi_bf16() {
-  static const bool on = [] {
+// operand mode of fc_o (and its adjoint) on the [B*m] query rows of a few-queries block:
+// 2 (default) hi + lo bf16 pairs on the MFMA - fp32-level Z, so the ReLU mask is the exact one;
+// PCA_FQ_EPI=bf16: single bf16 operands (round 2; 0.3-0.85 % of dQ elements then differ from the
+// emulation through flipped pre-activations); PCA_FQ_EPI_F32=1: the exact fp32 GEMM (22 us a call)
+static int fq_epi_bf16() {
+  static const int mode = [] {
     const char* e = getenv("PCA_FQ_EPI_F32");
-    return !(e != nullptr && e[0] == '1');
+    if (e != nullptr && e[0] == '1') return 0;
+    const char* f = getenv("PCA_FQ_EPI");
+    return (f != nullptr && f[0] == 'b') ? 1 : 2;
   }();
-  return on;
+  return mode;
 }
 int mab0_d256_fwd(const pca_mab_shape& s, const float* I, const void* X, const pca_mab_params& p,
                   float* Hout, void* saved, void* ws, hipStream_t st) {
@@ -444,7 +457,10 @@ static size_t fq_carve_bwd(const pca_mab_shape& s, Fq256BwdWs* out, void* base) 
     if (s.k_dtype == PCA_F32) w.dXb = c.take<__bf16>(nelem(s, true));
     w.Delta = c.take<float>((size_t)s.B * H8 * MQ);
     w.dQpPart = c.take<float>((size_t)s.B * S * m * D);
-    w.wg = c.take<char>(wgrad256_ws_bytes(3, (int64_t)s.B * s.nk));         // (+ mab1's handed-over job)
+    {   // three [B nk]-row jobs (+ mab1's handed-over one is among them) and the [B m]-row fc_o job
+      const int64_t Mk = (int64_t)s.B * s.nk;
+      w.wg = c.take<char>(wgrad256_ws_bytes(3, Mk > (int64_t)Bm ? Mk : (int64_t)Bm));
+    }
     w.slabs = c.take<float>((size_t)cdiv((int64_t)Bm, 512) * D);          // column-sum partials
   } else {
     w.Delta = c.take<float>((size_t)s.B * R);
@@ -535,10 +551,16 @@ int mab0_d256_bwd(const pca_mab_shape& s, const float* I, const void* X, const p
           g_handoff.has_dx = false;
           PCA_TRY(rowstream256_dx3(g_handoff.dx.dQp, w.dKp, w.dVp, g_handoff.dx.WqT, w.WkTP, w.WvTP,
                                    dXb, s.B, s.nk, st));
-        } else
-        PCA_TRY(rowstream256_dx2(w.dKp, w.dVp, w.WkTP, w.WvTP, dXb, s.B, s.nk,
-                                 (!f32 && dk_accumulate) ? 1 : 0, st));
+        } else {
+          // a pending hand-over that cannot be fused here: mab1's dX has to exist before anything
+          // is accumulated onto it (it used to be written by the later flush,
+          // over this block's sum)
+          if (g_handoff.has_dx) PCA_TRY(wgrad256_handoff_flush_dx(st));
+          PCA_TRY(rowstream256_dx2(w.dKp, w.dVp, w.WkTP, w.WvTP, dXb, s.B, s.nk,
+                                   (!f32 && dk_accumulate) ? 1 : 0, st));
+        }
       } else {
+        if (g_handoff.has_dx) PCA_TRY(wgrad256_handoff_flush_dx(st));
         PCA_TRY(prep_weight(p.wk, w.WkTP, D, D, 2, st));
         PCA_TRY(prep_weight(p.wv, w.WvTP, D, D, 2, st));
         PCA_TRY(rowgemm256_dx(w.dKp, w.WkTP, dXb, s.B, s.nk, (!f32 && dk_accumulate) ? 1 : 0, st));

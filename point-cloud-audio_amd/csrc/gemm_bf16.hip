@@ -142,7 +142,11 @@ struct Stage {
 //   long K (the per-head products that reduce over the points)
 // The MFMA runs transposed (B fragment as the first operand), so a lane ends up with four
 // consecutive columns of one row of C: 16-byte stores when C allows them (vec_c).
-template <int MA, int MB, int WM, int WN>
+// HL: both operands enter as hi + lo bf16 pairs (hi = bf16(x), lo = bf16(x - hi)) and a K step is
+// three MFMAs (hi hi, hi lo, lo hi): 16 significant bits per operand, i.e. fp32-level results at
+// the launch cost of the bf16 product - for the [B m]-row epilogue GEMMs whose ReLU mask must not
+// depend on operand rounding (d256_host.hip).
+template <int MA, int MB, int WM, int WN, bool HL = false>
 __global__ __launch_bounds__(256) void k_gemm_bf16(pca_gemm_desc g, const float* __restrict__ A,
                                                     const float* __restrict__ B,
                                                     const float* __restrict__ bias,
@@ -153,9 +157,11 @@ __global__ __launch_bounds__(256) void k_gemm_bf16(pca_gemm_desc g, const float*
   constexpr int BM = 32 * WM, BN = 32 * WN;
   using SA = Stage<MA, BM>;
   using SB = Stage<MB, BN>;
-  __shared__ __attribute__((aligned(16))) char smem[(BM + BN) * PITCH];
+  __shared__ __attribute__((aligned(16))) char smem[(BM + BN) * PITCH * (HL ? 2 : 1)];
   char* const As = smem;
   char* const Bs = smem + BM * PITCH;
+  char* const AsL = smem + (BM + BN) * PITCH;          // HL only: the lo halves
+  char* const BsL = AsL + BM * PITCH;
 
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int r = lane & 15, gq = lane >> 4;
@@ -208,6 +214,14 @@ __global__ __launch_bounds__(256) void k_gemm_bf16(pca_gemm_desc g, const float*
     __syncthreads();                     // previous tile consumed
     SA::store(As, tid, av);
     SB::store(Bs, tid, bv);
+    if constexpr (HL) {
+#pragma unroll
+      for (int e = 0; e < SA::NV; ++e) av[e] -= (float)(__bf16)av[e];
+#pragma unroll
+      for (int e = 0; e < SB::NV; ++e) bv[e] -= (float)(__bf16)bv[e];
+      SA::store(AsL, tid, av);
+      SB::store(BsL, tid, bv);
+    }
     __syncthreads();
     if (kt + BK < k_end) {               // next tile's loads fly under the MFMAs
       SA::load(Ab + (kt + BK) * g.sa_k, g.sa_m, g.sa_k, g.M - m0, k_end - kt - BK, tid, va, av);
@@ -222,6 +236,15 @@ __global__ __launch_bounds__(256) void k_gemm_bf16(pca_gemm_desc g, const float*
       const bf16x8 bf = *reinterpret_cast<const bf16x8*>(Bs + (wn + 16 * j + r) * PITCH + 16 * gq);
 #pragma unroll
       for (int i = 0; i < WM; ++i) acc[i][j] = mfma32(bf, af[i], acc[i][j]);
+      if constexpr (HL) {
+        const bf16x8 bl = *reinterpret_cast<const bf16x8*>(BsL + (wn + 16 * j + r) * PITCH + 16 * gq);
+#pragma unroll
+        for (int i = 0; i < WM; ++i) {
+          const bf16x8 al = *reinterpret_cast<const bf16x8*>(AsL + (wm + 16 * i + r) * PITCH + 16 * gq);
+          acc[i][j] = mfma32(bl, af[i], acc[i][j]);
+          acc[i][j] = mfma32(bf, al, acc[i][j]);
+        }
+      }
     }
   }
 
@@ -360,8 +383,8 @@ void launch_vec(int ma, int mb, dim3 grid, hipStream_t st, const pca_gemm_desc& 
 }
 }  // namespace
 
-int gemm_bf16(const pca_gemm_desc& gin, const float* A, const float* B, const float* bias,
-              float* C, hipStream_t st) {
+static int gemm_bf16_impl(const pca_gemm_desc& gin, const float* A, const float* B,
+                          const float* bias, float* C, hipStream_t st, bool hl) {
   pca_gemm_desc g = gin;
   PCA_REQUIRE(A && B && C, "gemm_bf16: null operand");
   PCA_REQUIRE(g.M >= 0 && g.N >= 0 && g.K >= 0, "gemm_bf16: negative extent");
@@ -374,7 +397,9 @@ int gemm_bf16(const pca_gemm_desc& gin, const float* A, const float* B, const fl
   const int mb = stage_mode(B, g.sb_n, g.sb_k, g.sb_b1, g.sb_b2, &vb);
   const int vab = (va ? 1 : 0) | (vb ? 2 : 0);
   // the narrow tiles exist for the staging modes 0 / 1 only
-  const int tv = (ma == 2 || mb == 2) ? 0 : tile_variant(g.M, g.N, g.K, (int64_t)g.nb1 * g.nb2);
+  if (hl && (ma == 2 || mb == 2)) return gemm_f32(gin, A, B, bias, C, st);   // exact anyway
+  // (hi + lo operands: 32 x 32 tiles only - the problems it serves are [B m] x 256 x 256)
+  const int tv = hl ? 5 : (ma == 2 || mb == 2) ? 0 : tile_variant(g.M, g.N, g.K, (int64_t)g.nb1 * g.nb2);
   const int64_t tiles_m = cdiv(g.M, kTileM[tv]), tiles_n = cdiv(g.N, kTileN[tv]);
   const int64_t nbatch = (int64_t)g.nb1 * g.nb2;
   int split = g.split_k;
@@ -409,6 +434,15 @@ int gemm_bf16(const pca_gemm_desc& gin, const float* A, const float* B, const fl
   const int tm = (int)tiles_m, tn = (int)tiles_n;
   const int vc = (reinterpret_cast<uintptr_t>(C) & 15) == 0 && g.sc_m % 4 == 0 &&
                  g.sc_b1 % 4 == 0 && g.sc_b2 % 4 == 0;
+  if (hl) {
+#define PCA_GEMM_CASE(X, Y)                                                                   \
+  if (ma == X && mb == Y)                                                                     \
+    hipLaunchKernelGGL((k_gemm_bf16<X, Y, 1, 1, true>), grid, dim3(256), 0, st, g, A, B, bias, \
+                       C, split, kchunk, vc, remap, tm, tn, (int)nz, vab)
+    PCA_GEMM_CASE(0, 0); PCA_GEMM_CASE(0, 1); PCA_GEMM_CASE(1, 0); PCA_GEMM_CASE(1, 1);
+#undef PCA_GEMM_CASE
+    return check_launch("k_gemm_bf16<hl>");
+  }
   switch (tv) {
     case 1: launch_vec<8, 1>(ma, mb, grid, st, g, A, B, bias, C, split, kchunk, vc, remap, tm, tn, (int)nz, vab); break;
     case 2: launch_vec<8, 2>(ma, mb, grid, st, g, A, B, bias, C, split, kchunk, vc, remap, tm, tn, (int)nz, vab); break;
@@ -427,6 +461,15 @@ int gemm_bf16(const pca_gemm_desc& gin, const float* A, const float* B, const fl
     }
   }
   return check_launch("k_gemm_bf16");
+}
+
+int gemm_bf16(const pca_gemm_desc& g, const float* A, const float* B, const float* bias,
+              float* C, hipStream_t st) {
+  return gemm_bf16_impl(g, A, B, bias, C, st, false);
+}
+int gemm_bf16_hl(const pca_gemm_desc& g, const float* A, const float* B, const float* bias,
+                 float* C, hipStream_t st) {
+  return gemm_bf16_impl(g, A, B, bias, C, st, true);
 }
 
 }  // namespace pca

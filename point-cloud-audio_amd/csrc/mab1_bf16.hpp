@@ -234,11 +234,12 @@ int mab_f32_bwd(const pca_mab_shape& s, const float* Q, const float* K,
                 const pca_mab_params& p, const void* saved, const float* dY, float* dQ,
                 float* dK, int dk_accumulate, const pca_mab_grads& g, void* ws,
                 hipStream_t st);
-// while alive: linear_fwd_f32 / linear_bwd_f32 / linear_dx_acc_f32 use k_gemm_bf16 (bf16 MFMA
-// operands, fp32 accumulation and I/O) instead of the exact fp32 GEMM
+// while alive: linear_fwd_f32 / linear_bwd_f32 / linear_dx_acc_f32 use k_gemm_bf16 instead of the
+// exact fp32 GEMM: mode 1 = bf16 MFMA operands, mode 2 = hi + lo bf16 pairs (fp32-level results
+// at the same launch cost); fp32 accumulation and I/O
 struct Bf16OperandScope {
-  bool prev;
-  explicit Bf16OperandScope(bool on);
+  int prev;
+  explicit Bf16OperandScope(int mode);
   ~Bf16OperandScope();
 };
 int linear_fwd_f32(const float* X, const float* W, const float* b, float* Y, int64_t M,

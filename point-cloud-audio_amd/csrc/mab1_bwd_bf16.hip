@@ -1080,8 +1080,13 @@ int mab1_bf16_bwd_ex(const pca_mab_shape& s, const void* X, const float* H,
   a.scale = 1.0f / sqrtf((float)d);
   a.scale_log2e = 1.4426950408889634f * a.scale;
   a.dbg_wg = getenv("PCA_DBG_WG") ? atoi(getenv("PCA_DBG_WG")) : 0;
-  // reference-formulation backward FLOPs of the block: 2x forward
-  const double flops = 4.0 * M * ((double)s.dq * d + (double)d * d + 2.0 * MI * d);
+  // reference-formulation FLOPs of what THIS launch computes (round 3: not the whole block's
+  // backward - dWo and, beyond layer 1, dWq run in k_wgrad128 and are charged there): fc_o adjoint
+  // dO = dY + dZ Wo (2 M d^2), attention adjoint (recomputed scores, dP, dQp, dKp, dVp: 8 M m d),
+  // dX = dQp Wq (2 M dq d) when asked for, layer 1's in-kernel dWq (2 M dq d)
+  const double flops = (double)M * (2.0 * d * d + 8.0 * MI * d +
+                                    (want_dx ? 2.0 * s.dq * d : 0.0) +
+                                    ((small && s.dq <= 3 && MI == 16) ? 2.0 * s.dq * d : 0.0));
   // algorithmic HBM bytes (each operand once): dY in, X in, dX out
   const double eb = abf ? 2.0 : 4.0;
   const double bytes = (double)M * (eb * d + (small ? 4.0 * s.dq : eb * s.dq) +

@@ -16,16 +16,17 @@ namespace pca {
 namespace {
 
 // PCA_MODE_BF16 on a shape without fused kernels: the same chain with bf16 MFMA operands
-thread_local bool t_bf16_operands = false;
+thread_local int t_bf16_operands = 0;    // 0 exact fp32, 1 bf16 MFMA operands, 2 hi + lo bf16 pairs
 struct OperandMode {
-  bool prev;
+  int prev;
   explicit OperandMode(const pca_mab_shape& s) : prev(t_bf16_operands) {
-    t_bf16_operands = s.mode != PCA_MODE_F32;
+    t_bf16_operands = s.mode != PCA_MODE_F32 ? 1 : 0;
   }
   ~OperandMode() { t_bf16_operands = prev; }
 };
 inline int gemm_sel(const pca_gemm_desc& g, const float* A, const float* B, const float* bias,
                     float* C, hipStream_t st) {
+  if (t_bf16_operands == 2) return gemm_bf16_hl(g, A, B, bias, C, st);
   return t_bf16_operands ? gemm_bf16(g, A, B, bias, C, st) : gemm_f32(g, A, B, bias, C, st);
 }
 
@@ -107,7 +108,7 @@ inline int linear(const float* X, const float* W, const float* b, float* Y, int6
 // 263 us at [524288, 256] x [256, 256]: the row-vector staging of B is the slower one)
 inline int linear_dx(const float* dY, const float* W, float* dX, int64_t M, int din,
                      int dout, int accumulate, hipStream_t st, float* Wt = nullptr) {
-  if (Wt != nullptr && t_bf16_operands && M * din >= (int64_t)1 << 24 && din % 4 == 0 &&
+  if (Wt != nullptr && t_bf16_operands == 1 && M * din >= (int64_t)1 << 24 && din % 4 == 0 &&
       dout % 4 == 0) {
     PCA_TRY(transpose_f32(W, Wt, dout, din, st));                 // Wt[n][k] = W[k][n]
     pca_gemm_desc g = gd(M, din, dout, dout, 1, 1, dout, din, accumulate);
@@ -283,7 +284,7 @@ int mab_f32_bwd(const pca_mab_shape& s, const float* Q, const float* K,
 
 // Scope guard for callers outside this file (the d = 256 blocks): the linear_* helpers below run
 // their GEMMs with bf16 MFMA operands while one is alive on the calling thread.
-Bf16OperandScope::Bf16OperandScope(bool on) : prev(t_bf16_operands) { t_bf16_operands = on; }
+Bf16OperandScope::Bf16OperandScope(int mode) : prev(t_bf16_operands) { t_bf16_operands = mode; }
 Bf16OperandScope::~Bf16OperandScope() { t_bf16_operands = prev; }
 
 // ---- classifier head ----------------------------------------------------------

@@ -80,6 +80,9 @@ int gemm_f32(const pca_gemm_desc& g, const float* A, const float* B, const float
 // same contract, operands rounded to bf16 on the way into the MFMA (gemm_bf16.hip)
 int gemm_bf16(const pca_gemm_desc& g, const float* A, const float* B, const float* bias,
               float* C, hipStream_t st);
+// same contract, operands as hi + lo bf16 pairs (three MFMAs per K step): fp32-level results
+int gemm_bf16_hl(const pca_gemm_desc& g, const float* A, const float* B, const float* bias,
+                 float* C, hipStream_t st);
 int softmax_rows(float* X, int64_t rows, int n, float scale, hipStream_t st,
                  const int32_t* lengths = nullptr, int64_t rows_per_set = 0);
 int layernorm_fwd(const float* X, const float* w, const float* b, float* Y, float* mean,

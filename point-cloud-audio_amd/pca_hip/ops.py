@@ -20,8 +20,9 @@ _MODE = "f32"           # "f32" | "bf16" | "fp8" | "auto"
 def set_mode(mode: str) -> None:
     """Arithmetic mode of MAB blocks: 'f32' = exact fp32 kernels (parity mode),
     'bf16' = bf16 MFMA operands with fp32 accumulate/softmax (fails for shapes the fused
-    kernels do not cover), 'fp8' = as bf16 with fp8 (e4m3) operands in the d x d projections of
-    the forward, 'auto' = bf16 where covered, else f32."""
+    kernels do not cover), 'fp8' = as bf16 with fp8 (e4m3) operands in fc_o of the many-queries
+    blocks and fc_k / fc_v of the d = 256 few-queries block (fc_q stays bf16 unless PCA_FP8_PROJ=qo:
+    include/pca_hip.h), 'auto' = bf16 where covered, else f32."""
     global _MODE
     if mode not in ("f32", "bf16", "fp8", "auto"):
         raise ValueError(mode)
@@ -54,8 +55,34 @@ def _f32c(t: torch.Tensor) -> torch.Tensor:
     return t.contiguous()
 
 
+# tests: with CANARY set, every scratch / saved block handed to the library is followed by a
+# guard region that check_canaries() verifies (a kernel writing past its workspace)
+CANARY = False
+_GUARD = 1 << 16
+_guards: list = []
+
+
 def _bytes(n: int, like: torch.Tensor) -> torch.Tensor:
-    return torch.empty(max(int(n), 256), dtype=torch.uint8, device=like.device)
+    n = max(int(n), 256)
+    if not CANARY:
+        return torch.empty(n, dtype=torch.uint8, device=like.device)
+    n = (n + 255) // 256 * 256
+    full = torch.empty(n + _GUARD, dtype=torch.uint8, device=like.device)
+    full[n:] = 0xA5
+    _guards.append(full[n:])
+    return full[:n]
+
+
+def check_canaries() -> int:
+    """Number of guard regions checked; raises if a library call wrote past a block it was given."""
+    torch.cuda.synchronize()
+    k = len(_guards)
+    for g in _guards:
+        if not bool((g == 0xA5).all()):
+            _guards.clear()
+            raise _lib.PcaHipError("a kernel wrote past the end of its workspace")
+    _guards.clear()
+    return k
 
 
 def _shape(B, nq, nk, dq, dk, d, h, q_shared, mode=_lib.MODE_F32, k_lengths=None,

@@ -121,8 +121,10 @@ def test_train_from_scratch_accuracy(mode, dev):
       * the converged accuracy = mean of the three best of the ten evaluations (2200 test sets
         each), averaged over RUNS >= 20 repetitions, against the mean of the reference's runs:
         SURVEY.md 8d's +-0.2 %, plus two standard errors of the difference of the two means
-        (about 0.15 % at 20 runs).  Measured over 24 runs each: fp32 0.9912 (sigma 0.0033),
-        bf16 0.9921 (sigma 0.0048) - bf16 is not below fp32."""
+        (about 0.15 % at 20 runs).  Every run but the first starts from the initial weights
+        perturbed by 1e-6 (relative), exactly as the reference's spread runs do, so that the
+        bit-reproducible bf16 step samples a distribution too (the measured means and sigmas
+        are printed by the test and recorded in DESIGN.md section 2)."""
     import dataset
     import models
     from pca_hip import _lib, trainer
@@ -142,8 +144,17 @@ def test_train_from_scratch_accuracy(mode, dev):
     for run in range(RUNS):
         net = models.ST(dim_input=2, num_outputs=1, dim_output=a["C"], num_inds=a["m"],
                         dim_hidden=a["d"], num_heads=a["h"]).to(dev)
-        net.load_state_dict({k[len("init/"):]: T(g[k]) for k in g.files
-                             if k.startswith("init/")})
+        # the reference's own spread (make_accuracy_spread.py) comes from initial weights
+        # multiplied by (1 + 1e-6 n), n ~ N(0, 1) seeded per run; the bf16 step is bit-reproducible
+        # (no atomics since round 2), so without the same perturbation its RUNS runs would be ONE
+        # draw repeated.  Run 0 keeps the unperturbed weights (the early-loss comparison below).
+        gen = torch.Generator().manual_seed(7000 + run)
+        sd = {}
+        for k in g.files:
+            if k.startswith("init/"):
+                w = torch.from_numpy(g[k])
+                sd[k[len("init/"):]] = w if run == 0 else w * (1.0 + 1e-6 * torch.randn(w.shape, generator=gen))
+        net.load_state_dict(sd)
         tr = trainer.Trainer(net, ds, a["B"], lr=a["lr"], weight_decay=a["wd"], mode=m,
                              seed=a["seed"], shuffle=True)
         losses, accs = np.zeros(steps), []
@@ -159,8 +170,9 @@ def test_train_from_scratch_accuracy(mode, dev):
         # step 22, 2e-3 at step 24): compare before the trajectories separate
         early = 20
         tol = 1e-3 if mode == "f32" else 3e-2
-        assert np.abs(losses[:early] - ref_losses[:early]).max() < tol, \
-            (losses[:early], ref_losses[:early])
+        if run == 0:     # (the perturbed runs separate from the reference's trajectory sooner)
+            assert np.abs(losses[:early] - ref_losses[:early]).max() < tol, \
+                (losses[:early], ref_losses[:early])
         print(f"{mode} run {run}: evaluations {np.round(accs, 4)} -> converged {top3(accs):.4f}; "
               f"largest loss spike {losses[50:].max():.1f}")
         conv.append(top3(accs))

@@ -8,6 +8,7 @@ import numpy as np
 import pytest
 import torch
 
+from emu import mab0_forward_bf16emu
 from util import T, close, close_robust
 
 pytestmark = pytest.mark.gpu
@@ -22,6 +23,21 @@ def dev():
     pca_hip.lib()
     yield torch.device("cuda", 0)
     pca_hip.set_mode("f32")
+
+
+@pytest.fixture(autouse=True)
+def _guard_workspaces():
+    """Every scratch / saved block the autograd glue hands to the library in this file is followed
+    by a guard region, verified after the test (pca_hip.ops.check_canaries)."""
+    from pca_hip import ops
+    ops.CANARY = True
+    ops._guards.clear()
+    try:
+        yield
+        ops.check_canaries()
+    finally:
+        ops.CANARY = False
+        ops._guards.clear()
 
 
 def _mab_params(dq, dk, d, seed):
@@ -50,6 +66,9 @@ MAB1_D256_CASES = [
     (3, 128, 32, 256, 256, 8),
     (2, 77, 32, 3, 256, 8),           # layer 1
     (1, 1, 32, 256, 256, 8),          # a single point
+    # 65 536 rows with N < 512: wgrad256_nwg() gives the long jobs 64 workgroups and the short
+    # [B m]-row jobs of the same workspace 128 (the slabs ran past the workspace)
+    (256, 256, 32, 256, 256, 8),
 ]
 
 
@@ -139,6 +158,37 @@ def test_mab1_bwd_bf16(dev, case):
     print(f"mab1 bwd {case}: " + " ".join(f"{k}={v:.1e}" for k, v in errs.items()))
 
 
+@pytest.mark.parametrize("d,h,m", [(128, 4, 16), (256, 8, 32)])
+def test_mab1_fwd_bf16_propagates_nan(dev, d, h, m):
+    """A NaN / Inf in X or H must come out as a non-finite Y (never as finite garbage): the d = 256
+    forward is compiled with -fno-honor-nans, the contract is checked here."""
+    import modules
+    import pca_hip
+    B, N = 2, 130
+    p = _mab_params(d, d, d, seed=5)
+    g = torch.Generator().manual_seed(6)
+    X = torch.randn(B, N, d, generator=g)
+    H = torch.randn(B, m, d, generator=g)
+    mab = modules.MAB(d, d, d, h).to(dev)
+    mab.load_state_dict(p)
+    pca_hip.set_mode("bf16")
+    try:
+        with torch.no_grad():
+            for bad in (float("nan"), float("inf")):
+                Xn = X.clone()
+                Xn[1, 77, 5] = bad
+                Y = mab(Xn.to(dev), H.to(dev)).cpu()
+                assert not torch.isfinite(Y[1, 77]).all(), "non-finite point came out finite"
+                assert torch.isfinite(Y[0]).all() and torch.isfinite(Y[1, :77]).all()
+                Hn = H.clone()
+                Hn[0, 3, 9] = bad
+                Y = mab(X.to(dev), Hn.to(dev)).cpu()
+                assert not torch.isfinite(Y[0]).any(dim=-1).all(), "non-finite key came out finite"
+                assert torch.isfinite(Y[1]).all()
+    finally:
+        pca_hip.set_mode("f32")
+
+
 def test_engine_bf16_vs_golden(dev, golden_st):
     """Whole ST (BASELINE cfg1/2 architecture) with mode = BF16: fused kernels where built,
     exact fp32 elsewhere; logits and all gradients vs the reference's golden vectors."""
@@ -203,74 +253,10 @@ def test_mab0_fwd_bf16(dev, case):
     with torch.no_grad():
         Y = mab(I.to(dev), X.to(dev), q_shared=True)
     pca_hip.set_mode("f32")
-    # (layer 1, dk <= 4: scores, softmax and fc_v are exact fp32 arithmetic on the points; at
-    #  d = 256 the block's fc_o runs on the MFMA with bf16 operands like every other block's)
-    err = close(Y, ref, FWD_TOL if dk > 4 or d == 256 else 2e-4, f"mab0 fwd {case}")
+    # (layer 1, dk <= 4: scores, softmax and fc_v are exact fp32 arithmetic on the points; fc_o
+    #  at d = 256 runs on the MFMA with hi + lo bf16 operand pairs: fp32-level)
+    err = close(Y, ref, FWD_TOL if dk > 4 else 2e-4, f"mab0 fwd {case}")
     print(f"mab0 fwd {case}: max err {err:.3e} (max|ref| {float(ref.abs().max()):.2f})")
-
-
-class _LinearBf16Operands(torch.autograd.Function):
-    """y = rb(x) rb(W)^T + b the way csrc/d256_host.hip runs fc_o of the few-queries block: both
-    GEMM operands rounded to bf16 in the forward AND in the backward (dx = rb(g) rb(W),
-    dW = rb(g)^T rb(x)), accumulation in fp32."""
-
-    @staticmethod
-    def forward(ctx, x, W, b):
-        r = lambda t: t.to(torch.bfloat16).to(torch.float32)
-        ctx.save_for_backward(x, W)
-        return r(x) @ r(W).t() + b
-
-    @staticmethod
-    def backward(ctx, g):
-        r = lambda t: t.to(torch.bfloat16).to(torch.float32)
-        x, W = ctx.saved_tensors
-        g2, x2 = g.reshape(-1, g.shape[-1]), x.reshape(-1, x.shape[-1])
-        return r(g) @ r(W), r(g2).t() @ r(x2), g2.sum(0)
-
-
-def mab0_forward_bf16emu(I, X, p, h, fp8=False):
-    """Reassociated mab0 with the MFMA operands (G' = sl2e Qp_h Wk_h, X, P) rounded to bf16 as
-    csrc/mab0_bf16.hip does; epilogue fp32 (d = 256: fc_o with bf16 operands).  Returns H.
-    d = 256 with dk = 256 (csrc/d256_*.hip): the keys ARE projected - Kp, Vp, the scaled query
-    and P are the bf16 operands."""
-    import math
-    from oracle.st_oracle import rb
-    B, N, dk = X.shape
-    m = I.shape[1]
-    d = p["fc_q.weight"].shape[0]
-    dh = d // h
-    sl2e = math.log2(math.e) / math.sqrt(d)
-    Qp = I[0] @ p["fc_q.weight"].t() + p["fc_q.bias"]                  # [m, d]
-    if d == 256 and dk == 256 and h * m > 16:
-        Xb = rb(X)
-        if fp8:            # PCA_MODE_FP8: fc_k / fc_v with e4m3 operands (oracle/st_oracle.py:_lin8)
-            from oracle.st_oracle import _lin8
-            Kp = rb(_lin8(Xb, p["fc_k.weight"], p["fc_k.bias"])).view(B, N, h, dh)
-            Vp = rb(_lin8(Xb, p["fc_v.weight"], p["fc_v.bias"])).view(B, N, h, dh)
-        else:
-            Kp = rb(Xb @ rb(p["fc_k.weight"]).t() + p["fc_k.bias"]).view(B, N, h, dh)
-            Vp = rb(Xb @ rb(p["fc_v.weight"]).t() + p["fc_v.bias"]).view(B, N, h, dh)
-        S2 = torch.einsum("qjf,bnjf->bjqn", rb(Qp * sl2e).view(m, h, dh), Kp)
-        P = torch.softmax(S2 * math.log(2.0), dim=-1)
-        O = Qp.view(1, m, h, dh) + torch.einsum("bjqn,bnjf->bqjf", rb(P), Vp)
-        O = O.reshape(B, m, d)
-        Z = _LinearBf16Operands.apply(O, p["fc_o.weight"], p["fc_o.bias"])   # d = 256: on the MFMA
-        return O + torch.relu(Z)
-    Wk = p["fc_k.weight"].view(h, dh, dk)
-    G = torch.einsum("qjf,jfc->jqc", Qp.view(m, h, dh), Wk) * sl2e      # [h, m, dk]
-    small = dk <= 4
-    Gs, Xs = (G, X) if small else (rb(G), rb(X))
-    S2 = torch.einsum("jqc,bnc->bjqn", Gs, Xs)                           # log2-domain scores
-    P = torch.softmax(S2 * math.log(2.0), dim=-1)
-    T = torch.einsum("bjqn,bnc->bjqc", P if small else rb(P), Xs)
-    Wv = p["fc_v.weight"].view(h, dh, dk)
-    O = Qp.view(1, m, h, dh) + torch.einsum("bjqc,jfc->bqjf", T, Wv) + p["fc_v.bias"].view(1, 1, h, dh)
-    O = O.reshape(B, m, d)
-    if d == 256:       # csrc/d256_host.hip: fc_o with bf16 MFMA operands (fp32 accumulation)
-        Z = _LinearBf16Operands.apply(O, p["fc_o.weight"], p["fc_o.bias"])
-    else:
-        Z = O @ p["fc_o.weight"].t() + p["fc_o.bias"]
-    return O + torch.relu(Z)
 
 
 @pytest.mark.parametrize("case", MAB0_CASES, ids=[str(c) for c in MAB0_CASES])
@@ -321,15 +307,8 @@ def test_mab0_bwd_bf16(dev, case):
             continue
         # (d = 256: the online softmax feeds un-normalised probabilities to the MFMA, the emulation
         #  normalised ones - a few more ReLU pre-activations of the 96 epilogue rows change sign)
-        # dQ at d = 256: every flipped pre-activation moves a whole 256-wide row of the [m, d] query
-        # gradient by ~|dH| |Wo| - held to the gradient tolerance of the module docstring instead
-        # fc_o at d = 256: a flipped pre-activation (b, q, f) moves row f of d/d(Wo) by dH.O - up to
-        # four such rows / bias elements of the 256 may differ from the emulation's
-        frac = 2e-4 if d == 128 else max(3e-3, 2.5 / v.numel())
-        if d == 256 and k.startswith("fc_o."):
-            frac = 4.0 / 256
-        errs[k] = close_robust(v, emu[k], BWD_TOL if (d == 256 and k == "dQ") else 1.5e-2, k,
-                               outlier_frac=frac)
+        errs[k] = close_robust(v, emu[k], 1.5e-2, k,
+                               outlier_frac=2e-4 if d == 128 else max(3e-3, 2.5 / v.numel()))
         sc = max(1.0, float(exact[k].abs().max()))
         rms = float((emu[k] - exact[k]).pow(2).mean().sqrt()) / sc
         assert rms < 3e-2, (k, rms)

@@ -32,6 +32,11 @@ def test_two_ranks_equal_one_rank_double_batch(tmp_path, mode, graph, overlap, b
     """overlap = 1: split step, bucket A reduced under enc.0's backward; 0: one all-reduce of
     the whole gradient vector between the backward graph and the Adam graph (the default for
     models of this size)."""
+    two_gpus = torch.cuda.device_count() >= 2
+    if backend == "nccl" and not two_gpus:
+        # RCCL refuses two ranks on one device ("Duplicate GPU detected", DESIGN.md section 5); on a
+        # box with >= 2 GPUs the case runs one rank per device, unmodified
+        pytest.skip("nccl needs one GPU per rank: this box has 1")
     out = str(tmp_path / "flat.pt")
     env = dict(os.environ, PCA_MODE=mode, PCA_GRAPH=graph, PCA_OUT=out, PCA_OVERLAP=overlap,
                HSA_ENABLE_IPC_MODE_LEGACY="0", PCA_DIST_BACKEND=backend)
@@ -41,12 +46,7 @@ def test_two_ranks_equal_one_rank_double_batch(tmp_path, mode, graph, overlap, b
                         os.path.join(ROOT, "scripts", "ddp_check.py")],
                        env=env, capture_output=True, text=True, timeout=600)
     assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-3000:]
-    if "BACKEND_REFUSED" in r.stdout:
-        assert backend == "nccl", r.stdout
-        line = [ln for ln in r.stdout.splitlines() if "BACKEND_REFUSED" in ln][0]
-        print(line)
-        pytest.skip(f"RCCL refused two ranks on this box ({torch.cuda.device_count()} GPU): "
-                    + line[:300])
+    assert "BACKEND_REFUSED" not in r.stdout, r.stdout
     if backend == "nccl":
         assert "NCCL_RANKS 2 probe 2.0" in r.stdout, r.stdout
     assert "RANKS_IDENTICAL True" in r.stdout, r.stdout

@@ -90,6 +90,15 @@ def test_cfg4_architecture_large_rows_vs_oracle(dev, mode):
     _check(dev, 3, 4096, 3, 256, 8, 32, 50, mode, seed=9300)
 
 
+def test_cfg4_bench_size_bf16_vs_oracle(dev):
+    """BASELINE configs[3] at its BENCH size (B = 128 sets per GPU, N = 4096 points, d = 256, 8
+    heads, m = 32, C = 50) in the fast mode: 524 288 rows - the 256-workgroup slab path of
+    k_wgrad256 with 2048 rows per workgroup, the deferred job hand-offs between the blocks and the
+    long-job k_wgrad256_sum, none of which the B = 3 case above reaches.  The CPU oracle needs
+    ~15 GB and ~1 min for this size."""
+    _check(dev, 128, 4096, 3, 256, 8, 32, 50, "bf16", seed=9400)
+
+
 def test_d256_step_is_bit_reproducible(dev):
     """The d = 256 / 8 heads / m = 32 training step uses no fp32 atomics (weight-gradient slabs,
     per-workgroup partials + fixed-order sums everywhere): two forward + backward passes over the

@@ -88,6 +88,69 @@ def test_mask_equals_truncation_engine(dev, case, mode):
         assert np.abs(dense - ref_lg).max() > 1e-3
 
 
+def _emu_truncated(net, X, y, lengths, h, fp8):
+    """logits, mean CE loss and gradients of the operand-rounding emulation (tests/emu.py) on the
+    un-padded sets X[b, :lengths[b]]."""
+    from emu import st_forward_emu
+    from oracle import st_oracle as orc
+    params = {k: v.detach().cpu().clone().requires_grad_(True) for k, v in net.state_dict().items()}
+    lg = torch.cat([st_forward_emu(torch.from_numpy(X[b:b + 1, :lengths[b]]), params, h, fp8=fp8)
+                    for b in range(X.shape[0])], 0)
+    loss = orc.cross_entropy(lg, torch.from_numpy(y))
+    loss.backward()
+    grads = {k: (v.grad if v.grad is not None else torch.zeros_like(v)).numpy()
+             for k, v in params.items()}
+    return lg.detach().numpy(), float(loss), grads
+
+
+@pytest.mark.parametrize("mode", ["bf16", "fp8"])
+def test_cfg5_train_step_vs_emulation(dev, mode):
+    """BASELINE configs[4] (the configs[3] architecture on padded variable-size sets) as a TRAINING
+    step in PCA_MODE_FP8 (and PCA_MODE_BF16 beside it): logits, loss and all 45 gradients of
+    STEngine(..., training=True) with lengths against (i) the emulation of the mode's forward
+    (e4m3 operands in fc_o of the many-queries blocks and fc_k / fc_v of the d -> d few-queries
+    block, bf16 elsewhere) differentiated with the mode's straight-through bf16 backward, and
+    (ii) the exact fp32 oracle on the truncated sets at the bf16 tolerances of
+    test_mask_equals_truncation_engine.  The fp8 forward must also differ from the bf16 one."""
+    import models
+    from pca_hip import _lib, trainer
+    name, din, d, h, m, C, N, lengths = CASES[-1]
+    assert name == "cfg5"
+    B = len(lengths)
+    torch.manual_seed(5)
+    net = models.ST(dim_input=din, num_outputs=1, dim_output=C, num_inds=m, dim_hidden=d,
+                    num_heads=h).to(dev)
+    X = gi.pc_input(4100, B, N, din)
+    for b, L in enumerate(lengths):
+        X[b, L:] = 0.0
+    y = gi.labels(4200, B, C)
+    fp8 = mode == "fp8"
+    emu_lg, emu_loss, emu_g = _emu_truncated(net, X, y, lengths, h, fp8)
+    ref_lg, ref_loss, ref_g = _oracle_truncated(net, X, y, lengths, h)
+    md = _lib.MODE_FP8 if fp8 else _lib.MODE_BF16
+    ld = torch.tensor(lengths, dtype=torch.int32, device=dev)
+    eng = trainer.STEngine(net, B, N, md, training=True)
+    eng.fwd_bwd(T(X, dev), T(y, dev), lengths=ld)
+    torch.cuda.synchronize()
+    e1 = close(eng.logits, emu_lg, 1.5e-2, "logits vs emulation")
+    close(eng.logits, ref_lg, 3e-2 if not fp8 else 6e-2, "logits vs exact oracle")
+    assert abs(float(eng.loss) - emu_loss) < 1.5e-2, (float(eng.loss), emu_loss)
+    assert abs(float(eng.loss) - ref_loss) < (3e-2 if not fp8 else 6e-2)
+    off, worst = 0, 0.0
+    for k, p in net.named_parameters():
+        g = eng.grads[off:off + p.numel()].view_as(p)
+        off += p.numel()
+        worst = max(worst, close_robust(g, emu_g[k], 3e-2, k + " vs emulation", outlier_frac=3e-3))
+        close_robust(g, ref_g[k], 5e-2 if not fp8 else 1e-1, k + " vs exact oracle",
+                     outlier_frac=2e-3 if not fp8 else 1e-2)
+    assert off == eng.grads.numel()
+    print(f"cfg5 {mode} train step: logits vs emulation {e1:.2e}, worst grad vs emulation {worst:.2e}")
+    if fp8:       # not the bf16 kernels under another name
+        engb = trainer.STEngine(net, B, N, _lib.MODE_BF16, training=True)
+        engb.fwd_bwd(T(X, dev), T(y, dev), lengths=ld)
+        assert float((engb.logits - eng.logits).abs().max()) > 1e-4
+
+
 def test_mask_equals_truncation_modules(dev):
     """nn.Module path (autograd through pca_mab_fwd/bwd with k_lengths): ST(X, lengths) against
     per-set dense calls of the same module, logits and gradients."""
