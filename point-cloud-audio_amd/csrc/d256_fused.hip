@@ -46,6 +46,7 @@ struct FusedFwdArgs {
   uint32_t* mask;         // ReLU mask bits in the layout of mab1_mask_index<256> (nullable)
   int B, N, dq, tiles_per_set, units_per_wg;
   float scale_log2e;
+  int ablate;             // measurement builds (-DPCA_FWD_ABLATE): PCA_AB_ABLATE bit mask, see the kernel
 };
 
 // 16-byte chunk c16 of row `row` of a [64][256] bf16 tile (swizzled like the weight images)
@@ -425,6 +426,465 @@ __global__ __launch_bounds__(512, 2) void k_isab1_fwd256(const FusedFwdArgs a) {
   }
 }
 
+
+// =====================================================================================
+// Round 3: the same block as a PRODUCER / CONSUMER pair of wave groups in one 1024-thread
+// workgroup (16 waves = 4 per SIMD, <= 128 registers each).  In k_isab1_fwd256 above every wave
+// walks GEMM1 -> softmax -> GEMM2 -> epilogue between the same two barriers, so the two waves of a
+// SIMD want the matrix pipe at the same time and leave it idle at the same time (MFMA utilisation
+// 0.33, waves waiting 69 % of their cycles: profiles/r02_fwd256_fused_sq.txt).  Here
+//     waves 0-7  (role A, wave = head j): X tile --GEMM1 (Wq_j in 64 registers)--> Qp_j
+//                --scores, softmax, A V--> O_j  --own slice of the O tile of unit k
+//     waves 8-15 (role B, wave = head j): O tile of unit k-1 --GEMM2 (Wo_j in 64 registers)-->
+//                Z_j ; Y_j = O_j + relu(Z_j)  --own slice of the Y tile; coalesced stores of the
+//                Y tile of unit k-2 (training: O, Qp tiles of unit k-1, mask words)
+// with ONE workgroup barrier per unit.  Each SIMD hosts two A and two B waves, whose VALU-heavy
+// (softmax, epilogue) and MFMA-heavy (the two GEMMs) stretches belong to different units and
+// overlap by construction; a wave holds one weight slice instead of two, which is what brings it
+// under 128 registers.  Tiles, swizzle, LDS-DMA and layouts are those of the kernel above.
+#ifdef PCA_FWD_STAMPS
+// measurement build: s_memtime stamps (low 32 bits) of workgroup 0 into LDS ([wave 16][iteration 32]
+// [stamp 8], copied to g_fwd_stamps at the end) - no global store inside the loop
+#define AB_STAMP(i)                                                                               \
+  do {                                                                                            \
+    __builtin_amdgcn_sched_barrier(0);                                                            \
+    if (blockIdx.x == 0 && k < 32) {                                                              \
+      const long long t_ = (long long)__builtin_readcyclecounter();                               \
+      if (lane == 0) sStamp[(wv * 32 + k) * 8 + (i)] = (unsigned)t_;                                     \
+    }                                                                                             \
+    __builtin_amdgcn_sched_barrier(0);                                                            \
+  } while (0)
+#else
+#define AB_STAMP(i)
+#endif
+
+template <bool SMALL, bool F8O, bool TRAIN>
+__global__ __launch_bounds__(1024) void k_isab1_fwd256_ab(const FusedFwdArgs a) {
+  constexpr int KS = D / 32, PF = TRAIN ? 2 : 3;     // (TRAIN: one fragment less ahead - 128 registers)
+  // ablation switches of the measurement build (results are garbage with any of them set):
+  // 1 no softmax arithmetic, 2 no epilogue arithmetic, 4 no barrier, 8 no LDS-DMA, 16 no Y stores,
+  // 32 no GEMM1, 64 no GEMM2
+#ifdef PCA_FWD_ABLATE
+  const int abl = a.ablate;
+#else
+  constexpr int abl = 0;
+#endif
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  // X tiles arrive XR - 1 units ahead (role A only).  One unit ahead is not enough: every CU asks
+  // for its tile at the same moment, the burst comes back after more than an iteration, and the
+  // wait for it sat on role A's path (no LDS-DMA: - 8 us of 93; no Y stores, i.e. a quieter
+  // memory system: - 15; scripts/experiments/ab_ablate.sh).  TRAIN has LDS for two tiles only.
+  constexpr int XR = TRAIN ? 2 : 3, AH = XR - 1;
+  char* sXb = smem;                         // X tiles [XR][TILEB]
+  char* sOb = smem + XR * TILEB;            // O tiles (A writes slices, B reads)
+  char* sYb = sOb + 2 * TILEB;              // Y tiles (B only)
+  char* sKb = sYb + 2 * TILEB;              // K slices of the current set, wave-private [8][2][64][16 B]
+  // V slices likewise when there is room (inference): 8 more registers for role A's read-ahead
+  constexpr bool VL = !TRAIN;
+  char* sVb = sKb + TILEB;
+  char* sQb = sKb + TILEB;                  // TRAIN: Qp tiles (A writes slices, B stores them)
+  uint32_t* sMaskb = reinterpret_cast<uint32_t*>(sKb + (TRAIN ? 3 : 2) * TILEB);
+  // bq [256], bo [256], and both again: point block nb reads copy nb, so that hipcc does not keep
+  // one read alive (8 registers) across the attention of block 0
+  float* sBias = reinterpret_cast<float*>(sMaskb + 2 * NBK * 2 * 64);
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int wv = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int role = wv >> 3, j = wv & 7;     // (waves w, w + 4, w + 8, w + 12 share a SIMD)
+#ifdef PCA_FWD_STAMPS
+  unsigned* sStamp = reinterpret_cast<unsigned*>(sBias + 4 * D);
+  for (int i = tid; i < 16 * 32 * 8; i += 1024) sStamp[i] = 0;
+#endif
+  const int r = lane & 15, g = lane >> 4;
+
+  // ---- this wave's ONE weight slice: A operands [row = feature 32 j + 16 t + r][k = 32 s + 8 g ..]
+  bf16x8 wa[KS][2];
+  f8x8 w8[F8O ? KS : 1][2];
+  {
+    const bool want = role == 1 ? !F8O : !SMALL;
+    const __bf16* Wsrc = role == 1 ? a.Wo : a.Wq;
+#pragma unroll
+    for (int s = 0; s < KS; ++s)
+#pragma unroll
+      for (int t = 0; t < 2; ++t) {
+        const int o = (32 * j + 16 * t + r) * D + 32 * s + 8 * g;
+        if (want) wa[s][t] = *reinterpret_cast<const bf16x8*>(Wsrc + o);
+        if (F8O && role == 1)
+          w8[F8O ? s : 0][t] =
+              *reinterpret_cast<const f8x8*>(reinterpret_cast<const uint8_t*>(a.Wo) + o);
+      }
+  }
+  if (tid < 2 * D) {
+    const float v = tid < D ? a.bq[tid] : a.bo[tid - D];
+    sBias[tid] = v;
+    sBias[2 * D + tid] = v;
+  }
+  auto bias4 = [&](int which, int t, int copy) {
+    const float4 q4 = *reinterpret_cast<const float4*>(sBias + (2 * copy + which) * D + 32 * j +
+                                                       16 * t + 4 * g);
+    return f32x4{q4.x, q4.y, q4.z, q4.w};
+  };
+  auto unit_barrier = [&] {                 // LDS traffic only (no vmcnt: see the kernel above)
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+    if (!(abl & 4)) __builtin_amdgcn_s_barrier();
+    asm volatile("" ::: "memory");
+  };
+
+  const int total_units = a.B * a.tiles_per_set;
+  const int u0 = blockIdx.x * a.units_per_wg;
+  const int u1 = (u0 + a.units_per_wg < total_units) ? u0 + a.units_per_wg : total_units;
+  const int n = u1 - u0;
+  int oB[4], oD[2];
+#pragma unroll
+  for (int k = 0; k < 4; ++k) oB[k] = toff(r, 4 * k + g);
+#pragma unroll
+  for (int t = 0; t < 2; ++t) oD[t] = toff(r, 4 * j + 2 * t + (g >> 1)) + 8 * (g & 1);
+  int cb = u0 / a.tiles_per_set, ct = u0 - cb * a.tiles_per_set;
+
+#ifdef PCA_FWD_ABLATE
+  {   // static wave priority per role: bits 8-9 role A, bits 10-11 role B
+    const int pr = role == 0 ? (abl >> 8) & 3 : (abl >> 10) & 3;
+    if (pr == 1) __builtin_amdgcn_s_setprio(1);
+    else if (pr == 2) __builtin_amdgcn_s_setprio(2);
+    else if (pr == 3) __builtin_amdgcn_s_setprio(3);
+  }
+#endif
+  if (role == 0) {
+    // ================================ role A ================================
+    // LDS-DMA of a unit's X tile: scalar tile base + a 32-bit lane offset (piece p of the tile,
+    // row p / 32, slot p % 32, holds chunk slot ^ (row & 15) of its row)
+    auto dma_x = [&](int b, int tile, char* dst) {
+      const int n0 = tile * P, last = a.N - 1 - n0;
+      const char* base = reinterpret_cast<const char*>(a.X) + ((int64_t)b * a.N + n0) * ROWB;
+#pragma unroll
+      for (int i = 0; i < DMA_PER_WAVE; ++i) {
+        const int p = (DMA_PER_WAVE * j + i) * 64 + lane;
+        const int row = p >> 5, slot = p & 31;
+        const int ch = (slot & ~15) | ((slot ^ row) & 15);
+        const unsigned off = (unsigned)((row < last ? row : last) * ROWB + ch * 16);   // padding rows: a valid line
+        const unsigned ldst = __builtin_amdgcn_readfirstlane(
+            (unsigned)(uintptr_t)(lptr_t*)(dst + (DMA_PER_WAVE * j + i) * 1024));
+        unsigned keep;
+        asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %3\n\ts_nop 0\n\t"
+                     "global_load_lds_dwordx4 %1, %2\n\ts_mov_b32 m0, %0"
+                     : "=&s"(keep) : "v"(off), "s"(base), "s"(ldst) : "memory");
+      }
+    };
+    auto load_points = [&](int b, int tile, float (&xv)[NBK][4]) {    // layer 1: points to registers
+      const int nlive = a.N - tile * P;
+      const float* base = reinterpret_cast<const float*>(a.X) + ((int64_t)b * a.N + tile * P) * a.dq;
+#pragma unroll
+      for (int nb = 0; nb < NBK; ++nb) {
+        const int nn = 16 * nb + r < nlive ? 16 * nb + r : nlive - 1;
+#pragma unroll
+        for (int c = 0; c < 4; ++c) xv[nb][c] = base[nn * a.dq + (c < a.dq ? c : 0)];
+      }
+    };
+    float wqs[SMALL ? 2 : 1][4][4];         // layer 1: fc_q rows of this lane's features
+    if (SMALL) {
+#pragma unroll
+      for (int t = 0; t < 2; ++t)
+#pragma unroll
+        for (int e = 0; e < 4; ++e)
+#pragma unroll
+          for (int c = 0; c < 4; ++c)
+            wqs[SMALL ? t : 0][e][c] = c < a.dq ? a.WqF[(32 * j + 16 * t + 4 * g + e) * a.dq + c] : 0.f;
+    }
+    float xv[NBK][4], xn[NBK][4];
+    int fb = cb, ft = ct;                    // the next unit to fetch (AH units ahead of the current)
+    auto fetch_advance = [&] { if (++ft == a.tiles_per_set) { ft = 0; ++fb; } };
+    if (!SMALL) {
+#pragma unroll
+      for (int q = 0; q < AH; ++q)
+        if (q < n) { dma_x(fb, ft, sXb + q * TILEB); fetch_advance(); }
+    } else {
+      load_points(cb, ct, xv);
+      fetch_advance();
+    }
+    // weights, X tile 0 (hidden from hipcc: waited for explicitly) - as a BUILTIN wait, so that the
+    // compiler's own counter bookkeeping knows no load is pending at the loop entry: left to
+    // itself it re-waits for the 16 weight loads inside the loop (vmcnt(15) ... vmcnt(0) between
+    // the MFMAs of GEMM1), and in steady state those waits hit the LDS-DMA just issued
+    __builtin_amdgcn_s_waitcnt(0x0F70);      // vmcnt(0)
+    __syncthreads();                         // biases visible; X tile 0 landed in every wave
+    int cur_b = -1;
+    bf16x8 vta[2];
+    char* sK = sKb + j * 2048 + lane * 16;   // this lane's 16 bytes of kpa[kt] at + 1024 kt
+    char* sV = sVb + j * 2048 + lane * 16;
+    int xs = 0;                              // slot of the current unit in the X ring
+    for (int k = 0; k <= n + 1; ++k) {
+      AB_STAMP(0);
+      if (k < n) {
+        const int par = k & 1;
+        int nb_ = cb, nt_ = ct + 1;
+        if (nt_ == a.tiles_per_set) { nt_ = 0; ++nb_; }
+        const int b = cb;
+        char* sXc = sXb + xs * TILEB;
+        char* sO = sOb + par * TILEB;
+        char* sQ = sQb + par * TILEB;
+        if (b != cur_b) {                    // this set's K / V slices of head j (once per set)
+#pragma unroll
+          for (int kt = 0; kt < 2; ++kt) {
+            *reinterpret_cast<bf16x8*>(sK + 1024 * kt) = *reinterpret_cast<const bf16x8*>(
+                a.KpP + ((int64_t)b * MI + 16 * kt + r) * D + 32 * j + 8 * g);
+            const bf16x8 vt = *reinterpret_cast<const bf16x8*>(
+                a.Vt + ((int64_t)b * D + 32 * j + 16 * kt + r) * MI + 8 * g);
+            if (VL) *reinterpret_cast<bf16x8*>(sV + 1024 * kt) = vt;
+            else vta[kt] = vt;
+          }
+          cur_b = b;
+          __builtin_amdgcn_s_waitcnt(0x0F70);   // vmcnt(0): before any LDS-DMA of this iteration
+        }
+        const bool more = k + (SMALL ? 1 : AH) < n;
+        if (more) {                          // the input of unit k + AH starts to arrive
+          if (!SMALL) {
+            const int fs = xs + AH >= XR ? xs + AH - XR : xs + AH;
+            if (!(abl & 8)) dma_x(fb, ft, sXb + fs * TILEB);
+          } else {
+            load_points(fb, ft, xn);
+          }
+          fetch_advance();
+        }
+        AB_STAMP(1);
+#pragma unroll
+        for (int nb = 0; nb < NBK; ++nb) {
+          f32x4 acc0 = bias4(0, 0, nb), acc1 = bias4(0, 1, nb);
+          bf16x8 kp0, kp1;
+          if (SMALL) {
+#pragma unroll
+            for (int e = 0; e < 4; ++e) {
+              acc0[e] += wqs[0][e][0] * xv[nb][0] + wqs[0][e][1] * xv[nb][1] +
+                         wqs[0][e][2] * xv[nb][2] + wqs[0][e][3] * xv[nb][3];
+              acc1[e] += wqs[SMALL ? 1 : 0][e][0] * xv[nb][0] + wqs[SMALL ? 1 : 0][e][1] * xv[nb][1] +
+                         wqs[SMALL ? 1 : 0][e][2] * xv[nb][2] + wqs[SMALL ? 1 : 0][e][3] * xv[nb][3];
+            }
+          } else {
+            // B-operand fragments PF k-steps ahead of the MFMAs that consume them: a k-step is
+            // 32 cycles of MFMA issue, an LDS read returns after ~100-130
+            bf16x8 bx[PF + 1];
+#pragma unroll
+            for (int s = 0; s < PF; ++s)
+              bx[s] = *reinterpret_cast<const bf16x8*>(sXc + oB[s & 3] + 256 * (s >> 2) + 8192 * nb);
+#pragma unroll
+            for (int s = 0; s < ((abl & 32) ? 1 : KS); ++s) {
+              if (s + PF < KS)
+                bx[(s + PF) % (PF + 1)] = *reinterpret_cast<const bf16x8*>(
+                    sXc + oB[(s + PF) & 3] + 256 * ((s + PF) >> 2) + 8192 * nb);
+              if (s == KS - PF) {          // this head's K slices: requested under the last MFMAs
+                kp0 = *reinterpret_cast<const bf16x8*>(sK);
+                kp1 = *reinterpret_cast<const bf16x8*>(sK + 1024);
+              }
+              acc0 = mfma32(wa[s][0], bx[s % (PF + 1)], acc0);
+              acc1 = mfma32(wa[s][1], bx[s % (PF + 1)], acc1);
+            }
+          }
+          if (SMALL || (abl & 32)) {
+            kp0 = *reinterpret_cast<const bf16x8*>(sK);
+            kp1 = *reinterpret_cast<const bf16x8*>(sK + 1024);
+          }
+          AB_STAMP(2 + 2 * nb);
+          if (TRAIN) {
+            *reinterpret_cast<bf16x4*>(sQ + oD[0] + 8192 * nb) = pack4(acc0);
+            *reinterpret_cast<bf16x4*>(sQ + oD[1] + 8192 * nb) = pack4(acc1);
+          }
+          // ---- attention over the 32 inducing keys, inside the wave ----
+          const bf16x8 qb = pack8(acc0, acc1);
+          const f32x4 z4 = {0.f, 0.f, 0.f, 0.f};
+          f32x4 s0 = mfma32(kp0, qb, z4);
+          f32x4 s1 = mfma32(kp1, qb, z4);
+          if (!(abl & 1)) {
+            float mx = fmaxf(fmaxf(fmaxf(s0[0], s0[1]), fmaxf(s0[2], s0[3])),
+                             fmaxf(fmaxf(s1[0], s1[1]), fmaxf(s1[2], s1[3])));
+            mx = wave16_max(mx);
+            const float mc = -mx * a.scale_log2e;
+#pragma unroll
+            for (int e = 0; e < 4; ++e) {
+              s0[e] = __builtin_amdgcn_exp2f(__builtin_fmaf(s0[e], a.scale_log2e, mc));
+              s1[e] = __builtin_amdgcn_exp2f(__builtin_fmaf(s1[e], a.scale_log2e, mc));
+            }
+          }
+          // Un-normalised probabilities go to the MFMA; their sum over the 32 keys comes from the
+          // matrix pipe as well - an A operand of ones gives every accumulator row the column sum,
+          // i.e. every lane the denominator of ITS point (one MFMA instead of 7 dependent adds and
+          // two cross-lane butterfly steps; the sum is that of the bf16 values actually multiplied)
+          const bf16x8 pb = pack8(s0, s1);
+          bf16x8 ones;
+#pragma unroll
+          for (int e = 0; e < 8; ++e) ones[e] = (__bf16)1.0f;
+          const f32x4 sm = mfma32(ones, pb, z4);
+          const f32x4 o0 = mfma32(VL ? *reinterpret_cast<const bf16x8*>(sV) : vta[0], pb, z4);
+          const f32x4 o1 = mfma32(VL ? *reinterpret_cast<const bf16x8*>(sV + 1024) : vta[1], pb, z4);
+          const float inv = (abl & 1) ? sm[0] : __builtin_amdgcn_rcpf(sm[0]);
+#pragma unroll
+          for (int e = 0; e < 4; ++e) {
+            acc0[e] = __builtin_fmaf(o0[e], inv, acc0[e]);
+            acc1[e] = __builtin_fmaf(o1[e], inv, acc1[e]);
+          }
+          *reinterpret_cast<bf16x4*>(sO + oD[0] + 8192 * nb) = pack4(acc0);
+          *reinterpret_cast<bf16x4*>(sO + oD[1] + 8192 * nb) = pack4(acc1);
+          AB_STAMP(3 + 2 * nb);
+        }
+        if (SMALL) {
+#pragma unroll
+          for (int nb = 0; nb < NBK; ++nb)
+#pragma unroll
+            for (int c = 0; c < 4; ++c) xv[nb][c] = xn[nb][c];
+        }
+        cb = nb_; ct = nt_;
+        if (++xs == XR) xs = 0;
+        // the next unit's X tile (this wave's pieces) has landed before the barrier releases it;
+        // the pieces of the units after it, issued later, stay in flight (vmcnt retires in order)
+        if (!SMALL) {
+          if (AH == 2 && more) asm volatile("s_waitcnt vmcnt(2)" ::: "memory");
+          else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        }
+      }
+      AB_STAMP(6);
+      unit_barrier();
+    }
+  } else {
+    // ================================ role B ================================
+    const int tb = tid & 511;                 // thread index inside the role
+    const float inv_o = F8O ? a.inv_o[0] : 1.f;
+    const int oC = toff(tb >> 5, tb & 31);
+    const int tiles128 = (a.tiles_per_set * P + 127) / 128;
+    int b1 = cb, t1 = ct, b2 = cb, t2 = ct;   // units k - 1 (GEMM2) and k - 2 (deferred Y stores)
+    __builtin_amdgcn_s_waitcnt(0x0F70);       // vmcnt(0): the weight slice (see role A)
+    __syncthreads();                          // pairs with role A's
+    for (int k = 0; k <= n + 1; ++k) {
+      const int par = k & 1;
+      AB_STAMP(0);
+      // Order inside an iteration: GEMM2 of BOTH point blocks first, then the epilogues, then the
+      // memory passes.  Role A's iteration is [input issue, GEMM1(0), softmax(0), GEMM1(1),
+      // softmax(1)]; with role B as [stores, GEMM2(0), epilogue(0), GEMM2(1), epilogue(1)] the two
+      // roles asked for the matrix pipe in the same stretches and left it idle in the same
+      // stretches (ablation: the costs of GEMM1, GEMM2, the stores and the LDS-DMA issue ADDED up,
+      // scripts/experiments/ab_ablate.sh).  Now B's 32 MFMAs run while A issues its input and
+      // does softmax(0), and B's VALU / memory work runs under A's GEMM1(1).
+      AB_STAMP(1);
+      if (k >= 1 && k <= n) {                 // unit k - 1
+        const int pq = par ^ 1;
+        char* sO = sOb + pq * TILEB;
+        char* sY = sYb + pq * TILEB;
+        uint32_t* sMask = sMaskb + pq * NBK * 128;
+        const f32x4 z4 = {0.f, 0.f, 0.f, 0.f};
+        f32x4 acc[NBK][2];
+        bf16x4 o4[NBK][2];
+#pragma unroll
+        for (int nb = 0; nb < NBK; ++nb) {
+          acc[nb][0] = F8O ? z4 : bias4(1, 0, nb);
+          acc[nb][1] = F8O ? z4 : bias4(1, 1, nb);
+          bf16x8 bo_[PF + 1];
+#pragma unroll
+          for (int s = 0; s < PF; ++s)
+            bo_[s] = *reinterpret_cast<const bf16x8*>(sO + oB[s & 3] + 256 * (s >> 2) + 8192 * nb);
+#pragma unroll
+          for (int s = 0; s < ((abl & 64) ? 1 : KS); ++s) {
+            if (s + PF < KS)
+              bo_[(s + PF) % (PF + 1)] = *reinterpret_cast<const bf16x8*>(
+                  sO + oB[(s + PF) & 3] + 256 * ((s + PF) >> 2) + 8192 * nb);
+            // the residual O_j of both blocks: requested under the last MFMAs, not after them
+            if (!TRAIN && nb == NBK - 1 && s == KS - PF) {       // (TRAIN: no registers to spare)
+#pragma unroll
+              for (int q = 0; q < NBK; ++q) {
+                o4[q][0] = *reinterpret_cast<const bf16x4*>(sO + oD[0] + 8192 * q);
+                o4[q][1] = *reinterpret_cast<const bf16x4*>(sO + oD[1] + 8192 * q);
+              }
+            }
+            const bf16x8 ob = bo_[s % (PF + 1)];
+            if (F8O) {
+              const f8x8 o8 = bf_to_f8(ob);
+              acc[nb][0] = mfma32_f8(w8[F8O ? s : 0][0], o8, acc[nb][0]);
+              acc[nb][1] = mfma32_f8(w8[F8O ? s : 0][1], o8, acc[nb][1]);
+            } else {
+              acc[nb][0] = mfma32(wa[s][0], ob, acc[nb][0]);
+              acc[nb][1] = mfma32(wa[s][1], ob, acc[nb][1]);
+            }
+          }
+          AB_STAMP(2 + nb);
+        }
+#pragma unroll
+        for (int nb = 0; nb < NBK; ++nb) {
+          uint32_t bits = 0u;
+#pragma unroll
+          for (int t = 0; t < 2; ++t) {
+            f32x4 bo4 = z4;
+            if (F8O) bo4 = bias4(1, t, nb);
+            if (TRAIN) o4[nb][t] = *reinterpret_cast<const bf16x4*>(sO + oD[t] + 8192 * nb);
+            f32x4 y;
+#pragma unroll
+            for (int e = 0; e < 4; ++e) {
+              const float zz = F8O ? acc[nb][t][e] * inv_o + bo4[e] : acc[nb][t][e];
+              y[e] = (abl & 2) ? zz : (float)o4[nb][t][e] + fmaxf(zz, 0.f);
+              if (TRAIN && zz > 0.f) bits |= 1u << (4 * t + e);
+            }
+            *reinterpret_cast<bf16x4*>(sY + oD[t] + 8192 * nb) = pack4(y);
+          }
+          if (TRAIN)
+            reinterpret_cast<uint8_t*>(sMask)[((nb * 2 + (j >> 2)) * 64 + lane) * 4 + (j & 3)] =
+                (uint8_t)bits;
+          AB_STAMP(4 + nb);
+        }
+        if (TRAIN) {                          // O and Qp tiles of the unit, saved for the backward
+          const int n0 = t1 * P, nlive = a.N - n0;
+          const int64_t rowbytes = ((int64_t)b1 * a.N + n0) * ROWB;
+          char* baseO = reinterpret_cast<char*>(a.OS) + rowbytes;
+          char* baseQ = reinterpret_cast<char*>(a.QpS) + rowbytes;
+          // (LDS reads unconditional, all ahead of the stores: a read under the divergent row guard
+          //  would get a basic block and a full wait of its own)
+          uint4 vo[P / 16];
+#pragma unroll
+          for (int i = 0; i < P / 16; ++i) vo[i] = *reinterpret_cast<const uint4*>(sO + oC + 8192 * i);
+#pragma unroll
+          for (int i = 0; i < P / 16; ++i) {
+            const int c = tb + 512 * i;
+            if ((c >> 5) < nlive) *reinterpret_cast<uint4*>(baseO + (unsigned)(c * 16)) = vo[i];
+          }
+          if (a.QpS != nullptr) {
+#pragma unroll
+            for (int i = 0; i < P / 16; ++i)
+              vo[i] = *reinterpret_cast<const uint4*>(sQb + pq * TILEB + oC + 8192 * i);
+#pragma unroll
+            for (int i = 0; i < P / 16; ++i) {
+              const int c = tb + 512 * i;
+              if ((c >> 5) < nlive) *reinterpret_cast<uint4*>(baseQ + (unsigned)(c * 16)) = vo[i];
+            }
+          }
+        }
+      }
+      if (k >= 2 && !(abl & 16)) {            // coalesced stores of the Y tile of unit k - 2
+        const int n0 = t2 * P, nlive = a.N - n0;
+        char* base = reinterpret_cast<char*>(a.Y) + ((int64_t)b2 * a.N + n0) * ROWB;
+        uint4 vy[P / 16];
+#pragma unroll
+        for (int i = 0; i < P / 16; ++i)
+          vy[i] = *reinterpret_cast<const uint4*>(sYb + par * TILEB + oC + 8192 * i);
+#pragma unroll
+        for (int i = 0; i < P / 16; ++i) {
+          const int c = tb + 512 * i;
+          if ((c >> 5) < nlive) *reinterpret_cast<uint4*>(base + (unsigned)(c * 16)) = vy[i];
+        }
+        if (TRAIN && tb < NBK * 128) {
+          const int nb = tb >> 7, w = (tb >> 6) & 1;
+          const int64_t blk = (int64_t)b2 * tiles128 * 8 + t2 * NBK + nb;
+          a.mask[(blk * 2 + w) * 64 + lane] = sMaskb[par * NBK * 128 + (nb * 2 + w) * 64 + lane];
+        }
+      }
+      AB_STAMP(6);
+      b2 = b1; t2 = t1;
+      b1 = cb; t1 = ct;
+      if (k < n) {
+        if (++ct == a.tiles_per_set) { ct = 0; ++cb; }
+      }
+      unit_barrier();
+    }
+  }
+#ifdef PCA_FWD_STAMPS
+  __syncthreads();
+  if (blockIdx.x == 0)
+    for (int i = tid; i < 16 * 32 * 8; i += 1024) g_fwd_stamps[i] = sStamp[i];
+#endif
+}
+
 }  // namespace
 
 int isab1_fwd256_fused(const void* X, int dq, const __bf16* WqB, const float* WqF, const float* bq,
@@ -438,6 +898,7 @@ int isab1_fwd256_fused(const void* X, int dq, const __bf16* WqB, const float* Wq
   a.B = B; a.N = N; a.dq = dq;
   a.tiles_per_set = (int)cdiv(N, P);
   a.scale_log2e = 1.4426950408889634f / sqrtf((float)D);
+  a.ablate = getenv("PCA_AB_ABLATE") ? atoi(getenv("PCA_AB_ABLATE")) : 0;
   const int total = B * a.tiles_per_set;
   int grid = total < 256 ? total : 256;
   a.units_per_wg = (int)cdiv(total, grid);
@@ -457,6 +918,41 @@ int isab1_fwd256_fused(const void* X, int dq, const __bf16* WqB, const float* Wq
   const double pts = (double)B * N;
   ProfScope ps(PCA_K_MAB1_FWD, st, 2.0 * pts * ((double)dq * D + (double)D * D + 2.0 * MI * D),
                pts * ((dq <= 4 ? 4.0 : 2.0) * dq + 2.0 * D));
+  // PCA_D256_AB=0: the one-role kernel (every wave walks the whole chain; A/B measurements)
+  static const bool ab = [] { const char* e = getenv("PCA_D256_AB"); return !(e && e[0] == '0'); }();
+  // (fp8 fc_o: the role-B weight slice in fp8 next to role A's bf16 one spills at 128 registers -
+  //  that mode keeps the one-role kernel)
+  if (ab && inv_o == nullptr) {
+    const bool train = OS != nullptr;
+    PCA_REQUIRE(!train || mask != nullptr, "isab1_fwd256_fused: training needs the mask buffer");
+    const size_t lds2 = 9 * (size_t)TILEB + 2 * NBK * 2 * 64 * sizeof(uint32_t) +
+                        4 * D * sizeof(float)
+#ifdef PCA_FWD_STAMPS
+                        + 16 * 32 * 8 * 4
+#endif
+        ;
+#define PCA_AB_LAUNCH(S, F, T)                                                                   \
+  do {                                                                                           \
+    static std::once_flag o2;                                                                    \
+    std::call_once(o2, [] {                                                                      \
+      (void)hipFuncSetAttribute(reinterpret_cast<const void*>(k_isab1_fwd256_ab<S, F, T>),       \
+                                hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);        \
+    });                                                                                          \
+    hipLaunchKernelGGL((k_isab1_fwd256_ab<S, F, T>), dim3(grid), dim3(1024), lds2, st, a);       \
+  } while (0)
+    const bool sm = dq <= 4, f8 = inv_o != nullptr;
+    if (sm && f8 && train) PCA_AB_LAUNCH(true, true, true);
+    else if (sm && f8) PCA_AB_LAUNCH(true, true, false);
+    else if (sm && train) PCA_AB_LAUNCH(true, false, true);
+    else if (sm) PCA_AB_LAUNCH(true, false, false);
+    else if (f8 && train) PCA_AB_LAUNCH(false, true, true);
+    else if (f8) PCA_AB_LAUNCH(false, true, false);
+    else if (train) PCA_AB_LAUNCH(false, false, true);
+    else PCA_AB_LAUNCH(false, false, false);
+#undef PCA_AB_LAUNCH
+    ps.end();
+    return check_launch("k_isab1_fwd256_ab");
+  }
   if (inv_o != nullptr) {
     if (dq <= 4) hipLaunchKernelGGL((k_isab1_fwd256<true, true>), dim3(grid), dim3(512), lds, st, a);
     else hipLaunchKernelGGL((k_isab1_fwd256<false, true>), dim3(grid), dim3(512), lds, st, a);
