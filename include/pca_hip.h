@@ -84,6 +84,19 @@ int pca_stft_logmag(const float* wave, int64_t L, int n_fft, int win_length, int
                     int n_bins, float* out, int64_t stride_f, int64_t stride_t,
                     void* stream);
 
+/* The same transform for a whole corpus in ONE launch
+ * replaces: the per-file loops Code/settransformer.py:43-53, Code/settransformertemp.py:45-61
+ * (one librosa.stft call per clip).  waves: the clips back to back; wave_off[n_clips + 1]
+ * (device) their sample offsets, frame_off[n_clips + 1] (device) the output column of each
+ * clip's first frame (clip c yields pca_stft_num_frames(len_c, hop) columns); max_len / min_len:
+ * the longest / shortest clip (host values: grid size and the reflect-padding check).  Element
+ * (f, t) of clip c is written to out[f*stride_f + (frame_off[c] + t)*stride_t], bit-identical to
+ * pca_stft_logmag of that clip. */
+int pca_stft_logmag_batch(const float* waves, const int64_t* wave_off, const int64_t* frame_off,
+                          int n_clips, int64_t max_len, int64_t min_len, int n_fft,
+                          int win_length, int hop, int n_bins, float* out, int64_t stride_f,
+                          int64_t stride_t, void* stream);
+
 /* 2-D point sets for a batch of frames
  * replaces: Code/dataset.py:50-54  ESC_pc.__getitem__ (+ default_collate)
  * spec element (f, t) at spec[f*stride_f + t*stride_t]; farr[F] float32 (the

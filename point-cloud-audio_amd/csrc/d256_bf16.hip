@@ -1580,10 +1580,20 @@ __global__ __launch_bounds__(512, 2) void k_fq_attn_fwd2(const FqArgs a) {
 struct FqProjArgs {
   FqArgs f;
   const __bf16* X;               // [B*N][256]
-  const __bf16 *WkB, *WvB;       // natural bf16 images [256][256]
+  const __bf16 *WkB, *WvB;       // natural bf16 images [256][256] (F8: fp8 e4m3 bytes of s * W)
   const float *bk, *bv;
   __bf16 *KpO, *VpO;             // [B*N][256] outputs (saved for the backward)
+  const float* inv_scale;        // F8: 1 / s_k, 1 / s_v
 };
+// F8 (PCA_MODE_FP8, round 3): fc_k / fc_v on v_mfma_scale_f32_16x16x128_f8f6f4 (e4m3 operands, block
+// scales 2^0: twice the bf16 rate, scripts/probe/mfma_f8_probe.hip).  The X tile is converted to
+// fp8 ONCE per tile by the whole workgroup (16 elements per thread, into an 8 KiB fp8 tile with
+// 16-byte chunks XOR-swizzled by row) instead of once per fragment and wave as k_rowstream<F8>
+// does (28 VALU instructions per fragment, eight waves converting the same values); the weight
+// slices are 32 + 32 registers instead of 64 + 64 and a tile's 64 MFMAs of 16 cycles become 16 of
+// 32.  The attention on the bf16 Kp / Vp slices is unchanged.
+typedef int fq_v8i __attribute__((ext_vector_type(8)));
+template <bool F8>
 __global__ __launch_bounds__(512, 2) void k_fq_proj_fwd(const FqProjArgs aa) {
   const FqArgs& a = aa.f;
   constexpr int D = 256, QT = 2, PV = 72, H = D / 32, MQ = 16 * QT, KS = D / 32;
@@ -1592,6 +1602,7 @@ __global__ __launch_bounds__(512, 2) void k_fq_proj_fwd(const FqProjArgs aa) {
   char* sXb = smem;                        // [NBUF][TILEB]
   char* sK = smem + NBUF * TILEB;          // Kp tile
   char* sV = sK + TILEB;                   // Vp tile
+  char* sX8 = sV + TILEB + H * 32 * PV;    // F8: the current X tile as fp8 [32][256 B]
   const int tid = threadIdx.x, lane = tid & 63;
   const int j = __builtin_amdgcn_readfirstlane(tid >> 6);
   const int r = lane & 15, g = lane >> 4;
@@ -1606,15 +1617,43 @@ __global__ __launch_bounds__(512, 2) void k_fq_proj_fwd(const FqProjArgs aa) {
   const int n_end = (n_lo + per < a.N) ? n_lo + per : a.N;
   const int n_hi = n_end < len ? n_end : len;
   const int T = n_lo < n_end ? (n_end - n_lo + 31) / 32 : 0;
-  bf16x8 wk[KS][2], wv[KS][2];
+  bf16x8 wk[F8 ? 1 : KS][2], wv[F8 ? 1 : KS][2];
+  fq_v8i wk8[F8 ? 2 : 1][2], wv8[F8 ? 2 : 1][2];
+  float inv_k = 1.f, inv_v = 1.f;
+  if (F8) {
+    inv_k = aa.inv_scale[0];
+    inv_v = aa.inv_scale[1];
 #pragma unroll
-  for (int s = 0; s < KS; ++s)
+    for (int S = 0; S < 2; ++S)
 #pragma unroll
-    for (int t = 0; t < 2; ++t) {
-      const int64_t o = (int64_t)(32 * j + 16 * t + r) * D + 32 * s + 8 * g;
-      wk[s][t] = *reinterpret_cast<const bf16x8*>(aa.WkB + o);
-      wv[s][t] = *reinterpret_cast<const bf16x8*>(aa.WvB + o);
-    }
+      for (int t = 0; t < 2; ++t) {
+        const int o = (32 * j + 16 * t + r) * D + 128 * S + 32 * g;
+        const uint4* pk = reinterpret_cast<const uint4*>(reinterpret_cast<const uint8_t*>(aa.WkB) + o);
+        const uint4* pv = reinterpret_cast<const uint4*>(reinterpret_cast<const uint8_t*>(aa.WvB) + o);
+        const uint4 k0 = pk[0], k1 = pk[1], v0 = pv[0], v1 = pv[1];
+        wk8[F8 ? S : 0][t] = fq_v8i{(int)k0.x, (int)k0.y, (int)k0.z, (int)k0.w,
+                                    (int)k1.x, (int)k1.y, (int)k1.z, (int)k1.w};
+        wv8[F8 ? S : 0][t] = fq_v8i{(int)v0.x, (int)v0.y, (int)v0.z, (int)v0.w,
+                                    (int)v1.x, (int)v1.y, (int)v1.z, (int)v1.w};
+      }
+  } else {
+#pragma unroll
+    for (int s = 0; s < KS; ++s)
+#pragma unroll
+      for (int t = 0; t < 2; ++t) {
+        const int64_t o = (int64_t)(32 * j + 16 * t + r) * D + 32 * s + 8 * g;
+        wk[F8 ? 0 : s][t] = *reinterpret_cast<const bf16x8*>(aa.WkB + o);
+        wv[F8 ? 0 : s][t] = *reinterpret_cast<const bf16x8*>(aa.WvB + o);
+      }
+  }
+  // F8: this thread's share of the tile conversion (row tid / 16, fp8 chunk tid % 16 = bf16 chunks
+  // 2 c, 2 c + 1) and this lane's two 16-byte chunks of an fp8 row (k = 32 g .. 32 g + 31; + 128 S)
+  const int cvr = tid >> 4, cvc = tid & 15;
+  const int cv_src0 = swz(cvr, 2 * cvc, ROWB), cv_src1 = swz(cvr, 2 * cvc + 1, ROWB);
+  const int cv_dst = cvr * D + ((cvc ^ (cvr & 15)) << 4);
+  int x8r[2];
+#pragma unroll
+  for (int c = 0; c < 2; ++c) x8r[c] = r * D + (((2 * g + c) ^ r) << 4);
   f32x4 bkz[2], bvz[2];
 #pragma unroll
   for (int t = 0; t < 2; ++t) {
@@ -1688,9 +1727,49 @@ __global__ __launch_bounds__(512, 2) void k_fq_proj_fwd(const FqProjArgs aa) {
       }
     }
     lds_barrier();                       // B0: X tile k; the previous Kp / Vp tiles are stored
+    if (F8) {
+      const bf16x8 x0 = *reinterpret_cast<const bf16x8*>(sX + cv_src0);
+      const bf16x8 x1 = *reinterpret_cast<const bf16x8*>(sX + cv_src1);
+      uint4 q;
+      q.x = cvt4_f8((float)x0[0], (float)x0[1], (float)x0[2], (float)x0[3]);
+      q.y = cvt4_f8((float)x0[4], (float)x0[5], (float)x0[6], (float)x0[7]);
+      q.z = cvt4_f8((float)x1[0], (float)x1[1], (float)x1[2], (float)x1[3]);
+      q.w = cvt4_f8((float)x1[4], (float)x1[5], (float)x1[6], (float)x1[7]);
+      *reinterpret_cast<uint4*>(sX8 + cv_dst) = q;
+      lds_barrier();                     // B0b: the fp8 tile (the previous tile's readers passed B1)
+    }
     // ---- Kp_h^T, Vp_h^T = W_h . X^T + b: own slices of the two tiles ----
     {
       f32x4 ak[2][2], av[2][2];
+      if (F8) {
+#pragma unroll
+        for (int nb = 0; nb < 2; ++nb) {
+          fq_v8i fb8[2];
+#pragma unroll
+          for (int S = 0; S < 2; ++S) {
+            const uint4 lo = *reinterpret_cast<const uint4*>(sX8 + 16 * D * nb + (x8r[0] ^ (S << 7)));
+            const uint4 hi = *reinterpret_cast<const uint4*>(sX8 + 16 * D * nb + (x8r[1] ^ (S << 7)));
+            fb8[S] = fq_v8i{(int)lo.x, (int)lo.y, (int)lo.z, (int)lo.w,
+                            (int)hi.x, (int)hi.y, (int)hi.z, (int)hi.w};
+          }
+#pragma unroll
+          for (int t = 0; t < 2; ++t) {
+            f32x4 k4 = {0.f, 0.f, 0.f, 0.f}, v4 = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+            for (int S = 0; S < 2; ++S) {
+              k4 = __builtin_amdgcn_mfma_scale_f32_16x16x128_f8f6f4(wk8[F8 ? S : 0][t], fb8[S], k4, 0, 0,
+                                                                   0, 0x7f7f7f7f, 0, 0x7f7f7f7f);
+              v4 = __builtin_amdgcn_mfma_scale_f32_16x16x128_f8f6f4(wv8[F8 ? S : 0][t], fb8[S], v4, 0, 0,
+                                                                   0, 0x7f7f7f7f, 0, 0x7f7f7f7f);
+            }
+#pragma unroll
+            for (int e = 0; e < 4; ++e) {
+              ak[t][nb][e] = __builtin_fmaf(k4[e], inv_k, bkz[t][e]);
+              av[t][nb][e] = __builtin_fmaf(v4[e], inv_v, bvz[t][e]);
+            }
+          }
+        }
+      } else {
 #pragma unroll
       for (int t = 0; t < 2; ++t)
 #pragma unroll
@@ -1701,11 +1780,12 @@ __global__ __launch_bounds__(512, 2) void k_fq_proj_fwd(const FqProjArgs aa) {
         for (int nb = 0; nb < 2; ++nb) {
           const bf16x8 bx =
               *reinterpret_cast<const bf16x8*>(sX + oB[s & 3] + 256 * (s >> 2) + 8192 * nb);
-          ak[0][nb] = mfma32(wk[s][0], bx, ak[0][nb]);
-          ak[1][nb] = mfma32(wk[s][1], bx, ak[1][nb]);
-          av[0][nb] = mfma32(wv[s][0], bx, av[0][nb]);
-          av[1][nb] = mfma32(wv[s][1], bx, av[1][nb]);
+          ak[0][nb] = mfma32(wk[F8 ? 0 : s][0], bx, ak[0][nb]);
+          ak[1][nb] = mfma32(wk[F8 ? 0 : s][1], bx, ak[1][nb]);
+          av[0][nb] = mfma32(wv[F8 ? 0 : s][0], bx, av[0][nb]);
+          av[1][nb] = mfma32(wv[F8 ? 0 : s][1], bx, av[1][nb]);
         }
+      }
 #pragma unroll
       for (int t = 0; t < 2; ++t)
 #pragma unroll
@@ -3112,7 +3192,7 @@ int fq_attn_fwd256(const __bf16* Kp, const __bf16* Vp, const float* Qp, int B, i
 int fq_proj_attn_fwd256(const __bf16* X, const __bf16* WkB, const __bf16* WvB, const float* bk,
                         const float* bv, const float* Qp, int B, int N, int m,
                         const int32_t* lengths, __bf16* Kp, __bf16* Vp, float* Op, float* Mp,
-                        float* Lp, float* O, float* LSE, hipStream_t st) {
+                        float* Lp, float* O, float* LSE, hipStream_t st, const float* inv_scale) {
   constexpr int D = 256;
   PCA_REQUIRE(m > 16 && m <= 32, "fq_proj_attn_fwd256: m = %d", m);
   int S2 = fq_splits256(B, N);
@@ -3123,13 +3203,18 @@ int fq_proj_attn_fwd256(const __bf16* X, const __bf16* WkB, const __bf16* WvB, c
   a.f.scale = 1.0f / sqrtf((float)D);
   a.f.scale_log2e = 1.4426950408889634f * a.f.scale;
   a.X = X; a.WkB = WkB; a.WvB = WvB; a.bk = bk; a.bv = bv; a.KpO = Kp; a.VpO = Vp;
+  a.inv_scale = inv_scale;
   static std::once_flag once;
   std::call_once(once, [] {
-    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(k_fq_proj_fwd),
+    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(k_fq_proj_fwd<false>),
+                              hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(k_fq_proj_fwd<true>),
                               hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
   });
-  const size_t lds = (size_t)5 * 32 * D * 2 + (size_t)(D / 32) * 32 * 72;
-  hipLaunchKernelGGL(k_fq_proj_fwd, dim3(B, S2), dim3(512), lds, st, a);
+  const size_t lds = (size_t)5 * 32 * D * 2 + (size_t)(D / 32) * 32 * 72 +
+                     (inv_scale != nullptr ? (size_t)32 * D : 0);
+  if (inv_scale != nullptr) hipLaunchKernelGGL(k_fq_proj_fwd<true>, dim3(B, S2), dim3(512), lds, st, a);
+  else hipLaunchKernelGGL(k_fq_proj_fwd<false>, dim3(B, S2), dim3(512), lds, st, a);
   PCA_TRY(check_launch("k_fq_proj_fwd"));
   hipLaunchKernelGGL(k_fq_merge, dim3((unsigned)cdiv((int64_t)B * m * D, 256)), dim3(256), 0, st,
                      Op, Mp, Lp, Qp, B, S2, m, D, 32, O, LSE);

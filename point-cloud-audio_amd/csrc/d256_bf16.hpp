@@ -85,7 +85,8 @@ int rowstream256_dx2(const __bf16* dKp, const __bf16* dVp, const __bf16* WkT, co
 int fq_proj_attn_fwd256(const __bf16* X, const __bf16* WkB, const __bf16* WvB, const float* bk,
                         const float* bv, const float* Qp, int B, int N, int m,
                         const int32_t* lengths, __bf16* Kp, __bf16* Vp, float* Op, float* Mp,
-                        float* Lp, float* O, float* LSE, hipStream_t st);
+                        float* Lp, float* O, float* LSE, hipStream_t st,
+                        const float* inv_scale = nullptr);   // non-null: WkB / WvB are fp8 images
 int rowstream256_dx3(const __bf16* dQp, const __bf16* dKp, const __bf16* dVp, const __bf16* WqT,
                      const __bf16* WkT, const __bf16* WvT, __bf16* dX, int B, int N, hipStream_t st);
 int rowstream256_dx1(const __bf16* dQp, const __bf16* WqT, __bf16* dX, int B, int N,

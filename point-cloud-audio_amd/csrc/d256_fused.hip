@@ -460,7 +460,8 @@ __global__ __launch_bounds__(512, 2) void k_isab1_fwd256(const FusedFwdArgs a) {
 
 template <bool SMALL, bool F8O, bool TRAIN>
 __global__ __launch_bounds__(1024) void k_isab1_fwd256_ab(const FusedFwdArgs a) {
-  constexpr int KS = D / 32, PF = TRAIN ? 2 : 3;     // (TRAIN: one fragment less ahead - 128 registers)
+  // (TRAIN: fewer fragments ahead - the kernel has to stay inside 128 registers without scratch)
+  constexpr int KS = D / 32, PF = TRAIN ? (F8O ? 1 : 2) : 3;
   // ablation switches of the measurement build (results are garbage with any of them set):
   // 1 no softmax arithmetic, 2 no epilogue arithmetic, 4 no barrier, 8 no LDS-DMA, 16 no Y stores,
   // 32 no GEMM1, 64 no GEMM2
@@ -470,20 +471,19 @@ __global__ __launch_bounds__(1024) void k_isab1_fwd256_ab(const FusedFwdArgs a) 
   constexpr int abl = 0;
 #endif
   extern __shared__ __attribute__((aligned(16))) char smem[];
-  // X tiles arrive XR - 1 units ahead (role A only).  One unit ahead is not enough: every CU asks
-  // for its tile at the same moment, the burst comes back after more than an iteration, and the
-  // wait for it sat on role A's path (no LDS-DMA: - 8 us of 93; no Y stores, i.e. a quieter
-  // memory system: - 15; scripts/experiments/ab_ablate.sh).  TRAIN has LDS for two tiles only.
-  constexpr int XR = TRAIN ? 2 : 3, AH = XR - 1;
-  char* sXb = smem;                         // X tiles [XR][TILEB]
+  // X tiles [XR]: one unit ahead.  (A ring of three tiles, two units ahead, measured no different:
+  // 91.8 against 91.9 us at B = 128, N = 2048 - the LDS-DMA is not what role A waits for.)
+  constexpr int XR = 2, AH = XR - 1;
+  char* sXb = smem;                         // X tiles [XR][TILEB]   (role A only)
   char* sOb = smem + XR * TILEB;            // O tiles (A writes slices, B reads)
   char* sYb = sOb + 2 * TILEB;              // Y tiles (B only)
   char* sKb = sYb + 2 * TILEB;              // K slices of the current set, wave-private [8][2][64][16 B]
-  // V slices likewise when there is room (inference): 8 more registers for role A's read-ahead
-  constexpr bool VL = !TRAIN;
-  char* sVb = sKb + TILEB;
-  char* sQb = sKb + TILEB;                  // TRAIN: Qp tiles (A writes slices, B stores them)
-  uint32_t* sMaskb = reinterpret_cast<uint32_t*>(sKb + (TRAIN ? 3 : 2) * TILEB);
+  char* sVb = sKb + TILEB;                  // V slices likewise (16 registers less in role A)
+  constexpr bool VL = true;
+  // F8O: the O tile once more as fp8 e4m3 [2][32 points][256 B] (16-byte chunks XOR-swizzled by
+  // row): role A converts its slice once, role B's GEMM2 reads fp8 fragments for the K = 128 MFMA
+  char* sO8b = sVb + TILEB;
+  uint32_t* sMaskb = reinterpret_cast<uint32_t*>(sVb + (F8O ? 2 : 1) * TILEB);
   // bq [256], bo [256], and both again: point block nb reads copy nb, so that hipcc does not keep
   // one read alive (8 registers) across the attention of block 0
   float* sBias = reinterpret_cast<float*>(sMaskb + 2 * NBK * 2 * 64);
@@ -496,23 +496,10 @@ __global__ __launch_bounds__(1024) void k_isab1_fwd256_ab(const FusedFwdArgs a) 
 #endif
   const int r = lane & 15, g = lane >> 4;
 
-  // ---- this wave's ONE weight slice: A operands [row = feature 32 j + 16 t + r][k = 32 s + 8 g ..]
-  bf16x8 wa[KS][2];
-  f8x8 w8[F8O ? KS : 1][2];
-  {
-    const bool want = role == 1 ? !F8O : !SMALL;
-    const __bf16* Wsrc = role == 1 ? a.Wo : a.Wq;
-#pragma unroll
-    for (int s = 0; s < KS; ++s)
-#pragma unroll
-      for (int t = 0; t < 2; ++t) {
-        const int o = (32 * j + 16 * t + r) * D + 32 * s + 8 * g;
-        if (want) wa[s][t] = *reinterpret_cast<const bf16x8*>(Wsrc + o);
-        if (F8O && role == 1)
-          w8[F8O ? s : 0][t] =
-              *reinterpret_cast<const f8x8*>(reinterpret_cast<const uint8_t*>(a.Wo) + o);
-      }
-  }
+  // ---- this wave's ONE weight slice: A operands [row = feature 32 j + 16 t + r][k = 32 s + 8 g ..],
+  // loaded inside the role's branch (role B in F8O mode holds fp8 fragments of the K = 128 MFMA
+  // instead: the two never live together)
+  typedef int v8i __attribute__((ext_vector_type(8)));
   if (tid < 2 * D) {
     const float v = tid < D ? a.bq[tid] : a.bo[tid - D];
     sBias[tid] = v;
@@ -589,6 +576,19 @@ __global__ __launch_bounds__(1024) void k_isab1_fwd256_ab(const FusedFwdArgs a) 
           for (int c = 0; c < 4; ++c)
             wqs[SMALL ? t : 0][e][c] = c < a.dq ? a.WqF[(32 * j + 16 * t + 4 * g + e) * a.dq + c] : 0.f;
     }
+    bf16x8 wa[KS][2];
+    if (!SMALL) {
+#pragma unroll
+      for (int s = 0; s < KS; ++s)
+#pragma unroll
+        for (int t = 0; t < 2; ++t)
+          wa[s][t] = *reinterpret_cast<const bf16x8*>(a.Wq + (32 * j + 16 * t + r) * D + 32 * s + 8 * g);
+    }
+    const int qoff = r * ROWB + (32 * j + 4 * g) * 2;      // TRAIN: this lane's 8 bytes of a Qp row
+    // F8O: this lane's 4-byte piece of the fp8 O tile: row r, byte 32 j + 16 t + 4 g
+    int o8[2];
+#pragma unroll
+    for (int t = 0; t < 2; ++t) o8[t] = r * D + (((2 * j + t) ^ r) << 4) + 4 * g;
     float xv[NBK][4], xn[NBK][4];
     int fb = cb, ft = ct;                    // the next unit to fetch (AH units ahead of the current)
     auto fetch_advance = [&] { if (++ft == a.tiles_per_set) { ft = 0; ++fb; } };
@@ -620,7 +620,12 @@ __global__ __launch_bounds__(1024) void k_isab1_fwd256_ab(const FusedFwdArgs a) 
         const int b = cb;
         char* sXc = sXb + xs * TILEB;
         char* sO = sOb + par * TILEB;
-        char* sQ = sQb + par * TILEB;
+        // TRAIN, d -> d blocks: Qp is saved for the backward - this wave's [32 points][32 features]
+        // slice goes straight to memory, 8 bytes per lane (round 2 staged a Qp tile in LDS for
+        // role-B-style coalesced rows: two tiles of LDS and a copy pass; the 64-byte row pieces of
+        // the eight heads meet in L2 before the line leaves it)
+        const int nliveA = a.N - ct * P;
+        char* qbase = reinterpret_cast<char*>(a.QpS) + ((int64_t)cb * a.N + ct * P) * ROWB;   // (uniform)
         if (b != cur_b) {                    // this set's K / V slices of head j (once per set)
 #pragma unroll
           for (int kt = 0; kt < 2; ++kt) {
@@ -682,9 +687,15 @@ __global__ __launch_bounds__(1024) void k_isab1_fwd256_ab(const FusedFwdArgs a) 
             kp1 = *reinterpret_cast<const bf16x8*>(sK + 1024);
           }
           AB_STAMP(2 + 2 * nb);
-          if (TRAIN) {
-            *reinterpret_cast<bf16x4*>(sQ + oD[0] + 8192 * nb) = pack4(acc0);
-            *reinterpret_cast<bf16x4*>(sQ + oD[1] + 8192 * nb) = pack4(acc1);
+          if (TRAIN && a.QpS != nullptr) {
+            char* q0 = qbase + (unsigned)(qoff + 16 * ROWB * nb);
+            if (nliveA >= P) {               // (uniform: a full tile stores unguarded, see the wait below)
+              *reinterpret_cast<bf16x4*>(q0) = pack4(acc0);
+              *reinterpret_cast<bf16x4*>(q0 + 32) = pack4(acc1);
+            } else if (16 * nb + r < nliveA) {
+              *reinterpret_cast<bf16x4*>(q0) = pack4(acc0);
+              *reinterpret_cast<bf16x4*>(q0 + 32) = pack4(acc1);
+            }
           }
           // ---- attention over the 32 inducing keys, inside the wave ----
           const bf16x8 qb = pack8(acc0, acc1);
@@ -721,6 +732,11 @@ __global__ __launch_bounds__(1024) void k_isab1_fwd256_ab(const FusedFwdArgs a) 
           }
           *reinterpret_cast<bf16x4*>(sO + oD[0] + 8192 * nb) = pack4(acc0);
           *reinterpret_cast<bf16x4*>(sO + oD[1] + 8192 * nb) = pack4(acc1);
+          if (F8O) {
+            char* sO8 = sO8b + par * (P * D) + (16 * D) * nb;
+            *reinterpret_cast<uint32_t*>(sO8 + o8[0]) = cvt4_f8(acc0[0], acc0[1], acc0[2], acc0[3]);
+            *reinterpret_cast<uint32_t*>(sO8 + o8[1]) = cvt4_f8(acc1[0], acc1[1], acc1[2], acc1[3]);
+          }
           AB_STAMP(3 + 2 * nb);
         }
         if (SMALL) {
@@ -733,8 +749,11 @@ __global__ __launch_bounds__(1024) void k_isab1_fwd256_ab(const FusedFwdArgs a) 
         if (++xs == XR) xs = 0;
         // the next unit's X tile (this wave's pieces) has landed before the barrier releases it;
         // the pieces of the units after it, issued later, stay in flight (vmcnt retires in order)
+        // (TRAIN: the four Qp stores of a full tile were issued after the LDS-DMA and may stay in
+        //  flight - vmcnt retires in issue order; a ragged tile's guarded stores may have been
+        //  skipped by whole waves, so its count is unknown: drain)
         if (!SMALL) {
-          if (AH == 2 && more) asm volatile("s_waitcnt vmcnt(2)" ::: "memory");
+          if (TRAIN && a.QpS != nullptr && nliveA >= P) asm volatile("s_waitcnt vmcnt(4)" ::: "memory");
           else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
         }
       }
@@ -745,6 +764,30 @@ __global__ __launch_bounds__(1024) void k_isab1_fwd256_ab(const FusedFwdArgs a) 
     // ================================ role B ================================
     const int tb = tid & 511;                 // thread index inside the role
     const float inv_o = F8O ? a.inv_o[0] : 1.f;
+    bf16x8 wa[F8O ? 1 : KS][2];
+    v8i wf[F8O ? 2 : 1][2];                   // F8O: [K step of 128][feature tile]: 32 bytes per lane
+    int o8r[2];                               // F8O: the lane's two 16-byte chunks of an fp8 O row
+#pragma unroll
+    for (int c = 0; c < 2; ++c) o8r[c] = r * D + (((2 * g + c) ^ r) << 4);
+    if (F8O) {
+#pragma unroll
+      for (int S = 0; S < 2; ++S)
+#pragma unroll
+        for (int t = 0; t < 2; ++t) {
+          const uint4* pw = reinterpret_cast<const uint4*>(reinterpret_cast<const uint8_t*>(a.Wo) +
+                                                           (32 * j + 16 * t + r) * D + 128 * S + 32 * g);
+          const uint4 lo = pw[0], hi = pw[1];
+          wf[F8O ? S : 0][t] = v8i{(int)lo.x, (int)lo.y, (int)lo.z, (int)lo.w,
+                                   (int)hi.x, (int)hi.y, (int)hi.z, (int)hi.w};
+        }
+    } else {
+#pragma unroll
+      for (int s = 0; s < KS; ++s)
+#pragma unroll
+        for (int t = 0; t < 2; ++t)
+          wa[F8O ? 0 : s][t] =
+              *reinterpret_cast<const bf16x8*>(a.Wo + (32 * j + 16 * t + r) * D + 32 * s + 8 * g);
+    }
     const int oC = toff(tb >> 5, tb & 31);
     const int tiles128 = (a.tiles_per_set * P + 127) / 128;
     int b1 = cb, t1 = ct, b2 = cb, t2 = ct;   // units k - 1 (GEMM2) and k - 2 (deferred Y stores)
@@ -773,6 +816,34 @@ __global__ __launch_bounds__(1024) void k_isab1_fwd256_ab(const FusedFwdArgs a) 
         for (int nb = 0; nb < NBK; ++nb) {
           acc[nb][0] = F8O ? z4 : bias4(1, 0, nb);
           acc[nb][1] = F8O ? z4 : bias4(1, 1, nb);
+          if (F8O) {
+            // GEMM2 on v_mfma_scale_f32_16x16x128_f8f6f4 (e4m3, block scales 2^0): 4 instructions
+            // of 32 cycles per point block instead of 16 of 16 cycles, fragments straight from the
+            // fp8 O tile (32 bytes per lane and K step: lane (r, g) holds k = 32 g .. 32 g + 31 of
+            // its row - verified by scripts/probe/mfma_f8_probe.hip, which also measured the rate)
+            const char* sO8 = sO8b + pq * (P * D) + (16 * D) * nb;
+            v8i fb8[2];
+#pragma unroll
+            for (int S = 0; S < 2; ++S) {
+              const uint4 lo = *reinterpret_cast<const uint4*>(sO8 + (o8r[0] ^ (S << 7)));
+              const uint4 hi = *reinterpret_cast<const uint4*>(sO8 + (o8r[1] ^ (S << 7)));
+              fb8[S] = v8i{(int)lo.x, (int)lo.y, (int)lo.z, (int)lo.w,
+                           (int)hi.x, (int)hi.y, (int)hi.z, (int)hi.w};
+            }
+            if (!TRAIN && nb == NBK - 1) {
+#pragma unroll
+              for (int q = 0; q < NBK; ++q) {
+                o4[q][0] = *reinterpret_cast<const bf16x4*>(sO + oD[0] + 8192 * q);
+                o4[q][1] = *reinterpret_cast<const bf16x4*>(sO + oD[1] + 8192 * q);
+              }
+            }
+#pragma unroll
+            for (int S = 0; S < 2; ++S)
+#pragma unroll
+              for (int t = 0; t < 2; ++t)
+                acc[nb][t] = __builtin_amdgcn_mfma_scale_f32_16x16x128_f8f6f4(
+                    wf[F8O ? S : 0][t], fb8[S], acc[nb][t], 0, 0, 0, 0x7f7f7f7f, 0, 0x7f7f7f7f);
+          } else {
           bf16x8 bo_[PF + 1];
 #pragma unroll
           for (int s = 0; s < PF; ++s)
@@ -790,15 +861,9 @@ __global__ __launch_bounds__(1024) void k_isab1_fwd256_ab(const FusedFwdArgs a) 
                 o4[q][1] = *reinterpret_cast<const bf16x4*>(sO + oD[1] + 8192 * q);
               }
             }
-            const bf16x8 ob = bo_[s % (PF + 1)];
-            if (F8O) {
-              const f8x8 o8 = bf_to_f8(ob);
-              acc[nb][0] = mfma32_f8(w8[F8O ? s : 0][0], o8, acc[nb][0]);
-              acc[nb][1] = mfma32_f8(w8[F8O ? s : 0][1], o8, acc[nb][1]);
-            } else {
-              acc[nb][0] = mfma32(wa[s][0], ob, acc[nb][0]);
-              acc[nb][1] = mfma32(wa[s][1], ob, acc[nb][1]);
-            }
+            acc[nb][0] = mfma32(wa[F8O ? 0 : s][0], bo_[s % (PF + 1)], acc[nb][0]);
+            acc[nb][1] = mfma32(wa[F8O ? 0 : s][1], bo_[s % (PF + 1)], acc[nb][1]);
+          }
           }
           AB_STAMP(2 + nb);
         }
@@ -828,7 +893,6 @@ __global__ __launch_bounds__(1024) void k_isab1_fwd256_ab(const FusedFwdArgs a) 
           const int n0 = t1 * P, nlive = a.N - n0;
           const int64_t rowbytes = ((int64_t)b1 * a.N + n0) * ROWB;
           char* baseO = reinterpret_cast<char*>(a.OS) + rowbytes;
-          char* baseQ = reinterpret_cast<char*>(a.QpS) + rowbytes;
           // (LDS reads unconditional, all ahead of the stores: a read under the divergent row guard
           //  would get a basic block and a full wait of its own)
           uint4 vo[P / 16];
@@ -838,16 +902,6 @@ __global__ __launch_bounds__(1024) void k_isab1_fwd256_ab(const FusedFwdArgs a) 
           for (int i = 0; i < P / 16; ++i) {
             const int c = tb + 512 * i;
             if ((c >> 5) < nlive) *reinterpret_cast<uint4*>(baseO + (unsigned)(c * 16)) = vo[i];
-          }
-          if (a.QpS != nullptr) {
-#pragma unroll
-            for (int i = 0; i < P / 16; ++i)
-              vo[i] = *reinterpret_cast<const uint4*>(sQb + pq * TILEB + oC + 8192 * i);
-#pragma unroll
-            for (int i = 0; i < P / 16; ++i) {
-              const int c = tb + 512 * i;
-              if ((c >> 5) < nlive) *reinterpret_cast<uint4*>(baseQ + (unsigned)(c * 16)) = vo[i];
-            }
           }
         }
       }
@@ -920,12 +974,10 @@ int isab1_fwd256_fused(const void* X, int dq, const __bf16* WqB, const float* Wq
                pts * ((dq <= 4 ? 4.0 : 2.0) * dq + 2.0 * D));
   // PCA_D256_AB=0: the one-role kernel (every wave walks the whole chain; A/B measurements)
   static const bool ab = [] { const char* e = getenv("PCA_D256_AB"); return !(e && e[0] == '0'); }();
-  // (fp8 fc_o: the role-B weight slice in fp8 next to role A's bf16 one spills at 128 registers -
-  //  that mode keeps the one-role kernel)
-  if (ab && inv_o == nullptr) {
+  if (ab) {
     const bool train = OS != nullptr;
     PCA_REQUIRE(!train || mask != nullptr, "isab1_fwd256_fused: training needs the mask buffer");
-    const size_t lds2 = 9 * (size_t)TILEB + 2 * NBK * 2 * 64 * sizeof(uint32_t) +
+    const size_t lds2 = (inv_o != nullptr ? 9 : 8) * (size_t)TILEB + 2 * NBK * 2 * 64 * sizeof(uint32_t) +
                         4 * D * sizeof(float)
 #ifdef PCA_FWD_STAMPS
                         + 16 * 32 * 8 * 4

@@ -377,13 +377,22 @@ int mab0_d256_fwd(const pca_mab_shape& s, const float* I, const void* X, const p
     }
     // PCA_FQ_FUSED_FWD=0: projection and attention as two launches (A/B measurements)
     static const bool fq_fused = [] { const char* e = getenv("PCA_FQ_FUSED_FWD"); return !(e && e[0] == '0'); }();
-    if (s.mode != PCA_MODE_FP8 && rowstream_on() && fq_fused && m > 16) {
+    // PCA_FQ_FUSED_F8=0: the fp8 mode on the two-launch form of round 2 (A/B measurements)
+    static const bool fq_fused8 = [] { const char* e = getenv("PCA_FQ_FUSED_F8"); return !(e && e[0] == '0'); }();
+    const bool f8 = s.mode == PCA_MODE_FP8;
+    if ((!f8 || fq_fused8) && rowstream_on() && fq_fused && m > 16) {
       // fc_k / fc_v over the keys and the attention in one pass over X (k_fq_proj_fwd)
-      PCA_TRY(weight_image2(p.wk, &WkP, 0, p.wv, &WvP, 0, D, D, st));
+      if (f8) {
+        PCA_TRY(prep_weight_f8(p.wk, WkP, D, D, 0, invs, st));
+        PCA_TRY(prep_weight_f8(p.wv, WvP, D, D, 0, invs + 1, st));
+      } else {
+        PCA_TRY(weight_image2(p.wk, &WkP, 0, p.wv, &WvP, 0, D, D, st));
+      }
       const double pts = (double)M;
       ProfScope ps(PCA_K_MAB0_FWD, st, 2.0 * pts * (2.0 * D * D + 2.0 * m * D), pts * 2.0 * D);
       PCA_TRY(fq_proj_attn_fwd256(Xb, WkP, WvP, p.bk, p.bv, v.Qp, s.B, s.nk, m, s.k_lengths, v.Kp,
-                                  v.Vp, v.Op, v.Mp, v.Lp, v.O, v.LSE, st));   // modules.py:21,28-29
+                                  v.Vp, v.Op, v.Mp, v.Lp, v.O, v.LSE, st,
+                                  f8 ? invs : nullptr));                      // modules.py:21,28-29
       ps.end();
     } else {
     if (s.mode == PCA_MODE_FP8) {           // fc_k / fc_v with fp8 e4m3 operands

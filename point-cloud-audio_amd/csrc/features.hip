@@ -20,16 +20,29 @@ namespace {
 // and stays HBM/LDS-bound.  LDS: n_fft complex doubles (data) + n_fft/2 (twiddles)
 // = 24 B * n_fft (96 KiB at n_fft = 4096).  Frame t covers samples
 // [t*hop - n_fft/2, t*hop + n_fft/2) of the reflect-padded signal (center=True).
+// Batched form (blockIdx.y = clip): clip c is wave[wave_off[c] .. wave_off[c + 1]) and its frame t
+// goes to output column frame_off[c] + t; a clip shorter than the longest one leaves the workgroups
+// past its last frame idle.  wave_off == nullptr: one clip of L samples, columns from 0.
 __global__ __launch_bounds__(256) void k_stft_logmag(const float* __restrict__ wave,
                                                       int64_t L, int n_fft, int log2n,
                                                       int win_length, int hop, int n_bins,
                                                       float* __restrict__ out,
-                                                      int64_t stride_f, int64_t stride_t) {
+                                                      int64_t stride_f, int64_t stride_t,
+                                                      const int64_t* __restrict__ wave_off,
+                                                      const int64_t* __restrict__ frame_off) {
   extern __shared__ __attribute__((aligned(16))) double2 lds_c[];
   double2* x = lds_c;                 // [n_fft]
   double2* tw = lds_c + n_fft;        // [n_fft/2]  exp(-2 pi i k / n_fft)
   const int tid = threadIdx.x;
   const int64_t t = blockIdx.x;
+  if (wave_off != nullptr) {
+    const int c = blockIdx.y;
+    const int64_t w0 = wave_off[c];
+    L = wave_off[c + 1] - w0;
+    if (t >= 1 + L / hop) return;     // (uniform over the workgroup)
+    wave += w0;
+    out += frame_off[c] * stride_t;
+  }
   const int lpad = (n_fft - win_length) / 2;
   const int64_t start = t * hop - n_fft / 2;
   const int half = n_fft >> 1;
@@ -166,8 +179,38 @@ int pca_stft_logmag(const float* wave, int64_t L, int n_fft, int win_length, int
   });
   hipLaunchKernelGGL(pca::k_stft_logmag, dim3((unsigned)T), dim3(256), lds,
                      pca::as_stream(stream), wave, L, n_fft, log2n, win_length, hop, n_bins,
-                     out, stride_f, stride_t);
+                     out, stride_f, stride_t, (const int64_t*)nullptr, (const int64_t*)nullptr);
   return pca::check_launch("k_stft_logmag");
+}
+
+int pca_stft_logmag_batch(const float* waves, const int64_t* wave_off, const int64_t* frame_off,
+                          int n_clips, int64_t max_len, int64_t min_len, int n_fft,
+                          int win_length, int hop, int n_bins, float* out, int64_t stride_f,
+                          int64_t stride_t, void* stream) {
+  PCA_REQUIRE(waves && wave_off && frame_off && out, "stft_logmag_batch: null pointer");
+  PCA_REQUIRE(n_clips > 0 && n_clips <= 65535, "stft_logmag_batch: n_clips=%d", n_clips);
+  PCA_REQUIRE(n_fft >= 64 && n_fft <= 4096 && (n_fft & (n_fft - 1)) == 0,
+              "stft_logmag_batch: n_fft=%d must be a power of two in [64, 4096]", n_fft);
+  PCA_REQUIRE(win_length > 0 && win_length <= n_fft, "stft_logmag_batch: win_length=%d",
+              win_length);
+  PCA_REQUIRE(hop > 0, "stft_logmag_batch: hop=%d", hop);
+  PCA_REQUIRE(n_bins > 0 && n_bins <= n_fft / 2 + 1, "stft_logmag_batch: n_bins=%d", n_bins);
+  PCA_REQUIRE(min_len > n_fft / 2 && max_len >= min_len,
+              "stft_logmag_batch: reflect padding needs every clip longer than n_fft/2 "
+              "(shortest %lld, longest %lld)", (long long)min_len, (long long)max_len);
+  int log2n = 0;
+  while ((1 << log2n) < n_fft) ++log2n;
+  const int64_t T = pca_stft_num_frames(max_len, hop);
+  const size_t lds = ((size_t)n_fft + n_fft / 2) * sizeof(double2);
+  static std::once_flag lds_once;
+  std::call_once(lds_once, [] {
+    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(pca::k_stft_logmag),
+                              hipFuncAttributeMaxDynamicSharedMemorySize, 96 * 1024);
+  });
+  hipLaunchKernelGGL(pca::k_stft_logmag, dim3((unsigned)T, (unsigned)n_clips), dim3(256), lds,
+                     pca::as_stream(stream), waves, (int64_t)0, n_fft, log2n, win_length, hop,
+                     n_bins, out, stride_f, stride_t, wave_off, frame_off);
+  return pca::check_launch("k_stft_logmag(batch)");
 }
 
 int pca_pack_points_2d(const float* spec, int64_t stride_f, int64_t stride_t,

@@ -310,6 +310,44 @@ def stft_logmag(wave: torch.Tensor, n_fft: int, win_length: Optional[int] = None
     return out
 
 
+def stft_logmag_batch(waves, n_fft: int, win_length: Optional[int] = None,
+                      hop: Optional[int] = None, drop_nyquist: bool = False,
+                      frame_major: bool = False):
+    """log(1e-8 + |stft|/n_fft) of a list of 1-D float32 device waveforms in ONE launch.
+    Returns (spec, frame_off): spec is [F, T_total] (or [T_total, F] with frame_major), clip c
+    occupies columns (rows) frame_off[c] : frame_off[c + 1]; each clip's block is bit-identical
+    to stft_logmag(clip)."""
+    assert len(waves) > 0
+    _need_cuda(*waves)
+    dev = waves[0].device
+    win_length = n_fft if win_length is None else win_length
+    hop = n_fft // 2 if hop is None else hop
+    lens = [int(w.numel()) for w in waves]
+    frames = [1 + n // hop for n in lens]
+    woff = [0]
+    foff = [0]
+    for n, t in zip(lens, frames):
+        woff.append(woff[-1] + n)
+        foff.append(foff[-1] + t)
+    T = foff[-1]
+    F = n_fft // 2 if drop_nyquist else n_fft // 2 + 1
+    L = lib()
+    with torch.cuda.device(dev):
+        cat = torch.cat([_f32c(w).reshape(-1) for w in waves])
+        woff_d = torch.tensor(woff, dtype=torch.int64, device=dev)
+        foff_d = torch.tensor(foff, dtype=torch.int64, device=dev)
+        if frame_major:
+            out = torch.empty((T, F), dtype=torch.float32, device=dev)
+            sf, st = 1, F
+        else:
+            out = torch.empty((F, T), dtype=torch.float32, device=dev)
+            sf, st = T, 1
+        check(L.pca_stft_logmag_batch(_ptr(cat), _ptr(woff_d), _ptr(foff_d), len(waves),
+                                      max(lens), min(lens), n_fft, win_length, hop, F, _ptr(out),
+                                      sf, st, _stream(cat)), "pca_stft_logmag_batch")
+    return out, foff
+
+
 def pack_points_2d(spec: torch.Tensor, farr: torch.Tensor, idx: torch.Tensor,
                    labels: Optional[torch.Tensor] = None, frame_major: bool = False,
                    out: Optional[torch.Tensor] = None, labels_out: Optional[torch.Tensor] = None

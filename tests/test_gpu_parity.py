@@ -264,6 +264,27 @@ def test_stft_logmag_vs_oracle(dev):
             assert np.max(np.abs(a - ref)) < 5e-5, (n_fft, float(np.max(np.abs(a - ref))))
 
 
+def test_stft_logmag_batch_equals_per_clip(dev):
+    """pca_stft_logmag_batch (a corpus in one launch, clips of different lengths) is bit-identical,
+    clip by clip, to pca_stft_logmag, in both output layouts."""
+    import pca_hip
+    from oracle import st_oracle as orc
+    secs = (0.5, 0.11, 0.37, 0.05, 0.5)
+    waves = [T(orc.synth_clip(20 + i, 3 * i, seconds=s), dev) for i, s in enumerate(secs)]
+    for n_fft, win, drop in ((1024, 1024, True), (256, 200, False), (2048, 2048, False)):
+        hop = n_fft // 2
+        for fm in (False, True):
+            spec, off = pca_hip.stft_logmag_batch(waves, n_fft, win, hop, drop_nyquist=drop,
+                                                  frame_major=fm)
+            assert off[-1] == (spec.shape[0] if fm else spec.shape[1])
+            for c, w in enumerate(waves):
+                one = pca_hip.stft_logmag(w, n_fft, win, hop, drop_nyquist=drop, frame_major=fm)
+                got = spec[off[c]:off[c + 1]] if fm else spec[:, off[c]:off[c + 1]]
+                assert torch.equal(got, one), (n_fft, fm, c)
+    with pytest.raises(pca_hip.PcaHipError):      # a clip shorter than the reflect padding
+        pca_hip.stft_logmag_batch([waves[0], waves[0][:100]], 1024)
+
+
 # ----------------------------------------------------------------------------- #
 # loss / optimiser / training trajectory                                         #
 # ----------------------------------------------------------------------------- #
