@@ -97,13 +97,15 @@ def build_dataset(cfg, n_clips, dev, seed):
             np.random.Generator(np.random.PCG64(77 + i)).uniform(1.0, 4.0))
         waves.append(torch.from_numpy(synth_clip(seed * 100000 + i, cls, seconds=secs)).to(dev))
         classes.append(cls)
-    # the whole corpus through ONE launch of the STFT kernel (round 2 launched it per clip)
-    torch.cuda.synchronize(dev)
-    t0 = time.perf_counter()
-    spec_all, foff = pca_hip.stft_logmag_batch(waves, n_fft, n_fft, hop, drop_nyquist=drop,
-                                               frame_major=True)
-    torch.cuda.synchronize(dev)
-    t_stft = time.perf_counter() - t0
+    # the whole corpus through ONE launch of the STFT kernel (round 2 launched it per clip); timed
+    # on the second call (the first pays the one-time costs of the kernel's first launch)
+    for _ in range(2):
+        torch.cuda.synchronize(dev)
+        t0 = time.perf_counter()
+        spec_all, foff = pca_hip.stft_logmag_batch(waves, n_fft, n_fft, hop, drop_nyquist=drop,
+                                                   frame_major=True)
+        torch.cuda.synchronize(dev)
+        t_stft = time.perf_counter() - t0
     specs, labels = [], []
     for i, cls in enumerate(classes):
         s = spec_all[foff[i]:foff[i + 1]]

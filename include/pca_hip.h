@@ -118,6 +118,13 @@ int pca_pack_points_2d_seq(const float* spec, int64_t stride_f, int64_t stride_t
                            const float* farr, const int64_t* idx_seq, const int32_t* step_dev,
                            const int32_t* base_dev, int B, int F, float* out,
                            const int64_t* labels, int64_t* labels_out, void* stream);
+/* Deferred packing (no reference counterpart).  While armed on the calling thread, the cursor
+ * packs above (pca_pack_points_2d_seq / _3d_seq) are not launched but handed to the next
+ * pca_st_forward / pca_st_train_fwd_bwd call of the same thread and stream, which runs them as extra
+ * workgroup rows of its first launch (the parameter-only preparation k_prep_all) or, where it has
+ * no such launch, on their own before anything reads X.  Results are those of the plain call.
+ * pca_pack_defer(0) fails if a deferred pack was never consumed. */
+int pca_pack_defer(int on);
 /* 3-D counterpart; nt_valid / lengths_out as in pca_pack_points_3d_var, or both NULL. */
 int pca_pack_points_3d_seq(const float* spec, int64_t stride_f, int64_t stride_t,
                            int64_t stride_s, const float* farr, const float* tarr,

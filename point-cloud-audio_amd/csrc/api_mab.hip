@@ -16,7 +16,8 @@ static int check_f32(const pca_mab_shape* s, bool inference) {
 
 // ---- mode resolution + dispatch, shared by the C entry points and the ST engine ----
 // kind: 0 = exact fp32 chain of GEMMs, 1 = fused bf16 mab1 (many queries, few keys),
-//       2 = fused bf16 mab0 (few shared queries, many keys)
+//       2 = fused bf16 mab0 (few shared queries, many keys),
+//       3 = the shipped d = 64 / 8-head shape, fused fp32 forward (inference only: sd64_fwd.hip)
 int mab_kind(const pca_mab_shape& s, bool inference) {
   // (a fused mab1 has the m inducing-point outputs as keys: always all of them; a caller that
   // masks keys of such a shape gets the exact path, whose softmax honours k_lengths)
@@ -24,6 +25,7 @@ int mab_kind(const pca_mab_shape& s, bool inference) {
   const bool fused_mode = s.mode == PCA_MODE_BF16 || s.mode == PCA_MODE_FP8;
   if (fused_mode && s.k_lengths == nullptr && mab1_bf16_supported(s, inference)) return 1;
   if (fused_mode && mab0_bf16_supported(s)) return 2;
+  if (fused_mode && inference && sd64_kind(s) != 0) return 3;
   return 0;
 }
 size_t mab_saved_bytes_any(const pca_mab_shape& s) {
@@ -36,7 +38,8 @@ size_t mab_fwd_ws_bytes_any(const pca_mab_shape& s) {
   // forward of the same shape never needs more (the exact chain's scratch is its saved block)
   const int k = mab_kind(s, true);
   if (k != mab_kind(s, false)) {
-    const size_t a = k == 1 ? mab1_bf16_fwd_ws_bytes(s) : mab0_bf16_fwd_ws_bytes(s);
+    const size_t a = k == 3 ? sd64_fwd_ws_bytes(s)
+                            : k == 1 ? mab1_bf16_fwd_ws_bytes(s) : mab0_bf16_fwd_ws_bytes(s);
     const size_t b = mab_f32_saved_bytes(s);
     return a > b ? a : b;
   }
@@ -51,6 +54,7 @@ size_t mab_bwd_ws_bytes_any(const pca_mab_shape& s) {
 int mab_fwd_any(const pca_mab_shape& s, const void* Q, const void* K, const pca_mab_params& p,
                 void* Y, void* saved, void* ws, hipStream_t st) {
   const int k = mab_kind(s, saved == nullptr);
+  if (k == 3) return sd64_fwd(s, (const float*)Q, (const float*)K, p, (float*)Y, ws, st);
   if (k == 1) return mab1_bf16_fwd(s, Q, (const float*)K, p, Y, saved, ws, st);
   if (k == 2) return mab0_bf16_fwd(s, (const float*)Q, K, p, (float*)Y, saved, ws, st);
   return mab_f32_fwd(s, (const float*)Q, (const float*)K, p, (float*)Y, saved ? saved : ws, st);

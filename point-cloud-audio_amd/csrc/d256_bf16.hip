@@ -1194,6 +1194,149 @@ __global__ __launch_bounds__(512, 2) void k_wgrad256(const Wgrad256Jobs jobs, in
   }
 }
 
+// Round 3: the bf16 jobs with the operand tiles streamed by LDS-DMA into a ring of four (G, A) tile
+// pairs (128 KiB), three pairs ahead.  k_wgrad256 above keeps two 32-row tiles in registers per
+// thread - 64 KiB in flight per CU, and 3.0 TB/s is what that bought by Little's law at the
+// latency this streaming pattern sees; its MFMA work would sustain 16 TB/s.  Here 96 KiB are in
+// flight, nothing is staged through registers, and the barrier per tile only publishes pieces
+// that have already landed.  A 1 KiB piece of the transposed-read layout is 4 rows x 256 bytes
+// of one [32][128] half: LDS is written linearly, so lane l fetches chunk (l & 15) ^ s(row) of row
+// 4 p + (l >> 4) - the swizzle is an involution, the permutation moves to the source side.
+__global__ __launch_bounds__(512, 2) void k_wgrad256_dma(const Wgrad256Jobs jobs, int rows_per_wg,
+                                                        float* __restrict__ slabs,
+                                                        float* __restrict__ bslabs) {
+  constexpr int D = 256, TB = 32 * D * 2, NB = 4, PD = NB - 1;
+  extern __shared__ __attribute__((aligned(16))) char lds[];    // [NB][G tile | A tile]
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int r = lane & 15, g = lane >> 4;
+  const int nwg = gridDim.x / jobs.n;
+  int bx, by;
+  if (nwg % 8 == 0 && rows_per_wg < 0) {
+    const int g8 = blockIdx.x >> 3, l8 = blockIdx.x & 7;
+    by = g8 % jobs.n;
+    bx = (g8 / jobs.n) * 8 + l8;
+  } else {
+    by = blockIdx.x / nwg;
+    bx = blockIdx.x - by * nwg;
+  }
+  const Wgrad256Job job = jobs.j[by];
+  const char* G = reinterpret_cast<const char*>(job.G);
+  const char* A = reinterpret_cast<const char*>(job.A);
+  const int64_t r0 = (int64_t)bx * 64, r1 = job.M, stride = (int64_t)nwg * 64;
+  // tiles of this workgroup: 64-row blocks dealt round-robin, two 32-row tiles per block
+  const int64_t nblk = r0 < r1 ? (r1 - r0 + stride - 1) / stride : 0;
+  const int ntile = (int)(2 * nblk);
+  auto tile_row = [&](int t) { return r0 + (int64_t)(t >> 1) * stride + 32 * (t & 1); };
+  const int gt0 = 4 * (wave >> 1), at0 = 8 * (wave & 1);
+  f32x4 acc[4][8];
+#pragma unroll
+  for (int i = 0; i < 4; ++i)
+#pragma unroll
+    for (int t = 0; t < 8; ++t) acc[i][t] = f32x4{0.f, 0.f, 0.f, 0.f};
+  float bs[8] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+  // this wave's four pieces of a tile pair: pieces 2 wave, 2 wave + 1 of G and of A (piece p:
+  // half p >> 3, rows 4 (p & 7) ..); per lane the row inside the tile and the source byte offset
+  int prow[2], poff[2];
+#pragma unroll
+  for (int e = 0; e < 2; ++e) {
+    const int p = 2 * wave + e, half = p >> 3, row = 4 * (p & 7) + (lane >> 4);
+    const int sw = ((row & 3) << 2) | ((row >> 2) & 3);
+    prow[e] = row;
+    poff[e] = half * 256 + (((lane & 15) ^ sw) << 4);
+  }
+  auto dma = [&](int t) {
+    const int64_t base = tile_row(t);
+    char* dst = lds + (t % NB) * 2 * TB;
+#pragma unroll
+    for (int op = 0; op < 2; ++op)
+#pragma unroll
+      for (int e = 0; e < 2; ++e) {
+        int64_t row = base + prow[e];
+        row = row < r1 ? row : r1 - 1;                 // rows past the end: a valid line (zeroed below)
+        const char* src = (op == 0 ? G : A) + row * (D * 2) + poff[e];
+        const unsigned ldst = __builtin_amdgcn_readfirstlane(
+            (unsigned)(uintptr_t)(lds_void_t*)(dst + op * TB + (2 * wave + e) * 1024));
+        unsigned keep;
+        asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %2\n\ts_nop 0\n\t"
+                     "global_load_lds_dwordx4 %1, off\n\ts_mov_b32 m0, %0"
+                     : "=&s"(keep) : "v"(src), "s"(ldst) : "memory");
+      }
+  };
+#pragma unroll 1
+  for (int t = 0; t < PD && t < ntile; ++t) dma(t);
+#pragma unroll 1
+  for (int t = 0; t < ntile; ++t) {
+    // tile t has landed when at most the pieces of the (up to PD - 1) tiles behind it are pending
+    {
+      const int ahead = (ntile - 1 - t) < (PD - 1) ? (ntile - 1 - t) : (PD - 1);
+      if (ahead >= 2) asm volatile("s_waitcnt vmcnt(8)" ::: "memory");
+      else if (ahead == 1) asm volatile("s_waitcnt vmcnt(4)" ::: "memory");
+      else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    }
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+    __builtin_amdgcn_s_barrier();                      // every wave's pieces; tile t - 1 consumed
+    asm volatile("" ::: "memory");
+    if (t + PD < ntile) dma(t + PD);                   // into the buffer tile t - 1 just left
+    char* sG = lds + (t % NB) * 2 * TB;
+    char* sA = sG + TB;
+    const int64_t base = tile_row(t);
+    if (base + 32 > r1) {                              // (uniform; the last tile of the job only)
+      const int c0 = tid, row0 = c0 >> 5;              // rows past the end contribute nothing
+#pragma unroll
+      for (int e = 0; e < 2; ++e) {
+        const int c = tid + e * 512, row = c >> 5, ch = c & 31;
+        if (base + row >= r1) *reinterpret_cast<uint4*>(sG + tr_off256(row, ch)) = uint4{0u, 0u, 0u, 0u};
+      }
+      (void)row0;
+      asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+      __builtin_amdgcn_s_barrier();
+      asm volatile("" ::: "memory");
+    }
+    if (job.db != nullptr) {
+#pragma unroll
+      for (int e = 0; e < 2; ++e) {
+        const int c = tid + e * 512, row = c >> 5, ch = c & 31;
+        const bf16x8 gv = *reinterpret_cast<const bf16x8*>(sG + tr_off256(row, ch));
+#pragma unroll
+        for (int k = 0; k < 8; ++k) bs[k] += (float)gv[k];
+      }
+    }
+    bf16x8 ga[4];
+#pragma unroll
+    for (int i = 0; i < 4; ++i) ga[i] = tr_frag256(sG, gt0 + i, lane);
+#pragma unroll
+    for (int tt = 0; tt < 8; ++tt) {
+      const bf16x8 ab = tr_frag256(sA, at0 + tt, lane);
+#pragma unroll
+      for (int i = 0; i < 4; ++i) acc[i][tt] = mfma32(ga[i], ab, acc[i][tt]);
+    }
+  }
+  float* slab = slabs + (int64_t)by * D * nwg * D + (int64_t)bx * D;
+#pragma unroll
+  for (int i = 0; i < 4; ++i)
+#pragma unroll
+    for (int e = 0; e < 4; ++e) {
+      const int grow = 16 * (gt0 + i) + 4 * g + e;
+#pragma unroll
+      for (int t = 0; t < 8; ++t)
+        slab[(int64_t)grow * nwg * D + 16 * (at0 + t) + r] = acc[i][t][e];
+    }
+  if (job.db != nullptr) {
+    __syncthreads();
+    float* red = reinterpret_cast<float*>(lds);             // [16][256]
+#pragma unroll
+    for (int k = 0; k < 8; ++k) red[(tid >> 5) * D + (tid & 31) * 8 + k] = bs[k];
+    __syncthreads();
+    if (tid < D) {
+      float t = 0.f;
+#pragma unroll
+      for (int q = 0; q < 16; ++q) t += red[q * D + tid];
+      bslabs[((int64_t)by * nwg + bx) * D + tid] = t;
+    }
+  }
+}
+
 __global__ __launch_bounds__(256) void k_wgrad256_sum(const Wgrad256Jobs jobs, int nwg,
                                                      int rows_per_wg,
                                                      const float* __restrict__ slabs,
@@ -3119,12 +3262,23 @@ int wgrad256_launch_t(const Wgrad256Jobs& jobs, void* ws, bool f32_operands, hip
   const double opbytes = shared ? eb * 256 * (rows + (double)jobs.j[0].M) : 2.0 * eb * 256 * rows;
   ProfScope ps(PCA_K_WGRAD, st, 2.0 * rows * 256 * 256, opbytes);
   if (shared) rpw = -rpw;
-  if (f32_operands)
+  // PCA_WGRAD256_DMA=0: the register-staged kernel for the bf16 jobs too (A/B measurements)
+  static const bool use_dma = [] { const char* e = getenv("PCA_WGRAD256_DMA"); return !(e && e[0] == '0'); }();
+  if (f32_operands) {
     hipLaunchKernelGGL(k_wgrad256<float>, dim3(nwg * jobs.n), dim3(512), 0, st, jobs, rpw, slabs,
                        bslabs);
-  else
+  } else if (use_dma) {
+    static std::once_flag once;
+    std::call_once(once, [] {
+      (void)hipFuncSetAttribute(reinterpret_cast<const void*>(k_wgrad256_dma),
+                                hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+    });
+    hipLaunchKernelGGL(k_wgrad256_dma, dim3(nwg * jobs.n), dim3(512), (size_t)4 * 2 * 32 * 256 * 2,
+                       st, jobs, rpw, slabs, bslabs);
+  } else {
     hipLaunchKernelGGL(k_wgrad256<__bf16>, dim3(nwg * jobs.n), dim3(512), 0, st, jobs, rpw, slabs,
                        bslabs);
+  }
   ps.end();
   PCA_TRY(check_launch("k_wgrad256"));
   hipLaunchKernelGGL(k_wgrad256_sum, dim3((256 * 256 + 256 + 255) / 256, jobs.n), dim3(256), 0, st,

@@ -448,7 +448,7 @@ __global__ __launch_bounds__(512, 2) void k_isab1_fwd256(const FusedFwdArgs a) {
 #define AB_STAMP(i)                                                                               \
   do {                                                                                            \
     __builtin_amdgcn_sched_barrier(0);                                                            \
-    if (blockIdx.x == 0 && k < 32) {                                                              \
+    if (blockIdx.x == 0 && k < 32 && ((i) == 0 || stamp_sel == 15 || stamp_sel == (i))) {                                                           \
       const long long t_ = (long long)__builtin_readcyclecounter();                               \
       if (lane == 0) sStamp[(wv * 32 + k) * 8 + (i)] = (unsigned)t_;                                     \
     }                                                                                             \
@@ -466,7 +466,7 @@ __global__ __launch_bounds__(1024) void k_isab1_fwd256_ab(const FusedFwdArgs a) 
   // 1 no softmax arithmetic, 2 no epilogue arithmetic, 4 no barrier, 8 no LDS-DMA, 16 no Y stores,
   // 32 no GEMM1, 64 no GEMM2
 #ifdef PCA_FWD_ABLATE
-  const int abl = a.ablate;
+  const int abl = a.ablate & 0xffff;
 #else
   constexpr int abl = 0;
 #endif
@@ -491,6 +491,9 @@ __global__ __launch_bounds__(1024) void k_isab1_fwd256_ab(const FusedFwdArgs a) 
   const int wv = __builtin_amdgcn_readfirstlane(tid >> 6);
   const int role = wv >> 3, j = wv & 7;     // (waves w, w + 4, w + 8, w + 12 share a SIMD)
 #ifdef PCA_FWD_STAMPS
+  // (PCA_AB_STAMPSEL = 1 .. 6: only stamp 0 and that one are taken - a stamp costs ~280 cycles,
+  //  seven of them per iteration distort what they measure; 15 = all)
+  const int stamp_sel = a.ablate >> 16;
   unsigned* sStamp = reinterpret_cast<unsigned*>(sBias + 4 * D);
   for (int i = tid; i < 16 * 32 * 8; i += 1024) sStamp[i] = 0;
 #endif
@@ -952,7 +955,8 @@ int isab1_fwd256_fused(const void* X, int dq, const __bf16* WqB, const float* Wq
   a.B = B; a.N = N; a.dq = dq;
   a.tiles_per_set = (int)cdiv(N, P);
   a.scale_log2e = 1.4426950408889634f / sqrtf((float)D);
-  a.ablate = getenv("PCA_AB_ABLATE") ? atoi(getenv("PCA_AB_ABLATE")) : 0;
+  a.ablate = (getenv("PCA_AB_ABLATE") ? atoi(getenv("PCA_AB_ABLATE")) : 0) |
+             ((getenv("PCA_AB_STAMPSEL") ? atoi(getenv("PCA_AB_STAMPSEL")) : 15) << 16);
   const int total = B * a.tiles_per_set;
   int grid = total < 256 ? total : 256;
   a.units_per_wg = (int)cdiv(total, grid);

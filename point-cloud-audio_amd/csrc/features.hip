@@ -7,6 +7,7 @@
 // The reference does this per item in Python/numpy on the host (45.6 us / 331 us per set);
 // here the spectrogram stays resident in HBM and a batch is assembled by one launch.
 #include "pca_common.h"
+#include "pack_body.hpp"
 
 #include <mutex>
 
@@ -93,67 +94,50 @@ __global__ __launch_bounds__(256) void k_stft_logmag(const float* __restrict__ w
   }
 }
 
-__global__ __launch_bounds__(256) void k_pack_2d(const float* __restrict__ spec,
-                                                  int64_t stride_f, int64_t stride_t,
-                                                  const float* __restrict__ farr,
-                                                  const int64_t* __restrict__ idx, int F,
-                                                  float* __restrict__ out,
-                                                  const int64_t* __restrict__ labels,
-                                                  int64_t* __restrict__ labels_out,
-                                                  const int32_t* __restrict__ step_dev,
-                                                  const int32_t* __restrict__ base_dev) {
-  const int b = blockIdx.y;
-  // device cursor: batch number (step - base) of a pre-staged index sequence, so that a
-  // captured step needs no per-step index upload
-  if (step_dev != nullptr) idx += (int64_t)(step_dev[0] - base_dev[0]) * gridDim.y;
-  const int64_t frame = idx[b];
-  if (labels != nullptr && labels_out != nullptr && blockIdx.x == 0 && threadIdx.x == 0)
-    labels_out[b] = labels[frame];
-  const int f = blockIdx.x * 256 + threadIdx.x;
-  if (f >= F) return;
-  float2 p;
-  p.x = farr[f];
-  p.y = spec[f * stride_f + frame * stride_t];
-  reinterpret_cast<float2*>(out)[(int64_t)b * F + f] = p;
+__global__ __launch_bounds__(256) void k_pack(const PackJob a) {
+  pack_body(a, blockIdx.y * a.bx + blockIdx.x);
 }
 
-__global__ __launch_bounds__(256) void k_pack_3d(const float* __restrict__ spec,
-                                                  int64_t stride_f, int64_t stride_t,
-                                                  int64_t stride_s,
-                                                  const float* __restrict__ farr,
-                                                  const float* __restrict__ tarr,
-                                                  const int64_t* __restrict__ idx, int F,
-                                                  int Nt, float* __restrict__ out,
-                                                  const int64_t* __restrict__ labels,
-                                                  int64_t* __restrict__ labels_out,
-                                                  const int32_t* __restrict__ nt_valid,
-                                                  int32_t* __restrict__ lengths_out,
-                                                  const int32_t* __restrict__ step_dev,
-                                                  const int32_t* __restrict__ base_dev) {
-  const int b = blockIdx.y;
-  if (step_dev != nullptr) idx += (int64_t)(step_dev[0] - base_dev[0]) * gridDim.y;
-  const int64_t chunk = idx[b];
-  // variable-size sets: chunk s holds nt_valid[s] <= Nt frames; time-major point order makes
-  // its points a prefix of the padded set, the padding rows are written as zeros
-  const int nt = nt_valid != nullptr ? (nt_valid[chunk] < Nt ? nt_valid[chunk] : Nt) : Nt;
-  if (blockIdx.x == 0 && threadIdx.x == 0) {
-    if (labels != nullptr && labels_out != nullptr) labels_out[b] = labels[chunk];
-    if (lengths_out != nullptr) lengths_out[b] = nt * F;
+thread_local bool t_pack_armed = false;
+thread_local PackJob t_pack_pending{};
+
+int pack_launch(const PackJob& j, hipStream_t st) {
+  hipLaunchKernelGGL(k_pack, dim3((unsigned)j.bx, (unsigned)j.B), dim3(256), 0, st, j);
+  return check_launch(j.kind == 2 ? "k_pack_2d" : "k_pack_3d");
+}
+// armed: remember the pack for the next k_prep_all launch of this thread instead of launching it
+int pack_submit(const PackJob& j, hipStream_t st) {
+  if (t_pack_armed) {
+    if (t_pack_pending.kind != 0) PCA_TRY(pack_launch(t_pack_pending, st));   // (never two pending)
+    t_pack_pending = j;
+    return PCA_OK;
   }
-  const int p = blockIdx.x * 256 + threadIdx.x;      // point index = t*F + f (time-major)
-  if (p >= F * Nt) return;
-  const int t = p / F, f = p - t * F;
-  float* o = out + ((int64_t)b * F * Nt + p) * 3;
-  const bool ok = t < nt;
-  o[0] = ok ? farr[f] : 0.f;
-  o[1] = ok ? tarr[t] : 0.f;
-  o[2] = ok ? spec[f * stride_f + t * stride_t + chunk * stride_s] : 0.f;
+  return pack_launch(j, st);
 }
 
 }  // namespace
+
+bool pack_take(PackJob* out) {
+  if (t_pack_pending.kind == 0) return false;
+  *out = t_pack_pending;
+  t_pack_pending.kind = 0;
+  return true;
+}
+int pack_flush(hipStream_t st) {
+  PackJob j;
+  return pack_take(&j) ? pack_launch(j, st) : PCA_OK;
+}
 }  // namespace pca
 
 extern "C" {
+
+int pca_pack_defer(int on) {
+  PCA_REQUIRE(on != 0 || pca::t_pack_pending.kind == 0,
+              "pack_defer(0): a deferred pack was never consumed (no engine call followed it)");
+  pca::t_pack_armed = on != 0;
+  return PCA_OK;
+}
+
 
 int64_t pca_stft_num_frames(int64_t L, int hop) { return hop > 0 ? 1 + L / hop : 0; }
 
@@ -227,10 +211,14 @@ int pca_pack_points_2d_seq(const float* spec, int64_t stride_f, int64_t stride_t
   PCA_REQUIRE(spec && farr && idx_seq && out, "pack_points_2d: null pointer");
   PCA_REQUIRE((step_dev == nullptr) == (base_dev == nullptr), "pack_points_2d: cursor needs both");
   PCA_REQUIRE(B > 0 && F > 0 && B <= 65535, "pack_points_2d: B=%d F=%d", B, F);
-  hipLaunchKernelGGL(pca::k_pack_2d, dim3((unsigned)pca::cdiv(F, 256), (unsigned)B),
-                     dim3(256), 0, pca::as_stream(stream), spec, stride_f, stride_t, farr,
-                     idx_seq, F, out, labels, labels_out, step_dev, base_dev);
-  return pca::check_launch("k_pack_2d");
+  pca::PackJob j{};
+  j.kind = 2; j.spec = spec; j.stride_f = stride_f; j.stride_t = stride_t; j.farr = farr;
+  j.idx = idx_seq; j.step_dev = step_dev; j.base_dev = base_dev; j.labels = labels;
+  j.labels_out = labels_out; j.out = out; j.B = B; j.F = F; j.Nt = 1;
+  j.bx = (int)pca::cdiv(F, 256);
+  // (only the cursor form is deferred: it is the one a captured training step issues)
+  return step_dev != nullptr ? pca::pack_submit(j, pca::as_stream(stream))
+                             : pca::pack_launch(j, pca::as_stream(stream));
 }
 
 int pca_pack_points_3d(const float* spec, int64_t stride_f, int64_t stride_t,
@@ -240,12 +228,13 @@ int pca_pack_points_3d(const float* spec, int64_t stride_f, int64_t stride_t,
   PCA_REQUIRE(spec && farr && tarr && idx && out, "pack_points_3d: null pointer");
   PCA_REQUIRE(B > 0 && F > 0 && Nt > 0 && B <= 65535, "pack_points_3d: B=%d F=%d Nt=%d", B,
               F, Nt);
-  hipLaunchKernelGGL(pca::k_pack_3d,
-                     dim3((unsigned)pca::cdiv((int64_t)F * Nt, 256), (unsigned)B), dim3(256),
-                     0, pca::as_stream(stream), spec, stride_f, stride_t, stride_s, farr,
-                     tarr, idx, F, Nt, out, labels, labels_out, nullptr, nullptr, nullptr,
-                     nullptr);
-  return pca::check_launch("k_pack_3d");
+  pca::PackJob j{};
+  j.kind = 3; j.spec = spec; j.stride_f = stride_f; j.stride_t = stride_t; j.stride_s = stride_s;
+  j.farr = farr; j.tarr = tarr; j.idx = idx; j.step_dev = nullptr; j.base_dev = nullptr;
+  j.nt_valid = nullptr; j.lengths_out = nullptr; j.labels = labels; j.labels_out = labels_out;
+  j.out = out; j.B = B; j.F = F; j.Nt = Nt;
+  j.bx = (int)pca::cdiv((int64_t)F * Nt, 256);
+  return pca::pack_launch(j, pca::as_stream(stream));
 }
 
 int pca_pack_points_3d_seq(const float* spec, int64_t stride_f, int64_t stride_t,
@@ -260,12 +249,13 @@ int pca_pack_points_3d_seq(const float* spec, int64_t stride_f, int64_t stride_t
               "pack_points_3d_seq: nt_valid and lengths_out go together");
   PCA_REQUIRE(B > 0 && F > 0 && Nt > 0 && B <= 65535, "pack_points_3d_seq: B=%d F=%d Nt=%d", B,
               F, Nt);
-  hipLaunchKernelGGL(pca::k_pack_3d,
-                     dim3((unsigned)pca::cdiv((int64_t)F * Nt, 256), (unsigned)B), dim3(256),
-                     0, pca::as_stream(stream), spec, stride_f, stride_t, stride_s, farr,
-                     tarr, idx_seq, F, Nt, out, labels, labels_out, nt_valid, lengths_out,
-                     step_dev, base_dev);
-  return pca::check_launch("k_pack_3d");
+  pca::PackJob j{};
+  j.kind = 3; j.spec = spec; j.stride_f = stride_f; j.stride_t = stride_t; j.stride_s = stride_s;
+  j.farr = farr; j.tarr = tarr; j.idx = idx_seq; j.step_dev = step_dev; j.base_dev = base_dev;
+  j.nt_valid = nt_valid; j.lengths_out = lengths_out; j.labels = labels; j.labels_out = labels_out;
+  j.out = out; j.B = B; j.F = F; j.Nt = Nt;
+  j.bx = (int)pca::cdiv((int64_t)F * Nt, 256);
+  return pca::pack_submit(j, pca::as_stream(stream));
 }
 
 int pca_pack_points_3d_var(const float* spec, int64_t stride_f, int64_t stride_t,
@@ -277,11 +267,12 @@ int pca_pack_points_3d_var(const float* spec, int64_t stride_f, int64_t stride_t
               "pack_points_3d_var: null pointer");
   PCA_REQUIRE(B > 0 && F > 0 && Nt > 0 && B <= 65535, "pack_points_3d_var: B=%d F=%d Nt=%d",
               B, F, Nt);
-  hipLaunchKernelGGL(pca::k_pack_3d,
-                     dim3((unsigned)pca::cdiv((int64_t)F * Nt, 256), (unsigned)B), dim3(256),
-                     0, pca::as_stream(stream), spec, stride_f, stride_t, stride_s, farr,
-                     tarr, idx, F, Nt, out, labels, labels_out, nt_valid, lengths_out, nullptr,
-                     nullptr);
-  return pca::check_launch("k_pack_3d");
+  pca::PackJob j{};
+  j.kind = 3; j.spec = spec; j.stride_f = stride_f; j.stride_t = stride_t; j.stride_s = stride_s;
+  j.farr = farr; j.tarr = tarr; j.idx = idx; j.step_dev = nullptr; j.base_dev = nullptr;
+  j.nt_valid = nt_valid; j.lengths_out = lengths_out; j.labels = labels; j.labels_out = labels_out;
+  j.out = out; j.B = B; j.F = F; j.Nt = Nt;
+  j.bx = (int)pca::cdiv((int64_t)F * Nt, 256);
+  return pca::pack_launch(j, pca::as_stream(stream));
 }
 }

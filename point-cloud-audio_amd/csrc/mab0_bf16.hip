@@ -23,6 +23,7 @@
 //                 set shared by two workgroups
 //   k_mab0_epi    per set: O, Z, H (fp32 VALU; 2*m*d*(dk+d) MACs)
 #include "mab1_bf16.hpp"
+#include "pack_body.hpp"
 #include "pma_head_bodies.hpp"
 
 #include <math.h>
@@ -65,9 +66,16 @@ __global__ __launch_bounds__(256) void k_mab0_prep(const Mab0PrepJobs jobs) {
 }
 
 // weight images (as k_prep_jobs, mab1_bf16.hip) and query-side tensors in one grid:
-// rows [0, Q.n) of blockIdx.y are query-side jobs, the rest weight-image jobs
-__global__ __launch_bounds__(256) void k_prep_all(const PrepJobs W, const Mab0PrepJobs Q) {
+// rows [0, Q.n) of blockIdx.y are query-side jobs, then the weight-image jobs, then (rider rows)
+// the step's deferred point-set pack - independent of everything else in this launch
+__global__ __launch_bounds__(256) void k_prep_all(const PrepJobs W, const Mab0PrepJobs Q,
+                                                  const PackJob P) {
   extern __shared__ float sq[];
+  if ((int)blockIdx.y >= Q.n + W.n) {
+    const int blk = ((int)blockIdx.y - Q.n - W.n) * gridDim.x + blockIdx.x;
+    if (blk < P.bx * P.B) pack_body(P, blk);
+    return;
+  }
   if ((int)blockIdx.y < Q.n) {
     mab0_prep_body(Q.j[blockIdx.y], sq, blockIdx.x);
     return;
@@ -814,7 +822,10 @@ int prep_all_launch(const PrepJobs& W, const Mab0PrepJobs& Q, hipStream_t st) {
   int gx = maxm + (spare ? PREP_SPARE : 0);
   const int gw = (int)cdiv(maxe, 256);
   gx = gx > gw ? gx : gw;
-  hipLaunchKernelGGL(k_prep_all, dim3(gx, Q.n + W.n), dim3(256), maxd * sizeof(float), st, W, Q);
+  PackJob P{};
+  const int prows = pack_take(&P) ? (int)cdiv(pack_blocks(P), gx) : 0;
+  hipLaunchKernelGGL(k_prep_all, dim3(gx, Q.n + W.n + prows), dim3(256), maxd * sizeof(float), st,
+                     W, Q, P);
   return check_launch("k_prep_all");
 }
 

@@ -250,6 +250,12 @@ int linear_dx_acc_f32(const float* dY, const float* W, float* dX, int64_t M, int
                       int accumulate, hipStream_t st);
 // fused mab1 (many queries X, few keys H).  X / Y / dY / dX are fp32 or bf16 per the shape's
 // q_dtype / y_dtype; H and dH are fp32
+// the shipped d = 64 / 8 heads / <= 64 inducing points shape: fused fp32 forward (sd64_fwd.hip);
+// kind 1 = many queries, 2 = few shared queries, 0 = another shape
+int sd64_kind(const pca_mab_shape& s);
+size_t sd64_fwd_ws_bytes(const pca_mab_shape& s);
+int sd64_fwd(const pca_mab_shape& s, const float* Q, const float* K, const pca_mab_params& p,
+             float* Y, void* ws, hipStream_t st);
 bool mab1_bf16_supported(const pca_mab_shape& s, bool inference = false);
 size_t mab1_bf16_saved_bytes(const pca_mab_shape& s);
 size_t mab1_bf16_fwd_ws_bytes(const pca_mab_shape& s);

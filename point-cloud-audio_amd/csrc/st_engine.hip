@@ -5,6 +5,7 @@
 // caller can capture the call in a hipGraph.
 #include <stdlib.h>
 #include "mab1_bf16.hpp"
+#include "pack_body.hpp"
 #include "d256_bf16.hpp"
 
 namespace pca {
@@ -281,8 +282,9 @@ int forward(const pca_st_config& c, const Layout& L, const Shapes& s, const floa
       mab0_carve_saved(s.pma, &v, w.saved[4]);
       mab0_collect_prep(s.pma, p + L.S, params_at(p, L.pma), v, true, true, &MJ);
     }
-    PCA_TRY(prep_all_launch(J, MJ, st));
+    PCA_TRY(prep_all_launch(J, MJ, st));    // (takes a deferred pack along: pca_pack_defer)
   }
+  PCA_TRY(pack_flush(st));                  // a deferred pack nobody took runs now, before X is read
   // d = 256: the query side of all three few-queries blocks in one launch (mab0_d256_prep_all)
   const bool prep256 = training && s.m0[0].d == 256 && mab_kind(s.m0[0]) == 2 &&
                        mab_kind(s.m0[1]) == 2 && mab_kind(s.pma) == 2 && !pma_head_ok(s);

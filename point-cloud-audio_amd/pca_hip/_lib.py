@@ -68,6 +68,7 @@ SIGNATURES = {
                                      c_vp]),
     "pca_pack_points_2d_seq": (C.c_int, [c_fp, C.c_int64, C.c_int64, c_fp, c_i64p, c_vp, c_vp,
                                          C.c_int, C.c_int, c_fp, c_i64p, c_i64p, c_vp]),
+    "pca_pack_defer": (C.c_int, [C.c_int]),
     "pca_pack_points_3d_seq": (C.c_int, [c_fp, C.c_int64, C.c_int64, C.c_int64, c_fp, c_fp,
                                          c_vp, c_i64p, c_vp, c_vp, C.c_int, C.c_int, C.c_int,
                                          c_fp, c_vp, c_i64p, c_i64p, c_vp]),

@@ -269,8 +269,21 @@ class Trainer:
     def _seg0(self):     # pack + zero grads + forward + loss + backward(dec, enc.1)
         if self._cursor_mode:
             kw = dict(lengths_out=self.lengths) if self.lengths is not None else {}
-            self.ds.batch_seq(self.seq, self.step_count, self.epoch_base, self.B, out=self.X,
-                              labels_out=self.labels, **kw)
+            # the pack rides in the engine's first launch (pca_pack_defer): one launch less per step
+            defer = os.environ.get("PCA_PACK_DEFER", "1") != "0"
+            if defer:
+                check(lib().pca_pack_defer(1), "pca_pack_defer")
+            try:
+                self.ds.batch_seq(self.seq, self.step_count, self.epoch_base, self.B, out=self.X,
+                                  labels_out=self.labels, **kw)
+                if self.keep_grads:
+                    self.eng.grads.zero_()
+                self.eng.fwd_bwd(self.X, self.labels, phase=0 if self._split else -1,
+                                 lengths=self.lengths)
+            finally:
+                if defer:
+                    check(lib().pca_pack_defer(0), "pca_pack_defer")
+            return
         elif self.lengths is not None:
             self.ds.batch(self.idx, out=self.X, labels_out=self.labels,
                           lengths_out=self.lengths)

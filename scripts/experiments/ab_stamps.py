@@ -31,6 +31,14 @@ out = np.zeros(16 * 32 * 16, dtype=np.int64)
 L.pca_debug_fwd_stamps.argtypes = [C.c_void_p]
 rc = L.pca_debug_fwd_stamps(out.ctypes.data)
 st = out[:16 * 32 * 8].reshape(16, 32, 8)[:, :, :7].astype(np.float64)
+sel = int(os.environ.get("PCA_AB_STAMPSEL", "15"))
+if sel != 15:       # one stamp per run: cycles from the iteration start to stamp `sel`, per wave
+    it = slice(6, 28)
+    per = np.diff(st[:, it, 0], axis=1).mean(axis=1)
+    d = ((st[:, it, sel] - st[:, it, 0]) % 2 ** 32).mean(axis=1)
+    print(f"stamp {sel}: cycles/iteration A {per[:8].mean():.0f} B {per[8:].mean():.0f}; start -> stamp: " +
+          "A " + " ".join(f"{v:.0f}" for v in d[:8]) + " | B " + " ".join(f"{v:.0f}" for v in d[8:]))
+    sys.exit(0)
 it = slice(6, 28)
 names = ["0>1 issue/stores", "1>2 GEMM(0)", "2>3 attn/epi(0)", "3>4 GEMM(1)", "4>5 attn/epi(1)", "5>6 tail", "6>0' barrier"]
 for w in range(16):

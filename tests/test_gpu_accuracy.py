@@ -43,10 +43,12 @@ def _agreement(net, ref_logits, seed, n, N, din, mode, dev, chunk=100):
     return agree / n, worst / scale
 
 
+@pytest.mark.parametrize("mode", ["f32", "bf16"])
 @pytest.mark.parametrize("tag,N,din,seed", [("fst", 1025, 2, 9000), ("3st", 5120, 3, 9500)])
-def test_shipped_weights_agreement(tag, N, din, seed, dev, golden_ckpt):
-    """Shipped FST / 3ST weights on 10 000 synthetic sets each (exact fp32 path: the shipped
-    architecture d=64, dh=8, m=64 has no fused bf16 kernels)."""
+def test_shipped_weights_agreement(tag, N, din, seed, mode, dev, golden_ckpt):
+    """Shipped FST / 3ST weights on 10 000 synthetic sets each: the exact fp32 chain, and (mode
+    bf16) the fused forward kernels of the shipped architecture d=64, dh=8, m=64
+    (csrc/sd64_fwd.hip: fp32 arithmetic on the vector ALU, so the same 1e-3 bound holds)."""
     import models
     from pca_hip import _lib
     ref = _npz("golden_agree.npz")[f"{tag}/logits"]
@@ -56,8 +58,16 @@ def test_shipped_weights_agreement(tag, N, din, seed, dev, golden_ckpt):
           for k, v in golden_ckpt.sub(("tst" if tag == "3st" else tag) + "/p/").items()}
     # (saved from a DP-wrapped model, hence the prefix)
     net.load_state_dict(sd)
-    frac, rel = _agreement(net, ref, seed, ref.shape[0], N, din, _lib.MODE_F32, dev)
-    print(f"{tag}: agreement {frac:.5f}, max|dlogit|/max|logit| {rel:.2e}")
+    md = _lib.MODE_F32 if mode == "f32" else _lib.MODE_BF16
+    if mode == "bf16":      # the fused kernels must be what serves the shape
+        import ctypes as C
+        for shp in (_lib.MabShape(100, N, 64, din, 64, 64, 8, 0, md, 0, 0, 0, None, 0),
+                    _lib.MabShape(100, 64, N, 64, din, 64, 8, 1, md, 0, 0, 0, None, 0),
+                    _lib.MabShape(100, 1, N, 64, 64, 64, 8, 1, md, 0, 0, 0, None, 0)):
+            assert _lib.lib().pca_mab_fwd_ws_bytes(C.byref(shp)) > 0, _lib.lib().pca_last_error()
+            assert _lib.lib().pca_mab_saved_bytes(C.byref(shp)) == 0     # (forward only)
+    frac, rel = _agreement(net, ref, seed, ref.shape[0], N, din, md, dev)
+    print(f"{tag} {mode}: agreement {frac:.5f}, max|dlogit|/max|logit| {rel:.2e}")
     assert ref.shape[0] >= 10000
     assert frac >= 0.998
     assert rel <= 1e-3
