@@ -452,6 +452,56 @@ def test_trainer_bf16_graph_equals_eager_bitwise(dev):
         assert torch.equal(g1[1], other[1])
 
 
+@pytest.mark.parametrize("cfgname", ["cfg2", "cfg3"])
+def test_deferred_pack_equals_own_launch(dev, cfgname, monkeypatch):
+    """pca_pack_defer: the step's point-set pack as rider rows of the engine's first launch
+    (k_prep_all) gives bit-identical parameters to the pack as a launch of its own
+    (PCA_PACK_DEFER=0), 2-D and 3-D sets, hipGraph replay; and a deferred pack that no engine call
+    consumed is reported, not dropped."""
+    import bench
+    import models
+    from pca_hip import _lib, trainer
+    cfg = dict(bench.CONFIGS[cfgname])
+    ds, _ = bench.build_dataset(cfg, 3, dev, seed=0)
+
+    def run():
+        torch.manual_seed(1)
+        net = models.ST(dim_input=cfg["din"], dim_output=cfg["C"], num_inds=cfg["m"],
+                        dim_hidden=cfg["d"], num_heads=cfg["h"]).to(dev)
+        tr = trainer.Trainer(net, ds, cfg["B"], mode=_lib.MODE_BF16, use_graph=True, seed=1)
+        for _ in range(6):
+            tr.step()
+        torch.cuda.synchronize()
+        return tr.eng.flat.clone(), tr.X.clone(), tr.labels.clone()
+
+    a = run()
+    monkeypatch.setenv("PCA_PACK_DEFER", "0")
+    b = run()
+    assert torch.isfinite(a[0]).all()
+    for x, y in zip(a, b):
+        assert torch.equal(x, y)
+    monkeypatch.delenv("PCA_PACK_DEFER")
+    # an armed, never-consumed pack must not vanish silently
+    L = _lib.lib()
+    _lib.check(L.pca_pack_defer(1))
+    idx = torch.arange(cfg["B"], device=dev)
+    step = torch.zeros(2, dtype=torch.int32, device=dev)
+    base = torch.zeros(1, dtype=torch.int32, device=dev)
+    keep = ds.batch_seq(idx, step, base, cfg["B"])      # (its outputs stay alive: the pack is pending)
+    assert L.pca_pack_defer(0) != 0
+    assert b"never consumed" in L.pca_last_error()
+    # ... and is still there for the engine call that follows
+    torch.manual_seed(1)
+    net = models.ST(dim_input=cfg["din"], dim_output=cfg["C"], num_inds=cfg["m"],
+                    dim_hidden=cfg["d"], num_heads=cfg["h"]).to(dev)
+    eng = trainer.STEngine(net, cfg["B"], ds.num_points, _lib.MODE_BF16, training=False)
+    X = torch.zeros(cfg["B"], ds.num_points, cfg["din"], device=dev)
+    eng.forward(X)
+    _lib.check(L.pca_pack_defer(0))
+    torch.cuda.synchronize()
+    assert float(keep[0].abs().max()) > 0           # the pack did run
+
+
 def test_trainer_full_size_graph_vs_eager_vs_oracle(dev):
     """BASELINE cfg2 size (B=128, N=512, d=128, h=4, m=16, C=50) on STFT-derived synthetic
     clips: (1) hipGraph replay and eager launches give the same parameters after 12 steps
