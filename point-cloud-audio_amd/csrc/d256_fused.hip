@@ -458,14 +458,14 @@ __global__ __launch_bounds__(512, 2) void k_isab1_fwd256(const FusedFwdArgs a) {
 #define AB_STAMP(i)
 #endif
 
-template <bool SMALL, bool F8O, bool TRAIN>
+template <bool SMALL, bool F8O, bool TRAIN, bool ABREAST = false>
 __global__ __launch_bounds__(1024) void k_isab1_fwd256_ab(const FusedFwdArgs a) {
   // (TRAIN: fewer fragments ahead - the kernel has to stay inside 128 registers without scratch)
   constexpr int KS = D / 32, PF = TRAIN ? (F8O ? 1 : 2) : 3;
   constexpr int PFB = PF;   // (role B 4-5 fragments ahead: 20 bytes of scratch and 102 us against 91.8)
   // ablation switches of the measurement build (results are garbage with any of them set):
   // 1 no softmax arithmetic, 2 no epilogue arithmetic, 4 no barrier, 8 no LDS-DMA, 16 no Y stores,
-  // 32 no GEMM1, 64 no GEMM2
+  // 32 no GEMM1, 64 no GEMM2, 128 the GEMMs' MFMAs without their B-operand reads (fragments re-used)
 #ifdef PCA_FWD_ABLATE
   const int abl = a.ablate & 0xffff;
 #else
@@ -654,6 +654,106 @@ __global__ __launch_bounds__(1024) void k_isab1_fwd256_ab(const FusedFwdArgs a) 
           fetch_advance();
         }
         AB_STAMP(1);
+        if (ABREAST && !SMALL) {
+          // ---- both point blocks of the unit ABREAST: every stage is written for block 0 and
+          // block 1 side by side, so that the wave always has a second, independent chain to issue
+          // from while the first waits on an MFMA result, an LDS read or a cross-lane step (with
+          // the blocks one after the other a wave is stalled 80 % of its cycles, and four such
+          // waves leave the SIMD idle about half the time)
+          constexpr int PA = 2;
+          const f32x4 z4 = {0.f, 0.f, 0.f, 0.f};
+          f32x4 acc[NBK][2];
+#pragma unroll
+          for (int nb = 0; nb < NBK; ++nb) { acc[nb][0] = bias4(0, 0, nb); acc[nb][1] = bias4(0, 1, nb); }
+          bf16x8 bx[PA + 1][NBK];
+#pragma unroll
+          for (int s = 0; s < PA; ++s)
+#pragma unroll
+            for (int nb = 0; nb < NBK; ++nb)
+              bx[s][nb] = *reinterpret_cast<const bf16x8*>(sXc + oB[s & 3] + 256 * (s >> 2) + 8192 * nb);
+#pragma unroll
+          for (int s = 0; s < ((abl & 32) ? 1 : KS); ++s) {
+            if (s + PA < KS) {
+#pragma unroll
+              for (int nb = 0; nb < NBK; ++nb)
+                bx[(s + PA) % (PA + 1)][nb] = *reinterpret_cast<const bf16x8*>(
+                    sXc + oB[(s + PA) & 3] + 256 * ((s + PA) >> 2) + 8192 * nb);
+            }
+#pragma unroll
+            for (int nb = 0; nb < NBK; ++nb) {
+              acc[nb][0] = mfma32(wa[s][0], bx[s % (PA + 1)][nb], acc[nb][0]);
+              acc[nb][1] = mfma32(wa[s][1], bx[s % (PA + 1)][nb], acc[nb][1]);
+            }
+          }
+          const bf16x8 kp0 = *reinterpret_cast<const bf16x8*>(sK);
+          const bf16x8 kp1 = *reinterpret_cast<const bf16x8*>(sK + 1024);
+          AB_STAMP(2);
+          if (TRAIN && a.QpS != nullptr) {
+#pragma unroll
+            for (int nb = 0; nb < NBK; ++nb) {
+              char* q0 = qbase + (unsigned)(qoff + 16 * ROWB * nb);
+              if (nliveA >= P || 16 * nb + r < nliveA) {
+                *reinterpret_cast<bf16x4*>(q0) = pack4(acc[nb][0]);
+                *reinterpret_cast<bf16x4*>(q0 + 32) = pack4(acc[nb][1]);
+              }
+            }
+          }
+          f32x4 s0[NBK], s1[NBK];
+#pragma unroll
+          for (int nb = 0; nb < NBK; ++nb) {
+            const bf16x8 qb = pack8(acc[nb][0], acc[nb][1]);
+            s0[nb] = mfma32(kp0, qb, z4);
+            s1[nb] = mfma32(kp1, qb, z4);
+          }
+          if (!(abl & 1)) {
+            float mx[NBK];
+#pragma unroll
+            for (int nb = 0; nb < NBK; ++nb)
+              mx[nb] = fmaxf(fmaxf(fmaxf(s0[nb][0], s0[nb][1]), fmaxf(s0[nb][2], s0[nb][3])),
+                             fmaxf(fmaxf(s1[nb][0], s1[nb][1]), fmaxf(s1[nb][2], s1[nb][3])));
+#pragma unroll
+            for (int nb = 0; nb < NBK; ++nb) mx[nb] = wave16_max(mx[nb]);
+#pragma unroll
+            for (int nb = 0; nb < NBK; ++nb) mx[nb] = -mx[nb] * a.scale_log2e;
+#pragma unroll
+            for (int e = 0; e < 4; ++e)
+#pragma unroll
+              for (int nb = 0; nb < NBK; ++nb) {
+                s0[nb][e] = __builtin_amdgcn_exp2f(__builtin_fmaf(s0[nb][e], a.scale_log2e, mx[nb]));
+                s1[nb][e] = __builtin_amdgcn_exp2f(__builtin_fmaf(s1[nb][e], a.scale_log2e, mx[nb]));
+              }
+          }
+          bf16x8 pb[NBK];
+#pragma unroll
+          for (int nb = 0; nb < NBK; ++nb) pb[nb] = pack8(s0[nb], s1[nb]);
+          bf16x8 ones;
+#pragma unroll
+          for (int e = 0; e < 8; ++e) ones[e] = (__bf16)1.0f;
+          const bf16x8 v0 = *reinterpret_cast<const bf16x8*>(sV);
+          const bf16x8 v1 = *reinterpret_cast<const bf16x8*>(sV + 1024);
+#pragma unroll
+          for (int nb = 0; nb < NBK; ++nb) {
+            const f32x4 sm = mfma32(ones, pb[nb], z4);
+            const f32x4 o0 = mfma32(v0, pb[nb], z4);
+            const f32x4 o1 = mfma32(v1, pb[nb], z4);
+            const float inv = (abl & 1) ? sm[0] : __builtin_amdgcn_rcpf(sm[0]);
+#pragma unroll
+            for (int e = 0; e < 4; ++e) {
+              acc[nb][0][e] = __builtin_fmaf(o0[e], inv, acc[nb][0][e]);
+              acc[nb][1][e] = __builtin_fmaf(o1[e], inv, acc[nb][1][e]);
+            }
+            *reinterpret_cast<bf16x4*>(sO + oD[0] + 8192 * nb) = pack4(acc[nb][0]);
+            *reinterpret_cast<bf16x4*>(sO + oD[1] + 8192 * nb) = pack4(acc[nb][1]);
+            if (F8O) {
+              char* sO8 = sO8b + par * (P * D) + (16 * D) * nb;
+              *reinterpret_cast<uint32_t*>(sO8 + o8[0]) =
+                  cvt4_f8(acc[nb][0][0], acc[nb][0][1], acc[nb][0][2], acc[nb][0][3]);
+              *reinterpret_cast<uint32_t*>(sO8 + o8[1]) =
+                  cvt4_f8(acc[nb][1][0], acc[nb][1][1], acc[nb][1][2], acc[nb][1][3]);
+            }
+          }
+          AB_STAMP(5);
+        } else
 #pragma unroll
         for (int nb = 0; nb < NBK; ++nb) {
           f32x4 acc0 = bias4(0, 0, nb), acc1 = bias4(0, 1, nb);
@@ -675,7 +775,7 @@ __global__ __launch_bounds__(1024) void k_isab1_fwd256_ab(const FusedFwdArgs a) 
               bx[s] = *reinterpret_cast<const bf16x8*>(sXc + oB[s & 3] + 256 * (s >> 2) + 8192 * nb);
 #pragma unroll
             for (int s = 0; s < ((abl & 32) ? 1 : KS); ++s) {
-              if (s + PF < KS)
+              if (s + PF < KS && !(abl & 128))
                 bx[(s + PF) % (PF + 1)] = *reinterpret_cast<const bf16x8*>(
                     sXc + oB[(s + PF) & 3] + 256 * ((s + PF) >> 2) + 8192 * nb);
               if (s == KS - PF) {          // this head's K slices: requested under the last MFMAs
@@ -854,7 +954,7 @@ __global__ __launch_bounds__(1024) void k_isab1_fwd256_ab(const FusedFwdArgs a) 
             bo_[s] = *reinterpret_cast<const bf16x8*>(sO + oB[s & 3] + 256 * (s >> 2) + 8192 * nb);
 #pragma unroll
           for (int s = 0; s < ((abl & 64) ? 1 : KS); ++s) {
-            if (s + PFB < KS)
+            if (s + PFB < KS && !(abl & 128))
               bo_[(s + PFB) % (PFB + 1)] = *reinterpret_cast<const bf16x8*>(
                   sO + oB[(s + PFB) & 3] + 256 * ((s + PFB) >> 2) + 8192 * nb);
             // the residual O_j of both blocks: requested under the last MFMAs, not after them
@@ -998,6 +1098,19 @@ int isab1_fwd256_fused(const void* X, int dq, const __bf16* WqB, const float* Wq
     hipLaunchKernelGGL((k_isab1_fwd256_ab<S, F, T>), dim3(grid), dim3(1024), lds2, st, a);       \
   } while (0)
     const bool sm = dq <= 4, f8 = inv_o != nullptr;
+    // PCA_AB_ABREAST=1: role A runs the two point blocks of a unit side by side (see the kernel)
+    static const bool abreast = [] { const char* e = getenv("PCA_AB_ABREAST"); return e && e[0] == '1'; }();
+    if (abreast && !sm && !f8 && !train) {
+      static std::once_flag o3;
+      std::call_once(o3, [] {
+        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(k_isab1_fwd256_ab<false, false, false, true>),
+                                  hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+      });
+      hipLaunchKernelGGL((k_isab1_fwd256_ab<false, false, false, true>), dim3(grid), dim3(1024), lds2,
+                         st, a);
+      ps.end();
+      return check_launch("k_isab1_fwd256_ab<abreast>");
+    }
     if (sm && f8 && train) PCA_AB_LAUNCH(true, true, true);
     else if (sm && f8) PCA_AB_LAUNCH(true, true, false);
     else if (sm && train) PCA_AB_LAUNCH(true, false, true);
