@@ -48,6 +48,15 @@ struct Wgrad256Jobs {
   Wgrad256Job j[8];
   int n;
 };
+// mid256.hip: the per-set stage between the two blocks of a d = 256 ISAB in one launch
+int mid256_fwd(const float* O, const float* Wo, const float* bo, const float* Wk, const float* bk,
+               const float* Wv, const float* bv, float* Z, float* H, __bf16* KpP, __bf16* VpP,
+               __bf16* Kt, __bf16* Vt, int B, hipStream_t st);
+// Armed by the engine around an ISAB's two forward calls (training): the few-queries block then
+// ends in mid256_fwd, which also writes the K / V images of the many-queries block described by
+// (s1, p1, saved1), and that block's forward skips its own projection of H (mid256_kv_ready()).
+void mid256_arm(const pca_mab_shape* s1, const pca_mab_params* p1, void* saved1);
+bool mid256_kv_ready();
 int mab0_d256_prep_all(int n, const pca_mab_shape* const* shapes, const float* const* I,
                        const pca_mab_params* params, void* const* saved, hipStream_t st);
 void mab0_d256_prep_done(bool on);

@@ -543,21 +543,38 @@ __global__ __launch_bounds__(1024) void k_isab1_fwd256_ab(const FusedFwdArgs a) 
     // ================================ role A ================================
     // LDS-DMA of a unit's X tile: scalar tile base + a 32-bit lane offset (piece p of the tile,
     // row p / 32, slot p % 32, holds chunk slot ^ (row & 15) of its row)
-    auto dma_x = [&](int b, int tile, char* dst) {
-      const int n0 = tile * P, last = a.N - 1 - n0;
-      const char* base = reinterpret_cast<const char*>(a.X) + ((int64_t)b * a.N + n0) * ROWB;
+    // (scalar work per piece kept to a minimum - the kernel's time follows its instruction count,
+    //  the tile base is advanced, not recomputed with 64-bit multiplies; LDS
+    //  addresses are integers off one base, not pointer casts with their null checks; M0 is read
+    //  once before the loop and only restored after a piece)
+    const unsigned lds0 = (unsigned)(uintptr_t)(lptr_t*)smem;
+    unsigned m0_keep;
+    asm volatile("s_mov_b32 %0, m0" : "=s"(m0_keep));
+    int poff[DMA_PER_WAVE], prow[DMA_PER_WAVE];
 #pragma unroll
-      for (int i = 0; i < DMA_PER_WAVE; ++i) {
-        const int p = (DMA_PER_WAVE * j + i) * 64 + lane;
-        const int row = p >> 5, slot = p & 31;
-        const int ch = (slot & ~15) | ((slot ^ row) & 15);
-        const unsigned off = (unsigned)((row < last ? row : last) * ROWB + ch * 16);   // padding rows: a valid line
-        const unsigned ldst = __builtin_amdgcn_readfirstlane(
-            (unsigned)(uintptr_t)(lptr_t*)(dst + (DMA_PER_WAVE * j + i) * 1024));
-        unsigned keep;
-        asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %3\n\ts_nop 0\n\t"
-                     "global_load_lds_dwordx4 %1, %2\n\ts_mov_b32 m0, %0"
-                     : "=&s"(keep) : "v"(off), "s"(base), "s"(ldst) : "memory");
+    for (int i = 0; i < DMA_PER_WAVE; ++i) {
+      const int p = (DMA_PER_WAVE * j + i) * 64 + lane;
+      const int row = p >> 5, slot = p & 31;
+      prow[i] = row;
+      poff[i] = row * ROWB + (((slot & ~15) | ((slot ^ row) & 15)) << 4);
+    }
+    auto dma_x = [&](const char* base, int nlive, int slot_x) {       // base: row 0 of the tile
+      const unsigned l0 = lds0 + (unsigned)(slot_x * TILEB + DMA_PER_WAVE * j * 1024);
+      if (nlive >= P) {                      // (uniform) a full tile: the lane offsets as they are
+#pragma unroll
+        for (int i = 0; i < DMA_PER_WAVE; ++i)
+          asm volatile("s_mov_b32 m0, %2\n\ts_nop 0\n\t"
+                       "global_load_lds_dwordx4 %0, %1\n\ts_mov_b32 m0, %3"
+                       :: "v"((unsigned)poff[i]), "s"(base), "s"(l0 + i * 1024), "s"(m0_keep) : "memory");
+      } else {                               // ragged: padding rows read the tile's last valid line
+#pragma unroll
+        for (int i = 0; i < DMA_PER_WAVE; ++i) {
+          const unsigned off =
+              (unsigned)(poff[i] - (prow[i] < nlive ? 0 : (prow[i] - nlive + 1) * ROWB));
+          asm volatile("s_mov_b32 m0, %2\n\ts_nop 0\n\t"
+                       "global_load_lds_dwordx4 %0, %1\n\ts_mov_b32 m0, %3"
+                       :: "v"(off), "s"(base), "s"(l0 + i * 1024), "s"(m0_keep) : "memory");
+        }
       }
     };
     auto load_points = [&](int b, int tile, float (&xv)[NBK][4]) {    // layer 1: points to registers
@@ -595,11 +612,18 @@ __global__ __launch_bounds__(1024) void k_isab1_fwd256_ab(const FusedFwdArgs a) 
     for (int t = 0; t < 2; ++t) o8[t] = r * D + (((2 * j + t) ^ r) << 4) + 4 * g;
     float xv[NBK][4], xn[NBK][4];
     int fb = cb, ft = ct;                    // the next unit to fetch (AH units ahead of the current)
-    auto fetch_advance = [&] { if (++ft == a.tiles_per_set) { ft = 0; ++fb; } };
+    // ... and the address of its first row: + 32 rows per unit, less across a ragged set end
+    const char* fbase = reinterpret_cast<const char*>(a.X) + ((int64_t)cb * a.N + ct * P) * ROWB;
+    const int last_rows = a.N - (a.tiles_per_set - 1) * P;             // rows of a set's last tile
+    auto fetch_advance = [&] {
+      if (++ft == a.tiles_per_set) { ft = 0; ++fb; fbase += (int64_t)last_rows * ROWB; }
+      else fbase += P * ROWB;
+    };
+    auto fetch_live = [&] { return ft == a.tiles_per_set - 1 ? last_rows : P; };
     if (!SMALL) {
 #pragma unroll
       for (int q = 0; q < AH; ++q)
-        if (q < n) { dma_x(fb, ft, sXb + q * TILEB); fetch_advance(); }
+        if (q < n) { dma_x(fbase, fetch_live(), q); fetch_advance(); }
     } else {
       load_points(cb, ct, xv);
       fetch_advance();
@@ -647,7 +671,7 @@ __global__ __launch_bounds__(1024) void k_isab1_fwd256_ab(const FusedFwdArgs a) 
         if (more) {                          // the input of unit k + AH starts to arrive
           if (!SMALL) {
             const int fs = xs + AH >= XR ? xs + AH - XR : xs + AH;
-            if (!(abl & 8)) dma_x(fb, ft, sXb + fs * TILEB);
+            if (!(abl & 8)) dma_x(fbase, fetch_live(), fs);
           } else {
             load_points(fb, ft, xn);
           }

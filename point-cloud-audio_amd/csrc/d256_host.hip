@@ -45,6 +45,30 @@ struct WgHandoff {
 };
 thread_local WgHandoff g_handoff;
 }  // namespace
+namespace {
+struct Mid256Handoff {
+  bool armed = false, ready = false;
+  pca_mab_shape s1{};
+  pca_mab_params p1{};
+  void* saved1 = nullptr;
+};
+thread_local Mid256Handoff g_mid256;
+}  // namespace
+void mid256_arm(const pca_mab_shape* s1, const pca_mab_params* p1, void* saved1) {
+  g_mid256.ready = false;
+  g_mid256.armed = s1 != nullptr && p1 != nullptr && saved1 != nullptr;
+  if (g_mid256.armed) { g_mid256.s1 = *s1; g_mid256.p1 = *p1; g_mid256.saved1 = saved1; }
+}
+bool mid256_kv_ready() {
+  const bool r = g_mid256.ready;
+  g_mid256.ready = false;
+  return r;
+}
+// PCA_D256_MID=0: the five-launch form of round 2 (A/B measurements)
+static bool mid256_on() {
+  static const bool on = [] { const char* e = getenv("PCA_D256_MID"); return !(e && e[0] == '0'); }();
+  return on;
+}
 void wgrad256_handoff_arm(bool on) {
   g_handoff.armed = on;
   if (!on) { g_handoff.has = false; g_handoff.has_dx = false; }
@@ -427,6 +451,17 @@ int mab0_d256_fwd(const pca_mab_shape& s, const float* I, const void* X, const p
     PCA_TRY(mab0_attn_small_launch(reinterpret_cast<const float*>(X), v.Gf, s.B, s.nk, s.h * m,
                                    s.dk, v.T, v.LSE, s.k_lengths, st));
     PCA_TRY(epi_small_fwd256(v.T, v.Qp, p.wv, p.bv, s.B, m, s.dk, v.O, st));
+  }
+  if (g_mid256.armed && mid256_on() && m == 32 && g_mid256.s1.nk == 32 && g_mid256.s1.d == D &&
+      g_mid256.s1.B == s.B && fq_epi_bf16() == 2) {
+    // epilogue + the next block's K / V projections and images in one launch per set (mid256.hip)
+    Mab1Saved v1;
+    mab1_carve_saved(g_mid256.s1, &v1, g_mid256.saved1);
+    const pca_mab_params& p1 = g_mid256.p1;
+    PCA_TRY(mid256_fwd(v.O, p.wo, p.bo, p1.wk, p1.bk, p1.wv, p1.bv, v.Z, Hout, v1.KpP, v1.VpP, v1.Kt,
+                       v1.Vt, s.B, st));
+    g_mid256.ready = true;
+    return PCA_OK;
   }
   PCA_TRY(linear_fwd_f32(v.O, p.wo, p.bo, v.Z, Bm, D, D, st));              // :31
   return add_relu(v.O, v.Z, Hout, Bm * D, st);

@@ -926,6 +926,7 @@ int mab1_bf16_fwd_ex(const pca_mab_shape& s, const void* X, const float* H,
     if (!small) PCA_TRY(weight_image2(p.wq, &WqB, 0, p.wo, &WoP, wo_mode, d, d, st));
     else PCA_TRY(weight_image1(p.wo, &WoP, d, d, wo_mode, st));
   }
+  if (d > 128 && training && mid256_kv_ready()) flags |= PCA_F_KV_READY;   // images written by mid256_fwd
   if (!(flags & PCA_F_KV_READY) && d > 128) {
     // Kp = H Wk^T + bk, Vp = H Wv^T + bv as MFMA products (fp32 accumulation; the operand
     // rounding is an order of magnitude below the bf16 rounding of the images), then the images

@@ -312,10 +312,18 @@ int forward(const pca_st_config& c, const Layout& L, const Shapes& s, const floa
       in = w.Y[li];
       continue;
     }
-    PCA_TRY(mab_fwd_any(s.m0[li], p + L.I[li], in, params_at(p, L.mab0[li]), w.H[li], sv0,
-                        w.scratch, st));                            // modules.py:52
-    PCA_TRY(mab_fwd_any(s.m1[li], in, w.H[li], params_at(p, L.mab1[li]), w.Y[li], sv1,
-                        w.scratch, st));                            // modules.py:53
+    // d = 256 training: the few-queries block ends in the per-set mid kernel, which also prepares
+    // the K / V images of the many-queries block (mid256.hip; the blocks' saved areas are disjoint)
+    const pca_mab_params p1 = params_at(p, L.mab1[li]);
+    const bool mid = training && s.m0[li].d == 256 && mab_kind(s.m0[li]) == 2 && mab_kind(s.m1[li]) == 1;
+    if (mid) mid256_arm(&s.m1[li], &p1, sv1);
+    const int rc0 = mab_fwd_any(s.m0[li], p + L.I[li], in, params_at(p, L.mab0[li]), w.H[li], sv0,
+                                w.scratch, st);                     // modules.py:52
+    const int rc1 = rc0 != PCA_OK ? rc0
+                                  : mab_fwd_any(s.m1[li], in, w.H[li], p1, w.Y[li], sv1, w.scratch,
+                                                st);                // modules.py:53
+    if (mid) mid256_arm(nullptr, nullptr, nullptr);
+    PCA_TRY(rc1);
     in = w.Y[li];
   }
   if (training && pma_head_ok(s))                                         // modules.py:63
