@@ -458,6 +458,19 @@ __global__ __launch_bounds__(512, 2) void k_isab1_fwd256(const FusedFwdArgs a) {
 #define AB_STAMP(i)
 #endif
 
+// Two 16-byte pieces to (uniform base + 32-bit lane offsets), as instructions in the scalar-base
+// form.  (Written as C++, the full-tile and the ragged store paths get merged by hipcc into one
+// exec-mask maze with the LDS reads under the row guards and a full wait in front of every store.)
+// The s_nop covers the store-data hazard, which hipcc's hazard recognizer cannot see inside inline
+// asm: without it the next instruction may overwrite a data register the store has not read yet.
+__device__ __forceinline__ void store2x16_s(char* base, unsigned off0, unsigned off1, const uint4& v0,
+                                            const uint4& v1) {
+  typedef unsigned u32x4 __attribute__((ext_vector_type(4)));
+  const u32x4 d0 = {v0.x, v0.y, v0.z, v0.w}, d1 = {v1.x, v1.y, v1.z, v1.w};
+  asm volatile("global_store_dwordx4 %0, %2, %4\n\tglobal_store_dwordx4 %1, %3, %4\n\ts_nop 1"
+               :: "v"(off0), "v"(off1), "v"(d0), "v"(d1), "s"(base) : "memory");
+}
+
 template <bool SMALL, bool F8O, bool TRAIN, bool ABREAST = false>
 __global__ __launch_bounds__(1024) void k_isab1_fwd256_ab(const FusedFwdArgs a) {
   // (TRAIN: fewer fragments ahead - the kernel has to stay inside 128 registers without scratch)
@@ -919,6 +932,10 @@ __global__ __launch_bounds__(1024) void k_isab1_fwd256_ab(const FusedFwdArgs a) 
     const int oC = toff(tb >> 5, tb & 31);
     const int tiles128 = (a.tiles_per_set * P + 127) / 128;
     int b1 = cb, t1 = ct, b2 = cb, t2 = ct;   // units k - 1 (GEMM2) and k - 2 (deferred Y stores)
+    // byte offset of row 0 of the current unit (cb, ct) in a [B*N][256] bf16 tensor, advanced with
+    // the unit (as role A's fbase: no 64-bit multiplies per unit), and of units k - 1 / k - 2
+    const int last_rows = a.N - (a.tiles_per_set - 1) * P;
+    int64_t ro0 = ((int64_t)cb * a.N + ct * P) * ROWB, ro1 = ro0, ro2 = ro0;
     __builtin_amdgcn_s_waitcnt(0x0F70);       // vmcnt(0): the weight slice (see role A)
     __syncthreads();                          // pairs with role A's
     for (int k = 0; k <= n + 1; ++k) {
@@ -1018,32 +1035,40 @@ __global__ __launch_bounds__(1024) void k_isab1_fwd256_ab(const FusedFwdArgs a) 
           AB_STAMP(4 + nb);
         }
         if (TRAIN) {                          // O and Qp tiles of the unit, saved for the backward
-          const int n0 = t1 * P, nlive = a.N - n0;
-          const int64_t rowbytes = ((int64_t)b1 * a.N + n0) * ROWB;
-          char* baseO = reinterpret_cast<char*>(a.OS) + rowbytes;
+          const int nlive = a.N - t1 * P;
+          char* baseO = reinterpret_cast<char*>(a.OS) + ro1;          // (uniform)
           // (LDS reads unconditional, all ahead of the stores: a read under the divergent row guard
           //  would get a basic block and a full wait of its own)
           uint4 vo[P / 16];
 #pragma unroll
           for (int i = 0; i < P / 16; ++i) vo[i] = *reinterpret_cast<const uint4*>(sO + oC + 8192 * i);
+          if (nlive >= P) {                   // (uniform) a full tile: no row guards
+            static_assert(P / 16 == 2, "two pieces per thread");
+            store2x16_s(baseO, (unsigned)(tb * 16), (unsigned)((tb + 512) * 16), vo[0], vo[1]);
+          } else {
 #pragma unroll
-          for (int i = 0; i < P / 16; ++i) {
-            const int c = tb + 512 * i;
-            if ((c >> 5) < nlive) *reinterpret_cast<uint4*>(baseO + (unsigned)(c * 16)) = vo[i];
+            for (int i = 0; i < P / 16; ++i) {
+              const int c = tb + 512 * i;
+              if ((c >> 5) < nlive) *reinterpret_cast<uint4*>(baseO + (unsigned)(c * 16)) = vo[i];
+            }
           }
         }
       }
       if (k >= 2 && !(abl & 16)) {            // coalesced stores of the Y tile of unit k - 2
-        const int n0 = t2 * P, nlive = a.N - n0;
-        char* base = reinterpret_cast<char*>(a.Y) + ((int64_t)b2 * a.N + n0) * ROWB;
+        const int nlive = a.N - t2 * P;
+        char* base = reinterpret_cast<char*>(a.Y) + ro2;               // (uniform)
         uint4 vy[P / 16];
 #pragma unroll
         for (int i = 0; i < P / 16; ++i)
           vy[i] = *reinterpret_cast<const uint4*>(sYb + par * TILEB + oC + 8192 * i);
+        if (nlive >= P) {                     // (uniform) a full tile: no row guards
+          store2x16_s(base, (unsigned)(tb * 16), (unsigned)((tb + 512) * 16), vy[0], vy[1]);
+        } else {
 #pragma unroll
-        for (int i = 0; i < P / 16; ++i) {
-          const int c = tb + 512 * i;
-          if ((c >> 5) < nlive) *reinterpret_cast<uint4*>(base + (unsigned)(c * 16)) = vy[i];
+          for (int i = 0; i < P / 16; ++i) {
+            const int c = tb + 512 * i;
+            if ((c >> 5) < nlive) *reinterpret_cast<uint4*>(base + (unsigned)(c * 16)) = vy[i];
+          }
         }
         if (TRAIN && tb < NBK * 128) {
           const int nb = tb >> 7, w = (tb >> 6) & 1;
@@ -1052,10 +1077,11 @@ __global__ __launch_bounds__(1024) void k_isab1_fwd256_ab(const FusedFwdArgs a) 
         }
       }
       AB_STAMP(6);
-      b2 = b1; t2 = t1;
-      b1 = cb; t1 = ct;
+      b2 = b1; t2 = t1; ro2 = ro1;
+      b1 = cb; t1 = ct; ro1 = ro0;
       if (k < n) {
-        if (++ct == a.tiles_per_set) { ct = 0; ++cb; }
+        if (++ct == a.tiles_per_set) { ct = 0; ++cb; ro0 += (int64_t)last_rows * ROWB; }
+        else ro0 += P * ROWB;
       }
       unit_barrier();
     }
