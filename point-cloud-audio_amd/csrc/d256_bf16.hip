@@ -720,7 +720,9 @@ struct Attn1Bwd3Args {
 // SMALLQ: layer 1 (two or three input columns).  The projected queries are not read back (the
 // forward does not save them: one [B*N, 256] tensor less written and one less read) but recomputed
 // from the tile's points with the forward's own expression, so the bf16 values are the same.
-template <int D, bool SMALLQ>
+// STORE_DZ = false: dZ does not leave the kernel - the fc_o weight-gradient job then reads dY and the
+// mask itself (Wgrad256Job::mask): one [B*N, 256] tensor less written per block.
+template <int D, bool SMALLQ, bool STORE_DZ = true>
 __global__ __launch_bounds__(64 * (D / 32), 2) void k_attn1_bwd3(const Attn1Bwd3Args aa) {
   const Attn1BwdArgs& a = aa.base;
   constexpr int MI = 32, ROWB = D * 2, TILEB = 32 * ROWB, KS = D / 32;
@@ -855,7 +857,7 @@ __global__ __launch_bounds__(64 * (D / 32), 2) void k_attn1_bwd3(const Attn1Bwd3
     // have landed is this tile's dY (issued after barrier B1 of iteration k - 1) and everything older:
     // younger are only the 4 stores of tile k - 1 (always a full tile) and the DMA just issued
     {
-      int younger = k > 0 ? 4 : 0;
+      int younger = k > 0 ? (STORE_DZ ? 4 : 2) : 0;
       if (k + 1 < T) {
         dma_q(k + 1);
         younger += nq;
@@ -896,12 +898,14 @@ __global__ __launch_bounds__(64 * (D / 32), 2) void k_attn1_bwd3(const Attn1Bwd3
     }
     lds_barrier();                       // B1: dZ tile complete; dY tile consumed
     if (k + 1 < T) dma_tile(aa.dY, k + 1, sY);
+    if (STORE_DZ) {
 #pragma unroll
-    for (int i = 0; i < 2; ++i) {
-      const int c = tid + 512 * i, row = c >> 5, ch = c & 31;
-      if (row < nlive)
-        *reinterpret_cast<uint4*>(aa.dZ + ((int64_t)b * a.N + n0 + row) * D + ch * 8) =
-            *reinterpret_cast<const uint4*>(sZ + oC + 8192 * i);
+      for (int i = 0; i < 2; ++i) {
+        const int c = tid + 512 * i, row = c >> 5, ch = c & 31;
+        if (row < nlive)
+          *reinterpret_cast<uint4*>(aa.dZ + ((int64_t)b * a.N + n0 + row) * D + ch * 8) =
+              *reinterpret_cast<const uint4*>(sZ + oC + 8192 * i);
+      }
     }
     // ---- phase B: dO_h = dY_h + (dZ Wo)_h, then the attention adjoint of this head ----
     f32x4 acc[2][2];
@@ -1245,6 +1249,11 @@ __global__ __launch_bounds__(512, 2) void k_wgrad256_dma(const Wgrad256Jobs jobs
     prow[e] = row;
     poff[e] = half * 256 + (((lane & 15) ^ sw) << 4);
   }
+  // job.mask: the 256 ReLU-mask words of the tile's 32 rows (1 KiB, contiguous) ride along as a fifth
+  // piece of wave 0 into the mask ring behind the tile ring
+  const bool masked = job.mask != nullptr;
+  const bool mask_wave = masked && wave == 0;
+  char* sMaskRing = lds + NB * 2 * TB;
   auto dma = [&](int t) {
     const int64_t base = tile_row(t);
     char* dst = lds + (t % NB) * 2 * TB;
@@ -1262,6 +1271,15 @@ __global__ __launch_bounds__(512, 2) void k_wgrad256_dma(const Wgrad256Jobs jobs
                      "global_load_lds_dwordx4 %1, off\n\ts_mov_b32 m0, %0"
                      : "=&s"(keep) : "v"(src), "s"(ldst) : "memory");
       }
+    if (mask_wave) {
+      const char* src = reinterpret_cast<const char*>(job.mask) + base * 32 + lane * 16;
+      const unsigned ldst = __builtin_amdgcn_readfirstlane(
+          (unsigned)(uintptr_t)(lds_void_t*)(sMaskRing + (t % NB) * 1024));
+      unsigned keep;
+      asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %2\n\ts_nop 0\n\t"
+                   "global_load_lds_dwordx4 %1, off\n\ts_mov_b32 m0, %0"
+                   : "=&s"(keep) : "v"(src), "s"(ldst) : "memory");
+    }
   };
 #pragma unroll 1
   for (int t = 0; t < PD && t < ntile; ++t) dma(t);
@@ -1270,9 +1288,15 @@ __global__ __launch_bounds__(512, 2) void k_wgrad256_dma(const Wgrad256Jobs jobs
     // tile t has landed when at most the pieces of the (up to PD - 1) tiles behind it are pending
     {
       const int ahead = (ntile - 1 - t) < (PD - 1) ? (ntile - 1 - t) : (PD - 1);
-      if (ahead >= 2) asm volatile("s_waitcnt vmcnt(8)" ::: "memory");
-      else if (ahead == 1) asm volatile("s_waitcnt vmcnt(4)" ::: "memory");
-      else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+      if (mask_wave) {                                 // (five pieces per tile in this wave)
+        if (ahead >= 2) asm volatile("s_waitcnt vmcnt(10)" ::: "memory");
+        else if (ahead == 1) asm volatile("s_waitcnt vmcnt(5)" ::: "memory");
+        else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+      } else {
+        if (ahead >= 2) asm volatile("s_waitcnt vmcnt(8)" ::: "memory");
+        else if (ahead == 1) asm volatile("s_waitcnt vmcnt(4)" ::: "memory");
+        else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+      }
     }
     asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
     __builtin_amdgcn_s_barrier();                      // every wave's pieces; tile t - 1 consumed
@@ -1293,7 +1317,33 @@ __global__ __launch_bounds__(512, 2) void k_wgrad256_dma(const Wgrad256Jobs jobs
       __builtin_amdgcn_s_barrier();
       asm volatile("" ::: "memory");
     }
-    if (job.db != nullptr) {
+    if (masked) {
+      // G . [mask] in place: thread = (row, 8 features) as below; the features 8 ch .. 8 ch + 7 of a row
+      // are two nibbles of the forward's layout (word = 16-row block x head half x lane (r, g), byte =
+      // head, bit 4 t + e  <->  feature 32 j + 16 t + 4 g + e): lanes g0 = 2 (ch & 1) and g0 + 1
+      const uint32_t* sM = reinterpret_cast<const uint32_t*>(sMaskRing + (t % NB) * 1024);
+#pragma unroll
+      for (int e = 0; e < 2; ++e) {
+        const int c = tid + e * 512, row = c >> 5, ch = c & 31;
+        const int wi = ((row >> 4) * 2 + (ch >> 4)) * 64 + (row & 15) + 32 * (ch & 1);
+        const int sh = 8 * ((ch >> 2) & 3) + 4 * ((ch >> 1) & 1);
+        const uint32_t n0 = sM[wi] >> sh, n1 = sM[wi + 16] >> sh;
+        bf16x8 gv = *reinterpret_cast<const bf16x8*>(sG + tr_off256(row, ch));
+#pragma unroll
+        for (int k = 0; k < 4; ++k) {
+          if (!((n0 >> k) & 1u)) gv[k] = (__bf16)0.f;
+          if (!((n1 >> k) & 1u)) gv[4 + k] = (__bf16)0.f;
+        }
+        *reinterpret_cast<bf16x8*>(sG + tr_off256(row, ch)) = gv;
+        if (job.db != nullptr) {
+#pragma unroll
+          for (int k = 0; k < 8; ++k) bs[k] += (float)gv[k];
+        }
+      }
+      asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+      __builtin_amdgcn_s_barrier();
+      asm volatile("" ::: "memory");
+    } else if (job.db != nullptr) {
 #pragma unroll
       for (int e = 0; e < 2; ++e) {
         const int c = tid + e * 512, row = c >> 5, ch = c & 31;
@@ -3205,14 +3255,25 @@ int attn1_bwd256_fused(const __bf16* dY, const uint32_t* mask, const __bf16* WoT
               "attn1_bwd256_fused: no saved Qp and no points to recompute it from");
   static std::once_flag once;
   std::call_once(once, [] {
-    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(k_attn1_bwd3<D, false>),
+    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(k_attn1_bwd3<D, false, true>),
                               hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
-    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(k_attn1_bwd3<D, true>),
+    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(k_attn1_bwd3<D, true, true>),
+                              hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(k_attn1_bwd3<D, false, false>),
+                              hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(k_attn1_bwd3<D, true, false>),
                               hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
   });
   const size_t lds = (size_t)5 * 32 * D * 2 + 2048 + (size_t)8 * 4 * 32 * 72;
-  if (smallq) hipLaunchKernelGGL((k_attn1_bwd3<D, true>), dim3(B * parts), dim3(512), lds, st, a);
-  else hipLaunchKernelGGL((k_attn1_bwd3<D, false>), dim3(B * parts), dim3(512), lds, st, a);
+  const dim3 grid(B * parts), block(512);
+  // dZ == nullptr: dZ stays inside the kernel (the weight-gradient job applies the mask to dY itself)
+  if (dZ != nullptr) {
+    if (smallq) hipLaunchKernelGGL((k_attn1_bwd3<D, true, true>), grid, block, lds, st, a);
+    else hipLaunchKernelGGL((k_attn1_bwd3<D, false, true>), grid, block, lds, st, a);
+  } else {
+    if (smallq) hipLaunchKernelGGL((k_attn1_bwd3<D, true, false>), grid, block, lds, st, a);
+    else hipLaunchKernelGGL((k_attn1_bwd3<D, false, false>), grid, block, lds, st, a);
+  }
   PCA_TRY(check_launch("k_attn1_bwd3"));
   hipLaunchKernelGGL(k_sum_parts256, dim3((unsigned)cdiv((int64_t)B * 32 * D, 256)), dim3(256), 0,
                      st, dKpPart, dVpPart, dKp, dVp, B, parts, 32 * D);
@@ -3240,6 +3301,15 @@ size_t wgrad256_ws_bytes(int njobs, int64_t maxM) {
 int wgrad256_launch(const Wgrad256Jobs& jobs, void* ws, hipStream_t st) {
   return wgrad256_launch_t(jobs, ws, false, st);
 }
+static bool wgrad256_use_dma() {      // PCA_WGRAD256_DMA=0: the register-staged kernel (A/B measurements)
+  static const bool on = [] { const char* e = getenv("PCA_WGRAD256_DMA"); return !(e && e[0] == '0'); }();
+  return on;
+}
+// May a bf16 job hand over dY + the forward's ReLU mask instead of dZ?  (PCA_D256_DZ_MASK=0: no)
+bool wgrad256_masked_ok(int64_t rows_per_set) {
+  static const bool on = [] { const char* e = getenv("PCA_D256_DZ_MASK"); return !(e && e[0] == '0'); }();
+  return on && wgrad256_use_dma() && rows_per_set % 128 == 0;
+}
 int wgrad256_launch_t(const Wgrad256Jobs& jobs, void* ws, bool f32_operands, hipStream_t st) {
   if (jobs.n == 0) return PCA_OK;
   int64_t maxM = 0;
@@ -3262,8 +3332,10 @@ int wgrad256_launch_t(const Wgrad256Jobs& jobs, void* ws, bool f32_operands, hip
   const double opbytes = shared ? eb * 256 * (rows + (double)jobs.j[0].M) : 2.0 * eb * 256 * rows;
   ProfScope ps(PCA_K_WGRAD, st, 2.0 * rows * 256 * 256, opbytes);
   if (shared) rpw = -rpw;
-  // PCA_WGRAD256_DMA=0: the register-staged kernel for the bf16 jobs too (A/B measurements)
-  static const bool use_dma = [] { const char* e = getenv("PCA_WGRAD256_DMA"); return !(e && e[0] == '0'); }();
+  const bool use_dma = wgrad256_use_dma();
+  for (int i = 0; i < jobs.n; ++i)
+    PCA_REQUIRE(jobs.j[i].mask == nullptr || (use_dma && !f32_operands),
+                "wgrad256: a masked job needs the LDS-DMA kernel");
   if (f32_operands) {
     hipLaunchKernelGGL(k_wgrad256<float>, dim3(nwg * jobs.n), dim3(512), 0, st, jobs, rpw, slabs,
                        bslabs);
@@ -3273,8 +3345,10 @@ int wgrad256_launch_t(const Wgrad256Jobs& jobs, void* ws, bool f32_operands, hip
       (void)hipFuncSetAttribute(reinterpret_cast<const void*>(k_wgrad256_dma),
                                 hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
     });
-    hipLaunchKernelGGL(k_wgrad256_dma, dim3(nwg * jobs.n), dim3(512), (size_t)4 * 2 * 32 * 256 * 2,
-                       st, jobs, rpw, slabs, bslabs);
+    for (int i = 0; i < jobs.n; ++i)
+      PCA_REQUIRE(jobs.j[i].mask == nullptr || jobs.j[i].M % 32 == 0, "wgrad256: masked job rows");
+    hipLaunchKernelGGL(k_wgrad256_dma, dim3(nwg * jobs.n), dim3(512),
+                       (size_t)4 * 2 * 32 * 256 * 2 + 4 * 1024, st, jobs, rpw, slabs, bslabs);
   } else {
     hipLaunchKernelGGL(k_wgrad256<__bf16>, dim3(nwg * jobs.n), dim3(512), 0, st, jobs, rpw, slabs,
                        bslabs);

@@ -43,11 +43,16 @@ struct Wgrad256Job {
   float* dW;
   float* db;
   int64_t M;
+  // optional (bf16 LDS-DMA kernel only, M % 32 == 0): ReLU mask words of the many-queries forward
+  // over the same rows (mab1_mask_index<256> with N % 128 == 0, i.e. 128 words per 16 rows); G is
+  // then used as G . [mask] - the job reads dY and the mask instead of a materialised dZ
+  const uint32_t* mask;
 };
 struct Wgrad256Jobs {
   Wgrad256Job j[8];
   int n;
 };
+bool wgrad256_masked_ok(int64_t rows_per_set);
 // mid256.hip: the per-set stage between the two blocks of a d = 256 ISAB in one launch
 int mid256_fwd(const float* O, const float* Wo, const float* bo, const float* Wk, const float* bk,
                const float* Wv, const float* bv, float* Z, float* H, __bf16* KpP, __bf16* VpP,

@@ -196,12 +196,15 @@ int mab1_d256_bwd(const pca_mab_shape& s, const void* X, const float* Hk, const 
   // in k_wgrad256, each with a scope of its own or none): dO = dY + dZ Wo (2 M d^2) and the
   // attention adjoint (8 M m d); dY and Qp (layer 1: the points) in, dZ and dQp out
   const double flops = (double)M * (2.0 * D * D + 8.0 * s.nk * D);
-  const double bytes = (double)M * (2.0 * D + (small ? 4.0 * s.dq : 2.0 * D) + 4.0 * D);
+  // dZ = dY . [Z > 0] is read by the fc_o weight-gradient job only: with whole 128-point mask blocks per
+  // set that job takes dY and the mask words instead (Wgrad256Job::mask) and dZ is never written
+  const bool dz_masked = fuse_o && wgrad256_masked_ok(s.nq);
+  const double bytes = (double)M * (2.0 * D + (small ? 4.0 * s.dq : 2.0 * D) + (dz_masked ? 2.0 : 4.0) * D);
   ProfScope ps(PCA_K_MAB1_BWD, st, flops, bytes);
   if (fuse_o) {
     // layer 1 (dq <= 4): Qp is recomputed from the points (mab1_saves_qp() == false: not saved)
     PCA_TRY(attn1_bwd256_fused(dYb, v.mask, w.WoTP, mab1_saves_qp(s) ? v.QpS : nullptr, v.KpP,
-                               v.VpP, v.Kt, w.dZ, w.dQp, w.dKpPart, w.dVpPart, w.dKp, w.dVp, s.B,
+                               v.VpP, v.Kt, dz_masked ? nullptr : w.dZ, w.dQp, w.dKpPart, w.dVpPart, w.dKp, w.dVp, s.B,
                                s.nq, st, reinterpret_cast<const float*>(X), p.wq, p.bq, s.dq));
   } else {
     PCA_TRY(rowgemm256_bwd_o(dYb, v.mask, w.WoTP, w.dZ, w.dO, s.B, s.nq, st));
@@ -224,7 +227,8 @@ int mab1_d256_bwd(const pca_mab_shape& s, const void* X, const float* Hk, const 
   }
   // weight gradients over the B*N rows
   Wgrad256Jobs jobs{};
-  jobs.j[jobs.n++] = Wgrad256Job{w.dZ, v.OS, gr.wo, gr.bo, M};
+  if (dz_masked) jobs.j[jobs.n++] = Wgrad256Job{dYb, v.OS, gr.wo, gr.bo, M, v.mask};
+  else jobs.j[jobs.n++] = Wgrad256Job{w.dZ, v.OS, gr.wo, gr.bo, M};
   if (!small) {
     const Wgrad256Job jq{w.dQp, Xb, gr.wq, gr.bq, M};
     if (g_handoff.armed && abf) {          // launched by the few-queries block with its own two jobs
