@@ -95,6 +95,10 @@ struct WgradJob {
   int g_lo, g_hi;
   float* slab;            // set by the launcher: [workgroups][(g_hi - g_lo) * 128 (+ 128 with db)]
                           // partials, summed in a fixed order afterwards (null: fp32 atomics)
+  // optional (bf16 G): ReLU mask words of the many-queries forward over the same rows
+  // (mab1_mask_index<128> with N % 128 == 0: 64 words per 16 rows); G is then used as G . [mask] -
+  // the fc_o job reads dY and the mask instead of a materialised dZ
+  const uint32_t* mask;
 };
 struct WgradJobs {
   WgradJob j[16];

@@ -264,7 +264,7 @@ void k_mab1_bwd(const Mab1BwdArgs a) {
 #pragma unroll
         for (int e = 0; e < 4; ++e)
           dz[t][e] = ((bits[t / 8] >> ((t & 7) * 4 + e)) & 1u) ? dO[t][nb][e] : 0.f;
-        if (live[nb])
+        if (live[nb] && a.dZ != nullptr)     // (null: the fc_o job masks dY itself, WgradJob::mask)
           *reinterpret_cast<bf16x4*>(a.dZ + row[nb] * D + 16 * t + 4 * g) = pack4(dz[t]);
       }
 #pragma unroll
@@ -608,6 +608,7 @@ __global__ __launch_bounds__(256 * NG) void k_wgrad128(const WgradJobs jobs, int
   float bs[8] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};   // column sums of G, columns 8*(tid&15)..
 
   bf16x8 vg[2], va[2];
+  uint32_t mk[2][2] = {{~0u, ~0u}, {~0u, ~0u}};       // ReLU mask words of the fetched chunks (job.mask)
   auto fetch = [&](int64_t base) {          // rows at and beyond r1 read as zeros
 #pragma unroll
     for (int e = 0; e < 2; ++e) {
@@ -616,6 +617,15 @@ __global__ __launch_bounds__(256 * NG) void k_wgrad128(const WgradJobs jobs, int
       if (base + row < r1) {          // (guarded on purpose: the unconditional form measured +18 %)
         vg[e] = load8(G + (base + row) * D + ch * 8);
         va[e] = load8(A + (base + row) * D + ch * 8);
+        if (job.mask != nullptr) {
+          // features 8 ch .. 8 ch + 7 of row R: two nibbles (bit 4 t + e of lane (r, g) <-> feature
+          // 16 t + 4 g + e, t = ch / 2) of the words of lanes g0 = 2 (ch & 1) and g0 + 1.  Only
+          // requested here; applied when the tile goes to LDS (the loads stay in flight meanwhile)
+          const int64_t R = base + row;
+          const uint32_t* mw = job.mask + (R >> 4) * 64 + (R & 15) + 32 * (ch & 1);
+          mk[e][0] = mw[0];
+          mk[e][1] = mw[16];
+        }
       } else {
 #pragma unroll
         for (int k = 0; k < 8; ++k) { vg[e][k] = (__bf16)0.f; va[e][k] = (__bf16)0.f; }
@@ -631,6 +641,14 @@ __global__ __launch_bounds__(256 * NG) void k_wgrad128(const WgradJobs jobs, int
     for (int e = 0; e < 2; ++e) {
       const int c = gtid + e * 256;
       const int row = c >> 4, ch = c & 15;
+      if (job.mask != nullptr) {
+        const uint32_t n0 = mk[e][0] >> (4 * (ch >> 1)), n1 = mk[e][1] >> (4 * (ch >> 1));
+#pragma unroll
+        for (int k = 0; k < 4; ++k) {
+          if (!((n0 >> k) & 1u)) vg[e][k] = (__bf16)0.f;
+          if (!((n1 >> k) & 1u)) vg[e][4 + k] = (__bf16)0.f;
+        }
+      }
       *reinterpret_cast<bf16x8*>(sG[buf] + tr_off(row, ch)) = vg[e];
       *reinterpret_cast<bf16x8*>(sA[buf] + tr_off(row, ch)) = va[e];
       if (job.db != nullptr) {
@@ -1072,9 +1090,14 @@ int mab1_bf16_bwd_ex(const pca_mab_shape& s, const void* X, const float* H,
     if (want_dx) PCA_TRY(prep_weight(p.wq, w.WqTP, d, d, 2, st));
   }
 
+  // dZ = dY . [Z > 0] is read by the fc_o weight-gradient job only: with bf16 gradients and whole
+  // 128-point mask blocks per set that job takes dY and the mask words (WgradJob::mask) and dZ is
+  // never written (PCA_D128_DZ_MASK=0: the materialised form)
+  static const bool dzm_on = [] { const char* e = getenv("PCA_D128_DZ_MASK"); return !(e && e[0] == '0'); }();
+  const bool dz_masked = dzm_on && abf && MI == 16 && s.nq % 128 == 0;
   Mab1BwdArgs a{};
   a.dY = dY; a.QpS = v.QpS; a.mask = v.mask; a.KpP = v.KpP; a.VpP = v.VpP; a.Kt = v.Kt;
-  a.WoTP = w.WoTP; a.WqTP = w.WqTP; a.dZ = w.dZ; a.dQp = w.dQp; a.dOs = w.dOs; a.dS = w.dS;
+  a.WoTP = w.WoTP; a.WqTP = w.WqTP; a.dZ = dz_masked ? nullptr : w.dZ; a.dQp = w.dQp; a.dOs = w.dOs; a.dS = w.dS;
   a.P = w.P; a.dX = want_dx ? dX : nullptr;
   a.B = s.B; a.N = s.nq; a.tiles_per_set = (int)cdiv(s.nq, TP);
   a.scale = 1.0f / sqrtf((float)d);
@@ -1151,7 +1174,10 @@ int mab1_bf16_bwd_ex(const pca_mab_shape& s, const void* X, const float* H,
   const bool wq_big = !small;
   {
     WgradJobs jobs{};
-    jobs.j[jobs.n++] = WgradJob{w.dZ, v.OS, gr.wo, gr.bo, M, 0, 128};
+    if (dz_masked)
+      jobs.j[jobs.n++] = WgradJob{dY, v.OS, gr.wo, gr.bo, M, 0, 128, nullptr, v.mask};
+    else
+      jobs.j[jobs.n++] = WgradJob{w.dZ, v.OS, gr.wo, gr.bo, M, 0, 128};
     if (wq_big && abf) jobs.j[jobs.n++] = WgradJob{w.dQp, X, gr.wq, gr.bq, M, 0, 128};
     hipStream_t ts = terminal_stream(st);
     if (defer != nullptr) {
