@@ -87,28 +87,63 @@ __global__ __launch_bounds__(256) void k_adam(float* __restrict__ p, float* __re
                                               int64_t n, float lr, float b1, float b2,
                                               float eps, float wd, float gscale,
                                               int32_t* __restrict__ step, int zero_grad) {
-  __shared__ int s_t;
-  if (threadIdx.x == 0) s_t = step[0] + 1;
-  __syncthreads();
-  const int ti = s_t;
+  // The kernel is one dependent chain of L2 round trips long (1.2 MB of parameters at configs[1]):
+  // the step count and the first batch of operands are requested together, 16-byte accesses, each
+  // thread two float4 quadruples in flight.
+  const int ti = step[0] + 1;
+  const int64_t n4 = n >> 2;
+  const int64_t stride = (int64_t)gridDim.x * blockDim.x;
+  int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  float4* p4 = reinterpret_cast<float4*>(p);
+  float4* g4 = reinterpret_cast<float4*>(g);
+  float4* m4 = reinterpret_cast<float4*>(m);
+  float4* v4 = reinterpret_cast<float4*>(v);
+  const bool vec = (((uintptr_t)p | (uintptr_t)g | (uintptr_t)m | (uintptr_t)v) & 15) == 0;
+  float4 w0, g0, m0, v0, w1, g1, m1, v1;
+  const bool h0 = vec && i < n4, h1 = vec && i + stride < n4;
+  if (h0) { w0 = p4[i]; g0 = g4[i]; m0 = m4[i]; v0 = v4[i]; }
+  if (h1) { w1 = p4[i + stride]; g1 = g4[i + stride]; m1 = m4[i + stride]; v1 = v4[i + stride]; }
   const float t = (float)ti;
   const float bc1 = 1.f - powf(b1, t);
   const float bc2 = 1.f - powf(b2, t);
   const float step_size = lr / bc1;
   const float inv_sqrt_bc2 = 1.f / sqrtf(bc2);
-  int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
-  const int64_t stride = (int64_t)gridDim.x * blockDim.x;
-#pragma unroll 4
-  for (; i < n; i += stride) {
-    const float w = p[i];
-    const float gi = g[i] * gscale + wd * w;         // coupled L2 (torch.optim.Adam)
-    const float mi = b1 * m[i] + (1.f - b1) * gi;
-    const float vi = b2 * v[i] + (1.f - b2) * gi * gi;
-    m[i] = mi;
-    v[i] = vi;
-    const float denom = sqrtf(vi) * inv_sqrt_bc2 + eps;
-    p[i] = w - step_size * (mi / denom);
-    if (zero_grad) g[i] = 0.f;
+  auto upd = [&](float& w, float& gg, float& mm, float& vv) {
+    const float gi = gg * gscale + wd * w;            // coupled L2 (torch.optim.Adam)
+    mm = b1 * mm + (1.f - b1) * gi;
+    vv = b2 * vv + (1.f - b2) * gi * gi;
+    const float denom = sqrtf(vv) * inv_sqrt_bc2 + eps;
+    w = w - step_size * (mm / denom);
+    if (zero_grad) gg = 0.f;
+  };
+  auto upd4 = [&](float4& w, float4& gg, float4& mm, float4& vv) {
+    upd(w.x, gg.x, mm.x, vv.x); upd(w.y, gg.y, mm.y, vv.y);
+    upd(w.z, gg.z, mm.z, vv.z); upd(w.w, gg.w, mm.w, vv.w);
+  };
+  if (h0) {
+    upd4(w0, g0, m0, v0);
+    p4[i] = w0; m4[i] = m0; v4[i] = v0;
+    if (zero_grad) g4[i] = g0;
+  }
+  if (h1) {
+    upd4(w1, g1, m1, v1);
+    p4[i + stride] = w1; m4[i + stride] = m1; v4[i + stride] = v1;
+    if (zero_grad) g4[i + stride] = g1;
+  }
+  if (vec) {
+    for (int64_t k = i + 2 * stride; k < n4; k += stride) {
+      float4 w = p4[k], gg = g4[k], mm = m4[k], vv = v4[k];
+      upd4(w, gg, mm, vv);
+      p4[k] = w; m4[k] = mm; v4[k] = vv;
+      if (zero_grad) g4[k] = gg;
+    }
+  }
+  // the tail (n % 4 elements), or everything when a pointer is not 16-byte aligned
+  for (int64_t k = (vec ? (n4 << 2) : 0) + i; k < n; k += stride) {
+    float w = p[k], gg = g[k], mm = m[k], vv = v[k];
+    upd(w, gg, mm, vv);
+    p[k] = w; m[k] = mm; v[k] = vv;
+    if (zero_grad) g[k] = gg;
   }
   if (threadIdx.x == 0) {
     const int ticket = atomicAdd(&step[1], 1);
@@ -165,6 +200,7 @@ int pca_adam_step(float* param, float* grad, float* exp_avg, float* exp_avg_sq, 
   PCA_REQUIRE(n >= 0, "adam_step: n=%lld", (long long)n);
   hipStream_t st = pca::as_stream(stream);
   // few, longer workgroups: the arrival tickets are serialised atomics on one address
+  // (two float4 quadruples per thread in the first pass)
   int64_t blocks = pca::cdiv(n, 256 * 8);
   if (blocks > 1024) blocks = 1024;
   if (blocks < 1) blocks = 1;                      // n == 0 still advances the step count
