@@ -1,5 +1,5 @@
 #!/bin/bash
-# usage (GPU box, through gpurun): scripts/profiles_r03.sh [part]   part = bench | stats | pmc | sq | fwd | all
+# usage (GPU box, through gpurun): scripts/profiles_r03.sh [part]   part = bench | stats | pmc | sq | fwd | isab | all
 # Everything under profiles/r03_* (see scripts/copy_profiles_r03.sh).  Outputs land in gpurun_out/r03/.
 set -e
 R=$GRAFT_REPO_ROOT
@@ -57,7 +57,11 @@ if [ $PART = fwd ] || [ $PART = all ]; then
     done
   done
   unset PCA_D256_AB
-  N=2048 REPS=10 rocprofv3 --kernel-trace --stats --output-format csv -d $O/isab256/trace -- python3 $R/scripts/isab256_fwd_bench.py > $O/isab256/bench.log 2>&1 || true
   echo "forward passes done"
+fi
+if [ $PART = isab ] || [ $PART = fwd ] || [ $PART = all ]; then
+  mkdir -p $O/isab256
+  N=2048 REPS=10 rocprofv3 --kernel-trace --stats --output-format csv -d $O/isab256/trace -- python3 $R/scripts/isab256_fwd_bench.py > $O/isab256/bench.log 2>&1 || true
+  echo "ISAB forward pass done"
 fi
 echo "all done"
