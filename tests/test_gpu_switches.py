@@ -1,0 +1,69 @@
+"""The A/B switches that select between two implementations of the SAME arithmetic must not move a
+bit of the result: each case runs one forward + backward of the whole-model engine in a fresh
+process per setting (the library reads these switches once per process) and compares SHA-256 of the
+logits, the loss and the 45 gradients.
+
+* ``PCA_D128_DZ_MASK`` / ``PCA_D256_DZ_MASK``: dZ = dY.[Z > 0] written by the backward and read back by
+  the fc_o weight-gradient job, or that job masking dY with the forward's ReLU bits itself - the same
+  bf16 values reach the same MFMAs in the same order.
+* ``PCA_WGRAD256_DMA``: operand tiles of the 256-wide weight gradients through registers or by LDS-DMA.
+* ``PCA_PACK_DEFER`` is covered in test_gpu_parity.py, ``PCA_D256_MID`` (a different summation order)
+  by the oracle parity of test_gpu_fullsize.py.
+"""
+import os
+import subprocess
+import sys
+
+import pytest
+
+pytestmark = pytest.mark.gpu
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+ROOT = os.path.dirname(HERE)
+
+SCRIPT = r"""
+import hashlib, sys
+sys.path.insert(0, {pkg!r}); sys.path.insert(0, {tests!r}); sys.path.insert(0, {golden!r})
+import torch
+import models, inputs as gi
+from pca_hip import _lib, trainer
+B, N, din, d, h, m, C = {shape}
+dev = torch.device("cuda", 0)
+torch.manual_seed(11)
+net = models.ST(dim_input=din, num_outputs=1, dim_output=C, num_inds=m, dim_hidden=d, num_heads=h).to(dev)
+X = torch.from_numpy(gi.pc_input(12, B, N, din)).to(dev)
+y = torch.from_numpy(gi.labels(13, B, C)).to(dev)
+eng = trainer.STEngine(net, B, N, _lib.MODE_BF16, training=True)
+eng.fwd_bwd(X, y, phase=-1)
+torch.cuda.synchronize()
+assert torch.isfinite(eng.grads).all()
+hsh = hashlib.sha256()
+for t in (eng.logits, eng.loss, eng.grads):
+    hsh.update(t.detach().cpu().numpy().tobytes())
+print("HASH", hsh.hexdigest())
+"""
+
+
+def _run(shape, env):
+    code = SCRIPT.format(pkg=os.path.join(ROOT, "point-cloud-audio_amd"), tests=HERE,
+                         golden=os.path.join(HERE, "golden"), shape=shape)
+    e = dict(os.environ)
+    e.update(env)
+    out = subprocess.run([sys.executable, "-c", code], env=e, capture_output=True, text=True, timeout=600)
+    assert out.returncode == 0, out.stderr[-2000:]
+    return [ln for ln in out.stdout.splitlines() if ln.startswith("HASH")][-1]
+
+
+CASES = [
+    # (shape, variable, why this shape)
+    ((6, 512, 2, 128, 4, 16, 50), "PCA_D128_DZ_MASK", "configs[1] architecture: both d = 128 blocks take the masked job"),
+    ((3, 384, 3, 256, 8, 32, 10), "PCA_D256_DZ_MASK", "configs[3] architecture, N % 128 == 0: masked job in k_wgrad256_dma"),
+    ((3, 384, 3, 256, 8, 32, 10), "PCA_WGRAD256_DMA", "LDS-DMA ring against register staging (the latter forces dZ to be written)"),
+]
+
+
+@pytest.mark.parametrize("shape,var,why", CASES, ids=[c[1] for c in CASES])
+def test_switch_is_bit_neutral(shape, var, why):
+    on = _run(shape, {})
+    off = _run(shape, {var: "0"})
+    assert on == off, f"{var}=0 changes the result ({why})"
