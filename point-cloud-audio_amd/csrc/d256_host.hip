@@ -410,9 +410,16 @@ int mab0_d256_fwd(const pca_mab_shape& s, const float* I, const void* X, const p
     const bool f8 = s.mode == PCA_MODE_FP8;
     if ((!f8 || fq_fused8) && rowstream_on() && fq_fused && m > 16) {
       // fc_k / fc_v over the keys and the attention in one pass over X (k_fq_proj_fwd)
-      if (f8) {
-        PCA_TRY(prep_weight_f8(p.wk, WkP, D, D, 0, invs, st));
-        PCA_TRY(prep_weight_f8(p.wv, WvP, D, D, 0, invs + 1, st));
+      const float* inv_kv = invs;
+      if (f8) {              // (the engine's one-launch images of the step, when there are any)
+        void *wk8 = WkP, *wv8 = WvP;
+        float *ik = invs, *iv = invs + 1;
+        PCA_TRY(weight_image_f8(p.wk, &wk8, D, D, 0, &ik, st));
+        PCA_TRY(weight_image_f8(p.wv, &wv8, D, D, 0, &iv, st));
+        PCA_REQUIRE(iv == ik + 1, "mab0_d256_fwd: fp8 inverse scales of fc_k / fc_v must be adjacent");
+        WkP = reinterpret_cast<decltype(WkP)>(wk8);
+        WvP = reinterpret_cast<decltype(WvP)>(wv8);
+        inv_kv = ik;
       } else {
         PCA_TRY(weight_image2(p.wk, &WkP, 0, p.wv, &WvP, 0, D, D, st));
       }
@@ -420,7 +427,7 @@ int mab0_d256_fwd(const pca_mab_shape& s, const float* I, const void* X, const p
       ProfScope ps(PCA_K_MAB0_FWD, st, 2.0 * pts * (2.0 * D * D + 2.0 * m * D), pts * 2.0 * D);
       PCA_TRY(fq_proj_attn_fwd256(Xb, WkP, WvP, p.bk, p.bv, v.Qp, s.B, s.nk, m, s.k_lengths, v.Kp,
                                   v.Vp, v.Op, v.Mp, v.Lp, v.O, v.LSE, st,
-                                  f8 ? invs : nullptr));                      // modules.py:21,28-29
+                                  f8 ? inv_kv : nullptr));                    // modules.py:21,28-29
       ps.end();
     } else {
     if (s.mode == PCA_MODE_FP8) {           // fc_k / fc_v with fp8 e4m3 operands

@@ -56,10 +56,9 @@ __global__ void k_prep_weight(const float* __restrict__ src, __bf16* __restrict_
 // inv_scale[0] = 1 / s.  gridDim.x workgroups convert 4096 elements each; EVERY workgroup finds
 // the maximum of the whole tensor for itself (256 KiB of L2 reads, 16-byte loads, all in flight) -
 // the one-workgroup form walked the tensor twice with 64 dependent loads per thread: 20 us.
-__global__ __launch_bounds__(1024) void k_prep_weight_f8(const float* __restrict__ src,
-                                                         uint8_t* __restrict__ dst, int rows,
-                                                         int cols, int mode,
-                                                         float* __restrict__ inv_scale) {
+__device__ __forceinline__ void prep_weight_f8_body(const float* __restrict__ src,
+                                                    uint8_t* __restrict__ dst, int rows, int cols,
+                                                    int mode, float* __restrict__ inv_scale) {
   __shared__ float red[16];
   __shared__ float s_scale;
   const int tid = threadIdx.x, n = rows * cols;
@@ -102,6 +101,18 @@ __global__ __launch_bounds__(1024) void k_prep_weight_f8(const float* __restrict
     }
     *reinterpret_cast<uint32_t*>(dst + i0) = cvt4_f8(v[0], v[1], v[2], v[3]);
   }
+}
+__global__ __launch_bounds__(1024) void k_prep_weight_f8(const float* __restrict__ src,
+                                                         uint8_t* __restrict__ dst, int rows,
+                                                         int cols, int mode,
+                                                         float* __restrict__ inv_scale) {
+  prep_weight_f8_body(src, dst, rows, cols, mode, inv_scale);
+}
+// all fp8 weight images of a step in one launch (blockIdx.y = image)
+__global__ __launch_bounds__(1024) void k_prep_weight_f8_jobs(const PrepF8Jobs jobs) {
+  const WeightImages::F8 jb = jobs.j[blockIdx.y];
+  if ((int64_t)blockIdx.x * 4096 >= (int64_t)jb.rows * jb.cols) return;
+  prep_weight_f8_body(jb.src, jb.img, jb.rows, jb.cols, jb.mode, jb.inv);
 }
 
 __global__ void k_prep_jobs(const PrepJobs jobs) {
@@ -795,6 +806,30 @@ static __bf16* image_of(const float* src, int mode, int rows, int cols) {
   }
   return nullptr;
 }
+int prep_f8_jobs_launch(const PrepF8Jobs& J, hipStream_t st) {
+  if (J.n == 0) return PCA_OK;
+  int64_t maxe = 0;
+  for (int i = 0; i < J.n; ++i) {
+    const int64_t e = (int64_t)J.j[i].rows * J.j[i].cols;
+    maxe = e > maxe ? e : maxe;
+  }
+  hipLaunchKernelGGL(k_prep_weight_f8_jobs, dim3((unsigned)cdiv(maxe, 4096), (unsigned)J.n), dim3(1024),
+                     0, st, J);
+  return check_launch("k_prep_weight_f8_jobs");
+}
+int weight_image_f8(const float* src, void** dst, int rows, int cols, int mode, float** inv,
+                    hipStream_t st) {
+  if (t_images != nullptr)
+    for (int i = 0; i < t_images->nf8; ++i) {
+      const WeightImages::F8& e = t_images->f8[i];
+      if (e.src == src && e.mode == mode && e.rows == rows && e.cols == cols) {
+        *dst = e.img;
+        *inv = e.inv;
+        return PCA_OK;
+      }
+    }
+  return prep_weight_f8(src, *dst, rows, cols, mode, *inv, st);
+}
 int weight_image1(const float* src, __bf16** dst, int rows, int cols, int mode, hipStream_t st) {
   if (__bf16* im = image_of(src, mode, rows, cols)) { *dst = im; return PCA_OK; }
   return prep_weight(src, *dst, rows, cols, mode, st);
@@ -893,6 +928,7 @@ int mab1_bf16_fwd_ex(const pca_mab_shape& s, const void* X, const float* H,
   float* Kf = s.d > 128 ? cw.take<float>((size_t)s.B * s.nk * s.d) : nullptr;
   float* Vf = s.d > 128 ? cw.take<float>((size_t)s.B * s.nk * s.d) : nullptr;
   float* invs = cw.take<float>(2);      // fp8 mode: inverse scales of the two weight images
+  float* inv_o = invs + 1;
   Mab1Saved v;
   const bool training = saved != nullptr;
   mab1_carve_saved(s, &v, training ? saved : (void*)(cw.base + cw.off));
@@ -915,8 +951,15 @@ int mab1_bf16_fwd_ex(const pca_mab_shape& s, const void* X, const float* H,
     // fp8 images of s * Wq (natural) and s * Wo (K-permuted; natural for the single-launch kernel);
     // bf16 image of Wq when it stays bf16
     if (!small && f8_q) PCA_TRY(prep_weight_f8(p.wq, WqB, d, d, 0, invs, st));
-    else if (!small) PCA_TRY(prep_weight(p.wq, WqB, d, d, 0, st));
-    PCA_TRY(prep_weight_f8(p.wo, WoP, d, d, f8_fused ? 0 : 1, invs + 1, st));
+    else if (!small) PCA_TRY(weight_image1(p.wq, &WqB, d, d, 0, st));
+    if (f8_fused) {          // (the single-launch kernel takes its inverse scale by pointer: the engine's
+                             //  one-launch image of the step, when there is one)
+      void* wo8 = WoP;
+      PCA_TRY(weight_image_f8(p.wo, &wo8, d, d, 0, &inv_o, st));
+      WoP = reinterpret_cast<decltype(WoP)>(wo8);
+    } else {
+      PCA_TRY(prep_weight_f8(p.wo, WoP, d, d, 1, invs + 1, st));
+    }
   } else if (img != nullptr) {
     WqB = img->WqB;
     WoP = img->WoP;
@@ -995,7 +1038,7 @@ int mab1_bf16_fwd_ex(const pca_mab_shape& s, const void* X, const float* H,
     if (f8_fused)
       return isab1_fwd256_fused(X, s.dq, WqB, p.wq, p.bq, v.KpP, v.Vt, WoP, p.bo,
                                 reinterpret_cast<__bf16*>(Y), a.QpS, training ? v.OS : nullptr,
-                                a.mask, s.B, s.nq, st, invs + 1);
+                                a.mask, s.B, s.nq, st, inv_o);
     if (abf && !f8 && fused256) {
       // one launch: wave = head, both weight slices in registers (d256_fused.hip)
       if (img != nullptr) PCA_TRY(prep_weight(p.wo, WoP, d, d, 0, st));   // natural image for this kernel

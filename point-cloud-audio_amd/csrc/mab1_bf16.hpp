@@ -150,7 +150,19 @@ int prep_jobs_launch(const PrepJobs& jobs, hipStream_t st);
 struct WeightImages {
   struct E { const float* src; int mode, rows, cols; __bf16* img; } e[24];
   int n;
+  // fp8 mode: e4m3 images of s * W (prep_weight_f8) with their inverse scales, one launch for all
+  struct F8 { const float* src; int mode, rows, cols; uint8_t* img; float* inv; } f8[8];
+  int nf8;
 };
+struct PrepF8Jobs {
+  WeightImages::F8 j[8];
+  int n;
+};
+int prep_f8_jobs_launch(const PrepF8Jobs& J, hipStream_t st);
+// the registered fp8 image of (src, mode) - *dst and *inv are redirected to it - or a conversion into
+// *dst / *inv on the spot
+int weight_image_f8(const float* src, void** dst, int rows, int cols, int mode, float** inv,
+                    hipStream_t st);
 void weight_images_use(const WeightImages* t);       // thread-local; nullptr ends the scope
 int weight_image1(const float* src, __bf16** dst, int rows, int cols, int mode, hipStream_t st);
 int weight_image2(const float* src0, __bf16** dst0, int mode0, const float* src1, __bf16** dst1,

@@ -134,6 +134,8 @@ struct Ws {
   float* wg_slabs;           // weight-gradient partials of the deferred reductions (fused d = 128)
   size_t wg_slab_bytes;
   __bf16* img256;            // d = 256: 24 weight images [256][256] prepared in one launch per step
+  uint8_t* img256f8;         // d = 256, fp8 mode: e4m3 weight images of the step (one launch) ...
+  float* inv256f8;           // ... and their inverse scales
   void* wg256_def;           // d = 256: slabs of the deferred [B*m]-row weight-gradient launch
   void* scratch_m0;          // d = 256: enc.0's few-queries backward (its ISAB partner's [B*m]-row
                              // operands in scratch_bw[0] stay in place until that launch)
@@ -193,8 +195,12 @@ inline size_t carve(const pca_st_config& c, int training, Ws* out, void* base) {
     w.wg_slab_bytes = 2 * (size_t)slab_mb * 1024 * 1024;
     w.wg_slabs = cv.take<float>(w.wg_slab_bytes / sizeof(float));
   }
-  if (training && c.d == 256 && c.mode == PCA_MODE_BF16)
+  if (training && c.d == 256 && (c.mode == PCA_MODE_BF16 || c.mode == PCA_MODE_FP8))
     w.img256 = cv.take<__bf16>((size_t)24 * 256 * 256);
+  if (training && c.d == 256 && c.mode == PCA_MODE_FP8) {
+    w.img256f8 = cv.take<uint8_t>((size_t)8 * 256 * 256);
+    w.inv256f8 = cv.take<float>(16);
+  }
   w.scratch_m0 = w.scratch_bw[0];
   if (training && c.d == 256 && mab_kind(s.m0[0]) == 2 && mab_kind(s.m1[0]) == 1) {
     w.wg256_def = cv.take<char>(wgrad256_ws_bytes(8, (int64_t)c.B * c.m));
@@ -234,8 +240,30 @@ inline int images256_prepare(const pca_st_config& c, const Layout& L, const Shap
       add(pk.wk, d256_bwd_kv_mode()); add(pk.wv, d256_bwd_kv_mode());
     }
   }
-  (void)c;
-  return launch ? prep_jobs_launch(J, st) : PCA_OK;
+  // fp8 mode: the e4m3 images of the forward projections (fc_o of the many-queries blocks, fc_k / fc_v of
+  // the d -> d few-queries block; natural layout: a block that wants another one converts its own)
+  PrepF8Jobs F{};
+  tab->nf8 = 0;
+  if (c.mode == PCA_MODE_FP8 && w.img256f8 != nullptr) {
+    auto add8 = [&](const float* src, int slot) {       // slot: index of the inverse scale
+      if (tab->nf8 >= 8) return;
+      const WeightImages::F8 e{src, 0, 256, 256, w.img256f8 + (size_t)tab->nf8 * 256 * 256,
+                               w.inv256f8 + slot};
+      tab->f8[tab->nf8++] = e;
+      F.j[F.n++] = e;
+    };
+    for (int li = 0; li < 2; ++li) {
+      if (mab_kind(s.m1[li]) == 1 && s.m1[li].d == 256 && s.m1[li].nk == 32)
+        add8(params_at(p, L.mab1[li]).wo, 4 * li + 1);                 // [., o]
+      if (mab_kind(s.m0[li]) == 2 && s.m0[li].d == 256 && s.m0[li].dk == 256) {
+        add8(params_at(p, L.mab0[li]).wk, 4 * li + 2);                 // [k, v]: adjacent
+        add8(params_at(p, L.mab0[li]).wv, 4 * li + 3);
+      }
+    }
+  }
+  if (!launch) return PCA_OK;
+  PCA_TRY(prep_jobs_launch(J, st));
+  return prep_f8_jobs_launch(F, st);
 }
 
 // PCA_D256_DEFER_POSTS=0: the d = 256 few-queries blocks run their post stages per block
