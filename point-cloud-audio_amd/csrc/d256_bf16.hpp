@@ -64,6 +64,10 @@ void mid256_arm(const pca_mab_shape* s1, const pca_mab_params* p1, void* saved1)
 bool mid256_kv_ready();
 int mab0_d256_prep_all(int n, const pca_mab_shape* const* shapes, const float* const* I,
                        const pca_mab_params* params, void* const* saved, hipStream_t st);
+// ... or only collected into `out`, for a launch the caller makes together with other preparation jobs
+struct Mab0PrepJobs;
+void mab0_d256_prep_collect(int n, const pca_mab_shape* const* shapes, const float* const* I,
+                            const pca_mab_params* params, void* const* saved, Mab0PrepJobs* out);
 void mab0_d256_prep_done(bool on);
 // image modes the d = 256 backward asks for (fc_o / fc_q of the many-queries block, fc_k / fc_v of
 // the few-queries block): they follow the A/B switches of d256_host.hip

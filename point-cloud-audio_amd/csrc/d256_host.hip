@@ -347,6 +347,14 @@ int mab0_d256_prep_all(int n, const pca_mab_shape* const* shapes, const float* c
   }
   return mab0_prep_launch(J, st);
 }
+void mab0_d256_prep_collect(int n, const pca_mab_shape* const* shapes, const float* const* I,
+                            const pca_mab_params* params, void* const* saved, Mab0PrepJobs* out) {
+  for (int i = 0; i < n; ++i) {
+    Fq256Saved v;
+    fq_carve_saved(*shapes[i], &v, saved[i]);
+    out->j[out->n++] = fq_prep_job(*shapes[i], I[i], params[i], v);
+  }
+}
 void mab0_d256_prep_done(bool on) { g_prep256_done = on; }
 
 // operand mode of fc_o (and its adjoint) on the [B*m] query rows of a few-queries block:

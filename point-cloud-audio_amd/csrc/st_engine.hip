@@ -213,8 +213,11 @@ inline size_t carve(const pca_st_config& c, int training, Ws* out, void* base) {
 // Every bf16 weight image the d = 256 blocks of a training step ask for (weight_image1 / 2 in
 // mab1_bf16.hip, d256_host.hip), registered in `tab`; launch != 0 also converts them, all in one
 // launch.  A request this list does not foresee is converted on the spot by the block itself.
+// (jobs_out != nullptr: the bf16 image jobs are handed to the caller, who launches them together with the
+//  step's other preparation work - forward() -, instead of being launched here)
 inline int images256_prepare(const pca_st_config& c, const Layout& L, const Shapes& s, const float* p,
-                             const Ws& w, WeightImages* tab, bool launch, hipStream_t st) {
+                             const Ws& w, WeightImages* tab, bool launch, hipStream_t st,
+                             PrepJobs* jobs_out = nullptr) {
   tab->n = 0;
   static const bool off = [] { const char* e = getenv("PCA_D256_IMAGES"); return e && e[0] == '0'; }();
   if (w.img256 == nullptr || off) return PCA_OK;       // (PCA_D256_IMAGES=0: per-block conversions)
@@ -262,7 +265,8 @@ inline int images256_prepare(const pca_st_config& c, const Layout& L, const Shap
     }
   }
   if (!launch) return PCA_OK;
-  PCA_TRY(prep_jobs_launch(J, st));
+  if (jobs_out != nullptr) *jobs_out = J;
+  else PCA_TRY(prep_jobs_launch(J, st));
   return prep_f8_jobs_launch(F, st);
 }
 
@@ -288,10 +292,19 @@ int validate(const pca_st_config* c) {
 }
 
 int forward(const pca_st_config& c, const Layout& L, const Shapes& s, const float* p,
-            const float* X, Ws& w, bool training, hipStream_t st) {
+            const float* X, Ws& w, bool training, hipStream_t st, const PrepJobs* image_jobs = nullptr) {
   const void* in = X;
+  // d = 256: the query side of all three few-queries blocks in the same launch (mab0_d256_prep_collect)
+  const bool prep256 = training && s.m0[0].d == 256 && mab_kind(s.m0[0]) == 2 &&
+                       mab_kind(s.m0[1]) == 2 && mab_kind(s.pma) == 2 && !pma_head_ok(s);
+  struct PrepGuard {
+    bool on;
+    explicit PrepGuard(bool o) : on(o) {}
+    ~PrepGuard() { if (on) mab0_d256_prep_done(false); }
+  } prep_guard(prep256);
   if (training) {               // all weight images of the step in ONE launch
     PrepJobs J{};
+    if (image_jobs != nullptr) J = *image_jobs;      // (d = 256: the step's image table, images256_prepare)
     for (int li = 0; li < 2; ++li)
       if (w.fused[li])
         isab_collect_prep(s.m0[li], params_at(p, L.mab0[li]), params_at(p, L.mab1[li]),
@@ -310,26 +323,18 @@ int forward(const pca_st_config& c, const Layout& L, const Shapes& s, const floa
       mab0_carve_saved(s.pma, &v, w.saved[4]);
       mab0_collect_prep(s.pma, p + L.S, params_at(p, L.pma), v, true, true, &MJ);
     }
+    if (prep256) {
+      const pca_mab_shape* sh[3] = {&s.m0[0], &s.m0[1], &s.pma};
+      const float* Iq[3] = {p + L.I[0], p + L.I[1], p + L.S};
+      const pca_mab_params pr[3] = {params_at(p, L.mab0[0]), params_at(p, L.mab0[1]),
+                                    params_at(p, L.pma)};
+      void* sv[3] = {w.saved[0], w.saved[2], w.saved[4]};
+      mab0_d256_prep_collect(3, sh, Iq, pr, sv, &MJ);
+    }
     PCA_TRY(prep_all_launch(J, MJ, st));    // (takes a deferred pack along: pca_pack_defer)
+    if (prep256) mab0_d256_prep_done(true);
   }
   PCA_TRY(pack_flush(st));                  // a deferred pack nobody took runs now, before X is read
-  // d = 256: the query side of all three few-queries blocks in one launch (mab0_d256_prep_all)
-  const bool prep256 = training && s.m0[0].d == 256 && mab_kind(s.m0[0]) == 2 &&
-                       mab_kind(s.m0[1]) == 2 && mab_kind(s.pma) == 2 && !pma_head_ok(s);
-  struct PrepGuard {
-    bool on;
-    explicit PrepGuard(bool o) : on(o) {}
-    ~PrepGuard() { if (on) mab0_d256_prep_done(false); }
-  } prep_guard(prep256);
-  if (prep256) {
-    const pca_mab_shape* sh[3] = {&s.m0[0], &s.m0[1], &s.pma};
-    const float* Iq[3] = {p + L.I[0], p + L.I[1], p + L.S};
-    const pca_mab_params pr[3] = {params_at(p, L.mab0[0]), params_at(p, L.mab0[1]),
-                                  params_at(p, L.pma)};
-    void* sv[3] = {w.saved[0], w.saved[2], w.saved[4]};
-    PCA_TRY(mab0_d256_prep_all(3, sh, Iq, pr, sv, st));
-    mab0_d256_prep_done(true);
-  }
   for (int li = 0; li < 2; ++li) {
     void* sv0 = training ? w.saved[2 * li] : nullptr;
     void* sv1 = training ? w.saved[2 * li + 1] : nullptr;
@@ -441,7 +446,8 @@ int pca_st_train_fwd_bwd(const pca_st_config* c, const float* params, const floa
     explicit ImagesGuard(const pca::WeightImages* t) { pca::weight_images_use(t); }
     ~ImagesGuard() { pca::weight_images_use(nullptr); }
   };
-  PCA_TRY(pca::images256_prepare(*c, L, s, p, w, &images, phase != 1, st));
+  pca::PrepJobs image_jobs{};
+  PCA_TRY(pca::images256_prepare(*c, L, s, p, w, &images, phase != 1, st, &image_jobs));
   ImagesGuard images_guard(images.n > 0 ? &images : nullptr);
   // d = 256: the [B*m]-row weight-gradient jobs of all five blocks in one launch at the flush -
   // needs every block's operands in place until then: the hand-over form of enc.1 (its few-queries
@@ -452,7 +458,7 @@ int pca_st_train_fwd_bwd(const pca_st_config* c, const float* params, const floa
                         pca::mab_kind(s.pma) == 2 && s.pma.d == 256;
   if (defer_wg) posts.wg256_ws = w.wg256_def;
   if (phase != 1) {
-    PCA_TRY(pca::forward(*c, L, s, p, X, w, true, st));
+    PCA_TRY(pca::forward(*c, L, s, p, X, w, true, st, &image_jobs));
     if (pca::pma_head_ok(s)) {
       // dec.0 epilogue + dec.1 (Linear) + mean cross-entropy forward and backward + dec.0
       // backward epilogue: one launch, one workgroup per set
