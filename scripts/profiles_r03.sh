@@ -12,10 +12,10 @@ if [ $PART = bench ] || [ $PART = all ]; then
   python3 $R/bench.py > $O/bf16_cfg2_bench.json 2> $O/bf16_cfg2_bench.err
   python3 $R/bench.py --mode f32 --no-cpu-baseline > $O/f32_cfg2_bench.json 2>> $O/bench.err
   python3 $R/bench.py --config cfg3 --no-cpu-baseline > $O/bf16_cfg3_bench.json 2>> $O/bench.err
-  python3 $R/bench.py --config cfg4 --steps 50 --warmup 5 --no-cpu-baseline > $O/bf16_cfg4_bench.json 2>> $O/bench.err
-  python3 $R/bench.py --config cfg4 --mode fp8 --steps 50 --warmup 5 --no-cpu-baseline > $O/fp8_cfg4_bench.json 2>> $O/bench.err
-  python3 $R/bench.py --config cfg5 --steps 50 --warmup 5 --no-cpu-baseline > $O/bf16_cfg5_bench.json 2>> $O/bench.err
-  python3 $R/bench.py --config cfg5 --mode fp8 --steps 50 --warmup 5 --no-cpu-baseline > $O/fp8_cfg5_bench.json 2>> $O/bench.err
+  python3 $R/bench.py --config cfg4 --steps 50 --warmup 60 --no-cpu-baseline > $O/bf16_cfg4_bench.json 2>> $O/bench.err
+  python3 $R/bench.py --config cfg4 --mode fp8 --steps 50 --warmup 60 --no-cpu-baseline > $O/fp8_cfg4_bench.json 2>> $O/bench.err
+  python3 $R/bench.py --config cfg5 --steps 50 --warmup 60 --no-cpu-baseline > $O/bf16_cfg5_bench.json 2>> $O/bench.err
+  python3 $R/bench.py --config cfg5 --mode fp8 --steps 50 --warmup 60 --no-cpu-baseline > $O/fp8_cfg5_bench.json 2>> $O/bench.err
   python3 $R/bench.py --batch 1024 --steps 50 --warmup 5 --no-cpu-baseline > $O/bf16_cfg2_B1024_bench.json 2>> $O/bench.err
   python3 $R/bench.py --config fst --steps 20 --warmup 3 --no-cpu-baseline --no-roofline > $O/bf16_fst_bench.json 2>> $O/bench.err
   (python3 $R/scripts/infer_bench.py fst 128; python3 $R/scripts/infer_bench.py 3st 16; python3 $R/scripts/infer_bench.py fst 8; python3 $R/scripts/infer_bench.py 3st 8) > $O/infer.txt 2>> $O/bench.err
