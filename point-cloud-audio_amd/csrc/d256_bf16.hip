@@ -2813,12 +2813,12 @@ __global__ __launch_bounds__(256, 1) void k_pma_fwd256(const PmaArgs a) {
     for (int e = 0; e < 16; ++e) {
       const int c = lane + 64 * e, row = c >> 5, ch = c & 31;
       const int nr = n0 + row;
+      // (rows past the end of the range read its last row and are zeroed when the tile goes to LDS,
+      //  one iteration later: zeroed here, hipcc waits for every load right behind its issue -
+      //  vmcnt(15) ... vmcnt(0) - and the tile that was meant to arrive during the current tile's
+      //  arithmetic is waited for before that arithmetic starts)
       nx[e] = *reinterpret_cast<const bf16x8*>(
           a.X + ((int64_t)b * a.N + (nr < n_hi ? nr : n_hi - 1)) * DK + ch * 8);
-      if (nr >= n_hi) {
-#pragma unroll
-        for (int k = 0; k < 8; ++k) nx[e][k] = (__bf16)0.f;
-      }
     }
   };
   if (n_lo + wave * 32 < n_hi) fetch_tile(n_lo + wave * 32);
@@ -2826,7 +2826,12 @@ __global__ __launch_bounds__(256, 1) void k_pma_fwd256(const PmaArgs a) {
 #pragma unroll
     for (int e = 0; e < 16; ++e) {
       const int c = lane + 64 * e, row = c >> 5, ch = c & 31;
-      *reinterpret_cast<bf16x8*>(myX + tr_off256(row, ch)) = nx[e];
+      bf16x8 v = nx[e];
+      if (n0 + row >= n_hi) {
+#pragma unroll
+        for (int k = 0; k < 8; ++k) v[k] = (__bf16)0.f;
+      }
+      *reinterpret_cast<bf16x8*>(myX + tr_off256(row, ch)) = v;
     }
     if (n0 + 128 < n_hi) fetch_tile(n0 + 128);
     f32x4 s[2];
@@ -3069,12 +3074,12 @@ __global__ __launch_bounds__(256, 1) void k_pma_bwd256(const PmaArgs a) {
     for (int e = 0; e < 16; ++e) {
       const int c = lane + 64 * e, row = c >> 5, ch = c & 31;
       const int nr = n0 + row;
+      // (rows past the end of the range read its last row and are zeroed when the tile goes to LDS,
+      //  one iteration later: zeroed here, hipcc waits for every load right behind its issue -
+      //  vmcnt(15) ... vmcnt(0) - and the tile that was meant to arrive during the current tile's
+      //  arithmetic is waited for before that arithmetic starts)
       nx[e] = *reinterpret_cast<const bf16x8*>(
           a.X + ((int64_t)b * a.N + (nr < n_hi ? nr : n_hi - 1)) * DK + ch * 8);
-      if (nr >= n_hi) {
-#pragma unroll
-        for (int k = 0; k < 8; ++k) nx[e][k] = (__bf16)0.f;
-      }
     }
   };
   if (n_lo + wave * 32 < n_hi) fetch_tile(n_lo + wave * 32);
@@ -3082,7 +3087,12 @@ __global__ __launch_bounds__(256, 1) void k_pma_bwd256(const PmaArgs a) {
 #pragma unroll
     for (int e = 0; e < 16; ++e) {
       const int c = lane + 64 * e, row = c >> 5, ch = c & 31;
-      *reinterpret_cast<bf16x8*>(myX + tr_off256(row, ch)) = nx[e];
+      bf16x8 v = nx[e];
+      if (n0 + row >= n_hi) {
+#pragma unroll
+        for (int k = 0; k < 8; ++k) v[k] = (__bf16)0.f;
+      }
+      *reinterpret_cast<bf16x8*>(myX + tr_off256(row, ch)) = v;
     }
     if (n0 + 128 < n_hi) fetch_tile(n0 + 128);
     bf16x8 pds[2];                          // B operand [k = (P rows | dS rows)][col = point]
