@@ -398,15 +398,28 @@ __global__ __launch_bounds__(256, 1) void k_mab0_attn(const Mab0AttnArgs a) {
     for (int ft = 0; ft < FT; ++ft) T[rb][ft] = f32x4{0.f, 0.f, 0.f, 0.f};
   }
 
+  // bf16 activations: the wave's next X tile is fetched into registers while the current one is worked
+  // on (as k_mab0_bwd does; every tile used to start with an exposed round trip to memory)
+  bf16x8 nx[8];
+  auto fetch_tile = [&](int n0) {
+#pragma unroll
+    for (int e = 0; e < 8; ++e) {
+      const int c = lane + 64 * e;
+      nx[e] = ld_x8_clamped(a.X, (int64_t)b * a.N, n0 + (c >> 4), n_hi, DK, c & 15);
+    }
+  };
+  if (ABF && n_lo + wave * 32 < n_hi) fetch_tile(n_lo + wave * 32);
   for (int n0 = n_lo + wave * 32; n0 < n_hi; n0 += 128) {
     // stage 32 rows of X (fp32 -> bf16)
 #pragma unroll
     for (int e = 0; e < 8; ++e) {
       const int c = lane + 64 * e;
       const int row = c >> 4, ch = c & 15;
-      const bf16x8 v = ld_x8_guard<ABF>(a.X, (int64_t)b * a.N, n0 + row, n_hi, DK, ch);
+      const bf16x8 v = ABF ? zero_unless(n0 + row < n_hi, nx[e])
+                           : ld_x8_guard<ABF>(a.X, (int64_t)b * a.N, n0 + row, n_hi, DK, ch);
       *reinterpret_cast<bf16x8*>(myX + tr_off(row, ch)) = v;
     }
+    if (ABF && n0 + 128 < n_hi) fetch_tile(n0 + 128);
     bf16x8 xrow[2][KS], xtr[FT];
 #pragma unroll
     for (int pb = 0; pb < 2; ++pb)

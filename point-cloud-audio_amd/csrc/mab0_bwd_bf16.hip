@@ -176,7 +176,9 @@ __global__ __launch_bounds__(256, 1) void k_mab0_bwd(const Mab0BwdArgs a) {
 #pragma unroll
     for (int e = 0; e < 8; ++e) {
       const int c = lane + 64 * e;
-      nx[e] = ld_x8_guard<ABF>(a.X, (int64_t)b * a.N, n0 + (c >> 4), n_hi, DK, c & 15);
+      // (bf16 activations: zeroed when the tile goes to LDS, see ld_x8_clamped)
+      nx[e] = ABF ? ld_x8_clamped(a.X, (int64_t)b * a.N, n0 + (c >> 4), n_hi, DK, c & 15)
+                  : ld_x8_guard<ABF>(a.X, (int64_t)b * a.N, n0 + (c >> 4), n_hi, DK, c & 15);
     }
   };
   if (n_lo + wave * 32 < n_hi) fetch_tile(n_lo + wave * 32);
@@ -185,7 +187,7 @@ __global__ __launch_bounds__(256, 1) void k_mab0_bwd(const Mab0BwdArgs a) {
     for (int e = 0; e < 8; ++e) {
       const int c = lane + 64 * e;
       const int row = c >> 4, ch = c & 15;
-      *reinterpret_cast<bf16x8*>(myX + tr_off(row, ch)) = nx[e];
+      *reinterpret_cast<bf16x8*>(myX + tr_off(row, ch)) = zero_unless(n0 + row < n_hi, nx[e]);
     }
     if (n0 + 128 < n_hi) fetch_tile(n0 + 128);
     // the rows this tile's dX is added onto (mab1's dQ part) are fetched now, a whole tile of work

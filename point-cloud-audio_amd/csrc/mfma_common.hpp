@@ -126,6 +126,22 @@ __device__ __forceinline__ bf16x8 ld_x8_guard(const void* X, int64_t set_row0, i
   return v;
 }
 
+// The same load WITHOUT the zeroing (ABF only): for a register prefetch the zeroing has to wait until
+// the registers are consumed - applied right behind the load it makes hipcc wait for the load there,
+// and the tile that was meant to arrive during the current tile's arithmetic is waited for before it.
+__device__ __forceinline__ bf16x8 ld_x8_clamped(const void* X, int64_t set_row0, int n, int n_hi,
+                                                int DK, int ch) {
+  const int64_t row = set_row0 + (n < n_hi ? n : n_hi - 1);
+  return *reinterpret_cast<const bf16x8*>(reinterpret_cast<const __bf16*>(X) + row * DK + ch * 8);
+}
+__device__ __forceinline__ bf16x8 zero_unless(bool ok, bf16x8 v) {
+  if (!ok) {
+#pragma unroll
+    for (int k = 0; k < 8; ++k) v[k] = (__bf16)0.f;
+  }
+  return v;
+}
+
 // A chunk of cn <= 1024 points with dk (<= 4) fp32 components each, contiguous in memory, into LDS as
 // [pair of points][component][2] (the operand pairs of the packed-fp32 loops of k_mab0_attn_small /
 // k_mab0_bwd_small), unused components and the odd point zero - in two halves, so that the loads of
