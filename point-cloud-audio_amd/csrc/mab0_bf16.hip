@@ -564,11 +564,11 @@ __global__ __launch_bounds__(256) void k_mab0_attn_h4(const Mab0AttnArgs a) {
       const int c = tid + 256 * e;
       const int row = c >> 4, ch = c & 15;
       const int n = n0 + row;
-      // (guarded on purpose - the prefetch already runs a tile ahead, and the unconditional form
-      //  of ld_x8_guard measured 7 % slower here)
-      if (n < n_hi && ABF) {
-        v[e] = *reinterpret_cast<const bf16x8*>(reinterpret_cast<const __bf16*>(a.X) +
-                                                ((int64_t)b * a.N + n) * DK + ch * 8);
+      // (bf16: unconditional clamped loads, rows past the range zeroed by stash() - zeroed here, or
+      //  loaded under the divergent `if`, every load is waited for where it is issued and nothing
+      //  arrives under the current tile's arithmetic)
+      if (ABF) {
+        v[e] = ld_x8_clamped(a.X, (int64_t)b * a.N, n, n_hi, DK, ch);
       } else if (n < n_hi) {
         const float4* src = reinterpret_cast<const float4*>(
             reinterpret_cast<const float*>(a.X) + ((int64_t)b * a.N + n) * DK + ch * 8);
@@ -581,17 +581,17 @@ __global__ __launch_bounds__(256) void k_mab0_attn_h4(const Mab0AttnArgs a) {
       }
     }
   };
-  auto stash = [&](int buf) {
+  auto stash = [&](int buf, int n0) {          // n0: first point of the tile fetch() was given
 #pragma unroll
     for (int e = 0; e < 4; ++e) {
       const int c = tid + 256 * e;
       const int row = c >> 4, ch = c & 15;
       *reinterpret_cast<bf16x8*>(sX + ((buf * 2 + (row >> 5)) * 32) * 256 + tr_off(row & 31, ch)) =
-          v[e];
+          ABF ? zero_unless(n0 + row < n_hi, v[e]) : v[e];
     }
   };
   fetch(n_lo);
-  stash(0);
+  stash(0, n_lo);
   __syncthreads();
   bf16x8 gf[KS];                    // this head's G rows: B operand of the score MFMAs
 #pragma unroll
@@ -653,7 +653,7 @@ __global__ __launch_bounds__(256) void k_mab0_attn_h4(const Mab0AttnArgs a) {
         T[ft] = mfma32(pa, tr_frag(img, ft, lane), T[ft]);
       }
     }
-    if (more) stash(buf ^ 1);
+    if (more) stash(buf ^ 1, n0 + TILE);
     __syncthreads();
   }
   const int64_t pbase = ((int64_t)b * a.S + sp) * a.R + 16 * wave;
