@@ -100,6 +100,7 @@ __global__ __launch_bounds__(256) void k_pack(const PackJob a) {
 
 thread_local bool t_pack_armed = false;
 thread_local PackJob t_pack_pending{};
+thread_local hipStream_t t_pack_stream = nullptr;   // stream the pending pack was submitted on
 
 int pack_launch(const PackJob& j, hipStream_t st) {
   hipLaunchKernelGGL(k_pack, dim3((unsigned)j.bx, (unsigned)j.B), dim3(256), 0, st, j);
@@ -110,6 +111,7 @@ int pack_submit(const PackJob& j, hipStream_t st) {
   if (t_pack_armed) {
     if (t_pack_pending.kind != 0) PCA_TRY(pack_launch(t_pack_pending, st));   // (never two pending)
     t_pack_pending = j;
+    t_pack_stream = st;
     return PCA_OK;
   }
   return pack_launch(j, st);
@@ -123,7 +125,10 @@ bool pack_take(PackJob* out) {
   t_pack_pending.kind = 0;
   return true;
 }
+// the documented contract of a deferred pack: consumed on the thread AND stream it was submitted on
+bool pack_stream_ok(hipStream_t st) { return t_pack_pending.kind == 0 || t_pack_stream == st; }
 int pack_flush(hipStream_t st) {
+  PCA_REQUIRE(pack_stream_ok(st), "deferred pack: submitted on another stream than the engine call's");
   PackJob j;
   return pack_take(&j) ? pack_launch(j, st) : PCA_OK;
 }
@@ -132,9 +137,13 @@ int pack_flush(hipStream_t st) {
 extern "C" {
 
 int pca_pack_defer(int on) {
-  PCA_REQUIRE(on != 0 || pca::t_pack_pending.kind == 0,
-              "pack_defer(0): a deferred pack was never consumed (no engine call followed it)");
+  // disarm FIRST: a pending job holds raw pointers to the caller's batch and must never ride a later
+  // engine call of this thread, whatever this call returns
+  const bool stale = on == 0 && pca::t_pack_pending.kind != 0;
   pca::t_pack_armed = on != 0;
+  if (on == 0) pca::t_pack_pending.kind = 0;
+  PCA_REQUIRE(!stale,
+              "pack_defer(0): a deferred pack was never consumed (no engine call followed it); dropped");
   return PCA_OK;
 }
 

@@ -835,6 +835,7 @@ int prep_all_launch(const PrepJobs& W, const Mab0PrepJobs& Q, hipStream_t st) {
   int gx = maxm + (spare ? PREP_SPARE : 0);
   const int gw = (int)cdiv(maxe, 256);
   gx = gx > gw ? gx : gw;
+  PCA_REQUIRE(pack_stream_ok(st), "deferred pack: submitted on another stream than the engine call's");
   PackJob P{};
   const int prows = pack_take(&P) ? (int)cdiv(pack_blocks(P), gx) : 0;
   hipLaunchKernelGGL(k_prep_all, dim3(gx, Q.n + W.n + prows), dim3(256), maxd * sizeof(float), st,

@@ -131,7 +131,9 @@ __device__ __forceinline__ bf16x8 ld_x8_guard(const void* X, int64_t set_row0, i
 // and the tile that was meant to arrive during the current tile's arithmetic is waited for before it.
 __device__ __forceinline__ bf16x8 ld_x8_clamped(const void* X, int64_t set_row0, int n, int n_hi,
                                                 int DK, int ch) {
-  const int64_t row = set_row0 + (n < n_hi ? n : n_hi - 1);
+  // (an empty range - n_hi == 0, a zero-length set - reads row 0 of the set, never row -1)
+  const int last = n_hi > 0 ? n_hi - 1 : 0;
+  const int64_t row = set_row0 + (n < n_hi ? n : last);
   return *reinterpret_cast<const bf16x8*>(reinterpret_cast<const __bf16*>(X) + row * DK + ch * 8);
 }
 __device__ __forceinline__ bf16x8 zero_unless(bool ok, bf16x8 v) {

@@ -63,6 +63,7 @@ __device__ __forceinline__ void pack_body(const PackJob& a, int block) {
 }
 
 // hand-off of a deferred pack (features.hip; thread-local like the library's other hand-offs)
+bool pack_stream_ok(hipStream_t st);  // the pending pack (if any) was submitted on `st`
 bool pack_take(PackJob* out);          // true: *out is the pending pack, now the caller's to launch
 int pack_flush(hipStream_t st);        // launches a pending pack on its own (no-op without one)
 

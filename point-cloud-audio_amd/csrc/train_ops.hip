@@ -145,6 +145,9 @@ __global__ __launch_bounds__(256) void k_adam(float* __restrict__ p, float* __re
     p[k] = w; m[k] = mm; v[k] = vv;
     if (zero_grad) g[k] = gg;
   }
+  // every wave of the workgroup has its step[0] (loaded at the top, consumed by the updates above)
+  // before thread 0 draws the ticket that may publish the next count
+  __syncthreads();
   if (threadIdx.x == 0) {
     const int ticket = atomicAdd(&step[1], 1);
     if (ticket == (int)gridDim.x - 1) {

@@ -280,9 +280,12 @@ class Trainer:
                     self.eng.grads.zero_()
                 self.eng.fwd_bwd(self.X, self.labels, phase=0 if self._split else -1,
                                  lengths=self.lengths)
-            finally:
-                if defer:
-                    check(lib().pca_pack_defer(0), "pca_pack_defer")
+            except BaseException:
+                if defer:            # disarm (drops a pending job) without masking the error in flight
+                    lib().pca_pack_defer(0)
+                raise
+            if defer:
+                check(lib().pca_pack_defer(0), "pca_pack_defer")
             return
         elif self.lengths is not None:
             self.ds.batch(self.idx, out=self.X, labels_out=self.labels,

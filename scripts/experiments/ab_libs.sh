@@ -7,6 +7,7 @@ cd $GRAFT_REPO_ROOT
 REPS=${1:-3}; shift; shift
 D=point-cloud-audio_amd/pca_hip
 cp $D/libpca_hip.so /tmp/lib_keep.so
+trap 'cp /tmp/lib_keep.so $D/libpca_hip.so' EXIT      # a failing command must not leave lib B installed
 for rep in $(seq $REPS); do
   for v in A B; do
     cp $D/ab/lib$v.so $D/libpca_hip.so
@@ -14,4 +15,3 @@ for rep in $(seq $REPS); do
     "$@"
   done
 done
-cp /tmp/lib_keep.so $D/libpca_hip.so
