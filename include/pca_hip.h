@@ -384,7 +384,9 @@ enum {
   PCA_K_MAB1_BWD = 3,      /* fused bf16 mab1 backward                         */
   PCA_K_MAB0_FWD = 4,      /* fused bf16 mab0 / PMA forward                    */
   PCA_K_MAB0_BWD = 5,
-  PCA_K_WGRAD = 6          /* bf16 weight-gradient GEMM                        */
+  PCA_K_WGRAD = 6,         /* bf16 weight-gradient GEMM                        */
+  PCA_K_SET_FWD = 7,       /* set-resident d = 128 forward (k_set128_fwd)      */
+  PCA_K_SET_BWD = 8        /* set-resident d = 128 backward                    */
 };
 int pca_prof_start(int kernel_id, int max_launches);
 int pca_prof_stop(double* total_ms, int64_t* launches, double* flops, double* bytes);

@@ -1,0 +1,53 @@
+// Set-resident kernels of the d = 128 / 4 heads / m = 16 / k = 1 train step (BASELINE configs[1]):
+// ONE workgroup carries a whole set through ISAB -> ISAB -> PMA (set_transformer-master/modules.py:
+// 51-53, 62-63 with :19-33 inside; Code/models.py:34-44), its [N, 128] activations resident in LDS.
+// Declarations shared by set128_fwd.hip and the ST engine.
+#pragma once
+#include "mab1_bf16.hpp"
+
+namespace pca {
+
+// everything one ISAB of the set-resident forward reads and writes (pointers into the engine's
+// weight images, the blocks' saved areas and the parameter vector; layouts are those the per-block
+// kernels use, so the backward kernels read what this forward saved)
+struct Set128Layer {
+  // mab0 = MAB(I, X): few shared queries
+  const float* Gf;        // [64][dk] fp32, sl2e folded in      (layer 1: dk = din <= 4)
+  const __bf16* Gb;       // [64][128] bf16                      (layer 2)
+  const float* Qp0;       // [16][128] fc_q(I)
+  const __bf16* Wv0;      // [128][128] natural bf16 image       (layer 2)
+  const float* Wv0f;      // [128][dk] fp32                      (layer 1)
+  const float *bv0, *bo0;
+  const __bf16* Wo0;      // natural
+  float *T, *LSE;         // saved: [B][64][dk], [B][64]
+  float *O0, *Z0, *H;     // [B][16][128] fp32
+  // mab1 = MAB(X, H): many queries
+  const __bf16 *Wk1, *Wv1;   // natural
+  const float *bk1, *bv1;
+  __bf16 *KpP, *VpP, *Kt, *Vt;
+  const __bf16* WqB;      // natural                              (layer 2)
+  const float* WqF;       // [128][dq] fp32                       (layer 1)
+  const float* bq1;
+  const __bf16* WoP;      // K-permuted
+  const float* bo1;
+  __bf16 *QpS, *OS, *Y;   // saved Qp (layer 2 only), saved O, the layer's output [B][N][128]
+  uint32_t* mask;         // ReLU mask words, mab1_mask_index<128> layout
+};
+
+struct Set128FwdArgs {
+  const float* X;         // [B][N][din] fp32
+  int B, N, din;
+  float scale_log2e;
+  Set128Layer L[2];
+  float *Tp2, *Mp2, *Lp2; // scratch: layer-2 attention partials [B][4][64][128], [B][4][64] x 2
+  const __bf16* Gpma;     // [>= 16][128] bf16, rows >= 4 zero
+  float *TpP, *MpP, *LpP; // PMA attention partials [B][Sp][4][128], [B][Sp][4] x 2 (read by k_pma_head1)
+  int Sp;                 // 1, 2 or 4
+};
+
+// N a multiple of 128, at most 512; din <= 4
+bool set128_shape_ok(int N, int din, int d, int h, int m, int k);
+size_t set128_fwd_ws_bytes(int B);
+int set128_fwd_launch(const Set128FwdArgs& a, hipStream_t st);
+
+}  // namespace pca

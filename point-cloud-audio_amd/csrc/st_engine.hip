@@ -7,6 +7,7 @@
 #include "mab1_bf16.hpp"
 #include "pack_body.hpp"
 #include "d256_bf16.hpp"
+#include "set128.hpp"
 
 namespace pca {
 
@@ -120,6 +121,16 @@ inline Shapes shapes(const pca_st_config& c, bool training, const int32_t* lengt
 // the PMA epilogue + classifier + loss launch (k_pma_head) exists for d = 128
 inline bool pma_head_ok(const Shapes& s) { return mab_kind(s.pma) == 2 && s.pma.d == 128; }
 
+// the set-resident forward (set128_fwd.hip) takes a training step whose blocks are all on the fused
+// d = 128 kernels, whose sets fit one workgroup's LDS and are dense (PCA_SET128=0: the per-block launches)
+inline bool set128_on(const pca_st_config& c, const Shapes& s) {
+  const char* e = getenv("PCA_SET128");          // (read per call: tests compare the two forms in-process)
+  const bool off = e != nullptr && e[0] == '0';
+  return !off && c.mode == PCA_MODE_BF16 && s.act_bf16 && set128_shape_ok(c.N, c.din, c.d, c.h, c.m, c.k) &&
+         isab_bf16_supported(s.m0[0], s.m1[0]) && isab_bf16_supported(s.m0[1], s.m1[1]) &&
+         pma_head_ok(s) && s.pma.k_lengths == nullptr;
+}
+
 struct Ws {
   void* saved[5];            // mab0[0], mab1[0], mab0[1], mab1[1], pma
   float *H[2], *Y[2], *P, *logits, *dlogits;
@@ -166,6 +177,10 @@ inline size_t carve(const pca_st_config& c, int training, Ws* out, void* base) {
       char* ib = cv.take<char>(isab_img_bytes());
       if (base != nullptr) isab_img_carve(ib, &w.img[li]);
     }
+  }
+  if (training && set128_shape_ok(c.N, c.din, c.d, c.h, c.m, c.k)) {
+    const size_t sb = set128_fwd_ws_bytes(c.B);
+    max_scratch = sb > max_scratch ? sb : max_scratch;
   }
   const size_t BN = (size_t)c.B * c.N, Bm = (size_t)c.B * c.m;
   w.H[0] = cv.take<float>(Bm * c.d);
@@ -335,6 +350,35 @@ int forward(const pca_st_config& c, const Layout& L, const Shapes& s, const floa
     if (prep256) mab0_d256_prep_done(true);
   }
   PCA_TRY(pack_flush(st));                  // a deferred pack nobody took runs now, before X is read
+  if (training && set128_on(c, s)) {
+    // one launch: both ISABs and the PMA's attention partials, the set resident in one workgroup's LDS
+    Set128FwdArgs a{};
+    a.X = X; a.B = c.B; a.N = c.N; a.din = c.din;
+    a.scale_log2e = 1.4426950408889634f / sqrtf((float)c.d);
+    for (int li = 0; li < 2; ++li) {
+      Mab0Saved v0;
+      mab0_carve_saved(s.m0[li], &v0, w.saved[2 * li]);
+      Mab1Saved v1;
+      mab1_carve_saved(s.m1[li], &v1, w.saved[2 * li + 1]);
+      const pca_mab_params p0 = params_at(p, L.mab0[li]), p1 = params_at(p, L.mab1[li]);
+      const IsabImg& im = w.img[li];
+      Set128Layer& S = a.L[li];
+      S.Gf = v0.Gf; S.Gb = v0.Gb; S.Qp0 = v0.Qp; S.Wv0 = im.Wv0; S.Wv0f = p0.wv; S.bv0 = p0.bv;
+      S.bo0 = p0.bo; S.Wo0 = im.Wo0; S.T = v0.T; S.LSE = v0.LSE; S.O0 = v0.O; S.Z0 = v0.Z; S.H = w.H[li];
+      S.Wk1 = im.Wk1; S.Wv1 = im.Wv1; S.bk1 = p1.bk; S.bv1 = p1.bv;
+      S.KpP = v1.KpP; S.VpP = v1.VpP; S.Kt = v1.Kt; S.Vt = v1.Vt;
+      S.WqB = im.WqB; S.WqF = p1.wq; S.bq1 = p1.bq; S.WoP = im.WoP; S.bo1 = p1.bo;
+      S.QpS = v1.QpS; S.OS = v1.OS; S.Y = reinterpret_cast<__bf16*>(w.Y[li]); S.mask = v1.mask;
+    }
+    Carver cs(w.scratch);
+    a.Tp2 = cs.take<float>((size_t)c.B * 4 * 64 * 128);
+    a.Mp2 = cs.take<float>((size_t)c.B * 4 * 64);
+    a.Lp2 = cs.take<float>((size_t)c.B * 4 * 64);
+    Mab0Saved vp;
+    mab0_carve_saved(s.pma, &vp, w.saved[4]);
+    a.Gpma = vp.Gb; a.TpP = vp.Tp; a.MpP = vp.Mp; a.LpP = vp.Lp; a.Sp = mab0_splits(s.pma);
+    return set128_fwd_launch(a, st);
+  }
   for (int li = 0; li < 2; ++li) {
     void* sv0 = training ? w.saved[2 * li] : nullptr;
     void* sv1 = training ? w.saved[2 * li + 1] : nullptr;

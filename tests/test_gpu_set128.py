@@ -1,0 +1,93 @@
+"""The set-resident forward of the d = 128 / 4 heads / m = 16 train step (csrc/set128_fwd.hip: one
+workgroup carries a set through ISAB -> ISAB -> PMA attention, activations resident in LDS) against
+
+* the per-block launches it replaces (``PCA_SET128=0``): same arithmetic on the same operand
+  roundings, so logits, loss and all 45 gradients agree to reduction-order rounding of the few fp32
+  merges that run in another order (layer-1 attention, partial merges) - a much tighter check of the
+  kernel's indexing than the oracle tolerance of the bf16 mode allows;
+* the CPU oracle (``oracle/st_oracle.py:st_grads``: the reference's ``ST`` + autograd restated,
+  Code/models.py:34-44, modules.py:19-33), at the bf16 mode's tolerance.
+
+Sizes: every N the kernel accepts (128, 256, 384, 512: one to four 32-point units per quad of waves),
+din 2 and 3, batch sizes that change the PMA's partial count (``mab0_splits``: 4, 2 partials)."""
+import os
+
+import numpy as np
+import pytest
+import torch
+
+from util import T, close, close_robust
+
+import inputs as gi
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.fixture(scope="module")
+def dev():
+    import pca_hip
+    pca_hip.lib()
+    return torch.device("cuda", 0)
+
+
+def _run(dev, net, X, y, B, N, set128):
+    from pca_hip import _lib, trainer
+    old = os.environ.get("PCA_SET128")
+    os.environ["PCA_SET128"] = "1" if set128 else "0"
+    try:
+        eng = trainer.STEngine(net, B, N, _lib.MODE_BF16, training=True)
+        eng.fwd_bwd(X, y, phase=-1)
+        torch.cuda.synchronize()
+        return eng.logits.clone(), float(eng.loss), eng.grads.clone()
+    finally:
+        if old is None:
+            del os.environ["PCA_SET128"]
+        else:
+            os.environ["PCA_SET128"] = old
+
+
+@pytest.mark.parametrize("B,N,din", [(5, 128, 2), (8, 256, 3), (3, 384, 2), (16, 512, 2), (7, 512, 3),
+                                     (260, 512, 2)])
+def test_set128_forward_equals_per_block_launches(dev, B, N, din):
+    import models
+    d, h, m, C = 128, 4, 16, 50
+    torch.manual_seed(100 + N + din)
+    net = models.ST(dim_input=din, num_outputs=1, dim_output=C, num_inds=m, dim_hidden=d,
+                    num_heads=h).to(dev)
+    X = T(gi.pc_input(7000 + N, B, N, din), dev)
+    y = T(gi.labels(7001 + N, B, C), dev)
+    lg0, loss0, g0 = _run(dev, net, X, y, B, N, set128=False)
+    lg1, loss1, g1 = _run(dev, net, X, y, B, N, set128=True)
+    assert torch.isfinite(lg1).all() and torch.isfinite(g1).all()
+    # bf16 activations: a one-ulp difference of a merged fp32 statistic can flip the rounding of a few
+    # hidden activations; everything else is the same arithmetic
+    e = close(lg1, lg0.cpu(), 4e-3, "logits")
+    assert abs(loss1 - loss0) < 2e-3 * max(1.0, abs(loss0)), (loss1, loss0)
+    off, worst = 0, 0.0
+    for k, prm in net.named_parameters():
+        a = g1[off:off + prm.numel()].view_as(prm)
+        bref = g0[off:off + prm.numel()].view_as(prm).cpu()
+        off += prm.numel()
+        worst = max(worst, close_robust(a, bref, 6e-3, k, outlier_frac=1e-3))
+    print(f"B={B} N={N} din={din}: logits {e:.2e}, worst grad {worst:.2e}")
+
+
+@pytest.mark.parametrize("B,N,din", [(6, 256, 2), (12, 512, 3)])
+def test_set128_train_step_vs_oracle(dev, B, N, din):
+    import models
+    from oracle import st_oracle as orc
+    d, h, m, C = 128, 4, 16, 50
+    torch.manual_seed(200 + N)
+    net = models.ST(dim_input=din, num_outputs=1, dim_output=C, num_inds=m, dim_hidden=d,
+                    num_heads=h).to(dev)
+    p = {k: v.detach().cpu().clone() for k, v in net.state_dict().items()}
+    Xn = gi.pc_input(7100 + N, B, N, din)
+    yn = gi.labels(7101 + N, B, C)
+    ref_loss, ref_lg, ref_g = orc.st_grads(torch.from_numpy(Xn), torch.from_numpy(yn), p, h)
+    lg, loss, g = _run(dev, net, T(Xn, dev), T(yn, dev), B, N, set128=True)
+    close(lg, ref_lg.reshape(B, C), 3e-2, "logits")
+    assert abs(loss - ref_loss) < 3e-2 * max(1.0, abs(ref_loss))
+    off = 0
+    for k, prm in net.named_parameters():
+        close_robust(g[off:off + prm.numel()].view_as(prm), ref_g[k], 5e-2, k, outlier_frac=5e-3)
+        off += prm.numel()
