@@ -319,6 +319,11 @@ int64_t pca_st_param_count(const pca_st_config* c);
  * [0, offset) (enc.0) after phase 1 -- the two all-reduce buckets of SURVEY.md 8e. */
 int64_t pca_st_bucket_split(const pca_st_config* c);
 size_t pca_st_ws_bytes(const pca_st_config* c, int training);
+/* Diagnostics only: byte offsets inside the workspace of the training step's per-block areas, so that
+ * a test can compare what two kernel variants left there.  out[0..4] = saved areas of enc.0.mab0,
+ * enc.0.mab1, enc.1.mab0, enc.1.mab1, dec.0; out[5..6] = H of the two ISABs (fp32 [B, m, d]);
+ * out[7..8] = their outputs Y ([B, N, d], bf16 in the fused modes); out[9] = scratch; out[10] = total. */
+int pca_st_ws_layout(const pca_st_config* c, int64_t* out11);
 
 /* logits[B*k, C] = ST(X[B, N, din]) -- inference, nothing saved.
  * lengths: NULL (dense batches, as the reference's), or device int32[B] with the number of

@@ -121,7 +121,9 @@ __global__ void k_prep_jobs(const PrepJobs jobs) {
   const int idx = blockIdx.x * blockDim.x + threadIdx.x;
   if (idx >= rows * cols) return;
   float v;
-  if (mode <= 1) {
+  if (mode == 4) {                     // clear job: rows * cols 16-bit words of zeros (no source)
+    v = 0.f;
+  } else if (mode <= 1) {
     const int n = idx / cols, k = idx - n * cols;
     const int kk = mode == 1 ? (k & ~31) + perm32(k & 31) : k;
     v = jb.src[(int64_t)n * cols + kk];

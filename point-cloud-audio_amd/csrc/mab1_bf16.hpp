@@ -135,7 +135,7 @@ struct IsabImg {
 struct PrepJob {
   const float* src;
   __bf16* dst;
-  int rows, cols, mode;      // modes of prep_weight
+  int rows, cols, mode;      // modes of prep_weight; 4: dst[0 .. rows * cols) = 0 (src unused)
 };
 struct PrepJobs {
   PrepJob j[32];

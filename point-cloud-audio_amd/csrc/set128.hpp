@@ -1,7 +1,7 @@
 // Set-resident kernels of the d = 128 / 4 heads / m = 16 / k = 1 train step (BASELINE configs[1]):
-// ONE workgroup carries a whole set through ISAB -> ISAB -> PMA (set_transformer-master/modules.py:
-// 51-53, 62-63 with :19-33 inside; Code/models.py:34-44), its [N, 128] activations resident in LDS.
-// Declarations shared by set128_fwd.hip and the ST engine.
+// a PAIR of workgroups carries a whole set through ISAB -> ISAB -> PMA (set_transformer-master/
+// modules.py:51-53, 62-63 with :19-33 inside; Code/models.py:34-44), each its half of the set's
+// [N, 128] activations resident in LDS.  Declarations shared by set128_fwd.hip and the ST engine.
 #pragma once
 #include "mab1_bf16.hpp"
 
@@ -39,15 +39,20 @@ struct Set128FwdArgs {
   int B, N, din;
   float scale_log2e;
   Set128Layer L[2];
-  float *Tp2, *Mp2, *Lp2; // scratch: layer-2 attention partials [B][4][64][128], [B][4][64] x 2
+  // pair exchange (scratch; `flags` is zeroed by the step's preparation launch):
+  uint32_t* flags;        // [4] header (word 0 counts spin timeouts) + [B][2 exchanges][2 halves]
+  float* ex1;             // [B][2][64][8]     layer-1 attention partials (t[4], m, l)
+  float* ex2;             // [B][2][8192 + 1024] layer-2 attention partials (T as float4 [8][4][64], m / l)
   const __bf16* Gpma;     // [>= 16][128] bf16, rows >= 4 zero
   float *TpP, *MpP, *LpP; // PMA attention partials [B][Sp][4][128], [B][Sp][4] x 2 (read by k_pma_head1)
-  int Sp;                 // 1, 2 or 4
+  int Sp;                 // 2 or 4
 };
 
-// N a multiple of 128, at most 512; din <= 4
-bool set128_shape_ok(int N, int din, int d, int h, int m, int k);
+// bytes of `flags` (the block the preparation launch clears) / of the whole exchange area
+size_t set128_flag_bytes(int B);
 size_t set128_fwd_ws_bytes(int B);
+// N = 256 or 512 (each half a multiple of 128 points); din <= 4; 2 B workgroups resident at once
+bool set128_shape_ok(int B, int N, int din, int d, int h, int m, int k);
 int set128_fwd_launch(const Set128FwdArgs& a, hipStream_t st);
 
 }  // namespace pca

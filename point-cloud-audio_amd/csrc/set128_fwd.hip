@@ -2,27 +2,30 @@
 // (Code/models.py:34-44: ISAB, ISAB, PMA; set_transformer-master/modules.py:19-33, 51-53, 62-63),
 // BASELINE configs[1] (N = 512, din = 2, B = 128).
 //
-// ONE 1024-thread workgroup carries ONE set through
+// A PAIR of 1024-thread workgroups carries ONE set through
 //     mab0(I1, X) -> mid -> mab1(X, H1) -> mab0(I2, Y1) -> mid -> mab1(Y1, H2) -> PMA attention partials
-// with the set's [N, 128] bf16 activation tensor resident in LDS (128 KiB at N = 512) from the moment
-// layer 1 produces it until the PMA has read it.  The per-block kernels this replaces (k_mab0_attn_small,
-// k_mid_fwd, k_mab1_fwd, k_mab0_attn_h4, k_mid_fwd, k_isab1_fwd_t, k_mab0_attn) each ran ONE 32-point
-// unit per wave with all 2048 waves of the chip in the same phase at the same time: every launch paid
-// its weight images, the input burst, the dependent MFMA chain and the store drain in lock-step, plus
-// ~5 us of launch and drain - seven times per forward.  Here a phase boundary is a workgroup barrier,
-// the activations between blocks never leave the CU (they go to HBM only as the tensors the backward
-// reads), and the attention partials of a set are merged by the workgroup that produced them.
+// each workgroup with ITS HALF of the set's [N, 128] bf16 activation tensor resident in LDS from the
+// moment layer 1 produces it until the PMA has read it (B = 128 sets -> 256 workgroups = one per CU).
+// The per-block kernels this replaces (k_mab0_attn_small, k_mid_fwd, k_mab1_fwd, k_mab0_attn_h4,
+// k_mid_fwd, k_isab1_fwd_t, k_mab0_attn) each ran ONE 32-point unit per wave with all 2048 waves of
+// the chip in the same phase at the same time: every launch paid its weight images, the input burst,
+// the dependent MFMA chain and the store drain in lock-step, plus ~5 us of launch and drain - seven
+// times per forward.  Here a phase boundary is a workgroup barrier, the activations between blocks
+// never leave the CU (they go to HBM only as the tensors the backward reads), and the only
+// cross-workgroup traffic of a set is the (m, l, T) partial of its two few-queries attentions, handed
+// to the partner workgroup through write-through (sc1) stores, one flag and sc1 loads
+// (cdna_hip_programming.md Guideline 16, R1); both halves then merge the same two partials in the same
+// order and run the per-set "mid" stage redundantly, so nothing else has to cross.
 //
-// Wave w = (quad q = w >> 2, head j = w & 3): quad q owns the points [q N/4, (q+1) N/4) of the set,
-// wave j of a quad the head j (features 32 j .. 32 j + 31) - the WAVE = HEAD, WEIGHTS IN REGISTERS form of
+// Wave w = (quad q = w >> 2, head j = w & 3): quad q owns a quarter of the workgroup's points, wave j of
+// a quad the head j (features 32 j .. 32 j + 31) - the WAVE = HEAD, WEIGHTS IN REGISTERS form of
 // k_isab1_fwd_t (d128_fused.hip) and k_mab0_attn_h4 (mab0_bf16.hip), whose arithmetic and saved layouts
-// this kernel keeps bit for bit in form (same MFMA operand orders, same K-permuted images), so that the
-// existing backward kernels read what it saves.
+// this kernel keeps (same MFMA operand orders, same K-permuted images), so that the existing backward
+// kernels read what it saves.
 //
-// LDS: sY [N][256 B] (rows XOR-swizzled as tr_off, so that both the row-major B-operand reads and the
-// transposing ds_read_tr16_b64 reads are conflict-free) + 32 KiB of phase scratch.  The cross-head
-// exchange of the many-queries blocks (fc_o contracts over all heads' features) happens IN PLACE in sY:
-// O slices overwrite the unit's input rows, Y slices overwrite the O rows, three barriers per block.
+// LDS: sY [N/2][256 B] (rows XOR-swizzled as tr_off, so that both the row-major B-operand reads and the
+// transposing ds_read_tr16_b64 reads are conflict-free), sO [N/2][256 B] (the O tile of a many-queries
+// block: fc_o contracts over all heads' features; between blocks: merge buffers), 32 KiB of images.
 //
 // Roofline unit: MACs_fwd / set = N (3 din d + 7 d^2 + 8 m d + 2 k d) + 6 m d^2 (the
 // PMA epilogue and the classifier run in k_pma_head1); algorithmic bytes 4 N din + 4 (2 N d) per set.
@@ -65,19 +68,82 @@ __device__ __forceinline__ bf16x8 gload8(const __bf16* p) {
 __device__ __forceinline__ void put_tile(char* img, int t, int r, int g, f32x4 v) {
   *reinterpret_cast<bf16x4*>(img + swz(r, 2 * t + (g >> 1), ROWB) + 8 * (g & 1)) = pack4(v);
 }
+// workgroup barrier that orders LDS traffic only: global stores in flight (saved tensors) are not
+// waited for, as __syncthreads()'s vmcnt(0) would
+__device__ __forceinline__ void lds_barrier() {
+  asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+  __builtin_amdgcn_s_barrier();
+  asm volatile("" ::: "memory");
+}
+// max as ONE instruction (v_med3_f32 with +inf; fmaxf costs a canonicalising v_max x, x in front).
+// A builtin, NOT inline asm: hipcc's hazard recognizer does not look inside asm, and a VALU
+// instruction reading an MFMA result needs wait states it would not insert (the first version of this
+// kernel read the accumulators of the mid stage one instruction after the MFMA - and got the old value)
+__device__ __forceinline__ float maxf(float x, float y) { return __builtin_amdgcn_fmed3f(x, y, INFINITY); }
+__device__ __forceinline__ float max0(float x) { return __builtin_amdgcn_fmed3f(x, 0.f, INFINITY); }
+// bits = 2 bits + (z > 0)
+__device__ __forceinline__ uint32_t push_gt0(uint32_t bits, float z) {
+  return (bits << 1) | (z > 0.f ? 1u : 0u);
+}
+
+// ---- cross-workgroup hand-off (cdna_hip_programming.md Guideline 16, form R1): payload by sc1
+// (write-through) stores, every storing wave drains, workgroup barrier, ONE lane stores the flag; the
+// consumer polls the flag (bounded), then reads the payload with sc1 loads only -------------------
+typedef __attribute__((address_space(1))) uint32_t gu32;
+__device__ __forceinline__ void st16_sc1(float* p, float4 v4) {
+  const f32x4 v = {v4.x, v4.y, v4.z, v4.w};
+  asm volatile("global_store_dwordx4 %0, %1, off sc1\n\ts_nop 1" ::"v"(p), "v"(v) : "memory");
+}
+__device__ __forceinline__ f32x4 ld16_sc1(const float* p) {       // caller: s_waitcnt vmcnt(0) before use
+  f32x4 v;
+  asm volatile("global_load_dwordx4 %0, %1, off sc1" : "=v"(v) : "v"(p) : "memory");
+  return v;
+}
+__device__ __forceinline__ void drain_vm() { asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); }
+// the wait as part of the data flow of a value loaded by ld16_sc1: hipcc does not know that the asm load
+// is still in flight and would otherwise be free to schedule uses of `v` above a bare s_waitcnt
+__device__ __forceinline__ void landed(f32x4& v) { asm volatile("s_waitcnt vmcnt(0)" : "+v"(v)::"memory"); }
+__device__ __forceinline__ void flag_store(uint32_t* f, uint32_t v) {
+  __hip_atomic_store((gu32*)(f), v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+}
+// one wave polls; a partner that never arrives (it would mean the pair is not co-resident) ends the
+// spin after ~1 s, counts it in tmo[0] and lets the kernel finish with whatever the slot holds
+__device__ __forceinline__ void flag_wait(uint32_t* f, uint32_t want, uint32_t* tmo) {
+  for (unsigned spins = 0; spins < (1u << 20); ++spins) {
+    if (__hip_atomic_load((gu32*)(f), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) == want) return;
+    __builtin_amdgcn_s_sleep(4);
+  }
+  if ((threadIdx.x & 63) == 0) atomicAdd(tmo, 1u);
+}
+
+// -DPCA_SET_STAMPS (scripts/experiments/set_stamps.sh): wall-clock stamps (10 ns units) of workgroup 0,
+// lane 0 of every wave, at the phase boundaries
+#ifdef PCA_SET_STAMPS
+__device__ unsigned long long g_set_stamps[16 * 32];
+#define STAMP(i)                                                                         \
+  do {                                                                                   \
+    if (blockIdx.x == 0 && (threadIdx.x & 63) == 0)                                      \
+      g_set_stamps[(threadIdx.x >> 6) * 32 + (i)] = wall_clock64();                      \
+  } while (0)
+#else
+#define STAMP(i) do { } while (0)
+#endif
 
 struct Ctx {
-  int b, N, tid, lane, wave, q, j, r, g;
-  int UPQ;          // 32-point units per quad (N / 128)
-  int qn0;          // first point of this wave's quad
+  int b, half, N, NH, tid, lane, wave, q, j, r, g;
+  int UPQ;          // 32-point units per quad (N / 256)
+  int qn0;          // first LOCAL row (of sY / sO) of this wave's quad
+  int64_t row0;     // global row (b N + half N/2) of local row 0
 };
 
 // ---------------------------------------------------------------------------------------------
-// per-set stage between the two blocks of an ISAB (k_mid_fwd, mid_bf16.hip, on 16 waves):
+// per-set stage between the two blocks of an ISAB (k_mid_fwd, mid_bf16.hip, on 16 waves), run by BOTH
+// workgroups of the pair on identical inputs (half 0 writes the saved copies):
 //   A  O = Qp + T_h Wv_h^T + bv        (modules.py:29, reassociated: SURVEY 8d)     waves 0-7, tile t = wave
 //   B  H = O + relu(O Wo^T + bo)       (modules.py:31)                              waves 0-7
 //   C  Kp = H Wk^T + bk, Vp = H Wv^T + bv of the many-queries block (modules.py:21) all waves:
-//      wave = (tile tc = wave >> 1, which = wave & 1), in the four bf16 images mab1 forward / backward read
+//      wave = (tile tc = wave >> 1, which = wave & 1); the two images the forward reads stay in LDS
+//      (sKp: K-permuted [key][feature], sVt: [feature][key]), all four go to memory for the backward
 // Every weight fragment a wave needs is requested by mid_prefetch() a phase ahead.
 // ---------------------------------------------------------------------------------------------
 struct MidPre {
@@ -120,12 +186,13 @@ __device__ __forceinline__ void mid_prefetch(const Set128Layer& L, const Ctx& c,
 }
 
 // sT: bf16 image [64][256 B] of the merged T (swz rows; !SMALL) / sTf: fp32 [64][4] (SMALL);
-// sA, sH: [16][256 B] bf16 images of O and H.  Ends with a barrier: the K / V images are visible
-// to the whole workgroup (global memory, same CU) when it returns.
+// sA, sH: [16][256 B] bf16 images of O and H.  Ends with a barrier.
 template <bool SMALL>
 __device__ __forceinline__ void mid_stage(const Set128Layer& L, const Ctx& c, const MidPre& P,
-                                          const char* sT, const float* sTf, char* sA, char* sH) {
+                                          const char* sT, const float* sTf, char* sA, char* sH,
+                                          char* sKp, char* sVt) {
   const int r = c.r, g = c.g, b = c.b;
+  const bool save = c.half == 0;
   f32x4 o = {0.f, 0.f, 0.f, 0.f};
   if (c.wave < 8) {                                   // ---- A
     const int t = c.wave, hh = t >> 1;
@@ -141,10 +208,11 @@ __device__ __forceinline__ void mid_stage(const Set128Layer& L, const Ctx& c, co
         o = mfma32(P.wa[ks], *reinterpret_cast<const bf16x8*>(sT + swz(16 * hh + r, 4 * ks + g, ROWB)), o);
     }
     put_tile(sA, t, r, g, o);
-    *reinterpret_cast<float4*>(L.O0 + ((int64_t)b * MQ + r) * D + 16 * t + 4 * g) =
-        float4{o[0], o[1], o[2], o[3]};
+    if (save)
+      *reinterpret_cast<float4*>(L.O0 + ((int64_t)b * MQ + r) * D + 16 * t + 4 * g) =
+          float4{o[0], o[1], o[2], o[3]};
   }
-  __syncthreads();
+  lds_barrier();
   if (c.wave < 8) {                                   // ---- B
     const int t = c.wave;
     f32x4 z = f32x4{P.bo0.x, P.bo0.y, P.bo0.z, P.bo0.w};
@@ -153,17 +221,17 @@ __device__ __forceinline__ void mid_stage(const Set128Layer& L, const Ctx& c, co
       z = mfma32(P.wb[ks], *reinterpret_cast<const bf16x8*>(sA + swz(r, 4 * ks + g, ROWB)), z);
     f32x4 hq;
 #pragma unroll
-    for (int e = 0; e < 4; ++e) hq[e] = o[e] + fmaxf(z[e], 0.f);
-    const int64_t off = ((int64_t)b * MQ + r) * D + 16 * t + 4 * g;
-    *reinterpret_cast<float4*>(L.Z0 + off) = float4{z[0], z[1], z[2], z[3]};
-    *reinterpret_cast<float4*>(L.H + off) = float4{hq[0], hq[1], hq[2], hq[3]};
+    for (int e = 0; e < 4; ++e) hq[e] = o[e] + max0(z[e]);
+    if (save) {
+      const int64_t off = ((int64_t)b * MQ + r) * D + 16 * t + 4 * g;
+      *reinterpret_cast<float4*>(L.Z0 + off) = float4{z[0], z[1], z[2], z[3]};
+      *reinterpret_cast<float4*>(L.H + off) = float4{hq[0], hq[1], hq[2], hq[3]};
+    }
     put_tile(sH, t, r, g, hq);
   }
-  __syncthreads();
+  lds_barrier();
   {                                                   // ---- C
     const int tc = c.wave >> 1, which = c.wave & 1;
-    __bf16* PP = which ? L.VpP : L.KpP;
-    __bf16* TT = which ? L.Vt : L.Kt;
     f32x4 fr = f32x4{P.bkv.x, P.bkv.y, P.bkv.z, P.bkv.w};     // rows = features, col = key
     f32x4 kr = f32x4{P.bkvc, P.bkvc, P.bkvc, P.bkvc};         // rows = keys,     col = feature
 #pragma unroll
@@ -172,27 +240,37 @@ __device__ __forceinline__ void mid_stage(const Set128Layer& L, const Ctx& c, co
       fr = mfma32(P.wc[ks], hf, fr);
       kr = mfma32(hf, P.wc[ks], kr);
     }
-    // keys 4g .. 4g+3 of feature 16 tc + r: 8 contiguous bytes of the [feature][key] image
-    *reinterpret_cast<bf16x4*>(TT + ((int64_t)b * D + 16 * tc + r) * MQ + 4 * g) = pack4(kr);
-    // features 32 (tc >> 1) + perm32(8 g + 4 (tc & 1) + e) of key r: half of the lane's 16 bytes of the
-    // K-permuted image (k_mid_fwd writes pack8 of the head's two tiles)
-    *reinterpret_cast<bf16x4*>(PP + ((int64_t)b * MQ + r) * D + 32 * (tc >> 1) + 8 * g + 4 * (tc & 1)) =
-        pack4(fr);
+    const bf16x4 krp = pack4(kr), frp = pack4(fr);
+    // [feature][key] image: keys 4g .. 4g+3 of feature 16 tc + r (8 contiguous bytes);
+    // K-permuted [key][feature] image: features 32 (tc >> 1) + perm32(8 g + 4 (tc & 1) + e) of key r -
+    // half of the lane's 16 bytes (k_mid_fwd writes pack8 of the head's two tiles)
+    const int o_t = (16 * tc + r) * MQ + 4 * g;
+    const int o_p = r * D + 32 * (tc >> 1) + 8 * g + 4 * (tc & 1);
+    if (which) *reinterpret_cast<bf16x4*>(sVt + o_t * 2) = krp;
+    else *reinterpret_cast<bf16x4*>(sKp + o_p * 2) = frp;
+    if (save) {
+      __bf16* PP = which ? L.VpP : L.KpP;
+      __bf16* TT = which ? L.Vt : L.Kt;
+      *reinterpret_cast<bf16x4*>(TT + (int64_t)b * D * MQ + o_t) = krp;
+      *reinterpret_cast<bf16x4*>(PP + (int64_t)b * MQ * D + o_p) = frp;
+    }
   }
-  __syncthreads();
+  lds_barrier();
 }
 
 // ---------------------------------------------------------------------------------------------
-// many-queries block mab1(X, H) (modules.py:19-33) on the set's rows in sY; wave = (quad, head):
-//   Qp_h = fc_q(x) ; A = softmax(Qp_h Kp_h^T / sqrt d) ; O_h = Qp_h + A Vp_h        per unit, in registers
-//   barrier ; O slices -> sY (in place) ; barrier ; Z_h = fc_o(O) ; Y_h = O_h + relu(Z_h)
-//   barrier ; Y slices -> sY ; barrier ; coalesced stores of the saved O and of Y from sY
+// many-queries block mab1(X, H) (modules.py:19-33) on the workgroup's rows; wave = (quad, head):
+//   Qp_h = fc_q(x) ; A = softmax(Qp_h Kp_h^T / sqrt d) ; O_h = Qp_h + A Vp_h -> own slice of sO
+//   barrier ; Z_h = fc_o(O) ; Y_h = O_h + relu(Z_h) -> own slice of sY ; barrier
+//   coalesced stores of the saved O (from sO) and of Y (from sY)
 // SMALL: layer 1 (dq = din <= 4: fc_q on the vector ALU from the points in sX, nothing in sY yet)
 // ---------------------------------------------------------------------------------------------
 template <bool SMALL>
-__device__ __forceinline__ void mab1_phase(const Set128Layer& L, const Ctx& c, char* sY,
-                                           const float* sX, int dq, float scale_log2e) {
-  const int r = c.r, g = c.g, j = c.j, b = c.b, N = c.N;
+__device__ __forceinline__ void mab1_phase(const Set128Layer& L, const Ctx& c, char* sY, char* sO,
+                                           const float* sX, const char* sKp, const char* sVt, int dq,
+                                           float scale_log2e, int stamp0) {
+  (void)stamp0;
+  const int r = c.r, g = c.g, j = c.j;
   constexpr int KS = 4;
   // this head's weight slices as A operands [row = feature 32 j + 16 t + r][k-slots 32 s + 8 g ..]
   bf16x8 wa[KS][2];
@@ -222,13 +300,13 @@ __device__ __forceinline__ void mab1_phase(const Set128Layer& L, const Ctx& c, c
   }
   // the head's 16 keys: A operand [key r][k-slots 8 g .. of the head's 32 features] and
   // V^T: A operand [feature 16 t + r][keys 4 g ..]
-  const bf16x8 kpa = gload8(L.KpP + ((int64_t)b * MQ + r) * D + 32 * j + 8 * g);
+  const bf16x8 kpa = *reinterpret_cast<const bf16x8*>(sKp + (r * D + 32 * j + 8 * g) * 2);
   bf16x4 vta[2];
 #pragma unroll
   for (int t = 0; t < 2; ++t)
-    vta[t] = *reinterpret_cast<const bf16x4*>(L.Vt + ((int64_t)b * D + 32 * j + 16 * t + r) * MQ + 4 * g);
+    vta[t] = *reinterpret_cast<const bf16x4*>(sVt + ((32 * j + 16 * t + r) * MQ + 4 * g) * 2);
 
-  // per-lane byte offsets inside a 16-row block of sY (y_off depends on row & 15 only)
+  // per-lane byte offsets inside a 16-row block of sY / sO (y_off depends on row & 15 only)
   int oB[KS], oD[2], oP[KS][2];
 #pragma unroll
   for (int s = 0; s < KS; ++s) {
@@ -239,9 +317,9 @@ __device__ __forceinline__ void mab1_phase(const Set128Layer& L, const Ctx& c, c
 #pragma unroll
   for (int t = 0; t < 2; ++t) oD[t] = y_off(r, 4 * j + 2 * t + (g >> 1)) + 8 * (g & 1);
 
-  bf16x4 opk[4][2][2];                // [unit][t][nb]: the wave's O slices, then its Y slices
+  bf16x4 opk[2][2][2];                // [unit][t][nb]: the wave's O slices (the residual of the epilogue)
 #pragma unroll
-  for (int u = 0; u < 4; ++u) {
+  for (int u = 0; u < 2; ++u) {
     if (u >= c.UPQ) break;
     const int n0 = c.qn0 + 32 * u;
     f32x4 acc[2][2];
@@ -275,8 +353,8 @@ __device__ __forceinline__ void mab1_phase(const Set128Layer& L, const Ctx& c, c
       for (int nb = 0; nb < 2; ++nb)
 #pragma unroll
         for (int t = 0; t < 2; ++t)
-          *reinterpret_cast<bf16x4*>(L.QpS + ((int64_t)b * N + n0 + 16 * nb + r) * D + 32 * j + 16 * t +
-                                     4 * g) = pack4(acc[t][nb]);
+          *reinterpret_cast<bf16x4*>(L.QpS + (c.row0 + n0 + 16 * nb + r) * D + 32 * j + 16 * t + 4 * g) =
+              pack4(acc[t][nb]);
     }
     // attention over the 16 inducing keys, all inside the wave
 #pragma unroll
@@ -284,7 +362,7 @@ __device__ __forceinline__ void mab1_phase(const Set128Layer& L, const Ctx& c, c
       const bf16x8 qb = pack8(acc[0][nb], acc[1][nb]);
       const f32x4 z4 = {0.f, 0.f, 0.f, 0.f};
       f32x4 s0 = mfma32(kpa, qb, z4);            // [key 4 g + e][point r]
-      float mx = fmaxf(fmaxf(s0[0], s0[1]), fmaxf(s0[2], s0[3]));
+      float mx = maxf(maxf(s0[0], s0[1]), maxf(s0[2], s0[3]));
       mx = wave16_max(mx);
       float sum = 0.f;
 #pragma unroll
@@ -303,35 +381,23 @@ __device__ __forceinline__ void mab1_phase(const Set128Layer& L, const Ctx& c, c
 #pragma unroll
     for (int nb = 0; nb < 2; ++nb)
 #pragma unroll
-      for (int t = 0; t < 2; ++t) opk[u][t][nb] = pack4(acc[t][nb]);
+      for (int t = 0; t < 2; ++t) {
+        opk[u][t][nb] = pack4(acc[t][nb]);
+        *reinterpret_cast<bf16x4*>(sO + (n0 + 16 * nb) * ROWB + oD[t]) = opk[u][t][nb];
+      }
   }
-  // fc_o's weight slice replaces fc_q's (K-permuted image: the O tiles come back from sY in
-  // accumulator order); requested before the barriers
+  // fc_o's weight slice replaces fc_q's (K-permuted image: the O tiles come back from sO in
+  // accumulator order); requested before the barrier
 #pragma unroll
   for (int s = 0; s < KS; ++s)
 #pragma unroll
     for (int t = 0; t < 2; ++t)
       wa[s][t] = gload8(L.WoP + (int64_t)(32 * j + 16 * t + r) * D + 32 * s + 8 * g);
-  if (!SMALL) __syncthreads();          // every head has read the unit's input rows
+  STAMP(stamp0);
+  lds_barrier();                        // O rows complete; every head has read the unit's input rows
+  STAMP(stamp0 + 1);
 #pragma unroll
-  for (int u = 0; u < 4; ++u) {
-    if (u >= c.UPQ) break;
-    const int n0 = c.qn0 + 32 * u;
-#pragma unroll
-    for (int nb = 0; nb < 2; ++nb)
-#pragma unroll
-      for (int t = 0; t < 2; ++t)
-        *reinterpret_cast<bf16x4*>(sY + (n0 + 16 * nb) * ROWB + oD[t]) = opk[u][t][nb];
-  }
-  __syncthreads();                      // O rows complete
-  // saved O: coalesced 16-byte pieces of full rows, from sY
-  for (int p = c.tid; p < N * 16; p += NT) {
-    const int row = p >> 4, ch = p & 15;
-    *reinterpret_cast<uint4*>(L.OS + ((int64_t)b * N + row) * D + ch * 8) =
-        *reinterpret_cast<const uint4*>(sY + y_off(row, ch));
-  }
-#pragma unroll
-  for (int u = 0; u < 4; ++u) {
+  for (int u = 0; u < 2; ++u) {
     if (u >= c.UPQ) break;
     const int n0 = c.qn0 + 32 * u;
     f32x4 acc[2][2];
@@ -344,7 +410,7 @@ __device__ __forceinline__ void mab1_phase(const Set128Layer& L, const Ctx& c, c
     for (int s = 0; s < KS; ++s)
 #pragma unroll
       for (int nb = 0; nb < 2; ++nb) {
-        const char* rowp = sY + (n0 + 16 * nb) * ROWB;
+        const char* rowp = sO + (n0 + 16 * nb) * ROWB;
         const bf16x4 lo = *reinterpret_cast<const bf16x4*>(rowp + oP[s][0]);
         const bf16x4 hi = *reinterpret_cast<const bf16x4*>(rowp + oP[s][1]);
         bf16x8 ob;
@@ -355,81 +421,112 @@ __device__ __forceinline__ void mab1_phase(const Set128Layer& L, const Ctx& c, c
       }
 #pragma unroll
     for (int nb = 0; nb < 2; ++nb) {
-      uint32_t bits = 0u;                // byte j of the lane's mask word: feature tiles 2 j, 2 j + 1
+      // Y = O + relu(Z) = max(O + Z, O); byte j of the lane's mask word: bit 4 t + e <-> Z > 0
+      uint32_t bits = 0u;
+      f32x4 y[2];
 #pragma unroll
-      for (int t = 0; t < 2; ++t) {
+      for (int t = 1; t >= 0; --t) {
         const bf16x4 o4 = opk[u][t][nb];
-        f32x4 y;
 #pragma unroll
-        for (int e = 0; e < 4; ++e) {
-          const float zz = acc[t][nb][e];
-          y[e] = (float)o4[e] + fmaxf(zz, 0.f);
-          if (zz > 0.f) bits |= 1u << (4 * t + e);
+        for (int e = 3; e >= 0; --e) {
+          const float zz = acc[t][nb][e], of = (float)o4[e];
+          bits = push_gt0(bits, zz);
+          y[t][e] = maxf(of + zz, of);
         }
-        opk[u][t][nb] = pack4(y);
       }
-      const int64_t blk = ((int64_t)b * N + n0) / 16 + nb;
+#pragma unroll
+      for (int t = 0; t < 2; ++t)
+        *reinterpret_cast<bf16x4*>(sY + (n0 + 16 * nb) * ROWB + oD[t]) = pack4(y[t]);
+      const int64_t blk = (c.row0 + n0) / 16 + nb;
       reinterpret_cast<uint8_t*>(L.mask)[(blk * 64 + c.lane) * 4 + j] = (uint8_t)bits;
     }
   }
-  __syncthreads();                      // every head has read the O rows (and they are stored)
-#pragma unroll
-  for (int u = 0; u < 4; ++u) {
-    if (u >= c.UPQ) break;
-    const int n0 = c.qn0 + 32 * u;
-#pragma unroll
-    for (int nb = 0; nb < 2; ++nb)
-#pragma unroll
-      for (int t = 0; t < 2; ++t)
-        *reinterpret_cast<bf16x4*>(sY + (n0 + 16 * nb) * ROWB + oD[t]) = opk[u][t][nb];
-  }
-  __syncthreads();                      // Y rows complete
-  for (int p = c.tid; p < N * 16; p += NT) {
+  STAMP(stamp0 + 2);
+  lds_barrier();                        // Y rows complete (and every head has read the O rows)
+  STAMP(stamp0 + 3);
+  // saved O and the block's output: coalesced 16-byte pieces of full rows
+  for (int p = c.tid; p < c.NH * 16; p += NT) {
     const int row = p >> 4, ch = p & 15;
-    *reinterpret_cast<uint4*>(L.Y + ((int64_t)b * N + row) * D + ch * 8) =
+    *reinterpret_cast<uint4*>(L.OS + (c.row0 + row) * D + ch * 8) =
+        *reinterpret_cast<const uint4*>(sO + y_off(row, ch));
+    *reinterpret_cast<uint4*>(L.Y + (c.row0 + row) * D + ch * 8) =
         *reinterpret_cast<const uint4*>(sY + y_off(row, ch));
   }
+  STAMP(stamp0 + 4);
 }
 
-__global__ __launch_bounds__(NT) void k_set128_fwd(const Set128FwdArgs a) {
+typedef __attribute__((address_space(4))) const Set128FwdArgs karg_t;
+// The kernel's arguments are ~75 pointers: left to itself hipcc loads them all at entry and then spills
+// SGPRs to VGPR lanes (930 v_readlane in the first version).  Reading them through a pointer the
+// optimiser cannot see through keeps every s_load at its phase.
+__device__ __forceinline__ karg_t* launder(karg_t* p) {
+  asm volatile("" : "+s"(p));
+  return p;
+}
+
+// (explicit address-space cast: the host pass of hipcc rejects the implicit one; the optimiser infers the
+//  constant address space back, the loads stay scalar)
+#define LAYER(i) (*(const Set128Layer*)(&ap->L[i]))
+
+__global__ __launch_bounds__(NT) void k_set128_fwd(const Set128FwdArgs a_by_value) {
+  (void)a_by_value;
+  karg_t* ap = launder((karg_t*)__builtin_amdgcn_kernarg_segment_ptr());
   extern __shared__ __attribute__((aligned(16))) char smem[];
-  char* sY = smem;                               // [512][256 B]
-  char* sS = smem + 512 * ROWB;                  // 32 KiB of phase scratch
-  float* sX = reinterpret_cast<float*>(sS);      // [N][4] the set's points (layer 1)            0 ..  8 K
-  char* sA = sS + 8192;                          // O image of the mid stage                     8 .. 12 K
-  char* sH = sS + 12288;                         // H image                                     12 .. 16 K
-  char* sT = sS + 16384;                         // bf16 image of the merged T (layer 2)        16 .. 32 K
-  float* sTf = reinterpret_cast<float*>(sT);     // fp32 [64][4] (layer 1)
-  float* sAl = reinterpret_cast<float*>(sA);     // layer-2 attention: 16 alphas per wave (1 KiB)
+  char* sY = smem;                               // [256][256 B]
+  char* sO = smem + 256 * ROWB;                  // [256][256 B]; between blocks: merge buffers
+  char* sS = smem + 512 * ROWB;                  // 32 KiB of images
+  float* sX = reinterpret_cast<float*>(sS);      // [N/2][4] the points (layer 1)               0 ..  4 K
+  char* sA = sS + 4096;                          // O image of the mid stage                    4 ..  8 K
+  char* sH = sS + 8192;                          // H image                                     8 .. 12 K
+  char* sKp = sS + 12288;                        // K image of the many-queries block          12 .. 16 K
+  char* sVt = sS + 16384;                        // V^T image                                  16 .. 20 K
+  float* sTf = reinterpret_cast<float*>(sS + 20480);   // layer 1: merged T fp32 [64][4]       20 .. 21 K
+  float* sAl = reinterpret_cast<float*>(sS + 21504);   // 32 floats per wave                   21 .. 23 K
+  float* sML = reinterpret_cast<float*>(sS + 23552);   // [16 waves][64] float2 (m, l)         23 .. 31 K
+  char* sT = sO;                                 // bf16 image of the merged T (layer 2)
 
   Ctx c;
-  c.b = blockIdx.x; c.N = a.N; c.tid = threadIdx.x; c.lane = c.tid & 63;
+  c.tid = threadIdx.x; c.lane = c.tid & 63;
   c.wave = __builtin_amdgcn_readfirstlane(c.tid >> 6);
   c.q = c.wave >> 2; c.j = c.wave & 3; c.r = c.lane & 15; c.g = c.lane >> 4;
-  c.UPQ = a.N >> 7; c.qn0 = c.q * (a.N >> 2);
-  const int b = c.b, N = a.N, dk = a.din, tid = c.tid, lane = c.lane, r = c.r, g = c.g;
+  {
+    // pair = workgroups w and w + 8: the same XCD when ids are dealt round-robin over the 8 XCDs (a
+    // placement bonus - same L2 - never a correctness condition)
+    const int w = blockIdx.x, xcd = w & 7, k = w >> 3;
+    c.half = k & 1;
+    c.b = (k >> 1) * 8 + xcd;
+  }
+  if (c.b >= ap->B) return;
+  c.N = ap->N; c.NH = c.N >> 1;
+  c.UPQ = c.N >> 8; c.qn0 = c.q * (c.NH >> 2);
+  c.row0 = (int64_t)c.b * c.N + c.half * c.NH;
+  const int b = c.b, dk = ap->din, tid = c.tid, lane = c.lane, r = c.r, g = c.g, NH = c.NH;
+  uint32_t* const flags = ap->flags;
+  STAMP(0);
 
   // ================= layer 1, few-queries block: scores G x, online softmax, T = A x =============
   // (k_mab0_attn_small's arithmetic: exact fp32 on the vector ALU.)  lane = score row (head * 16 +
-  // query), wave w walks the points [w N/16, (w+1) N/16) - their coordinates are wave-uniform LDS
-  // broadcasts - and the 16 partial (m, l, t) per row are merged by wave 0.
+  // query), wave w walks the points [w NH/16, (w+1) NH/16) - their coordinates are wave-uniform LDS
+  // broadcasts; wave 0 merges the 16 partial (m, l, t), hands the workgroup's to the partner and
+  // merges the partner's.
   MidPre pre;
-  mid_prefetch<true>(a.L[0], c, dk, pre);
+  mid_prefetch<true>(LAYER(0), c, dk, pre);
   {
-    for (int i = tid; i < N * 4; i += NT) {
+    const Set128Layer& L = LAYER(0);
+    for (int i = tid; i < NH * 4; i += NT) {
       const int pt = i >> 2, cc = i & 3;
-      sX[i] = cc < dk ? a.X[((int64_t)b * N + pt) * dk + cc] : 0.f;
+      sX[i] = cc < dk ? ap->X[(c.row0 + pt) * dk + cc] : 0.f;
     }
     float gk[4];
 #pragma unroll
-    for (int cc = 0; cc < 4; ++cc) gk[cc] = cc < dk ? a.L[0].Gf[lane * dk + cc] : 0.f;
+    for (int cc = 0; cc < 4; ++cc) gk[cc] = cc < dk ? L.Gf[lane * dk + cc] : 0.f;
     __syncthreads();
-    const int pw = N >> 4, p0 = c.wave * pw;       // 8 .. 32 points per wave
+    const int pw = NH >> 4, p0 = c.wave * pw;       // 8 or 16 points per wave
     float m = -INFINITY;
 #pragma unroll 8
     for (int i = 0; i < pw; ++i) {
       const float4 x4 = *reinterpret_cast<const float4*>(sX + (p0 + i) * 4);
-      m = fmaxf(m, gk[0] * x4.x + gk[1] * x4.y + gk[2] * x4.z + gk[3] * x4.w);
+      m = maxf(m, gk[0] * x4.x + gk[1] * x4.y + gk[2] * x4.z + gk[3] * x4.w);
     }
     float l = 0.f, t4[4] = {0.f, 0.f, 0.f, 0.f};
 #pragma unroll 8
@@ -439,19 +536,19 @@ __global__ __launch_bounds__(NT) void k_set128_fwd(const Set128FwdArgs a) {
       l += p;
       t4[0] += p * x4.x; t4[1] += p * x4.y; t4[2] += p * x4.z; t4[3] += p * x4.w;
     }
-    float* sM = reinterpret_cast<float*>(sS + 8192);       // [16][64]
-    float* sL = reinterpret_cast<float*>(sS + 12288);      // [16][64]
-    float* sTp = reinterpret_cast<float*>(sS + 16384);     // [16][64][4]
+    float* sM = reinterpret_cast<float*>(sO);              // [16][64]
+    float* sL = sM + 16 * 64;                              // [16][64]
+    float* sTp = sL + 16 * 64;                             // [16][64][4]
     sM[c.wave * 64 + lane] = m;
     sL[c.wave * 64 + lane] = l;
     *reinterpret_cast<float4*>(sTp + (c.wave * 64 + lane) * 4) = float4{t4[0], t4[1], t4[2], t4[3]};
-    __syncthreads();
-    float tt[4] = {0.f, 0.f, 0.f, 0.f};
+    STAMP(1);
+    lds_barrier();
     if (c.wave == 0) {
       float M = -INFINITY;
 #pragma unroll
-      for (int p = 0; p < 16; ++p) M = fmaxf(M, sM[p * 64 + lane]);
-      float Ls = 0.f;
+      for (int p = 0; p < 16; ++p) M = maxf(M, sM[p * 64 + lane]);
+      float Ls = 0.f, tt[4] = {0.f, 0.f, 0.f, 0.f};
 #pragma unroll
       for (int p = 0; p < 16; ++p) {
         const float f = __builtin_amdgcn_exp2f(sM[p * 64 + lane] - M);
@@ -459,28 +556,51 @@ __global__ __launch_bounds__(NT) void k_set128_fwd(const Set128FwdArgs a) {
         Ls += sL[p * 64 + lane] * f;
         tt[0] += tp.x * f; tt[1] += tp.y * f; tt[2] += tp.z * f; tt[3] += tp.w * f;
       }
-      const float inv = 1.f / Ls;
+      // hand-off 1: this workgroup's (t, m, l) of the 64 score rows
+      float* mine = ap->ex1 + ((int64_t)(b * 2 + c.half) * 64 + lane) * 8;
+      float* theirs = ap->ex1 + ((int64_t)(b * 2 + (c.half ^ 1)) * 64 + lane) * 8;
+      st16_sc1(mine, float4{tt[0], tt[1], tt[2], tt[3]});
+      st16_sc1(mine + 4, float4{M, Ls, 0.f, 0.f});
+      drain_vm();
+      if (lane == 0) flag_store(flags + 4 + (b * 2 + 0) * 2 + c.half, 1u);
+      flag_wait(flags + 4 + (b * 2 + 0) * 2 + (c.half ^ 1), 1u, flags);
+      f32x4 pt = ld16_sc1(theirs), pm = ld16_sc1(theirs + 4);
+      landed(pt);
+      landed(pm);
+      // merge: products rounded separately, sums commutative - both halves get the same bits
+      const float Mx = fmaxf(M, pm.x);
+      const float fo = __builtin_amdgcn_exp2f(M - Mx), fp = __builtin_amdgcn_exp2f(pm.x - Mx);
+      const float Lt = __fadd_rn(__fmul_rn(fo, Ls), __fmul_rn(fp, pm.y));
+      const float inv = 1.f / Lt;
+      const float tp4[4] = {pt.x, pt.y, pt.z, pt.w};
+      float res[4];
 #pragma unroll
-      for (int cc = 0; cc < 4; ++cc) tt[cc] *= inv;
-      for (int cc = 0; cc < dk; ++cc) a.L[0].T[((int64_t)b * 64 + lane) * dk + cc] = tt[cc];
-      a.L[0].LSE[(int64_t)b * 64 + lane] = M + log2f(Ls);
+      for (int cc = 0; cc < 4; ++cc) res[cc] = __fadd_rn(__fmul_rn(fo, tt[cc]), __fmul_rn(fp, tp4[cc])) * inv;
+      *reinterpret_cast<float4*>(sTf + lane * 4) = float4{res[0], res[1], res[2], res[3]};
+      if (c.half == 0) {
+        for (int cc = 0; cc < dk; ++cc) L.T[((int64_t)b * 64 + lane) * dk + cc] = res[cc];
+        L.LSE[(int64_t)b * 64 + lane] = Mx + log2f(Lt);
+      }
     }
-    __syncthreads();                      // the partial buffers are dead: sTf aliases them
-    if (c.wave == 0) *reinterpret_cast<float4*>(sTf + lane * 4) = float4{tt[0], tt[1], tt[2], tt[3]};
-    __syncthreads();
+    lds_barrier();
   }
-  mid_stage<true>(a.L[0], c, pre, sT, sTf, sA, sH);
+  STAMP(2);
+  ap = launder(ap);
+  mid_stage<true>(LAYER(0), c, pre, sT, sTf, sA, sH, sKp, sVt);
+  STAMP(3);
 
   // ================= layer 1, many-queries block ================================================
-  mab1_phase<true>(a.L[0], c, sY, sX, dk, a.scale_log2e);
+  ap = launder(ap);
+  mab1_phase<true>(LAYER(0), c, sY, sO, sX, sKp, sVt, dk, ap->scale_log2e, 4);
 
   // ================= layer 2, few-queries block over the rows in sY (k_mab0_attn_h4) ==============
+  ap = launder(ap);
   {
-    const Set128Layer& L = a.L[1];
+    const Set128Layer& L = LAYER(1);
     bf16x8 gf[4];                     // this head's G rows: B operand of the score MFMAs
 #pragma unroll
     for (int ks = 0; ks < 4; ++ks) gf[ks] = gload8(L.Gb + (int64_t)(16 * c.j + r) * D + 32 * ks + 8 * g);
-    float* myAl = sAl + c.wave * 16;
+    float* myAl = sAl + c.wave * 32;
     float mrow = -INFINITY, lrow = 0.f;
     f32x4 T[8];
 #pragma unroll
@@ -501,16 +621,16 @@ __global__ __launch_bounds__(NT) void k_set128_fwd(const Set128FwdArgs a) {
 #pragma unroll
       for (int pb = 0; pb < 2; ++pb)
 #pragma unroll
-        for (int e = 0; e < 4; ++e) mt = fmaxf(mt, s[pb][e]);
+        for (int e = 0; e < 4; ++e) mt = maxf(mt, s[pb][e]);
       mt = wave16_max(mt);
-      const float mnew = fmaxf(mrow, mt);
-      const float alpha = exp2f(mrow - mnew);
+      const float mnew = maxf(mrow, mt);
+      const float alpha = __builtin_amdgcn_exp2f(mrow - mnew);
       float ls = 0.f;
 #pragma unroll
       for (int pb = 0; pb < 2; ++pb)
 #pragma unroll
         for (int e = 0; e < 4; ++e) {
-          s[pb][e] = exp2f(s[pb][e] - mnew);
+          s[pb][e] = __builtin_amdgcn_exp2f(s[pb][e] - mnew);
           ls += s[pb][e];
         }
       ls = wave16_sum(ls);
@@ -525,66 +645,129 @@ __global__ __launch_bounds__(NT) void k_set128_fwd(const Set128FwdArgs a) {
         T[ft] = mfma32(pa, y_tr_frag(img, ft, lane), T[ft]);
       }
     }
-    // the four quads' partials of a head meet in global memory (L2: the workgroup's own lines);
-    // 8 KiB per wave - there is no room for them next to sY
-    mid_prefetch<false>(L, c, D, pre);
-    const int64_t pbase = ((int64_t)b * 4 + c.q) * 64 + 16 * c.j;
+    STAMP(9);
+    // ---- the four quads' partials of a head -> quad 0, in two rounds through sO (8 KiB per wave) ----
+    // (m, l) of query row r live in every lane of column r; the T accumulators hold query rows
+    // 4 g + e: their factors come back from LDS as a float4
+    auto put_partial = [&](int slot) {
+      float4* dst = reinterpret_cast<float4*>(sO) + slot * 512;
 #pragma unroll
-    for (int ft = 0; ft < 8; ++ft)
+      for (int ft = 0; ft < 8; ++ft) dst[ft * 64 + lane] = float4{T[ft][0], T[ft][1], T[ft][2], T[ft][3]};
+      *reinterpret_cast<float2*>(sML + (c.wave * 64 + lane) * 2) = float2{mrow, lrow};
+    };
+    auto take_partial = [&](int slot, int from_wave) {
+      const float2 ml = *reinterpret_cast<const float2*>(sML + (from_wave * 64 + lane) * 2);
+      const float mn = maxf(mrow, ml.x);
+      const float f1 = __builtin_amdgcn_exp2f(mrow - mn), f2 = __builtin_amdgcn_exp2f(ml.x - mn);
+      lrow = lrow * f1 + ml.y * f2;
+      mrow = mn;
+      if (g == 0) {
+        myAl[r] = f1;
+        myAl[16 + r] = f2;
+      }
+      const float4 a1 = *reinterpret_cast<const float4*>(&myAl[4 * g]);
+      const float4 a2 = *reinterpret_cast<const float4*>(&myAl[16 + 4 * g]);
+      const float4* src = reinterpret_cast<const float4*>(sO) + slot * 512;
 #pragma unroll
-      for (int e = 0; e < 4; ++e) a.Tp2[(pbase + 4 * g + e) * D + 16 * ft + r] = T[ft][e];
-    if (g == 0) {
-      a.Mp2[pbase + r] = mrow;
-      a.Lp2[pbase + r] = lrow;
+      for (int ft = 0; ft < 8; ++ft) {
+        const float4 o = src[ft * 64 + lane];
+        T[ft][0] = T[ft][0] * a1.x + o.x * a2.x;
+        T[ft][1] = T[ft][1] * a1.y + o.y * a2.y;
+        T[ft][2] = T[ft][2] * a1.z + o.z * a2.z;
+        T[ft][3] = T[ft][3] * a1.w + o.w * a2.w;
+      }
+    };
+    lds_barrier();                       // all score reads of sY done; sO (saved O rows) is stored
+    if (c.q & 1) put_partial((c.q >> 1) * 4 + c.j);
+    lds_barrier();
+    if (!(c.q & 1)) take_partial((c.q >> 1) * 4 + c.j, c.wave + 4);
+    lds_barrier();
+    if (c.q == 2) put_partial(c.j);
+    lds_barrier();
+    float* mine = ap->ex2 + (int64_t)(b * 2 + c.half) * 9216;
+    float* theirs = ap->ex2 + (int64_t)(b * 2 + (c.half ^ 1)) * 9216;
+    if (c.q == 0) {
+      take_partial(c.j, c.wave + 8);
+      // hand-off 2: the workgroup's partial of head j (unnormalised T, m, l)
+#pragma unroll
+      for (int ft = 0; ft < 8; ++ft)
+        st16_sc1(mine + ((ft * 4 + c.j) * 64 + lane) * 4, float4{T[ft][0], T[ft][1], T[ft][2], T[ft][3]});
+      st16_sc1(mine + 8192 + (c.j * 64 + lane) * 4, float4{mrow, lrow, 0.f, 0.f});
+      drain_vm();
     }
-    __syncthreads();
-    {                                  // merge -> T (global fp32, saved) and its bf16 image
+    mid_prefetch<false>(L, c, D, pre);
+    lds_barrier();                       // every storing wave has drained
+    if (tid == 0) flag_store(flags + 4 + (b * 2 + 1) * 2 + c.half, 2u);
+    if (c.wave == 0) flag_wait(flags + 4 + (b * 2 + 1) * 2 + (c.half ^ 1), 2u, flags);
+    lds_barrier();
+    float* sTs = reinterpret_cast<float*>(sO) + 8192;       // staging [64][128] fp32 behind the slots
+    if (c.q == 0) {
+      f32x4 pt[8];
+#pragma unroll
+      for (int ft = 0; ft < 8; ++ft) pt[ft] = ld16_sc1(theirs + ((ft * 4 + c.j) * 64 + lane) * 4);
+      f32x4 pml = ld16_sc1(theirs + 8192 + (c.j * 64 + lane) * 4);
+#pragma unroll
+      for (int ft = 0; ft < 8; ++ft) landed(pt[ft]);
+      landed(pml);
+      const float Mx = fmaxf(mrow, pml.x);
+      const float fo = __builtin_amdgcn_exp2f(mrow - Mx), fp = __builtin_amdgcn_exp2f(pml.x - Mx);
+      const float Lt = __fadd_rn(__fmul_rn(fo, lrow), __fmul_rn(fp, pml.y));
+      const float inv = 1.f / Lt;
+      if (g == 0) {
+        myAl[r] = fo;
+        myAl[16 + r] = fp;
+      }
+      *reinterpret_cast<float2*>(sML + (c.wave * 64 + lane) * 2) = float2{inv, Mx + log2f(Lt)};
+      const float4 a1 = *reinterpret_cast<const float4*>(&myAl[4 * g]);
+      const float4 a2 = *reinterpret_cast<const float4*>(&myAl[16 + 4 * g]);
+      const float a1v[4] = {a1.x, a1.y, a1.z, a1.w}, a2v[4] = {a2.x, a2.y, a2.z, a2.w};
+#pragma unroll
+      for (int ft = 0; ft < 8; ++ft) {
+        const float pv[4] = {pt[ft].x, pt[ft].y, pt[ft].z, pt[ft].w};
+#pragma unroll
+        for (int e = 0; e < 4; ++e)       // unnormalised; row 16 j + 4 g + e, feature 16 ft + r
+          sTs[(16 * c.j + 4 * g + e) * D + 16 * ft + r] =
+              __fadd_rn(__fmul_rn(a1v[e], T[ft][e]), __fmul_rn(a2v[e], pv[e]));
+      }
+    }
+    lds_barrier();
+    {                                  // T (global fp32, saved) and its bf16 image; (inv, lse) of row: lane `row & 15` of wave j
       const int row = tid >> 4, ch = tid & 15;
-      float msv[4], lpv[4];
-      float4 lo[4], hi[4];
-#pragma unroll
-      for (int s = 0; s < 4; ++s) {
-        const int64_t o = ((int64_t)b * 4 + s) * 64 + row;
-        msv[s] = a.Mp2[o];
-        lpv[s] = a.Lp2[o];
-        const float4* tp = reinterpret_cast<const float4*>(a.Tp2 + o * D + ch * 8);
-        lo[s] = tp[0];
-        hi[s] = tp[1];
-      }
-      const float M = fmaxf(fmaxf(msv[0], msv[1]), fmaxf(msv[2], msv[3]));
-      float Ls = 0.f, t[8] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
-#pragma unroll
-      for (int s = 0; s < 4; ++s) {
-        const float fs = exp2f(msv[s] - M);
-        Ls += fs * lpv[s];
-        t[0] += fs * lo[s].x; t[1] += fs * lo[s].y; t[2] += fs * lo[s].z; t[3] += fs * lo[s].w;
-        t[4] += fs * hi[s].x; t[5] += fs * hi[s].y; t[6] += fs * hi[s].z; t[7] += fs * hi[s].w;
-      }
-      const float inv = 1.f / Ls;
+      const float2 il = *reinterpret_cast<const float2*>(sML + ((row >> 4) * 64 + (row & 15)) * 2);
+      const float4 lo = *reinterpret_cast<const float4*>(sTs + row * D + ch * 8);
+      const float4 hi = *reinterpret_cast<const float4*>(sTs + row * D + ch * 8 + 4);
+      float t[8] = {lo.x, lo.y, lo.z, lo.w, hi.x, hi.y, hi.z, hi.w};
       bf16x8 v;
 #pragma unroll
-      for (int k = 0; k < 8; ++k) { t[k] *= inv; v[k] = (__bf16)t[k]; }
-      float4* tg = reinterpret_cast<float4*>(L.T + ((int64_t)b * 64 + row) * D + ch * 8);
-      tg[0] = float4{t[0], t[1], t[2], t[3]};
-      tg[1] = float4{t[4], t[5], t[6], t[7]};
+      for (int k = 0; k < 8; ++k) { t[k] *= il.x; v[k] = (__bf16)t[k]; }
+      if (c.half == 0) {
+        float4* tg = reinterpret_cast<float4*>(L.T + ((int64_t)b * 64 + row) * D + ch * 8);
+        tg[0] = float4{t[0], t[1], t[2], t[3]};
+        tg[1] = float4{t[4], t[5], t[6], t[7]};
+        if (ch == 0) L.LSE[(int64_t)b * 64 + row] = il.y;
+      }
       *reinterpret_cast<bf16x8*>(sT + swz(row, ch, ROWB)) = v;
-      if (ch == 0) L.LSE[(int64_t)b * 64 + row] = M + log2f(Ls);
     }
-    __syncthreads();
-    mid_stage<false>(L, c, pre, sT, sTf, sA, sH);
+    lds_barrier();
+    STAMP(10);
+    mid_stage<false>(L, c, pre, sT, sTf, sA, sH, sKp, sVt);
+    STAMP(11);
   }
 
   // ================= layer 2, many-queries block ================================================
-  mab1_phase<false>(a.L[1], c, sY, sX, D, a.scale_log2e);
+  ap = launder(ap);
+  mab1_phase<false>(LAYER(1), c, sY, sO, sX, sKp, sVt, D, ap->scale_log2e, 12);
 
-  // ================= PMA attention partials over Y2 (k_mab0_attn<1>): wave (q, j) = unit j of quad q ===
+  // ================= PMA attention partials over Y2 (k_mab0_attn<1>): wave w < NH / 32 = unit w ====
+  ap = launder(ap);
   {
     float mrow = -INFINITY, lrow = 0.f;
     f32x4 T[8];
 #pragma unroll
     for (int ft = 0; ft < 8; ++ft) T[ft] = f32x4{0.f, 0.f, 0.f, 0.f};
-    if (c.j < c.UPQ) {
-      const char* img = sY + (c.qn0 + 32 * c.j) * ROWB;
+    const int nun = NH >> 5;                    // 4 or 8 units
+    if (c.wave < nun) {
+      const char* img = sY + (32 * c.wave) * ROWB;
       f32x4 s[2];
 #pragma unroll
       for (int pb = 0; pb < 2; ++pb) {
@@ -592,20 +775,20 @@ __global__ __launch_bounds__(NT) void k_set128_fwd(const Set128FwdArgs a) {
 #pragma unroll
         for (int ks = 0; ks < 4; ++ks)
           s[pb] = mfma32(*reinterpret_cast<const bf16x8*>(img + y_off(16 * pb + r, 4 * ks + g)),
-                         gload8(a.Gpma + (int64_t)r * D + 32 * ks + 8 * g), s[pb]);
+                         gload8(ap->Gpma + (int64_t)r * D + 32 * ks + 8 * g), s[pb]);
       }
       float mt = -INFINITY;
 #pragma unroll
       for (int pb = 0; pb < 2; ++pb)
 #pragma unroll
-        for (int e = 0; e < 4; ++e) mt = fmaxf(mt, s[pb][e]);
+        for (int e = 0; e < 4; ++e) mt = maxf(mt, s[pb][e]);
       mrow = wave16_max(mt);
       float ls = 0.f;
 #pragma unroll
       for (int pb = 0; pb < 2; ++pb)
 #pragma unroll
         for (int e = 0; e < 4; ++e) {
-          s[pb][e] = exp2f(s[pb][e] - mrow);
+          s[pb][e] = __builtin_amdgcn_exp2f(s[pb][e] - mrow);
           ls += s[pb][e];
         }
       lrow = wave16_sum(ls);
@@ -613,9 +796,11 @@ __global__ __launch_bounds__(NT) void k_set128_fwd(const Set128FwdArgs a) {
 #pragma unroll
       for (int ft = 0; ft < 8; ++ft) T[ft] = mfma32(pa, y_tr_frag(img, ft, lane), T[ft]);
     }
-    __syncthreads();                   // sY is dead (its rows are on their way to memory): the slabs alias it
-    float* slab = reinterpret_cast<float*>(sY) + c.wave * 520;     // [4 rows][128] + m[4] + l[4]
-    if (g == 0) {
+    STAMP(17);
+    lds_barrier();                     // sO is dead (its rows are on their way to memory): the slabs alias it
+    STAMP(18);
+    float* slab = reinterpret_cast<float*>(sO) + c.wave * 520;     // [4 rows][128] + m[4] + l[4]
+    if (g == 0 && c.wave < nun) {
 #pragma unroll
       for (int ft = 0; ft < 8; ++ft)
 #pragma unroll
@@ -625,45 +810,64 @@ __global__ __launch_bounds__(NT) void k_set128_fwd(const Set128FwdArgs a) {
         slab[516 + r] = lrow;
       }
     }
-    __syncthreads();
-    const int Sp = a.Sp, qpp = 4 / Sp;           // quads per partial
-    if (tid < Sp * 512) {
+    lds_barrier();
+    const int Spw = ap->Sp >> 1, upp = nun / Spw;           // partials of this workgroup, units per partial
+    if (tid < Spw * 512) {
       const int p = tid >> 9, rr = (tid >> 7) & 3, f = tid & 127;
-      const float* s0 = reinterpret_cast<const float*>(sY);
+      const float* s0 = reinterpret_cast<const float*>(sO);
       float M = -INFINITY;
-      for (int w = p * qpp * 4; w < (p + 1) * qpp * 4; ++w) M = fmaxf(M, s0[w * 520 + 512 + rr]);
+      for (int w = p * upp; w < (p + 1) * upp; ++w) M = fmaxf(M, s0[w * 520 + 512 + rr]);
       float Ls = 0.f, t = 0.f;
-      for (int w = p * qpp * 4; w < (p + 1) * qpp * 4; ++w) {
-        const float mw = s0[w * 520 + 512 + rr];
-        if (mw == -INFINITY) continue;
-        const float fs = exp2f(mw - M);
+      for (int w = p * upp; w < (p + 1) * upp; ++w) {
+        const float fs = __builtin_amdgcn_exp2f(s0[w * 520 + 512 + rr] - M);
         Ls += fs * s0[w * 520 + 516 + rr];
         t += fs * s0[w * 520 + rr * D + f];
       }
-      const int64_t o = ((int64_t)b * Sp + p) * 4 + rr;
-      a.TpP[o * D + f] = t;
+      const int64_t o = ((int64_t)b * ap->Sp + c.half * Spw + p) * 4 + rr;
+      ap->TpP[o * D + f] = t;
       if (f == 0) {
-        a.MpP[o] = M;
-        a.LpP[o] = Ls;
+        ap->MpP[o] = M;
+        ap->LpP[o] = Ls;
       }
     }
+    STAMP(19);
   }
 }
 
 }  // namespace
 
-bool set128_shape_ok(int N, int din, int d, int h, int m, int k) {
-  return d == 128 && h == 4 && m == 16 && k == 1 && din >= 1 && din <= 4 && N % 128 == 0 && N >= 128 &&
-         N <= 512;
+#ifdef PCA_SET_STAMPS
+extern "C" int pca_debug_set_stamps(unsigned long long* out) {
+  return (int)hipMemcpyFromSymbol(out, HIP_SYMBOL(g_set_stamps), sizeof(g_set_stamps));
 }
+#endif
+
+size_t set128_flag_bytes(int B) { return align256((size_t)(4 + B * 4) * sizeof(uint32_t)); }
 
 size_t set128_fwd_ws_bytes(int B) {
-  return align256((size_t)B * 4 * 64 * 128 * sizeof(float)) + 2 * align256((size_t)B * 4 * 64 * sizeof(float));
+  return set128_flag_bytes(B) + align256((size_t)B * 2 * 64 * 8 * sizeof(float)) +
+         align256((size_t)B * 2 * 9216 * sizeof(float));
+}
+
+bool set128_shape_ok(int B, int N, int din, int d, int h, int m, int k) {
+  if (!(d == 128 && h == 4 && m == 16 && k == 1 && din >= 1 && din <= 4 && (N == 256 || N == 512)))
+    return false;
+  // the two workgroups of a set wait for each other: every pair must be resident at once - one
+  // workgroup per CU (160 KiB of LDS), workgroup ids dealt in order
+  static const int cus = [] {
+    int dev = 0, n = 0;
+    if (hipGetDevice(&dev) != hipSuccess) return 0;
+    if (hipDeviceGetAttribute(&n, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess) return 0;
+    return n;
+  }();
+  return 16 * (int)cdiv(B, 8) <= cus;
 }
 
 int set128_fwd_launch(const Set128FwdArgs& a, hipStream_t st) {
-  PCA_REQUIRE(set128_shape_ok(a.N, a.din, 128, 4, 16, 1), "set128_fwd: N=%d din=%d not built", a.N, a.din);
-  PCA_REQUIRE(a.Sp == 1 || a.Sp == 2 || a.Sp == 4, "set128_fwd: %d PMA partials", a.Sp);
+  PCA_REQUIRE(set128_shape_ok(a.B, a.N, a.din, 128, 4, 16, 1), "set128_fwd: B=%d N=%d din=%d not built",
+              a.B, a.N, a.din);
+  PCA_REQUIRE(a.Sp == 2 || a.Sp == 4, "set128_fwd: %d PMA partials", a.Sp);
+  PCA_REQUIRE(a.Sp <= a.N / 128, "set128_fwd: %d PMA partials of %d points", a.Sp, a.N);
   static std::once_flag once;
   std::call_once(once, [] {
     (void)hipFuncSetAttribute(reinterpret_cast<const void*>(k_set128_fwd),
@@ -676,7 +880,7 @@ int set128_fwd_launch(const Set128FwdArgs& a, hipStream_t st) {
   const double Nn = a.N, dd = 128, mm = 16;
   const double macs = Nn * (3.0 * a.din * dd + 7.0 * dd * dd + 8.0 * mm * dd + 2.0 * dd) + 6.0 * mm * dd * dd;
   ProfScope ps(PCA_K_SET_FWD, st, 2.0 * macs * a.B, (double)a.B * (4.0 * Nn * a.din + 8.0 * Nn * dd));
-  hipLaunchKernelGGL(k_set128_fwd, dim3(a.B), dim3(NT), lds, st, a);
+  hipLaunchKernelGGL(k_set128_fwd, dim3(16 * (unsigned)cdiv(a.B, 8)), dim3(NT), lds, st, a);
   ps.end();
   return check_launch("k_set128_fwd");
 }

@@ -126,7 +126,8 @@ inline bool pma_head_ok(const Shapes& s) { return mab_kind(s.pma) == 2 && s.pma.
 inline bool set128_on(const pca_st_config& c, const Shapes& s) {
   const char* e = getenv("PCA_SET128");          // (read per call: tests compare the two forms in-process)
   const bool off = e != nullptr && e[0] == '0';
-  return !off && c.mode == PCA_MODE_BF16 && s.act_bf16 && set128_shape_ok(c.N, c.din, c.d, c.h, c.m, c.k) &&
+  return !off && c.mode == PCA_MODE_BF16 && s.act_bf16 &&
+         set128_shape_ok(c.B, c.N, c.din, c.d, c.h, c.m, c.k) &&
          isab_bf16_supported(s.m0[0], s.m1[0]) && isab_bf16_supported(s.m0[1], s.m1[1]) &&
          pma_head_ok(s) && s.pma.k_lengths == nullptr;
 }
@@ -178,7 +179,7 @@ inline size_t carve(const pca_st_config& c, int training, Ws* out, void* base) {
       if (base != nullptr) isab_img_carve(ib, &w.img[li]);
     }
   }
-  if (training && set128_shape_ok(c.N, c.din, c.d, c.h, c.m, c.k)) {
+  if (training && set128_shape_ok(c.B, c.N, c.din, c.d, c.h, c.m, c.k)) {
     const size_t sb = set128_fwd_ws_bytes(c.B);
     max_scratch = sb > max_scratch ? sb : max_scratch;
   }
@@ -324,6 +325,9 @@ int forward(const pca_st_config& c, const Layout& L, const Shapes& s, const floa
       if (w.fused[li])
         isab_collect_prep(s.m0[li], params_at(p, L.mab0[li]), params_at(p, L.mab1[li]),
                           w.img[li], true, li == 1, &J);
+    if (set128_on(c, s))           // the pair flags of the set-resident forward start every step at zero
+      J.j[J.n++] = PrepJob{nullptr, reinterpret_cast<__bf16*>(w.scratch), 1,
+                           (int)(set128_flag_bytes(c.B) / 2), 4};
     // (launched together with the query-side jobs below)
     // query-side preparation (Qp, G images) of every fused mab0 / PMA, also one launch
     Mab0PrepJobs MJ{};
@@ -371,9 +375,9 @@ int forward(const pca_st_config& c, const Layout& L, const Shapes& s, const floa
       S.QpS = v1.QpS; S.OS = v1.OS; S.Y = reinterpret_cast<__bf16*>(w.Y[li]); S.mask = v1.mask;
     }
     Carver cs(w.scratch);
-    a.Tp2 = cs.take<float>((size_t)c.B * 4 * 64 * 128);
-    a.Mp2 = cs.take<float>((size_t)c.B * 4 * 64);
-    a.Lp2 = cs.take<float>((size_t)c.B * 4 * 64);
+    a.flags = reinterpret_cast<uint32_t*>(cs.take<char>(set128_flag_bytes(c.B)));   // (cleared by k_prep_all)
+    a.ex1 = cs.take<float>((size_t)c.B * 2 * 64 * 8);
+    a.ex2 = cs.take<float>((size_t)c.B * 2 * 9216);
     Mab0Saved vp;
     mab0_carve_saved(s.pma, &vp, w.saved[4]);
     a.Gpma = vp.Gb; a.TpP = vp.Tp; a.MpP = vp.Mp; a.LpP = vp.Lp; a.Sp = mab0_splits(s.pma);
@@ -435,6 +439,22 @@ int64_t pca_st_bucket_split(const pca_st_config* c) {
 size_t pca_st_ws_bytes(const pca_st_config* c, int training) {
   if (pca::validate(c) != PCA_OK) return 0;
   return pca::carve(*c, training, nullptr, nullptr);
+}
+
+int pca_st_ws_layout(const pca_st_config* c, int64_t* out) {
+  PCA_TRY(pca::validate(c));
+  PCA_REQUIRE(out != nullptr, "st_ws_layout: null pointer");
+  pca::Ws w;
+  char* const base = reinterpret_cast<char*>(256);      // (never dereferenced: offsets only)
+  const size_t total = pca::carve(*c, 1, &w, base);
+  for (int i = 0; i < 5; ++i) out[i] = reinterpret_cast<char*>(w.saved[i]) - base;
+  for (int i = 0; i < 2; ++i) {
+    out[5 + i] = reinterpret_cast<char*>(w.H[i]) - base;
+    out[7 + i] = reinterpret_cast<char*>(w.Y[i]) - base;
+  }
+  out[9] = reinterpret_cast<char*>(w.scratch) - base;
+  out[10] = (int64_t)total;
+  return PCA_OK;
 }
 
 int pca_st_forward(const pca_st_config* c, const float* params, const float* X,

@@ -1,5 +1,6 @@
-"""The set-resident forward of the d = 128 / 4 heads / m = 16 train step (csrc/set128_fwd.hip: one
-workgroup carries a set through ISAB -> ISAB -> PMA attention, activations resident in LDS) against
+"""The set-resident forward of the d = 128 / 4 heads / m = 16 train step (csrc/set128_fwd.hip: a pair of
+workgroups carries a set through ISAB -> ISAB -> PMA attention, activations resident in LDS, the
+few-queries attention partials handed across by write-through stores + a flag) against
 
 * the per-block launches it replaces (``PCA_SET128=0``): same arithmetic on the same operand
   roundings, so logits, loss and all 45 gradients agree to reduction-order rounding of the few fp32
@@ -8,8 +9,10 @@ workgroup carries a set through ISAB -> ISAB -> PMA attention, activations resid
 * the CPU oracle (``oracle/st_oracle.py:st_grads``: the reference's ``ST`` + autograd restated,
   Code/models.py:34-44, modules.py:19-33), at the bf16 mode's tolerance.
 
-Sizes: every N the kernel accepts (128, 256, 384, 512: one to four 32-point units per quad of waves),
-din 2 and 3, batch sizes that change the PMA's partial count (``mab0_splits``: 4, 2 partials)."""
+Sizes: both N the kernel accepts (256, 512: one or two 32-point units per quad of waves, 2 or 4 PMA
+partials per set), din 2 and 3, batch sizes that are not a multiple of 8 (idle workgroup pairs) up to the
+128 sets whose 256 workgroups fill the chip; B = 130 (260 workgroups would not all be resident: the
+engine keeps the per-block launches) checks the fall-back."""
 import os
 
 import numpy as np
@@ -46,8 +49,8 @@ def _run(dev, net, X, y, B, N, set128):
             os.environ["PCA_SET128"] = old
 
 
-@pytest.mark.parametrize("B,N,din", [(5, 128, 2), (8, 256, 3), (3, 384, 2), (16, 512, 2), (7, 512, 3),
-                                     (260, 512, 2)])
+@pytest.mark.parametrize("B,N,din", [(5, 256, 2), (8, 256, 3), (3, 512, 2), (16, 512, 2), (7, 512, 3),
+                                     (128, 512, 2), (130, 512, 2)])
 def test_set128_forward_equals_per_block_launches(dev, B, N, din):
     import models
     d, h, m, C = 128, 4, 16, 50
