@@ -41,7 +41,6 @@ struct Set128FwdArgs {
   Set128Layer L[2];
   // pair exchange (scratch; `flags` is zeroed by the step's preparation launch):
   uint32_t* flags;        // [4] header (word 0 counts spin timeouts) + [B][2 exchanges][2 halves]
-  float* ex1;             // [B][2][64][8]     layer-1 attention partials (t[4], m, l)
   float* ex2;             // [B][2][8192 + 1024] layer-2 attention partials (T as float4 [8][4][64], m / l)
   const __bf16* Gpma;     // [>= 16][128] bf16, rows >= 4 zero
   float *TpP, *MpP, *LpP; // PMA attention partials [B][Sp][4][128], [B][Sp][4] x 2 (read by k_pma_head1)

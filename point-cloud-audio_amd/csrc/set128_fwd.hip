@@ -156,8 +156,10 @@ struct MidPre {
 template <bool SMALL>
 __device__ __forceinline__ void mid_prefetch(const Set128Layer& L, const Ctx& c, int dk, MidPre& P) {
   const int r = c.r, g = c.g;
-  if (c.wave < 8) {
-    const int t = c.wave;
+  {
+    // (waves 8-15 load the fragments of tile wave - 8 and never use them: under `if (wave < 8)` hipcc
+    //  spilled every value of this block right behind its load, each with an s_waitcnt vmcnt(0))
+    const int t = c.wave & 7;
     P.qp = *reinterpret_cast<const float4*>(L.Qp0 + r * D + 16 * t + 4 * g);
     P.bv0 = *reinterpret_cast<const float4*>(L.bv0 + 16 * t + 4 * g);
     P.bo0 = *reinterpret_cast<const float4*>(L.bo0 + 16 * t + 4 * g);
@@ -475,14 +477,14 @@ __global__ __launch_bounds__(NT) void k_set128_fwd(const Set128FwdArgs a_by_valu
   char* sY = smem;                               // [256][256 B]
   char* sO = smem + 256 * ROWB;                  // [256][256 B]; between blocks: merge buffers
   char* sS = smem + 512 * ROWB;                  // 32 KiB of images
-  float* sX = reinterpret_cast<float*>(sS);      // [N/2][4] the points (layer 1)               0 ..  4 K
-  char* sA = sS + 4096;                          // O image of the mid stage                    4 ..  8 K
-  char* sH = sS + 8192;                          // H image                                     8 .. 12 K
-  char* sKp = sS + 12288;                        // K image of the many-queries block          12 .. 16 K
-  char* sVt = sS + 16384;                        // V^T image                                  16 .. 20 K
-  float* sTf = reinterpret_cast<float*>(sS + 20480);   // layer 1: merged T fp32 [64][4]       20 .. 21 K
-  float* sAl = reinterpret_cast<float*>(sS + 21504);   // 32 floats per wave                   21 .. 23 K
-  float* sML = reinterpret_cast<float*>(sS + 23552);   // [16 waves][64] float2 (m, l)         23 .. 31 K
+  float* sX = reinterpret_cast<float*>(sS);      // [N][4] the set's points (layer 1)           0 ..  8 K
+  char* sA = sS + 8192;                          // O image of the mid stage                    8 .. 12 K
+  char* sH = sS + 12288;                         // H image                                    12 .. 16 K
+  char* sKp = sS + 16384;                        // K image of the many-queries block          16 .. 20 K
+  char* sVt = sS + 20480;                        // V^T image                                  20 .. 24 K
+  float* sTf = reinterpret_cast<float*>(sS + 24576);   // layer 1: merged T fp32 [64][4]       24 .. 25 K
+  float* sAl = reinterpret_cast<float*>(sS + 25600);   // 32 floats per wave                   25 .. 27 K
+  float* sML = reinterpret_cast<float*>(sS + 27648);   // [16 waves][16 columns] float2        27 .. 29 K
   char* sT = sO;                                 // bf16 image of the merged T (layer 2)
 
   Ctx c;
@@ -504,24 +506,35 @@ __global__ __launch_bounds__(NT) void k_set128_fwd(const Set128FwdArgs a_by_valu
   uint32_t* const flags = ap->flags;
   STAMP(0);
 
-  // ================= layer 1, few-queries block: scores G x, online softmax, T = A x =============
-  // (k_mab0_attn_small's arithmetic: exact fp32 on the vector ALU.)  lane = score row (head * 16 +
-  // query), wave w walks the points [w NH/16, (w+1) NH/16) - their coordinates are wave-uniform LDS
-  // broadcasts; wave 0 merges the 16 partial (m, l, t), hands the workgroup's to the partner and
-  // merges the partner's.
+  // ================= layer 1, few-queries block: scores G x, softmax over the points, T = A x ====
+  // (k_mab0_attn_small's arithmetic: exact fp32 on the vector ALU.)  Its cost is 2 din + 6 operations
+  // per (score row, point): BOTH workgroups of the pair run it over the WHOLE set instead of handing
+  // partials to each other.  lane = score row (head * 16 + query), wave w walks the points
+  // [w N/16, (w+1) N/16) - their coordinates are wave-uniform LDS broadcasts; wave 0 merges.
   MidPre pre;
-  mid_prefetch<true>(LAYER(0), c, dk, pre);
   {
     const Set128Layer& L = LAYER(0);
-    for (int i = tid; i < NH * 4; i += NT) {
+    const int N = c.N;
+    float xs[2];
+#pragma unroll
+    for (int it = 0; it < 2; ++it) {                 // N * 4 <= 2048 staged words
+      const int i = tid + NT * it;
       const int pt = i >> 2, cc = i & 3;
-      sX[i] = cc < dk ? ap->X[(c.row0 + pt) * dk + cc] : 0.f;
+      const int ptc = pt < N ? pt : N - 1, ccc = cc < dk ? cc : 0;      // unconditional, clamped
+      const float v = ap->X[((int64_t)b * N + ptc) * dk + ccc];
+      xs[it] = cc < dk ? v : 0.f;
     }
     float gk[4];
 #pragma unroll
-    for (int cc = 0; cc < 4; ++cc) gk[cc] = cc < dk ? L.Gf[lane * dk + cc] : 0.f;
-    __syncthreads();
-    const int pw = NH >> 4, p0 = c.wave * pw;       // 8 or 16 points per wave
+    for (int cc = 0; cc < 4; ++cc) {
+      const float v = L.Gf[lane * dk + (cc < dk ? cc : 0)];
+      gk[cc] = cc < dk ? v : 0.f;
+    }
+#pragma unroll
+    for (int it = 0; it < 2; ++it)
+      if (tid + NT * it < N * 4) sX[tid + NT * it] = xs[it];
+    lds_barrier();
+    const int pw = N >> 4, p0 = c.wave * pw;         // 16 or 32 points per wave
     float m = -INFINITY;
 #pragma unroll 8
     for (int i = 0; i < pw; ++i) {
@@ -542,44 +555,31 @@ __global__ __launch_bounds__(NT) void k_set128_fwd(const Set128FwdArgs a_by_valu
     sM[c.wave * 64 + lane] = m;
     sL[c.wave * 64 + lane] = l;
     *reinterpret_cast<float4*>(sTp + (c.wave * 64 + lane) * 4) = float4{t4[0], t4[1], t4[2], t4[3]};
+    // the mid stage's weight fragments, one barrier ahead.  (Requested at kernel entry they were live
+    // across the whole attention loop and hipcc spilled every one of them right behind its load: seven
+    // serialised round trips at the start of the kernel.)
+    mid_prefetch<true>(L, c, dk, pre);
     STAMP(1);
     lds_barrier();
     if (c.wave == 0) {
       float M = -INFINITY;
-#pragma unroll
+#pragma unroll 4
       for (int p = 0; p < 16; ++p) M = maxf(M, sM[p * 64 + lane]);
       float Ls = 0.f, tt[4] = {0.f, 0.f, 0.f, 0.f};
-#pragma unroll
+#pragma unroll 4
       for (int p = 0; p < 16; ++p) {
         const float f = __builtin_amdgcn_exp2f(sM[p * 64 + lane] - M);
         const float4 tp = *reinterpret_cast<const float4*>(sTp + (p * 64 + lane) * 4);
         Ls += sL[p * 64 + lane] * f;
         tt[0] += tp.x * f; tt[1] += tp.y * f; tt[2] += tp.z * f; tt[3] += tp.w * f;
       }
-      // hand-off 1: this workgroup's (t, m, l) of the 64 score rows
-      float* mine = ap->ex1 + ((int64_t)(b * 2 + c.half) * 64 + lane) * 8;
-      float* theirs = ap->ex1 + ((int64_t)(b * 2 + (c.half ^ 1)) * 64 + lane) * 8;
-      st16_sc1(mine, float4{tt[0], tt[1], tt[2], tt[3]});
-      st16_sc1(mine + 4, float4{M, Ls, 0.f, 0.f});
-      drain_vm();
-      if (lane == 0) flag_store(flags + 4 + (b * 2 + 0) * 2 + c.half, 1u);
-      flag_wait(flags + 4 + (b * 2 + 0) * 2 + (c.half ^ 1), 1u, flags);
-      f32x4 pt = ld16_sc1(theirs), pm = ld16_sc1(theirs + 4);
-      landed(pt);
-      landed(pm);
-      // merge: products rounded separately, sums commutative - both halves get the same bits
-      const float Mx = fmaxf(M, pm.x);
-      const float fo = __builtin_amdgcn_exp2f(M - Mx), fp = __builtin_amdgcn_exp2f(pm.x - Mx);
-      const float Lt = __fadd_rn(__fmul_rn(fo, Ls), __fmul_rn(fp, pm.y));
-      const float inv = 1.f / Lt;
-      const float tp4[4] = {pt.x, pt.y, pt.z, pt.w};
-      float res[4];
+      const float inv = 1.f / Ls;
 #pragma unroll
-      for (int cc = 0; cc < 4; ++cc) res[cc] = __fadd_rn(__fmul_rn(fo, tt[cc]), __fmul_rn(fp, tp4[cc])) * inv;
-      *reinterpret_cast<float4*>(sTf + lane * 4) = float4{res[0], res[1], res[2], res[3]};
+      for (int cc = 0; cc < 4; ++cc) tt[cc] *= inv;
+      *reinterpret_cast<float4*>(sTf + lane * 4) = float4{tt[0], tt[1], tt[2], tt[3]};
       if (c.half == 0) {
-        for (int cc = 0; cc < dk; ++cc) L.T[((int64_t)b * 64 + lane) * dk + cc] = res[cc];
-        L.LSE[(int64_t)b * 64 + lane] = Mx + log2f(Lt);
+        for (int cc = 0; cc < dk; ++cc) L.T[((int64_t)b * 64 + lane) * dk + cc] = tt[cc];
+        L.LSE[(int64_t)b * 64 + lane] = M + log2f(Ls);
       }
     }
     lds_barrier();
@@ -591,7 +591,7 @@ __global__ __launch_bounds__(NT) void k_set128_fwd(const Set128FwdArgs a_by_valu
 
   // ================= layer 1, many-queries block ================================================
   ap = launder(ap);
-  mab1_phase<true>(LAYER(0), c, sY, sO, sX, sKp, sVt, dk, ap->scale_log2e, 4);
+  mab1_phase<true>(LAYER(0), c, sY, sO, sX + c.half * NH * 4, sKp, sVt, dk, ap->scale_log2e, 4);
 
   // ================= layer 2, few-queries block over the rows in sY (k_mab0_attn_h4) ==============
   ap = launder(ap);
@@ -653,10 +653,10 @@ __global__ __launch_bounds__(NT) void k_set128_fwd(const Set128FwdArgs a_by_valu
       float4* dst = reinterpret_cast<float4*>(sO) + slot * 512;
 #pragma unroll
       for (int ft = 0; ft < 8; ++ft) dst[ft * 64 + lane] = float4{T[ft][0], T[ft][1], T[ft][2], T[ft][3]};
-      *reinterpret_cast<float2*>(sML + (c.wave * 64 + lane) * 2) = float2{mrow, lrow};
+      if (g == 0) *reinterpret_cast<float2*>(sML + (c.wave * 16 + r) * 2) = float2{mrow, lrow};
     };
     auto take_partial = [&](int slot, int from_wave) {
-      const float2 ml = *reinterpret_cast<const float2*>(sML + (from_wave * 64 + lane) * 2);
+      const float2 ml = *reinterpret_cast<const float2*>(sML + (from_wave * 16 + r) * 2);
       const float mn = maxf(mrow, ml.x);
       const float f1 = __builtin_amdgcn_exp2f(mrow - mn), f2 = __builtin_amdgcn_exp2f(ml.x - mn);
       lrow = lrow * f1 + ml.y * f2;
@@ -678,12 +678,15 @@ __global__ __launch_bounds__(NT) void k_set128_fwd(const Set128FwdArgs a_by_valu
       }
     };
     lds_barrier();                       // all score reads of sY done; sO (saved O rows) is stored
+    STAMP(20);
     if (c.q & 1) put_partial((c.q >> 1) * 4 + c.j);
     lds_barrier();
     if (!(c.q & 1)) take_partial((c.q >> 1) * 4 + c.j, c.wave + 4);
     lds_barrier();
+    STAMP(21);
     if (c.q == 2) put_partial(c.j);
     lds_barrier();
+    STAMP(22);
     float* mine = ap->ex2 + (int64_t)(b * 2 + c.half) * 9216;
     float* theirs = ap->ex2 + (int64_t)(b * 2 + (c.half ^ 1)) * 9216;
     if (c.q == 0) {
@@ -695,20 +698,22 @@ __global__ __launch_bounds__(NT) void k_set128_fwd(const Set128FwdArgs a_by_valu
       st16_sc1(mine + 8192 + (c.j * 64 + lane) * 4, float4{mrow, lrow, 0.f, 0.f});
       drain_vm();
     }
-    mid_prefetch<false>(L, c, D, pre);
+    STAMP(23);
     lds_barrier();                       // every storing wave has drained
     if (tid == 0) flag_store(flags + 4 + (b * 2 + 1) * 2 + c.half, 2u);
     if (c.wave == 0) flag_wait(flags + 4 + (b * 2 + 1) * 2 + (c.half ^ 1), 2u, flags);
     lds_barrier();
+    STAMP(24);
     float* sTs = reinterpret_cast<float*>(sO) + 8192;       // staging [64][128] fp32 behind the slots
     if (c.q == 0) {
       f32x4 pt[8];
+      f32x4 pml = ld16_sc1(theirs + 8192 + (c.j * 64 + lane) * 4);
 #pragma unroll
       for (int ft = 0; ft < 8; ++ft) pt[ft] = ld16_sc1(theirs + ((ft * 4 + c.j) * 64 + lane) * 4);
-      f32x4 pml = ld16_sc1(theirs + 8192 + (c.j * 64 + lane) * 4);
 #pragma unroll
       for (int ft = 0; ft < 8; ++ft) landed(pt[ft]);
       landed(pml);
+      STAMP(26);
       const float Mx = fmaxf(mrow, pml.x);
       const float fo = __builtin_amdgcn_exp2f(mrow - Mx), fp = __builtin_amdgcn_exp2f(pml.x - Mx);
       const float Lt = __fadd_rn(__fmul_rn(fo, lrow), __fmul_rn(fp, pml.y));
@@ -717,7 +722,7 @@ __global__ __launch_bounds__(NT) void k_set128_fwd(const Set128FwdArgs a_by_valu
         myAl[r] = fo;
         myAl[16 + r] = fp;
       }
-      *reinterpret_cast<float2*>(sML + (c.wave * 64 + lane) * 2) = float2{inv, Mx + log2f(Lt)};
+      if (g == 0) *reinterpret_cast<float2*>(sML + (c.wave * 16 + r) * 2) = float2{inv, Mx + log2f(Lt)};
       const float4 a1 = *reinterpret_cast<const float4*>(&myAl[4 * g]);
       const float4 a2 = *reinterpret_cast<const float4*>(&myAl[16 + 4 * g]);
       const float a1v[4] = {a1.x, a1.y, a1.z, a1.w}, a2v[4] = {a2.x, a2.y, a2.z, a2.w};
@@ -730,10 +735,12 @@ __global__ __launch_bounds__(NT) void k_set128_fwd(const Set128FwdArgs a_by_valu
               __fadd_rn(__fmul_rn(a1v[e], T[ft][e]), __fmul_rn(a2v[e], pv[e]));
       }
     }
+    mid_prefetch<false>(L, c, D, pre);   // one barrier ahead of the mid stage (see layer 1)
+    STAMP(25);
     lds_barrier();
     {                                  // T (global fp32, saved) and its bf16 image; (inv, lse) of row: lane `row & 15` of wave j
       const int row = tid >> 4, ch = tid & 15;
-      const float2 il = *reinterpret_cast<const float2*>(sML + ((row >> 4) * 64 + (row & 15)) * 2);
+      const float2 il = *reinterpret_cast<const float2*>(sML + ((row >> 4) * 16 + (row & 15)) * 2);
       const float4 lo = *reinterpret_cast<const float4*>(sTs + row * D + ch * 8);
       const float4 hi = *reinterpret_cast<const float4*>(sTs + row * D + ch * 8 + 4);
       float t[8] = {lo.x, lo.y, lo.z, lo.w, hi.x, hi.y, hi.z, hi.w};
@@ -845,8 +852,7 @@ extern "C" int pca_debug_set_stamps(unsigned long long* out) {
 size_t set128_flag_bytes(int B) { return align256((size_t)(4 + B * 4) * sizeof(uint32_t)); }
 
 size_t set128_fwd_ws_bytes(int B) {
-  return set128_flag_bytes(B) + align256((size_t)B * 2 * 64 * 8 * sizeof(float)) +
-         align256((size_t)B * 2 * 9216 * sizeof(float));
+  return set128_flag_bytes(B) + align256((size_t)B * 2 * 9216 * sizeof(float));
 }
 
 bool set128_shape_ok(int B, int N, int din, int d, int h, int m, int k) {

@@ -376,7 +376,6 @@ int forward(const pca_st_config& c, const Layout& L, const Shapes& s, const floa
     }
     Carver cs(w.scratch);
     a.flags = reinterpret_cast<uint32_t*>(cs.take<char>(set128_flag_bytes(c.B)));   // (cleared by k_prep_all)
-    a.ex1 = cs.take<float>((size_t)c.B * 2 * 64 * 8);
     a.ex2 = cs.take<float>((size_t)c.B * 2 * 9216);
     Mab0Saved vp;
     mab0_carve_saved(s.pma, &vp, w.saved[4]);

@@ -32,10 +32,11 @@ t0 = st[:, 0].min()
 names = {0: "start", 1: "L1 attn", 2: "L1 merged", 3: "L1 mid", 4: "L1 mab1 chain", 5: "L1 O in sY", 6: "L1 gemm2",
          7: "L1 Y in sY", 8: "L1 Y stored", 9: "L2 attn", 10: "L2 merged", 11: "L2 mid", 12: "L2 mab1 chain",
          13: "L2 O in sY", 14: "L2 gemm2", 15: "L2 Y in sY", 16: "L2 Y stored", 17: "PMA scores", 18: "PMA barrier",
-         19: "end"}
+         19: "end", 20: "L2m: bar0", 21: "L2m: round A", 22: "L2m: round B", 23: "L2m: published",
+         24: "L2m: partner flag", 25: "L2m: merged", 26: "L2m: loads landed"}
 print("stamp                 wave0      min      max   (us since first start; 100 MHz clock)")
 prev = 0.0
-for i in range(20):
+for i in [0, 1, 2, 3, 4, 5, 6, 7, 8, 9, 20, 21, 22, 23, 24, 26, 25, 10, 11, 12, 13, 14, 15, 16, 17, 18, 19]:
     col = (st[:, i] - t0) / 100.0
     w0 = col[0]
     print(f"{i:2d} {names.get(i, ''):16s} {w0:8.2f} {col.min():8.2f} {col.max():8.2f}   d(w0) {w0 - prev:6.2f}")
