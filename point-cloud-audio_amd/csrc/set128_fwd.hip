@@ -267,16 +267,16 @@ __device__ __forceinline__ void mid_stage(const Set128Layer& L, const Ctx& c, co
 //   coalesced stores of the saved O (from sO) and of Y (from sY)
 // SMALL: layer 1 (dq = din <= 4: fc_q on the vector ALU from the points in sX, nothing in sY yet)
 // ---------------------------------------------------------------------------------------------
-template <bool SMALL>
+template <bool SMALL, int DQ>
 __device__ __forceinline__ void mab1_phase(const Set128Layer& L, const Ctx& c, char* sY, char* sO,
-                                           const float* sX, const char* sKp, const char* sVt, int dq,
+                                           const float* sX, const char* sKp, const char* sVt,
                                            float scale_log2e, int stamp0) {
   (void)stamp0;
   const int r = c.r, g = c.g, j = c.j;
   constexpr int KS = 4;
   // this head's weight slices as A operands [row = feature 32 j + 16 t + r][k-slots 32 s + 8 g ..]
   bf16x8 wa[KS][2];
-  float wqs[2][4][4];
+  float wqs[2][4][SMALL ? DQ : 1];
   if (!SMALL) {
 #pragma unroll
     for (int s = 0; s < KS; ++s)
@@ -289,16 +289,14 @@ __device__ __forceinline__ void mab1_phase(const Set128Layer& L, const Ctx& c, c
 #pragma unroll
       for (int e = 0; e < 4; ++e)
 #pragma unroll
-        for (int cc = 0; cc < 4; ++cc)
-          wqs[t][e][cc] = cc < dq ? L.WqF[(32 * j + 16 * t + 4 * g + e) * dq + cc] : 0.f;
+        for (int cc = 0; cc < DQ; ++cc)
+          wqs[t][e][SMALL ? cc : 0] = L.WqF[(32 * j + 16 * t + 4 * g + e) * DQ + cc];
   }
-  f32x4 bqv[2], bov[2];
+  f32x4 bqv[2];
 #pragma unroll
   for (int t = 0; t < 2; ++t) {
     const float4 q4 = *reinterpret_cast<const float4*>(L.bq1 + 32 * j + 16 * t + 4 * g);
-    const float4 o4 = *reinterpret_cast<const float4*>(L.bo1 + 32 * j + 16 * t + 4 * g);
     bqv[t] = f32x4{q4.x, q4.y, q4.z, q4.w};
-    bov[t] = f32x4{o4.x, o4.y, o4.z, o4.w};
   }
   // the head's 16 keys: A operand [key r][k-slots 8 g .. of the head's 32 features] and
   // V^T: A operand [feature 16 t + r][keys 4 g ..]
@@ -308,18 +306,15 @@ __device__ __forceinline__ void mab1_phase(const Set128Layer& L, const Ctx& c, c
   for (int t = 0; t < 2; ++t)
     vta[t] = *reinterpret_cast<const bf16x4*>(sVt + ((32 * j + 16 * t + r) * MQ + 4 * g) * 2);
 
-  // per-lane byte offsets inside a 16-row block of sY / sO (y_off depends on row & 15 only)
-  int oB[KS], oD[2], oP[KS][2];
+  // per-lane byte offsets inside a 16-row block of sY / sO (y_off depends on row & 15 only); each
+  // set is computed where its phase starts - held from the top they cost 14 registers the kernel does
+  // not have (a spilled index reloaded next to a prefetch makes the reload's vmcnt(0) wait for it)
+  int oB[KS], oD[2];
 #pragma unroll
-  for (int s = 0; s < KS; ++s) {
-    oB[s] = y_off(r, 4 * s + g);
-#pragma unroll
-    for (int hh = 0; hh < 2; ++hh) oP[s][hh] = y_off(r, 4 * s + 2 * hh + (g >> 1)) + 8 * (g & 1);
-  }
+  for (int s = 0; s < KS; ++s) oB[s] = y_off(r, 4 * s + g);
 #pragma unroll
   for (int t = 0; t < 2; ++t) oD[t] = y_off(r, 4 * j + 2 * t + (g >> 1)) + 8 * (g & 1);
 
-  bf16x4 opk[2][2][2];                // [unit][t][nb]: the wave's O slices (the residual of the epilogue)
 #pragma unroll
   for (int u = 0; u < 2; ++u) {
     if (u >= c.UPQ) break;
@@ -329,12 +324,16 @@ __device__ __forceinline__ void mab1_phase(const Set128Layer& L, const Ctx& c, c
 #pragma unroll
       for (int nb = 0; nb < 2; ++nb) {
         const float4 x4 = *reinterpret_cast<const float4*>(sX + (n0 + 16 * nb + r) * 4);
+        const float xc[4] = {x4.x, x4.y, x4.z, x4.w};
 #pragma unroll
         for (int t = 0; t < 2; ++t)
 #pragma unroll
-          for (int e = 0; e < 4; ++e)
-            acc[t][nb][e] = bqv[t][e] + wqs[t][e][0] * x4.x + wqs[t][e][1] * x4.y +
-                            wqs[t][e][2] * x4.z + wqs[t][e][3] * x4.w;
+          for (int e = 0; e < 4; ++e) {
+            float v = bqv[t][e];
+#pragma unroll
+            for (int cc = 0; cc < DQ; ++cc) v += wqs[t][e][SMALL ? cc : 0] * xc[cc];
+            acc[t][nb][e] = v;
+          }
       }
     } else {
 #pragma unroll
@@ -383,10 +382,8 @@ __device__ __forceinline__ void mab1_phase(const Set128Layer& L, const Ctx& c, c
 #pragma unroll
     for (int nb = 0; nb < 2; ++nb)
 #pragma unroll
-      for (int t = 0; t < 2; ++t) {
-        opk[u][t][nb] = pack4(acc[t][nb]);
-        *reinterpret_cast<bf16x4*>(sO + (n0 + 16 * nb) * ROWB + oD[t]) = opk[u][t][nb];
-      }
+      for (int t = 0; t < 2; ++t)
+        *reinterpret_cast<bf16x4*>(sO + (n0 + 16 * nb) * ROWB + oD[t]) = pack4(acc[t][nb]);
   }
   // fc_o's weight slice replaces fc_q's (K-permuted image: the O tiles come back from sO in
   // accumulator order); requested before the barrier
@@ -395,6 +392,17 @@ __device__ __forceinline__ void mab1_phase(const Set128Layer& L, const Ctx& c, c
 #pragma unroll
     for (int t = 0; t < 2; ++t)
       wa[s][t] = gload8(L.WoP + (int64_t)(32 * j + 16 * t + r) * D + 32 * s + 8 * g);
+  f32x4 bov[2];
+#pragma unroll
+  for (int t = 0; t < 2; ++t) {
+    const float4 o4 = *reinterpret_cast<const float4*>(L.bo1 + 32 * j + 16 * t + 4 * g);
+    bov[t] = f32x4{o4.x, o4.y, o4.z, o4.w};
+  }
+  int oP[KS][2];
+#pragma unroll
+  for (int s = 0; s < KS; ++s)
+#pragma unroll
+    for (int hh = 0; hh < 2; ++hh) oP[s][hh] = y_off(r, 4 * s + 2 * hh + (g >> 1)) + 8 * (g & 1);
   STAMP(stamp0);
   lds_barrier();                        // O rows complete; every head has read the unit's input rows
   STAMP(stamp0 + 1);
@@ -428,7 +436,7 @@ __device__ __forceinline__ void mab1_phase(const Set128Layer& L, const Ctx& c, c
       f32x4 y[2];
 #pragma unroll
       for (int t = 1; t >= 0; --t) {
-        const bf16x4 o4 = opk[u][t][nb];
+        const bf16x4 o4 = *reinterpret_cast<const bf16x4*>(sO + (n0 + 16 * nb) * ROWB + oD[t]);   // the residual
 #pragma unroll
         for (int e = 3; e >= 0; --e) {
           const float zz = acc[t][nb][e], of = (float)o4[e];
@@ -465,11 +473,21 @@ __device__ __forceinline__ karg_t* launder(karg_t* p) {
   asm volatile("" : "+s"(p));
   return p;
 }
+// The same for the thread index at a phase boundary: everything derived from it (lane, r, g, the swizzled
+// LDS offsets ...) is recomputed in the next phase - a handful of VALU instructions - instead of being kept
+// alive across phases by common-subexpression elimination, which cost ~20 spilled registers whose scratch
+// reloads (vmcnt!) then sat next to the prefetches
+__device__ __forceinline__ void rederive(Ctx& c) {
+  int t = c.tid;
+  asm volatile("" : "+v"(t));
+  c.tid = t; c.lane = t & 63; c.r = t & 15; c.g = (t >> 4) & 3;
+}
 
 // (explicit address-space cast: the host pass of hipcc rejects the implicit one; the optimiser infers the
 //  constant address space back, the loads stay scalar)
 #define LAYER(i) (*(const Set128Layer*)(&ap->L[i]))
 
+template <int DIN>
 __global__ __launch_bounds__(NT) void k_set128_fwd(const Set128FwdArgs a_by_value) {
   (void)a_by_value;
   karg_t* ap = launder((karg_t*)__builtin_amdgcn_kernarg_segment_ptr());
@@ -502,7 +520,8 @@ __global__ __launch_bounds__(NT) void k_set128_fwd(const Set128FwdArgs a_by_valu
   c.N = ap->N; c.NH = c.N >> 1;
   c.UPQ = c.N >> 8; c.qn0 = c.q * (c.NH >> 2);
   c.row0 = (int64_t)c.b * c.N + c.half * c.NH;
-  const int b = c.b, dk = ap->din, tid = c.tid, lane = c.lane, r = c.r, g = c.g, NH = c.NH;
+  constexpr int dk = DIN;
+  const int b = c.b, NH = c.NH;
   uint32_t* const flags = ap->flags;
   STAMP(0);
 
@@ -514,7 +533,7 @@ __global__ __launch_bounds__(NT) void k_set128_fwd(const Set128FwdArgs a_by_valu
   MidPre pre;
   {
     const Set128Layer& L = LAYER(0);
-    const int N = c.N;
+    const int N = c.N, tid = c.tid, lane = c.lane;
     float xs[2];
 #pragma unroll
     for (int it = 0; it < 2; ++it) {                 // N * 4 <= 2048 staged words
@@ -586,17 +605,21 @@ __global__ __launch_bounds__(NT) void k_set128_fwd(const Set128FwdArgs a_by_valu
   }
   STAMP(2);
   ap = launder(ap);
+  rederive(c);
   mid_stage<true>(LAYER(0), c, pre, sT, sTf, sA, sH, sKp, sVt);
   STAMP(3);
 
   // ================= layer 1, many-queries block ================================================
   ap = launder(ap);
-  mab1_phase<true>(LAYER(0), c, sY, sO, sX + c.half * NH * 4, sKp, sVt, dk, ap->scale_log2e, 4);
+  rederive(c);
+  mab1_phase<true, DIN>(LAYER(0), c, sY, sO, sX + c.half * NH * 4, sKp, sVt, ap->scale_log2e, 4);
 
   // ================= layer 2, few-queries block over the rows in sY (k_mab0_attn_h4) ==============
   ap = launder(ap);
+  rederive(c);
   {
     const Set128Layer& L = LAYER(1);
+    const int tid = c.tid, lane = c.lane, r = c.r, g = c.g;
     bf16x8 gf[4];                     // this head's G rows: B operand of the score MFMAs
 #pragma unroll
     for (int ks = 0; ks < 4; ++ks) gf[ks] = gload8(L.Gb + (int64_t)(16 * c.j + r) * D + 32 * ks + 8 * g);
@@ -763,11 +786,14 @@ __global__ __launch_bounds__(NT) void k_set128_fwd(const Set128FwdArgs a_by_valu
 
   // ================= layer 2, many-queries block ================================================
   ap = launder(ap);
-  mab1_phase<false>(LAYER(1), c, sY, sO, sX, sKp, sVt, D, ap->scale_log2e, 12);
+  rederive(c);
+  mab1_phase<false, D>(LAYER(1), c, sY, sO, sX, sKp, sVt, ap->scale_log2e, 12);
 
   // ================= PMA attention partials over Y2 (k_mab0_attn<1>): wave w < NH / 32 = unit w ====
   ap = launder(ap);
+  rederive(c);
   {
+    const int tid = c.tid, lane = c.lane, r = c.r, g = c.g;
     float mrow = -INFINITY, lrow = 0.f;
     f32x4 T[8];
 #pragma unroll
@@ -876,8 +902,9 @@ int set128_fwd_launch(const Set128FwdArgs& a, hipStream_t st) {
   PCA_REQUIRE(a.Sp <= a.N / 128, "set128_fwd: %d PMA partials of %d points", a.Sp, a.N);
   static std::once_flag once;
   std::call_once(once, [] {
-    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(k_set128_fwd),
-                              hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+    const void* ks[4] = {reinterpret_cast<const void*>(k_set128_fwd<1>), reinterpret_cast<const void*>(k_set128_fwd<2>),
+                         reinterpret_cast<const void*>(k_set128_fwd<3>), reinterpret_cast<const void*>(k_set128_fwd<4>)};
+    for (const void* k : ks) (void)hipFuncSetAttribute(k, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
   });
   const size_t lds = (size_t)512 * ROWB + 32768;
   // reference-formulation FLOPs of the three blocks this launch covers (the PMA's
@@ -886,7 +913,13 @@ int set128_fwd_launch(const Set128FwdArgs& a, hipStream_t st) {
   const double Nn = a.N, dd = 128, mm = 16;
   const double macs = Nn * (3.0 * a.din * dd + 7.0 * dd * dd + 8.0 * mm * dd + 2.0 * dd) + 6.0 * mm * dd * dd;
   ProfScope ps(PCA_K_SET_FWD, st, 2.0 * macs * a.B, (double)a.B * (4.0 * Nn * a.din + 8.0 * Nn * dd));
-  hipLaunchKernelGGL(k_set128_fwd, dim3(16 * (unsigned)cdiv(a.B, 8)), dim3(NT), lds, st, a);
+  const dim3 grid(16 * (unsigned)cdiv(a.B, 8));
+  switch (a.din) {
+    case 1: hipLaunchKernelGGL(k_set128_fwd<1>, grid, dim3(NT), lds, st, a); break;
+    case 2: hipLaunchKernelGGL(k_set128_fwd<2>, grid, dim3(NT), lds, st, a); break;
+    case 3: hipLaunchKernelGGL(k_set128_fwd<3>, grid, dim3(NT), lds, st, a); break;
+    default: hipLaunchKernelGGL(k_set128_fwd<4>, grid, dim3(NT), lds, st, a); break;
+  }
   ps.end();
   return check_launch("k_set128_fwd");
 }
