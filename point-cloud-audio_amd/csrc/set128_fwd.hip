@@ -267,7 +267,7 @@ __device__ __forceinline__ void mid_stage(const Set128Layer& L, const Ctx& c, co
 //   coalesced stores of the saved O (from sO) and of Y (from sY)
 // SMALL: layer 1 (dq = din <= 4: fc_q on the vector ALU from the points in sX, nothing in sY yet)
 // ---------------------------------------------------------------------------------------------
-template <bool SMALL, int DQ>
+template <bool SMALL, int DQ, int UPQ>
 __device__ __forceinline__ void mab1_phase(const Set128Layer& L, const Ctx& c, char* sY, char* sO,
                                            const float* sX, const char* sKp, const char* sVt,
                                            float scale_log2e, int stamp0) {
@@ -316,8 +316,8 @@ __device__ __forceinline__ void mab1_phase(const Set128Layer& L, const Ctx& c, c
   for (int t = 0; t < 2; ++t) oD[t] = y_off(r, 4 * j + 2 * t + (g >> 1)) + 8 * (g & 1);
 
 #pragma unroll
-  for (int u = 0; u < 2; ++u) {
-    if (u >= c.UPQ) break;
+  for (int u = 0; u < UPQ; ++u) {     // (a compile-time bound: both units of a wave in ONE basic block, so
+                                      //  that hipcc interleaves their dependent MFMA -> softmax -> MFMA chains)
     const int n0 = c.qn0 + 32 * u;
     f32x4 acc[2][2];
     if (SMALL) {
@@ -407,8 +407,8 @@ __device__ __forceinline__ void mab1_phase(const Set128Layer& L, const Ctx& c, c
   lds_barrier();                        // O rows complete; every head has read the unit's input rows
   STAMP(stamp0 + 1);
 #pragma unroll
-  for (int u = 0; u < 2; ++u) {
-    if (u >= c.UPQ) break;
+  for (int u = 0; u < UPQ; ++u) {     // (a compile-time bound: both units of a wave in ONE basic block, so
+                                      //  that hipcc interleaves their dependent MFMA -> softmax -> MFMA chains)
     const int n0 = c.qn0 + 32 * u;
     f32x4 acc[2][2];
 #pragma unroll
@@ -487,7 +487,7 @@ __device__ __forceinline__ void rederive(Ctx& c) {
 //  constant address space back, the loads stay scalar)
 #define LAYER(i) (*(const Set128Layer*)(&ap->L[i]))
 
-template <int DIN>
+template <int DIN, int UPQ>
 __global__ __launch_bounds__(NT) void k_set128_fwd(const Set128FwdArgs a_by_value) {
   (void)a_by_value;
   karg_t* ap = launder((karg_t*)__builtin_amdgcn_kernarg_segment_ptr());
@@ -543,31 +543,54 @@ __global__ __launch_bounds__(NT) void k_set128_fwd(const Set128FwdArgs a_by_valu
       const float v = ap->X[((int64_t)b * N + ptc) * dk + ccc];
       xs[it] = cc < dk ? v : 0.f;
     }
-    float gk[4];
+    float gk[DIN];
 #pragma unroll
-    for (int cc = 0; cc < 4; ++cc) {
-      const float v = L.Gf[lane * dk + (cc < dk ? cc : 0)];
-      gk[cc] = cc < dk ? v : 0.f;
+    for (int cc = 0; cc < DIN; ++cc) gk[cc] = L.Gf[lane * dk + cc];
+    // two images of the points: [point][4] for the layer-1 projection of the many-queries block, and
+    // [pair of points][component][2] - the operand pairs of the packed-fp32 loop below (v_pk_fma_f32 /
+    // v_pk_mul_f32 work on two points per issue slot, as in k_mab0_attn_small)
+    float* sXp = reinterpret_cast<float*>(sO) + 8192;
+#pragma unroll
+    for (int it = 0; it < 2; ++it) {
+      const int i = tid + NT * it;
+      if (i < N * 4) {
+        const int pt = i >> 2, cc = i & 3;
+        sX[i] = xs[it];
+        sXp[(pt >> 1) * 8 + cc * 2 + (pt & 1)] = xs[it];
+      }
     }
-#pragma unroll
-    for (int it = 0; it < 2; ++it)
-      if (tid + NT * it < N * 4) sX[tid + NT * it] = xs[it];
     lds_barrier();
-    const int pw = N >> 4, p0 = c.wave * pw;         // 16 or 32 points per wave
+    const int npw = N >> 5, q0 = c.wave * npw;       // 8 or 16 pairs of points per wave
     float m = -INFINITY;
 #pragma unroll 8
-    for (int i = 0; i < pw; ++i) {
-      const float4 x4 = *reinterpret_cast<const float4*>(sX + (p0 + i) * 4);
-      m = maxf(m, gk[0] * x4.x + gk[1] * x4.y + gk[2] * x4.z + gk[3] * x4.w);
+    for (int i = 0; i < npw; ++i) {
+      const float* px = sXp + (q0 + i) * 8;
+      f32x2 sv = gk[0] * *reinterpret_cast<const f32x2*>(px);
+#pragma unroll
+      for (int cc = 1; cc < DIN; ++cc) sv += gk[cc] * *reinterpret_cast<const f32x2*>(px + 2 * cc);
+      m = maxf(m, maxf(sv[0], sv[1]));
     }
-    float l = 0.f, t4[4] = {0.f, 0.f, 0.f, 0.f};
+    f32x2 l2 = {0.f, 0.f}, t2[DIN];
+#pragma unroll
+    for (int cc = 0; cc < DIN; ++cc) t2[cc] = f32x2{0.f, 0.f};
 #pragma unroll 8
-    for (int i = 0; i < pw; ++i) {
-      const float4 x4 = *reinterpret_cast<const float4*>(sX + (p0 + i) * 4);
-      const float p = __builtin_amdgcn_exp2f(gk[0] * x4.x + gk[1] * x4.y + gk[2] * x4.z + gk[3] * x4.w - m);
-      l += p;
-      t4[0] += p * x4.x; t4[1] += p * x4.y; t4[2] += p * x4.z; t4[3] += p * x4.w;
+    for (int i = 0; i < npw; ++i) {
+      const float* px = sXp + (q0 + i) * 8;
+      f32x2 xv[DIN];
+#pragma unroll
+      for (int cc = 0; cc < DIN; ++cc) xv[cc] = *reinterpret_cast<const f32x2*>(px + 2 * cc);
+      f32x2 sv = gk[0] * xv[0];
+#pragma unroll
+      for (int cc = 1; cc < DIN; ++cc) sv += gk[cc] * xv[cc];
+      const f32x2 p = {__builtin_amdgcn_exp2f(sv[0] - m), __builtin_amdgcn_exp2f(sv[1] - m)};
+      l2 += p;
+#pragma unroll
+      for (int cc = 0; cc < DIN; ++cc) t2[cc] += p * xv[cc];
     }
+    const float l = l2[0] + l2[1];
+    float t4[4] = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+    for (int cc = 0; cc < DIN; ++cc) t4[cc] = t2[cc][0] + t2[cc][1];
     float* sM = reinterpret_cast<float*>(sO);              // [16][64]
     float* sL = sM + 16 * 64;                              // [16][64]
     float* sTp = sL + 16 * 64;                             // [16][64][4]
@@ -612,7 +635,7 @@ __global__ __launch_bounds__(NT) void k_set128_fwd(const Set128FwdArgs a_by_valu
   // ================= layer 1, many-queries block ================================================
   ap = launder(ap);
   rederive(c);
-  mab1_phase<true, DIN>(LAYER(0), c, sY, sO, sX + c.half * NH * 4, sKp, sVt, ap->scale_log2e, 4);
+  mab1_phase<true, DIN, UPQ>(LAYER(0), c, sY, sO, sX + c.half * NH * 4, sKp, sVt, ap->scale_log2e, 4);
 
   // ================= layer 2, few-queries block over the rows in sY (k_mab0_attn_h4) ==============
   ap = launder(ap);
@@ -628,7 +651,8 @@ __global__ __launch_bounds__(NT) void k_set128_fwd(const Set128FwdArgs a_by_valu
     f32x4 T[8];
 #pragma unroll
     for (int ft = 0; ft < 8; ++ft) T[ft] = f32x4{0.f, 0.f, 0.f, 0.f};
-    for (int u = 0; u < c.UPQ; ++u) {
+#pragma unroll
+    for (int u = 0; u < UPQ; ++u) {
       const char* img = sY + (c.qn0 + 32 * u) * ROWB;
       f32x4 s[2];
 #pragma unroll
@@ -787,7 +811,7 @@ __global__ __launch_bounds__(NT) void k_set128_fwd(const Set128FwdArgs a_by_valu
   // ================= layer 2, many-queries block ================================================
   ap = launder(ap);
   rederive(c);
-  mab1_phase<false, D>(LAYER(1), c, sY, sO, sX, sKp, sVt, ap->scale_log2e, 12);
+  mab1_phase<false, D, UPQ>(LAYER(1), c, sY, sO, sX, sKp, sVt, ap->scale_log2e, 12);
 
   // ================= PMA attention partials over Y2 (k_mab0_attn<1>): wave w < NH / 32 = unit w ====
   ap = launder(ap);
@@ -902,8 +926,10 @@ int set128_fwd_launch(const Set128FwdArgs& a, hipStream_t st) {
   PCA_REQUIRE(a.Sp <= a.N / 128, "set128_fwd: %d PMA partials of %d points", a.Sp, a.N);
   static std::once_flag once;
   std::call_once(once, [] {
-    const void* ks[4] = {reinterpret_cast<const void*>(k_set128_fwd<1>), reinterpret_cast<const void*>(k_set128_fwd<2>),
-                         reinterpret_cast<const void*>(k_set128_fwd<3>), reinterpret_cast<const void*>(k_set128_fwd<4>)};
+    const void* ks[8] = {reinterpret_cast<const void*>(k_set128_fwd<1, 1>), reinterpret_cast<const void*>(k_set128_fwd<2, 1>),
+                         reinterpret_cast<const void*>(k_set128_fwd<3, 1>), reinterpret_cast<const void*>(k_set128_fwd<4, 1>),
+                         reinterpret_cast<const void*>(k_set128_fwd<1, 2>), reinterpret_cast<const void*>(k_set128_fwd<2, 2>),
+                         reinterpret_cast<const void*>(k_set128_fwd<3, 2>), reinterpret_cast<const void*>(k_set128_fwd<4, 2>)};
     for (const void* k : ks) (void)hipFuncSetAttribute(k, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
   });
   const size_t lds = (size_t)512 * ROWB + 32768;
@@ -914,11 +940,16 @@ int set128_fwd_launch(const Set128FwdArgs& a, hipStream_t st) {
   const double macs = Nn * (3.0 * a.din * dd + 7.0 * dd * dd + 8.0 * mm * dd + 2.0 * dd) + 6.0 * mm * dd * dd;
   ProfScope ps(PCA_K_SET_FWD, st, 2.0 * macs * a.B, (double)a.B * (4.0 * Nn * a.din + 8.0 * Nn * dd));
   const dim3 grid(16 * (unsigned)cdiv(a.B, 8));
-  switch (a.din) {
-    case 1: hipLaunchKernelGGL(k_set128_fwd<1>, grid, dim3(NT), lds, st, a); break;
-    case 2: hipLaunchKernelGGL(k_set128_fwd<2>, grid, dim3(NT), lds, st, a); break;
-    case 3: hipLaunchKernelGGL(k_set128_fwd<3>, grid, dim3(NT), lds, st, a); break;
-    default: hipLaunchKernelGGL(k_set128_fwd<4>, grid, dim3(NT), lds, st, a); break;
+  const int key = a.din * 2 + (a.N == 512 ? 1 : 0);       // units per quad of waves: N / 256
+  switch (key) {
+    case 2: hipLaunchKernelGGL((k_set128_fwd<1, 1>), grid, dim3(NT), lds, st, a); break;
+    case 3: hipLaunchKernelGGL((k_set128_fwd<1, 2>), grid, dim3(NT), lds, st, a); break;
+    case 4: hipLaunchKernelGGL((k_set128_fwd<2, 1>), grid, dim3(NT), lds, st, a); break;
+    case 5: hipLaunchKernelGGL((k_set128_fwd<2, 2>), grid, dim3(NT), lds, st, a); break;
+    case 6: hipLaunchKernelGGL((k_set128_fwd<3, 1>), grid, dim3(NT), lds, st, a); break;
+    case 7: hipLaunchKernelGGL((k_set128_fwd<3, 2>), grid, dim3(NT), lds, st, a); break;
+    case 8: hipLaunchKernelGGL((k_set128_fwd<4, 1>), grid, dim3(NT), lds, st, a); break;
+    default: hipLaunchKernelGGL((k_set128_fwd<4, 2>), grid, dim3(NT), lds, st, a); break;
   }
   ps.end();
   return check_launch("k_set128_fwd");
