@@ -279,7 +279,12 @@ def main():
     if world > 1:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         backend = os.environ.get("PCA_DIST_BACKEND", "nccl")
-        dist.init_process_group(backend, device_id=dev)
+        # a multi-GPU line is an RCCL line: another backend is accepted only for the one-GPU rehearsal
+        # (PCA_FORCE_DEVICE), so that a gloo fall-back can never produce a SCALE record
+        if backend != "nccl" and "PCA_FORCE_DEVICE" not in os.environ:
+            raise SystemExit(f"bench: --gpus {world} needs backend nccl (RCCL), got PCA_DIST_BACKEND="
+                             f"{backend}; set PCA_FORCE_DEVICE to rehearse on one GPU")
+        dist.init_process_group(backend, device_id=dev if backend == "nccl" else None)
         # self-check of the exchange the step relies on: a sum of ones over the ranks, on the
         # device, through the same backend (nccl = RCCL over xGMI) - reported in the JSON line
         ones = torch.ones(1, dtype=torch.float32, device=dev)
@@ -310,6 +315,55 @@ def main():
         if world > 1:
             dist.barrier()
         torch.cuda.synchronize(dev)
+
+    # ---- several GPUs: which step shape exchanges the gradients fastest is measured, not assumed ---
+    # (round-3 verdict: the overlap / serial choice had never met a real all-reduce.)  A short window
+    # of each form after a warm-up of its own; every rank takes the same decision (max over ranks);
+    # the timed region below runs the winner.
+    exchange = None
+    if world > 1:
+        forms = ["serial", "overlap"] + (["captured"] if backend == "nccl" else [])
+        k_probe = max(10, min(50, args.steps))
+        exchange = {}
+        for form in forms:
+            try:
+                tr.set_exchange(form)
+                for _ in range(max(5, args.warmup // 2)):
+                    tr.step()
+                barrier()
+                t0 = time.perf_counter()
+                for _ in range(k_probe):
+                    tr.step()
+                barrier()
+                t = torch.tensor([(time.perf_counter() - t0) / k_probe * 1e3], dtype=torch.float64,
+                                 device=dev)
+                dist.all_reduce(t, op=dist.ReduceOp.MAX)
+                exchange[form + "_ms"] = round(float(t), 4)
+            except Exception as e:          # e.g. a backend that refuses stream capture
+                exchange[form + "_error"] = repr(e)[:300]
+        timed = {f: exchange[f + "_ms"] for f in forms if f + "_ms" in exchange}
+        # (a form that failed on ANY rank is out: agree on it)
+        for f in list(timed):
+            bad = torch.tensor([0.0 if f + "_ms" in exchange else 1.0], device=dev)
+            dist.all_reduce(bad)
+            if float(bad) > 0:
+                timed.pop(f)
+        chosen = min(timed, key=timed.get)
+        exchange["chosen"] = chosen
+        tr.set_exchange(chosen)
+        # the all-reduce by itself (HIP events on the stream it is issued from), eager
+        ev = [torch.cuda.Event(enable_timing=True) for _ in range(2)]
+        g = tr.eng.grads
+        for _ in range(3):
+            dist.all_reduce(g)
+        torch.cuda.synchronize(dev)
+        ev[0].record()
+        for _ in range(20):
+            dist.all_reduce(g)
+        ev[1].record()
+        torch.cuda.synchronize(dev)
+        exchange["allreduce_alone_ms"] = round(ev[0].elapsed_time(ev[1]) / 20, 4)
+        g.zero_()
 
     for _ in range(args.warmup):
         tr.step()
@@ -364,6 +418,8 @@ def main():
         "dist_backend": backend, "rccl_ranks": rccl_ranks,
         "grad_allreduce_bytes": int(tr.eng.grads.numel()) * 4 if world > 1 else 0,
     }
+    if exchange is not None:
+        out["exchange"] = exchange
     if win_ms:
         q = np.percentile(np.asarray(win_ms), [10, 50, 90])
         out["windows"] = {"n": len(win_ms), "steps_each": args.steps,
@@ -405,6 +461,16 @@ def main():
             ]
         else:
             kernels = [
+                # round 4: the set-resident forward (one launch: both ISABs + the PMA attention of a
+                # set, a pair of workgroups per set) is the longest launch of the cfg2 step; on shapes
+                # it does not take (cfg3, B > #CUs / 2) it never runs and the next entries report
+                (_lib.K_SET_FWD, "k_set128_fwd (set-resident forward: ISAB, ISAB, PMA attention of a set "
+                                 "in ONE launch, a pair of workgroups per set)",
+                 "k_set128_fwd_bytes_per_launch",
+                 "reference-formulation FLOPs of the three blocks (SURVEY.md 8d: 2 * B * [N (3 din d + "
+                 "7 d^2 + 8 m d + 2 d) + 6 m d^2]); algorithmic bytes = 4 N din + 4 (2 N d) per set "
+                 "(SURVEY.md 8d 'algorithmic bytes per set'): the saved tensors the training forward "
+                 "also writes (O, Qp, masks) are traffic, not algorithmic bytes"),
                 (_lib.K_MAB1_BWD, "k_mab1_bwd (fused ISAB mab1 backward chain, both layers)",
                  "k_mab1_bwd_bytes_per_launch",
                  "reference-formulation FLOPs of what the launch computes: M*(2*d^2 + 8*m*d "
@@ -416,11 +482,16 @@ def main():
                  "reference-formulation FLOPs 4*M*(2*dk*d + 2*m*d) per launch; algorithmic bytes "
                  "= X in + dX read-modify-write"),
             ]
-        names = ["roofline", "roofline2"]
-        for (kid, label, tkey, note), key in zip(kernels, names):
+        names = ["roofline", "roofline2", "roofline3"]
+        ni = 0
+        for (kid, label, tkey, note) in kernels:
+            if ni >= 2 and len(kernels) <= 2:
+                break
             r = measure_kernel(L, _lib, tr, dev, kid, min(args.steps, 20), peak)
             if r is None:
                 continue
+            key = names[ni]
+            ni += 1
             r["kernel"] = label
             r["traffic"] = committed_traffic(tkey) if args.config == "cfg2" else None
             r["clock"] = ("HIP events recorded by the library around every launch of this kernel on "

@@ -270,20 +270,14 @@ __device__ __forceinline__ void mid_stage(const Set128Layer& L, const Ctx& c, co
 template <bool SMALL, int DQ, int UPQ>
 __device__ __forceinline__ void mab1_phase(const Set128Layer& L, const Ctx& c, char* sY, char* sO,
                                            const float* sX, const char* sKp, const char* sVt,
-                                           float scale_log2e, int stamp0) {
+                                           float scale_log2e, int stamp0, bf16x8 (&wa)[4][2]) {
   (void)stamp0;
   const int r = c.r, g = c.g, j = c.j;
   constexpr int KS = 4;
-  // this head's weight slices as A operands [row = feature 32 j + 16 t + r][k-slots 32 s + 8 g ..]
-  bf16x8 wa[KS][2];
+  // this head's weight slices as A operands [row = feature 32 j + 16 t + r][k-slots 32 s + 8 g ..]:
+  // wa arrives holding fc_q's (requested by the caller one stage ahead: mab1_load_wq)
   float wqs[2][4][SMALL ? DQ : 1];
-  if (!SMALL) {
-#pragma unroll
-    for (int s = 0; s < KS; ++s)
-#pragma unroll
-      for (int t = 0; t < 2; ++t)
-        wa[s][t] = gload8(L.WqB + (int64_t)(32 * j + 16 * t + r) * D + 32 * s + 8 * g);
-  } else {
+  if (SMALL) {
 #pragma unroll
     for (int t = 0; t < 2; ++t)
 #pragma unroll
@@ -465,6 +459,14 @@ __device__ __forceinline__ void mab1_phase(const Set128Layer& L, const Ctx& c, c
   STAMP(stamp0 + 4);
 }
 
+__device__ __forceinline__ void mab1_load_wq(const Set128Layer& L, const Ctx& c, bf16x8 (&wa)[4][2]) {
+#pragma unroll
+  for (int s = 0; s < 4; ++s)
+#pragma unroll
+    for (int t = 0; t < 2; ++t)
+      wa[s][t] = gload8(L.WqB + (int64_t)(32 * c.j + 16 * t + c.r) * D + 32 * s + 8 * c.g);
+}
+
 typedef __attribute__((address_space(4))) const Set128FwdArgs karg_t;
 // The kernel's arguments are ~75 pointers: left to itself hipcc loads them all at entry and then spills
 // SGPRs to VGPR lanes (930 v_readlane in the first version).  Reading them through a pointer the
@@ -635,7 +637,8 @@ __global__ __launch_bounds__(NT) void k_set128_fwd(const Set128FwdArgs a_by_valu
   // ================= layer 1, many-queries block ================================================
   ap = launder(ap);
   rederive(c);
-  mab1_phase<true, DIN, UPQ>(LAYER(0), c, sY, sO, sX + c.half * NH * 4, sKp, sVt, ap->scale_log2e, 4);
+  bf16x8 wa[4][2];
+  mab1_phase<true, DIN, UPQ>(LAYER(0), c, sY, sO, sX + c.half * NH * 4, sKp, sVt, ap->scale_log2e, 4, wa);
 
   // ================= layer 2, few-queries block over the rows in sY (k_mab0_attn_h4) ==============
   ap = launder(ap);
@@ -804,6 +807,7 @@ __global__ __launch_bounds__(NT) void k_set128_fwd(const Set128FwdArgs a_by_valu
     }
     lds_barrier();
     STAMP(10);
+    mab1_load_wq(L, c, wa);            // fc_q's slice of the many-queries block, a stage ahead
     mid_stage<false>(L, c, pre, sT, sTf, sA, sH, sKp, sVt);
     STAMP(11);
   }
@@ -811,7 +815,7 @@ __global__ __launch_bounds__(NT) void k_set128_fwd(const Set128FwdArgs a_by_valu
   // ================= layer 2, many-queries block ================================================
   ap = launder(ap);
   rederive(c);
-  mab1_phase<false, D, UPQ>(LAYER(1), c, sY, sO, sX, sKp, sVt, ap->scale_log2e, 12);
+  mab1_phase<false, D, UPQ>(LAYER(1), c, sY, sO, sX, sKp, sVt, ap->scale_log2e, 12, wa);
 
   // ================= PMA attention partials over Y2 (k_mab0_attn<1>): wave w < NH / 32 = unit w ====
   ap = launder(ap);

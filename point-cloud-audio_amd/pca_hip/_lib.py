@@ -14,6 +14,7 @@ LIB_PATH = os.path.join(_HERE, "libpca_hip.so")
 
 PCA_F32, PCA_BF16 = 0, 1
 K_GEMM_F32, K_MAB1_FWD, K_MAB1_BWD, K_MAB0_FWD, K_MAB0_BWD, K_WGRAD = 1, 2, 3, 4, 5, 6
+K_SET_FWD, K_SET_BWD = 7, 8
 MODE_F32, MODE_BF16, MODE_FP8 = 0, 1, 2
 
 c_fp = C.c_void_p       # float* (device)

@@ -252,6 +252,9 @@ class Trainer:
                 os.environ.get("PCA_FORCE_SPLIT") == "1"
             # (PCA_FORCE_SPLIT=2: the overlap=False step shape on one GPU, minus the all-reduce)
             self._exchange = self.world > 1 or os.environ.get("PCA_FORCE_SPLIT") == "2"
+            # third form (set_exchange("captured")): the all-reduce is captured INSIDE the step's one
+            # graph, [pack .. backward | all-reduce | Adam] = one graph launch per step
+            self._captured = False
             self.comm_stream = torch.cuda.Stream(self.dev) if self._split else None
         self._cursor_mode = callable(getattr(dataset, "batch_seq", None))
         self._k = 0                       # optimiser steps issued so far (host copy)
@@ -260,6 +263,30 @@ class Trainer:
                                           shuffle, self.dev)
         if self.world > 1:      # identical initial weights on every rank (rank 0's)
             dist.broadcast(self.eng.flat, src=0, group=self.pg)
+
+    # ---- how the gradients are exchanged ---------------------------------------------
+    def set_exchange(self, form: str) -> None:
+        """Choose the step shape of a multi-rank run and drop the captured graphs (the next step
+        re-captures).  "serial": [graph: pack .. backward] -> all-reduce of the whole vector -> Adam;
+        "overlap": the step split at the bucket boundary, bucket A reduced on a side stream under
+        enc.0's backward; "captured": ONE graph per step with the all-reduce recorded inside it
+        (needs a backend whose collectives can be stream-captured: RCCL / nccl).  bench.py times all
+        three on the first windows of a multi-GPU run and keeps the fastest."""
+        if form not in ("serial", "overlap", "captured"):
+            raise ValueError(form)
+        torch.cuda.synchronize(self.dev)
+        self.g0 = self.g1 = self.g2 = None
+        multi = self.world > 1 or (dist.is_initialized() and os.environ.get("PCA_EXCHANGE_WORLD1") == "1")
+        self._split = form == "overlap" and multi
+        self._captured = form == "captured" and multi
+        self._exchange = multi
+        if self._split and self.comm_stream is None:
+            self.comm_stream = torch.cuda.Stream(self.dev)
+        self.exchange_form = form
+
+    def _allreduce_all(self):
+        if self.world > 1 or self._captured:
+            dist.all_reduce(self.eng.grads, group=self.pg)
 
     # ---- index stream ------------------------------------------------------------
     def _next_indices(self) -> torch.Tensor:
@@ -332,7 +359,13 @@ class Trainer:
         # thread-local capture mode: a HIP call from another thread (e.g. the RCCL watchdog of
         # torch.distributed) must not invalidate the capture
         mode = dict(capture_error_mode="thread_local")
-        if not self._split and not self._exchange:
+        if self._captured:              # [pack .. backward | all-reduce | Adam] in ONE graph
+            self.g0 = torch.cuda.CUDAGraph()
+            with torch.cuda.graph(self.g0, **mode):
+                self._seg0(); self._seg1()
+                self._allreduce_all()
+                self._seg2()
+        elif not self._split and not self._exchange:
             self.g0 = torch.cuda.CUDAGraph()
             with torch.cuda.graph(self.g0, **mode):
                 self._seg0(); self._seg1(); self._seg2()
@@ -370,6 +403,12 @@ class Trainer:
         if self.use_graph and self.g0 is None:
             self._capture()
         main = torch.cuda.current_stream(self.dev)
+        if self._captured:
+            if self.use_graph:
+                self.g0.replay()
+            else:
+                self._seg0(); self._seg1(); self._allreduce_all(); self._seg2()
+            return
         if not self._split and not self._exchange:
             if self.use_graph:
                 self.g0.replay()

@@ -10,7 +10,8 @@ parity cases never reach.
 
 Tolerances: exact mode 2e-4 (logits) / 2e-3 (gradients) relative to max(1, max|ref|) (fp32
 reduction order over 65 536 rows); bf16 mode 3e-2 on logits / loss and the robust criterion of
-tests/util.py (rms <= 2.5e-2, <= 0.5 % of the elements beyond 5e-2) on gradients."""
+tests/util.py (rms <= 2.5e-2, <= 0.1 % of the elements beyond 5e-2) on gradients (round 4: was 0.5 %;
+the fp8 / variable-size cases at the end compare with the mode's emulation at 1.5e-2 instead)."""
 import numpy as np
 import pytest
 import torch
@@ -55,7 +56,7 @@ def _check(dev, B, N, din, d, h, m, C, mode, seed):
         if mode == "f32":
             worst = max(worst, close(g, ref_g[k], 2e-3, k))
         else:
-            worst = max(worst, close_robust(g, ref_g[k], 5e-2, k, outlier_frac=5e-3))
+            worst = max(worst, close_robust(g, ref_g[k], 5e-2, k, outlier_frac=1e-3))
     assert off == eng.grads.numel()
     inf = trainer.STEngine(net, B, N, md, training=False)
     close(inf.forward(T(X, dev)), ref_lg.reshape(B, C), tol_l, "logits(inference)")
@@ -161,3 +162,89 @@ def test_d128_step_is_bit_reproducible(dev, din, monkeypatch):
     sc = max(1.0, float(ref[0].abs().max()))
     assert float((runs[0][0] - ref[0]).abs().max()) <= 2e-5 * sc
     assert abs(runs[0][1] - ref[1]) <= 1e-6 * max(1.0, abs(ref[1]))
+
+
+# ---- round 4: the fp8 mode and the variable-size sets at their BENCH sizes ---------------------------
+def _emu_oracle_per_set(net, X, y, lengths, h, fp8):
+    """(emulation, exact oracle) of logits / loss / gradients on the un-padded sets X[b, :lengths[b]]
+    (tests/emu.py: the mode's operand roundings, differentiated with its straight-through bf16
+    backward; oracle/st_oracle.py: the reference restated in fp32)."""
+    from emu import st_forward_emu
+    from oracle import st_oracle as orc
+    out = []
+    for fwd in (lambda x, p: st_forward_emu(x, p, h, fp8=fp8),
+                lambda x, p: orc.st_forward(x, p, h).reshape(1, -1)):
+        params = {k: v.detach().cpu().clone().requires_grad_(True) for k, v in net.state_dict().items()}
+        lg = torch.cat([fwd(torch.from_numpy(X[b:b + 1, :lengths[b]]), params)
+                        for b in range(X.shape[0])], 0)
+        loss = orc.cross_entropy(lg, torch.from_numpy(y))
+        loss.backward()
+        g = {k: (v.grad if v.grad is not None else torch.zeros_like(v)).numpy() for k, v in params.items()}
+        out.append((lg.detach().numpy(), float(loss), g))
+    return out
+
+
+def _bench_lengths(B, N, F=512):
+    """Valid points per set as bench.py's configs[4] corpus produces them (clips of 1-4 s cut into sets
+    of 8 frames of F bins: full sets, plus each clip's short last chunk of 1..8 frames), with the two
+    edge cases the kernels branch on forced in: one set shorter than a 32-point tile, one odd length."""
+    rng = np.random.Generator(np.random.PCG64(44))
+    L = np.full(B, N, dtype=np.int64)
+    short = rng.choice(B, size=B // 4, replace=False)
+    L[short] = F * rng.integers(1, N // F + 1, size=short.size)
+    L[short[0]] = 17
+    L[short[1]] = 1000
+    L[short[2]] = N
+    return [int(v) for v in L]
+
+
+def _check_vs_emulation(dev, B, N, mode, lengths, seed):
+    import models
+    from pca_hip import _lib, trainer
+    din, d, h, m, C = 3, 256, 8, 32, 10
+    torch.manual_seed(seed)
+    net = models.ST(dim_input=din, num_outputs=1, dim_output=C, num_inds=m, dim_hidden=d,
+                    num_heads=h).to(dev)
+    X = gi.pc_input(seed + 1, B, N, din)
+    for b, L in enumerate(lengths):
+        X[b, L:] = 0.0
+    y = gi.labels(seed + 2, B, C)
+    fp8 = mode == "fp8"
+    torch.set_num_threads(16)
+    (emu_lg, emu_loss, emu_g), (ref_lg, ref_loss, ref_g) = _emu_oracle_per_set(net, X, y, lengths, h, fp8)
+    md = _lib.MODE_FP8 if fp8 else _lib.MODE_BF16
+    ld = None if min(lengths) == N else torch.tensor(lengths, dtype=torch.int32, device=dev)
+    eng = trainer.STEngine(net, B, N, md, training=True)
+    eng.fwd_bwd(T(X, dev), T(y, dev), lengths=ld)
+    torch.cuda.synchronize()
+    e1 = close(eng.logits, emu_lg, 1.5e-2, "logits vs emulation")
+    close(eng.logits, ref_lg, 3e-2 if not fp8 else 6e-2, "logits vs exact oracle")
+    assert abs(float(eng.loss) - emu_loss) < 1.5e-2, (float(eng.loss), emu_loss)
+    off, worst = 0, 0.0
+    for k, p in net.named_parameters():
+        g = eng.grads[off:off + p.numel()].view_as(p)
+        off += p.numel()
+        # against the emulation (same operand roundings, same ReLU masks up to rounding): 1.5e-2 with
+        # at most 1e-3 of the elements beyond it - a wrong 64-row tile of a [256, 256] weight gradient
+        # (1.6e-2 of its elements, off by O(1) of its scale) cannot hide in that
+        worst = max(worst, close_robust(g, emu_g[k], 1.5e-2, k + " vs emulation", outlier_frac=1e-3))
+        close_robust(g, ref_g[k], 5e-2 if not fp8 else 1e-1, k + " vs exact oracle",
+                     outlier_frac=1e-3 if not fp8 else 1e-2)
+    assert off == eng.grads.numel()
+    print(f"B={B} N={N} {mode} lengths {min(lengths)}..{max(lengths)}: logits vs emulation {e1:.2e}, "
+          f"worst grad vs emulation {worst:.2e}")
+
+
+def test_cfg4_bench_size_fp8_vs_emulation(dev):
+    """BASELINE configs[3] at its BENCH size (B = 128, N = 4096) in PCA_MODE_FP8: the multi-tile rings
+    and 256-workgroup grids of k_isab1_fwd256_ab<.., F8O> and k_fq_proj_fwd<F8> (VERDICT round 3, weak
+    1: checked at B = 5, N = 300 only) against the fp8 emulation of the whole model and the oracle."""
+    _check_vs_emulation(dev, 128, 4096, "fp8", [4096] * 128, seed=9500)
+
+
+@pytest.mark.parametrize("mode", ["bf16", "fp8"])
+def test_cfg5_bench_size_varlen_vs_emulation(dev, mode):
+    """BASELINE configs[4] at its BENCH size: B = 128 padded sets of up to N = 4096 points with the
+    lengths bench.py's corpus produces (incl. a set shorter than one tile and a full one), bf16 and fp8,
+    against the emulation on the TRUNCATED sets (mask == truncation at full size) and the oracle."""
+    _check_vs_emulation(dev, 128, 4096, mode, _bench_lengths(128, 4096), seed=9600)
