@@ -84,6 +84,20 @@ int pca_stft_logmag(const float* wave, int64_t L, int n_fft, int win_length, int
                     int n_bins, float* out, int64_t stride_f, int64_t stride_t,
                     void* stream);
 
+/* Band-limited sinc resampling of one waveform (the sampling-rate axis of the evaluation sweep)
+ * replaces: Code/pceval.py:74, Code/pc_temp3d_eval.py:74, Code/rebut_expts.py:76
+ *           (librosa.resample(x, fsog, fs, res_type='kaiser_fast', scale=True) = resampy's
+ *            interpolation with a Kaiser-windowed sinc table, third-party and not vendored: the filter
+ *            parameters are the caller's - oracle/resample_oracle.py documents the ones used -
+ *            "parity unpinned")
+ * y[t] = gain * sum_i h(|t / ratio - i|) x[i], t < n_out, ratio = fs_new / fs_old; h is given as the
+ * right wing of the interpolation filter sampled num_table times per zero crossing: win[nwin] (fp64,
+ * already multiplied by min(1, ratio)) with its forward differences delta[nwin] for the linear
+ * interpolation between table entries (Smith's algorithm); accumulation in fp64.  All pointers are
+ * device pointers. */
+int pca_resample(const float* x, int64_t n_in, double ratio, const double* win, const double* delta,
+                 int nwin, int num_table, float gain, float* y, int64_t n_out, void* stream);
+
 /* The same transform for a whole corpus in ONE launch
  * replaces: the per-file loops Code/settransformer.py:43-53, Code/settransformertemp.py:45-61
  * (one librosa.stft call per clip).  waves: the clips back to back; wave_off[n_clips + 1]

@@ -94,6 +94,48 @@ __global__ __launch_bounds__(256) void k_stft_logmag(const float* __restrict__ w
   }
 }
 
+// Smith's band-limited interpolation (resampy's resample_f restated): one thread per output sample,
+// both wings of the filter, table entries linearly interpolated, fp64 accumulation.  Per output sample
+// 2 * num_zeros / min(1, ratio) input samples are read (L2-resident: neighbouring threads share them).
+__global__ __launch_bounds__(256) void k_resample(const float* __restrict__ x, int64_t n_in, double ratio,
+                                                  const double* __restrict__ win,
+                                                  const double* __restrict__ delta, int nwin,
+                                                  int num_table, float gain, float* __restrict__ y,
+                                                  int64_t n_out) {
+  const int64_t t = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (t >= n_out) return;
+  const double scale = ratio < 1.0 ? ratio : 1.0;
+  const int index_step = (int)(scale * num_table);
+  const double time_register = (double)t / ratio;
+  const int64_t n = (int64_t)time_register;
+  double acc = 0.0;
+  {   // left wing: x[n], x[n - 1], ...
+    const double frac = scale * (time_register - (double)n);
+    const double index_frac = frac * num_table;
+    const int offset = (int)index_frac;
+    const double eta = index_frac - offset;
+    int64_t i_max = (nwin - offset) / index_step;
+    if (n + 1 < i_max) i_max = n + 1;
+    for (int64_t i = 0; i < i_max; ++i) {
+      const int k = offset + (int)i * index_step;
+      acc += (win[k] + eta * delta[k]) * (double)x[n - i];
+    }
+  }
+  {   // right wing: x[n + 1], x[n + 2], ...
+    const double frac = scale - scale * (time_register - (double)n);
+    const double index_frac = frac * num_table;
+    const int offset = (int)index_frac;
+    const double eta = index_frac - offset;
+    int64_t k_max = (nwin - offset) / index_step;
+    if (n_in - n - 1 < k_max) k_max = n_in - n - 1;
+    for (int64_t k2 = 0; k2 < k_max; ++k2) {
+      const int k = offset + (int)k2 * index_step;
+      acc += (win[k] + eta * delta[k]) * (double)x[n + k2 + 1];
+    }
+  }
+  y[t] = (float)(acc * (double)gain);
+}
+
 __global__ __launch_bounds__(256) void k_pack(const PackJob a) {
   pack_body(a, blockIdx.y * a.bx + blockIdx.x);
 }
@@ -147,6 +189,21 @@ int pca_pack_defer(int on) {
   return PCA_OK;
 }
 
+
+int pca_resample(const float* x, int64_t n_in, double ratio, const double* win, const double* delta,
+                 int nwin, int num_table, float gain, float* y, int64_t n_out, void* stream) {
+  PCA_REQUIRE(x && win && delta && y, "resample: null pointer");
+  PCA_REQUIRE(n_in > 0 && n_out > 0 && ratio > 0.0, "resample: n_in=%lld n_out=%lld ratio=%g",
+              (long long)n_in, (long long)n_out, ratio);
+  PCA_REQUIRE(nwin > 1 && num_table > 0 && (int)((ratio < 1.0 ? ratio : 1.0) * num_table) >= 1,
+              "resample: filter table of %d entries, %d per zero crossing, ratio %g", nwin, num_table, ratio);
+  // the last output sample must have an input sample under it
+  PCA_REQUIRE((int64_t)((double)(n_out - 1) / ratio) < n_in, "resample: n_out=%lld beyond the input",
+              (long long)n_out);
+  hipLaunchKernelGGL(pca::k_resample, dim3((unsigned)pca::cdiv(n_out, 256)), dim3(256), 0,
+                     pca::as_stream(stream), x, n_in, ratio, win, delta, nwin, num_table, gain, y, n_out);
+  return pca::check_launch("k_resample");
+}
 
 int64_t pca_stft_num_frames(int64_t L, int hop) { return hop > 0 ? 1 + L / hop : 0; }
 

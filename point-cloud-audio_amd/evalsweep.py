@@ -8,9 +8,14 @@ short tail (``Code/pceval.py:76-97``).  Here the STFT, the point-set packing and
 run on the GPU; accuracy does not depend on the batch order, so batches are taken in order
 and, as in the reference, an incomplete last batch is left out.
 
-Not covered: ``librosa.load`` / ``effects.trim`` / ``resample`` (third-party, not vendored,
-"parity unpinned" - SURVEY.md 8c): the sweep over sampling rates of ``pceval.py:55`` needs a
-resampler, so ``fs`` is a property of the clips passed in.
+The sampling-rate axis (``for F in list_Fs``, ``librosa.resample(x, fsog, fs, 'kaiser_fast',
+scale=True)``, ``Code/pceval.py:55,61,74``) runs on the device too: ``pca_hip.resample`` is a
+band-limited sinc interpolation with resampy's documented ``kaiser_fast`` design.  librosa / resampy are
+third-party, not vendored and not installed here, and the reference holds no resampled fixture, so this
+axis is **parity unpinned** (SURVEY.md 8c); the kernel is checked against the CPU restatement of the
+same algorithm (tests/test_resample.py).
+Not covered: ``librosa.load`` / ``effects.trim`` (file decoding and silence trimming: the clips passed
+in are waveforms already).
 """
 import json
 import math
@@ -48,11 +53,25 @@ def framewise_dataset(clips: Sequence[torch.Tensor], labels: Sequence[int], fs: 
 @torch.no_grad()
 def reframe_sweep(model, clips: Sequence[torch.Tensor], labels: Sequence[int], fs: float,
                   list_N: Iterable[int], hf: float = 0.5, batch_size: int = 8,
-                  mode: int = _lib.MODE_F32, json_file: Optional[str] = None) -> Dict:
-    """Accuracy of ``model`` for every analysis length in ``list_N``; returns (and optionally
-    writes) the dictionary ``Code/pceval.py:57-59,99-104`` stores:
-    ``{"data": {fs: [acc per N]}, "list_Fs": [fs], "list_N": [...]}``."""
+                  mode: int = _lib.MODE_F32, json_file: Optional[str] = None,
+                  list_Fs: Optional[Iterable[float]] = None) -> Dict:
+    """Accuracy of ``model`` for every analysis length in ``list_N`` - and, with ``list_Fs``, for every
+    sampling rate the clips (recorded at ``fs``) are resampled to first, as the double loop of
+    ``Code/pceval.py:61-98`` does; returns (and optionally writes) the dictionary
+    ``Code/pceval.py:57-59,99-104`` stores: ``{"data": {Fs: [acc per N]}, "list_Fs": [...],
+    "list_N": [...]}``."""
     list_N = [int(n) for n in list_N]
+    if list_Fs is not None:
+        list_Fs = list(list_Fs)
+        data = {}
+        for F in list_Fs:
+            rs = [pca_hip.resample(x, fs, F, scale=True) for x in clips]     # pceval.py:74
+            data[F] = reframe_sweep(model, rs, labels, F, list_N, hf, batch_size, mode)["data"][F]
+        out = {"data": data, "list_Fs": list_Fs, "list_N": list_N}
+        if json_file is not None:
+            with open(json_file, "w") as f:
+                json.dump(out, f)
+        return out
     accs: List[float] = []
     for N in list_N:
         ds = framewise_dataset(clips, labels, fs, N, hf)

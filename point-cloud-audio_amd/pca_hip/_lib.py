@@ -62,6 +62,8 @@ SIGNATURES = {
     "pca_stft_logmag_batch": (C.c_int, [c_fp, c_i64p, c_i64p, C.c_int, C.c_int64, C.c_int64,
                                         C.c_int, C.c_int, C.c_int, C.c_int, c_fp, C.c_int64,
                                         C.c_int64, c_vp]),
+    "pca_resample": (C.c_int, [c_fp, C.c_int64, C.c_double, c_vp, c_vp, C.c_int, C.c_int, C.c_float, c_fp,
+                               C.c_int64, c_vp]),
     "pca_pack_points_2d": (C.c_int, [c_fp, C.c_int64, C.c_int64, c_fp, c_i64p, C.c_int,
                                      C.c_int, c_fp, c_i64p, c_i64p, c_vp]),
     "pca_pack_points_3d": (C.c_int, [c_fp, C.c_int64, C.c_int64, C.c_int64, c_fp, c_fp,

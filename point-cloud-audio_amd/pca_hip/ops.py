@@ -9,6 +9,8 @@ from __future__ import annotations
 import ctypes as C
 from typing import Optional, Tuple
 
+import math
+
 import torch
 
 from . import _lib
@@ -307,6 +309,55 @@ def stft_logmag(wave: torch.Tensor, n_fft: int, win_length: Optional[int] = None
             sf, st = T, 1
         check(L.pca_stft_logmag(_ptr(wave), wave.numel(), n_fft, win_length, hop, F,
                                 _ptr(out), sf, st, _stream(wave)), "pca_stft_logmag")
+    return out
+
+
+# ---- resampling (the sampling-rate axis of the evaluation sweep, Code/pceval.py:74) ----------------
+# librosa.resample(.., res_type='kaiser_fast', scale=True) = resampy's band-limited interpolation; the
+# filter design below is resampy's documented kaiser_fast (16 zero crossings, 512 table entries per
+# zero crossing, roll-off 0.85, Kaiser beta 8.5555): "parity unpinned" (neither package is available).
+KAISER_FAST = dict(num_zeros=16, precision=9, rolloff=0.85, beta=8.555504641634386)
+_resample_tables = {}
+
+
+def _resample_filter(ratio: float, device, design):
+    import numpy as np
+    key = (round(ratio, 12), str(device), tuple(sorted(design.items())))
+    if key not in _resample_tables:
+        num_table = 2 ** design["precision"]
+        n = num_table * design["num_zeros"]
+        win = design["rolloff"] * np.sinc(design["rolloff"] * np.linspace(0, design["num_zeros"], n + 1))
+        win = win * np.kaiser(2 * n + 1, design["beta"])[n:]
+        if ratio < 1:
+            win = win * ratio
+        delta = np.zeros_like(win)
+        delta[:-1] = np.diff(win)
+        _resample_tables[key] = (torch.from_numpy(win).to(device), torch.from_numpy(delta).to(device),
+                                 num_table)
+    return _resample_tables[key]
+
+
+def resample(wave: torch.Tensor, fs_old: float, fs_new: float, scale: bool = True,
+             **design) -> torch.Tensor:
+    """1-D float32 device waveform at fs_old -> ceil(n * fs_new / fs_old) samples at fs_new
+    (librosa.resample(x, fs_old, fs_new, res_type='kaiser_fast', fix=True, scale=scale))."""
+    _need_cuda(wave)
+    wave = _f32c(wave)
+    ratio = float(fs_new) / float(fs_old)
+    if ratio == 1.0:
+        return wave.clone()
+    d = dict(KAISER_FAST)
+    d.update(design)
+    win, delta, num_table = _resample_filter(ratio, wave.device, d)
+    n_in = wave.numel()
+    n_res = int(n_in * ratio)
+    n_out = int(math.ceil(n_in * ratio))
+    with torch.cuda.device(wave.device):
+        out = torch.zeros(n_out, dtype=torch.float32, device=wave.device)
+        if n_res > 0:
+            check(lib().pca_resample(_ptr(wave), n_in, ratio, _ptr(win), _ptr(delta), win.numel(),
+                                     num_table, (1.0 / math.sqrt(ratio)) if scale else 1.0, _ptr(out),
+                                     min(n_res, n_out), _stream(wave)), "pca_resample")
     return out
 
 

@@ -46,8 +46,15 @@ def run(world_sim, rank_sim, batch, pg):
         tr.indices = trainer.ShardedIndexStream(len(ds), batch, 0, 1, 11, True, dev)
         tr.comm_stream = None
         tr._split = tr._exchange = False
-    for _ in range(4):
+    for _ in range(2 if (pg is not None and os.environ.get("PCA_SWITCH_TO")) else 4):
         tr.step()
+    if pg is not None and os.environ.get("PCA_SWITCH_TO"):
+        # bench.py's dual measurement: the other step shape on the same Trainer, mid-run
+        tr.set_exchange(os.environ["PCA_SWITCH_TO"])
+        for _ in range(2):
+            tr.step()
+        if rank == 0:
+            print("SWITCHED_TO", tr.exchange_form, flush=True)
     torch.cuda.synchronize()
     return tr.eng.flat.detach().cpu().clone(), tr.read_stats() if pg is not None else None
 

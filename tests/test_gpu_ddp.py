@@ -86,3 +86,38 @@ def test_two_ranks_equal_one_rank_double_batch(tmp_path, mode, graph, overlap, b
     #  that 1e-7 noise into parameter differences of up to ~2e-5 - measured 2.1e-5 once in ~20 runs)
     close(flat2[keep], mine[keep], 1e-4 if mode == "f32" else 2e-3, "2 ranks x B vs 1 rank x 2B")
     close(flat2[~keep], mine[~keep], 5e-3, "noise-gradient biases")
+
+
+def test_allreduce_captured_in_step_graph_world1_nccl():
+    """Trainer.set_exchange("captured"): [pack .. backward | all-reduce | Adam] as ONE hipGraph, the
+    all-reduce recorded by RCCL's stream capture - provable on one GPU with a one-rank nccl group (the
+    all-reduce over one rank is the identity: parameters after 6 replays must equal the plain one-graph
+    step's bit for bit).  If RCCL refuses the capture the error text is printed (DESIGN.md section 5
+    quotes it) and the case skips: the serial form stays the default."""
+    env = dict(os.environ, HSA_ENABLE_IPC_MODE_LEGACY="0", MASTER_ADDR="127.0.0.1",
+               MASTER_PORT=str(_free_port()))
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "scripts", "ddp_capture_check.py")],
+                       env=env, capture_output=True, text=True, timeout=600)
+    print(r.stdout[-3000:])
+    assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-3000:]
+    if "BACKEND_REFUSED" in r.stdout or "CAPTURE_REFUSED" in r.stdout:
+        pytest.skip("RCCL refused: " + r.stdout[-1500:])
+    assert "CAPTURE_OK True" in r.stdout, r.stdout
+
+
+@pytest.mark.parametrize("form", ["serial", "overlap"])
+def test_set_exchange_forms_two_ranks_gloo(tmp_path, form):
+    """The step shapes bench.py times against each other at world > 1, switched on ONE Trainer with
+    set_exchange (graphs dropped and re-captured): after switching, two gloo ranks still end with
+    identical parameters and finite losses."""
+    env = dict(os.environ, PCA_MODE="bf16", PCA_GRAPH="1", PCA_OUT=str(tmp_path / "flat.pt"),
+               PCA_OVERLAP="0" if form == "overlap" else "1", PCA_SWITCH_TO=form,
+               HSA_ENABLE_IPC_MODE_LEGACY="0", PCA_DIST_BACKEND="gloo")
+    r = subprocess.run([sys.executable, "-m", "torch.distributed.run", "--nnodes=1",
+                        "--nproc-per-node", "2", "--master-addr", "127.0.0.1",
+                        "--master-port", str(_free_port()),
+                        os.path.join(ROOT, "scripts", "ddp_check.py")],
+                       env=env, capture_output=True, text=True, timeout=600)
+    assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-3000:]
+    assert "RANKS_IDENTICAL True" in r.stdout, r.stdout
+    assert f"SWITCHED_TO {form}" in r.stdout, r.stdout
