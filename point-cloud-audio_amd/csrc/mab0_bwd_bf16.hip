@@ -554,28 +554,6 @@ __global__ __launch_bounds__(256) void k_mab0_post2(const Mab0PostJobs jobs, con
 
 }  // namespace
 namespace {
-struct PmaHeadArgs {
-  // forward epilogue
-  const float *Tp, *Mp, *Lp;
-  int S;
-  float *T, *LSE;
-  const float *Qp, *WvT, *bv, *WoT, *bo;
-  int m, d, dk, h;
-  float *H, *Osave, *Zsave;
-  // classifier + loss
-  const float *Wc, *bc;
-  const int64_t* labels;
-  int B, C;
-  float grad_scale;
-  float *logits, *dlogits, *dP, *lossv, *corrv;
-  // backward epilogue
-  const float *Wo, *Wv;
-  int Rp;
-  float *dZ, *dO, *Th, *dTf;
-  __bf16 *dTb, *dTt;
-  float *Delta, *LSEp, *zero_ptr;
-  int zero_n;
-};
 // Everything a set needs between its attention forward and its attention backward.  The stages
 // hand over through global memory written by this very workgroup (H = pooled features, Z, T,
 // LSE, dP): a workgroup barrier makes those stores visible to the next stage.
@@ -824,11 +802,11 @@ __global__ __launch_bounds__(256) void k_pma_head1(const PmaHeadArgs a) {
 }
 }  // namespace
 
-int pma_head_launch(const pca_mab_shape& s, const pca_mab_params& p, void* saved, void* ws_bwd,
-                    float* P, const float* Wc, const float* bc, const int64_t* labels, int C,
-                    float grad_scale, float* logits, float* dlogits, float* dP, float* dWc,
-                    float* dbc, float* loss_out, float* stats, float* cls_ws, BwdDefer* defer,
-                    hipStream_t st) {
+int pma_head_args(const pca_mab_shape& s, const pca_mab_params& p, void* saved, void* ws_bwd,
+                  float* P, const float* Wc, const float* bc, const int64_t* labels, int C,
+                  float grad_scale, float* logits, float* dlogits, float* dP, float* dWc,
+                  float* dbc, float* loss_out, float* stats, float* cls_ws, BwdDefer* defer,
+                  PmaHeadArgs* out) {
   PCA_REQUIRE(s.nq == 1 && s.dk > 4 && defer != nullptr, "pma_head: needs the fused PMA (k = 1)");
   Mab0Saved v;
   mab0_carve_saved(s, &v, saved);
@@ -844,6 +822,21 @@ int pma_head_launch(const pca_mab_shape& s, const pca_mab_params& p, void* saved
   a.Wo = p.wo; a.Wv = p.wv; a.Rp = Rp; a.dZ = w.dZ; a.dO = w.dO; a.Th = w.Th; a.dTf = nullptr;
   a.dTb = w.dTb; a.dTt = w.dTt; a.Delta = w.Delta; a.LSEp = w.LSEp;
   a.zero_ptr = w.DG; a.zero_n = Rp * dk;
+  *out = a;
+  defer->cls = ClsWgradArgs{dlogits, P, a.lossv, a.corrv, s.B, d, C, dWc, dbc, loss_out, stats};
+  defer->has_cls = 1;
+  return PCA_OK;
+}
+
+int pma_head_launch(const pca_mab_shape& s, const pca_mab_params& p, void* saved, void* ws_bwd,
+                    float* P, const float* Wc, const float* bc, const int64_t* labels, int C,
+                    float grad_scale, float* logits, float* dlogits, float* dP, float* dWc,
+                    float* dbc, float* loss_out, float* stats, float* cls_ws, BwdDefer* defer,
+                    hipStream_t st) {
+  PmaHeadArgs a{};
+  PCA_TRY(pma_head_args(s, p, saved, ws_bwd, P, Wc, bc, labels, C, grad_scale, logits, dlogits, dP, dWc, dbc,
+                        loss_out, stats, cls_ws, defer, &a));
+  const int d = s.d, m = s.nq, h = s.h, dk = s.dk, R = h * m, Rp = a.Rp;
   size_t lds = ((size_t)R * dk + (size_t)m * d) * sizeof(float);
   const size_t l2 = (size_t)(d + C) * sizeof(float);
   const size_t l3 = (2 * (size_t)m * d + (size_t)Rp + (size_t)d) * sizeof(float);
@@ -854,10 +847,7 @@ int pma_head_launch(const pca_mab_shape& s, const pca_mab_params& p, void* saved
     hipLaunchKernelGGL(k_pma_head1, dim3(s.B), dim3(256), 0, st, a);
   else
     hipLaunchKernelGGL(k_pma_head, dim3(s.B), dim3(256), lds, st, a);
-  PCA_TRY(check_launch("k_pma_head"));
-  defer->cls = ClsWgradArgs{dlogits, P, a.lossv, a.corrv, s.B, d, C, dWc, dbc, loss_out, stats};
-  defer->has_cls = 1;
-  return PCA_OK;
+  return check_launch("k_pma_head");
 }
 
 int terminal_launch(const BwdDefer& D, hipStream_t st, const SlabSumJobs* late_in) {

@@ -389,6 +389,35 @@ int pma_head_launch(const pca_mab_shape& s, const pca_mab_params& p, void* saved
                     float grad_scale, float* logits, float* dlogits, float* dP, float* dWc,
                     float* dbc, float* loss_out, float* stats, float* cls_ws, BwdDefer* defer,
                     hipStream_t st);
+// arguments of that launch (k_pma_head / k_pma_head1; the set-resident forward runs the same stages in its
+// own tail: set128_fwd.hip)
+struct PmaHeadArgs {
+  // forward epilogue
+  const float *Tp, *Mp, *Lp;
+  int S;
+  float *T, *LSE;
+  const float *Qp, *WvT, *bv, *WoT, *bo;
+  int m, d, dk, h;
+  float *H, *Osave, *Zsave;
+  // classifier + loss
+  const float *Wc, *bc;
+  const int64_t* labels;
+  int B, C;
+  float grad_scale;
+  float *logits, *dlogits, *dP, *lossv, *corrv;
+  // backward epilogue
+  const float *Wo, *Wv;
+  int Rp;
+  float *dZ, *dO, *Th, *dTf;
+  __bf16 *dTb, *dTt;
+  float *Delta, *LSEp, *zero_ptr;
+  int zero_n;
+};
+int pma_head_args(const pca_mab_shape& s, const pca_mab_params& p, void* saved, void* ws_bwd,
+                  float* P, const float* Wc, const float* bc, const int64_t* labels, int C,
+                  float grad_scale, float* logits, float* dlogits, float* dP, float* dWc,
+                  float* dbc, float* loss_out, float* stats, float* cls_ws, BwdDefer* defer,
+                  PmaHeadArgs* out);
 // post stages + riders (`late`: sums nobody reads before the optimizer, e.g. weight gradients)
 int terminal_launch(const BwdDefer& D, hipStream_t st, const SlabSumJobs* late = nullptr);
 // launch `jobs` now, or append them to the matching list of `defer`

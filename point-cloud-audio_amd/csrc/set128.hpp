@@ -45,6 +45,12 @@ struct Set128FwdArgs {
   const __bf16* Gpma;     // [>= 16][128] bf16, rows >= 4 zero
   float *TpP, *MpP, *LpP; // PMA attention partials [B][Sp][4][128], [B][Sp][4] x 2 (read by k_pma_head1)
   int Sp;                 // 2 or 4
+  // fuse_head != 0: the stages of k_pma_head1 (PMA epilogue, classifier, cross-entropy forward and
+  // backward, PMA backward epilogue) run in this launch's tail on workgroup 0 of the pair, which gets
+  // the partner's PMA partial through exP [B][2][528]; TpP / MpP / LpP are then not written
+  int fuse_head;
+  float* exP;
+  PmaHeadArgs head;
 };
 
 // bytes of `flags` (the block the preparation launch clears) / of the whole exchange area

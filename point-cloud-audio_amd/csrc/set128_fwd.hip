@@ -459,6 +459,254 @@ __device__ __forceinline__ void mab1_phase(const Set128Layer& L, const Ctx& c, c
   STAMP(stamp0 + 4);
 }
 
+// ---------------------------------------------------------------------------------------------
+// The per-set stages between the PMA's attention forward and its attention backward (k_pma_head1,
+// mab0_bwd_bf16.hip, on 1024 threads): PMA epilogue O = Qp + T_h Wv_h^T + bv, P = O + relu(O Wo^T + bo)
+// (modules.py:29-31), classifier + mean cross-entropy forward and backward (Code/models.py:40,
+// Code/settransformer.py:104), and the adjoint of the epilogue: dZ, dO = dP + dZ Wo, dT_h = dO_h Wv_h,
+// Delta = rowdot(dT, T).  Products over the INPUT index take 8 (16) adjacent lanes per output and a
+// shuffle reduction; products over the OUTPUT index take thread = (column, eighth of the rows), coalesced
+// weight rows, and an LDS reduction.  sPm: this workgroup's PMA partial, theirs: the partner's (sc1).
+// ---------------------------------------------------------------------------------------------
+__device__ __forceinline__ void head_stages(const PmaHeadArgs& a, const Ctx& c, const float* sPm,
+                                            const float* theirs, float* sh) {
+  constexpr int DH = 32, R = 4;
+  float* sT = sh;                 // [4][128] merged, normalised T
+  float* sOv = sT + 512;          // O, P, Z, dP, dZ, dO: [128] each
+  float* sP = sOv + 128;
+  float* sZ = sP + 128;
+  float* sdP = sZ + 128;
+  float* sdZ = sdP + 128;
+  float* sdO = sdZ + 128;
+  float* sL = sdO + 128;          // logits / dlogits [64]
+  float* part = sL + 64;          // [8][128] partial sums of the output-index products
+  float* sDl = part + 1024;       // [4][2]
+  float* red = sDl + 8;           // m, sum
+  int* ramax = reinterpret_cast<int*>(red + 2);
+  float* sLSE = red + 4;          // [4]
+  const int tid = c.tid, b = c.b, C = a.C, B = a.B;
+  const int fA = tid >> 3, pA = tid & 7;            // mapping A: 8 adjacent lanes per output f
+  const int fB = tid & 127, pB = tid >> 7;          // mapping B: column f, eighth pB of the rows
+
+  // everything the first three stages read from memory, requested together
+  float pth = 0.f;
+  if (tid < 520)
+    pth = __hip_atomic_load((__attribute__((address_space(1))) const float*)(theirs + tid), __ATOMIC_RELAXED,
+                            __HIP_MEMORY_SCOPE_AGENT);
+  float4 wv4[4], wo4[4], wc4[2];
+#pragma unroll
+  for (int u = 0; u < 4; ++u) {
+    wv4[u] = *reinterpret_cast<const float4*>(a.Wv + (int64_t)fA * D + 16 * pA + 4 * u);
+    wo4[u] = *reinterpret_cast<const float4*>(a.Wo + (int64_t)fA * D + 16 * pA + 4 * u);
+  }
+  const int c3 = tid >> 4, p3 = tid & 15;
+#pragma unroll
+  for (int u = 0; u < 2; ++u)
+    wc4[u] = *reinterpret_cast<const float4*>(a.Wc + (int64_t)(c3 < C ? c3 : 0) * D + 8 * p3 + 4 * u);
+  const float qb = a.Qp[fA] + a.bv[fA], bo_f = a.bo[fA], bc3 = a.bc[c3 < C ? c3 : 0];
+  const int64_t y = a.labels[b];
+  if (a.zero_ptr != nullptr)
+    for (int i = b * NT + tid; i < a.zero_n; i += B * NT) a.zero_ptr[i] = 0.f;
+
+  // ---- merge the two halves' partials (ordered by half: this is half 0) ----
+  float* sEx = part;                                  // the partner's 520 values
+  if (tid < 520) sEx[tid] = pth;
+  lds_barrier();
+  if (tid < 512) {
+    const int rr = tid >> 7;
+    const float m0 = sPm[512 + rr], m1 = sEx[512 + rr];
+    const float M = fmaxf(m0, m1);
+    const float f0 = __builtin_amdgcn_exp2f(m0 - M), f1 = __builtin_amdgcn_exp2f(m1 - M);
+    const float Lt = f0 * sPm[516 + rr] + f1 * sEx[516 + rr];
+    const float v = (f0 * sPm[tid] + f1 * sEx[tid]) / Lt;
+    sT[tid] = v;
+    a.T[(int64_t)b * R * D + tid] = v;
+    if ((tid & 127) == 0) {
+      const float lse = M + log2f(Lt);
+      a.LSE[(int64_t)b * R + rr] = lse;
+      sLSE[rr] = lse;
+    }
+  }
+  lds_barrier();
+  auto dot16 = [&](const float4 (&w)[4], const float* v) {
+    float acc = 0.f;
+#pragma unroll
+    for (int u = 0; u < 4; ++u) {
+      const float4 x = *reinterpret_cast<const float4*>(v + 4 * u);
+      acc += w[u].x * x.x + w[u].y * x.y + w[u].z * x.z + w[u].w * x.w;
+    }
+    acc += __shfl_xor(acc, 1, 64);
+    acc += __shfl_xor(acc, 2, 64);
+    acc += __shfl_xor(acc, 4, 64);
+    return acc;
+  };
+  // O = Qp + T_h Wv_h^T + bv
+  {
+    const float o1 = qb + dot16(wv4, sT + (fA / DH) * D + 16 * pA);
+    if (pA == 0) sOv[fA] = o1;
+  }
+  lds_barrier();
+  // Z = O Wo^T + bo ; P = O + relu(Z)
+  {
+    const float z1 = bo_f + dot16(wo4, sOv + 16 * pA);
+    if (pA == 0) {
+      const float o1 = sOv[fA], hv = o1 + fmaxf(z1, 0.f);
+      const int64_t o = (int64_t)b * D + fA;
+      a.H[o] = hv;
+      a.Osave[o] = o1;
+      a.Zsave[o] = z1;
+      sP[fA] = hv;
+      sZ[fA] = z1;
+    }
+  }
+  lds_barrier();
+  // the weights of the adjoint stages, requested under the classifier
+  float wcB[8], woB[16];
+#pragma unroll
+  for (int u = 0; u < 8; ++u) {
+    const int cc = pB + 8 * u;
+    wcB[u] = a.Wc[(int64_t)(cc < C ? cc : 0) * D + fB];
+  }
+#pragma unroll
+  for (int u = 0; u < 16; ++u) woB[u] = a.Wo[(int64_t)(pB + 8 * u) * D + fB];
+  // logits
+  {
+    float acc = 0.f;
+    const float* x = sP + 8 * p3;
+#pragma unroll
+    for (int u = 0; u < 2; ++u) {
+      const float4 x4 = *reinterpret_cast<const float4*>(x + 4 * u);
+      acc += wc4[u].x * x4.x + wc4[u].y * x4.y + wc4[u].z * x4.z + wc4[u].w * x4.w;
+    }
+    acc += __shfl_xor(acc, 1, 64);
+    acc += __shfl_xor(acc, 2, 64);
+    acc += __shfl_xor(acc, 4, 64);
+    acc += __shfl_xor(acc, 8, 64);
+    if (c3 < C && p3 == 0) {
+      acc += bc3;
+      sL[c3] = acc;
+      a.logits[(int64_t)b * C + c3] = acc;
+    }
+  }
+  lds_barrier();
+  if (tid < 64) {
+    float m = -INFINITY;
+    int am = 0x7fffffff;
+    for (int j = tid; j < C; j += 64)
+      if (sL[j] > m) { m = sL[j]; am = j; }
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) {
+      const float om = __shfl_xor(m, o, 64);
+      const int oa = __shfl_xor(am, o, 64);
+      if (om > m || (om == m && oa < am)) { m = om; am = oa; }
+    }
+    float sm = 0.f;
+    for (int j = tid; j < C; j += 64) sm += expf(sL[j] - m);
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) sm += __shfl_xor(sm, o, 64);
+    if (tid == 0) { red[0] = m; red[1] = sm; *ramax = am; }
+  }
+  lds_barrier();
+  {
+    const float m = red[0], sm = red[1];
+    const float gs = a.grad_scale / (float)B;
+    float g = 0.f;
+    if (tid < C) g = (expf(sL[tid] - m) / sm - (tid == y ? 1.f : 0.f)) * gs;
+    if (tid == 0) {
+      a.lossv[b] = m + logf(sm) - sL[y];
+      a.corrv[b] = *ramax == (int)y ? 1.f : 0.f;
+    }
+    lds_barrier();
+    if (tid < C) {
+      sL[tid] = g;
+      a.dlogits[(int64_t)b * C + tid] = g;
+    }
+    lds_barrier();
+  }
+  // dP = dlogits Wc
+  {
+    float acc = 0.f;
+#pragma unroll
+    for (int u = 0; u < 8; ++u) {
+      const int cc = pB + 8 * u;
+      if (cc < C) acc = fmaf(sL[cc], wcB[u], acc);
+    }
+    part[pB * D + fB] = acc;
+  }
+  lds_barrier();
+  if (tid < D) {
+    float dp = 0.f;
+#pragma unroll
+    for (int p = 0; p < 8; ++p) dp += part[p * D + tid];
+    a.dP[(int64_t)b * D + tid] = dp;
+    sdP[tid] = dp;
+    const float v = sZ[tid] > 0.f ? dp : 0.f;          // dZ = dP . [Z > 0]
+    sdZ[tid] = v;
+    a.dZ[(int64_t)b * D + tid] = v;
+  }
+  lds_barrier();
+  // dO = dP + dZ Wo
+  float wvB[16];
+  {
+    const int j = (tid >> 7) & 3, hlf = tid >> 9;      // stage after this one: (column, head, half of the head)
+#pragma unroll
+    for (int u = 0; u < 16; ++u) wvB[u] = a.Wv[(int64_t)(j * DH + 16 * hlf + u) * D + fB];
+    float acc = 0.f;
+#pragma unroll
+    for (int u = 0; u < 16; ++u) acc = fmaf(sdZ[pB + 8 * u], woB[u], acc);
+    part[pB * D + fB] = acc;
+  }
+  lds_barrier();
+  if (tid < D) {
+    float v = sdP[tid];
+#pragma unroll
+    for (int p = 0; p < 8; ++p) v += part[p * D + tid];
+    sdO[tid] = v;
+    a.dO[(int64_t)b * D + tid] = v;
+  }
+  lds_barrier();
+  // dT_h = dO_h Wv_h ; Delta = rowdot(dT, T) ; the images k_mab0_bwd reads
+  {
+    const int j = (tid >> 7) & 3, hlf = tid >> 9;
+    float acc = 0.f;
+#pragma unroll
+    for (int u = 0; u < 16; ++u) acc = fmaf(sdO[j * DH + 16 * hlf + u], wvB[u], acc);
+    part[(hlf * 4 + j) * D + fB] = acc;
+  }
+  lds_barrier();
+  if (tid < 512) {
+    const int j = tid >> 7, f = tid & 127;
+    const float acc = part[j * D + f] + part[(4 + j) * D + f];
+    const float tv = sT[j * D + f];
+    a.Th[((int64_t)j * B + b) * D + f] = tv;
+    a.dTb[((int64_t)b * a.Rp + j) * D + f] = (__bf16)acc;
+    int pos = 0;
+#pragma unroll
+    for (int p = 0; p < 32; ++p)
+      if (perm32(p) == j) pos = p;
+    a.dTt[((int64_t)b * D + f) * a.Rp + pos] = (__bf16)acc;
+    float dl = acc * tv;
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) dl += __shfl_xor(dl, o, 64);
+    if ((tid & 63) == 0) sDl[2 * j + ((tid >> 6) & 1)] = dl;
+  }
+  lds_barrier();
+  for (int r = tid; r < a.Rp; r += NT) {
+    a.Delta[(int64_t)b * a.Rp + r] = r < R ? sDl[2 * r] + sDl[2 * r + 1] : 0.f;
+    a.LSEp[(int64_t)b * a.Rp + r] = r < R ? sLSE[r] : 1.0e30f;
+  }
+  for (int o = tid; o < (a.Rp - R) * D; o += NT) {          // padding rows / columns of the images
+    const int r = R + o / D, cc = o % D;
+    a.dTb[((int64_t)b * a.Rp + r) * D + cc] = (__bf16)0.f;
+    const int rb32 = r & ~31, ro = r & 31;
+    int pos = 0;
+#pragma unroll
+    for (int p = 0; p < 32; ++p)
+      if (perm32(p) == ro) pos = p;
+    a.dTt[((int64_t)b * D + cc) * a.Rp + rb32 + pos] = (__bf16)0.f;
+  }
+}
+
 __device__ __forceinline__ void mab1_load_wq(const Set128Layer& L, const Ctx& c, bf16x8 (&wa)[4][2]) {
 #pragma unroll
   for (int s = 0; s < 4; ++s)
@@ -872,25 +1120,64 @@ __global__ __launch_bounds__(NT) void k_set128_fwd(const Set128FwdArgs a_by_valu
       }
     }
     lds_barrier();
-    const int Spw = ap->Sp >> 1, upp = nun / Spw;           // partials of this workgroup, units per partial
-    if (tid < Spw * 512) {
-      const int p = tid >> 9, rr = (tid >> 7) & 3, f = tid & 127;
+    if (!ap->fuse_head) {
+      const int Spw = ap->Sp >> 1, upp = nun / Spw;         // partials of this workgroup, units per partial
+      if (tid < Spw * 512) {
+        const int p = tid >> 9, rr = (tid >> 7) & 3, f = tid & 127;
+        const float* s0 = reinterpret_cast<const float*>(sO);
+        float M = -INFINITY;
+        for (int w = p * upp; w < (p + 1) * upp; ++w) M = fmaxf(M, s0[w * 520 + 512 + rr]);
+        float Ls = 0.f, t = 0.f;
+        for (int w = p * upp; w < (p + 1) * upp; ++w) {
+          const float fs = __builtin_amdgcn_exp2f(s0[w * 520 + 512 + rr] - M);
+          Ls += fs * s0[w * 520 + 516 + rr];
+          t += fs * s0[w * 520 + rr * D + f];
+        }
+        const int64_t o = ((int64_t)b * ap->Sp + c.half * Spw + p) * 4 + rr;
+        ap->TpP[o * D + f] = t;
+        if (f == 0) {
+          ap->MpP[o] = M;
+          ap->LpP[o] = Ls;
+        }
+      }
+      STAMP(19);
+      return;
+    }
+    // ---- the workgroup's ONE partial over all its units: (t [4][128], m [4], l [4]) -> sPm --------
+    float* sPm = reinterpret_cast<float*>(sS);              // 528 floats (the images in sS are dead)
+    if (tid < 512) {
+      const int rr = tid >> 7, f = tid & 127;
       const float* s0 = reinterpret_cast<const float*>(sO);
       float M = -INFINITY;
-      for (int w = p * upp; w < (p + 1) * upp; ++w) M = fmaxf(M, s0[w * 520 + 512 + rr]);
+      for (int w = 0; w < nun; ++w) M = fmaxf(M, s0[w * 520 + 512 + rr]);
       float Ls = 0.f, t = 0.f;
-      for (int w = p * upp; w < (p + 1) * upp; ++w) {
+      for (int w = 0; w < nun; ++w) {
         const float fs = __builtin_amdgcn_exp2f(s0[w * 520 + 512 + rr] - M);
         Ls += fs * s0[w * 520 + 516 + rr];
         t += fs * s0[w * 520 + rr * D + f];
       }
-      const int64_t o = ((int64_t)b * ap->Sp + c.half * Spw + p) * 4 + rr;
-      ap->TpP[o * D + f] = t;
+      sPm[tid] = t;
       if (f == 0) {
-        ap->MpP[o] = M;
-        ap->LpP[o] = Ls;
+        sPm[512 + rr] = M;
+        sPm[516 + rr] = Ls;
       }
     }
+    lds_barrier();
+    float* exMine = ap->exP + (int64_t)(b * 2 + c.half) * 528;
+    float* exTheirs = ap->exP + (int64_t)(b * 2 + (c.half ^ 1)) * 528;
+    if (c.half == 1) {
+      // hand-off 3 (R1 again: 4-byte write-through stores, drained, barrier, one flag): half 1 is done
+      if (tid < 520)
+        __hip_atomic_store((__attribute__((address_space(1))) float*)(exMine + tid), sPm[tid],
+                           __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+      drain_vm();
+      lds_barrier();
+      if (tid == 0) flag_store(flags + 4 + (b * 2 + 0) * 2 + 1, 3u);
+      return;
+    }
+    if (c.wave == 0) flag_wait(flags + 4 + (b * 2 + 0) * 2 + 1, 3u, flags);
+    lds_barrier();
+    head_stages(*(const PmaHeadArgs*)(&ap->head), c, sPm, exTheirs, reinterpret_cast<float*>(sS) + 1024);
     STAMP(19);
   }
 }
@@ -906,7 +1193,8 @@ extern "C" int pca_debug_set_stamps(unsigned long long* out) {
 size_t set128_flag_bytes(int B) { return align256((size_t)(4 + B * 4) * sizeof(uint32_t)); }
 
 size_t set128_fwd_ws_bytes(int B) {
-  return set128_flag_bytes(B) + align256((size_t)B * 2 * 9216 * sizeof(float));
+  return set128_flag_bytes(B) + align256((size_t)B * 2 * 9216 * sizeof(float)) +
+         align256((size_t)B * 2 * 528 * sizeof(float));
 }
 
 bool set128_shape_ok(int B, int N, int din, int d, int h, int m, int k) {

@@ -151,6 +151,8 @@ struct Ws {
   void* wg256_def;           // d = 256: slabs of the deferred [B*m]-row weight-gradient launch
   void* scratch_m0;          // d = 256: enc.0's few-queries backward (its ISAB partner's [B*m]-row
                              // operands in scratch_bw[0] stay in place until that launch)
+  void* set128_ws;           // set-resident forward: pair flags + hand-off slots (its fused head writes the
+                             // PMA's backward operands into `scratch` while other pairs still exchange)
 };
 
 inline size_t carve(const pca_st_config& c, int training, Ws* out, void* base) {
@@ -179,10 +181,8 @@ inline size_t carve(const pca_st_config& c, int training, Ws* out, void* base) {
       if (base != nullptr) isab_img_carve(ib, &w.img[li]);
     }
   }
-  if (training && set128_shape_ok(c.B, c.N, c.din, c.d, c.h, c.m, c.k)) {
-    const size_t sb = set128_fwd_ws_bytes(c.B);
-    max_scratch = sb > max_scratch ? sb : max_scratch;
-  }
+  if (training && set128_shape_ok(c.B, c.N, c.din, c.d, c.h, c.m, c.k))
+    w.set128_ws = cv.take<char>(set128_fwd_ws_bytes(c.B));
   const size_t BN = (size_t)c.B * c.N, Bm = (size_t)c.B * c.m;
   w.H[0] = cv.take<float>(Bm * c.d);
   w.H[1] = cv.take<float>(Bm * c.d);
@@ -308,7 +308,8 @@ int validate(const pca_st_config* c) {
 }
 
 int forward(const pca_st_config& c, const Layout& L, const Shapes& s, const float* p,
-            const float* X, Ws& w, bool training, hipStream_t st, const PrepJobs* image_jobs = nullptr) {
+            const float* X, Ws& w, bool training, hipStream_t st, const PrepJobs* image_jobs = nullptr,
+            const PmaHeadArgs* head = nullptr) {
   const void* in = X;
   // d = 256: the query side of all three few-queries blocks in the same launch (mab0_d256_prep_collect)
   const bool prep256 = training && s.m0[0].d == 256 && mab_kind(s.m0[0]) == 2 &&
@@ -326,7 +327,7 @@ int forward(const pca_st_config& c, const Layout& L, const Shapes& s, const floa
         isab_collect_prep(s.m0[li], params_at(p, L.mab0[li]), params_at(p, L.mab1[li]),
                           w.img[li], true, li == 1, &J);
     if (set128_on(c, s))           // the pair flags of the set-resident forward start every step at zero
-      J.j[J.n++] = PrepJob{nullptr, reinterpret_cast<__bf16*>(w.scratch), 1,
+      J.j[J.n++] = PrepJob{nullptr, reinterpret_cast<__bf16*>(w.set128_ws), 1,
                            (int)(set128_flag_bytes(c.B) / 2), 4};
     // (launched together with the query-side jobs below)
     // query-side preparation (Qp, G images) of every fused mab0 / PMA, also one launch
@@ -374,9 +375,14 @@ int forward(const pca_st_config& c, const Layout& L, const Shapes& s, const floa
       S.WqB = im.WqB; S.WqF = p1.wq; S.bq1 = p1.bq; S.WoP = im.WoP; S.bo1 = p1.bo;
       S.QpS = v1.QpS; S.OS = v1.OS; S.Y = reinterpret_cast<__bf16*>(w.Y[li]); S.mask = v1.mask;
     }
-    Carver cs(w.scratch);
+    Carver cs(w.set128_ws);
     a.flags = reinterpret_cast<uint32_t*>(cs.take<char>(set128_flag_bytes(c.B)));   // (cleared by k_prep_all)
     a.ex2 = cs.take<float>((size_t)c.B * 2 * 9216);
+    a.exP = cs.take<float>((size_t)c.B * 2 * 528);
+    if (head != nullptr) {             // the PMA epilogue, the classifier and the loss in the same launch
+      a.fuse_head = 1;
+      a.head = *head;
+    }
     Mab0Saved vp;
     mab0_carve_saved(s.pma, &vp, w.saved[4]);
     a.Gpma = vp.Gb; a.TpP = vp.Tp; a.MpP = vp.Mp; a.LpP = vp.Lp; a.Sp = mab0_splits(s.pma);
@@ -521,10 +527,19 @@ int pca_st_train_fwd_bwd(const pca_st_config* c, const float* params, const floa
                         pca::mab_kind(s.pma) == 2 && s.pma.d == 256;
   if (defer_wg) posts.wg256_ws = w.wg256_def;
   if (phase != 1) {
-    PCA_TRY(pca::forward(*c, L, s, p, X, w, true, st, &image_jobs));
+    // the set-resident forward runs the head stages in its own tail (PCA_SET128_HEAD=0: as a launch)
+    const char* he = getenv("PCA_SET128_HEAD");
+    const bool fuse_head = pca::set128_on(*c, s) && c->C <= 64 && !(he != nullptr && he[0] == '0');
+    pca::PmaHeadArgs head{};
+    if (fuse_head)
+      PCA_TRY(pca::pma_head_args(s.pma, pca::params_at(p, L.pma), w.saved[4], w.scratch, w.P,
+                                 p + L.wc, p + L.bc, labels, c->C, grad_scale, w.logits, w.dlogits,
+                                 w.dP, g + L.wc, g + L.bc, loss_out, stats, w.clsws, &posts, &head));
+    PCA_TRY(pca::forward(*c, L, s, p, X, w, true, st, &image_jobs, fuse_head ? &head : nullptr));
     if (pca::pma_head_ok(s)) {
       // dec.0 epilogue + dec.1 (Linear) + mean cross-entropy forward and backward + dec.0
       // backward epilogue: one launch, one workgroup per set
+      if (!fuse_head)
       PCA_TRY(pca::pma_head_launch(s.pma, pca::params_at(p, L.pma), w.saved[4], w.scratch, w.P,
                                    p + L.wc, p + L.bc, labels, c->C, grad_scale, w.logits,
                                    w.dlogits, w.dP, g + L.wc, g + L.bc, loss_out, stats,

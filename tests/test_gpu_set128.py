@@ -33,25 +33,30 @@ def dev():
     return torch.device("cuda", 0)
 
 
-def _run(dev, net, X, y, B, N, set128):
+def _run(dev, net, X, y, B, N, set128, head=True):
+    """head: the PMA epilogue / classifier / loss stages in the set-resident launch's tail (the default)
+    or as the launch of their own (k_pma_head1, ``PCA_SET128_HEAD=0``)."""
     from pca_hip import _lib, trainer
-    old = os.environ.get("PCA_SET128")
+    old = {k: os.environ.get(k) for k in ("PCA_SET128", "PCA_SET128_HEAD")}
     os.environ["PCA_SET128"] = "1" if set128 else "0"
+    os.environ["PCA_SET128_HEAD"] = "1" if head else "0"
     try:
         eng = trainer.STEngine(net, B, N, _lib.MODE_BF16, training=True)
         eng.fwd_bwd(X, y, phase=-1)
         torch.cuda.synchronize()
         return eng.logits.clone(), float(eng.loss), eng.grads.clone()
     finally:
-        if old is None:
-            del os.environ["PCA_SET128"]
-        else:
-            os.environ["PCA_SET128"] = old
+        for k, v in old.items():
+            if v is None:
+                del os.environ[k]
+            else:
+                os.environ[k] = v
 
 
+@pytest.mark.parametrize("head", [True, False], ids=["head-fused", "head-launch"])
 @pytest.mark.parametrize("B,N,din", [(5, 256, 2), (8, 256, 3), (3, 512, 2), (16, 512, 2), (7, 512, 3),
                                      (128, 512, 2), (130, 512, 2)])
-def test_set128_forward_equals_per_block_launches(dev, B, N, din):
+def test_set128_forward_equals_per_block_launches(dev, B, N, din, head):
     import models
     d, h, m, C = 128, 4, 16, 50
     torch.manual_seed(100 + N + din)
@@ -60,7 +65,7 @@ def test_set128_forward_equals_per_block_launches(dev, B, N, din):
     X = T(gi.pc_input(7000 + N, B, N, din), dev)
     y = T(gi.labels(7001 + N, B, C), dev)
     lg0, loss0, g0 = _run(dev, net, X, y, B, N, set128=False)
-    lg1, loss1, g1 = _run(dev, net, X, y, B, N, set128=True)
+    lg1, loss1, g1 = _run(dev, net, X, y, B, N, set128=True, head=head)
     assert torch.isfinite(lg1).all() and torch.isfinite(g1).all()
     # bf16 activations: a one-ulp difference of a merged fp32 statistic can flip the rounding of a few
     # hidden activations; everything else is the same arithmetic
