@@ -52,13 +52,25 @@ enum { PCA_F32 = 0, PCA_BF16 = 1 };
 /* PCA_MODE_FP8 (BASELINE configs[4]): as PCA_MODE_BF16, but these d x d projections of the forward
  * take fp8 e4m3 (OCP) MFMA operands: fc_o of the many-queries block (d = 128 and 256) and fc_k,
  * fc_v of the few-queries block where the keys are projected (d = 256).  fc_q of the many-queries
- * block stays bf16 by default (with it in fp8 - the measured, non-default A/B switch
- * PCA_FP8_PROJ=qo - a trained model agrees on 99.39 % of 10 000 sets, below the 99.8 % bar; the
- * default measures 99.83 %).  Weights are scaled per tensor by a power of two, activations
+ * block stays bf16 (with it in fp8 a trained model agreed on 99.39 % of 10 000 sets, below the 99.8 %
+ * bar - that variant is no longer selectable; the shipped split measures 99.83 %).  Weights are scaled per tensor by a power of two, activations
  * converted in registers; attention, softmax, residuals, the backward and the optimiser are those
  * of PCA_MODE_BF16 (straight-through gradient of the operand rounding). */
 enum { PCA_MODE_F32 = 0, PCA_MODE_BF16 = 1, PCA_MODE_FP8 = 2 };
 
+/* Per-thread state.  The library keeps no state between public calls EXCEPT, per calling thread:
+ *   - the last error string (pca_last_error);
+ *   - a deferred pack (pca_pack_defer): armed by the caller, filled by the next cursor pack, consumed by
+ *     the next pca_st_forward / pca_st_train_fwd_bwd of the same thread AND stream, or dropped - with an
+ *     error - by pca_pack_defer(0);
+ *   - the measurement hook (pca_prof_start / pca_prof_stop).
+ * Inside one public call the engine hands a few things from one internal stage to the next through
+ * thread-local slots (the step's weight-image table, the d = 256 mid-stage arm / ready flags, the
+ * query-side "prepared" flag, a weight-gradient job hand-over); they are set and cleared within that
+ * call.  pca_mab_fwd / pca_mab_bwd / pca_st_forward / pca_st_train_fwd_bwd check at entry AND at exit
+ * that every such slot is empty (PCA_EINVAL naming the slot otherwise), so a forward on the main thread
+ * and a backward on the autograd worker thread (SURVEY.md 8b "Threading") can never pick up each
+ * other's - or a failed call's - leftovers. */
 int pca_abi_version(void);
 /* Test aid (no reference counterpart): overwrites the LDS of every CU with NaN bit patterns.
  * The parity tests call it before each case so that a kernel reading LDS it has not written

@@ -74,6 +74,20 @@ int mab_bwd_any(const pca_mab_shape& s, const void* Q, const void* K, const pca_
 }
 }  // namespace pca
 
+namespace pca {
+int handoffs_empty(const char* where, bool pack_allowed) {
+  PCA_REQUIRE(!mid256_pending(), "%s: a d = 256 mid-stage hand-off is pending on this thread", where);
+  PCA_REQUIRE(!mab0_d256_prep_pending(), "%s: a query-side preparation flag is pending on this thread", where);
+  PCA_REQUIRE(!weight_images_active(), "%s: a weight-image table is still registered on this thread", where);
+  PCA_REQUIRE(!wgrad256_handoff_pending(), "%s: a weight-gradient job hand-over is pending on this thread",
+              where);
+  PCA_REQUIRE(pack_allowed || !pack_pending(),
+              "%s: a deferred pack is pending on this thread (only pca_st_forward / pca_st_train_fwd_bwd "
+              "consume it)", where);
+  return PCA_OK;
+}
+}  // namespace pca
+
 extern "C" {
 
 // An explicit PCA_MODE_BF16 request must be served by a fused kernel (no silent change of
@@ -105,6 +119,16 @@ size_t pca_mab_bwd_ws_bytes(const pca_mab_shape* s) {
   return pca::mab_bwd_ws_bytes_any(*s);
 }
 
+
+// runs the body, then re-checks the hand-offs: nothing may be left behind by this call either
+#define PCA_WITH_HANDOFF_CHECK(where, pack_allowed, call)            \
+  do {                                                               \
+    PCA_TRY(pca::handoffs_empty(where, pack_allowed));              \
+    const int rc_ = (call);                                          \
+    if (rc_ != PCA_OK) return rc_;                                   \
+    return pca::handoffs_empty(where " (exit)", false);             \
+  } while (0)
+
 int pca_mab_fwd(const pca_mab_shape* s, const void* Q, const void* K,
                 const pca_mab_params* p, void* Y, void* saved, void* ws, void* stream) {
   PCA_TRY(pca::validate_shape(s));
@@ -115,7 +139,8 @@ int pca_mab_fwd(const pca_mab_shape* s, const void* Q, const void* K,
   PCA_TRY(pca::check_f32(s, saved == nullptr));
   PCA_REQUIRE(ws != nullptr || (saved != nullptr && pca::mab_kind(*s, false) == 0),
               "mab_fwd: scratch block required");
-  return pca::mab_fwd_any(*s, Q, K, *p, Y, saved, ws, pca::as_stream(stream));
+  PCA_WITH_HANDOFF_CHECK("pca_mab_fwd", false,
+                         pca::mab_fwd_any(*s, Q, K, *p, Y, saved, ws, pca::as_stream(stream)));
 }
 
 int pca_mab_bwd(const pca_mab_shape* s, const void* Q, const void* K,
@@ -127,8 +152,9 @@ int pca_mab_bwd(const pca_mab_shape* s, const void* Q, const void* K,
               "mab_bwd: null gradient buffer");
   PCA_TRY(bf16_demand(s));
   PCA_TRY(pca::check_f32(s, false));
-  return pca::mab_bwd_any(*s, Q, K, *p, saved, dY, dQ, dK, dk_accumulate, *g, ws,
-                          pca::as_stream(stream));
+  PCA_WITH_HANDOFF_CHECK("pca_mab_bwd", false,
+                         pca::mab_bwd_any(*s, Q, K, *p, saved, dY, dQ, dK, dk_accumulate, *g, ws,
+                                          pca::as_stream(stream)));
 }
 
 int pca_linear_fwd(const float* X, const float* W, const float* b, float* Y, int64_t M,

@@ -35,7 +35,6 @@ namespace pca {
 namespace {
 
 constexpr int TP = M1_TP;      // 128 points per 4-wave tile (as the forward: the ReLU mask index)
-constexpr int NB = M1_NB;
 
 typedef __attribute__((address_space(3))) s16x4 lds_s16x4;
 
@@ -375,145 +374,15 @@ struct Attn1BwdArgs {
   float scale, scale_log2e;
 };
 
-template <int D>
-__global__ __launch_bounds__(64 * (D / 32), 2) void k_attn1_bwd(const Attn1BwdArgs a) {
-  constexpr int MI = 32, NW = D / 32;
-  constexpr int PQ = 72;                 // row pitch of the per-wave images: 64 B + 8 (banks)
-  constexpr int IMG = 32 * PQ;
-  extern __shared__ __attribute__((aligned(16))) char smem[];
-  const int tid = threadIdx.x, lane = tid & 63, j = tid >> 6;      // j = head of this wave
-  const int r = lane & 15, g = lane >> 4;
-  const int b = blockIdx.x / a.nparts, part = blockIdx.x - b * a.nparts;
-  char* myDS = smem + j * 4 * IMG;
-  char* myP = myDS + IMG;
-  char* myQ = myP + IMG;
-  char* myO = myQ + IMG;
-  (void)NW;
+// (k_attn1_bwd, the per-wave global-traffic form of round 1, was removed in round 4: k_attn1_bwd2 below has
+//  been the measured winner since round 2 - DESIGN.md 4.5.)
 
-  // the head's slices of the set's K / V images: MFMA A operands, resident in registers
-  bf16x8 kpa[2], vpa[2], kta[2];
-#pragma unroll
-  for (int kt = 0; kt < 2; ++kt) {
-    const int64_t o = ((int64_t)b * MI + 16 * kt + r) * D + 32 * j + 8 * g;
-    kpa[kt] = *reinterpret_cast<const bf16x8*>(a.KpP + o);
-    vpa[kt] = *reinterpret_cast<const bf16x8*>(a.VpP + o);
-    kta[kt] = *reinterpret_cast<const bf16x8*>(a.Kt + ((int64_t)b * D + 32 * j + 16 * kt + r) * MI +
-                                               8 * g);
-  }
-  f32x4 dkp[2][2], dvp[2][2];             // [key tile][feature tile]
-#pragma unroll
-  for (int kt = 0; kt < 2; ++kt)
-#pragma unroll
-    for (int tt = 0; tt < 2; ++tt) {
-      dkp[kt][tt] = f32x4{0.f, 0.f, 0.f, 0.f};
-      dvp[kt][tt] = f32x4{0.f, 0.f, 0.f, 0.f};
-    }
-  const int n_lo = part * a.pts_per_part;
-  const int n_hi = n_lo + a.pts_per_part < a.N ? n_lo + a.pts_per_part : a.N;
-  for (int n0 = n_lo; n0 < n_hi; n0 += 32) {
-#pragma unroll
-    for (int nb = 0; nb < NB; ++nb) {
-      const int n = n0 + 16 * nb + r;
-      const bool live = n < n_hi;
-      const int64_t row = (int64_t)b * a.N + (live ? n : 0);
-      // (guarded loads on purpose: the unconditional form measured 8 % slower here)
-      bf16x4 qlo = zero4b(), qhi = zero4b(), o0 = zero4b(), o1 = zero4b();
-      if (live) {
-        qlo = *reinterpret_cast<const bf16x4*>(a.QpS + row * D + 32 * j + 4 * g);
-        qhi = *reinterpret_cast<const bf16x4*>(a.QpS + row * D + 32 * j + 16 + 4 * g);
-        o0 = *reinterpret_cast<const bf16x4*>(a.dO + row * D + 32 * j + 4 * g);
-        o1 = *reinterpret_cast<const bf16x4*>(a.dO + row * D + 32 * j + 16 + 4 * g);
-      }
-      const bf16x8 qb = cat8(qlo, qhi), dob = cat8(o0, o1);
-      f32x4 dq0 = tof(o0), dq1 = tof(o1);                 // dQp starts as dO (residual Q_)
-      f32x4 p0 = {0.f, 0.f, 0.f, 0.f}, p1 = p0, da0 = p0, da1 = p0;
-      p0 = mfma32(kpa[0], qb, p0);
-      p1 = mfma32(kpa[1], qb, p1);
-      da0 = mfma32(vpa[0], dob, da0);
-      da1 = mfma32(vpa[1], dob, da1);
-      float mx = fmaxf(fmaxf(fmaxf(p0[0], p0[1]), fmaxf(p0[2], p0[3])),
-                       fmaxf(fmaxf(p1[0], p1[1]), fmaxf(p1[2], p1[3])));
-      mx = wave16_max(mx);
-      float sum = 0.f;
-#pragma unroll
-      for (int e = 0; e < 4; ++e) {
-        p0[e] = __builtin_amdgcn_exp2f((p0[e] - mx) * a.scale_log2e);
-        p1[e] = __builtin_amdgcn_exp2f((p1[e] - mx) * a.scale_log2e);
-        sum += p0[e] + p1[e];
-      }
-      sum = wave16_sum(sum);
-      const float inv = __builtin_amdgcn_rcpf(sum);
-      float delta = 0.f;
-#pragma unroll
-      for (int e = 0; e < 4; ++e) {
-        p0[e] *= inv;
-        p1[e] *= inv;
-        delta += p0[e] * da0[e] + p1[e] * da1[e];
-      }
-      delta = wave16_sum(delta);
-      f32x4 ds0, ds1;
-#pragma unroll
-      for (int e = 0; e < 4; ++e) {
-        ds0[e] = p0[e] * (da0[e] - delta) * a.scale;
-        ds1[e] = p1[e] * (da1[e] - delta) * a.scale;
-      }
-      // wave-private [point][.] images for the sums over points (padding points: zeros)
-      const int pt = 16 * nb + r;
-      const f32x4 zero4 = {0.f, 0.f, 0.f, 0.f};
-      *reinterpret_cast<bf16x4*>(myDS + pt * PQ + 8 * g) = pack4(live ? ds0 : zero4);
-      *reinterpret_cast<bf16x4*>(myDS + pt * PQ + 32 + 8 * g) = pack4(live ? ds1 : zero4);
-      *reinterpret_cast<bf16x4*>(myP + pt * PQ + 8 * g) = pack4(live ? p0 : zero4);
-      *reinterpret_cast<bf16x4*>(myP + pt * PQ + 32 + 8 * g) = pack4(live ? p1 : zero4);
-      *reinterpret_cast<bf16x4*>(myQ + pt * PQ + 8 * g) = qlo;
-      *reinterpret_cast<bf16x4*>(myQ + pt * PQ + 32 + 8 * g) = qhi;
-      *reinterpret_cast<bf16x4*>(myO + pt * PQ + 8 * g) = o0;
-      *reinterpret_cast<bf16x4*>(myO + pt * PQ + 32 + 8 * g) = o1;
-      // dQp_h^T += Kp_h^T . dS^T   (k = the 32 keys, perm32 order on both operands)
-      const bf16x8 dsb = pack8(ds0, ds1);
-      dq0 = mfma32(kta[0], dsb, dq0);
-      dq1 = mfma32(kta[1], dsb, dq1);
-      if (live) {
-        *reinterpret_cast<bf16x4*>(a.dQp + row * D + 32 * j + 4 * g) = pack4(dq0);
-        *reinterpret_cast<bf16x4*>(a.dQp + row * D + 32 * j + 16 + 4 * g) = pack4(dq1);
-      }
-    }
-    // dKp_h[key][f] += sum_pt dS[pt][key] Qp[pt][f] ; dVp_h[key][f] += sum_pt P[pt][key] dO[pt][f]
-    bf16x8 qf[2], of[2];
-#pragma unroll
-    for (int tt = 0; tt < 2; ++tt) {
-      qf[tt] = tr_frag_small(myQ, PQ, 16 * tt, lane);
-      of[tt] = tr_frag_small(myO, PQ, 16 * tt, lane);
-    }
-#pragma unroll
-    for (int kt = 0; kt < 2; ++kt) {
-      const bf16x8 ads = tr_frag_small(myDS, PQ, 16 * kt, lane);
-      const bf16x8 ap = tr_frag_small(myP, PQ, 16 * kt, lane);
-#pragma unroll
-      for (int tt = 0; tt < 2; ++tt) {
-        dkp[kt][tt] = mfma32(ads, qf[tt], dkp[kt][tt]);
-        dvp[kt][tt] = mfma32(ap, of[tt], dvp[kt][tt]);
-      }
-    }
-  }
-  const int64_t pbase = ((int64_t)b * a.nparts + part) * MI * D;
-#pragma unroll
-  for (int kt = 0; kt < 2; ++kt)
-#pragma unroll
-    for (int tt = 0; tt < 2; ++tt)
-#pragma unroll
-      for (int e = 0; e < 4; ++e) {
-        const int64_t o = pbase + (int64_t)(16 * kt + 4 * g + e) * D + 32 * j + 16 * tt + r;
-        a.dKpPart[o] = dkp[kt][tt][e];
-        a.dVpPart[o] = dvp[kt][tt][e];
-      }
-}
-
-// k_attn1_bwd2: the same arithmetic with full-line global traffic.  In k_attn1_bwd every wave
-// fetches its head's 64-byte slice of each row straight from memory (16 rows x 32 bytes per load
-// instruction, 8-byte stores): 243 us at configs[3] for 0.8 GB, 3.3 TB/s.  Here the workgroup moves
-// whole [32 points][256] tiles: Qp and dO arrive by LDS-DMA (1 KiB per wave instruction, double
-// buffered, swizzled like the single-launch forward's tiles), each wave reads / writes its head's
-// slice of the tiles in LDS, and the dQp tile leaves in 16-byte pieces of full rows.
+// k_attn1_bwd2: the attention adjoint of the many-queries block, WAVE = HEAD, with full-line global
+// traffic.  (With every wave fetching its head's 64-byte slice of each row straight from memory - 16 rows
+// x 32 bytes per load instruction, 8-byte stores - it took 243 us at configs[3] for 0.8 GB, 3.3 TB/s.)
+// Here the workgroup moves whole [32 points][256] tiles: Qp and dO arrive by LDS-DMA (1 KiB per wave
+// instruction, double buffered, swizzled like the single-launch forward's tiles), each wave reads /
+// writes its head's slice of the tiles in LDS, and the dQp tile leaves in 16-byte pieces of full rows.
 typedef __attribute__((address_space(3))) void lds_void_t;
 template <int D>
 __global__ __launch_bounds__(64 * (D / 32), 2) void k_attn1_bwd2(const Attn1BwdArgs a) {
@@ -3213,31 +3082,19 @@ int attn1_bwd256(const __bf16* dO, const __bf16* QpS, const __bf16* KpP, const _
                  float* dVp, int B, int N, hipStream_t st) {
   constexpr int D = 256;
   int parts = attn1_bwd256_parts(B, N);
-  {
-    const char* e = getenv("PCA_ATTN1_V1");
-    // (k_attn1_bwd2 holds 152 KiB of LDS: one workgroup per CU, so half the ranges of the
-    //  two-per-CU form; the partial buffers are sized for the larger count)
-    if (!(e && e[0] == '1') && B * parts > 256 && parts > 1) parts /= 2;
-  }
+  // (k_attn1_bwd2 holds 152 KiB of LDS: one workgroup per CU, so half the ranges of the
+  //  two-per-CU form; the partial buffers are sized for the larger count)
+  if (B * parts > 256 && parts > 1) parts /= 2;
   const int ppp = (int)cdiv(cdiv(N, 32), parts) * 32;
   Attn1BwdArgs a{dO, QpS, KpP, VpP, Kt, dQp, dKpPart, dVpPart, B, N, parts, ppp,
                  1.0f / sqrtf((float)D), 1.4426950408889634f / sqrtf((float)D)};
   static std::once_flag once;
   std::call_once(once, [] {
-    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(k_attn1_bwd<D>),
-                              hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
     (void)hipFuncSetAttribute(reinterpret_cast<const void*>(k_attn1_bwd2<D>),
                               hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
   });
-  // PCA_ATTN1_V1=1: the per-wave global-traffic form (A/B measurements)
-  static const bool v1 = [] { const char* e = getenv("PCA_ATTN1_V1"); return e && e[0] == '1'; }();
-  if (v1) {
-    hipLaunchKernelGGL((k_attn1_bwd<D>), dim3(B * parts), dim3(64 * (D / 32)),
-                       (size_t)(D / 32) * 4 * 32 * 72, st, a);
-  } else {
-    hipLaunchKernelGGL((k_attn1_bwd2<D>), dim3(B * parts), dim3(64 * (D / 32)),
-                       (size_t)5 * 32 * D * 2 + (size_t)(D / 32) * 4 * 32 * 72, st, a);
-  }
+  hipLaunchKernelGGL((k_attn1_bwd2<D>), dim3(B * parts), dim3(64 * (D / 32)),
+                     (size_t)5 * 32 * D * 2 + (size_t)(D / 32) * 4 * 32 * 72, st, a);
   PCA_TRY(check_launch("k_attn1_bwd"));
   hipLaunchKernelGGL(k_sum_parts256, dim3((unsigned)cdiv((int64_t)B * 32 * D, 256)), dim3(256), 0,
                      st, dKpPart, dVpPart, dKp, dVp, B, parts, 32 * D);
@@ -3404,8 +3261,7 @@ int fq_attn_fwd256(const __bf16* Kp, const __bf16* Vp, const float* Qp, int B, i
   a.scale = 1.0f / sqrtf((float)D);
   a.scale_log2e = 1.4426950408889634f * a.scale;
   const size_t lds = (size_t)(D / 32) * 32 * 72;
-  // PCA_FQ_FWD_V1=1: the per-wave global-traffic form (A/B measurements)
-  static const bool v1 = [] { const char* e = getenv("PCA_FQ_FWD_V1"); return e && e[0] == '1'; }();
+  constexpr bool v1 = false;       // (the per-wave global-traffic form: only for m <= 16 below)
   int S2 = S;
   if (QT == 2 && !v1) {
     while (S2 > 1 && B * S2 > 256) S2 /= 2;       // 82 KiB of LDS: one workgroup per CU
@@ -3474,8 +3330,7 @@ int fq_attn_bwd256(const __bf16* Kp, const __bf16* Vp, const float* Qp, const fl
   a.scale = 1.0f / sqrtf((float)D);
   a.scale_log2e = 1.4426950408889634f * a.scale;
   const size_t lds = (size_t)(D / 32) * 32 * 72;
-  // PCA_FQ_BWD_V1=1: the per-wave global-traffic form (A/B measurements)
-  static const bool v1 = [] { const char* e = getenv("PCA_FQ_BWD_V1"); return e && e[0] == '1'; }();
+  constexpr bool v1 = false;       // (the per-wave global-traffic form: only for m <= 16 below)
   int S2 = S;
   if (QT == 2 && !v1) {
     // full-line traffic through LDS tiles: 114 KiB per workgroup, one per CU - fewer point ranges

@@ -1106,8 +1106,12 @@ int isab1_fwd256_fused(const void* X, int dq, const __bf16* WqB, const float* Wq
   a.B = B; a.N = N; a.dq = dq;
   a.tiles_per_set = (int)cdiv(N, P);
   a.scale_log2e = 1.4426950408889634f / sqrtf((float)D);
+#if defined(PCA_FWD_ABLATE) || defined(PCA_FWD_STAMPS)      // diagnostic builds only (scripts/experiments)
   a.ablate = (getenv("PCA_AB_ABLATE") ? atoi(getenv("PCA_AB_ABLATE")) : 0) |
              ((getenv("PCA_AB_STAMPSEL") ? atoi(getenv("PCA_AB_STAMPSEL")) : 15) << 16);
+#else
+  a.ablate = 15 << 16;
+#endif
   const int total = B * a.tiles_per_set;
   int grid = total < 256 ? total : 256;
   a.units_per_wg = (int)cdiv(total, grid);
@@ -1148,8 +1152,13 @@ int isab1_fwd256_fused(const void* X, int dq, const __bf16* WqB, const float* Wq
     hipLaunchKernelGGL((k_isab1_fwd256_ab<S, F, T>), dim3(grid), dim3(1024), lds2, st, a);       \
   } while (0)
     const bool sm = dq <= 4, f8 = inv_o != nullptr;
-    // PCA_AB_ABREAST=1: role A runs the two point blocks of a unit side by side (see the kernel)
+    // (role A with the two point blocks of a unit side by side: measured, no gain - DESIGN.md 4.5.1; the
+    //  kernel variant is kept for the ablation scripts only)
+#ifdef PCA_FWD_ABLATE
     static const bool abreast = [] { const char* e = getenv("PCA_AB_ABREAST"); return e && e[0] == '1'; }();
+#else
+    constexpr bool abreast = false;
+#endif
     if (abreast && !sm && !f8 && !train) {
       static std::once_flag o3;
       std::call_once(o3, [] {

@@ -59,6 +59,7 @@ void mid256_arm(const pca_mab_shape* s1, const pca_mab_params* p1, void* saved1)
   g_mid256.armed = s1 != nullptr && p1 != nullptr && saved1 != nullptr;
   if (g_mid256.armed) { g_mid256.s1 = *s1; g_mid256.p1 = *p1; g_mid256.saved1 = saved1; }
 }
+bool mid256_pending() { return g_mid256.armed || g_mid256.ready; }
 bool mid256_kv_ready() {
   const bool r = g_mid256.ready;
   g_mid256.ready = false;
@@ -78,8 +79,7 @@ bool wgrad256_handoff_pending() { return g_handoff.has || g_handoff.has_dx; }
 // PCA_ROWSTREAM=0: the LDS-resident-weight row-GEMMs (k_rowgemm) instead of the register-resident
 // streaming ones (d256_stream.hip), for A/B measurements
 static bool rowstream_on() {
-  static const bool on = [] { const char* e = getenv("PCA_ROWSTREAM"); return !(e && e[0] == '0'); }();
-  return on;
+  return true;
 }
 
 static size_t mab1_d256_carve(const pca_mab_shape& s, Mab1D256Ws* out, void* base) {
@@ -152,8 +152,7 @@ int wgrad256_flush_deferred(BwdDefer& D, hipStream_t st) {
 
 // PCA_BWD_O_FUSED=0: fc_o adjoint as its own row-GEMM launch (A/B measurements)
 static bool fuse_o_on() {
-  static const bool on = [] { const char* e = getenv("PCA_BWD_O_FUSED"); return !(e && e[0] == '0'); }();
-  return on;
+  return true;
 }
 int d256_bwd_wo_mode() { return fuse_o_on() ? 3 : 2; }
 int d256_bwd_wq_mode() { return rowstream_on() ? 3 : 2; }
@@ -356,19 +355,14 @@ void mab0_d256_prep_collect(int n, const pca_mab_shape* const* shapes, const flo
   }
 }
 void mab0_d256_prep_done(bool on) { g_prep256_done = on; }
+bool mab0_d256_prep_pending() { return g_prep256_done; }
 
 // operand mode of fc_o (and its adjoint) on the [B*m] query rows of a few-queries block:
 // 2 (default) hi + lo bf16 pairs on the MFMA - fp32-level Z, so the ReLU mask is the exact one;
 // PCA_FQ_EPI=bf16: single bf16 operands (round 2; 0.3-0.85 % of dQ elements then differ from the
 // emulation through flipped pre-activations); PCA_FQ_EPI_F32=1: the exact fp32 GEMM (22 us a call)
 static int fq_epi_bf16() {
-  static const int mode = [] {
-    const char* e = getenv("PCA_FQ_EPI_F32");
-    if (e != nullptr && e[0] == '1') return 0;
-    const char* f = getenv("PCA_FQ_EPI");
-    return (f != nullptr && f[0] == 'b') ? 1 : 2;
-  }();
-  return mode;
+  return 2;
 }
 int mab0_d256_fwd(const pca_mab_shape& s, const float* I, const void* X, const pca_mab_params& p,
                   float* Hout, void* saved, void* ws, hipStream_t st) {
@@ -412,9 +406,9 @@ int mab0_d256_fwd(const pca_mab_shape& s, const float* I, const void* X, const p
       Xb = v.Xb;
     }
     // PCA_FQ_FUSED_FWD=0: projection and attention as two launches (A/B measurements)
-    static const bool fq_fused = [] { const char* e = getenv("PCA_FQ_FUSED_FWD"); return !(e && e[0] == '0'); }();
+    constexpr bool fq_fused = true;
     // PCA_FQ_FUSED_F8=0: the fp8 mode on the two-launch form of round 2 (A/B measurements)
-    static const bool fq_fused8 = [] { const char* e = getenv("PCA_FQ_FUSED_F8"); return !(e && e[0] == '0'); }();
+    constexpr bool fq_fused8 = true;
     const bool f8 = s.mode == PCA_MODE_FP8;
     if ((!f8 || fq_fused8) && rowstream_on() && fq_fused && m > 16) {
       // fc_k / fc_v over the keys and the attention in one pass over X (k_fq_proj_fwd)

@@ -76,10 +76,9 @@ thread_local SideCtx g_side;
 }  // namespace
 
 void terminal_enable(bool on) {
-  static const bool allowed = [] {
-    const char* e = getenv("PCA_SIDE_STREAM");
-    return e != nullptr && e[0] == '1';       // opt-in: measured slower on MI355X
-  }();
+  // the helper stream stays OFF: measured slower on MI355X at every size tried (DESIGN.md 4.4, 4.5;
+  // round 4: the [B*N]-row weight gradients of enc.1 under enc.0's backward, 0.285 against 0.260 ms)
+  constexpr bool allowed = false;
   g_side.enabled = on && allowed;
 }
 

@@ -161,6 +161,7 @@ int pack_submit(const PackJob& j, hipStream_t st) {
 
 }  // namespace
 
+bool pack_pending() { return t_pack_pending.kind != 0; }
 bool pack_take(PackJob* out) {
   if (t_pack_pending.kind == 0) return false;
   *out = t_pack_pending;

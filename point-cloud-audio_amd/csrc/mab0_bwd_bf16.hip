@@ -842,7 +842,7 @@ int pma_head_launch(const pca_mab_shape& s, const pca_mab_params& p, void* saved
   const size_t l3 = (2 * (size_t)m * d + (size_t)Rp + (size_t)d) * sizeof(float);
   lds = lds > l2 ? lds : l2;
   lds = lds > l3 ? lds : l3;
-  static const bool v1 = getenv("PCA_PMA_HEAD_V1") != nullptr && getenv("PCA_PMA_HEAD_V1")[0] == '1';
+  constexpr bool v1 = false;       // (the generic k_pma_head serves the shapes k_pma_head1 does not)
   if (!v1 && d == 128 && dk == 128 && h == 4 && m == 1 && C <= 64 && a.S >= 1 && a.S <= 8)
     hipLaunchKernelGGL(k_pma_head1, dim3(s.B), dim3(256), 0, st, a);
   else

@@ -800,6 +800,7 @@ int prep_weight(const float* src, __bf16* dst, int rows, int cols, int mode, hip
 
 static thread_local const WeightImages* t_images = nullptr;
 void weight_images_use(const WeightImages* t) { t_images = t; }
+bool weight_images_active() { return t_images != nullptr; }
 static __bf16* image_of(const float* src, int mode, int rows, int cols) {
   if (t_images == nullptr) return nullptr;
   for (int i = 0; i < t_images->n; ++i) {
@@ -849,11 +850,7 @@ int weight_image2(const float* src0, __bf16** dst0, int mode0, const float* src1
 
 // PCA_D256_FUSED=0: the two-launch form (Q phase + row-GEMM O phase) for A/B measurements
 static bool fused256_on() {
-  static const bool on = [] {
-    const char* e = getenv("PCA_D256_FUSED");
-    return !(e != nullptr && e[0] == '0');
-  }();
-  return on;
+  return true;        // (the two-launch Q + O form of round 1 still serves fp32 activations)
 }
 
 // Does the training forward save the projected queries?  Not at layer 1 (two or three input
@@ -862,10 +859,7 @@ static bool fused256_on() {
 bool mab1_saves_qp(const pca_mab_shape& s) {
   if (s.dq > 4) return true;
   if (s.nk == 16 && s.dq <= 3) return false;
-  static const bool fuse_o = [] { const char* e = getenv("PCA_BWD_O_FUSED"); return !(e && e[0] == '0'); }();
-  // PCA_L1_SAVE_QP=1: save them at d = 256 as well (A/B measurements)
-  static const bool save256 = [] { const char* e = getenv("PCA_L1_SAVE_QP"); return e && e[0] == '1'; }();
-  if (s.d == 256 && s.nk == 32 && fuse_o && !save256) return false;
+  if (s.d == 256 && s.nk == 32) return false;       // k_attn1_bwd3<256, SMALLQ> recomputes them
   return true;
 }
 
@@ -943,10 +937,7 @@ int mab1_bf16_fwd_ex(const pca_mab_shape& s, const void* X, const float* H,
   //   fc_o only       99.83 %   <- default: meets the 99.8 % bar of SURVEY.md 8d
   //   fc_q and fc_o   99.39 %   (PCA_FP8_PROJ=qo): the 4 significant bits of e4m3 on the projected
   //                             queries perturb the softmax logits of every head
-  static const bool f8_q = [] {
-    const char* e = getenv("PCA_FP8_PROJ");
-    return e != nullptr && e[0] == 'q';
-  }();
+  constexpr bool f8_q = false;      // (fc_q in fp8 as well fails the 99.8 % bar: not selectable any more)
   // d = 256, bf16 activations, fc_o in fp8 (the default split): the single-launch kernel
   const bool f8_fused = f8 && !f8_q && d == 256 && s.y_dtype == PCA_BF16 && fused256_on();
   if (f8) {
@@ -1019,10 +1010,7 @@ int mab1_bf16_fwd_ex(const pca_mab_shape& s, const void* X, const float* H,
   }
   if (s.nk == 16) {
     // PCA_D128_FUSED=0: the LDS-resident-weight kernel (k_mab1_fwd) instead of the wave = head one
-    static const bool fused128 = [] {
-      const char* e = getenv("PCA_D128_FUSED");
-      return !(e != nullptr && e[0] == '0');
-    }();
+    constexpr bool fused128 = true;
     // (d -> d blocks only: at layer 1 - two or three input columns, no X tile to stream - the
     //  wave = head kernel measured 17.6 us against 17.0)
     if (abf && fused128 && !small)

@@ -994,8 +994,6 @@ int bwd_defer_flush(BwdDefer& D, hipStream_t st) {
     // (measured at 3 x 65536 rows: 512 -> 41 us, 768 -> 41, 1024 -> 31, 1536 -> 31, 2048 -> 39)
     int rpw = 512 * (int)((rows + 98303.0) / 98304.0);
     rpw = rpw < 512 ? 512 : (rpw > 1024 ? 1024 : rpw);
-    static const int rpw_env = getenv("PCA_WGRAD_RPW") ? atoi(getenv("PCA_WGRAD_RPW")) : 0;
-    if (rpw_env > 0) rpw = rpw_env;
     WgradSlabs sl{slab_mode ? D.slab_ws : nullptr, D.slab_cap * 3 / 4, &late, &D.sums, 0};
     PCA_TRY(wgrad128_launch(D.wg_bf16, true, true, rpw, ts, &sl));
     used = (sl.used + 255) & ~(size_t)255;
@@ -1007,8 +1005,7 @@ int bwd_defer_flush(BwdDefer& D, hipStream_t st) {
     // 64: 18.7 us, 128: 14.2, 256: 15.3
     WgradSlabs sl{slab_mode ? D.slab_ws + used / sizeof(float) : nullptr, D.slab_cap - used, &late,
                   &D.sums, 0};
-    static const int rpw32_env = getenv("PCA_WGRAD_RPW_F32") ? atoi(getenv("PCA_WGRAD_RPW_F32")) : 0;
-    PCA_TRY(wgrad128_launch(D.wg_f32, false, false, rpw32_env > 0 ? rpw32_env : 128, ts, &sl));
+    PCA_TRY(wgrad128_launch(D.wg_f32, false, false, 128, ts, &sl));
     used += (sl.used + 255) & ~(size_t)255;
     D.wg_f32.n = 0;
     D.sums.n = 0;
@@ -1102,7 +1099,11 @@ int mab1_bf16_bwd_ex(const pca_mab_shape& s, const void* X, const float* H,
   a.B = s.B; a.N = s.nq; a.tiles_per_set = (int)cdiv(s.nq, TP);
   a.scale = 1.0f / sqrtf((float)d);
   a.scale_log2e = 1.4426950408889634f * a.scale;
+#ifdef PCA_DEBUG_CLOCKS
   a.dbg_wg = getenv("PCA_DBG_WG") ? atoi(getenv("PCA_DBG_WG")) : 0;
+#else
+  a.dbg_wg = 0;
+#endif
   // reference-formulation FLOPs of what THIS launch computes (round 3: not the whole block's
   // backward - dWo and, beyond layer 1, dWq run in k_wgrad128 and are charged there): fc_o adjoint
   // dO = dY + dZ Wo (2 M d^2), attention adjoint (recomputed scores, dP, dQp, dKp, dVp: 8 M m d),

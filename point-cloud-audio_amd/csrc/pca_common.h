@@ -74,6 +74,20 @@ void terminal_enable(bool on);
 hipStream_t terminal_stream(hipStream_t main);
 void terminal_join(hipStream_t main);
 
+// ---- per-thread hand-off state (documented in include/pca_hip.h, "Per-thread state") ----------------
+// Every hand-off between two internal calls of ONE public entry (the step's weight-image table, the
+// d = 256 mid-stage arm / K-V-ready flags, the query-side "prepared" flag, the weight-gradient job
+// hand-over) must be empty when a public pca_* call is entered and when it returns; the deferred pack is
+// the one hand-off BETWEEN public calls and is allowed at the entry of its documented consumers only.
+bool mid256_pending();
+bool mab0_d256_prep_pending();
+bool weight_images_active();
+bool wgrad256_handoff_pending();
+bool pack_pending();
+// PCA_EINVAL with a message naming the stale hand-off (a previous call on this thread left it behind:
+// an error path that skipped its guard, or a pack armed and never consumed)
+int handoffs_empty(const char* where, bool pack_allowed);
+
 // ---- internal launchers used across translation units -------------------
 int gemm_f32(const pca_gemm_desc& g, const float* A, const float* B, const float* bias,
              float* C, hipStream_t st);

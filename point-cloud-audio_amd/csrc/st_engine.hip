@@ -207,7 +207,7 @@ inline size_t carve(const pca_st_config& c, int training, Ws* out, void* base) {
   if ((w.fused[0] || w.fused[1]) && wgrad_slabs_on()) {
     // two lists (B*N-row and B*m-row jobs) of up to ~600 [128 x 128 (+128)] fp32 slabs each;
     // bwd_defer_flush gives a workgroup more rows when a list would not fit
-    static const int slab_mb = getenv("PCA_WGRAD_SLAB_MB") ? atoi(getenv("PCA_WGRAD_SLAB_MB")) : 40;
+    constexpr int slab_mb = 40;
     w.wg_slab_bytes = 2 * (size_t)slab_mb * 1024 * 1024;
     w.wg_slabs = cv.take<float>(w.wg_slab_bytes / sizeof(float));
   }
@@ -235,8 +235,7 @@ inline int images256_prepare(const pca_st_config& c, const Layout& L, const Shap
                              const Ws& w, WeightImages* tab, bool launch, hipStream_t st,
                              PrepJobs* jobs_out = nullptr) {
   tab->n = 0;
-  static const bool off = [] { const char* e = getenv("PCA_D256_IMAGES"); return e && e[0] == '0'; }();
-  if (w.img256 == nullptr || off) return PCA_OK;       // (PCA_D256_IMAGES=0: per-block conversions)
+  if (w.img256 == nullptr) return PCA_OK;
   PrepJobs J{};
   auto add = [&](const float* src, int mode) {
     if (tab->n >= 24) return;
@@ -286,14 +285,8 @@ inline int images256_prepare(const pca_st_config& c, const Layout& L, const Shap
   return prep_f8_jobs_launch(F, st);
 }
 
-// PCA_D256_DEFER_POSTS=0: the d = 256 few-queries blocks run their post stages per block
-inline bool defer256_on() {
-  static const bool on = [] {
-    const char* e = getenv("PCA_D256_DEFER_POSTS");
-    return !(e != nullptr && e[0] == '0');
-  }();
-  return on;
-}
+// the d = 256 few-queries blocks' post stages: one deferred launch pair per step (per block in round 2)
+inline bool defer256_on() { return true; }
 
 int validate(const pca_st_config* c) {
   PCA_REQUIRE(c != nullptr, "st: null config");
@@ -462,8 +455,8 @@ int pca_st_ws_layout(const pca_st_config* c, int64_t* out) {
   return PCA_OK;
 }
 
-int pca_st_forward(const pca_st_config* c, const float* params, const float* X,
-                   const int32_t* lengths, float* logits, void* ws, void* stream) {
+static int st_forward_impl(const pca_st_config* c, const float* params, const float* X,
+                           const int32_t* lengths, float* logits, void* ws, void* stream) {
   PCA_TRY(pca::validate(c));
   PCA_REQUIRE(params && X && logits && ws, "st_forward: null pointer");
   hipStream_t st = pca::as_stream(stream);
@@ -477,11 +470,18 @@ int pca_st_forward(const pca_st_config* c, const float* params, const float* X,
   return pca::forward(*c, L, s, params, X, w, false, st);
 }
 
-int pca_st_train_fwd_bwd(const pca_st_config* c, const float* params, const float* X,
-                         const int32_t* lengths, const int64_t* labels, float* grads,
-                         float* loss_out, float* stats,
-                         float* logits, float grad_scale, int phase, void* ws,
-                         void* stream) {
+int pca_st_forward(const pca_st_config* c, const float* params, const float* X,
+                   const int32_t* lengths, float* logits, void* ws, void* stream) {
+  PCA_TRY(pca::handoffs_empty("pca_st_forward", true));
+  const int rc = st_forward_impl(c, params, X, lengths, logits, ws, stream);
+  return rc != PCA_OK ? rc : pca::handoffs_empty("pca_st_forward (exit)", false);
+}
+
+static int st_train_fwd_bwd_impl(const pca_st_config* c, const float* params, const float* X,
+                                 const int32_t* lengths, const int64_t* labels, float* grads,
+                                 float* loss_out, float* stats,
+                                 float* logits, float grad_scale, int phase, void* ws,
+                                 void* stream) {
   PCA_TRY(pca::validate(c));
   PCA_REQUIRE(params && X && labels && grads && loss_out && ws,
               "st_train_fwd_bwd: null pointer");
@@ -522,8 +522,7 @@ int pca_st_train_fwd_bwd(const pca_st_config* c, const float* params, const floa
   // needs every block's operands in place until then: the hand-over form of enc.1 (its few-queries
   // block works in w.scratch) and a workspace of its own for enc.0's few-queries block
   const bool hand1 = s.m1[1].d == 256 && pca::mab_kind(s.m1[1]) == 1 && pca::mab_kind(s.m0[1]) == 2;
-  static const bool wg_off = [] { const char* e = getenv("PCA_D256_DEFER_WGRAD"); return e && e[0] == '0'; }();
-  const bool defer_wg = !wg_off && w.wg256_def != nullptr && hand1 && pca::defer256_on() &&
+  const bool defer_wg = w.wg256_def != nullptr && hand1 && pca::defer256_on() &&
                         pca::mab_kind(s.pma) == 2 && s.pma.d == 256;
   if (defer_wg) posts.wg256_ws = w.wg256_def;
   if (phase != 1) {
@@ -628,5 +627,17 @@ int pca_st_train_fwd_bwd(const pca_st_config* c, const float* params, const floa
     }
   }
   return pca::bwd_defer_flush(posts, st);
+}
+
+int pca_st_train_fwd_bwd(const pca_st_config* c, const float* params, const float* X,
+                         const int32_t* lengths, const int64_t* labels, float* grads,
+                         float* loss_out, float* stats,
+                         float* logits, float grad_scale, int phase, void* ws,
+                         void* stream) {
+  // phase 1 of a split step reads X again: the pack was consumed by phase 0
+  PCA_TRY(pca::handoffs_empty("pca_st_train_fwd_bwd", phase != 1));
+  const int rc = st_train_fwd_bwd_impl(c, params, X, lengths, labels, grads, loss_out, stats, logits,
+                                       grad_scale, phase, ws, stream);
+  return rc != PCA_OK ? rc : pca::handoffs_empty("pca_st_train_fwd_bwd (exit)", false);
 }
 }

@@ -23,7 +23,7 @@ def set_mode(mode: str) -> None:
     """Arithmetic mode of MAB blocks: 'f32' = exact fp32 kernels (parity mode),
     'bf16' = bf16 MFMA operands with fp32 accumulate/softmax (fails for shapes the fused
     kernels do not cover), 'fp8' = as bf16 with fp8 (e4m3) operands in fc_o of the many-queries
-    blocks and fc_k / fc_v of the d = 256 few-queries block (fc_q stays bf16 unless PCA_FP8_PROJ=qo:
+    blocks and fc_k / fc_v of the d = 256 few-queries block (fc_q stays bf16:
     include/pca_hip.h), 'auto' = bf16 where covered, else f32."""
     global _MODE
     if mode not in ("f32", "bf16", "fp8", "auto"):

@@ -8,6 +8,15 @@ logits, the loss and the 45 gradients.
   bf16 values reach the same MFMAs in the same order.
 * ``PCA_WGRAD256_DMA``: operand tiles of the 256-wide weight gradients through registers or by LDS-DMA.
 * ``PCA_PACK_DEFER`` is covered in test_gpu_parity.py.
+* ``PCA_WGRAD_SLABS`` (fixed-order slabs vs fp32 atomics) in tests/test_gpu_fullsize.py
+  (test_d128_step_is_bit_reproducible), ``PCA_SET128`` / ``PCA_SET128_HEAD`` (the set-resident forward and
+  its fused head stages against the per-block launches) in tests/test_gpu_set128.py.
+
+Round 4 removed every other ``PCA_*`` switch of the library (22 of them: the defaults had been the measured
+winners for a round or more; ``k_attn1_bwd`` went with its switch).  What is left, all covered by a test:
+PCA_SET128, PCA_SET128_HEAD, PCA_WGRAD_SLABS, PCA_D128_DZ_MASK, PCA_D256_DZ_MASK, PCA_WGRAD256_DMA,
+PCA_D256_MID, PCA_D256_AB (+ PCA_PACK_DEFER in the Python trainer).  PCA_AB_ABLATE / PCA_AB_STAMPSEL /
+PCA_AB_ABREAST / PCA_DBG_WG exist in the diagnostic builds of scripts/experiments only (#ifdef).
 
 Switches between two implementations with a different summation order or operand rounding point
 (``PCA_D256_MID``: the per-set mid stage in one launch or five; ``PCA_D256_AB``: the producer / consumer
