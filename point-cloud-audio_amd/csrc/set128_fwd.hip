@@ -1012,9 +1012,16 @@ __global__ __launch_bounds__(NT) void k_set128_fwd(const Set128FwdArgs a_by_valu
       for (int ft = 0; ft < 8; ++ft) landed(pt[ft]);
       landed(pml);
       STAMP(26);
+      // the SAME expression in both halves - f_1 x_1 + (f_0 x_0), the half-0 product rounded first, whoever
+      // "own" is - so that the two workgroups of a set merge to bit-identical T (hipcc contracts
+      // __fadd_rn(__fmul_rn(..), __fmul_rn(..)) into v_fmac: "own product first" differed between them)
+      const bool h0 = c.half == 0;
+      auto comb = [&](float fo_, float xo_, float fp_, float xp_) {
+        return h0 ? __builtin_fmaf(fp_, xp_, fo_ * xo_) : __builtin_fmaf(fo_, xo_, fp_ * xp_);
+      };
       const float Mx = fmaxf(mrow, pml.x);
       const float fo = __builtin_amdgcn_exp2f(mrow - Mx), fp = __builtin_amdgcn_exp2f(pml.x - Mx);
-      const float Lt = __fadd_rn(__fmul_rn(fo, lrow), __fmul_rn(fp, pml.y));
+      const float Lt = comb(fo, lrow, fp, pml.y);
       const float inv = 1.f / Lt;
       if (g == 0) {
         myAl[r] = fo;
@@ -1029,8 +1036,7 @@ __global__ __launch_bounds__(NT) void k_set128_fwd(const Set128FwdArgs a_by_valu
         const float pv[4] = {pt[ft].x, pt[ft].y, pt[ft].z, pt[ft].w};
 #pragma unroll
         for (int e = 0; e < 4; ++e)       // unnormalised; row 16 j + 4 g + e, feature 16 ft + r
-          sTs[(16 * c.j + 4 * g + e) * D + 16 * ft + r] =
-              __fadd_rn(__fmul_rn(a1v[e], T[ft][e]), __fmul_rn(a2v[e], pv[e]));
+          sTs[(16 * c.j + 4 * g + e) * D + 16 * ft + r] = comb(a1v[e], T[ft][e], a2v[e], pv[e]);
       }
     }
     mid_prefetch<false>(L, c, D, pre);   // one barrier ahead of the mid stage (see layer 1)

@@ -57,6 +57,7 @@ out = {
                   "coalesced reads); WRITE_SIZE (KiB) as is",
     "library_sha16": hashlib.sha256(open(so, "rb").read()).hexdigest()[:16],
     "k_mab1_bwd_bytes_per_launch": round(agg * 1e6),
+    "k_set128_fwd_bytes_per_launch": round(family("k_set128_fwd") * 1e6),
     "k_mab0_bwd_bytes_per_launch": round(family("k_mab0_bwd") * 1e6),
     "per_kernel_per_launch": per,
 }
