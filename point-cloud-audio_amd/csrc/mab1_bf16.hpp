@@ -240,6 +240,14 @@ int prep_weight_f8(const float* src, void* dst, int rows, int cols, int mode, fl
                    hipStream_t st);
 
 // ---- host entry points of the fused blocks (single source of truth for every TU) --------
+// fused attention core of the bf16-operand GEMM chain for head dims <= 16 (attn_core.hip): O = Q_ + A V_
+// and its adjoint without the [B h, nq, nk] matrix A (LSE [B][h][nq] is what is saved instead)
+bool attn_core_ok(const pca_mab_shape& s);
+int attn_core_fwd(const pca_mab_shape& s, const float* Qp, const float* Kp, const float* Vp, float* O,
+                  float* LSE, hipStream_t st);
+int attn_core_bwd(const pca_mab_shape& s, const float* Qp, const float* Kp, const float* Vp,
+                  const float* O, const float* LSE, const float* dO, float* dQp, float* dKp, float* dVp,
+                  float* Delta, hipStream_t st);
 // exact fp32 path (mab_f32.hip)
 int validate_shape(const pca_mab_shape* s);
 size_t mab_f32_saved_bytes(const pca_mab_shape& s);

@@ -43,7 +43,8 @@ inline size_t saved_elems(const pca_mab_shape& s, SavedF32* out, void* base) {
   v.Qp = c.take<float>((size_t)Bq * s.nq * s.d);
   v.Kp = c.take<float>((size_t)s.B * s.nk * s.d);
   v.Vp = c.take<float>((size_t)s.B * s.nk * s.d);
-  v.A = c.take<float>((size_t)s.B * s.h * s.nq * s.nk);
+  // (the fused attention core keeps the log-sum-exp [B][h][nq] here instead of the matrix A)
+  v.A = c.take<float>(attn_core_ok(s) ? (size_t)s.B * s.h * s.nq : (size_t)s.B * s.h * s.nq * s.nk);
   v.O = c.take<float>((size_t)s.B * s.nq * s.d);
   v.Z = c.take<float>((size_t)s.B * s.nq * s.d);
   v.O1 = v.Ypre = v.mean0 = v.rstd0 = v.mean1 = v.rstd1 = nullptr;
@@ -72,7 +73,7 @@ inline size_t bwd_ws_elems(const pca_mab_shape& s, BwdWsF32* out, void* base) {
   v.dZ = c.take<float>((size_t)s.B * s.nq * s.d);
   v.dO = c.take<float>((size_t)s.B * s.nq * s.d);
   v.dQp = c.take<float>((size_t)s.B * s.nq * s.d);
-  v.dA = c.take<float>((size_t)s.B * s.h * s.nq * s.nk);
+  v.dA = c.take<float>(attn_core_ok(s) ? (size_t)s.B * s.h * s.nq : (size_t)s.B * s.h * s.nq * s.nk);
   v.dKp = c.take<float>((size_t)s.B * s.nk * s.d);
   v.dVp = c.take<float>((size_t)s.B * s.nk * s.d);
   v.dQps = c.take<float>((size_t)s.nq * s.d);
@@ -163,6 +164,10 @@ int mab_f32_fwd(const pca_mab_shape& s, const float* Q, const float* K,
   PCA_TRY(linear(K, p.wk, p.bk, v.Kp, (int64_t)s.B * nk, s.dk, d, 0, st)); // :21
   PCA_TRY(linear(K, p.wv, p.bv, v.Vp, (int64_t)s.B * nk, s.dk, d, 0, st)); // :21
 
+  if (attn_core_ok(s)) {
+    // head dim <= 16 in the bf16-operand mode: scores, softmax and A V in one launch, A never exists
+    PCA_TRY(attn_core_fwd(s, v.Qp, v.Kp, v.Vp, v.O, v.A, st));             // :28-29
+  } else {
   {  // S[b,j] = Qp_j Kp_j^T  -> A buffer                                       :28
     pca_gemm_desc g = gd(nq, nk, dh, d, 1, 1, d, nk, 0);
     g.split_k = 1;
@@ -178,6 +183,7 @@ int mab_f32_fwd(const pca_mab_shape& s, const float* Q, const float* K,
     set_heads(g, s, (int64_t)h * nq * nk, (int64_t)nq * nk, (int64_t)nk * d, dh,
               (int64_t)nq * d, dh);
     PCA_TRY(gemm_sel(g, v.A, v.Vp, nullptr, v.O, st));
+  }
   }
   const int64_t Mq = (int64_t)s.B * nq;
   const float* Oe = v.O;
@@ -227,6 +233,11 @@ int mab_f32_bwd(const pca_mab_shape& s, const float* Q, const float* K,
   if (s.ln)     // in place: every element is read before it is rewritten
     PCA_TRY(layernorm_bwd(w.dO, v.O, v.mean0, v.rstd0, p.ln0_w, w.dO, g.ln0_w, g.ln0_b, Mq, d, st));
 
+  if (attn_core_ok(s)) {
+    // the adjoint of the fused core: P recomputed from the saved log-sum-exp, dQp (incl. the residual),
+    // dKp and dVp written once each (w.dA holds delta = rowdot(dO, A V))
+    PCA_TRY(attn_core_bwd(s, v.Qp, v.Kp, v.Vp, v.O, v.A, w.dO, w.dQp, w.dKp, w.dVp, w.dA, st));
+  } else {
   // attention: dV_j = A_j^T dO_j
   PCA_TRY(fill_zero(w.dVp, Mk * d, st));
   PCA_TRY(fill_zero(w.dKp, Mk * d, st));
@@ -256,6 +267,7 @@ int mab_f32_bwd(const pca_mab_shape& s, const float* Q, const float* K,
     pca_gemm_desc gg = gd(nk, dh, nq, 1, nk, d, 1, d, 1);
     set_heads(gg, s, (int64_t)h * nq * nk, (int64_t)nq * nk, qb, dh, (int64_t)nk * d, dh);
     PCA_TRY(gemm_sel(gg, w.dA, v.Qp, nullptr, w.dKp, st));
+  }
   }
 
   // fc_k / fc_v
