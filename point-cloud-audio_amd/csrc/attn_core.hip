@@ -43,25 +43,29 @@ struct AttnCoreArgs {
   float scale, c;              // 1 / sqrt(d), scale * log2(e)
 };
 
-// 4 consecutive fp32 features (f0 .. f0 + 3) of one row as a bf16 MFMA operand; zeros beyond the head dim
+// 4 consecutive fp32 features (f0 .. f0 + 3) of one row as a bf16 MFMA operand; zeros beyond the head dim.
+// The loads are UNCONDITIONAL (clamped address, value selected afterwards): under a divergent `if` every
+// load gets a basic block and an s_waitcnt vmcnt(0) of its own, and these helpers are
+// the kernels' whole memory traffic.
 __device__ __forceinline__ bf16x4 row4(const float* row, int f0, int dh) {
-  bf16x4 v = {(__bf16)0.f, (__bf16)0.f, (__bf16)0.f, (__bf16)0.f};
-  if (f0 < dh) {
-    const float4 x = *reinterpret_cast<const float4*>(row + f0);
-    v[0] = (__bf16)x.x; v[1] = (__bf16)x.y; v[2] = (__bf16)x.z; v[3] = (__bf16)x.w;
-  }
+  const bool on = f0 < dh;
+  const float4 x = *reinterpret_cast<const float4*>(row + (on ? f0 : 0));
+  bf16x4 v;
+  v[0] = (__bf16)(on ? x.x : 0.f); v[1] = (__bf16)(on ? x.y : 0.f);
+  v[2] = (__bf16)(on ? x.z : 0.f); v[3] = (__bf16)(on ? x.w : 0.f);
   return v;
 }
 // the transposed operand X^T[row = feature f][k = rows i0 .. i0 + 3 of X]: four strided scalars
 __device__ __forceinline__ bf16x4 col4(const float* base, int64_t i0, int64_t imax, int64_t stride, int f,
                                        int dh) {
-  bf16x4 v = {(__bf16)0.f, (__bf16)0.f, (__bf16)0.f, (__bf16)0.f};
-  if (f < dh) {
+  const bool on = f < dh;
+  const int fc = on ? f : 0;
+  bf16x4 v;
 #pragma unroll
-    for (int jj = 0; jj < 4; ++jj) {
-      const int64_t i = i0 + jj < imax ? i0 + jj : imax - 1;
-      v[jj] = (__bf16)base[i * stride + f];
-    }
+  for (int jj = 0; jj < 4; ++jj) {
+    const int64_t i = i0 + jj < imax ? i0 + jj : imax - 1;
+    const float x = base[i * stride + fc];
+    v[jj] = (__bf16)(on ? x : 0.f);
   }
   return v;
 }
@@ -80,32 +84,44 @@ __global__ __launch_bounds__(256) void k_attnc_fwd(const AttnCoreArgs a) {
   const float* Vb = a.Vp + (int64_t)b * nk * d + j * dh;
   float m = -INFINITY, l = 0.f;
   f32x4 acc = {0.f, 0.f, 0.f, 0.f};
-  for (int k0 = 0; k0 < len; k0 += 16) {
-    const int ki = k0 + r < nk ? k0 + r : nk - 1;
-    const bf16x4 ka = row4(Kb + (int64_t)ki * d, 4 * g, dh);
-    const bf16x4 va = col4(Vb, k0 + 4 * g, nk, d, r, dh);
-    const f32x4 z4 = {0.f, 0.f, 0.f, 0.f};
-    f32x4 s = mfma16(ka, qb4, z4);                    // [key 4 g + e][query r]
-    float mt = -INFINITY;
+  // four key tiles per trip, the operands of all four requested before the first is used: one tile per
+  // trip left every trip's load latency exposed (a wave of the few-queries blocks walks 65 tiles)
+  for (int kb0 = 0; kb0 < len; kb0 += 64) {
+    bf16x4 ka4[4], va4[4];
 #pragma unroll
-    for (int e = 0; e < 4; ++e) {
-      s[e] = k0 + 4 * g + e < len ? s[e] * a.c : -INFINITY;
-      mt = fmaxf(mt, s[e]);
+    for (int u = 0; u < 4; ++u) {
+      const int k0 = kb0 + 16 * u;
+      const int ki = k0 + r < nk ? k0 + r : nk - 1;
+      ka4[u] = row4(Kb + (int64_t)ki * d, 4 * g, dh);
+      va4[u] = col4(Vb, k0 + 4 * g, nk, d, r, dh);
     }
-    mt = wave16_max(mt);
-    const float mn = fmaxf(m, mt);                    // finite: the tile has at least one live key
-    const float alpha = exp2f(m - mn);
-    float ls = 0.f;
 #pragma unroll
-    for (int e = 0; e < 4; ++e) {
-      s[e] = exp2f(s[e] - mn);
-      ls += s[e];
+    for (int u = 0; u < 4; ++u) {
+      const int k0 = kb0 + 16 * u;
+      if (k0 >= len) break;
+      const f32x4 z4 = {0.f, 0.f, 0.f, 0.f};
+      f32x4 s = mfma16(ka4[u], qb4, z4);              // [key 4 g + e][query r]
+      float mt = -INFINITY;
+#pragma unroll
+      for (int e = 0; e < 4; ++e) {
+        s[e] = k0 + 4 * g + e < len ? s[e] * a.c : -INFINITY;
+        mt = __builtin_amdgcn_fmed3f(mt, s[e], INFINITY);
+      }
+      mt = wave16_max(mt);
+      const float mn = __builtin_amdgcn_fmed3f(m, mt, INFINITY);                 // finite: the tile has at least one live key
+      const float alpha = __builtin_amdgcn_exp2f(m - mn);
+      float ls = 0.f;
+#pragma unroll
+      for (int e = 0; e < 4; ++e) {
+        s[e] = __builtin_amdgcn_exp2f(s[e] - mn);
+        ls += s[e];
+      }
+      l = l * alpha + wave16_sum(ls);
+      m = mn;
+#pragma unroll
+      for (int e = 0; e < 4; ++e) acc[e] *= alpha;    // the accumulator's column is this lane's query
+      acc = mfma16(va4[u], pack4(s), acc);            // [feature 4 g + e][query r]
     }
-    l = l * alpha + wave16_sum(ls);
-    m = mn;
-#pragma unroll
-    for (int e = 0; e < 4; ++e) acc[e] *= alpha;      // the accumulator's column is this lane's query
-    acc = mfma16(va, pack4(s), acc);                  // [feature 4 g + e][query r]
   }
   if (q0 + r < nq) {
     if (4 * g < dh) {
@@ -143,21 +159,31 @@ __global__ __launch_bounds__(256) void k_attnc_bwd_q(const AttnCoreArgs a) {
   const float* Kb = a.Kp + (int64_t)b * nk * d + j * dh;
   const float* Vb = a.Vp + (int64_t)b * nk * d + j * dh;
   f32x4 acc = {0.f, 0.f, 0.f, 0.f};
-  for (int k0 = 0; k0 < len; k0 += 16) {
-    const int ki = k0 + r < nk ? k0 + r : nk - 1;
-    const bf16x4 ka = row4(Kb + (int64_t)ki * d, 4 * g, dh);
-    const bf16x4 vr = row4(Vb + (int64_t)ki * d, 4 * g, dh);
-    const bf16x4 kt = col4(Kb, k0 + 4 * g, nk, d, r, dh);
-    const f32x4 z4 = {0.f, 0.f, 0.f, 0.f};
-    const f32x4 s = mfma16(ka, qb4, z4);              // [key 4 g + e][query r]
-    const f32x4 dp = mfma16(vr, dob, z4);             // dP^T = V dO^T
-    f32x4 ds;
+  for (int kb0 = 0; kb0 < len; kb0 += 64) {          // (four key tiles per trip: see the forward)
+    bf16x4 ka4[4], vr4[4], kt4[4];
 #pragma unroll
-    for (int e = 0; e < 4; ++e) {
-      const float p = k0 + 4 * g + e < len ? exp2f(s[e] * a.c - lse) : 0.f;
-      ds[e] = p * (dp[e] - delta) * a.scale;
+    for (int u = 0; u < 4; ++u) {
+      const int k0 = kb0 + 16 * u;
+      const int ki = k0 + r < nk ? k0 + r : nk - 1;
+      ka4[u] = row4(Kb + (int64_t)ki * d, 4 * g, dh);
+      vr4[u] = row4(Vb + (int64_t)ki * d, 4 * g, dh);
+      kt4[u] = col4(Kb, k0 + 4 * g, nk, d, r, dh);
     }
-    acc = mfma16(kt, pack4(ds), acc);                 // dQ^T += K^T dS^T
+#pragma unroll
+    for (int u = 0; u < 4; ++u) {
+      const int k0 = kb0 + 16 * u;
+      if (k0 >= len) break;
+      const f32x4 z4 = {0.f, 0.f, 0.f, 0.f};
+      const f32x4 s = mfma16(ka4[u], qb4, z4);        // [key 4 g + e][query r]
+      const f32x4 dp = mfma16(vr4[u], dob, z4);       // dP^T = V dO^T
+      f32x4 ds;
+#pragma unroll
+      for (int e = 0; e < 4; ++e) {
+        const float p = k0 + 4 * g + e < len ? __builtin_amdgcn_exp2f(s[e] * a.c - lse) : 0.f;
+        ds[e] = p * (dp[e] - delta) * a.scale;
+      }
+      acc = mfma16(kt4[u], pack4(ds), acc);           // dQ^T += K^T dS^T
+    }
   }
   if (q0 + r < nq) {
     if (4 * g < dh)
@@ -185,31 +211,41 @@ __global__ __launch_bounds__(256) void k_attnc_bwd_kv(const AttnCoreArgs a) {
   const float* lseb = a.LSE + ((int64_t)b * gridDim.y + j) * nq;
   const float* delb = a.Delta + ((int64_t)b * gridDim.y + j) * nq;
   f32x4 dk = {0.f, 0.f, 0.f, 0.f}, dv = {0.f, 0.f, 0.f, 0.f};
-  for (int q0 = 0; q0 < nq; q0 += 16) {
-    const int qi = q0 + r < nq ? q0 + r : nq - 1;
-    const bf16x4 qa = row4(Qb + (int64_t)qi * d, 4 * g, dh);        // A operand [row = query r][k = feature]
-    const bf16x4 doa = row4(dOb + (int64_t)qi * d, 4 * g, dh);
-    const bf16x4 qt = col4(Qb, q0 + 4 * g, nq, d, r, dh);           // Q^T, dO^T: [row = feature][k = query]
-    const bf16x4 dot = col4(dOb, q0 + 4 * g, nq, d, r, dh);
-    float lse4[4], del4[4];
+  for (int qb0 = 0; qb0 < nq; qb0 += 32) {           // (two query tiles per trip, operands first)
+    bf16x4 qa2[2], doa2[2], qt2[2], dot2[2];
+    float lse8[2][4], del8[2][4];
 #pragma unroll
-    for (int e = 0; e < 4; ++e) {
-      const int qq = q0 + 4 * g + e < nq ? q0 + 4 * g + e : nq - 1;
-      lse4[e] = lseb[qq];
-      del4[e] = delb[qq];
-    }
-    const f32x4 z4 = {0.f, 0.f, 0.f, 0.f};
-    const f32x4 s = mfma16(qa, kb4, z4);              // [query 4 g + e][key r]
-    const f32x4 dp = mfma16(doa, vb4, z4);            // dP = dO V^T
-    f32x4 p, ds;
+    for (int u = 0; u < 2; ++u) {
+      const int q0 = qb0 + 16 * u;
+      const int qi = q0 + r < nq ? q0 + r : nq - 1;
+      qa2[u] = row4(Qb + (int64_t)qi * d, 4 * g, dh);     // A operand [row = query r][k = feature]
+      doa2[u] = row4(dOb + (int64_t)qi * d, 4 * g, dh);
+      qt2[u] = col4(Qb, q0 + 4 * g, nq, d, r, dh);        // Q^T, dO^T: [row = feature][k = query]
+      dot2[u] = col4(dOb, q0 + 4 * g, nq, d, r, dh);
 #pragma unroll
-    for (int e = 0; e < 4; ++e) {
-      const bool on = klive && q0 + 4 * g + e < nq;
-      p[e] = on ? exp2f(s[e] * a.c - lse4[e]) : 0.f;
-      ds[e] = p[e] * (dp[e] - del4[e]) * a.scale;
+      for (int e = 0; e < 4; ++e) {
+        const int qq = q0 + 4 * g + e < nq ? q0 + 4 * g + e : nq - 1;
+        lse8[u][e] = lseb[qq];
+        del8[u][e] = delb[qq];
+      }
     }
-    dv = mfma16(dot, pack4(p), dv);                   // dV^T += dO^T P     [feature 4 g + e][key r]
-    dk = mfma16(qt, pack4(ds), dk);                   // dK^T += Q^T dS
+#pragma unroll
+    for (int u = 0; u < 2; ++u) {
+      const int q0 = qb0 + 16 * u;
+      if (q0 >= nq) break;
+      const f32x4 z4 = {0.f, 0.f, 0.f, 0.f};
+      const f32x4 s = mfma16(qa2[u], kb4, z4);        // [query 4 g + e][key r]
+      const f32x4 dp = mfma16(doa2[u], vb4, z4);      // dP = dO V^T
+      f32x4 p, ds;
+#pragma unroll
+      for (int e = 0; e < 4; ++e) {
+        const bool on = klive && q0 + 4 * g + e < nq;
+        p[e] = on ? __builtin_amdgcn_exp2f(s[e] * a.c - lse8[u][e]) : 0.f;
+        ds[e] = p[e] * (dp[e] - del8[u][e]) * a.scale;
+      }
+      dv = mfma16(dot2[u], pack4(p), dv);             // dV^T += dO^T P     [feature 4 g + e][key r]
+      dk = mfma16(qt2[u], pack4(ds), dk);             // dK^T += Q^T dS
+    }
   }
   if (k0 + r < nk && 4 * g < dh) {
     const int64_t o = ((int64_t)b * nk + k0 + r) * d + j * dh + 4 * g;

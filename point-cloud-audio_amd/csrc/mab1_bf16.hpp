@@ -248,6 +248,11 @@ int attn_core_fwd(const pca_mab_shape& s, const float* Qp, const float* Kp, cons
 int attn_core_bwd(const pca_mab_shape& s, const float* Qp, const float* Kp, const float* Vp,
                   const float* O, const float* LSE, const float* dO, float* dQp, float* dKp, float* dVp,
                   float* Delta, hipStream_t st);
+// weight + bias gradient of a 64 -> 64 (or <= 4 -> 64) Linear over a tall activation in one launch
+// (wgrad64.hip)
+bool wgrad64_ok(const float* dY, const float* X, int64_t M, int din, int dout);
+int wgrad64(const float* dY, const float* X, float* dW, float* db, int64_t M, int din,
+            hipStream_t st);
 // exact fp32 path (mab_f32.hip)
 int validate_shape(const pca_mab_shape* s);
 size_t mab_f32_saved_bytes(const pca_mab_shape& s);

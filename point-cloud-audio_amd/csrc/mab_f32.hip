@@ -127,6 +127,15 @@ inline int linear_dw(const float* dY, const float* X, float* dW, int64_t M, int 
   return gemm_sel(g, dY, X, nullptr, dW, st);
 }
 
+// dW += dY^T X and db += colsum(dY): one launch that reads each operand once where the shape has
+// one (wgrad64.hip: 64 -> 64 layers in the bf16-operand chain), the GEMM and the column sum otherwise
+inline int linear_dw_db(const float* dY, const float* X, float* dW, float* db, int64_t M, int din,
+                        int dout, hipStream_t st) {
+  if (t_bf16_operands == 1 && wgrad64_ok(dY, X, M, din, dout)) return wgrad64(dY, X, dW, db, M, din, st);
+  PCA_TRY(linear_dw(dY, X, dW, M, din, dout, st));
+  return colsum(dY, M, dout, db, 1, st);
+}
+
 inline void set_heads(pca_gemm_desc& g, const pca_mab_shape& s, int64_t a_b, int64_t a_h,
                       int64_t b_b, int64_t b_h, int64_t c_b, int64_t c_h) {
   g.nb1 = s.B; g.nb2 = s.h;
@@ -226,8 +235,7 @@ int mab_f32_bwd(const pca_mab_shape& s, const float* Q, const float* K,
     Oe = v.O1;
   }
   PCA_TRY(relu_bwd(dYe, v.Z, w.dZ, Mq * d, st));
-  PCA_TRY(linear_dw(w.dZ, Oe, g.wo, Mq, d, d, st));
-  PCA_TRY(colsum(w.dZ, Mq, d, g.bo, 1, st));
+  PCA_TRY(linear_dw_db(w.dZ, Oe, g.wo, g.bo, Mq, d, d, st));
   PCA_TRY(copy_rows(dYe, Mq, w.dO, Mq, d, st));
   PCA_TRY(linear_dx(w.dZ, p.wo, w.dO, Mq, d, d, 1, st, w.Wt));
   if (s.ln)     // in place: every element is read before it is rewritten
@@ -271,10 +279,8 @@ int mab_f32_bwd(const pca_mab_shape& s, const float* Q, const float* K,
   }
 
   // fc_k / fc_v
-  PCA_TRY(linear_dw(w.dKp, K, g.wk, Mk, s.dk, d, st));
-  PCA_TRY(colsum(w.dKp, Mk, d, g.bk, 1, st));
-  PCA_TRY(linear_dw(w.dVp, K, g.wv, Mk, s.dk, d, st));
-  PCA_TRY(colsum(w.dVp, Mk, d, g.bv, 1, st));
+  PCA_TRY(linear_dw_db(w.dKp, K, g.wk, g.bk, Mk, s.dk, d, st));
+  PCA_TRY(linear_dw_db(w.dVp, K, g.wv, g.bv, Mk, s.dk, d, st));
   if (dK != nullptr) {
     PCA_TRY(linear_dx(w.dKp, p.wk, dK, Mk, s.dk, d, dk_accumulate ? 1 : 0, st, w.Wt));
     PCA_TRY(linear_dx(w.dVp, p.wv, dK, Mk, s.dk, d, 1, st, w.Wt));
@@ -287,8 +293,7 @@ int mab_f32_bwd(const pca_mab_shape& s, const float* Q, const float* K,
     PCA_TRY(colsum(w.dQps, nq, d, g.bq, 1, st));
     if (dQ != nullptr) PCA_TRY(linear_dx(w.dQps, p.wq, dQ, nq, s.dq, d, 1, st));
   } else {
-    PCA_TRY(linear_dw(w.dQp, Q, g.wq, Mq, s.dq, d, st));
-    PCA_TRY(colsum(w.dQp, Mq, d, g.bq, 1, st));
+    PCA_TRY(linear_dw_db(w.dQp, Q, g.wq, g.bq, Mq, s.dq, d, st));
     if (dQ != nullptr) PCA_TRY(linear_dx(w.dQp, p.wq, dQ, Mq, s.dq, d, 0, st, w.Wt));
   }
   return PCA_OK;
@@ -310,8 +315,12 @@ int linear_dx_acc_f32(const float* dY, const float* W, float* dX, int64_t M, int
 }
 int linear_bwd_f32(const float* X, const float* W, const float* dY, float* dX, float* dW,
                    float* db, int64_t M, int din, int dout, hipStream_t st) {
-  if (dW) PCA_TRY(linear_dw(dY, X, dW, M, din, dout, st));
-  if (db) PCA_TRY(colsum(dY, M, dout, db, 1, st));
+  if (dW && db) {
+    PCA_TRY(linear_dw_db(dY, X, dW, db, M, din, dout, st));
+  } else {
+    if (dW) PCA_TRY(linear_dw(dY, X, dW, M, din, dout, st));
+    if (db) PCA_TRY(colsum(dY, M, dout, db, 1, st));
+  }
   if (dX) PCA_TRY(linear_dx(dY, W, dX, M, din, dout, 0, st));
   return PCA_OK;
 }

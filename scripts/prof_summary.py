@@ -2,7 +2,7 @@ import csv, glob, re, sys
 tag = sys.argv[1]
 steps = int(sys.argv[2]) if len(sys.argv) > 2 else 106
 import os
-f = max(glob.glob(f'/root/repo/gpurun_out/prof_{tag}/*/*kernel_stats.csv'), key=os.path.getmtime)
+f = max(glob.glob(f'gpurun_out/prof_{tag}/*/*kernel_stats.csv'), key=os.path.getmtime)
 rows = list(csv.DictReader(open(f)))
 for r in rows[:int(sys.argv[3]) if len(sys.argv) > 3 else 24]:
     name = r['Name']
