@@ -50,25 +50,49 @@ struct AttnCoreArgs {
   float* LSE;                  // [B][h][nq]  log2 domain: m + log2(l)
   float* Delta;                // [B][h][nq]
   float *dQp, *dKp, *dVp;
+  float* part;                 // S > 1: per-split partial results (layouts at the kernels)
   const int32_t* lengths;
   int B, nq, nk, d, dh, h;
-  int gx;                      // workgroups per set
+  int nt, gt, S, cps;          // Plan of the launch
   int64_t qb;                  // batch stride of Qp (0: shared)
   float scale, c;              // 1 / sqrt(d), scale * log2(e)
 };
 
-constexpr int CH = 128;        // streamed rows per chunk: keys of k_attnc_fwd / k_attnc_bwd_q
-constexpr int CHQ = 64;        //                          queries of k_attnc_bwd_kv
+constexpr int CH = 64;         // streamed rows per chunk
 // bf16 elements of one staged chunk: row form has one spare row (the last head's upper lanes read on
 // into the next row), transposed form 16 spare feature rows
-__host__ __device__ constexpr int row_elems(int ch, int d) { return (ch + 1) * (d + 4); }
-__host__ __device__ constexpr int tr_elems(int ch, int d) { return (d + 16) * (ch + 4); }
+__host__ __device__ constexpr int row_elems(int d) { return (CH + 1) * (d + 4); }
+__host__ __device__ constexpr int tr_elems(int d) { return (d + 16) * (CH + 4); }
 
-// workgroup id -> (set, index within the set): see the header
-__device__ __forceinline__ void wg_coords(int gx, int& b, int& x) {
-  const int id = blockIdx.x, slot = id >> 3;
-  x = slot % gx;
+// How a launch is cut.  The side that stays in registers (queries; keys in k_attnc_bwd_kv) has nt tiles of
+// 16 rows; gt workgroups per set share them (workgroup xt takes tiles xt, xt + gt, ...).  Where that alone
+// leaves the chip short of workgroups - few tiles and few sets: nq = 64 or 1 at B = 16 - the streamed
+// side is cut as well, into S ranges of cps chunks whose partial results a small second kernel merges.
+struct Plan { int nt, gt, S, cps; };
+inline Plan plan_of(int B, int reg_rows, int str_rows) {
+  Plan p;
+  p.nt = (int)cdiv(reg_rows, 16);
+  const int nch = (int)cdiv(str_rows, CH);
+  const int want = (int)cdiv(512, B);                 // workgroups per set for two per CU
+  p.gt = p.nt < want ? p.nt : want;
+  int S = 1;
+  if (2 * p.gt <= want && nch >= 4) {
+    S = want / p.gt;
+    if (S > nch / 2) S = nch / 2;                     // >= 2 chunks per range
+  }
+  p.cps = (int)cdiv(nch, S);
+  p.S = (int)cdiv(nch, p.cps);                        // no empty range
+  return p;
+}
+
+// workgroup id -> set b, tile slot xt, range sp: sets b and b + 8 k sit on the same XCD (id mod 8), the
+// workgroups of one set in consecutive slots of it
+__device__ __forceinline__ void wg_coords(const AttnCoreArgs& a, int& b, int& xt, int& sp) {
+  const int id = blockIdx.x, slot = id >> 3, gx = a.gt * a.S;
+  const int x = slot % gx;
   b = (slot / gx) * 8 + (id & 7);
+  xt = x % a.gt;
+  sp = x / a.gt;
 }
 
 // 4 consecutive fp32 features (f0 .. f0 + 3) of one row as a bf16 MFMA operand; zeros beyond the head dim
@@ -82,41 +106,71 @@ __device__ __forceinline__ bf16x4 row4(const float* row, int f0, int dh) {
   return v;
 }
 
-// rows r0 .. r0 + CHN - 1 of X[nrows][d] (fp32) -> bf16 in LDS, all heads at once; rows >= nrows are zeros
-template <int CHN, bool ROW, bool TR>
-__device__ __forceinline__ void stage(const float* __restrict__ X, int nrows, int r0, int d,
-                                      __bf16* __restrict__ Rw, __bf16* __restrict__ Tr, int tid,
-                                      int nthr) {
-  const int cg = d >> 2;
-  for (int i = tid; i < (CHN / 4) * cg; i += nthr) {
-    const int q = i / cg, c4 = i - q * cg;
-    float4 v[4];
+// Staging of a chunk, all heads at once: thread -> rows 4 q .. 4 q + 3, features 4 c4 .. 4 c4 + 3 of
+// X[nrows][d] (CH / 4 x d / 4 items <= the workgroup's 64 h threads because d / h <= 16); rows >= nrows
+// are zeros.  Synchronous - the other workgroups of the CU (four fit) cover the loads: holding the next
+// chunk in registers under the products was tried and costs more than it hides (32 VGPRs per operand
+// take the kernels to the 128-register cap, two workgroups per CU, and hipcc copies parts of the loaded
+// quads right behind the loads, i.e. waits for them where they were issued).
+struct StageId {
+  int q, c4;
+  unsigned off;                                        // (4 q) d + 4 c4: the item's first float in a chunk
+  bool act;
+};
+__device__ __forceinline__ StageId stage_id(int d, int tid) {
+  const int cg = d >> 2, total = (CH / 4) * cg;
+  const int i = tid < total ? tid : total - 1;
+  StageId s;
+  s.q = i / cg; s.c4 = i - s.q * cg; s.act = tid < total;
+  s.off = (unsigned)(4 * s.q * d + 4 * s.c4);
+  return s;
+}
+struct Staged { float4 v[4]; };
+// X: the set's [nrows][d] array (a uniform pointer: the loads take it as their scalar base)
+__device__ __forceinline__ Staged stage_load(const float* __restrict__ X, int nrows, int r0, int d,
+                                             const StageId& id) {
+  Staged s;
+  if (id.act) {
+    if (r0 + CH <= nrows) {                            // (uniform) the whole chunk exists
+      const float* p = X + (size_t)r0 * d;
 #pragma unroll
-    for (int e = 0; e < 4; ++e) {
-      const int row = r0 + 4 * q + e;
-      const int rc = row < nrows ? row : nrows - 1;
-      v[e] = *reinterpret_cast<const float4*>(X + (int64_t)rc * d + 4 * c4);
-      if (row >= nrows) v[e] = make_float4(0.f, 0.f, 0.f, 0.f);
-    }
-    if constexpr (ROW) {
+      for (int e = 0; e < 4; ++e) s.v[e] = *reinterpret_cast<const float4*>(p + (id.off + e * d));
+    } else {
 #pragma unroll
       for (int e = 0; e < 4; ++e) {
-        bf16x4 t;
-        t[0] = (__bf16)v[e].x; t[1] = (__bf16)v[e].y; t[2] = (__bf16)v[e].z; t[3] = (__bf16)v[e].w;
-        *reinterpret_cast<bf16x4*>(Rw + (4 * q + e) * (d + 4) + 4 * c4) = t;
+        const int row = r0 + 4 * id.q + e;
+        const int rc = row < nrows ? row : nrows - 1;
+        s.v[e] = *reinterpret_cast<const float4*>(X + (size_t)rc * d + 4 * id.c4);
       }
     }
-    if constexpr (TR) {
-      bf16x4 t0, t1, t2, t3;
-      t0[0] = (__bf16)v[0].x; t0[1] = (__bf16)v[1].x; t0[2] = (__bf16)v[2].x; t0[3] = (__bf16)v[3].x;
-      t1[0] = (__bf16)v[0].y; t1[1] = (__bf16)v[1].y; t1[2] = (__bf16)v[2].y; t1[3] = (__bf16)v[3].y;
-      t2[0] = (__bf16)v[0].z; t2[1] = (__bf16)v[1].z; t2[2] = (__bf16)v[2].z; t2[3] = (__bf16)v[3].z;
-      t3[0] = (__bf16)v[0].w; t3[1] = (__bf16)v[1].w; t3[2] = (__bf16)v[2].w; t3[3] = (__bf16)v[3].w;
-      __bf16* dst = Tr + (4 * c4) * (CHN + 4) + 4 * q;
-      *reinterpret_cast<bf16x4*>(dst) = t0;
-      *reinterpret_cast<bf16x4*>(dst + (CHN + 4)) = t1;
-      *reinterpret_cast<bf16x4*>(dst + 2 * (CHN + 4)) = t2;
-      *reinterpret_cast<bf16x4*>(dst + 3 * (CHN + 4)) = t3;
+  }
+  return s;                                            // (rows past the end are zeroed at stage_store: a
+}                                                      //  select here would wait for the loads at once)
+template <bool ROW, bool TR>
+__device__ __forceinline__ void stage_store(const Staged& s, int nrows, int r0, int d, const StageId& id,
+                                            __bf16* __restrict__ Rw, __bf16* __restrict__ Tr) {
+  if (!id.act) return;
+  f32x4 v[4];
+#pragma unroll
+  for (int e = 0; e < 4; ++e) v[e] = f32x4{s.v[e].x, s.v[e].y, s.v[e].z, s.v[e].w};
+  if (r0 + CH > nrows) {                               // (uniform) the ragged last chunk
+    const int live = nrows - (r0 + 4 * id.q);
+#pragma unroll
+    for (int e = 0; e < 4; ++e)
+      if (e >= live) v[e] = f32x4{0.f, 0.f, 0.f, 0.f};
+  }
+  if constexpr (ROW) {
+#pragma unroll
+    for (int e = 0; e < 4; ++e)
+      *reinterpret_cast<bf16x4*>(Rw + (4 * id.q + e) * (d + 4) + 4 * id.c4) =
+          __builtin_convertvector(v[e], bf16x4);
+  }
+  if constexpr (TR) {
+    __bf16* dst = Tr + (4 * id.c4) * (CH + 4) + 4 * id.q;
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+      const f32x4 t = {v[0][i], v[1][i], v[2][i], v[3][i]};
+      *reinterpret_cast<bf16x4*>(dst + i * (CH + 4)) = __builtin_convertvector(t, bf16x4);
     }
   }
 }
@@ -165,290 +219,323 @@ __device__ __forceinline__ void fwd_keys64(const bf16x4 (&ka)[4], const bf16x4 (
   for (int u = 0; u < 4; ++u) acc = mfma16(va[u], pack4(s[u]), acc);   // [feature 4 g + e][query r]
 }
 
-template <int QT>
-__global__ __launch_bounds__(1024) void k_attnc_fwd(const AttnCoreArgs a) {
+// S > 1: part = { ml [B][S][h][nq][2] , acc [B][S][nq][d] } (unnormalised), merged by k_attnc_fwd_merge
+template <int NW>   // waves (= heads) the launch may have
+__global__ __launch_bounds__(64 * NW, 4) void k_attnc_fwd(const AttnCoreArgs a) {
   extern __shared__ __attribute__((aligned(16))) __bf16 lds[];
   const int tid = threadIdx.x, lane = tid & 63, j = tid >> 6, r = lane & 15, g = lane >> 4;
   const int nthr = blockDim.x, d = a.d, dh = a.dh, nq = a.nq, nk = a.nk;
-  int b, x;
-  wg_coords(a.gx, b, x);
+  int b, xt, sp;
+  wg_coords(a, b, xt, sp);
   if (b >= a.B) return;
   __bf16* Krow = lds;
-  __bf16* Vtr = lds + row_elems(CH, d);
-  lds_clear(lds, row_elems(CH, d) + tr_elems(CH, d), tid, nthr);
+  __bf16* Vtr = lds + row_elems(d);
+  lds_clear(lds, row_elems(d) + tr_elems(d), tid, nthr);
   int len = nk;
   if (a.lengths != nullptr) len = a.lengths[b] < nk ? a.lengths[b] : nk;
-  const int t0 = x * QT;                               // first query tile
-  bf16x4 qb4[QT];
-  float m[QT], l[QT];
-  f32x4 acc[QT];
-#pragma unroll
-  for (int t = 0; t < QT; ++t) {
-    const int q0 = (t0 + t) * 16;
-    const int qi = q0 + r < nq ? q0 + r : nq - 1;
-    qb4[t] = row4(a.Qp + (int64_t)b * a.qb + (int64_t)qi * d + j * dh, 4 * g, dh);
-    m[t] = -INFINITY; l[t] = 0.f;
-    acc[t] = f32x4{0.f, 0.f, 0.f, 0.f};
-  }
+  const int nlive = (len + CH - 1) / CH;               // chunks that hold live keys
+  const int cb = sp * a.cps, ce = cb + a.cps < nlive ? cb + a.cps : nlive;
+  const bool single = ce - cb == 1;                    // one chunk: staged once for all the tiles
+  const StageId id = stage_id(d, tid);
   const float* Kb = a.Kp + (int64_t)b * nk * d;
   const float* Vb = a.Vp + (int64_t)b * nk * d;
-  for (int c0 = 0; c0 < len; c0 += CH) {
-    __syncthreads();                                   // the previous chunk is consumed (first: cleared)
-    stage<CH, true, false>(Kb, nk, c0, d, Krow, nullptr, tid, nthr);
-    stage<CH, false, true>(Vb, nk, c0, d, nullptr, Vtr, tid, nthr);
-    __syncthreads();
-    const int cn = len - c0 < CH ? len - c0 : CH;
-    for (int k0 = 0; k0 < cn; k0 += 64) {
+  bool staged = false;
+  for (int t = xt; t < a.nt; t += a.gt) {
+    const int q0 = t * 16;
+    const int qi = q0 + r < nq ? q0 + r : nq - 1;
+    const float* qrow = a.Qp + (int64_t)b * a.qb + (int64_t)qi * d + j * dh;
+    const bf16x4 qb4 = row4(qrow, 4 * g, dh);
+    float m = -INFINITY, l = 0.f;
+    f32x4 acc = {0.f, 0.f, 0.f, 0.f};
+    const bool fill = !(single && staged);
+    for (int c = cb; c < ce; ++c) {
+      if (fill) {
+        __syncthreads();                               // the previous chunk is consumed (first: cleared)
+        const Staged kr = stage_load(Kb, nk, c * CH, d, id);
+        const Staged vr = stage_load(Vb, nk, c * CH, d, id);
+        stage_store<true, false>(kr, nk, c * CH, d, id, Krow, nullptr);
+        stage_store<false, true>(vr, nk, c * CH, d, id, nullptr, Vtr);
+        __syncthreads();
+      }
       bf16x4 ka[4], va[4];
 #pragma unroll
       for (int u = 0; u < 4; ++u) {
-        ka[u] = *reinterpret_cast<const bf16x4*>(Krow + (k0 + 16 * u + r) * (d + 4) + j * dh + 4 * g);
-        va[u] = *reinterpret_cast<const bf16x4*>(Vtr + (j * dh + r) * (CH + 4) + k0 + 16 * u + 4 * g);
+        ka[u] = *reinterpret_cast<const bf16x4*>(Krow + (16 * u + r) * (d + 4) + j * dh + 4 * g);
+        va[u] = *reinterpret_cast<const bf16x4*>(Vtr + (j * dh + r) * (CH + 4) + 16 * u + 4 * g);
       }
-      const bool full = k0 + 64 <= cn;
-#pragma unroll
-      for (int t = 0; t < QT; ++t) {
-        if ((t0 + t) * 16 >= nq) break;
-        if (full) fwd_keys64<false>(ka, va, qb4[t], a.c, 64, g, m[t], l[t], acc[t]);
-        else      fwd_keys64<true>(ka, va, qb4[t], a.c, cn - k0, g, m[t], l[t], acc[t]);
-      }
+      if ((c + 1) * CH <= len) fwd_keys64<false>(ka, va, qb4, a.c, 64, g, m, l, acc);
+      else                     fwd_keys64<true>(ka, va, qb4, a.c, len - c * CH, g, m, l, acc);
     }
-  }
-#pragma unroll
-  for (int t = 0; t < QT; ++t) {
-    const int q0 = (t0 + t) * 16;
-    if (q0 >= nq) break;
-    const float lt = wave16_sum(l[t]);
+    staged = true;
+    const float lt = wave16_sum(l);
     if (q0 + r < nq) {
-      if (4 * g < dh) {
-        const float4 q4 = *reinterpret_cast<const float4*>(a.Qp + (int64_t)b * a.qb +
-                                                           (int64_t)(q0 + r) * d + j * dh + 4 * g);
-        const float inv = 1.f / lt;
-        *reinterpret_cast<float4*>(a.Oout + ((int64_t)b * nq + q0 + r) * d + j * dh + 4 * g) =
-            float4{q4.x + acc[t][0] * inv, q4.y + acc[t][1] * inv, q4.z + acc[t][2] * inv,
-                   q4.w + acc[t][3] * inv};
+      if (a.S == 1) {
+        if (4 * g < dh) {
+          const float4 q4 = *reinterpret_cast<const float4*>(qrow + 4 * g);
+          const float inv = 1.f / lt;
+          *reinterpret_cast<float4*>(a.Oout + ((int64_t)b * nq + q0 + r) * d + j * dh + 4 * g) =
+              float4{q4.x + acc[0] * inv, q4.y + acc[1] * inv, q4.z + acc[2] * inv, q4.w + acc[3] * inv};
+        }
+        if (g == 0) a.LSE[((int64_t)b * a.h + j) * nq + q0 + r] = m + log2f(lt);
+      } else {
+        float* ml = a.part;
+        float* pa = a.part + (int64_t)a.B * a.S * a.h * nq * 2;
+        const int64_t bs = (int64_t)b * a.S + sp;
+        if (4 * g < dh)
+          *reinterpret_cast<float4*>(pa + (bs * nq + q0 + r) * d + j * dh + 4 * g) =
+              float4{acc[0], acc[1], acc[2], acc[3]};
+        if (g == 0)
+          *reinterpret_cast<float2*>(ml + ((bs * a.h + j) * nq + q0 + r) * 2) = float2{m, lt};
       }
-      if (g == 0) a.LSE[((int64_t)b * a.h + j) * nq + q0 + r] = m[t] + log2f(lt);
     }
   }
 }
 
-template <int QT>
-__global__ __launch_bounds__(1024) void k_attnc_bwd_q(const AttnCoreArgs a) {
+// one thread per (set, query, head, 4 features): O = Q_ + sum_s 2^(m_s - M) acc_s / L, LSE = M + log2 L
+__global__ __launch_bounds__(256) void k_attnc_fwd_merge(const AttnCoreArgs a) {
+  const int f4 = a.dh >> 2;
+  const int64_t n = (int64_t)a.B * a.nq * a.h * f4;
+  const int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x;
+  if (i >= n) return;
+  const int g = (int)(i % f4), j = (int)((i / f4) % a.h);
+  const int q = (int)((i / ((int64_t)f4 * a.h)) % a.nq), b = (int)(i / ((int64_t)f4 * a.h * a.nq));
+  const float* ml = a.part;
+  const float* pa = a.part + (int64_t)a.B * a.S * a.h * a.nq * 2;
+  float M = -INFINITY;
+  for (int s = 0; s < a.S; ++s)
+    M = fmaxf(M, ml[((((int64_t)b * a.S + s) * a.h + j) * a.nq + q) * 2]);
+  float L = 0.f;
+  float4 acc = {0.f, 0.f, 0.f, 0.f};
+  for (int s = 0; s < a.S; ++s) {
+    const int64_t bs = (int64_t)b * a.S + s;
+    const float2 v = *reinterpret_cast<const float2*>(ml + ((bs * a.h + j) * a.nq + q) * 2);
+    const float w = __builtin_amdgcn_exp2f(v.x - M);   // a range without live keys: 2^(-inf) = 0
+    const float4 p = *reinterpret_cast<const float4*>(pa + (bs * a.nq + q) * a.d + j * a.dh + 4 * g);
+    L = fmaf(v.y, w, L);
+    acc.x = fmaf(p.x, w, acc.x); acc.y = fmaf(p.y, w, acc.y);
+    acc.z = fmaf(p.z, w, acc.z); acc.w = fmaf(p.w, w, acc.w);
+  }
+  const float4 q4 = *reinterpret_cast<const float4*>(a.Qp + (int64_t)b * a.qb + (int64_t)q * a.d +
+                                                     j * a.dh + 4 * g);
+  const float inv = 1.f / L;
+  *reinterpret_cast<float4*>(a.Oout + ((int64_t)b * a.nq + q) * a.d + j * a.dh + 4 * g) =
+      float4{q4.x + acc.x * inv, q4.y + acc.y * inv, q4.z + acc.z * inv, q4.w + acc.w * inv};
+  if (g == 0) a.LSE[((int64_t)b * a.h + j) * a.nq + q] = M + log2f(L);
+}
+
+// dst[b][row][:] = (res ? res[b][row][:] : 0) + sum_s part[b][s][row][:]      (rows x d floats per set)
+__global__ __launch_bounds__(256) void k_attnc_sum(float* __restrict__ dst, const float* __restrict__ res,
+                                                   const float* __restrict__ part, int B, int S,
+                                                   int64_t per_set4) {
+  const int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x;
+  if (i >= (int64_t)B * per_set4) return;
+  const int64_t b = i / per_set4, o = i - b * per_set4;
+  float4 v = res != nullptr ? reinterpret_cast<const float4*>(res)[i] : make_float4(0.f, 0.f, 0.f, 0.f);
+  for (int s = 0; s < S; ++s) {
+    const float4 p = reinterpret_cast<const float4*>(part)[(b * S + s) * per_set4 + o];
+    v.x += p.x; v.y += p.y; v.z += p.z; v.w += p.w;
+  }
+  reinterpret_cast<float4*>(dst)[i] = v;
+}
+
+// S > 1: part = dQ partials [B][S][nq][d] (without the residual), summed onto dO by k_attnc_sum
+template <int NW>   // waves (= heads) the launch may have
+__global__ __launch_bounds__(64 * NW, 4) void k_attnc_bwd_q(const AttnCoreArgs a) {
   extern __shared__ __attribute__((aligned(16))) __bf16 lds[];
   const int tid = threadIdx.x, lane = tid & 63, j = tid >> 6, r = lane & 15, g = lane >> 4;
   const int nthr = blockDim.x, d = a.d, dh = a.dh, nq = a.nq, nk = a.nk;
-  int b, x;
-  wg_coords(a.gx, b, x);
+  int b, xt, sp;
+  wg_coords(a, b, xt, sp);
   if (b >= a.B) return;
   __bf16* Krow = lds;
-  __bf16* Vrow = Krow + row_elems(CH, d);
-  __bf16* Ktr = Vrow + row_elems(CH, d);
-  lds_clear(lds, 2 * row_elems(CH, d) + tr_elems(CH, d), tid, nthr);
+  __bf16* Vrow = Krow + row_elems(d);
+  __bf16* Ktr = Vrow + row_elems(d);
+  lds_clear(lds, 2 * row_elems(d) + tr_elems(d), tid, nthr);
   int len = nk;
   if (a.lengths != nullptr) len = a.lengths[b] < nk ? a.lengths[b] : nk;
-  const int t0 = x * QT;
-  bf16x4 qb4[QT], dob[QT];
-  float nlse[QT], nds[QT], delta[QT];
-  float4 do4[QT];
-  f32x4 acc[QT];
-#pragma unroll
-  for (int t = 0; t < QT; ++t) {
-    const int q0 = (t0 + t) * 16;
-    const int qi = q0 + r < nq ? q0 + r : nq - 1;
-    const float* qrow = a.Qp + (int64_t)b * a.qb + (int64_t)qi * d + j * dh;
-    const int64_t orow = ((int64_t)b * nq + qi) * d + j * dh;
-    qb4[t] = row4(qrow, 4 * g, dh);
-    dob[t] = row4(a.dO + orow, 4 * g, dh);
-    nlse[t] = -a.LSE[((int64_t)b * a.h + j) * nq + qi];
-    const int fo = 4 * g < dh ? 4 * g : 0;
-    do4[t] = *reinterpret_cast<const float4*>(a.dO + orow + fo);
-    const float4 o4 = *reinterpret_cast<const float4*>(a.O + orow + fo);
-    const float4 q4 = *reinterpret_cast<const float4*>(qrow + fo);
-    float dl = do4[t].x * (o4.x - q4.x) + do4[t].y * (o4.y - q4.y) + do4[t].z * (o4.z - q4.z) +
-               do4[t].w * (o4.w - q4.w);
-    if (4 * g >= dh) dl = 0.f;
-    delta[t] = wave16_sum(dl);                         // rowdot(dO_j, A V_j) of query r
-    nds[t] = -delta[t] * a.scale;
-    acc[t] = f32x4{0.f, 0.f, 0.f, 0.f};
-  }
+  const int nlive = (len + CH - 1) / CH;
+  const int cb = sp * a.cps, ce = cb + a.cps < nlive ? cb + a.cps : nlive;
+  const bool single = ce - cb == 1;
+  const StageId id = stage_id(d, tid);
   const float* Kb = a.Kp + (int64_t)b * nk * d;
   const float* Vb = a.Vp + (int64_t)b * nk * d;
   const f32x4 z4 = {0.f, 0.f, 0.f, 0.f};
-  for (int c0 = 0; c0 < len; c0 += CH) {
-    __syncthreads();
-    stage<CH, true, true>(Kb, nk, c0, d, Krow, Ktr, tid, nthr);
-    stage<CH, true, false>(Vb, nk, c0, d, Vrow, nullptr, tid, nthr);
-    __syncthreads();
-    const int cn = len - c0 < CH ? len - c0 : CH;
-    for (int k0 = 0; k0 < cn; k0 += 32) {
-      bf16x4 ka[2], vr[2], kt[2];
-#pragma unroll
-      for (int u = 0; u < 2; ++u) {
-        const int ro = (k0 + 16 * u + r) * (d + 4) + j * dh + 4 * g;
-        ka[u] = *reinterpret_cast<const bf16x4*>(Krow + ro);
-        vr[u] = *reinterpret_cast<const bf16x4*>(Vrow + ro);
-        kt[u] = *reinterpret_cast<const bf16x4*>(Ktr + (j * dh + r) * (CH + 4) + k0 + 16 * u + 4 * g);
+  bool staged = false;
+  for (int t = xt; t < a.nt; t += a.gt) {
+    const int q0 = t * 16;
+    const int qi = q0 + r < nq ? q0 + r : nq - 1;
+    const float* qrow = a.Qp + (int64_t)b * a.qb + (int64_t)qi * d + j * dh;
+    const int64_t orow = ((int64_t)b * nq + qi) * d + j * dh;
+    const bf16x4 qb4 = row4(qrow, 4 * g, dh);
+    const bf16x4 dob = row4(a.dO + orow, 4 * g, dh);
+    const float nlse = -a.LSE[((int64_t)b * a.h + j) * nq + qi];
+    const int fo = 4 * g < dh ? 4 * g : 0;
+    const float4 do4 = *reinterpret_cast<const float4*>(a.dO + orow + fo);
+    const float4 o4 = *reinterpret_cast<const float4*>(a.O + orow + fo);
+    const float4 q4 = *reinterpret_cast<const float4*>(qrow + fo);
+    float dl = do4.x * (o4.x - q4.x) + do4.y * (o4.y - q4.y) + do4.z * (o4.z - q4.z) +
+               do4.w * (o4.w - q4.w);
+    if (4 * g >= dh) dl = 0.f;
+    const float delta = wave16_sum(dl);                // rowdot(dO_j, A V_j) of query r
+    const float nds = -delta * a.scale;
+    f32x4 acc = {0.f, 0.f, 0.f, 0.f};
+    const bool fill = !(single && staged);
+    for (int c = cb; c < ce; ++c) {
+      if (fill) {
+        __syncthreads();
+        const Staged kr = stage_load(Kb, nk, c * CH, d, id);
+        const Staged vr = stage_load(Vb, nk, c * CH, d, id);
+        stage_store<true, true>(kr, nk, c * CH, d, id, Krow, Ktr);
+        stage_store<true, false>(vr, nk, c * CH, d, id, Vrow, nullptr);
+        __syncthreads();
       }
-      const bool full = k0 + 32 <= cn;
+      const int klim = len - c * CH;                   // live keys of the chunk (may exceed 64)
 #pragma unroll
-      for (int t = 0; t < QT; ++t) {
-        if ((t0 + t) * 16 >= nq) break;
+      for (int u = 0; u < 4; ++u) {
+        if (16 * u >= klim) break;
+        const int ro = (16 * u + r) * (d + 4) + j * dh + 4 * g;
+        const bf16x4 ka = *reinterpret_cast<const bf16x4*>(Krow + ro);
+        const bf16x4 vv = *reinterpret_cast<const bf16x4*>(Vrow + ro);
+        const bf16x4 kt = *reinterpret_cast<const bf16x4*>(Ktr + (j * dh + r) * (CH + 4) + 16 * u + 4 * g);
+        const f32x4 s = mfma16(ka, qb4, z4);            // [key 4 g + e][query r]
+        const f32x4 dp = mfma16(vv, dob, z4);           // dP^T = V dO^T
+        f32x4 ds;
 #pragma unroll
-        for (int u = 0; u < 2; ++u) {
-          const f32x4 s = mfma16(ka[u], qb4[t], z4);    // [key 4 g + e][query r]
-          const f32x4 dp = mfma16(vr[u], dob[t], z4);   // dP^T = V dO^T
-          f32x4 ds;
-#pragma unroll
-          for (int e = 0; e < 4; ++e) {
-            float pe = __builtin_amdgcn_exp2f(fmaf(s[e], a.c, nlse[t]));
-            if (!full && k0 + 16 * u + 4 * g + e >= cn) pe = 0.f;
-            ds[e] = pe * fmaf(dp[e], a.scale, nds[t]);
-          }
-          acc[t] = mfma16(kt[u], pack4(ds), acc[t]);    // dQ^T += K^T dS^T
+        for (int e = 0; e < 4; ++e) {
+          float pe = __builtin_amdgcn_exp2f(fmaf(s[e], a.c, nlse));
+          if (16 * u + 16 > klim) pe = 16 * u + 4 * g + e < klim ? pe : 0.f;
+          ds[e] = pe * fmaf(dp[e], a.scale, nds);
         }
+        acc = mfma16(kt, pack4(ds), acc);               // dQ^T += K^T dS^T
       }
     }
-  }
-#pragma unroll
-  for (int t = 0; t < QT; ++t) {
-    const int q0 = (t0 + t) * 16;
-    if (q0 >= nq) break;
+    staged = true;
     if (q0 + r < nq) {
-      if (4 * g < dh)
-        *reinterpret_cast<float4*>(a.dQp + ((int64_t)b * nq + q0 + r) * d + j * dh + 4 * g) =
-            float4{do4[t].x + acc[t][0], do4[t].y + acc[t][1], do4[t].z + acc[t][2],
-                   do4[t].w + acc[t][3]};                                   // + the residual Q_
-      if (g == 0) a.Delta[((int64_t)b * a.h + j) * nq + q0 + r] = delta[t];
+      if (4 * g < dh) {
+        if (a.S == 1)
+          *reinterpret_cast<float4*>(a.dQp + ((int64_t)b * nq + q0 + r) * d + j * dh + 4 * g) =
+              float4{do4.x + acc[0], do4.y + acc[1], do4.z + acc[2], do4.w + acc[3]};  // + the residual Q_
+        else
+          *reinterpret_cast<float4*>(a.part + (((int64_t)b * a.S + sp) * nq + q0 + r) * d + j * dh +
+                                     4 * g) = float4{acc[0], acc[1], acc[2], acc[3]};
+      }
+      if (g == 0 && sp == 0) a.Delta[((int64_t)b * a.h + j) * nq + q0 + r] = delta;
     }
   }
 }
 
-template <int KT>
-__global__ __launch_bounds__(1024) void k_attnc_bwd_kv(const AttnCoreArgs a) {
+// S > 1: part = { dK partials [B][S][nk][d], dV partials [B][S][nk][d] }, summed by k_attnc_sum
+template <int NW>   // waves (= heads) the launch may have
+__global__ __launch_bounds__(64 * NW, 4) void k_attnc_bwd_kv(const AttnCoreArgs a) {
   extern __shared__ __attribute__((aligned(16))) __bf16 lds[];
   const int tid = threadIdx.x, lane = tid & 63, j = tid >> 6, r = lane & 15, g = lane >> 4;
   const int nthr = blockDim.x, d = a.d, dh = a.dh, nq = a.nq, nk = a.nk, h = a.h;
-  int b, x;
-  wg_coords(a.gx, b, x);
+  int b, xt, sp;
+  wg_coords(a, b, xt, sp);
   if (b >= a.B) return;
   __bf16* Qrow = lds;
-  __bf16* Drow = Qrow + row_elems(CHQ, d);
-  __bf16* Qtr = Drow + row_elems(CHQ, d);
-  __bf16* Dtr = Qtr + tr_elems(CHQ, d);
-  const int nb16 = 2 * row_elems(CHQ, d) + 2 * tr_elems(CHQ, d);
-  float* lseS = reinterpret_cast<float*>(lds + ((nb16 + 7) & ~7));   // [h][CHQ] each
-  float* delS = lseS + h * CHQ;
+  __bf16* Drow = Qrow + row_elems(d);
+  __bf16* Qtr = Drow + row_elems(d);
+  __bf16* Dtr = Qtr + tr_elems(d);
+  const int nb16 = 2 * row_elems(d) + 2 * tr_elems(d);
+  float* lseS = reinterpret_cast<float*>(lds + ((nb16 + 7) & ~7));   // [h][CH] each; one entry per thread
+  float* delS = lseS + h * CH;
   lds_clear(lds, nb16, tid, nthr);
   int len = nk;
   if (a.lengths != nullptr) len = a.lengths[b] < nk ? a.lengths[b] : nk;
-  const int t0 = x * KT;                               // first key tile
-  bf16x4 kb4[KT], vb4[KT];
-  f32x4 dk[KT], dv[KT];
-  const float* Kb = a.Kp + (int64_t)b * nk * d + j * dh;
-  const float* Vb = a.Vp + (int64_t)b * nk * d + j * dh;
-#pragma unroll
-  for (int t = 0; t < KT; ++t) {
-    const int k0 = (t0 + t) * 16;
-    const int ki = k0 + r < nk ? k0 + r : nk - 1;
-    kb4[t] = row4(Kb + (int64_t)ki * d, 4 * g, dh);    // B operand [k = feature][col = key r]
-    vb4[t] = row4(Vb + (int64_t)ki * d, 4 * g, dh);
-    dk[t] = f32x4{0.f, 0.f, 0.f, 0.f};
-    dv[t] = f32x4{0.f, 0.f, 0.f, 0.f};
-  }
+  const int nch = (nq + CH - 1) / CH;
+  const int cb = sp * a.cps, ce = cb + a.cps < nch ? cb + a.cps : nch;
+  const bool single = ce - cb == 1;
+  const StageId id = stage_id(d, tid);
   const float* Qb = a.Qp + (int64_t)b * a.qb;
   const float* dOb = a.dO + (int64_t)b * nq * d;
-  const float* lseb = a.LSE + (int64_t)b * h * nq;
-  const float* delb = a.Delta + (int64_t)b * h * nq;
+  const float* lseb = a.LSE + ((int64_t)b * h + j) * nq;
+  const float* delb = a.Delta + ((int64_t)b * h + j) * nq;
   const f32x4 z4 = {0.f, 0.f, 0.f, 0.f};
-  for (int c0 = 0; c0 < nq; c0 += CHQ) {
-    __syncthreads();
-    stage<CHQ, true, true>(Qb, nq, c0, d, Qrow, Qtr, tid, nthr);
-    stage<CHQ, true, true>(dOb, nq, c0, d, Drow, Dtr, tid, nthr);
-    for (int i = tid; i < h * CHQ; i += nthr) {        // queries past the end: P = exp2(-inf) = 0
-      const int hh = i / CHQ, qq = i - hh * CHQ;
-      const bool on = c0 + qq < nq;
-      const int qc = on ? c0 + qq : nq - 1;
-      const float lv = lseb[(int64_t)hh * nq + qc], dlv = delb[(int64_t)hh * nq + qc];
-      lseS[i] = on ? -lv : -INFINITY;
-      delS[i] = on ? -dlv * a.scale : 0.f;
-    }
-    __syncthreads();
-#pragma unroll 2
-    for (int u = 0; u < CHQ / 16; ++u) {
-      if (c0 + 16 * u >= nq) break;
-      const int ro = (16 * u + r) * (d + 4) + j * dh + 4 * g;
-      const int to = (j * dh + r) * (CHQ + 4) + 16 * u + 4 * g;
-      const bf16x4 qa = *reinterpret_cast<const bf16x4*>(Qrow + ro);    // A operand [query r][k = feature]
-      const bf16x4 doa = *reinterpret_cast<const bf16x4*>(Drow + ro);
-      const bf16x4 qt = *reinterpret_cast<const bf16x4*>(Qtr + to);     // Q^T, dO^T: [feature][k = query]
-      const bf16x4 dot = *reinterpret_cast<const bf16x4*>(Dtr + to);
-      const float4 nl = *reinterpret_cast<const float4*>(lseS + j * CHQ + 16 * u + 4 * g);
-      const float4 nd = *reinterpret_cast<const float4*>(delS + j * CHQ + 16 * u + 4 * g);
-      const float nl4[4] = {nl.x, nl.y, nl.z, nl.w}, nd4[4] = {nd.x, nd.y, nd.z, nd.w};
+  bool staged = false;
+  for (int t = xt; t < a.nt; t += a.gt) {
+    const int k0 = t * 16;
+    const int ki = k0 + r < nk ? k0 + r : nk - 1;
+    const bf16x4 kb4 = row4(a.Kp + ((int64_t)b * nk + ki) * d + j * dh, 4 * g, dh);   // B operand
+    const bf16x4 vb4 = row4(a.Vp + ((int64_t)b * nk + ki) * d + j * dh, 4 * g, dh);   // [k = feature][key r]
+    const bool ragged = k0 + 16 > len, dead = k0 + r >= len;
+    f32x4 dk = {0.f, 0.f, 0.f, 0.f}, dv = {0.f, 0.f, 0.f, 0.f};
+    const bool fill = !(single && staged);
+    for (int c = cb; c < ce; ++c) {
+      if (fill) {
+        __syncthreads();
+        const Staged qr = stage_load(Qb, nq, c * CH, d, id);
+        const Staged dr = stage_load(dOb, nq, c * CH, d, id);
+        const int qq = c * CH + lane;                  // this thread's entry: head j (its wave), query qq
+        const int qc = qq < nq ? qq : nq - 1;
+        const float lr = lseb[qc], er = delb[qc];
+        stage_store<true, true>(qr, nq, c * CH, d, id, Qrow, Qtr);
+        stage_store<true, true>(dr, nq, c * CH, d, id, Drow, Dtr);
+        lseS[j * CH + lane] = qq < nq ? -lr : -INFINITY;      // queries past the end: P = 2^(-inf) = 0
+        delS[j * CH + lane] = qq < nq ? -er * a.scale : 0.f;
+        __syncthreads();
+      }
 #pragma unroll
-      for (int t = 0; t < KT; ++t) {
-        const int k0 = (t0 + t) * 16;
-        if (k0 >= nk) break;
-        const f32x4 s = mfma16(qa, kb4[t], z4);        // [query 4 g + e][key r]
-        const f32x4 dp = mfma16(doa, vb4[t], z4);      // dP = dO V^T
-        const bool dead = k0 + r >= len;
+      for (int u = 0; u < CH / 16; ++u) {
+        if (c * CH + 16 * u >= nq) break;
+        const int ro = (16 * u + r) * (d + 4) + j * dh + 4 * g;
+        const int to = (j * dh + r) * (CH + 4) + 16 * u + 4 * g;
+        const bf16x4 qa = *reinterpret_cast<const bf16x4*>(Qrow + ro);    // A operand [query r][k = feature]
+        const bf16x4 doa = *reinterpret_cast<const bf16x4*>(Drow + ro);
+        const bf16x4 qt = *reinterpret_cast<const bf16x4*>(Qtr + to);     // Q^T, dO^T: [feature][k = query]
+        const bf16x4 dot = *reinterpret_cast<const bf16x4*>(Dtr + to);
+        const float4 nl = *reinterpret_cast<const float4*>(lseS + j * CH + 16 * u + 4 * g);
+        const float4 nd = *reinterpret_cast<const float4*>(delS + j * CH + 16 * u + 4 * g);
+        const float nl4[4] = {nl.x, nl.y, nl.z, nl.w}, nd4[4] = {nd.x, nd.y, nd.z, nd.w};
+        const f32x4 s = mfma16(qa, kb4, z4);           // [query 4 g + e][key r]
+        const f32x4 dp = mfma16(doa, vb4, z4);         // dP = dO V^T
         f32x4 p, ds;
 #pragma unroll
         for (int e = 0; e < 4; ++e) {
           p[e] = __builtin_amdgcn_exp2f(fmaf(s[e], a.c, nl4[e]));
-          if (k0 + 16 > len) p[e] = dead ? 0.f : p[e];
+          if (ragged) p[e] = dead ? 0.f : p[e];
           ds[e] = p[e] * fmaf(dp[e], a.scale, nd4[e]);
         }
-        dv[t] = mfma16(dot, pack4(p), dv[t]);          // dV^T += dO^T P     [feature 4 g + e][key r]
-        dk[t] = mfma16(qt, pack4(ds), dk[t]);          // dK^T += Q^T dS
+        dv = mfma16(dot, pack4(p), dv);                // dV^T += dO^T P     [feature 4 g + e][key r]
+        dk = mfma16(qt, pack4(ds), dk);                // dK^T += Q^T dS
       }
     }
-  }
-#pragma unroll
-  for (int t = 0; t < KT; ++t) {
-    const int k0 = (t0 + t) * 16;
+    staged = true;
     if (k0 + r < nk && 4 * g < dh) {
-      const int64_t o = ((int64_t)b * nk + k0 + r) * d + j * dh + 4 * g;
-      *reinterpret_cast<float4*>(a.dKp + o) = float4{dk[t][0], dk[t][1], dk[t][2], dk[t][3]};
-      *reinterpret_cast<float4*>(a.dVp + o) = float4{dv[t][0], dv[t][1], dv[t][2], dv[t][3]};
+      float *pk = a.dKp, *pv = a.dVp;
+      int64_t o = ((int64_t)b * nk + k0 + r) * d + j * dh + 4 * g;
+      if (a.S > 1) {
+        pk = a.part;
+        pv = a.part + (int64_t)a.B * a.S * nk * d;
+        o = (((int64_t)b * a.S + sp) * nk + k0 + r) * d + j * dh + 4 * g;
+      }
+      *reinterpret_cast<float4*>(pk + o) = float4{dk[0], dk[1], dk[2], dk[3]};
+      *reinterpret_cast<float4*>(pv + o) = float4{dv[0], dv[1], dv[2], dv[3]};
     }
   }
 }
 
-inline AttnCoreArgs core_args(const pca_mab_shape& s) {
+inline AttnCoreArgs core_args(const pca_mab_shape& s, const Plan& p) {
   AttnCoreArgs a{};
   a.B = s.B; a.nq = s.nq; a.nk = s.nk; a.d = s.d; a.dh = s.d / s.h; a.h = s.h;
   a.qb = s.q_shared ? 0 : (int64_t)s.nq * s.d;
   a.scale = 1.0f / sqrtf((float)s.d);                 // modules.py:28: sqrt(dim_V)
   a.c = a.scale * 1.4426950408889634f;
   a.lengths = s.k_lengths;
+  a.nt = p.nt; a.gt = p.gt; a.S = p.S; a.cps = p.cps;
   return a;
 }
-
-// tiles of the register side per wave: as many (4, 2, 1) as still leave two workgroups per CU
-inline int tiles_per_wave(int B, int rows) {
-  const int nt = (int)cdiv(rows, 16);
-  for (int t = 4; t > 1; t >>= 1)
-    if ((int64_t)B * cdiv(nt, t) >= 512) return t;
-  return 1;
+inline unsigned grid_of(const pca_mab_shape& s, const Plan& p) {
+  return (unsigned)(8 * p.gt * p.S * cdiv(s.B, 8));
 }
-inline unsigned grid_of(AttnCoreArgs& a, int rows, int t) {
-  a.gx = (int)cdiv(cdiv(rows, 16), t);
-  return (unsigned)(8 * a.gx * cdiv(a.B, 8));
+inline size_t fwd_part_elems(const pca_mab_shape& s, const Plan& p) {
+  return p.S > 1 ? (size_t)s.B * p.S * s.nq * (2 * s.h + s.d) : 0;
 }
-
-#define PCA_ATTNC_LAUNCH(KERN, T, GRID, LDSB)                                                     \
-  switch (T) {                                                                                    \
-    case 4: hipLaunchKernelGGL((KERN<4>), dim3(GRID), dim3(64 * s.h), LDSB, st, a); break;        \
-    case 2: hipLaunchKernelGGL((KERN<2>), dim3(GRID), dim3(64 * s.h), LDSB, st, a); break;        \
-    default: hipLaunchKernelGGL((KERN<1>), dim3(GRID), dim3(64 * s.h), LDSB, st, a); break;       \
-  }
 
 }  // namespace
 
 // head dims whose 16-byte row pieces the K = 16 MFMA serves, d small enough for the staged chunks
-// (55 KB of LDS at d = 64); the exact fp32 mode keeps its chain (the parity path materialises A like
+// (44 KB of LDS at d = 64); the exact fp32 mode keeps its chain (the parity path materialises A like
 // the reference)
 bool attn_core_ok(const pca_mab_shape& s) {
   const int dh = s.d / s.h;
@@ -456,37 +543,77 @@ bool attn_core_ok(const pca_mab_shape& s) {
          s.h <= 16;
 }
 
-int attn_core_fwd(const pca_mab_shape& s, const float* Qp, const float* Kp, const float* Vp, float* O,
-                  float* LSE, hipStream_t st) {
-  AttnCoreArgs a = core_args(s);
-  a.Qp = Qp; a.Kp = Kp; a.Vp = Vp; a.Oout = O; a.LSE = LSE;
-  const int t = tiles_per_wave(s.B, s.nq);
-  const unsigned grid = grid_of(a, s.nq, t);
-  const size_t ldsb = (size_t)(row_elems(CH, s.d) + tr_elems(CH, s.d)) * sizeof(__bf16);
-  PCA_ATTNC_LAUNCH(k_attnc_fwd, t, grid, ldsb)
-  return check_launch("k_attnc_fwd");
+// floats behind `LSE` (forward) / `Delta` (backward): the statistics [B][h][nq], then the partial
+// results of a launch whose streamed side is cut (Plan::S > 1)
+size_t attn_core_fwd_elems(const pca_mab_shape& s) {
+  return (size_t)s.B * s.h * s.nq + fwd_part_elems(s, plan_of(s.B, s.nq, s.nk));
+}
+size_t attn_core_bwd_elems(const pca_mab_shape& s) {
+  const Plan pq = plan_of(s.B, s.nq, s.nk), pk = plan_of(s.B, s.nk, s.nq);
+  const size_t eq = pq.S > 1 ? (size_t)s.B * pq.S * s.nq * s.d : 0;
+  const size_t ek = pk.S > 1 ? 2 * (size_t)s.B * pk.S * s.nk * s.d : 0;
+  return (size_t)s.B * s.h * s.nq + (eq > ek ? eq : ek);
 }
 
-// Delta: [B][h][nq] floats of scratch
+int attn_core_fwd(const pca_mab_shape& s, const float* Qp, const float* Kp, const float* Vp, float* O,
+                  float* LSE, hipStream_t st) {
+  const Plan p = plan_of(s.B, s.nq, s.nk);
+  AttnCoreArgs a = core_args(s, p);
+  a.Qp = Qp; a.Kp = Kp; a.Vp = Vp; a.Oout = O; a.LSE = LSE;
+  a.part = LSE + (size_t)s.B * s.h * s.nq;
+  const size_t ldsb = (size_t)(row_elems(s.d) + tr_elems(s.d)) * sizeof(__bf16);
+  if (s.h <= 8) hipLaunchKernelGGL(k_attnc_fwd<8>, dim3(grid_of(s, p)), dim3(64 * s.h), ldsb, st, a);
+  else hipLaunchKernelGGL(k_attnc_fwd<16>, dim3(grid_of(s, p)), dim3(64 * s.h), ldsb, st, a);
+  PCA_TRY(check_launch("k_attnc_fwd"));
+  if (p.S > 1) {
+    const int64_t n = (int64_t)s.B * s.nq * s.h * (a.dh / 4);
+    hipLaunchKernelGGL(k_attnc_fwd_merge, dim3((unsigned)cdiv(n, 256)), dim3(256), 0, st, a);
+    PCA_TRY(check_launch("k_attnc_fwd_merge"));
+  }
+  return PCA_OK;
+}
+
+// Delta: attn_core_bwd_elems(s) floats of scratch
 int attn_core_bwd(const pca_mab_shape& s, const float* Qp, const float* Kp, const float* Vp,
                   const float* O, const float* LSE, const float* dO, float* dQp, float* dKp, float* dVp,
                   float* Delta, hipStream_t st) {
-  AttnCoreArgs a = core_args(s);
-  a.Qp = Qp; a.Kp = Kp; a.Vp = Vp; a.O = O; a.LSE = const_cast<float*>(LSE); a.dO = dO;
-  a.dQp = dQp; a.dKp = dKp; a.dVp = dVp; a.Delta = Delta;
+  float* part = Delta + (size_t)s.B * s.h * s.nq;
   {
-    const int t = tiles_per_wave(s.B, s.nq);
-    const unsigned grid = grid_of(a, s.nq, t);
-    const size_t ldsb = (size_t)(2 * row_elems(CH, s.d) + tr_elems(CH, s.d)) * sizeof(__bf16);
-    PCA_ATTNC_LAUNCH(k_attnc_bwd_q, t, grid, ldsb)
+    const Plan p = plan_of(s.B, s.nq, s.nk);
+    AttnCoreArgs a = core_args(s, p);
+    a.Qp = Qp; a.Kp = Kp; a.Vp = Vp; a.O = O; a.LSE = const_cast<float*>(LSE); a.dO = dO;
+    a.dQp = dQp; a.Delta = Delta; a.part = part;
+    const size_t ldsb = (size_t)(2 * row_elems(s.d) + tr_elems(s.d)) * sizeof(__bf16);
+    if (s.h <= 8) hipLaunchKernelGGL(k_attnc_bwd_q<8>, dim3(grid_of(s, p)), dim3(64 * s.h), ldsb, st, a);
+  else hipLaunchKernelGGL(k_attnc_bwd_q<16>, dim3(grid_of(s, p)), dim3(64 * s.h), ldsb, st, a);
     PCA_TRY(check_launch("k_attnc_bwd_q"));
+    if (p.S > 1) {
+      const int64_t per4 = (int64_t)s.nq * s.d / 4;
+      hipLaunchKernelGGL(k_attnc_sum, dim3((unsigned)cdiv(s.B * per4, 256)), dim3(256), 0, st, dQp, dO,
+                         part, s.B, p.S, per4);
+      PCA_TRY(check_launch("k_attnc_sum"));
+    }
   }
-  const int t = tiles_per_wave(s.B, s.nk);
-  const unsigned grid = grid_of(a, s.nk, t);
-  const size_t nb16 = 2 * (size_t)row_elems(CHQ, s.d) + 2 * (size_t)tr_elems(CHQ, s.d);
-  const size_t ldsb = ((nb16 + 7) & ~(size_t)7) * sizeof(__bf16) + 2 * (size_t)s.h * CHQ * sizeof(float);
-  PCA_ATTNC_LAUNCH(k_attnc_bwd_kv, t, grid, ldsb)
-  return check_launch("k_attnc_bwd_kv");
+  const Plan p = plan_of(s.B, s.nk, s.nq);
+  AttnCoreArgs a = core_args(s, p);
+  a.Qp = Qp; a.Kp = Kp; a.Vp = Vp; a.LSE = const_cast<float*>(LSE); a.dO = dO;
+  a.dKp = dKp; a.dVp = dVp; a.Delta = Delta; a.part = part;
+  const size_t nb16 = 2 * (size_t)row_elems(s.d) + 2 * (size_t)tr_elems(s.d);
+  const size_t ldsb = ((nb16 + 7) & ~(size_t)7) * sizeof(__bf16) + 2 * (size_t)s.h * CH * sizeof(float);
+  if (s.h <= 8) hipLaunchKernelGGL(k_attnc_bwd_kv<8>, dim3(grid_of(s, p)), dim3(64 * s.h), ldsb, st, a);
+  else hipLaunchKernelGGL(k_attnc_bwd_kv<16>, dim3(grid_of(s, p)), dim3(64 * s.h), ldsb, st, a);
+  PCA_TRY(check_launch("k_attnc_bwd_kv"));
+  if (p.S > 1) {
+    const int64_t per4 = (int64_t)s.nk * s.d / 4;
+    const unsigned grid = (unsigned)cdiv(s.B * per4, 256);
+    hipLaunchKernelGGL(k_attnc_sum, dim3(grid), dim3(256), 0, st, dKp, (const float*)nullptr, part, s.B,
+                       p.S, per4);
+    PCA_TRY(check_launch("k_attnc_sum"));
+    hipLaunchKernelGGL(k_attnc_sum, dim3(grid), dim3(256), 0, st, dVp, (const float*)nullptr,
+                       part + (size_t)s.B * p.S * s.nk * s.d, s.B, p.S, per4);
+    PCA_TRY(check_launch("k_attnc_sum"));
+  }
+  return PCA_OK;
 }
 
 }  // namespace pca

@@ -243,6 +243,9 @@ int prep_weight_f8(const float* src, void* dst, int rows, int cols, int mode, fl
 // fused attention core of the bf16-operand GEMM chain for head dims <= 16 (attn_core.hip): O = Q_ + A V_
 // and its adjoint without the [B h, nq, nk] matrix A (LSE [B][h][nq] is what is saved instead)
 bool attn_core_ok(const pca_mab_shape& s);
+// floats of the forward's saved statistics area / of the backward's Delta scratch
+size_t attn_core_fwd_elems(const pca_mab_shape& s);
+size_t attn_core_bwd_elems(const pca_mab_shape& s);
 int attn_core_fwd(const pca_mab_shape& s, const float* Qp, const float* Kp, const float* Vp, float* O,
                   float* LSE, hipStream_t st);
 int attn_core_bwd(const pca_mab_shape& s, const float* Qp, const float* Kp, const float* Vp,

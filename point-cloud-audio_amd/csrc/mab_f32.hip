@@ -44,7 +44,7 @@ inline size_t saved_elems(const pca_mab_shape& s, SavedF32* out, void* base) {
   v.Kp = c.take<float>((size_t)s.B * s.nk * s.d);
   v.Vp = c.take<float>((size_t)s.B * s.nk * s.d);
   // (the fused attention core keeps the log-sum-exp [B][h][nq] here instead of the matrix A)
-  v.A = c.take<float>(attn_core_ok(s) ? (size_t)s.B * s.h * s.nq : (size_t)s.B * s.h * s.nq * s.nk);
+  v.A = c.take<float>(attn_core_ok(s) ? attn_core_fwd_elems(s) : (size_t)s.B * s.h * s.nq * s.nk);
   v.O = c.take<float>((size_t)s.B * s.nq * s.d);
   v.Z = c.take<float>((size_t)s.B * s.nq * s.d);
   v.O1 = v.Ypre = v.mean0 = v.rstd0 = v.mean1 = v.rstd1 = nullptr;
@@ -73,7 +73,7 @@ inline size_t bwd_ws_elems(const pca_mab_shape& s, BwdWsF32* out, void* base) {
   v.dZ = c.take<float>((size_t)s.B * s.nq * s.d);
   v.dO = c.take<float>((size_t)s.B * s.nq * s.d);
   v.dQp = c.take<float>((size_t)s.B * s.nq * s.d);
-  v.dA = c.take<float>(attn_core_ok(s) ? (size_t)s.B * s.h * s.nq : (size_t)s.B * s.h * s.nq * s.nk);
+  v.dA = c.take<float>(attn_core_ok(s) ? attn_core_bwd_elems(s) : (size_t)s.B * s.h * s.nq * s.nk);
   v.dKp = c.take<float>((size_t)s.B * s.nk * s.d);
   v.dVp = c.take<float>((size_t)s.B * s.nk * s.d);
   v.dQps = c.take<float>((size_t)s.nq * s.d);
