@@ -100,6 +100,18 @@ def test_cfg4_bench_size_bf16_vs_oracle(dev):
     _check(dev, 128, 4096, 3, 256, 8, 32, 50, "bf16", seed=9400)
 
 
+@pytest.mark.parametrize("shape", [(128, 1025, 2), (16, 5120, 3)], ids=["fst", "3st"])
+def test_shipped_shapes_bench_size_bf16_vs_oracle(dev, shape):
+    """The reference's own hyper-parameters (Code/settransformer.py:81-83, Code/settransformertemp.py:95-97:
+    d = 64, 8 heads of dim 8, m = 64) at the sizes ``bench.py --config fst / 3st`` times - B = 128 sets
+    of N = 1025 2-D points, B = 16 sets of N = 5120 3-D points - in the fast mode, whose attention core
+    is fused (csrc/attn_core.hip: no matrix A; at B = 16 the key range of the few-queries blocks and the
+    query range of the many-queries blocks' dK / dV are cut into ranges and merged) and whose weight /
+    bias gradients come from csrc/wgrad64.hip.  Logits, loss and all 45 gradients against the oracle."""
+    B, N, din = shape
+    _check(dev, B, N, din, 64, 8, 64, 10, "bf16", seed=9500 + N)
+
+
 def test_d256_step_is_bit_reproducible(dev):
     """The d = 256 / 8 heads / m = 32 training step uses no fp32 atomics (weight-gradient slabs,
     per-workgroup partials + fixed-order sums everywhere): two forward + backward passes over the
