@@ -95,17 +95,6 @@ __device__ __forceinline__ void wg_coords(const AttnCoreArgs& a, int& b, int& xt
   sp = x / a.gt;
 }
 
-// 4 consecutive fp32 features (f0 .. f0 + 3) of one row as a bf16 MFMA operand; zeros beyond the head dim
-// (unconditional clamped load, value selected afterwards: DESIGN.md 4.5)
-__device__ __forceinline__ bf16x4 row4(const float* row, int f0, int dh) {
-  const bool on = f0 < dh;
-  const float4 x = *reinterpret_cast<const float4*>(row + (on ? f0 : 0));
-  bf16x4 v;
-  v[0] = (__bf16)(on ? x.x : 0.f); v[1] = (__bf16)(on ? x.y : 0.f);
-  v[2] = (__bf16)(on ? x.z : 0.f); v[3] = (__bf16)(on ? x.w : 0.f);
-  return v;
-}
-
 // Staging of a chunk, all heads at once: thread -> rows 4 q .. 4 q + 3, features 4 c4 .. 4 c4 + 3 of
 // X[nrows][d] (CH / 4 x d / 4 items <= the workgroup's 64 h threads because d / h <= 16); rows >= nrows
 // are zeros.  Synchronous - the other workgroups of the CU (four fit) cover the loads: holding the next
@@ -240,11 +229,22 @@ __global__ __launch_bounds__(64 * NW, 4) void k_attnc_fwd(const AttnCoreArgs a) 
   const float* Kb = a.Kp + (int64_t)b * nk * d;
   const float* Vb = a.Vp + (int64_t)b * nk * d;
   bool staged = false;
+  // the tile's query rows: 4 features per lane (fo = the lane's piece, clamped into the head), loaded
+  // a tile ahead - a tile of the many-queries blocks is four key tiles of arithmetic
+  const int fo = 4 * g < dh ? 4 * g : 0;
+  const float* Qb = a.Qp + (int64_t)b * a.qb + j * dh + fo;
+  auto q_of = [&](int t) {
+    const int qi = t * 16 + r < nq ? t * 16 + r : nq - 1;
+    return *reinterpret_cast<const float4*>(Qb + (int64_t)qi * d);
+  };
+  float4 qv = q_of(xt < a.nt ? xt : 0);
   for (int t = xt; t < a.nt; t += a.gt) {
     const int q0 = t * 16;
-    const int qi = q0 + r < nq ? q0 + r : nq - 1;
-    const float* qrow = a.Qp + (int64_t)b * a.qb + (int64_t)qi * d + j * dh;
-    const bf16x4 qb4 = row4(qrow, 4 * g, dh);
+    const float4 q4 = qv;
+    qv = q_of(t + a.gt < a.nt ? t + a.gt : t);
+    bf16x4 qb4;
+    qb4[0] = (__bf16)(4 * g < dh ? q4.x : 0.f); qb4[1] = (__bf16)(4 * g < dh ? q4.y : 0.f);
+    qb4[2] = (__bf16)(4 * g < dh ? q4.z : 0.f); qb4[3] = (__bf16)(4 * g < dh ? q4.w : 0.f);
     float m = -INFINITY, l = 0.f;
     f32x4 acc = {0.f, 0.f, 0.f, 0.f};
     const bool fill = !(single && staged);
@@ -271,7 +271,6 @@ __global__ __launch_bounds__(64 * NW, 4) void k_attnc_fwd(const AttnCoreArgs a) 
     if (q0 + r < nq) {
       if (a.S == 1) {
         if (4 * g < dh) {
-          const float4 q4 = *reinterpret_cast<const float4*>(qrow + 4 * g);
           const float inv = 1.f / lt;
           *reinterpret_cast<float4*>(a.Oout + ((int64_t)b * nq + q0 + r) * d + j * dh + 4 * g) =
               float4{q4.x + acc[0] * inv, q4.y + acc[1] * inv, q4.z + acc[2] * inv, q4.w + acc[3] * inv};
@@ -361,21 +360,35 @@ __global__ __launch_bounds__(64 * NW, 4) void k_attnc_bwd_q(const AttnCoreArgs a
   const float* Vb = a.Vp + (int64_t)b * nk * d;
   const f32x4 z4 = {0.f, 0.f, 0.f, 0.f};
   bool staged = false;
+  // the tile's rows of Q_, dO, O (the lane's 4 features) and its LSE, loaded a tile ahead (see k_attnc_fwd)
+  const int fo = 4 * g < dh ? 4 * g : 0;
+  const bool on = 4 * g < dh;
+  struct TileIn { float4 q, dO, o; float lse; };
+  auto tile_in = [&](int t) {
+    const int qi = t * 16 + r < nq ? t * 16 + r : nq - 1;
+    const int64_t orow = ((int64_t)b * nq + qi) * d + j * dh + fo;
+    TileIn x;
+    x.q = *reinterpret_cast<const float4*>(a.Qp + (int64_t)b * a.qb + (int64_t)qi * d + j * dh + fo);
+    x.dO = *reinterpret_cast<const float4*>(a.dO + orow);
+    x.o = *reinterpret_cast<const float4*>(a.O + orow);
+    x.lse = a.LSE[((int64_t)b * a.h + j) * nq + qi];
+    return x;
+  };
+  TileIn nx = tile_in(xt < a.nt ? xt : 0);
   for (int t = xt; t < a.nt; t += a.gt) {
     const int q0 = t * 16;
-    const int qi = q0 + r < nq ? q0 + r : nq - 1;
-    const float* qrow = a.Qp + (int64_t)b * a.qb + (int64_t)qi * d + j * dh;
-    const int64_t orow = ((int64_t)b * nq + qi) * d + j * dh;
-    const bf16x4 qb4 = row4(qrow, 4 * g, dh);
-    const bf16x4 dob = row4(a.dO + orow, 4 * g, dh);
-    const float nlse = -a.LSE[((int64_t)b * a.h + j) * nq + qi];
-    const int fo = 4 * g < dh ? 4 * g : 0;
-    const float4 do4 = *reinterpret_cast<const float4*>(a.dO + orow + fo);
-    const float4 o4 = *reinterpret_cast<const float4*>(a.O + orow + fo);
-    const float4 q4 = *reinterpret_cast<const float4*>(qrow + fo);
+    const TileIn cur = nx;
+    nx = tile_in(t + a.gt < a.nt ? t + a.gt : t);
+    const float4 do4 = cur.dO, o4 = cur.o, q4 = cur.q;
+    bf16x4 qb4, dob;
+    qb4[0] = (__bf16)(on ? q4.x : 0.f); qb4[1] = (__bf16)(on ? q4.y : 0.f);
+    qb4[2] = (__bf16)(on ? q4.z : 0.f); qb4[3] = (__bf16)(on ? q4.w : 0.f);
+    dob[0] = (__bf16)(on ? do4.x : 0.f); dob[1] = (__bf16)(on ? do4.y : 0.f);
+    dob[2] = (__bf16)(on ? do4.z : 0.f); dob[3] = (__bf16)(on ? do4.w : 0.f);
+    const float nlse = -cur.lse;
     float dl = do4.x * (o4.x - q4.x) + do4.y * (o4.y - q4.y) + do4.z * (o4.z - q4.z) +
                do4.w * (o4.w - q4.w);
-    if (4 * g >= dh) dl = 0.f;
+    if (!on) dl = 0.f;
     const float delta = wave16_sum(dl);                // rowdot(dO_j, A V_j) of query r
     const float nds = -delta * a.scale;
     f32x4 acc = {0.f, 0.f, 0.f, 0.f};
@@ -453,11 +466,28 @@ __global__ __launch_bounds__(64 * NW, 4) void k_attnc_bwd_kv(const AttnCoreArgs 
   const float* delb = a.Delta + ((int64_t)b * h + j) * nq;
   const f32x4 z4 = {0.f, 0.f, 0.f, 0.f};
   bool staged = false;
+  // the tile's rows of K_ and V_ (the lane's 4 features), loaded a tile ahead (see k_attnc_fwd)
+  const int fo = 4 * g < dh ? 4 * g : 0;
+  const bool on = 4 * g < dh;
+  struct TileIn { float4 k, v; };
+  auto tile_in = [&](int t) {
+    const int ki = t * 16 + r < nk ? t * 16 + r : nk - 1;
+    const int64_t o = ((int64_t)b * nk + ki) * d + j * dh + fo;
+    TileIn x;
+    x.k = *reinterpret_cast<const float4*>(a.Kp + o);
+    x.v = *reinterpret_cast<const float4*>(a.Vp + o);
+    return x;
+  };
+  TileIn nx = tile_in(xt < a.nt ? xt : 0);
   for (int t = xt; t < a.nt; t += a.gt) {
     const int k0 = t * 16;
-    const int ki = k0 + r < nk ? k0 + r : nk - 1;
-    const bf16x4 kb4 = row4(a.Kp + ((int64_t)b * nk + ki) * d + j * dh, 4 * g, dh);   // B operand
-    const bf16x4 vb4 = row4(a.Vp + ((int64_t)b * nk + ki) * d + j * dh, 4 * g, dh);   // [k = feature][key r]
+    const TileIn cur = nx;
+    nx = tile_in(t + a.gt < a.nt ? t + a.gt : t);
+    bf16x4 kb4, vb4;                                   // B operands [k = feature][col = key r]
+    kb4[0] = (__bf16)(on ? cur.k.x : 0.f); kb4[1] = (__bf16)(on ? cur.k.y : 0.f);
+    kb4[2] = (__bf16)(on ? cur.k.z : 0.f); kb4[3] = (__bf16)(on ? cur.k.w : 0.f);
+    vb4[0] = (__bf16)(on ? cur.v.x : 0.f); vb4[1] = (__bf16)(on ? cur.v.y : 0.f);
+    vb4[2] = (__bf16)(on ? cur.v.z : 0.f); vb4[3] = (__bf16)(on ? cur.v.w : 0.f);
     const bool ragged = k0 + 16 > len, dead = k0 + r >= len;
     f32x4 dk = {0.f, 0.f, 0.f, 0.f}, dv = {0.f, 0.f, 0.f, 0.f};
     const bool fill = !(single && staged);

@@ -4,12 +4,14 @@
 set -e
 cd "$(dirname "$0")/.."
 O=gpurun_out/r04
-for f in bf16_cfg2 bf16_cfg2_perblock bf16_cfg2_headlaunch f32_cfg2 bf16_cfg3 bf16_cfg4 fp8_cfg4 bf16_cfg5 fp8_cfg5 bf16_cfg2_B1024 bf16_fst; do
+for f in bf16_cfg2 bf16_cfg2_perblock bf16_cfg2_headlaunch f32_cfg2 bf16_cfg3 bf16_cfg4 fp8_cfg4 bf16_cfg5 fp8_cfg5 bf16_cfg2_B1024 bf16_fst bf16_3st; do
   [ -s $O/${f}_bench.json ] && tail -n 1 $O/${f}_bench.json > profiles/r04_${f}_bench.json
 done
 [ -s $O/infer.txt ] && cp $O/infer.txt profiles/r04_infer.txt
 cp $O/stats_cfg2/*/*kernel_stats.csv profiles/r04_bf16_cfg2_kernel_stats.csv
 cp $O/stats_cfg4/*/*kernel_stats.csv profiles/r04_bf16_cfg4_kernel_stats.csv
+cp $O/stats_fst/*/*kernel_stats.csv profiles/r04_bf16_fst_kernel_stats.csv
+cp $O/stats_3st/*/*kernel_stats.csv profiles/r04_bf16_3st_kernel_stats.csv
 python3 scripts/pmc_summary.py profiles/r04_hbm_traffic.json > /dev/null
 (echo "# SQ counters of the cfg4 step (bench.py --config cfg4 --no-graph, 3 steps), one rocprofv3 --pmc pass per counter group; kernel time from the --kernel-trace --stats pass of the same (un-captured) workload"
  python3 scripts/sq_summary.py $O/sqcfg4) > profiles/r04_sq_cfg4.txt

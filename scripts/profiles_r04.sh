@@ -19,13 +19,16 @@ if [ $PART = bench ] || [ $PART = all ]; then
   python3 $R/bench.py --config cfg5 --steps 50 --warmup 60 --no-cpu-baseline > $O/bf16_cfg5_bench.json 2>> $O/bench.err
   python3 $R/bench.py --config cfg5 --mode fp8 --steps 50 --warmup 60 --no-cpu-baseline > $O/fp8_cfg5_bench.json 2>> $O/bench.err
   python3 $R/bench.py --batch 1024 --steps 50 --warmup 5 --no-cpu-baseline > $O/bf16_cfg2_B1024_bench.json 2>> $O/bench.err
-  python3 $R/bench.py --config fst --steps 20 --warmup 3 --no-cpu-baseline --no-roofline > $O/bf16_fst_bench.json 2>> $O/bench.err
+  python3 $R/bench.py --config fst --steps 50 --warmup 5 --no-cpu-baseline --no-roofline > $O/bf16_fst_bench.json 2>> $O/bench.err
+  python3 $R/bench.py --config 3st --steps 50 --warmup 5 --no-cpu-baseline --no-roofline > $O/bf16_3st_bench.json 2>> $O/bench.err
   (python3 $R/scripts/infer_bench.py fst 128; python3 $R/scripts/infer_bench.py 3st 16; python3 $R/scripts/infer_bench.py fst 8; python3 $R/scripts/infer_bench.py 3st 8) > $O/infer.txt 2>> $O/bench.err
   echo "bench lines done"
 fi
 if [ $PART = stats ] || [ $PART = all ]; then
   rocprofv3 --kernel-trace --stats --output-format csv -d $O/stats_cfg2 -- python3 $R/bench.py --no-cpu-baseline > $O/stats_cfg2.json 2> $O/stats_cfg2.err
   rocprofv3 --kernel-trace --stats --output-format csv -d $O/stats_cfg4 -- python3 $R/bench.py --config cfg4 --steps 20 --warmup 3 --windows 1 --no-cpu-baseline --no-roofline > $O/stats_cfg4.json 2> $O/stats_cfg4.err
+  rocprofv3 --kernel-trace --stats --output-format csv -d $O/stats_fst -- python3 $R/bench.py --config fst --steps 20 --warmup 3 --windows 1 --no-cpu-baseline --no-roofline > $O/stats_fst.json 2> $O/stats_fst.err
+  rocprofv3 --kernel-trace --stats --output-format csv -d $O/stats_3st -- python3 $R/bench.py --config 3st --steps 20 --warmup 3 --windows 1 --no-cpu-baseline --no-roofline > $O/stats_3st.json 2> $O/stats_3st.err
   echo "kernel stats done"
 fi
 if [ $PART = pmc ] || [ $PART = all ]; then
