@@ -256,6 +256,16 @@ int attn_core_bwd(const pca_mab_shape& s, const float* Qp, const float* Kp, cons
 bool wgrad64_ok(const float* dY, const float* X, int64_t M, int din, int dout);
 int wgrad64(const float* dY, const float* X, float* dW, float* db, int64_t M, int din,
             hipStream_t st);
+// the 64 -> 64 / <= 4 -> 64 Linear layers over a tall activation with the weights in registers
+// (linear64.hip): forward, input gradient, fc_o with the block's epilogue Y = O + relu(Z)
+bool lin64_ok(const float* X, const float* Y, int64_t M, int din, int dout);
+int lin64_fwd(const float* X, const float* W, const float* b, float* Y, int64_t M, int din,
+              hipStream_t st);
+int lin64_dx(const float* dY, const float* W, float* dX, int64_t M, int accumulate, hipStream_t st);
+int lin64_fc_o(const float* O, const float* W, const float* b, float* Z, float* Y, int64_t M,
+               hipStream_t st);
+int lin64_fc_o_bwd(const float* dY, const float* Z, const float* W, float* dZ, float* dO, int64_t M,
+                   hipStream_t st);
 // exact fp32 path (mab_f32.hip)
 int validate_shape(const pca_mab_shape* s);
 size_t mab_f32_saved_bytes(const pca_mab_shape& s);

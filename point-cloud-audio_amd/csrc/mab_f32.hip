@@ -99,6 +99,9 @@ inline pca_gemm_desc gd(int64_t M, int64_t N, int64_t K, int64_t sa_m, int64_t s
 // Y[M, dout] (+)= X[M, din] W^T (+ b)
 inline int linear(const float* X, const float* W, const float* b, float* Y, int64_t M,
                   int din, int dout, int accumulate, hipStream_t st) {
+  // the shipped d = 64 layers over a tall activation: the weights stay in registers (linear64.hip)
+  if (t_bf16_operands == 1 && !accumulate && lin64_ok(X, Y, M, din, dout))
+    return lin64_fwd(X, W, b, Y, M, din, st);
   pca_gemm_desc g = gd(M, dout, din, din, 1, 1, din, dout, accumulate);
   g.split_k = 1;
   return gemm_sel(g, X, W, b, Y, st);
@@ -109,6 +112,8 @@ inline int linear(const float* X, const float* W, const float* b, float* Y, int6
 // 263 us at [524288, 256] x [256, 256]: the row-vector staging of B is the slower one)
 inline int linear_dx(const float* dY, const float* W, float* dX, int64_t M, int din,
                      int dout, int accumulate, hipStream_t st, float* Wt = nullptr) {
+  if (t_bf16_operands == 1 && din == 64 && dout == 64 && lin64_ok(dY, dX, M, 64, 64))
+    return lin64_dx(dY, W, dX, M, accumulate, st);
   if (Wt != nullptr && t_bf16_operands == 1 && M * din >= (int64_t)1 << 24 && din % 4 == 0 &&
       dout % 4 == 0) {
     PCA_TRY(transpose_f32(W, Wt, dout, din, st));                 // Wt[n][k] = W[k][n]
@@ -201,6 +206,8 @@ int mab_f32_fwd(const pca_mab_shape& s, const float* Q, const float* K,
     PCA_TRY(layernorm_fwd(v.O, p.ln0_w, p.ln0_b, v.O1, v.mean0, v.rstd0, Mq, d, st));
     Oe = v.O1;
   }
+  if (!s.ln && t_bf16_operands == 1 && d == 64 && lin64_ok(Oe, Y, Mq, d, d) && lin64_ok(Oe, v.Z, Mq, d, d))
+    return lin64_fc_o(Oe, p.wo, p.bo, v.Z, Y, Mq, st);                      // :31, one launch
   PCA_TRY(linear(Oe, p.wo, p.bo, v.Z, Mq, d, d, 0, st));                    // :31
   if (s.ln) {
     PCA_TRY(add_relu(Oe, v.Z, v.Ypre, Mq * d, st));                         // :31
@@ -234,10 +241,17 @@ int mab_f32_bwd(const pca_mab_shape& s, const float* Q, const float* K,
     dYe = w.dYp;
     Oe = v.O1;
   }
-  PCA_TRY(relu_bwd(dYe, v.Z, w.dZ, Mq * d, st));
-  PCA_TRY(linear_dw_db(w.dZ, Oe, g.wo, g.bo, Mq, d, d, st));
-  PCA_TRY(copy_rows(dYe, Mq, w.dO, Mq, d, st));
-  PCA_TRY(linear_dx(w.dZ, p.wo, w.dO, Mq, d, d, 1, st, w.Wt));
+  if (!s.ln && t_bf16_operands == 1 && d == 64 && lin64_ok(dYe, w.dO, Mq, d, d) &&
+      lin64_ok(v.Z, w.dZ, Mq, d, d)) {
+    // dZ = dY . [Z > 0] and dO = dY + dZ Wo in one launch (linear64.hip)
+    PCA_TRY(lin64_fc_o_bwd(dYe, v.Z, p.wo, w.dZ, w.dO, Mq, st));
+    PCA_TRY(linear_dw_db(w.dZ, Oe, g.wo, g.bo, Mq, d, d, st));
+  } else {
+    PCA_TRY(relu_bwd(dYe, v.Z, w.dZ, Mq * d, st));
+    PCA_TRY(linear_dw_db(w.dZ, Oe, g.wo, g.bo, Mq, d, d, st));
+    PCA_TRY(copy_rows(dYe, Mq, w.dO, Mq, d, st));
+    PCA_TRY(linear_dx(w.dZ, p.wo, w.dO, Mq, d, d, 1, st, w.Wt));
+  }
   if (s.ln)     // in place: every element is read before it is rewritten
     PCA_TRY(layernorm_bwd(w.dO, v.O, v.mean0, v.rstd0, p.ln0_w, w.dO, g.ln0_w, g.ln0_b, Mq, d, st));
 
