@@ -303,8 +303,7 @@ int mab_f32_bwd(const pca_mab_shape& s, const float* Q, const float* K,
   // fc_q
   if (s.q_shared) {
     PCA_TRY(colsum(w.dQp, s.B, nq * d, w.dQps, 0, st));   // sum over sets
-    PCA_TRY(linear_dw(w.dQps, Q, g.wq, nq, s.dq, d, st));
-    PCA_TRY(colsum(w.dQps, nq, d, g.bq, 1, st));
+    PCA_TRY(linear_dw_db(w.dQps, Q, g.wq, g.bq, nq, s.dq, d, st));
     if (dQ != nullptr) PCA_TRY(linear_dx(w.dQps, p.wq, dQ, nq, s.dq, d, 1, st));
   } else {
     PCA_TRY(linear_dw_db(w.dQp, Q, g.wq, g.bq, Mq, s.dq, d, st));

@@ -181,9 +181,9 @@ __global__ __launch_bounds__(256) void k_wgrad64_narrow(const float* __restrict_
 }  // namespace
 
 bool wgrad64_ok(const float* dY, const float* X, int64_t M, int din, int dout) {
-  if (dout == 64 && din >= 1 && din <= 4 && M >= 1024)
+  if (dout == 64 && din >= 1 && din <= 4 && M >= 16)
     return (reinterpret_cast<uintptr_t>(dY) & 15) == 0;
-  return din == 64 && dout == 64 && M >= 1024 && ((reinterpret_cast<uintptr_t>(dY) | reinterpret_cast<uintptr_t>(X)) & 15) == 0;
+  return din == 64 && dout == 64 && M >= 16 && ((reinterpret_cast<uintptr_t>(dY) | reinterpret_cast<uintptr_t>(X)) & 15) == 0;
 }
 
 // dW += dY^T X and (db != nullptr) db += colsum(dY); both outputs are accumulated into
