@@ -24,11 +24,7 @@ for src in "$HERE"/*.hip; do
   if [ ! -f "$obj" ] || [ "$src" -nt "$obj" ] || [ "$HERE/pca_common.h" -nt "$obj" ] || \
      [ "$ROOT/include/pca_hip.h" -nt "$obj" ] || \
      { ls "$HERE"/*.hpp >/dev/null 2>&1 && [ -n "$(find "$HERE" -name '*.hpp' -newer "$obj")" ]; }; then
-    # d256_fused.hip: no NaN / infinity ever enters its arithmetic (softmax over 32 finite scores),
-    # so the canonicalising v_max and the select chains of the IEEE-exact fmaxf are dropped there
-    extra=""
-    [ "$(basename "$src")" = "d256_fused.hip" ] && extra="-fno-honor-nans -fno-honor-infinities"
-    $HIPCC $FLAGS $extra -c "$src" -o "$obj" &
+    $HIPCC $FLAGS -c "$src" -o "$obj" &
     pids+=($!)
   fi
 done

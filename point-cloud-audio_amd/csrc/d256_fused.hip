@@ -340,9 +340,9 @@ __global__ __launch_bounds__(512, 2) void k_isab1_fwd256(const FusedFwdArgs a) {
       const bf16x8 qb = pack8(acc[0][nb], acc[1][nb]);
       const f32x4 z4 = {0.f, 0.f, 0.f, 0.f};
       f32x4 s0 = mfma32(kpa[0], qb, z4), s1 = mfma32(kpa[1], qb, z4);
-      float mx = fmaxf(fmaxf(fmaxf(s0[0], s0[1]), fmaxf(s0[2], s0[3])),
-                       fmaxf(fmaxf(s1[0], s1[1]), fmaxf(s1[2], s1[3])));
-      mx = wave16_max(mx);
+      float mx = max_nn(max_nn(max_nn(s0[0], s0[1]), max_nn(s0[2], s0[3])),
+                       max_nn(max_nn(s1[0], s1[1]), max_nn(s1[2], s1[3])));
+      mx = wave16_max_nn(mx);
       float sum = 0.f;
 #pragma unroll
       for (int e = 0; e < 4; ++e) {
@@ -408,7 +408,7 @@ __global__ __launch_bounds__(512, 2) void k_isab1_fwd256(const FusedFwdArgs a) {
 #pragma unroll
         for (int e = 0; e < 4; ++e) {
           const float zz = F8O ? acc[t][nb][e] * inv_o + bo4[e] : acc[t][nb][e];
-          y[e] = (float)o4[e] + fmaxf(zz, 0.f);
+          y[e] = (float)o4[e] + max_nn(zz, 0.f);
           if (zz > 0.f) bits |= 1u << (4 * t + e);
         }
         *reinterpret_cast<bf16x4*>(sY + oD[t] + 8192 * nb) = pack4(y);
@@ -746,10 +746,10 @@ __global__ __launch_bounds__(1024) void k_isab1_fwd256_ab(const FusedFwdArgs a) 
             float mx[NBK];
 #pragma unroll
             for (int nb = 0; nb < NBK; ++nb)
-              mx[nb] = fmaxf(fmaxf(fmaxf(s0[nb][0], s0[nb][1]), fmaxf(s0[nb][2], s0[nb][3])),
-                             fmaxf(fmaxf(s1[nb][0], s1[nb][1]), fmaxf(s1[nb][2], s1[nb][3])));
+              mx[nb] = max_nn(max_nn(max_nn(s0[nb][0], s0[nb][1]), max_nn(s0[nb][2], s0[nb][3])),
+                             max_nn(max_nn(s1[nb][0], s1[nb][1]), max_nn(s1[nb][2], s1[nb][3])));
 #pragma unroll
-            for (int nb = 0; nb < NBK; ++nb) mx[nb] = wave16_max(mx[nb]);
+            for (int nb = 0; nb < NBK; ++nb) mx[nb] = wave16_max_nn(mx[nb]);
 #pragma unroll
             for (int nb = 0; nb < NBK; ++nb) mx[nb] = -mx[nb] * a.scale_log2e;
 #pragma unroll
@@ -844,9 +844,9 @@ __global__ __launch_bounds__(1024) void k_isab1_fwd256_ab(const FusedFwdArgs a) 
           f32x4 s0 = mfma32(kp0, qb, z4);
           f32x4 s1 = mfma32(kp1, qb, z4);
           if (!(abl & 1)) {
-            float mx = fmaxf(fmaxf(fmaxf(s0[0], s0[1]), fmaxf(s0[2], s0[3])),
-                             fmaxf(fmaxf(s1[0], s1[1]), fmaxf(s1[2], s1[3])));
-            mx = wave16_max(mx);
+            float mx = max_nn(max_nn(max_nn(s0[0], s0[1]), max_nn(s0[2], s0[3])),
+                             max_nn(max_nn(s1[0], s1[1]), max_nn(s1[2], s1[3])));
+            mx = wave16_max_nn(mx);
             const float mc = -mx * a.scale_log2e;
 #pragma unroll
             for (int e = 0; e < 4; ++e) {
@@ -1024,7 +1024,7 @@ __global__ __launch_bounds__(1024) void k_isab1_fwd256_ab(const FusedFwdArgs a) 
 #pragma unroll
             for (int e = 0; e < 4; ++e) {
               const float zz = F8O ? acc[nb][t][e] * inv_o + bo4[e] : acc[nb][t][e];
-              y[e] = (abl & 2) ? zz : (float)o4[nb][t][e] + fmaxf(zz, 0.f);
+              y[e] = (abl & 2) ? zz : (float)o4[nb][t][e] + max_nn(zz, 0.f);
               if (TRAIN && zz > 0.f) bits |= 1u << (4 * t + e);
             }
             *reinterpret_cast<bf16x4*>(sY + oD[t] + 8192 * nb) = pack4(y);

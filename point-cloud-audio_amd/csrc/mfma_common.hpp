@@ -87,6 +87,15 @@ __device__ __forceinline__ int swz(int row, int c16, int row_bytes) {
 // VALU (no trip through the LDS crossbar as ds_bpermute / __shfl_xor would take):
 //   permlane32_swap(v, v) -> ([lo, lo], [hi, hi]);  permlane16_swap(v, v) -> ([r0,r0,r2,r2],
 //   [r1,r1,r3,r3]); combining the two results of each is the xor-32 / xor-16 butterfly step.
+// max as ONE instruction (v_med3_f32 with +inf); fmaxf costs a canonicalising v_max x, x in front of every
+// operand the compiler cannot prove quiet.  For operands that are never NaN (scores of finite inputs).
+__device__ __forceinline__ float max_nn(float x, float y) { return __builtin_amdgcn_fmed3f(x, y, INFINITY); }
+__device__ __forceinline__ float wave16_max_nn(float v) {
+  auto a = __builtin_amdgcn_permlane32_swap(__float_as_uint(v), __float_as_uint(v), false, false);
+  v = max_nn(__uint_as_float(a[0]), __uint_as_float(a[1]));
+  auto b = __builtin_amdgcn_permlane16_swap(__float_as_uint(v), __float_as_uint(v), false, false);
+  return max_nn(__uint_as_float(b[0]), __uint_as_float(b[1]));
+}
 __device__ __forceinline__ float wave16_max(float v) {
   auto a = __builtin_amdgcn_permlane32_swap(__float_as_uint(v), __float_as_uint(v), false, false);
   v = fmaxf(__uint_as_float(a[0]), __uint_as_float(a[1]));
