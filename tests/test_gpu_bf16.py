@@ -161,7 +161,8 @@ def test_mab1_bwd_bf16(dev, case):
 @pytest.mark.parametrize("d,h,m", [(128, 4, 16), (256, 8, 32)])
 def test_mab1_fwd_bf16_propagates_nan(dev, d, h, m):
     """A NaN / Inf in X or H must come out as a non-finite Y (never as finite garbage): the d = 256
-    forward is compiled with -fno-honor-nans, the contract is checked here."""
+    forward takes its softmax maxima with v_med3_f32 (max_nn, mfma_common.hpp; until round 4 the file was
+    compiled with -fno-honor-nans), the contract is checked here."""
     import modules
     import pca_hip
     B, N = 2, 130
