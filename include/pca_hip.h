@@ -351,6 +351,14 @@ size_t pca_st_ws_bytes(const pca_st_config* c, int training);
  * out[7..8] = their outputs Y ([B, N, d], bf16 in the fused modes); out[9] = scratch; out[10] = total. */
 int pca_st_ws_layout(const pca_st_config* c, int64_t* out11);
 
+/* The set-resident forward of a TRAINING workspace hands partial results between the two
+ * workgroups of a set through flags it polls with a BOUNDED spin; a wait that expires (a partner that was
+ * never scheduled: another process holding CUs, a hung device) is counted in a device word and the step's
+ * results are then garbage.  *counter = the device address of that word inside `ws` (uint32; the library only
+ * ever increments it: zero it once after allocating `ws`, read it whenever the host synchronises anyway -
+ * the Trainer does at read_stats() and raises), or NULL when this configuration has no such launch. */
+int pca_st_handoff_counter(const pca_st_config* c, void* ws, uint32_t** counter);
+
 /* logits[B*k, C] = ST(X[B, N, din]) -- inference, nothing saved.
  * lengths: NULL (dense batches, as the reference's), or device int32[B] with the number of
  * valid points of each set (1 <= lengths[b] <= N, padding rows of X finite): the logits of

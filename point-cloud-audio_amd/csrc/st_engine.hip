@@ -320,8 +320,10 @@ int forward(const pca_st_config& c, const Layout& L, const Shapes& s, const floa
         isab_collect_prep(s.m0[li], params_at(p, L.mab0[li]), params_at(p, L.mab1[li]),
                           w.img[li], true, li == 1, &J);
     if (set128_on(c, s))           // the pair flags of the set-resident forward start every step at zero
-      J.j[J.n++] = PrepJob{nullptr, reinterpret_cast<__bf16*>(w.set128_ws), 1,
-                           (int)(set128_flag_bytes(c.B) / 2), 4};
+      // (not the 16-byte header in front of them: word 0 counts expired spin-waits and is the CALLER's to
+      // clear and read - pca_st_handoff_counter)
+      J.j[J.n++] = PrepJob{nullptr, reinterpret_cast<__bf16*>(static_cast<char*>(w.set128_ws) + 16), 1,
+                           (int)((set128_flag_bytes(c.B) - 16) / 2), 4};
     // (launched together with the query-side jobs below)
     // query-side preparation (Qp, G images) of every fused mab0 / PMA, also one launch
     Mab0PrepJobs MJ{};
@@ -437,6 +439,15 @@ int64_t pca_st_bucket_split(const pca_st_config* c) {
 size_t pca_st_ws_bytes(const pca_st_config* c, int training) {
   if (pca::validate(c) != PCA_OK) return 0;
   return pca::carve(*c, training, nullptr, nullptr);
+}
+
+int pca_st_handoff_counter(const pca_st_config* c, void* ws, uint32_t** counter) {
+  PCA_TRY(pca::validate(c));
+  PCA_REQUIRE(ws != nullptr && counter != nullptr, "st_handoff_counter: null pointer");
+  pca::Ws w;
+  pca::carve(*c, 1, &w, ws);
+  *counter = static_cast<uint32_t*>(w.set128_ws);      // nullptr: no set-resident launch for this shape
+  return PCA_OK;
 }
 
 int pca_st_ws_layout(const pca_st_config* c, int64_t* out) {

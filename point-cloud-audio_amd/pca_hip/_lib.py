@@ -108,6 +108,7 @@ SIGNATURES = {
     "pca_st_bucket_split": (C.c_int64, [C.POINTER(StConfig)]),
     "pca_st_ws_bytes": (C.c_size_t, [C.POINTER(StConfig), C.c_int]),
     "pca_st_ws_layout": (C.c_int, [C.POINTER(StConfig), C.c_void_p]),
+    "pca_st_handoff_counter": (C.c_int, [C.POINTER(StConfig), C.c_void_p, C.POINTER(C.c_void_p)]),
     "pca_st_forward": (C.c_int, [C.POINTER(StConfig), c_fp, c_fp, c_vp, c_fp, c_vp, c_vp]),
     "pca_st_train_fwd_bwd": (C.c_int, [C.POINTER(StConfig), c_fp, c_fp, c_vp, c_i64p, c_fp,
                                        c_fp, c_fp, c_fp, C.c_float, C.c_int, c_vp, c_vp]),

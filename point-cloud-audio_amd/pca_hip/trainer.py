@@ -163,6 +163,29 @@ class STEngine:
                 self.grads = torch.zeros_like(self.flat)
                 self.loss = torch.zeros(1, dtype=torch.float32, device=self.dev)
                 self.stats = torch.zeros(2, dtype=torch.float32, device=self.dev)
+        # the set-resident forward's bounded spin-waits (csrc/set128_fwd.hip) count their expiries in a
+        # word of the workspace that only the caller clears: zero it now, look at it at every host sync
+        self._handoff_word = None
+        if training:
+            ptr = C.c_void_p()
+            check(L.pca_st_handoff_counter(C.byref(self.cfg), self.ws.data_ptr(), C.byref(ptr)),
+                  "pca_st_handoff_counter")
+            if ptr.value:
+                off = ptr.value - self.ws.data_ptr()
+                self._handoff_word = self.ws[off:off + 4].view(torch.int32)
+                self._handoff_word.zero_()
+
+    def check_handoffs(self) -> None:
+        """Raise if a pair hand-off of the set-resident forward ever timed out (one host sync): a
+        workgroup whose partner was not scheduled within ~1 s went on with stale data, i.e. every
+        result since is garbage - e.g. another process holding compute units of this GPU."""
+        if self._handoff_word is not None:
+            n = int(self._handoff_word.item())
+            if n:
+                raise _lib.PcaHipError(
+                    f"set-resident forward: {n} pair hand-off(s) timed out - the step's results are "
+                    "invalid (is another process using this GPU?); PCA_SET128=0 selects the per-block "
+                    "launches, which need no co-resident workgroups")
 
     def _stream(self):
         return C.c_void_p(torch.cuda.current_stream(self.dev).cuda_stream)
@@ -441,6 +464,7 @@ class Trainer:
         if self.world > 1:
             dist.all_reduce(st, group=self.pg)
         out = st.cpu().tolist()
+        self.eng.check_handoffs()
         if reset:
             self.eng.stats.zero_()
         return float(out[0]), float(out[1])

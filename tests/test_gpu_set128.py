@@ -44,6 +44,7 @@ def _run(dev, net, X, y, B, N, set128, head=True):
         eng = trainer.STEngine(net, B, N, _lib.MODE_BF16, training=True)
         eng.fwd_bwd(X, y, phase=-1)
         torch.cuda.synchronize()
+        eng.check_handoffs()           # no bounded spin-wait of the pair hand-offs expired
         return eng.logits.clone(), float(eng.loss), eng.grads.clone()
     finally:
         for k, v in old.items():
@@ -99,3 +100,32 @@ def test_set128_train_step_vs_oracle(dev, B, N, din):
     for k, prm in net.named_parameters():
         close_robust(g[off:off + prm.numel()].view_as(prm), ref_g[k], 5e-2, k, outlier_frac=5e-3)
         off += prm.numel()
+
+
+def test_handoff_timeouts_are_surfaced(dev):
+    """The pair hand-offs poll with a bounded spin; an expiry is counted in a word of the workspace
+    (``pca_st_handoff_counter``) that the library never clears - not by the per-step flag reset either -
+    and ``STEngine.check_handoffs`` / ``Trainer.read_stats`` raise on it.  A shape without the
+    set-resident launch has no such word."""
+    import models
+    from pca_hip import _lib, trainer
+    torch.manual_seed(5)
+    net = models.ST(dim_input=2, num_outputs=1, dim_output=7, num_inds=16, dim_hidden=128,
+                    num_heads=4).to(dev)
+    B, N = 6, 512
+    eng = trainer.STEngine(net, B, N, _lib.MODE_BF16, training=True)
+    assert eng._handoff_word is not None
+    X, y = T(gi.pc_input(31, B, N, 2), dev), T(gi.labels(32, B, 7), dev)
+    for _ in range(3):                 # the flag block is reset every step, the counter is not
+        eng.fwd_bwd(X, y, phase=-1)
+    torch.cuda.synchronize()
+    eng.check_handoffs()
+    assert int(eng._handoff_word.item()) == 0
+    eng._handoff_word.fill_(2)         # what two expired waits would leave
+    eng.fwd_bwd(X, y, phase=-1)
+    torch.cuda.synchronize()
+    assert int(eng._handoff_word.item()) == 2          # survived the step's flag reset
+    with pytest.raises(_lib.PcaHipError, match="hand-off"):
+        eng.check_handoffs()
+    other = trainer.STEngine(net, B, 300, _lib.MODE_BF16, training=True)   # N = 300: per-block launches
+    assert other._handoff_word is None
