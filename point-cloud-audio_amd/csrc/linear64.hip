@@ -35,39 +35,52 @@ struct Lin64Args {
   int accumulate;     // Y += (EPI = 0 only)
 };
 
-constexpr int LW = 4;              // waves per workgroup
+constexpr int LW = 8;              // waves per workgroup
+constexpr int WS = 68;             // floats per weight row in LDS (64 + 4: the 16 rows of an operand read
+                                   // spread over the banks)
 
 // EPI 0: Y (+)= X op(W) + b ; EPI 1: Z = X W^T + b, Y = X + relu(Z) ;
 // EPI 2 (the adjoint of EPI 1, X = dY): dZ = dY . [Zin > 0] stored, Y = dY + dZ W
 template <int EPI>
 __global__ __launch_bounds__(64 * LW) void k_lin64(const Lin64Args a) {
-  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  // The weights reach the waves through LDS, read from memory ONCE per workgroup: every wave fetching its
+  // own operands made 4096 waves ask the same 128 cache lines of the same 16 L2 channels while the
+  // activation stream keeps evicting them from L1 (35 us per call; 1024 waves 14 us).
+  __shared__ float sW[64 * WS + 64];     // sW[f][k] = the weight of output f, input k ; then the bias
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int r = lane & 15, kg = lane >> 4;
+  for (int i = tid; i < 64 * 16; i += 64 * LW) {
+    const int row = i >> 4, c4 = (i & 15) * 4;
+    const float4 w = *reinterpret_cast<const float4*>(a.W + row * 64 + c4);
+    if (a.wt) {                          // W[k = row][f = c4 ..]
+      sW[(c4 + 0) * WS + row] = w.x; sW[(c4 + 1) * WS + row] = w.y;
+      sW[(c4 + 2) * WS + row] = w.z; sW[(c4 + 3) * WS + row] = w.w;
+    } else {                             // W[f = row][k = c4 ..]
+      *reinterpret_cast<float4*>(sW + row * WS + c4) = w;
+    }
+  }
+  if (tid < 64) sW[64 * WS + tid] = a.b != nullptr ? a.b[tid] : 0.f;
+  __syncthreads();
   // A operands: tile nt, k-step s: row m' = lane & 15 <-> output feature 16 nt + m', k slots e <-> input
   // feature 16 s + 4 kg + e
   bf16x4 aw[4][4];
 #pragma unroll
-  for (int nt = 0; nt < 4; ++nt) {
-    const int f = 16 * nt + r;
-#pragma unroll
-    for (int s = 0; s < 4; ++s) {
-      const int k0 = 16 * s + 4 * kg;
-      float w[4];
-#pragma unroll
-      for (int e = 0; e < 4; ++e) w[e] = a.wt ? a.W[(k0 + e) * 64 + f] : a.W[f * 64 + k0 + e];
-      aw[nt][s][0] = (__bf16)w[0]; aw[nt][s][1] = (__bf16)w[1];
-      aw[nt][s][2] = (__bf16)w[2]; aw[nt][s][3] = (__bf16)w[3];
-    }
-  }
-  f32x4 bias[4];
-#pragma unroll
   for (int nt = 0; nt < 4; ++nt)
 #pragma unroll
-    for (int e = 0; e < 4; ++e) bias[nt][e] = a.b != nullptr ? a.b[16 * nt + 4 * kg + e] : 0.f;
+    for (int s = 0; s < 4; ++s) {
+      const float4 w = *reinterpret_cast<const float4*>(sW + (16 * nt + r) * WS + 16 * s + 4 * kg);
+      const f32x4 wv = {w.x, w.y, w.z, w.w};
+      aw[nt][s] = __builtin_convertvector(wv, bf16x4);
+    }
+  f32x4 bias[4];
+#pragma unroll
+  for (int nt = 0; nt < 4; ++nt) {
+    const float4 bb = *reinterpret_cast<const float4*>(sW + 64 * WS + 16 * nt + 4 * kg);
+    bias[nt] = f32x4{bb.x, bb.y, bb.z, bb.w};
+  }
 
   // two 16-row groups per trip, the next two requested under the current products: 16 KB in flight per
-  // wave (one group per trip left the load latency exposed at one wave per SIMD: 4096 short waves 35 us
-  // per call, 1024 long ones 14)
+  // wave
   const int64_t groups = (a.M + 15) / 16;
   const int64_t nw = (int64_t)gridDim.x * LW;
   int64_t g = (int64_t)blockIdx.x * LW + wave;
@@ -192,7 +205,7 @@ __global__ __launch_bounds__(256) void k_lin64_narrow(const float* __restrict__ 
 inline bool al16p(const void* p) { return (reinterpret_cast<uintptr_t>(p) & 15) == 0; }
 inline unsigned lin64_grid(int64_t M) {
   int64_t wgs = cdiv(cdiv(M, 16), LW * 4);              // >= 2 trips per wave where there are that many
-  if (wgs > 256) wgs = 256;                             // (the weights are set up once per wave: few, long waves)
+  if (wgs > 256) wgs = 256;                             // one workgroup per CU: 512 measured 15 % slower
   return (unsigned)(wgs < 1 ? 1 : wgs);
 }
 
