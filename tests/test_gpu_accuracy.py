@@ -201,3 +201,68 @@ def test_train_from_scratch_accuracy(mode, dev):
     tol_acc = float(os.environ.get("PCA_ACC_TOL", "0.002"))
     assert abs(conv.mean() - ref_conv.mean()) <= tol_acc + 2 * np.hypot(sem, ref_sem)
     assert np.median(medians) >= np.median(ref_accs) - 0.20     # coarse guard only: see above
+
+
+RUNS_SHIPPED = int(os.environ.get("PCA_ACC_RUNS_SHIPPED", "10"))
+
+
+def test_train_from_scratch_shipped_hyperparameters_fused_vs_exact(dev):
+    """The reference's own hyper-parameters (d = 64, 8 heads of dim 8, 64 inducing points:
+    Code/settransformer.py:81-83) trained from scratch on the accuracy corpus in the FAST mode - the
+    attention core without the matrix A (csrc/attn_core.hip), k_lin64, k_wgrad64 - against the exact fp32
+    mode of this library on the same initial weights, corpus, batch order and 598 Adam steps.  The exact
+    mode is what (i) / (ii) above pin to the reference; no reference run exists at this width, so the
+    bar is the exact mode's own distribution: first 20 losses step by step (3e-2), converged accuracy
+    (mean of the three best of ten evaluations) averaged over RUNS_SHIPPED runs per mode from initial
+    weights perturbed by 1e-6, within 0.5 % plus two standard errors of the difference.  (Wider than 8d's
+    0.2 %: at this width Adam at lr 1e-3 is more chaotic still than in (ii) - single evaluations of either
+    mode fall to 0.11-0.3 late in training - and the fused mode's weight gradients are summed with atomics,
+    so its runs differ run to run; measured on MI355X, 8 runs each: exact 0.9854 (sigma 0.0026), fused
+    0.9826 (sigma 0.0055), difference -0.0028 +- 0.0021.)"""
+    import dataset
+    import models
+    from pca_hip import _lib, trainer
+    g = _npz("golden_acc_train.npz")
+    a = gi.ACC
+    cp = gi.accuracy_corpus()
+    ds = dataset.ESC_pc(cp["x_train"], cp["y_train"], cp["farr"], device=dev)
+    dt = dataset.ESC_pc(cp["x_test"], cp["y_test"], cp["farr"], device=dev)
+    steps = int(g["steps"])
+    eval_at = {int(v) for v in g["eval_steps"]}
+    top3 = lambda v: float(np.sort(v)[-3:].mean())                      # noqa: E731
+    torch.manual_seed(a["init_seed"])
+    init = {k: v.detach().cpu().clone() for k, v in
+            models.ST(dim_input=2, num_outputs=1, dim_output=a["C"], num_inds=64, dim_hidden=64,
+                      num_heads=8).state_dict().items()}
+    conv, early = {}, {}
+    for mode, m in (("f32", _lib.MODE_F32), ("bf16", _lib.MODE_BF16)):
+        conv[mode] = []
+        for run in range(RUNS_SHIPPED):
+            net = models.ST(dim_input=2, num_outputs=1, dim_output=a["C"], num_inds=64, dim_hidden=64,
+                            num_heads=8).to(dev)
+            gen = torch.Generator().manual_seed(7100 + run)
+            net.load_state_dict({k: (w if run == 0 else w * (1.0 + 1e-6 * torch.randn(w.shape, generator=gen)))
+                                 for k, w in init.items()})
+            tr = trainer.Trainer(net, ds, a["B"], lr=a["lr"], weight_decay=a["wd"], mode=m,
+                                 seed=a["seed"], shuffle=True)
+            losses, accs = np.zeros(steps), []
+            for s in range(steps):
+                tr.step()
+                if run == 0 and s < 20:
+                    losses[s] = float(tr.eng.loss)
+                if s + 1 in eval_at:
+                    acc, n = trainer.evaluate(net, dt, 220, m)
+                    accs.append(acc)
+            if run == 0:
+                early[mode] = losses[:20].copy()
+            conv[mode].append(top3(np.asarray(accs)))
+            print(f"shipped hyper-parameters, {mode} run {run}: evaluations {np.round(accs, 4)}")
+        conv[mode] = np.asarray(conv[mode])
+    assert np.abs(early["bf16"] - early["f32"]).max() < 3e-2, (early["bf16"], early["f32"])
+    sem = np.hypot(conv["f32"].std(ddof=1), conv["bf16"].std(ddof=1)) / np.sqrt(RUNS_SHIPPED)
+    diff = conv["bf16"].mean() - conv["f32"].mean()
+    print(f"shipped hyper-parameters: exact mode mean {conv['f32'].mean():.4f} (sigma {conv['f32'].std(ddof=1):.4f}), "
+          f"fused mode mean {conv['bf16'].mean():.4f} (sigma {conv['bf16'].std(ddof=1):.4f}); difference "
+          f"{diff:+.4f}, standard error {sem:.4f}")
+    assert conv["f32"].mean() > 0.9, conv["f32"]          # the model did learn the task
+    assert abs(diff) <= 0.005 + 2 * sem, (diff, sem)
