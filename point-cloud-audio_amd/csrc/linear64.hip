@@ -213,7 +213,7 @@ inline unsigned lin64_grid(int64_t M) {
 
 // shapes these kernels serve (anything else stays on the generic GEMM)
 bool lin64_ok(const float* X, const float* Y, int64_t M, int din, int dout) {
-  if (dout != 64 || M < 16 || !al16p(Y)) return false;
+  if (dout != 64 || M < 1 || !al16p(Y)) return false;
   return (din == 64 && al16p(X)) || (din >= 1 && din <= 4);
 }
 
