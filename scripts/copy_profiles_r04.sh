@@ -12,6 +12,7 @@ cp $O/stats_cfg2/*/*kernel_stats.csv profiles/r04_bf16_cfg2_kernel_stats.csv
 cp $O/stats_cfg4/*/*kernel_stats.csv profiles/r04_bf16_cfg4_kernel_stats.csv
 cp $O/stats_fst/*/*kernel_stats.csv profiles/r04_bf16_fst_kernel_stats.csv
 cp $O/stats_3st/*/*kernel_stats.csv profiles/r04_bf16_3st_kernel_stats.csv
+[ -d $O/sqfst ] && (echo "# SQ counters of the FST step (bench.py --config fst --no-graph, 3 steps), one rocprofv3 --pmc pass per counter group; kernel time from a --kernel-trace --stats pass of the same (un-captured) workload"; python3 scripts/sq_summary.py $O/sqfst) > profiles/r04_sq_fst.txt
 python3 scripts/pmc_summary.py profiles/r04_hbm_traffic.json > /dev/null
 (echo "# SQ counters of the cfg4 step (bench.py --config cfg4 --no-graph, 3 steps), one rocprofv3 --pmc pass per counter group; kernel time from the --kernel-trace --stats pass of the same (un-captured) workload"
  python3 scripts/sq_summary.py $O/sqcfg4) > profiles/r04_sq_cfg4.txt
