@@ -38,9 +38,9 @@ if [ $PART = pmc ] || [ $PART = all ]; then
   echo "traffic passes done"
 fi
 if [ $PART = sq ] || [ $PART = all ]; then
-  for cfg in cfg2 cfg4; do
+  for cfg in cfg2 cfg4 fst; do
     i=0
-    if [ $cfg = cfg2 ]; then A="--steps 6 --warmup 2"; else A="--config cfg4 --steps 3 --warmup 1"; fi
+    if [ $cfg = cfg2 ]; then A="--steps 6 --warmup 2"; else A="--config $cfg --steps 3 --warmup 1"; fi
     for grp in "${GRP[@]}"; do
       i=$((i+1))
       rocprofv3 --kernel-trace --pmc $grp --output-format csv -d $O/sq$cfg/sq_$i -- python3 $R/bench.py $A --windows 1 --no-cpu-baseline --no-roofline --no-graph > $O/sq${cfg}_$i.log 2>&1 || echo "$cfg group $i failed"
