@@ -204,7 +204,7 @@ __global__ __launch_bounds__(256) void k_lin64_narrow(const float* __restrict__ 
 
 inline bool al16p(const void* p) { return (reinterpret_cast<uintptr_t>(p) & 15) == 0; }
 inline unsigned lin64_grid(int64_t M) {
-  int64_t wgs = cdiv(cdiv(M, 16), LW * 4);              // >= 2 trips per wave where there are that many
+  int64_t wgs = cdiv(cdiv(M, 16), LW);                  // a group per wave before anyone gets a second
   if (wgs > 256) wgs = 256;                             // one workgroup per CU: 512 measured 15 % slower
   return (unsigned)(wgs < 1 ? 1 : wgs);
 }

@@ -218,7 +218,7 @@ int wgrad64(const float* dY, const float* X, float* dW, float* db, int64_t M, in
   const int64_t groups = (M + 15) / 16;
   // one workgroup per CU at most (its 8 wave slabs take 130 KB of LDS), >= 2 groups per wave where
   // the rows allow; 256 x 4160 atomics per call
-  int64_t wgs = cdiv(groups, 2 * WG_WAVES);
+  int64_t wgs = cdiv(groups, WG_WAVES);
   if (wgs > 256) wgs = 256;
   if (wgs < 1) wgs = 1;
   static const int once = [] {
