@@ -122,8 +122,7 @@ __global__ __launch_bounds__(64 * WG_WAVES) void k_wgrad64(const float* __restri
 
 // Narrow input (layer 1: the points have DQ <= 4 coordinates): dW[64][DQ] += dY[M][64]^T X[M][DQ],
 // db += colsum(dY), all fp32 on the vector ALU -- dY is the only stream (256 B per row), X rides in L1.
-// Lane (og, kg) of a wave takes columns 4 og .. 4 og + 3 of every fourth row; four rows are in flight
-// per lane.
+// Lane (og, kg) of a wave takes columns 4 og .. 4 og + 3 of four rows of the wave's 16-row group.
 template <int DQ>
 __global__ __launch_bounds__(256) void k_wgrad64_narrow(const float* __restrict__ dY,
                                                         const float* __restrict__ X,
@@ -138,30 +137,58 @@ __global__ __launch_bounds__(256) void k_wgrad64_narrow(const float* __restrict_
   for (int c = 0; c < 4; ++c)
 #pragma unroll
     for (int q = 0; q < DQ; ++q) acc[c][q] = 0.f;
-  const int64_t stride = (int64_t)gridDim.x * 16;              // rows per sweep of the grid
-  constexpr int U = 4;                                         // rows in flight per lane (8: 12 % slower)
-  for (int64_t r = ((int64_t)blockIdx.x * 4 + wave) * 4 + kg; r < M; r += U * stride) {
-    float4 y[U];
-    float x[U][DQ];
+  // a wave takes two 16-row groups per trip (lane (og, kg): rows 4 kg .. 4 kg + 3, columns 4 og ..), the
+  // next two requested under the current ones' arithmetic: the launch is a handful of dependent round
+  // trips long, so fewer and fatter trips (one group per trip: 18.7 us at M = 131 200)
+  const int64_t groups = (M + 15) / 16;
+  const int64_t nw = (int64_t)gridDim.x * 4;
+  int64_t g = (int64_t)blockIdx.x * 4 + wave;
+  float4 y[2][4];
+  float x[2][4][DQ];
+  auto rows_of = [&](int64_t gg, float4 (&yy)[4], float (&xx)[4][DQ]) {
 #pragma unroll
-    for (int u = 0; u < U; ++u) {
-      const int64_t ru = r + u * stride;
-      const int64_t rc = ru < M ? ru : M - 1;
-      y[u] = *reinterpret_cast<const float4*>(dY + rc * 64 + 4 * og);
+    for (int e = 0; e < 4; ++e) {
+      const int64_t r = gg * 16 + 4 * kg + e;
+      const int64_t rc = r < M ? r : M - 1;                     // clamped; zeroed in the ragged trip
+      yy[e] = *reinterpret_cast<const float4*>(dY + rc * 64 + 4 * og);
 #pragma unroll
-      for (int q = 0; q < DQ; ++q) x[u][q] = X[rc * DQ + q];
+      for (int q = 0; q < DQ; ++q) xx[e][q] = X[rc * DQ + q];
     }
+  };
+  rows_of(g, y[0], x[0]);
+  rows_of(g + nw, y[1], x[1]);
+  for (; g < groups; g += 2 * nw) {
+    float4 yn[2][4];
+    float xn[2][4][DQ];
+    rows_of(g + 2 * nw, yn[0], xn[0]);
+    rows_of(g + 3 * nw, yn[1], xn[1]);
 #pragma unroll
-    for (int u = 0; u < U; ++u) {
-      const bool on = r + u * stride < M;                      // (selected here, after all the loads)
-      const float yv[4] = {on ? y[u].x : 0.f, on ? y[u].y : 0.f, on ? y[u].z : 0.f, on ? y[u].w : 0.f};
+    for (int u = 0; u < 2; ++u) {
+      const int64_t gu = g + u * nw;
+      if (gu * 16 + 16 > M) {                                   // (uniform) ragged or past the end
 #pragma unroll
-      for (int c = 0; c < 4; ++c) {
-        bs[c] += yv[c];
+        for (int e = 0; e < 4; ++e)
+          if (gu * 16 + 4 * kg + e >= M) y[u][e] = make_float4(0.f, 0.f, 0.f, 0.f);
+      }
 #pragma unroll
-        for (int q = 0; q < DQ; ++q) acc[c][q] = fmaf(yv[c], x[u][q], acc[c][q]);
+      for (int e = 0; e < 4; ++e) {
+        const float yv[4] = {y[u][e].x, y[u][e].y, y[u][e].z, y[u][e].w};
+#pragma unroll
+        for (int c = 0; c < 4; ++c) {
+          bs[c] += yv[c];
+#pragma unroll
+          for (int q = 0; q < DQ; ++q) acc[c][q] = fmaf(yv[c], x[u][e][q], acc[c][q]);
+        }
       }
     }
+#pragma unroll
+    for (int u = 0; u < 2; ++u)
+#pragma unroll
+      for (int e = 0; e < 4; ++e) {
+        y[u][e] = yn[u][e];
+#pragma unroll
+        for (int q = 0; q < DQ; ++q) x[u][e][q] = xn[u][e][q];
+      }
   }
 #pragma unroll
   for (int c = 0; c < 4; ++c) {
@@ -202,7 +229,7 @@ int wgrad64(const float* dY, const float* X, float* dW, float* db, int64_t M, in
   PCA_REQUIRE(dY && X && dW && M > 0 && (din == 64 || (din >= 1 && din <= 4)),
               "wgrad64: bad arguments");
   if (din <= 4) {
-    int64_t wgs = cdiv(M, 64);                  // >= 4 rows per lane where there are that many
+    int64_t wgs = cdiv(cdiv(M, 16), 8);         // two 16-row groups per wave before anyone gets more
     if (wgs > 512) wgs = 512;
 #define PCA_NARROW(Q)                                                                          \
   case Q:                                                                                      \
