@@ -123,12 +123,14 @@ __global__ __launch_bounds__(64 * WG_WAVES) void k_wgrad64(const float* __restri
 // Narrow input (layer 1: the points have DQ <= 4 coordinates): dW[64][DQ] += dY[M][64]^T X[M][DQ],
 // db += colsum(dY), all fp32 on the vector ALU -- dY is the only stream (256 B per row), X rides in L1.
 // Lane (og, kg) of a wave takes columns 4 og .. 4 og + 3 of four rows of the wave's 16-row group.
+constexpr int NWN = 16;            // waves per workgroup of the narrow kernel
+
 template <int DQ>
-__global__ __launch_bounds__(256) void k_wgrad64_narrow(const float* __restrict__ dY,
+__global__ __launch_bounds__(64 * NWN) void k_wgrad64_narrow(const float* __restrict__ dY,
                                                         const float* __restrict__ X,
                                                         float* __restrict__ dW,
                                                         float* __restrict__ db, int64_t M) {
-  __shared__ float sP[4][64 * (DQ + 1)];
+  __shared__ float sP[NWN][64 * (DQ + 1)];
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int og = lane & 15, kg = lane >> 4;
   float acc[4][DQ];
@@ -137,14 +139,14 @@ __global__ __launch_bounds__(256) void k_wgrad64_narrow(const float* __restrict_
   for (int c = 0; c < 4; ++c)
 #pragma unroll
     for (int q = 0; q < DQ; ++q) acc[c][q] = 0.f;
-  // a wave takes two 16-row groups per trip (lane (og, kg): rows 4 kg .. 4 kg + 3, columns 4 og ..), the
-  // next two requested under the current ones' arithmetic: the launch is a handful of dependent round
-  // trips long, so fewer and fatter trips (one group per trip: 18.7 us at M = 131 200)
+  // a wave takes 16 consecutive rows per trip (lane (og, kg): rows 4 kg .. 4 kg + 3, columns 4 og ..), the
+  // next group's rows requested under the current one's arithmetic - k_wgrad64's stream (two groups per
+  // trip do not fit the 128 registers of a 16-wave workgroup)
   const int64_t groups = (M + 15) / 16;
-  const int64_t nw = (int64_t)gridDim.x * 4;
-  int64_t g = (int64_t)blockIdx.x * 4 + wave;
-  float4 y[2][4];
-  float x[2][4][DQ];
+  const int64_t nw = (int64_t)gridDim.x * NWN;
+  int64_t g = (int64_t)blockIdx.x * NWN + wave;
+  float4 y[4];
+  float x[4][DQ];
   auto rows_of = [&](int64_t gg, float4 (&yy)[4], float (&xx)[4][DQ]) {
 #pragma unroll
     for (int e = 0; e < 4; ++e) {
@@ -155,40 +157,32 @@ __global__ __launch_bounds__(256) void k_wgrad64_narrow(const float* __restrict_
       for (int q = 0; q < DQ; ++q) xx[e][q] = X[rc * DQ + q];
     }
   };
-  rows_of(g, y[0], x[0]);
-  rows_of(g + nw, y[1], x[1]);
-  for (; g < groups; g += 2 * nw) {
-    float4 yn[2][4];
-    float xn[2][4][DQ];
-    rows_of(g + 2 * nw, yn[0], xn[0]);
-    rows_of(g + 3 * nw, yn[1], xn[1]);
+  rows_of(g, y, x);
+  for (; g < groups; g += nw) {
+    float4 yn[4];
+    float xn[4][DQ];
+    rows_of(g + nw, yn, xn);
+    if (g * 16 + 16 > M) {                                      // (uniform) the ragged last group
 #pragma unroll
-    for (int u = 0; u < 2; ++u) {
-      const int64_t gu = g + u * nw;
-      if (gu * 16 + 16 > M) {                                   // (uniform) ragged or past the end
+      for (int e = 0; e < 4; ++e)
+        if (g * 16 + 4 * kg + e >= M) y[e] = make_float4(0.f, 0.f, 0.f, 0.f);
+    }
 #pragma unroll
-        for (int e = 0; e < 4; ++e)
-          if (gu * 16 + 4 * kg + e >= M) y[u][e] = make_float4(0.f, 0.f, 0.f, 0.f);
-      }
+    for (int e = 0; e < 4; ++e) {
+      const float yv[4] = {y[e].x, y[e].y, y[e].z, y[e].w};
 #pragma unroll
-      for (int e = 0; e < 4; ++e) {
-        const float yv[4] = {y[u][e].x, y[u][e].y, y[u][e].z, y[u][e].w};
+      for (int c = 0; c < 4; ++c) {
+        bs[c] += yv[c];
 #pragma unroll
-        for (int c = 0; c < 4; ++c) {
-          bs[c] += yv[c];
-#pragma unroll
-          for (int q = 0; q < DQ; ++q) acc[c][q] = fmaf(yv[c], x[u][e][q], acc[c][q]);
-        }
+        for (int q = 0; q < DQ; ++q) acc[c][q] = fmaf(yv[c], x[e][q], acc[c][q]);
       }
     }
 #pragma unroll
-    for (int u = 0; u < 2; ++u)
+    for (int e = 0; e < 4; ++e) {
+      y[e] = yn[e];
 #pragma unroll
-      for (int e = 0; e < 4; ++e) {
-        y[u][e] = yn[u][e];
-#pragma unroll
-        for (int q = 0; q < DQ; ++q) x[u][e][q] = xn[u][e][q];
-      }
+      for (int q = 0; q < DQ; ++q) x[e][q] = xn[e][q];
+    }
   }
 #pragma unroll
   for (int c = 0; c < 4; ++c) {
@@ -209,8 +203,12 @@ __global__ __launch_bounds__(256) void k_wgrad64_narrow(const float* __restrict_
     }
   }
   __syncthreads();
-  for (int i = tid; i < 64 * DQ + (db != nullptr ? 64 : 0); i += 256) {
-    const float v = sP[0][i] + sP[1][i] + sP[2][i] + sP[3][i];
+  // few, wide workgroups on purpose: the 64 DQ + 64 results are a handful of cache lines, and atomics of
+  // different workgroups onto ONE line serialise at ~25 ns each - 512 workgroups cost 13 us here
+  for (int i = tid; i < 64 * DQ + (db != nullptr ? 64 : 0); i += 64 * NWN) {
+    float v = 0.f;
+#pragma unroll
+    for (int w = 0; w < NWN; ++w) v += sP[w][i];
     atomicAdd(i < 64 * DQ ? dW + i : db + (i - 64 * DQ), v);
   }
 }
@@ -229,11 +227,11 @@ int wgrad64(const float* dY, const float* X, float* dW, float* db, int64_t M, in
   PCA_REQUIRE(dY && X && dW && M > 0 && (din == 64 || (din >= 1 && din <= 4)),
               "wgrad64: bad arguments");
   if (din <= 4) {
-    int64_t wgs = cdiv(cdiv(M, 16), 8);         // two 16-row groups per wave before anyone gets more
-    if (wgs > 512) wgs = 512;
+    int64_t wgs = cdiv(cdiv(M, 16), NWN);       // a 16-row group per wave before anyone gets a second
+    if (wgs > 128) wgs = 128;                   // (see the kernel's last loop)
 #define PCA_NARROW(Q)                                                                          \
   case Q:                                                                                      \
-    hipLaunchKernelGGL((k_wgrad64_narrow<Q>), dim3((unsigned)wgs), dim3(256), 0, st, dY, X, dW, \
+    hipLaunchKernelGGL((k_wgrad64_narrow<Q>), dim3((unsigned)wgs), dim3(64 * NWN), 0, st, dY, X, dW, \
                        db, M);                                                                 \
     break;
     switch (din) {
