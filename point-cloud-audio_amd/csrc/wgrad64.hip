@@ -41,13 +41,14 @@ __device__ __forceinline__ bf16x4 col_of(const float4 (&t)[4], int j) {
   return r;
 }
 
-constexpr int WG_WAVES = 8;
+constexpr int WG_WAVES = 16;       // waves per workgroup
+constexpr int WG_SLABS = 8;        // LDS slabs: waves w and w + 8 share one (two rounds)
 
 __global__ __launch_bounds__(64 * WG_WAVES) void k_wgrad64(const float* __restrict__ dY,
                                                            const float* __restrict__ X,
                                                            float* __restrict__ dW,
                                                            float* __restrict__ db, int64_t M) {
-  extern __shared__ float sW[];                 // [WG_WAVES][64 * 64 + 64]: one slab per wave
+  extern __shared__ float sW[];                 // [WG_SLABS][64 * 64 + 64]
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int og = lane & 15, kg = lane >> 4;
 
@@ -68,12 +69,6 @@ __global__ __launch_bounds__(64 * WG_WAVES) void k_wgrad64(const float* __restri
     x[e] = ld_row(X, g * 16 + 4 * kg + e, M, 4 * og);
   }
   for (; g < groups; g += nw) {
-    float4 yn[4], xn[4];                         // the next group's rows, in flight under the products
-#pragma unroll
-    for (int e = 0; e < 4; ++e) {
-      yn[e] = ld_row(dY, (g + nw) * 16 + 4 * kg + e, M, 4 * og);
-      xn[e] = ld_row(X, (g + nw) * 16 + 4 * kg + e, M, 4 * og);
-    }
     if (g * 16 + 16 > M) {                        // (uniform) the ragged last group
 #pragma unroll
       for (int e = 0; e < 4; ++e)
@@ -89,33 +84,53 @@ __global__ __launch_bounds__(64 * WG_WAVES) void k_wgrad64(const float* __restri
     bf16x4 a[4], b[4];
 #pragma unroll
     for (int j = 0; j < 4; ++j) { a[j] = col_of(y, j); b[j] = col_of(x, j); }
+    // the next group's rows into the registers the conversions just freed, in flight under the products
+    // (a second register set does not fit beside the 64 accumulators at 16 waves per workgroup)
+#pragma unroll
+    for (int e = 0; e < 4; ++e) {
+      y[e] = ld_row(dY, (g + nw) * 16 + 4 * kg + e, M, 4 * og);
+      x[e] = ld_row(X, (g + nw) * 16 + 4 * kg + e, M, 4 * og);
+    }
 #pragma unroll
     for (int j = 0; j < 4; ++j)
 #pragma unroll
       for (int k = 0; k < 4; ++k) acc[j][k] = mfma16(a[j], b[k], acc[j][k]);
-#pragma unroll
-    for (int e = 0; e < 4; ++e) { y[e] = yn[e]; x[e] = xn[e]; }
   }
 
-  float* slab = sW + wave * (64 * 64 + 64);
-#pragma unroll
-  for (int j = 0; j < 4; ++j)
-#pragma unroll
-    for (int e = 0; e < 4; ++e) {
-      const int o = 16 * kg + 4 * e + j;
-      *reinterpret_cast<float4*>(slab + o * 64 + 4 * og) =
-          make_float4(acc[j][0][e], acc[j][1][e], acc[j][2][e], acc[j][3][e]);
-    }
   bs.x += __shfl_xor(bs.x, 16); bs.y += __shfl_xor(bs.y, 16);
   bs.z += __shfl_xor(bs.z, 16); bs.w += __shfl_xor(bs.w, 16);
   bs.x += __shfl_xor(bs.x, 32); bs.y += __shfl_xor(bs.y, 32);
   bs.z += __shfl_xor(bs.z, 32); bs.w += __shfl_xor(bs.w, 32);
-  if (kg == 0) *reinterpret_cast<float4*>(slab + 64 * 64 + 4 * og) = bs;
-  __syncthreads();
+  // waves 0..7 store their blocks, waves 8..15 add theirs on top (each lane its own elements)
+  float* slab = sW + (wave & (WG_SLABS - 1)) * (64 * 64 + 64);
+#pragma unroll
+  for (int round = 0; round < WG_WAVES / WG_SLABS; ++round) {
+    if (wave / WG_SLABS == round) {
+#pragma unroll
+      for (int j = 0; j < 4; ++j)
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+          const int o = 16 * kg + 4 * e + j;
+          float4* dst = reinterpret_cast<float4*>(slab + o * 64 + 4 * og);
+          float4 v = make_float4(acc[j][0][e], acc[j][1][e], acc[j][2][e], acc[j][3][e]);
+          if (round > 0) { const float4 p = *dst; v.x += p.x; v.y += p.y; v.z += p.z; v.w += p.w; }
+          *dst = v;
+        }
+      if (kg == 0) {
+        float4* dst = reinterpret_cast<float4*>(slab + 64 * 64 + 4 * og);
+        float4 v = bs;
+        if (round > 0) { const float4 p = *dst; v.x += p.x; v.y += p.y; v.z += p.z; v.w += p.w; }
+        *dst = v;
+      }
+    }
+    __syncthreads();
+  }
+  // (few, wide workgroups: atomics of different workgroups onto one cache line serialise, ~25 ns each -
+  // 256 workgroups x 130 lines cost ~6 us per call)
   for (int i = tid; i < 64 * 64 + (db != nullptr ? 64 : 0); i += 64 * WG_WAVES) {
     float v = 0.f;
 #pragma unroll
-    for (int w = 0; w < WG_WAVES; ++w) v += sW[w * (64 * 64 + 64) + i];
+    for (int w = 0; w < WG_SLABS; ++w) v += sW[w * (64 * 64 + 64) + i];
     atomicAdd(i < 64 * 64 ? dW + i : db + (i - 64 * 64), v);
   }
 }
@@ -241,20 +256,19 @@ int wgrad64(const float* dY, const float* X, float* dW, float* db, int64_t M, in
     return check_launch("k_wgrad64_narrow");
   }
   const int64_t groups = (M + 15) / 16;
-  // one workgroup per CU at most (its 8 wave slabs take 130 KB of LDS), >= 2 groups per wave where
-  // the rows allow; 256 x 4160 atomics per call
+  // one workgroup per CU at most (its 8 slabs take 130 KB of LDS); 128 x 4160 atomics per call
   int64_t wgs = cdiv(groups, WG_WAVES);
-  if (wgs > 256) wgs = 256;
+  if (wgs > 128) wgs = 128;
   if (wgs < 1) wgs = 1;
   static const int once = [] {
     return (int)hipFuncSetAttribute(reinterpret_cast<const void*>(k_wgrad64),
                                     hipFuncAttributeMaxDynamicSharedMemorySize,
-                                    WG_WAVES * (64 * 64 + 64) * (int)sizeof(float));
+                                    WG_SLABS * (64 * 64 + 64) * (int)sizeof(float));
   }();
   PCA_REQUIRE(once == 0, "wgrad64: cannot reserve %d bytes of LDS",
-              WG_WAVES * (64 * 64 + 64) * (int)sizeof(float));
+              WG_SLABS * (64 * 64 + 64) * (int)sizeof(float));
   hipLaunchKernelGGL(k_wgrad64, dim3((unsigned)wgs), dim3(64 * WG_WAVES),
-                     WG_WAVES * (64 * 64 + 64) * sizeof(float), st, dY, X, dW, db, M);
+                     WG_SLABS * (64 * 64 + 64) * sizeof(float), st, dY, X, dW, db, M);
   return check_launch("k_wgrad64");
 }
 
