@@ -322,7 +322,7 @@ def main():
     # the timed region below runs the winner.
     exchange = None
     if world > 1:
-        forms = ["serial", "overlap"] + (["captured"] if backend == "nccl" else [])
+        forms = ["serial", "overlap"] + (["captured", "captured_overlap"] if backend == "nccl" else [])
         k_probe = max(10, min(50, args.steps))
         exchange = {}
         for form in forms:

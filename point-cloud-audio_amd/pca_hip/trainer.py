@@ -293,15 +293,18 @@ class Trainer:
         re-captures).  "serial": [graph: pack .. backward] -> all-reduce of the whole vector -> Adam;
         "overlap": the step split at the bucket boundary, bucket A reduced on a side stream under
         enc.0's backward; "captured": ONE graph per step with the all-reduce recorded inside it
-        (needs a backend whose collectives can be stream-captured: RCCL / nccl).  bench.py times all
-        three on the first windows of a multi-GPU run and keeps the fastest."""
-        if form not in ("serial", "overlap", "captured"):
+        (needs a backend whose collectives can be stream-captured: RCCL / nccl);
+        "captured_overlap": ONE graph per step as well, split at the bucket boundary INSIDE it - bucket A's
+        all-reduce forks onto a side stream under enc.0's backward and joins before Adam (the overlap of
+        "overlap" without its three graph launches and cross-stream events per step, which cost 68 us).
+        bench.py times all of them on the first windows of a multi-GPU run and keeps the fastest."""
+        if form not in ("serial", "overlap", "captured", "captured_overlap"):
             raise ValueError(form)
         torch.cuda.synchronize(self.dev)
         self.g0 = self.g1 = self.g2 = None
         multi = self.world > 1 or (dist.is_initialized() and os.environ.get("PCA_EXCHANGE_WORLD1") == "1")
-        self._split = form == "overlap" and multi
-        self._captured = form == "captured" and multi
+        self._split = form in ("overlap", "captured_overlap") and multi
+        self._captured = form in ("captured", "captured_overlap") and multi
         self._exchange = multi
         if self._split and self.comm_stream is None:
             self.comm_stream = torch.cuda.Stream(self.dev)
@@ -310,6 +313,23 @@ class Trainer:
     def _allreduce_all(self):
         if self.world > 1 or self._captured:
             dist.all_reduce(self.eng.grads, group=self.pg)
+
+    def _captured_body(self):
+        """[pack .. backward | all-reduce | Adam] as it is recorded into (or, without graphs, run as) one
+        step.  Split form: bucket A (enc.1 + dec, final after phase 0) is reduced on the side stream
+        while enc.0's backward runs on the main one; both join before Adam."""
+        self._seg0()
+        if not self._split:
+            self._seg1()
+            self._allreduce_all()
+        else:
+            main = torch.cuda.current_stream(self.dev)
+            self.comm_stream.wait_stream(main)                    # fork
+            second = allreduce_buckets(self.eng.grads, self.eng.split, self.pg, self.comm_stream)
+            self._seg1()
+            second()                                              # bucket B on the main stream
+            main.wait_stream(self.comm_stream)                    # join
+        self._seg2()
 
     # ---- index stream ------------------------------------------------------------
     def _next_indices(self) -> torch.Tensor:
@@ -385,9 +405,7 @@ class Trainer:
         if self._captured:              # [pack .. backward | all-reduce | Adam] in ONE graph
             self.g0 = torch.cuda.CUDAGraph()
             with torch.cuda.graph(self.g0, **mode):
-                self._seg0(); self._seg1()
-                self._allreduce_all()
-                self._seg2()
+                self._captured_body()
         elif not self._split and not self._exchange:
             self.g0 = torch.cuda.CUDAGraph()
             with torch.cuda.graph(self.g0, **mode):
@@ -430,7 +448,7 @@ class Trainer:
             if self.use_graph:
                 self.g0.replay()
             else:
-                self._seg0(); self._seg1(); self._allreduce_all(); self._seg2()
+                self._captured_body()
             return
         if not self._split and not self._exchange:
             if self.use_graph:

@@ -51,4 +51,15 @@ try:
     print("CAPTURE_OK", bool(torch.equal(plain, cap)), float((plain - cap).abs().max()), flush=True)
 except Exception as e:
     print("CAPTURE_REFUSED", repr(e)[:1500].replace("\n", " | "), flush=True)
+# the split form of the same graph: bucket A's all-reduce forked onto a side stream under enc.0's backward.
+# The phase-split backward sums some gradients in another order than the one-call backward: compare with
+# the un-captured split step ("overlap"), whose arithmetic it shares, bit for bit.
+try:
+    ovl, _ = run("overlap")
+    cov, tr = run("captured_overlap")
+    assert tr._captured and tr._split and tr.g0 is not None and tr.g1 is None
+    print("CAPTURE_OVERLAP_OK", bool(torch.equal(ovl, cov)), float((ovl - cov).abs().max()),
+          float((plain - cov).abs().max()), flush=True)
+except Exception as e:
+    print("CAPTURE_OVERLAP_REFUSED", repr(e)[:1500].replace("\n", " | "), flush=True)
 dist.destroy_process_group()

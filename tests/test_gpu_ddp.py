@@ -103,6 +103,11 @@ def test_allreduce_captured_in_step_graph_world1_nccl():
     if "BACKEND_REFUSED" in r.stdout or "CAPTURE_REFUSED" in r.stdout:
         pytest.skip("RCCL refused: " + r.stdout[-1500:])
     assert "CAPTURE_OK True" in r.stdout, r.stdout
+    # the split form ("captured_overlap": bucket A's all-reduce forked onto a side stream inside the same
+    # graph) against the un-captured split step, bit for bit
+    if "CAPTURE_OVERLAP_REFUSED" in r.stdout:
+        pytest.skip("RCCL refused the forked capture: " + r.stdout[-1500:])
+    assert "CAPTURE_OVERLAP_OK True" in r.stdout, r.stdout
 
 
 @pytest.mark.parametrize("form", ["serial", "overlap"])
