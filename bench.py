@@ -21,6 +21,7 @@ import ctypes as C
 import json
 import os
 import sys
+import threading
 import time
 
 ROOT = os.path.dirname(os.path.abspath(__file__))
@@ -326,6 +327,14 @@ def main():
         k_probe = max(10, min(50, args.steps))
         exchange = {}
         for form in forms:
+            # a collective that never completes inside a replayed graph is invisible to RCCL's watchdog:
+            # give every probe a deadline of its own, so that a hung form ends the run in minutes with a
+            # message instead of holding eight GPUs until the caller's limit
+            dog = threading.Timer(300.0, lambda f=form: (sys.stderr.write(
+                f"bench: exchange form '{f}' made no progress for 300 s on rank {rank}, aborting\n"),
+                sys.stderr.flush(), os._exit(3)))
+            dog.daemon = True
+            dog.start()
             try:
                 tr.set_exchange(form)
                 for _ in range(max(5, args.warmup // 2)):
@@ -341,6 +350,8 @@ def main():
                 exchange[form + "_ms"] = round(float(t), 4)
             except Exception as e:          # e.g. a backend that refuses stream capture
                 exchange[form + "_error"] = repr(e)[:300]
+            finally:
+                dog.cancel()
         timed = {f: exchange[f + "_ms"] for f in forms if f + "_ms" in exchange}
         # (a form that failed on ANY rank is out: agree on it)
         for f in list(timed):
